@@ -1,0 +1,155 @@
+/* rllab_amd.h -- C ABI of librllab_amd.so, the MI355X (gfx950) engine underneath
+ * the rllab Env / Policy / Sampler / optimizer seams.
+ *
+ * The reference (rll/rllab) is pure Python: its plug-in boundary is duck typing
+ * (SURVEY.md section 8b).  This header is what a maintainer binds with ctypes
+ *  from exactly those seams.  Each entry point names the
+ * reference function it replaces.
+ *
+ * Conventions
+ *  - every pointer argument is a DEVICE pointer owned by the caller unless the
+ *    comment says "host";
+ *  - per-env arrays are struct-of-arrays "planes": a quantity with D components
+ *    for N envs is float[D][N]; trajectory quantities are float[D][T][N];
+ *  - `stream` is a hipStream_t (may be NULL = default stream); calls only
+ *    enqueue work, they never synchronise;
+ *  - return value 0 = ok, negative = error; rl_last_error() (host string,
+ *    thread-local) describes the last failure.  No exceptions cross the ABI.
+ */
+#ifndef RLLAB_AMD_H
+#define RLLAB_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum rl_env_kind {
+    RL_ENV_CARTPOLE = 0,         /* rllab/envs/box2d/cartpole_env.py:10-56 */
+    RL_ENV_DOUBLE_PENDULUM = 1,  /* rllab/envs/box2d/double_pendulum_env.py:11-61 */
+    RL_ENV_SWIMMER = 2,          /* rllab/envs/mujoco/swimmer_env.py:10-62 (swimmer-style planar chain) */
+    RL_ENV_HALF_CHEETAH = 3      /* rllab/envs/mujoco/half_cheetah_env.py:14-56 (cheetah-style planar tree) */
+};
+
+enum rl_status {
+    RL_OK = 0,
+    RL_ERR_ARG = -1,       /* bad argument (unknown env kind, null pointer, bad size) */
+    RL_ERR_UNSUPPORTED = -2, /* valid request the engine has no kernel for (e.g. hidden sizes) */
+    RL_ERR_HIP = -3        /* HIP runtime error; rl_last_error() has hipGetErrorString */
+};
+
+/* Human-readable description of the last error on this thread (host string). */
+const char* rl_last_error(void);
+
+/* Library / ABI version, bumped when a signature changes. */
+int rl_abi_version(void);
+
+/* Static facts about an env kind: observation / action / persisted-state sizes,
+ * number of random draws one reset consumes and whether they are N(0,1)
+ * (1) or U[0,1) (0).  Replaces Env.observation_space / action_space shape
+ * queries (rllab/envs/base.py:31-50).  All outputs are host ints. */
+int rl_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim,
+                 int* reset_draws, int* reset_is_normal);
+
+/* Action bounds of the un-normalised env (host arrays of act_dim floats).
+ * Replaces Box2DEnv.action_space (box2d_env.py:99-103) and
+ * MujocoEnv.action_space (mujoco_env.py:85-90). */
+int rl_env_action_bounds(int kind, float* lb_host, float* ub_host);
+
+/* Env.reset for the envs selected by `mask` (NULL = all).
+ *   state   float[state_dim][n]   in/out (persisted solver state survives reset
+ *                                 where the reference's does)
+ *   ts      int32[n]              steps since reset, zeroed for reset envs
+ *   draws   float[reset_draws][n] injected random draws (parity mode) or NULL:
+ *                                 then Philox4x32-10 keyed by `seed`, counter
+ *                                 (env index + env_offset, step_counter, RESET)
+ *   obs     float[obs_dim][n]     written for reset envs only
+ * Replaces CartpoleEnv.reset (cartpole_env.py:28-43), DoublePendulumEnv.reset
+ * (double_pendulum_env.py:32-41), MujocoEnv.reset (mujoco_env.py:109-123) and
+ * VecEnvExecutor.reset (sandbox/rocky/tf/envs/vec_env_executor.py:30-33). */
+int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const uint8_t* mask,
+                    const float* draws, uint64_t seed, uint64_t step_counter,
+                    int env_offset, float* obs, void* stream);
+
+/* One lock-step Env.step over n envs, with the VecEnvExecutor contract: ts += 1,
+ * done |= ts >= max_path_length, done envs are reset inside the call and the
+ * returned obs is the post-reset observation
+ * (sandbox/rocky/tf/envs/vec_env_executor.py:16-28).
+ *   normalize != 0 applies NormalizedEnv's action affine map + clip
+ *                  (rllab/envs/normalized_env.py:78-92); scale_reward as there.
+ *   actions float[act_dim][n]; reward float[n]; done uint8[n].
+ *   auto_reset == 0 gives plain Env.step semantics (rllab/envs/base.py:7-22): the
+ *   terminal observation is returned and the caller resets.
+ * Replaces NormalizedEnv.step -> Box2DEnv.step / MujocoEnv.forward_dynamics. */
+int rl_vecenv_step(int kind, int n, int normalize, float scale_reward, int max_path_length,
+                   int auto_reset, float* state, int32_t* ts, const float* actions,
+                   const float* reset_draws, uint64_t seed, uint64_t step_counter,
+                   int env_offset, float* obs, float* reward, uint8_t* done, void* stream);
+
+/* Arguments of the fused rollout: T lock-step iterations of
+ *   policy.get_actions -> env.step -> record -> auto-reset
+ * for n envs in ONE launch (every env is independent, so no grid-wide
+ * synchronisation exists).  Replaces the per-step Python loop of rollout()
+ * (rllab/sampler/utils.py:18-31) as driven by BatchSampler.obtain_samples
+ * (rllab/algos/batch_polopt.py:22-34), with GaussianMLPPolicy.get_actions
+ * (rllab/policies/gaussian_mlp_policy.py:132-137) evaluated in-kernel. */
+typedef struct rl_rollout_args {
+    int32_t kind;             /* rl_env_kind */
+    int32_t n_envs;
+    int32_t horizon;          /* T: steps recorded per env in this call */
+    int32_t max_path_length;  /* forced done when ts reaches it */
+    int32_t normalize;        /* NormalizedEnv action map on/off */
+    int32_t reset_at_start;   /* reset every env before step 0 */
+    int32_t hidden0, hidden1; /* tanh MLP hidden sizes (supported: 32x32, 64x64) */
+    int32_t env_offset;       /* global index of env 0 (multi-GPU sharding) */
+    float scale_reward;
+    float log_min_std;        /* log_std floor, log(min_std) (gaussian_mlp_policy.py:100-101) */
+    uint64_t seed;
+    uint64_t step_counter;    /* global step index of t = 0 (RNG counter base) */
+    float* state;             /* float[state_dim][n]  in/out */
+    int32_t* ts;              /* int32[n]             in/out */
+    const float* theta;       /* flat policy params, reference layout W0,b0,W1,b1,Wout,bout,log_std,
+                                 W stored [in][out] row-major (parameterized.py:54-58) */
+    const float* eps;         /* NULL or float[act_dim][T][n] injected N(0,1) policy noise */
+    const float* reset_draws; /* NULL or float[T+1][reset_draws][n] injected reset draws;
+                                 slice 0 = initial reset, slice t+1 = reset after step t */
+    float* obs;               /* float[obs_dim][T][n]  observation the action was computed from */
+    float* actions;           /* float[act_dim][T][n] */
+    float* means;             /* float[act_dim][T][n]  agent_info "mean" */
+    float* rewards;           /* float[T][n] */
+    uint8_t* dones;           /* uint8[T][n]  env done OR ts == max_path_length */
+    float* last_obs;          /* NULL or float[obs_dim][n]: observation after the last step (post-reset) */
+} rl_rollout_args;
+
+int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);
+
+/* Segmented reverse linear-recurrence scans over [T][n] planes, fused:
+ *   delta[t] = r[t] + gamma * V[t+1] * (1 - end[t]) - V[t]
+ *   adv[t]   = delta[t] + gamma*lambda * (1 - end[t]) * adv[t+1]
+ *   ret[t]   = r[t]     + gamma        * (1 - end[t]) * ret[t+1]
+ * where end[t] = done[t] | (t == T-1) and V after a path's last step is 0.
+ * gamma / lambda are doubles (the reference's Python floats); accumulates in f64,
+ * stores f32.  Replaces the per-path loop of
+ * BaseSampler.process_samples (rllab/sampler/base.py:57-66) and
+ * special.discount_cumsum (rllab/misc/special.py:107-111).
+ *   values: f64 plane [T][n] of baseline predictions (the reference predicts in
+ *   float64), may be NULL (ZeroBaseline / LinearFeatureBaseline before first fit). */
+int rl_gae(int T, int n, const float* rewards, const double* values, const uint8_t* dones,
+           double gamma, double lambda, float* adv, float* ret, void* stream);
+
+/* y[t] = x[t] + discount * (1 - end[t]) * y[t+1] on a [T][n] plane
+ * (special.discount_cumsum with path boundaries; dones may be NULL = one path
+ * per column). */
+int rl_discount_cumsum(int T, int n, const float* x, const uint8_t* dones, double discount,
+                       float* y, void* stream);
+
+/* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
+ * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */
+int rl_debug_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                    int count, uint32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLLAB_AMD_H */

@@ -1,0 +1,159 @@
+// oracle/env_host.cpp -- TEST INFRASTRUCTURE (never imported by the product).
+//
+// Host build of the env dynamics headers (rllab_amd/csrc/dyn_*.h): the same
+// source the gfx950 kernels are compiled from, instantiated
+//   * in float  -- the bit-exact leg: GPU kernel output must equal this, bit for
+//     bit, on identical states / actions / injected draws.  It pins the device
+//     toolchain, the SoA plane indexing, the auto-reset / horizon logic and the
+//     RNG plumbing, which is everything that differs between the two builds;
+//   * in double -- the physics leg: compared against the INDEPENDENT float64
+//     restatements in oracle/np_*.py (written from the reference's XML / MJCF
+//     constants with a different formulation), which is what catches a wrong
+//     equation that a shared source cannot.
+// Parity status: the reference's own arithmetic for these envs lives in pybox2d /
+// MuJoCo 1.31 (third party, absent) and its tests hold no golden vectors for it
+//  => env dynamics are "parity unpinned" against the reference.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -mfma).
+#include <stdint.h>
+#include <string.h>
+
+#include "../rllab_amd/csrc/envs.h"
+
+namespace {
+
+template <class E, typename R>
+int reset_t(R* s, const R* draws) { E::template reset<R>(s, draws); return 0; }
+
+template <class E, typename R>
+int observe_t(const R* s, R* o) { E::template observe<R>(s, o); return 0; }
+
+template <class E, typename R>
+int step_t(R* s, const R* a, int normalize, R* obs, R* reward, int* done) {
+    bool d;
+    E::template step<R>(s, a, normalize, obs, *reward, d);
+    *done = d ? 1 : 0;
+    return 0;
+}
+
+template <class E>
+int query_t(int* obs_dim, int* act_dim, int* state_dim, int* reset_draws, int* reset_is_normal) {
+    *obs_dim = E::OBS; *act_dim = E::ACT; *state_dim = E::STATE;
+    *reset_draws = E::RESET_DRAWS; *reset_is_normal = E::RESET_NORMAL ? 1 : 0;
+    return 0;
+}
+
+// Serial replay of the lock-step VecEnvExecutor contract over n envs with the
+// GPU's plane layout (state [S][n], actions [A][n], obs [O][n]) -- one env after
+// the other, the way the reference's VecEnvExecutor.step loops
+// (sandbox/rocky/tf/envs/vec_env_executor.py:16-28).
+template <class E>
+int vec_step_t(int n, int normalize, float scale_reward, int max_path_length, int auto_reset, float* state,
+               int32_t* ts, const float* actions, const float* reset_draws, float* obs, float* reward,
+               uint8_t* done) {
+    for (int i = 0; i < n; ++i) {
+        float s[E::STATE], a[E::ACT], o[E::OBS], d[E::RESET_DRAWS], r;
+        for (int k = 0; k < E::STATE; ++k) s[k] = state[(size_t)k * n + i];
+        for (int k = 0; k < E::ACT; ++k) a[k] = actions[(size_t)k * n + i];
+        bool dn;
+        E::template step<float>(s, a, normalize, o, r, dn);
+        int t = ts[i] + 1;
+        if (max_path_length > 0 && t >= max_path_length) dn = true;
+        if (dn && auto_reset) {
+            for (int k = 0; k < E::RESET_DRAWS; ++k) d[k] = reset_draws[(size_t)k * n + i];
+            E::template reset<float>(s, d);
+            E::template observe<float>(s, o);
+            t = 0;
+        }
+        for (int k = 0; k < E::STATE; ++k) state[(size_t)k * n + i] = s[k];
+        ts[i] = t;
+        for (int k = 0; k < E::OBS; ++k) obs[(size_t)k * n + i] = o[k];
+        reward[i] = r * scale_reward;
+        done[i] = dn ? 1 : 0;
+    }
+    return 0;
+}
+
+template <class E>
+int vec_reset_t(int n, float* state, int32_t* ts, const uint8_t* mask, const float* draws, float* obs) {
+    for (int i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        float s[E::STATE], o[E::OBS], d[E::RESET_DRAWS];
+        for (int k = 0; k < E::STATE; ++k) s[k] = state[(size_t)k * n + i];
+        for (int k = 0; k < E::RESET_DRAWS; ++k) d[k] = draws[(size_t)k * n + i];
+        E::template reset<float>(s, d);
+        E::template observe<float>(s, o);
+        for (int k = 0; k < E::STATE; ++k) state[(size_t)k * n + i] = s[k];
+        ts[i] = 0;
+        for (int k = 0; k < E::OBS; ++k) obs[(size_t)k * n + i] = o[k];
+    }
+    return 0;
+}
+
+}  // namespace
+
+// `FN` is a function template name, `...` its call arguments.
+#define ORACLE_DISPATCH(kind, FN, ...)                         \
+    switch (kind) {                                            \
+        case 0: return FN<rl::Cartpole>(__VA_ARGS__);          \
+        ORACLE_EXTRA_ENV_CASES(FN, __VA_ARGS__)                \
+        default: return -1;                                    \
+    }
+#define ORACLE_DISPATCH_R(kind, FN, R, ...)                    \
+    switch (kind) {                                            \
+        case 0: return FN<rl::Cartpole, R>(__VA_ARGS__);       \
+        ORACLE_EXTRA_ENV_CASES_R(FN, R, __VA_ARGS__)           \
+        default: return -1;                                    \
+    }
+
+#ifndef ORACLE_EXTRA_ENV_CASES
+#define ORACLE_EXTRA_ENV_CASES(FN, ...)
+#define ORACLE_EXTRA_ENV_CASES_R(FN, R, ...)
+#endif
+
+extern "C" {
+
+int oracle_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim, int* reset_draws, int* reset_is_normal) {
+    ORACLE_DISPATCH(kind, query_t, obs_dim, act_dim, state_dim, reset_draws, reset_is_normal)
+}
+
+// single env, array-of-struct state (state_dim contiguous values)
+int oracle_env_reset_f32(int kind, float* s, const float* draws) { ORACLE_DISPATCH_R(kind, reset_t, float, s, draws) }
+int oracle_env_reset_f64(int kind, double* s, const double* draws) { ORACLE_DISPATCH_R(kind, reset_t, double, s, draws) }
+int oracle_env_observe_f32(int kind, const float* s, float* o) { ORACLE_DISPATCH_R(kind, observe_t, float, s, o) }
+int oracle_env_observe_f64(int kind, const double* s, double* o) { ORACLE_DISPATCH_R(kind, observe_t, double, s, o) }
+int oracle_env_step_f32(int kind, float* s, const float* a, int normalize, float* obs, float* reward, int* done) {
+    ORACLE_DISPATCH_R(kind, step_t, float, s, a, normalize, obs, reward, done)
+}
+int oracle_env_step_f64(int kind, double* s, const double* a, int normalize, double* obs, double* reward, int* done) {
+    ORACLE_DISPATCH_R(kind, step_t, double, s, a, normalize, obs, reward, done)
+}
+
+int oracle_vecenv_step_f32(int kind, int n, int normalize, float scale_reward, int max_path_length,
+                           int auto_reset, float* state, int32_t* ts, const float* actions,
+                           const float* reset_draws, float* obs, float* reward, uint8_t* done) {
+    ORACLE_DISPATCH(kind, vec_step_t, n, normalize, scale_reward, max_path_length, auto_reset, state, ts,
+                    actions, reset_draws, obs, reward, done)
+}
+
+int oracle_vecenv_reset_f32(int kind, int n, float* state, int32_t* ts, const uint8_t* mask,
+                            const float* draws, float* obs) {
+    ORACLE_DISPATCH(kind, vec_reset_t, n, state, ts, mask, draws, obs)
+}
+
+// Philox4x32-10 blocks for counters (c0 + i, c1, c2, c3): the integer stream the
+// device RNG must reproduce exactly.
+int oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int count,
+                  uint32_t* out) {
+    for (int i = 0; i < count; ++i) {
+        rl::Philox4 p = rl::philox4x32_10(c0 + (uint32_t)i, c1, c2, c3, k0, k1);
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = p.v[k];
+    }
+    return 0;
+}
+
+void oracle_sincos_f32(int n, const float* x, float* s, float* c) {
+    for (int i = 0; i < n; ++i) rl::rl_sincos(x[i], s[i], c[i]);
+}
+
+}  // extern "C"

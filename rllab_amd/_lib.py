@@ -1,0 +1,107 @@
+"""ctypes binding of librllab_amd.so (the C ABI declared in include/rllab_amd.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module
+raises at import time, and every entry point raises ``RuntimeError`` with
+``rl_last_error()`` on a non-zero status.  PyTorch is used only as plumbing
+(device memory, streams); no torch type crosses the ABI -- tensors are handed
+over as raw device pointers.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librllab_amd.so")
+
+ENV_CARTPOLE = 0
+ENV_DOUBLE_PENDULUM = 1
+ENV_SWIMMER = 2
+ENV_HALF_CHEETAH = 3
+
+# every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds",
+    "rl_vecenv_reset", "rl_vecenv_step", "rl_rollout_gaussian_mlp", "rl_gae",
+    "rl_discount_cumsum", "rl_debug_philox",
+]
+
+
+class RolloutArgs(ctypes.Structure):
+    """Mirror of ``rl_rollout_args`` (include/rllab_amd.h)."""
+    _fields_ = [
+        ("kind", ctypes.c_int32), ("n_envs", ctypes.c_int32), ("horizon", ctypes.c_int32),
+        ("max_path_length", ctypes.c_int32), ("normalize", ctypes.c_int32),
+        ("reset_at_start", ctypes.c_int32), ("hidden0", ctypes.c_int32), ("hidden1", ctypes.c_int32),
+        ("env_offset", ctypes.c_int32), ("scale_reward", ctypes.c_float),
+        ("log_min_std", ctypes.c_float), ("seed", ctypes.c_uint64), ("step_counter", ctypes.c_uint64),
+        ("state", ctypes.c_void_p), ("ts", ctypes.c_void_p), ("theta", ctypes.c_void_p),
+        ("eps", ctypes.c_void_p), ("reset_draws", ctypes.c_void_p), ("obs", ctypes.c_void_p),
+        ("actions", ctypes.c_void_p), ("means", ctypes.c_void_p), ("rewards", ctypes.c_void_p),
+        ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "rllab_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, u64, f32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float, ctypes.c_double
+    u32 = ctypes.c_uint32
+    ip = ctypes.POINTER(ctypes.c_int)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.rl_last_error.restype = ctypes.c_char_p
+    lib.rl_last_error.argtypes = []
+    lib.rl_abi_version.restype = i32
+    lib.rl_env_query.argtypes = [i32, ip, ip, ip, ip, ip]
+    lib.rl_env_action_bounds.argtypes = [i32, fp, fp]
+    lib.rl_vecenv_reset.argtypes = [i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp]
+    lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp, vp, vp]
+    lib.rl_rollout_gaussian_mlp.argtypes = [ctypes.POINTER(RolloutArgs), vp]
+    lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp]
+    lib.rl_discount_cumsum.argtypes = [i32, i32, vp, vp, f64, vp, vp]
+    lib.rl_debug_philox.argtypes = [u32, u32, u32, u32, u32, u32, i32, vp, vp]
+    for name in SYMBOLS:
+        getattr(lib, name)  # AttributeError here = header / library mismatch
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what="rllab_amd"):
+    if status != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, status, lib.rl_last_error().decode()))
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "rllab_amd C ABI takes contiguous planes"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    if not torch.cuda.is_available():
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def env_query(kind):
+    o, a, s, r, nrm = (ctypes.c_int() for _ in range(5))
+    check(lib.rl_env_query(kind, ctypes.byref(o), ctypes.byref(a), ctypes.byref(s), ctypes.byref(r),
+                           ctypes.byref(nrm)), "rl_env_query")
+    return dict(obs_dim=o.value, act_dim=a.value, state_dim=s.value, reset_draws=r.value,
+                reset_is_normal=bool(nrm.value))
+
+
+def env_action_bounds(kind):
+    import numpy as np
+    q = env_query(kind)
+    lb = (ctypes.c_float * q["act_dim"])()
+    ub = (ctypes.c_float * q["act_dim"])()
+    check(lib.rl_env_action_bounds(kind, lb, ub), "rl_env_action_bounds")
+    return np.array(lb[:], dtype=np.float64), np.array(ub[:], dtype=np.float64)

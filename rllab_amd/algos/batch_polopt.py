@@ -1,0 +1,118 @@
+"""BatchPolopt driver and the in-process BatchSampler
+(API of rllab/algos/batch_polopt.py:9-161).
+
+``train()`` is the reference's loop: obtain_samples -> process_samples ->
+log_diagnostics -> optimize_policy -> snapshot -> dump_tabular.  The default
+``sampler_cls`` is the lock-step GPU ``VectorizedSampler`` when the env is
+HIP-native (``env.vectorized``); otherwise the plain ``BatchSampler`` below, which
+rolls a Python env in-process exactly like the reference does at n_parallel = 1.
+"""
+import time
+
+import rllab_amd.misc.logger as logger
+from rllab_amd.algos.base import RLAlgorithm
+from rllab_amd.sampler.base import BaseSampler
+from rllab_amd.sampler.utils import rollout, truncate_paths
+
+
+class BatchSampler(BaseSampler):
+    """Single-process whole-path sampler for arbitrary Python envs
+    (reference: batch_polopt.py:9-34 + parallel_sampler.sample_paths with one worker)."""
+
+    def __init__(self, algo):
+        self.algo = algo
+
+    def start_worker(self):
+        pass
+
+    def shutdown_worker(self):
+        pass
+
+    def obtain_samples(self, itr):
+        algo = self.algo
+        paths, n = [], 0
+        while n < algo.batch_size:
+            path = rollout(algo.env, algo.policy, algo.max_path_length)
+            paths.append(path)
+            n += len(path["rewards"])
+        if algo.whole_paths:
+            return paths
+        return truncate_paths(paths, algo.batch_size)
+
+
+class BatchPolopt(RLAlgorithm):
+    def __init__(self, env, policy, baseline, scope=None, n_itr=500, start_itr=0, batch_size=5000,
+                 max_path_length=500, discount=0.99, gae_lambda=1, plot=False, pause_for_plot=False,
+                 center_adv=True, positive_adv=False, store_paths=False, whole_paths=True,
+                 sampler_cls=None, sampler_args=None, **kwargs):
+        self.env = env
+        self.policy = policy
+        self.baseline = baseline
+        self.scope = scope
+        self.n_itr = n_itr
+        self.current_itr = start_itr
+        self.batch_size = batch_size
+        self.max_path_length = max_path_length
+        self.discount = discount
+        self.gae_lambda = gae_lambda
+        self.plot = plot
+        self.pause_for_plot = pause_for_plot
+        self.center_adv = center_adv
+        self.positive_adv = positive_adv
+        self.store_paths = store_paths
+        self.whole_paths = whole_paths
+        if plot:
+            raise NotImplementedError("plotting is out of scope (SURVEY.md section 2, row 27)")
+        if sampler_cls is None:
+            if getattr(env, "vectorized", False) and getattr(policy, "vectorized", False):
+                from rllab_amd.sampler.vectorized_sampler import VectorizedSampler
+                sampler_cls = VectorizedSampler
+            else:
+                sampler_cls = BatchSampler
+        if sampler_args is None:
+            sampler_args = dict()
+        self.sampler = sampler_cls(self, **sampler_args)
+        self.itr_times = []
+
+    def start_worker(self):
+        self.sampler.start_worker()
+
+    def shutdown_worker(self):
+        self.sampler.shutdown_worker()
+
+    def train(self):
+        self.start_worker()
+        self.init_opt()
+        for itr in range(self.current_itr, self.n_itr):
+            itr_start = time.time()
+            with logger.prefix('itr #%d | ' % itr):
+                paths = self.sampler.obtain_samples(itr)
+                samples_data = self.sampler.process_samples(itr, paths)
+                self.log_diagnostics(paths)
+                self.optimize_policy(itr, samples_data)
+                logger.log("saving snapshot...")
+                params = self.get_itr_snapshot(itr, samples_data)
+                self.current_itr = itr + 1
+                params["algo"] = self
+                if self.store_paths:
+                    params["paths"] = samples_data["paths"]
+                logger.save_itr_params(itr, params)
+                logger.log("saved")
+                self.itr_times.append(time.time() - itr_start)
+                logger.record_tabular('ItrTime', self.itr_times[-1])
+                logger.dump_tabular(with_prefix=False)
+        self.shutdown_worker()
+
+    def log_diagnostics(self, paths):
+        self.env.log_diagnostics(paths)
+        self.policy.log_diagnostics(paths)
+        self.baseline.log_diagnostics(paths)
+
+    def init_opt(self):
+        raise NotImplementedError
+
+    def get_itr_snapshot(self, itr, samples_data):
+        raise NotImplementedError
+
+    def optimize_policy(self, itr, samples_data):
+        raise NotImplementedError

@@ -1,0 +1,89 @@
+"""Natural Policy Optimization (API of rllab/algos/npo.py:10-132).
+
+``init_opt`` hands the optimizer two closures instead of Theano expressions:
+    surr_loss(theta) = - sum_b w_b * lr_b * adv_b / W      lr = p_theta(a|o) / p_old(a|o)
+    mean_kl(theta)   =   sum_b w_b * KL(old_b || theta) / W
+(reference :72-82; w = 0/1 validity weights of the dense batch, W = global number
+of valid samples, so a sum all-reduce over env shards yields the global mean).
+Inputs follow the reference's order [obs, actions, advantages, *state_infos,
+old mean, old log_std] (:84-88) with the two batch-normalisation extras appended:
+[..., weights, 1/W].  All per-sample tensors are "planes" with the sample axis
+LAST (obs [Do, B], actions [Da, B], ...).
+"""
+import torch
+
+import rllab_amd.misc.logger as logger
+from rllab_amd.algos.batch_polopt import BatchPolopt
+from rllab_amd.sampler import dist as D
+
+
+def npo_inputs(policy, samples_data):
+    """Build the optimizer input tuple from a processed dense batch."""
+    traj = samples_data["_traj"]
+    B = traj.B
+    w = traj.valid.reshape(B).to(torch.float32)
+    cnt = D.all_reduce_sum_(w.to(torch.float64).sum())
+    return (traj.obs.reshape(traj.obs_dim, B), traj.actions.reshape(traj.act_dim, B),
+            traj.advantages.reshape(B), traj.means.reshape(traj.act_dim, B),
+            traj.log_std.reshape(-1, 1), w, (1.0 / cnt))
+
+
+class NPO(BatchPolopt):
+    def __init__(self, optimizer=None, optimizer_args=None, step_size=0.01,
+                 truncate_local_is_ratio=None, **kwargs):
+        if optimizer is None:
+            raise NotImplementedError(
+                "NPO's default PenaltyLbfgsOptimizer is outside the TRPO/VPG hot path "
+                "(SURVEY.md section 2, row 6); pass optimizer= or use TRPO")
+        self.optimizer = optimizer
+        self.step_size = step_size
+        self.truncate_local_is_ratio = truncate_local_is_ratio
+        super(NPO, self).__init__(**kwargs)
+
+    def init_opt(self):
+        if self.policy.recurrent:
+            raise NotImplementedError("recurrent policies are outside the hot path built here")
+        policy = self.policy
+        dist = policy.distribution
+        trunc = self.truncate_local_is_ratio
+
+        def _new_dist(flat, obs):
+            return policy.dist_info_planes(obs, flat)
+
+        def surr_loss(flat, obs, act, adv, old_mean, old_log_std, w, inv_count):
+            new = _new_dist(flat, obs)
+            old = dict(mean=old_mean, log_std=old_log_std)
+            lr = dist.likelihood_ratio_sym(act, old, new, axis=0)
+            if trunc is not None:
+                lr = torch.clamp(lr, max=trunc)
+            return -(lr * adv * w).sum() * inv_count.to(lr.dtype)
+
+        def mean_kl(flat, obs, act, adv, old_mean, old_log_std, w, inv_count):
+            new = _new_dist(flat, obs)
+            old = dict(mean=old_mean, log_std=old_log_std)
+            kl = dist.kl_sym(old, new, axis=0)
+            return (kl * w).sum() * inv_count.to(kl.dtype)
+
+        fused = None
+        if trunc is None and hasattr(policy, "fused_ops"):
+            fused = policy.fused_ops()
+        self.optimizer.update_opt(loss=surr_loss, target=policy, leq_constraint=(mean_kl, self.step_size),
+                                  inputs=None, constraint_name="mean_kl", fused=fused)
+        return dict()
+
+    def optimize_policy(self, itr, samples_data):
+        all_input_values = npo_inputs(self.policy, samples_data)
+        loss_before = self.optimizer.loss(all_input_values)
+        mean_kl_before = self.optimizer.constraint_val(all_input_values)
+        self.optimizer.optimize(all_input_values)
+        mean_kl = self.optimizer.constraint_val(all_input_values)
+        loss_after = self.optimizer.loss(all_input_values)
+        logger.record_tabular('LossBefore', loss_before)
+        logger.record_tabular('LossAfter', loss_after)
+        logger.record_tabular('MeanKLBefore', mean_kl_before)
+        logger.record_tabular('MeanKL', mean_kl)
+        logger.record_tabular('dLoss', loss_before - loss_after)
+        return dict()
+
+    def get_itr_snapshot(self, itr, samples_data):
+        return dict(itr=itr, policy=self.policy, baseline=self.baseline, env=self.env)

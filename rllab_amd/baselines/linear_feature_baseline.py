@@ -1,0 +1,87 @@
+"""LinearFeatureBaseline (mirrors rllab/baselines/linear_feature_baseline.py:6-43).
+
+Ridge regression of returns on phi = [clip(o,-10,10), clip(o)^2, t/100,
+(t/100)^2, (t/100)^3, 1] with t the step index inside the path.  The per-path
+``fit`` / ``predict`` keep the reference's numpy semantics for API users; the
+sampler uses the dense forms: features are built as float64 device planes, the
+normal equations Phi^T Phi and Phi^T y are accumulated on the device in float64
+(all-reduced across ranks when sharded -- every rank then solves the same
+(2*Do+4)^2 system with the reference's lstsq + regularisation-retry rule).
+"""
+import numpy as np
+import torch
+
+from rllab_amd.baselines.base import Baseline
+
+
+class LinearFeatureBaseline(Baseline):
+    def __init__(self, env_spec, reg_coeff=1e-5):
+        self._coeffs = None
+        self._reg_coeff = reg_coeff
+
+    def get_param_values(self, **tags):
+        return self._coeffs
+
+    def set_param_values(self, val, **tags):
+        self._coeffs = val
+
+    # -- per-path numpy API (reference semantics) -----------------------------------
+    def _features(self, path):
+        o = np.clip(path["observations"], -10, 10)
+        l = len(path["rewards"])
+        al = np.arange(l).reshape(-1, 1) / 100.0
+        return np.concatenate([o, o ** 2, al, al ** 2, al ** 3, np.ones((l, 1))], axis=1)
+
+    def _solve(self, gram, rhs):
+        reg_coeff = self._reg_coeff
+        coeffs = None
+        for _ in range(5):
+            coeffs = np.linalg.lstsq(gram + reg_coeff * np.identity(gram.shape[0]), rhs, rcond=None)[0]
+            if not np.any(np.isnan(coeffs)):
+                break
+            reg_coeff *= 10
+        return coeffs
+
+    def fit(self, paths):
+        if hasattr(paths, "traj"):  # lazy PathList of a dense batch
+            return self.fit_dense(paths.traj)
+        featmat = np.concatenate([self._features(path) for path in paths])
+        returns = np.concatenate([path["returns"] for path in paths])
+        self._coeffs = self._solve(featmat.T.dot(featmat), featmat.T.dot(returns))
+
+    def predict(self, path):
+        if self._coeffs is None:
+            return np.zeros(len(path["rewards"]))
+        return self._features(path).dot(self._coeffs)
+
+    # -- dense device forms ------------------------------------------------------------
+    @staticmethod
+    def _features_dense(traj):
+        """[F, T*N] float64 feature planes, F = 2*Do + 4."""
+        o = traj.obs.reshape(traj.obs_dim, -1).to(torch.float64).clamp(-10, 10)
+        al = (traj.time_in_path().reshape(1, -1).to(torch.float64)) / 100.0
+        return torch.cat([o, o ** 2, al, al ** 2, al ** 3, torch.ones_like(al)], dim=0)
+
+    def predict_dense(self, traj):
+        """[T, N] float64 baseline plane, or None before the first fit (== zeros)."""
+        if self._coeffs is None:
+            return None
+        w = torch.as_tensor(self._coeffs, dtype=torch.float64, device=traj.device)
+        return (w @ self._features_dense(traj)).reshape(traj.T, traj.N)
+
+    def fit_dense(self, traj, all_reduce=None):
+        phi = self._features_dense(traj)
+        w = traj.valid.reshape(1, -1).to(torch.float64) if traj.valid is not None else None
+        y = traj.returns.reshape(-1).to(torch.float64)
+        if w is not None:
+            phi_w = phi * w
+        else:
+            phi_w = phi
+        gram = phi_w @ phi.t()
+        rhs = phi_w @ y
+        if all_reduce is not None:
+            packed = torch.cat([gram.reshape(-1), rhs])
+            all_reduce(packed)
+            F = gram.shape[0]
+            gram, rhs = packed[:F * F].reshape(F, F), packed[F * F:]
+        self._coeffs = self._solve(gram.cpu().numpy(), rhs.cpu().numpy())

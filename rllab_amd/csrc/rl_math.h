@@ -1,0 +1,113 @@
+// rl_math.h -- arithmetic primitives shared by every env dynamics header.
+//
+// Everything in the env step path must produce the same bits when the header is
+// compiled by hipcc for gfx950 and by g++ for the host oracle build
+// (oracle/env_host.cpp).  That rules out libm / ocml transcendentals (their
+// last-ulp behaviour differs), implicit FMA contraction (both builds use
+// -ffp-contract=off) and anything order-dependent.  What is left is IEEE-754
+// +,-,*,/ and sqrt (correctly rounded on both targets), float<->int conversion
+// and explicit rl_fma (one rounding on both targets).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define RL_HD __host__ __device__ __forceinline__
+#else
+#define RL_HD inline __attribute__((always_inline))
+#endif
+
+namespace rl {
+
+// explicit fused multiply-add: v_fma_f32 on gfx950, vfmadd on the host (-mfma).
+RL_HD float rl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RL_HD double rl_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+RL_HD float rl_sqrt(float x) { return __builtin_sqrtf(x); }
+RL_HD double rl_sqrt(double x) { return __builtin_sqrt(x); }
+RL_HD float rl_abs(float x) { return __builtin_fabsf(x); }
+RL_HD double rl_abs(double x) { return __builtin_fabs(x); }
+
+template <typename R> RL_HD R rl_min(R a, R b) { return a < b ? a : b; }
+template <typename R> RL_HD R rl_max(R a, R b) { return a > b ? a : b; }
+template <typename R> RL_HD R rl_clamp(R x, R lo, R hi) { return rl_max(lo, rl_min(x, hi)); }
+
+// Deterministic single-precision sin/cos.  Cody-Waite three-term reduction by
+// pi/4 followed by degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]
+// (the classic single-precision kernel; max error < 1.5 ulp for |x| < 8192,
+// which covers every joint angle these envs can reach).  Only mul/add/sub and
+// float->int truncation, so host and device agree bit for bit.
+RL_HD void rl_sincos(float x, float& s, float& c) {
+    const float FOPI = 1.27323954473516f;  // 4/pi
+    const float DP1 = 0.78515625f;
+    const float DP2 = 2.4187564849853515625e-4f;
+    const float DP3 = 3.77489497744594108e-8f;
+    float ax = rl_abs(x);
+    int j = (int)(ax * FOPI);
+    j = (j + 1) & ~1;  // round up to even octant boundary
+    float y = (float)j;
+    float r = ((ax - y * DP1) - y * DP2) - y * DP3;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    int q = (j >> 1) & 3;  // quadrant of the reduced argument
+    float sv = (q & 1) ? pc : ps;
+    float cv = (q & 1) ? ps : pc;
+    if (q & 2) sv = -sv;
+    if ((q == 1) || (q == 2)) cv = -cv;
+    s = (x < 0.0f) ? -sv : sv;
+    c = cv;
+}
+
+// The double instantiation is host-only (independent physics checks at 1e-10);
+// it may use libm.
+RL_HD void rl_sincos(double x, double& s, double& c) {
+    s = sin(x);
+    c = cos(x);
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11).  Pure 32/64-bit
+// integer arithmetic: the stream is identical on host and device and is pinned
+// against a numpy restatement in tests/.  Key = (seed_lo, seed_hi); counter =
+// (env index, step, episode/iteration counter, purpose tag).
+// ---------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+RL_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 r;
+    r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
+    return r;
+}
+
+// 24-bit uniform in [0, 1): exact in float, identical on host and device.
+RL_HD float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// (0, 1] variant for Box-Muller's log.
+RL_HD float u32_to_unit_open(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+
+enum RngPurpose : uint32_t {
+    RNG_RESET = 0x52455345u,   // reset draws
+    RNG_POLICY = 0x504f4c49u,  // policy action noise
+};
+
+}  // namespace rl

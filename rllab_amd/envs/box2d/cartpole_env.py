@@ -1,0 +1,18 @@
+"""CartpoleEnv (API of rllab/envs/box2d/cartpole_env.py:10-56); dynamics in
+csrc/dyn_cartpole.h (``rl::Cartpole``)."""
+from rllab_amd import _lib
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.envs.box2d.box2d_env import Box2DEnv
+
+
+class CartpoleEnv(Box2DEnv, Serializable):
+    KIND = _lib.ENV_CARTPOLE
+
+    def __init__(self, *args, **kwargs):
+        self.max_pole_angle = .2
+        self.max_cart_pos = 2.4
+        self.max_cart_speed = 4.
+        self.max_pole_speed = 4.
+        self.reset_range = 0.05
+        super(CartpoleEnv, self).__init__(None, *args, **kwargs)
+        Serializable.__init__(self, *args, **kwargs)

@@ -1,0 +1,209 @@
+"""HIP-native envs: the Python face of the env kernels.
+
+``HipVecEnv`` is the vectorised boundary of sandbox/rocky/tf/envs/
+vec_env_executor.py:8-48 (``reset() -> obs_n``, ``step(action_n) -> (obs_n,
+rewards, dones, env_infos)``, ``num_envs``, ``terminate()``) with every per-env
+Python loop replaced by one kernel launch over SoA state planes in HBM.
+``HipEnv`` is the single-env ``Env`` face (reset/step on a 1-env executor) that
+keeps scripts written against rllab/envs/base.py working.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from rllab_amd import _lib, spaces
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.envs.base import Env, Step
+from rllab_amd.misc import ext
+from rllab_amd.sampler.trajectories import Trajectories
+
+BIG = 1e6
+
+
+def _require_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("rllab_amd: no HIP device visible -- env kernels have no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _fresh_seed():
+    s = ext.get_seed()
+    if s is None:
+        s = int(np.random.randint(0, 2 ** 31 - 1))
+    return int(s)
+
+
+class HipVecEnv(object):
+    """n lock-step copies of one env kind on the current HIP device."""
+
+    def __init__(self, kind, n_envs, max_path_length, normalize=False, scale_reward=1.0, seed=None,
+                 env_offset=0, action_space=None, observation_space=None, auto_reset=True):
+        self.kind = kind
+        self.n = int(n_envs)
+        self.max_path_length = int(max_path_length) if max_path_length is not None else 0
+        self.normalize = bool(normalize)
+        self.scale_reward = float(scale_reward)
+        self.seed = _fresh_seed() if seed is None else int(seed)
+        self.env_offset = int(env_offset)
+        self.auto_reset = bool(auto_reset)
+        self.q = _lib.env_query(kind)
+        self.device = _require_device()
+        self.state = torch.zeros((self.q["state_dim"], self.n), dtype=torch.float32, device=self.device)
+        self.ts = torch.zeros((self.n,), dtype=torch.int32, device=self.device)
+        self._obs = torch.zeros((self.q["obs_dim"], self.n), dtype=torch.float32, device=self.device)
+        self._reward = torch.zeros((self.n,), dtype=torch.float32, device=self.device)
+        self._done = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+        self.step_counter = 0  # global step index: RNG counter base
+        self._action_space, self._observation_space = action_space, observation_space
+
+    # -- VecEnvExecutor surface ------------------------------------------------
+    @property
+    def num_envs(self):
+        return self.n
+
+    @property
+    def action_space(self):
+        return self._action_space
+
+    @property
+    def observation_space(self):
+        return self._observation_space
+
+    def terminate(self):
+        pass
+
+    def reset(self, mask=None, draws=None):
+        """Reset all envs (or those in ``mask``); returns obs_n as an [n, Do] view."""
+        if draws is not None:
+            draws = torch.as_tensor(draws, dtype=torch.float32, device=self.device).contiguous()
+            assert draws.shape == (self.q["reset_draws"], self.n)
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        _lib.check(_lib.lib.rl_vecenv_reset(
+            self.kind, self.n, _lib.ptr(self.state), _lib.ptr(self.ts), _lib.ptr(mask), _lib.ptr(draws),
+            self.seed, self.step_counter, self.env_offset, _lib.ptr(self._obs), _lib.stream_ptr()),
+            "rl_vecenv_reset")
+        self.step_counter += 1
+        return self._obs.t()
+
+    def step(self, action_n, reset_draws=None):
+        """One lock-step transition.  ``action_n``: [n, Da] numpy array or tensor.
+        numpy in -> numpy out; tensor in -> device tensors out (views of buffers
+        that the next call overwrites)."""
+        is_np = not torch.is_tensor(action_n)
+        a = torch.as_tensor(np.asarray(action_n) if is_np else action_n)
+        a = a.to(device=self.device, dtype=torch.float32).reshape(self.n, self.q["act_dim"]).t().contiguous()
+        if reset_draws is not None:
+            reset_draws = torch.as_tensor(reset_draws, dtype=torch.float32, device=self.device).contiguous()
+        _lib.check(_lib.lib.rl_vecenv_step(
+            self.kind, self.n, int(self.normalize), self.scale_reward, self.max_path_length,
+            int(self.auto_reset), _lib.ptr(self.state), _lib.ptr(self.ts), _lib.ptr(a), _lib.ptr(reset_draws), self.seed,
+            self.step_counter, self.env_offset, _lib.ptr(self._obs), _lib.ptr(self._reward),
+            _lib.ptr(self._done), _lib.stream_ptr()), "rl_vecenv_step")
+        self.step_counter += 1
+        obs, rew, done = self._obs.t(), self._reward, self._done.bool()
+        if is_np:
+            return (obs.cpu().numpy().astype(np.float64), rew.cpu().numpy().astype(np.float64),
+                    done.cpu().numpy(), dict())
+        return obs, rew, done, dict()
+
+    # -- fused rollout ---------------------------------------------------------
+    def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None):
+        """``horizon`` lock-step iterations of get_actions -> step -> record ->
+        auto-reset in ONE launch (rl_rollout_gaussian_mlp).  Returns
+        ``Trajectories``.  ``eps`` [Da, T, n] / ``reset_draws`` [T+1, R, n]
+        inject pre-generated noise (parity runs)."""
+        T, n = int(horizon), self.n
+        do, da = self.q["obs_dim"], self.q["act_dim"]
+        hs = tuple(policy.hidden_sizes)
+        if len(hs) != 2 or not policy.fusable:
+            raise NotImplementedError("fused rollout needs a 2-hidden-layer tanh GaussianMLPPolicy")
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        obs = torch.empty((do, T, n), **f32)
+        act = torch.empty((da, T, n), **f32)
+        mean = torch.empty((da, T, n), **f32)
+        rew = torch.empty((T, n), **f32)
+        done = torch.empty((T, n), dtype=torch.uint8, device=dev)
+        theta = policy.flat_params.detach()
+        assert theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous()
+        if eps is not None:
+            eps = torch.as_tensor(eps, **f32).contiguous()
+            assert eps.shape == (da, T, n)
+        if reset_draws is not None:
+            reset_draws = torch.as_tensor(reset_draws, **f32).contiguous()
+            assert reset_draws.shape == (T + 1, self.q["reset_draws"], n)
+        log_min_std = math.log(policy.min_std) if policy.min_std is not None else -1e30
+        args = _lib.RolloutArgs(
+            kind=self.kind, n_envs=n, horizon=T, max_path_length=self.max_path_length,
+            normalize=int(self.normalize), reset_at_start=int(reset_at_start),
+            hidden0=hs[0], hidden1=hs[1], env_offset=self.env_offset,
+            scale_reward=self.scale_reward, log_min_std=log_min_std, seed=self.seed,
+            step_counter=self.step_counter,
+            state=self.state.data_ptr(), ts=self.ts.data_ptr(), theta=theta.data_ptr(),
+            eps=eps.data_ptr() if eps is not None else None,
+            reset_draws=reset_draws.data_ptr() if reset_draws is not None else None,
+            obs=obs.data_ptr(), actions=act.data_ptr(), means=mean.data_ptr(),
+            rewards=rew.data_ptr(), dones=done.data_ptr(), last_obs=self._obs.data_ptr())
+        _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
+                   "rl_rollout_gaussian_mlp")
+        self.step_counter += T + 1
+        return Trajectories(obs, act, mean, policy.effective_log_std().detach(), rew, done,
+                            self.max_path_length)
+
+
+class HipEnv(Env, Serializable):
+    """Base of the HIP-native envs; subclasses set ``KIND``."""
+    KIND = None
+
+    def __init__(self):
+        q = _lib.env_query(self.KIND)
+        self._q = q
+        lb, ub = _lib.env_action_bounds(self.KIND)
+        self._action_space = spaces.Box(lb, ub)
+        ob = BIG * np.ones(q["obs_dim"])
+        self._observation_space = spaces.Box(-ob, ob)
+        self._single = None
+
+    @property
+    def action_space(self):
+        return self._action_space
+
+    @property
+    def observation_space(self):
+        return self._observation_space
+
+    @property
+    def action_bounds(self):
+        return self.action_space.bounds
+
+    @property
+    def vectorized(self):
+        return True
+
+    def vec_env_executor(self, n_envs, max_path_length, normalize=False, scale_reward=1.0, seed=None,
+                         env_offset=0, auto_reset=True):
+        return HipVecEnv(self.KIND, n_envs, max_path_length, normalize=normalize,
+                         scale_reward=scale_reward, seed=seed, env_offset=env_offset,
+                         action_space=self.action_space, observation_space=self.observation_space,
+                         auto_reset=auto_reset)
+
+    # -- single-env face (rllab/envs/base.py) on a 1-env executor --------------
+    def _one(self):
+        if self._single is None:
+            self._single = self.vec_env_executor(1, 0, auto_reset=False)
+        return self._single
+
+    def reset(self):
+        return self._one().reset()[0].cpu().numpy().astype(np.float64)
+
+    def step(self, action):
+        v = self._one()
+        a = np.asarray(action, dtype=np.float64).reshape(1, -1)
+        obs, rew, done, _ = v.step(a)  # auto_reset off: terminal observation, caller resets
+        return Step(observation=obs[0], reward=float(rew[0]), done=bool(done[0]))
+
+    def terminate(self):
+        self._single = None

@@ -1,0 +1,72 @@
+"""The few helpers of rllab/misc/ext.py the hot path uses: ``extract`` (:14-20),
+``set_seed`` (:188-206), ``sliced_fun`` (:341-370), ``lazydict``."""
+import random
+
+import numpy as np
+
+seed_ = None
+
+
+def extract(x, *keys):
+    if isinstance(x, dict):
+        return tuple(x[k] for k in keys)
+    elif isinstance(x, list):
+        return tuple([xi[k] for xi in x] for k in keys)
+    raise NotImplementedError
+
+
+def set_seed(seed):
+    """Seeds ``random`` / ``np.random`` / torch, and becomes the key of the
+    in-kernel Philox streams (samplers read ``get_seed()``)."""
+    global seed_
+    seed %= 4294967294
+    seed_ = seed
+    random.seed(seed)
+    np.random.seed(seed)
+    import torch
+    torch.manual_seed(seed)
+
+
+def get_seed():
+    return seed_
+
+
+class lazydict(object):
+    def __init__(self, **kwargs):
+        self._lazy_dict = kwargs
+        self._dict = {}
+
+    def __getitem__(self, key):
+        if key not in self._dict:
+            self._dict[key] = self._lazy_dict[key]()
+        return self._dict[key]
+
+    def set(self, key, value):
+        self._lazy_dict[key] = value
+
+
+def sliced_fun(f, n_slices):
+    """Evaluate ``f`` on ``n_slices`` slices of the sample axis and return the
+    sample-weighted mean (reference :341-370).  With ``n_slices == 1`` it is a
+    plain call."""
+    def sliced_f(sliced_inputs, non_sliced_inputs=None):
+        if non_sliced_inputs is None:
+            non_sliced_inputs = []
+        non_sliced_inputs = list(non_sliced_inputs)
+        n_paths = len(sliced_inputs[0])
+        slice_size = max(1, n_paths // n_slices)
+        ret_vals = None
+        was_tuple = was_seq = False
+        for start in range(0, n_paths, slice_size):
+            inputs_slice = [v[start:start + slice_size] for v in sliced_inputs]
+            out = f(*(inputs_slice + non_sliced_inputs))
+            was_seq = isinstance(out, (tuple, list))
+            was_tuple = isinstance(out, tuple)
+            outs = list(out) if was_seq else [out]
+            scaled = [np.asarray(v) * len(inputs_slice[0]) for v in outs]
+            ret_vals = scaled if ret_vals is None else [x + y for x, y in zip(ret_vals, scaled)]
+        ret_vals = [v / n_paths for v in ret_vals]
+        if not was_seq:
+            return ret_vals[0]
+        return tuple(ret_vals) if was_tuple else ret_vals
+    return sliced_f

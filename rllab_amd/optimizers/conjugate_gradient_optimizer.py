@@ -1,0 +1,247 @@
+"""ConjugateGradientOptimizer + Hessian-vector-product plug-ins
+(API and numerics of rllab/optimizers/conjugate_gradient_optimizer.py:13-296).
+
+Where the reference hands Theano *expressions* to ``update_opt`` and compiles
+``f_loss / f_grad / f_constraint / f_loss_constraint / f_Hx_plain``, this version
+takes torch *closures* ``loss(flat_params, *inputs) -> 0-d tensor`` and
+differentiates them with autograd.  The control flow of ``optimize`` is the
+reference's (:229-296): loss_before -> flat gradient -> CG(Hx, g, cg_iters) ->
+initial step sqrt(2*delta / (d^T H d + 1e-8)) -> backtracking line search over
+``backtrack_ratio**k`` with parameter update ``prev - ratio*step`` -> accept /
+reject predicate, including its ``<=`` / ``>=`` asymmetry.
+
+Differences, all below the numeric contract:
+  * every vector stays on the device; CG runs in float64 without host syncs;
+  * each evaluated quantity is a SUM of per-rank terms already normalised by the
+    global sample count, so one sum all-reduce (RCCL) per evaluation makes the
+    sharded run identical to the single-process one.
+"""
+import numpy as np
+import torch
+
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.misc import krylov, logger
+from rllab_amd.sampler import dist as D
+
+
+def _flat_for_grad(target):
+    return target.flat_params.detach().clone().requires_grad_(True)
+
+
+class PerlmutterHvp(Serializable):
+    """Hx = grad(grad(f) . x) + reg*x by double back-propagation (reference :13-55)."""
+
+    def __init__(self, num_slices=1):
+        Serializable.quick_init(self, locals())
+        self.target = None
+        self.reg_coeff = None
+        self._f = None
+        self._num_slices = num_slices
+
+    def update_opt(self, f, target, inputs, reg_coeff):
+        self.target, self.reg_coeff, self._f = target, reg_coeff, f
+
+    def build_eval(self, inputs, trainable_index=None):
+        target, f, reg = self.target, self._f, self.reg_coeff
+
+        def eval(x):
+            flat = _flat_for_grad(target)
+            g = torch.autograd.grad(f(flat, *inputs), flat, create_graph=True)[0]
+            xf = torch.zeros_like(flat)
+            if trainable_index is None:
+                xf = x.to(flat.dtype)
+            else:
+                xf[trainable_index] = x.to(flat.dtype)
+            hx = torch.autograd.grad((g * xf).sum(), flat)[0]
+            if trainable_index is not None:
+                hx = hx[trainable_index]
+            hx = D.all_reduce_sum_(hx.to(torch.float64))
+            return hx + reg * x
+        return eval
+
+
+class FiniteDifferenceHvp(Serializable):
+    """Hx ~ (g(theta + eps x) - g(theta - eps x)) / (2 eps), eps = base_eps / ||theta||
+    (reference :58-115)."""
+
+    def __init__(self, base_eps=1e-8, symmetric=True, grad_clip=None, num_slices=1):
+        Serializable.quick_init(self, locals())
+        self.base_eps = base_eps
+        self.symmetric = symmetric
+        self.grad_clip = grad_clip
+        self._num_slices = num_slices
+
+    def update_opt(self, f, target, inputs, reg_coeff):
+        self.target, self.reg_coeff, self._f = target, reg_coeff, f
+
+    def build_eval(self, inputs, trainable_index=None):
+        target, f, reg = self.target, self._f, self.reg_coeff
+
+        def grad_at(theta):
+            flat = theta.detach().clone().requires_grad_(True)
+            g = torch.autograd.grad(f(flat, *inputs), flat)[0]
+            if trainable_index is not None:
+                g = g[trainable_index]
+            return D.all_reduce_sum_(g.to(torch.float64))
+
+        def eval(x):
+            theta = target.flat_params.detach().to(torch.float64)
+            pv = theta if trainable_index is None else theta[trainable_index]
+            eps = float(np.float32(self.base_eps / (float(pv.norm()) + 1e-8)))
+
+            def shifted(sign):
+                th = theta.clone()
+                if trainable_index is None:
+                    th = th + sign * eps * x
+                else:
+                    th[trainable_index] += sign * eps * x
+                return th.to(target.flat_params.dtype)
+            gp = grad_at(shifted(+1.0))
+            if self.symmetric:
+                gm = grad_at(shifted(-1.0))
+                hx = (gp - gm) / (2 * eps)
+            else:
+                hx = (gp - grad_at(theta.to(target.flat_params.dtype))) / eps
+            return hx + reg * x
+        return eval
+
+
+class ConjugateGradientOptimizer(Serializable):
+    def __init__(self, cg_iters=10, reg_coeff=1e-5, subsample_factor=1., backtrack_ratio=0.8,
+                 max_backtracks=15, accept_violation=False, hvp_approach=None, num_slices=1):
+        Serializable.quick_init(self, locals())
+        self._cg_iters = cg_iters
+        self._reg_coeff = reg_coeff
+        self._subsample_factor = subsample_factor
+        self._backtrack_ratio = backtrack_ratio
+        self._max_backtracks = max_backtracks
+        self._num_slices = num_slices
+        self._loss = None
+        self._constraint = None
+        self._target = None
+        self._max_constraint_val = None
+        self._constraint_name = None
+        self._accept_violation = accept_violation
+        self._hvp_given = hvp_approach is not None
+        if hvp_approach is None:
+            hvp_approach = PerlmutterHvp(num_slices)
+        self._hvp_approach = hvp_approach
+        self._fused = None
+        self.last_backtrack_iters = None
+
+    def update_opt(self, loss, target, leq_constraint, inputs=None, extra_inputs=None,
+                   constraint_name="constraint", fused=None, *args, **kwargs):
+        """``loss`` and ``leq_constraint[0]`` are closures ``f(flat_params, *inputs)``;
+        ``leq_constraint[1]`` is the bound.  ``fused`` optionally supplies HIP-kernel
+        implementations of the same functions (see policies/fused_ops.py)."""
+        constraint_term, constraint_value = leq_constraint
+        self._loss = loss
+        self._constraint = constraint_term
+        self._target = target
+        self._max_constraint_val = constraint_value
+        self._constraint_name = constraint_name
+        self._fused = fused
+        if fused is not None and not self._hvp_given:
+            self._hvp_approach = fused.hvp_approach()
+        self._hvp_approach.update_opt(f=constraint_term, target=target, inputs=inputs,
+                                      reg_coeff=self._reg_coeff)
+
+    # -- evaluations ------------------------------------------------------------
+    def _trainable_index(self):
+        return self._target._flat_index(trainable=True)
+
+    def _eval_scalar(self, fn, inputs):
+        with torch.no_grad():
+            v = fn(self._target.flat_params, *inputs).to(torch.float64)
+        return D.all_reduce_sum_(v)
+
+    def loss(self, inputs, extra_inputs=None):
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if self._fused is not None:
+            return float(self._fused.loss_and_kl(inputs)[0])
+        return float(self._eval_scalar(self._loss, inputs))
+
+    def constraint_val(self, inputs, extra_inputs=None):
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if self._fused is not None:
+            return float(self._fused.loss_and_kl(inputs)[1])
+        return float(self._eval_scalar(self._constraint, inputs))
+
+    def _loss_constraint(self, inputs):
+        if self._fused is not None:
+            return self._fused.loss_and_kl(inputs)
+        return (self._eval_scalar(self._loss, inputs), self._eval_scalar(self._constraint, inputs))
+
+    def _flat_grad(self, inputs):
+        if self._fused is not None:
+            g = self._fused.loss_grad(inputs)
+        else:
+            flat = _flat_for_grad(self._target)
+            g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
+            g = D.all_reduce_sum_(g.to(torch.float64))
+        idx = self._trainable_index()
+        return g if idx is None else g[idx]
+
+    # -- the update ---------------------------------------------------------------
+    def optimize(self, inputs, extra_inputs=None, subsample_grouped_inputs=None):
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        target = self._target
+        idx = self._trainable_index()
+
+        if self._subsample_factor < 1:
+            n_samples = inputs[0].shape[-1]
+            inds = torch.as_tensor(
+                np.random.choice(n_samples, int(n_samples * self._subsample_factor), replace=False),
+                device=inputs[0].device)
+            subsample_inputs = list(
+                x.index_select(-1, inds) if torch.is_tensor(x) and x.dim() > 0 and x.shape[-1] == n_samples
+                else x for x in inputs)
+            # input convention (algos/npo.py): [..., weights, inv_count]; renormalise the mean
+            cnt = D.all_reduce_sum_(subsample_inputs[-2].to(torch.float64).sum())
+            subsample_inputs[-1] = (1.0 / cnt).to(inputs[-1].dtype)
+            subsample_inputs = tuple(subsample_inputs)
+        else:
+            subsample_inputs = inputs
+
+        logger.log("computing loss before")
+        loss_before = float(self._loss_constraint(inputs)[0])
+        logger.log("performing update")
+        logger.log("computing descent direction")
+        flat_g = self._flat_grad(inputs)
+        Hx = self._hvp_approach.build_eval(subsample_inputs, idx)
+        descent_direction = krylov.cg(Hx, flat_g, cg_iters=self._cg_iters)
+        initial_step_size = torch.sqrt(
+            2.0 * self._max_constraint_val * (1. / (descent_direction.dot(Hx(descent_direction)) + 1e-8)))
+        initial_step_size = torch.where(torch.isnan(initial_step_size),
+                                        torch.ones_like(initial_step_size), initial_step_size)
+        flat_descent_step = initial_step_size * descent_direction
+        logger.log("descent direction computed")
+
+        full_prev = target.flat_params.detach().clone()
+        prev_param = (full_prev if idx is None else full_prev[idx]).to(torch.float64)
+        n_iter = 0
+        loss = constraint_val = float("nan")
+        for n_iter, ratio in enumerate(self._backtrack_ratio ** np.arange(self._max_backtracks)):
+            cur_param = prev_param - float(ratio) * flat_descent_step
+            target.set_param_values(cur_param, trainable=True)
+            l_t, c_t = self._loss_constraint(inputs)
+            loss, constraint_val = float(l_t), float(c_t)
+            if loss < loss_before and constraint_val <= self._max_constraint_val:
+                break
+        if (np.isnan(loss) or np.isnan(constraint_val) or loss >= loss_before or
+                constraint_val >= self._max_constraint_val) and not self._accept_violation:
+            logger.log("Line search condition violated. Rejecting the step!")
+            if np.isnan(loss):
+                logger.log("Violated because loss is NaN")
+            if np.isnan(constraint_val):
+                logger.log("Violated because constraint %s is NaN" % self._constraint_name)
+            if loss >= loss_before:
+                logger.log("Violated because loss not improving")
+            if constraint_val >= self._max_constraint_val:
+                logger.log("Violated because constraint %s is violated" % self._constraint_name)
+            with torch.no_grad():
+                target.flat_params.copy_(full_prev)
+        self.last_backtrack_iters = n_iter
+        logger.log("backtrack iters: %d" % n_iter)
+        logger.log("computing loss after")
+        logger.log("optimization finished")

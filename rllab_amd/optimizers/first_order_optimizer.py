@@ -1,0 +1,121 @@
+"""FirstOrderOptimizer (API of rllab/optimizers/first_order_optimizer.py:14-137).
+
+VPG uses it with ``batch_size=None, max_epochs=1`` (rllab/algos/vpg.py:26-34): one
+full-batch Adam step per iteration, moments persisting across iterations.  The
+update rule is Lasagne's ``adam`` (third party, pinned fork in the reference's
+environment.yml): t += 1; a_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1*m + (1-b1)*g;
+v = b2*v + (1-b2)*g^2; theta -= a_t * m / (sqrt(v) + eps), b1=0.9, b2=0.999,
+eps=1e-8.  State lives on the device; gradients are sum-all-reduced across ranks.
+"""
+import time
+
+import numpy as np
+import torch
+
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.misc import logger
+from rllab_amd.sampler import dist as D
+
+
+class _Adam(object):
+    def __init__(self, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        self.t = 0
+        self.m = None
+        self.v = None
+
+    def step(self, param, grad):
+        if self.m is None:
+            self.m = torch.zeros_like(grad)
+            self.v = torch.zeros_like(grad)
+        self.t += 1
+        a_t = self.lr * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        self.m = self.b1 * self.m + (1 - self.b1) * grad
+        self.v = self.b2 * self.v + (1 - self.b2) * grad * grad
+        return param - a_t * self.m / (torch.sqrt(self.v) + self.eps)
+
+
+class _SGD(object):
+    def __init__(self, learning_rate=1e-3):
+        self.lr = learning_rate
+
+    def step(self, param, grad):
+        return param - self.lr * grad
+
+
+def adam(learning_rate=1e-3, **kw):
+    return _Adam(learning_rate=learning_rate, **kw)
+
+
+def sgd(learning_rate=1e-3, **kw):
+    return _SGD(learning_rate=learning_rate)
+
+
+class FirstOrderOptimizer(Serializable):
+    def __init__(self, update_method=adam, learning_rate=1e-3, max_epochs=1000, tolerance=1e-6,
+                 batch_size=32, callback=None, verbose=False, **kwargs):
+        Serializable.quick_init(self, locals())
+        self._loss = None
+        self._target = None
+        self._callback = callback
+        self._update_factory = lambda: update_method(learning_rate=learning_rate)
+        self._updater = None
+        self._max_epochs = max_epochs
+        self._tolerance = tolerance
+        self._batch_size = batch_size
+        self._verbose = verbose
+
+    def update_opt(self, loss, target, inputs=None, extra_inputs=None, gradients=None, **kwargs):
+        """``loss`` is a closure ``loss(flat_params, *inputs) -> 0-d tensor``.  The
+        update state (Adam moments) is created here, once, like the reference's
+        shared variables (:62-65)."""
+        self._target = target
+        self._loss = loss
+        self._updater = self._update_factory()
+
+    def loss(self, inputs, extra_inputs=None):
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        with torch.no_grad():
+            v = self._loss(self._target.flat_params, *inputs).to(torch.float64)
+        return float(D.all_reduce_sum_(v))
+
+    def _step(self, inputs):
+        target = self._target
+        flat = target.flat_params.detach().clone().requires_grad_(True)
+        g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
+        g = D.all_reduce_sum_(g.to(torch.float64))
+        idx = target._flat_index(trainable=True)
+        theta = target.flat_params.detach().to(torch.float64)
+        if idx is not None:
+            g, theta = g[idx], theta[idx]
+        target.set_param_values(self._updater.step(theta, g), trainable=True)
+
+    def optimize(self, inputs, extra_inputs=None, callback=None, **kwargs):
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if len(inputs) == 0:
+            raise NotImplementedError
+        last_loss = self.loss(inputs)
+        start_time = time.time()
+        n = inputs[0].shape[-1]
+        for epoch in range(self._max_epochs):
+            if self._batch_size is None:
+                self._step(inputs)
+            else:
+                ids = torch.as_tensor(np.random.permutation(n), device=inputs[0].device)
+                for s in range(0, n, self._batch_size):
+                    sel = ids[s:s + self._batch_size]
+                    self._step(tuple(x.index_select(-1, sel) if torch.is_tensor(x) and x.dim() > 0 and
+                                     x.shape[-1] == n else x for x in inputs))
+            new_loss = self.loss(inputs)
+            if self._verbose:
+                logger.log("Epoch %d, loss %s" % (epoch, new_loss))
+            if self._callback or callback:
+                cb = dict(loss=new_loss, params=self._target.get_param_values(trainable=True),
+                          itr=epoch, elapsed=time.time() - start_time)
+                if self._callback:
+                    self._callback(cb)
+                if callback:
+                    callback(**cb)
+            if abs(last_loss - new_loss) < self._tolerance:
+                break
+            last_loss = new_loss

@@ -1,0 +1,55 @@
+"""Thin helpers over ``torch.distributed`` for the env-sharded data-parallel run
+(one process per GPU, backend "nccl" == RCCL over xGMI; "gloo" in CPU tests).
+
+The path has exactly one exchange family -- small sum/min/max all-reduces of
+statistics, normal equations, the flat gradient and each Fisher-vector product
+(SURVEY.md section 8e).  Every rank applies the identical parameter update, so no
+broadcast is needed after the initial parameter sync.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def rank():
+    return dist.get_rank() if is_distributed() else 0
+
+
+def all_reduce_sum_(t):
+    """In-place sum all-reduce (no-op on a single process).  Returns ``t``."""
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_min_(t):
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t
+
+
+def all_reduce_max_(t):
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def broadcast_(t, src=0):
+    if is_distributed():
+        dist.broadcast(t, src=src)
+    return t
+
+
+def sums(*scalars):
+    """All-reduce a handful of 0-d float64 tensors in ONE message; returns a list of
+    0-d tensors holding the global sums."""
+    packed = torch.stack([s.to(torch.float64).reshape(()) for s in scalars])
+    all_reduce_sum_(packed)
+    return list(packed.unbind(0))

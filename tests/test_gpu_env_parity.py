@@ -1,0 +1,190 @@
+"""GPU parity tests proper (``-m gpu``): every call goes through the C ABI of
+librllab_amd.so; the checker is the host oracle (oracle/)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ENV_KINDS = [0]
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def test_philox_device_matches_host():
+    from rllab_amd import _lib
+    from oracle import host_env as H
+    n = 1000
+    out = torch.zeros(4 * n, dtype=torch.int32, device=_dev())
+    args = (12345, 7, 0xdeadbeef, 0x52455345, 0x1234abcd, 0x9e3779b9)
+    _lib.check(_lib.lib.rl_debug_philox(*args, n, _lib.ptr(out), _lib.stream_ptr()))
+    got = out.cpu().numpy().view(np.uint32).reshape(n, 4)
+    want = H.philox(*args, n)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ENV_KINDS)
+@pytest.mark.parametrize("normalize", [False, True])
+def test_vecenv_step_bit_exact(kind, normalize):
+    """reset + 60 lock-step transitions with auto-reset and a horizon: every state
+    plane, observation, reward and done flag equals the host build bit for bit."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from oracle import host_env as H
+    rng = np.random.RandomState(0)
+    n, mpl = 257, 25
+    gpu = HipVecEnv(kind, n, mpl, normalize=normalize, scale_reward=0.5, seed=3)
+    cpu = H.HostVecEnv(kind, n, mpl, normalize=normalize, scale_reward=0.5)
+    q = gpu.q
+    draw = (lambda: rng.randn(q["reset_draws"], n)) if q["reset_is_normal"] else \
+        (lambda: rng.rand(q["reset_draws"], n))
+    d0 = draw().astype(np.float32)
+    o_gpu = gpu.reset(draws=d0)
+    o_cpu = cpu.reset(d0)
+    assert np.array_equal(o_gpu.t().cpu().numpy().view(np.uint32), o_cpu.view(np.uint32))
+    lb, ub = H.HostEnv(kind).q, None
+    n_done = 0
+    for t in range(60):
+        scale = 1.0 if normalize else 10.0
+        a = (rng.randn(n, q["act_dim"]) * scale).astype(np.float32)
+        dr = draw().astype(np.float32)
+        og, rg, dg, _ = gpu.step(torch.as_tensor(a, device=gpu.device), reset_draws=dr)
+        oc, rc, dc = cpu.step(a.T, dr)
+        assert np.array_equal(gpu.state.cpu().numpy().view(np.uint32), cpu.state.view(np.uint32)), t
+        assert np.array_equal(og.t().cpu().numpy().view(np.uint32), oc.view(np.uint32)), t
+        assert np.array_equal(rg.cpu().numpy().view(np.uint32), rc.view(np.uint32)), t
+        assert np.array_equal(dg.cpu().numpy(), dc.astype(bool)), t
+        assert np.array_equal(gpu.ts.cpu().numpy(), cpu.ts), t
+        n_done += int(dc.sum())
+    assert n_done > 0  # the auto-reset branch was exercised
+
+
+def _make_policy(kind, hidden=(32, 32), seed=0):
+    from rllab_amd import _lib
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    q = _lib.env_query(kind)
+    np.random.seed(seed)
+    spec = EnvSpec(Box(-1e6 * np.ones(q["obs_dim"]), 1e6 * np.ones(q["obs_dim"])),
+                   Box(-np.ones(q["act_dim"]), np.ones(q["act_dim"])))
+    return GaussianMLPPolicy(spec, hidden_sizes=hidden)
+
+
+@pytest.mark.parametrize("kind", ENV_KINDS)
+@pytest.mark.parametrize("hidden", [(32, 32), (64, 64)])
+def test_fused_rollout_injected_noise(kind, hidden):
+    """Fused rollout with injected policy noise and reset draws:
+       * env dynamics replayed on the host oracle from the recorded actions: bit-exact;
+       * recorded means vs a float64 torch forward of the same theta: <= 1e-5;
+       * recorded action == mean + eps * exp(log_std) (<= 1 ulp-ish, fma vs mul+add)."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from oracle.replay import replay_check
+    rng = np.random.RandomState(1)
+    n, T, mpl = 130, 40, 17
+    policy = _make_policy(kind, hidden)
+    v = HipVecEnv(kind, n, mpl, normalize=True, seed=11)
+    q = v.q
+    eps = rng.randn(q["act_dim"], T, n).astype(np.float32)
+    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    traj = v.rollout(policy, T, reset_at_start=True, eps=eps, reset_draws=draws)
+    torch.cuda.synchronize()
+    assert replay_check(v, traj, max_envs=n) == n * T
+    assert int(traj.dones.sum()) > 0
+    # policy parity
+    obs64 = traj.obs.reshape(q["obs_dim"], -1).double()
+    with torch.no_grad():
+        mean64 = policy.mean_planes(obs64, policy.flat_params.double())
+    got = traj.means.reshape(q["act_dim"], -1).double()
+    assert float((got - mean64).abs().max()) <= 1e-5
+    std = torch.exp(policy.effective_log_std().double())[:, None]
+    act64 = got + torch.as_tensor(eps, device=got.device).reshape(q["act_dim"], -1).double() * std
+    assert float((traj.actions.reshape(q["act_dim"], -1).double() - act64).abs().max()) <= 1e-6
+    # reset draws were consumed from the right slice: path-start observations of Cartpole are
+    # affine in the draws
+    if kind == 0:
+        b = np.array([2.4, 4.0, 0.2, 4.0], np.float32) * np.float32(0.05)
+        o0 = traj.obs[:, 0, :].cpu().numpy()
+        want = (-b[:, None] + draws[0] * (b[:, None] - (-b[:, None]))).astype(np.float32)
+        assert np.array_equal(o0.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ENV_KINDS)
+def test_fused_rollout_production_rng(kind):
+    """Production mode (in-kernel Philox): dynamics still replay bit-exactly, the
+    policy noise has the right moments, and two runs with the same seed / counter agree."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from oracle.replay import replay_check
+    n, T = 4096, 50
+    policy = _make_policy(kind)
+    v = HipVecEnv(kind, n, T, normalize=True, seed=5)
+    traj = v.rollout(policy, T)
+    v2 = HipVecEnv(kind, n, T, normalize=True, seed=5)
+    traj2 = v2.rollout(policy, T)
+    torch.cuda.synchronize()
+    assert torch.equal(traj.actions, traj2.actions) and torch.equal(traj.obs, traj2.obs)
+    replay_check(v, traj, max_envs=32)
+    z = (traj.actions - traj.means) / torch.exp(traj.log_std)[:, None, None]
+    z = z.double().reshape(-1)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.1
+    # a different seed gives a different stream
+    v3 = HipVecEnv(kind, n, T, normalize=True, seed=6)
+    assert not torch.equal(v3.rollout(policy, T).actions, traj.actions)
+
+
+def _ref_scan(x, c):
+    y = np.zeros_like(x, dtype=np.float64)
+    acc = np.zeros(x.shape[1])
+    for t in range(x.shape[0] - 1, -1, -1):
+        acc = x[t] + c[t] * acc
+        y[t] = acc
+    return y
+
+
+@pytest.mark.parametrize("T,n", [(1, 1), (7, 3), (100, 257), (500, 1000), (513, 64)])
+def test_gae_kernel_vs_float64_loop(T, n):
+    from rllab_amd import _lib
+    rng = np.random.RandomState(T * 1000 + n)
+    dev = _dev()
+    r = rng.randn(T, n).astype(np.float32)
+    v = rng.randn(T, n) * 3
+    done = (rng.rand(T, n) < 0.05).astype(np.uint8)
+    gamma, lam = 0.99, 0.97
+    adv = torch.empty((T, n), dtype=torch.float32, device=dev)
+    ret = torch.empty((T, n), dtype=torch.float32, device=dev)
+    tr, tv, td = (torch.as_tensor(x, device=dev) for x in (r, v, done))
+    _lib.check(_lib.lib.rl_gae(T, n, _lib.ptr(tr), _lib.ptr(tv), _lib.ptr(td), gamma, lam, _lib.ptr(adv),
+                               _lib.ptr(ret), _lib.stream_ptr()))
+    end = done.astype(bool).copy()
+    end[-1] = True
+    keep = 1.0 - end
+    vnext = np.vstack([v[1:], np.zeros((1, n))])
+    delta = r.astype(np.float64) + gamma * vnext * keep - v
+    want_adv = _ref_scan(delta, gamma * lam * keep)
+    want_ret = _ref_scan(r.astype(np.float64), gamma * keep)
+    scale = max(1.0, np.abs(want_adv).max())
+    assert np.abs(adv.cpu().numpy() - want_adv).max() <= 1e-5 * scale
+    assert np.abs(ret.cpu().numpy() - want_ret).max() <= 1e-5 * max(1.0, np.abs(want_ret).max())
+    # values=None path
+    _lib.check(_lib.lib.rl_gae(T, n, _lib.ptr(tr), None, _lib.ptr(td), gamma, 1.0, _lib.ptr(adv),
+                               _lib.ptr(ret), _lib.stream_ptr()))
+    assert np.abs(adv.cpu().numpy() - want_ret).max() <= 1e-5 * max(1.0, np.abs(want_ret).max())
+
+
+def test_discount_cumsum_special():
+    from rllab_amd.misc import special
+    # known answer from the reference run in the survey container
+    y = special.discount_cumsum(np.arange(5, dtype=np.float64), 0.9)
+    assert np.allclose(y, [7.3314, 8.146, 7.94, 6.6, 4.0], atol=1e-5)
+    rng = np.random.RandomState(0)
+    x = rng.randn(500, 33)
+    want = _ref_scan(x, np.full_like(x, 0.99))
+    assert np.abs(special.discount_cumsum(x, 0.99) - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
