@@ -71,4 +71,7 @@ def set_state_from_obs(env, o):
         s[6] = -sn[0] * np.float32(0.5)
         s[7] = np.float32(0.86602540378443864676) + cs[0] * np.float32(0.5)
         return
+    if kind == 2:  # Swimmer: obs[:10] = (qpos, qvel) is the whole state
+        env.state[:] = o[:10]
+        return
     raise NotImplementedError("set_state_from_obs: env kind %d" % kind)

@@ -84,24 +84,29 @@ class BatchPolopt(RLAlgorithm):
         self.start_worker()
         self.init_opt()
         for itr in range(self.current_itr, self.n_itr):
-            itr_start = time.time()
-            with logger.prefix('itr #%d | ' % itr):
-                paths = self.sampler.obtain_samples(itr)
-                samples_data = self.sampler.process_samples(itr, paths)
-                self.log_diagnostics(paths)
-                self.optimize_policy(itr, samples_data)
-                logger.log("saving snapshot...")
-                params = self.get_itr_snapshot(itr, samples_data)
-                self.current_itr = itr + 1
-                params["algo"] = self
-                if self.store_paths:
-                    params["paths"] = samples_data["paths"]
-                logger.save_itr_params(itr, params)
-                logger.log("saved")
-                self.itr_times.append(time.time() - itr_start)
-                logger.record_tabular('ItrTime', self.itr_times[-1])
-                logger.dump_tabular(with_prefix=False)
+            self.train_iteration(itr)
         self.shutdown_worker()
+
+    def train_iteration(self, itr):
+        """One pass of the reference's loop body (batch_polopt.py:119-132)."""
+        itr_start = time.time()
+        with logger.prefix('itr #%d | ' % itr):
+            paths = self.sampler.obtain_samples(itr)
+            samples_data = self.sampler.process_samples(itr, paths)
+            self.log_diagnostics(paths)
+            self.optimize_policy(itr, samples_data)
+            logger.log("saving snapshot...")
+            params = self.get_itr_snapshot(itr, samples_data)
+            self.current_itr = itr + 1
+            params["algo"] = self
+            if self.store_paths:
+                params["paths"] = samples_data["paths"]
+            logger.save_itr_params(itr, params)
+            logger.log("saved")
+            self.itr_times.append(time.time() - itr_start)
+            logger.record_tabular('ItrTime', self.itr_times[-1])
+            logger.dump_tabular(with_prefix=False)
+        return samples_data
 
     def log_diagnostics(self, paths):
         self.env.log_diagnostics(paths)

@@ -1,0 +1,152 @@
+// dyn_swimmer.h -- SwimmerEnv-style env: planar 3-link chain in a viscous / inertial
+// fluid, single source for the gfx950 kernels and the host oracle build.
+//
+// Replaces, for one env copy:
+//   SwimmerEnv.step / get_current_obs      rllab/envs/mujoco/swimmer_env.py:25-45
+//   MujocoEnv.reset_mujoco / forward_dynamics  rllab/envs/mujoco/mujoco_env.py:109-116,184-191
+//   MjModel.step x frame_skip, forward, _compute_subtree (comvel)
+//                                           rllab/mujoco_py/mjcore.py:46-84
+//   model constants                         vendor/mujoco_models/swimmer.xml:3-42
+//   NormalizedEnv.step                      rllab/envs/normalized_env.py:78-92
+// Constants from the MJCF: three capsules (radius 0.1, cylinder length 1,
+// density 1000), torso = 2 slides + hinge at the world origin with its capsule
+// spanning local x in [0.5, 1.5]; mid hinged at torso-local (0.5, 0), back hinged at
+// mid-local (-1, 0), both capsules spanning local x in [-1, 0]; hinges limited to
+// +-100 deg; two motors, gear 1, ctrlrange +-50; timestep 0.001, frame_skip 50,
+// Euler; fluid density 4000, viscosity 0.1; no contacts (collision="predefined").
+// Fluid forces follow MuJoCo's documented inertia-box model (per body, in the body
+// frame at the COM):  viscous  f = -3*pi*d*mu*v, t = -pi*d^3*mu*w  and inertial
+// drag  f_i = -0.5*rho*b_j*b_k*|v_i|*v_i, t_z = -rho*b_z*(b_x^4+b_y^4)*|w|*w/64,
+// with b the equivalent inertia box of the capsule and d its mean edge.
+// Joint limits: spring-damper penalty, not MuJoCo's soft-constraint solver.
+//
+// State (10 reals per env): qpos[5] = x, y, torso angle, rot2, rot3; qvel[5].
+#pragma once
+#include "dyn_planar.h"
+
+namespace rl {
+
+struct SwimmerModel {
+    static constexpr int NB = 3;
+    RL_HD static constexpr int parent(int i) { return i - 1; }
+    // hinge anchor in the parent frame
+    RL_HD static constexpr double jx(int i) { return i == 1 ? 0.5 : (i == 2 ? -1.0 : 0.0); }
+    RL_HD static constexpr double jy(int) { return 0.0; }
+    // capsule centre in the own frame
+    RL_HD static constexpr double cx(int i) { return i == 0 ? 1.0 : -0.5; }
+    RL_HD static constexpr double cy(int) { return 0.0; }
+    // capsule r = 0.1, L = 1, rho = 1000: m = rho*(pi r^2 L + 4/3 pi r^3)
+    RL_HD static constexpr double mass(int) { return 35.604716740684324; }
+    // about the COM, axis normal to the plane: cylinder m_c (L^2/12 + r^2/4) + two
+    // hemispheres 2*m_h*(83/320 r^2 + (L/2 + 3r/8)^2)
+    RL_HD static constexpr double inertia(int) { return 3.917566039026472; }
+    RL_HD static constexpr double armature(int) { return 0.0; }
+    RL_HD static constexpr double damping(int) { return 0.0; }
+    RL_HD static constexpr double stiffness(int) { return 0.0; }
+    RL_HD static constexpr bool limited(int i) { return i >= 1; }
+    RL_HD static constexpr double lo(int) { return -1.7453292519943295; }  // -100 deg
+    RL_HD static constexpr double hi(int) { return 1.7453292519943295; }
+    RL_HD static constexpr double limit_k() { return 1.0e4; }  // N m / rad beyond the range
+    RL_HD static constexpr double limit_b() { return 5.0e2; }  // N m s / rad while beyond
+    RL_HD static constexpr double gx() { return 0.0; }
+    RL_HD static constexpr double gy() { return 0.0; }  // gravity is normal to the plane
+
+    // equivalent inertia box of the capsule: bx = sqrt(6 (Iyy + Izz - Ixx) / m) along the
+    // axis, by = bz = sqrt(6 Ixx / m) across, with Ixx = m_c r^2/2 + 2/5 m_s r^2
+    static constexpr double BX = 1.1362476946200648, BY = 0.17115524428733953;
+    static constexpr double RHO = 4000.0, MU = 0.1;
+    static constexpr double DIAM = (BX + 2.0 * BY) / 3.0;
+    static constexpr double PI = 3.14159265358979323846;
+    static constexpr double VISC_LIN = 3.0 * PI * DIAM * MU;
+    static constexpr double VISC_ANG = PI * DIAM * DIAM * DIAM * MU;
+    static constexpr double DRAG_AX = 0.5 * RHO * BY * BY;        // along the capsule axis
+    static constexpr double DRAG_PERP = 0.5 * RHO * BX * BY;      // across it
+    static constexpr double DRAG_ANG = RHO * BY * (BX * BX * BX * BX + BY * BY * BY * BY) / 64.0;
+
+    template <typename R>
+    RL_HD static void external(const R* /*q*/, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {
+        RL_UNROLL
+        for (int i = 0; i < NB; ++i) {
+            // COM velocity in the body frame
+            const R vl = k.cs[i] * k.vpx[i] + k.sn[i] * k.vpy[i];
+            const R vt = -k.sn[i] * k.vpx[i] + k.cs[i] * k.vpy[i];
+            const R w = k.om[i];
+            const R fl = -(R)VISC_LIN * vl - (R)DRAG_AX * rl_abs(vl) * vl;
+            const R ft = -(R)VISC_LIN * vt - (R)DRAG_PERP * rl_abs(vt) * vt;
+            fx[i] = fx[i] + (k.cs[i] * fl - k.sn[i] * ft);
+            fy[i] = fy[i] + (k.sn[i] * fl + k.cs[i] * ft);
+            tz[i] = tz[i] - (R)VISC_ANG * w - (R)DRAG_ANG * rl_abs(w) * w;
+        }
+    }
+};
+
+struct Swimmer {
+    static constexpr int OBS = 13;
+    static constexpr int ACT = 2;
+    static constexpr int STATE = 10;
+    static constexpr int RESET_DRAWS = 10;  // N(0,1): 5 for qpos, 5 for qvel
+    static constexpr bool RESET_NORMAL = true;
+    static constexpr int KIND = 2;
+    static constexpr int FRAME_SKIP = 50;
+    using Tree = PlanarTree<SwimmerModel>;
+
+    template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
+        lb[0] = (R)-50; lb[1] = (R)-50;
+        ub[0] = (R)50; ub[1] = (R)50;
+    }
+
+    // MujocoEnv.reset_mujoco: qpos = init_qpos + 0.01*N(0,1), qvel = init_qvel + 0.1*N(0,1),
+    // init_qpos = init_qvel = 0 (mujoco_env.py:109-116)
+    template <typename R> RL_HD static void reset(R* s, const R* z) {
+        RL_UNROLL
+        for (int i = 0; i < 5; ++i) {
+            s[i] = z[i] * (R)0.01;
+            s[5 + i] = z[5 + i] * (R)0.1;
+        }
+    }
+
+    // obs = [qpos, qvel, com_subtree(torso)] (swimmer_env.py:25-30); the plane is z = 0
+    template <typename R> RL_HD static void observe(const R* s, R* o) {
+        R cx, cy, vx, vy;
+        Tree::template com<R>(s, s + 5, cx, cy, vx, vy);
+        RL_UNROLL
+        for (int i = 0; i < 10; ++i) o[i] = s[i];
+        o[10] = cx; o[11] = cy; o[12] = (R)0;
+    }
+
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+        const R lb = (R)-50, ub = (R)50;
+        R act[2], ctrl[3];
+        ctrl[0] = (R)0;
+        RL_UNROLL
+        for (int k = 0; k < 2; ++k) {
+            R v = a[k];
+            if (normalize) {
+                v = lb + (v + (R)1) * (R)0.5 * (ub - lb);
+                v = rl_clamp(v, lb, ub);
+            }
+            act[k] = v;
+            ctrl[1 + k] = rl_clamp(v, lb, ub);  // ctrllimited: MuJoCo clamps ctrl to ctrlrange
+        }
+        R q[5], qd[5];
+        RL_UNROLL
+        for (int i = 0; i < 5; ++i) { q[i] = s[i]; qd[i] = s[5 + i]; }
+        for (int it = 0; it < FRAME_SKIP; ++it) Tree::template substep<R>(q, qd, ctrl, (R)0.001);
+        RL_UNROLL
+        for (int i = 0; i < 5; ++i) { s[i] = q[i]; s[5 + i] = qd[i]; }
+        R cx, cy, vx, vy;
+        Tree::template com<R>(q, qd, cx, cy, vx, vy);
+        RL_UNROLL
+        for (int i = 0; i < 10; ++i) obs[i] = s[i];
+        obs[10] = cx; obs[11] = cy; obs[12] = (R)0;
+        // reward = comvel_x - 0.5 * 1e-2 * sum((action / scaling)^2), scaling = (ub - lb)/2
+        const R scaling = (ub - lb) * (R)0.5;
+        const R a0 = act[0] / scaling, a1 = act[1] / scaling;
+        const R ctrl_cost = (R)0.5 * (R)1e-2 * (a0 * a0 + a1 * a1);
+        reward = vx - ctrl_cost;
+        done = false;
+    }
+};
+
+}  // namespace rl

@@ -1,0 +1,57 @@
+"""MujocoEnv base (API of rllab/envs/mujoco/mujoco_env.py:36-238).
+
+The reference loads an MJCF into the proprietary MuJoCo 1.31 binary through ctypes
+(rllab/mujoco_py); importing this module needs no MuJoCo: each task's model is
+compiled into a HIP kernel (csrc/dyn_planar.h + dyn_<task>.h).  Options that change
+the simulated world are rejected loudly.
+"""
+from rllab_amd.envs.hip_env import HipEnv
+
+
+class MujocoEnv(HipEnv):
+    FILE = None
+
+    def __init__(self, action_noise=0.0, file_path=None, template_args=None):
+        unsupported = []
+        if action_noise != 0.0:
+            unsupported.append("action_noise")
+        if file_path is not None or template_args is not None:
+            unsupported.append("file_path/template_args")
+        if unsupported:
+            raise NotImplementedError(
+                "%s: options %s are not compiled into the HIP kernel of this env" %
+                (type(self).__name__, ", ".join(unsupported)))
+        self.action_noise = action_noise
+        HipEnv.__init__(self)
+
+    def _log_forward_progress(self, paths):
+        """Average/Max/Min/StdForwardProgress = obs[-1][-3] - obs[0][-3] per path
+        (swimmer_env.py:48-62, half_cheetah_env.py:48-56), computed on the device for
+        a dense batch."""
+        import numpy as np
+        import torch
+        from rllab_amd.misc import logger
+        from rllab_amd.sampler import dist as D
+        from rllab_amd.sampler.trajectories import PathList
+        if isinstance(paths, PathList):
+            env, t0, t1 = paths.index()
+            comx = paths.traj.obs[paths.traj.obs_dim - 3]
+            progs = (comx[t1, env] - comx[t0, env]).to(torch.float64)
+            n, s = D.sums(torch.as_tensor(float(progs.numel()), dtype=torch.float64, device=progs.device),
+                          progs.sum())
+            if float(n) > 0:
+                mean = s / n
+                (ss,) = D.sums(((progs - mean) ** 2).sum())
+                mx = D.all_reduce_max_(progs.max() if progs.numel() else torch.tensor(-np.inf, device=progs.device))
+                mn = D.all_reduce_min_(progs.min() if progs.numel() else torch.tensor(np.inf, device=progs.device))
+                vals = (float(mean), float(mx), float(mn), float(torch.sqrt(ss / n)))
+            else:
+                vals = (np.nan,) * 4
+        elif len(paths) > 0:
+            progs = [p["observations"][-1][-3] - p["observations"][0][-3] for p in paths]
+            vals = (np.mean(progs), np.max(progs), np.min(progs), np.std(progs))
+        else:
+            vals = (np.nan,) * 4
+        for k, v in zip(('AverageForwardProgress', 'MaxForwardProgress', 'MinForwardProgress',
+                         'StdForwardProgress'), vals):
+            logger.record_tabular(k, v)

@@ -1,0 +1,22 @@
+"""SwimmerEnv (API of rllab/envs/mujoco/swimmer_env.py:10-62); dynamics in
+csrc/dyn_swimmer.h (``rl::Swimmer``, a swimmer-style planar 3-link chain built from
+the constants of vendor/mujoco_models/swimmer.xml)."""
+from rllab_amd import _lib
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.envs.mujoco.mujoco_env import MujocoEnv
+
+
+class SwimmerEnv(MujocoEnv, Serializable):
+    FILE = 'swimmer.xml'
+    ORI_IND = 2
+    KIND = _lib.ENV_SWIMMER
+
+    def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
+        if ctrl_cost_coeff != 1e-2:
+            raise NotImplementedError("SwimmerEnv: ctrl_cost_coeff is compiled into the HIP kernel (1e-2)")
+        self.ctrl_cost_coeff = ctrl_cost_coeff
+        super(SwimmerEnv, self).__init__(*args, **kwargs)
+        Serializable.quick_init(self, locals())
+
+    def log_diagnostics(self, paths):
+        self._log_forward_progress(paths)

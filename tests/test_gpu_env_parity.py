@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV_KINDS = [0]
+ENV_KINDS = [0, 2]
 
 
 def _dev():
@@ -58,7 +58,7 @@ def test_vecenv_step_bit_exact(kind, normalize):
         assert np.array_equal(dg.cpu().numpy(), dc.astype(bool)), t
         assert np.array_equal(gpu.ts.cpu().numpy(), cpu.ts), t
         n_done += int(dc.sum())
-    assert n_done > 0  # the auto-reset branch was exercised
+    assert n_done > 0  # the auto-reset branch (env done or horizon) was exercised
 
 
 def _make_policy(kind, hidden=(32, 32), seed=0):
