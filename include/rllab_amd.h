@@ -19,6 +19,7 @@
 #ifndef RLLAB_AMD_H
 #define RLLAB_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -143,6 +144,46 @@ int rl_gae(int T, int n, const float* rewards, const double* values, const uint8
  * per column). */
 int rl_discount_cumsum(int T, int n, const float* x, const uint8_t* dones, double discount,
                        float* y, void* stream);
+
+/* One dense batch for the fused GaussianMLPPolicy update kernels.  Per-sample arrays
+ * are planes with the sample axis last (B = n_samples). */
+typedef struct rl_policy_batch {
+    int32_t n_samples;         /* B */
+    int32_t obs_dim, act_dim;  /* Do, Da */
+    int32_t hidden0, hidden1;  /* tanh MLP hidden sizes */
+    float inv_count;           /* 1 / (global number of valid samples) */
+    float log_min_std;         /* log_std floor */
+    const float* theta;        /* [P] flat params, reference layout (see rl_rollout_args.theta) */
+    const float* obs;          /* [Do][B] */
+    const float* actions;      /* [Da][B] */
+    const float* advantages;   /* [B] */
+    const float* old_means;    /* [Da][B]  agent_infos["mean"] */
+    const float* old_log_std;  /* [Da]     agent_infos["log_std"] (one constant row) */
+    const float* weights;      /* [B] 0/1 validity */
+} rl_policy_batch;
+
+/* Scratch the three calls below need (device memory, caller-owned, reusable). */
+size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1);
+
+/* out4 (device, 4 doubles) = [ sum_b w lr adv, sum_b w KL, sum_b w logp adv, max_b KL ] at theta:
+ * surrogate loss = -out4[0]*inv_count, mean KL = out4[1]*inv_count.  Replaces the compiled
+ * f_loss / f_constraint / f_loss_constraint of ConjugateGradientOptimizer
+ * (rllab/optimizers/conjugate_gradient_optimizer.py:194-215) on NPO's surr_loss / mean_kl
+ * (rllab/algos/npo.py:72-82) and VPG's f_kl (rllab/algos/vpg.py:100-107). */
+int rl_policy_loss_kl(const rl_policy_batch* batch, void* workspace, size_t workspace_bytes,
+                      double* out4, void* stream);
+
+/* grad_out (device, P doubles) = d/dtheta of -sum_b w lr adv * inv_count (vpg == 0, f_grad of
+ * conjugate_gradient_optimizer.py:199-203) or of -sum_b w logp adv * inv_count (vpg != 0,
+ * rllab/algos/vpg.py:91 through FirstOrderOptimizer, first_order_optimizer.py:63-65). */
+int rl_policy_grad(const rl_policy_batch* batch, int vpg, void* workspace, size_t workspace_bytes,
+                   double* grad_out, void* stream);
+
+/* fvp_out (device, P doubles) = Fisher-vector product of the mean KL with `vec` [P] at
+ * theta_new == theta_old, WITHOUT the reg_coeff*vec term.  Replaces f_Hx_plain of PerlmutterHvp
+ * (conjugate_gradient_optimizer.py:27-46).  Uses obs, weights, inv_count, theta only. */
+int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspace,
+                  size_t workspace_bytes, double* fvp_out, void* stream);
 
 /* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
  * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */

@@ -23,7 +23,8 @@ ENV_HALF_CHEETAH = 3
 SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_rollout_gaussian_mlp", "rl_gae",
-    "rl_discount_cumsum", "rl_debug_philox",
+    "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_loss_kl",
+    "rl_policy_grad", "rl_policy_fvp",
 ]
 
 
@@ -39,6 +40,17 @@ class RolloutArgs(ctypes.Structure):
         ("eps", ctypes.c_void_p), ("reset_draws", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("means", ctypes.c_void_p), ("rewards", ctypes.c_void_p),
         ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p),
+    ]
+
+
+class PolicyBatch(ctypes.Structure):
+    """Mirror of ``rl_policy_batch`` (include/rllab_amd.h)."""
+    _fields_ = [
+        ("n_samples", ctypes.c_int32), ("obs_dim", ctypes.c_int32), ("act_dim", ctypes.c_int32),
+        ("hidden0", ctypes.c_int32), ("hidden1", ctypes.c_int32), ("inv_count", ctypes.c_float),
+        ("log_min_std", ctypes.c_float), ("theta", ctypes.c_void_p), ("obs", ctypes.c_void_p),
+        ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
+        ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p),
     ]
 
 
@@ -63,6 +75,12 @@ def _load():
     lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp]
     lib.rl_discount_cumsum.argtypes = [i32, i32, vp, vp, f64, vp, vp]
     lib.rl_debug_philox.argtypes = [u32, u32, u32, u32, u32, u32, i32, vp, vp]
+    pb = ctypes.POINTER(PolicyBatch)
+    lib.rl_policy_workspace_bytes.restype = ctypes.c_size_t
+    lib.rl_policy_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.rl_policy_loss_kl.argtypes = [pb, vp, ctypes.c_size_t, vp, vp]
+    lib.rl_policy_grad.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp]
+    lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = header / library mismatch
     return lib

@@ -65,7 +65,7 @@ class NPO(BatchPolopt):
             return (kl * w).sum() * inv_count.to(kl.dtype)
 
         fused = None
-        if trunc is None and hasattr(policy, "fused_ops"):
+        if trunc is None and hasattr(policy, "fused_ops") and getattr(self, "use_fused", True):
             fused = policy.fused_ops()
         self.optimizer.update_opt(loss=surr_loss, target=policy, leq_constraint=(mean_kl, self.step_size),
                                   inputs=None, constraint_name="mean_kl", fused=fused)

@@ -46,7 +46,12 @@ class VPG(BatchPolopt, Serializable):
                 max_kl = D.all_reduce_max_(torch.where(w > 0, kl, neg).max().to(torch.float64))
             return float(mean_kl), float(max_kl)
 
-        self.optimizer.update_opt(surr_obj, target=policy, inputs=None)
+        fused = policy.fused_ops() if hasattr(policy, "fused_ops") and getattr(self, "use_fused", True) else None
+        if fused is not None:
+            def f_kl(inputs):  # noqa: F811  (HIP kernel version of the same statistic)
+                s = fused.loss_stats(inputs)
+                return float(s[1]), float(s[3])
+        self.optimizer.update_opt(surr_obj, target=policy, inputs=None, fused=fused)
         self.opt_info = dict(f_kl=f_kl)
 
     def optimize_policy(self, itr, samples_data):

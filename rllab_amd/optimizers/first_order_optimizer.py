@@ -72,18 +72,24 @@ class FirstOrderOptimizer(Serializable):
         self._target = target
         self._loss = loss
         self._updater = self._update_factory()
+        self._fused = kwargs.get("fused")
 
     def loss(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if getattr(self, "_fused", None) is not None:
+            return float(-self._fused.loss_stats(inputs)[2])
         with torch.no_grad():
             v = self._loss(self._target.flat_params, *inputs).to(torch.float64)
         return float(D.all_reduce_sum_(v))
 
     def _step(self, inputs):
         target = self._target
-        flat = target.flat_params.detach().clone().requires_grad_(True)
-        g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
-        g = D.all_reduce_sum_(g.to(torch.float64))
+        if getattr(self, "_fused", None) is not None:
+            g = self._fused.loss_grad(inputs, vpg=True)
+        else:
+            flat = target.flat_params.detach().clone().requires_grad_(True)
+            g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
+            g = D.all_reduce_sum_(g.to(torch.float64))
         idx = target._flat_index(trainable=True)
         theta = target.flat_params.detach().to(torch.float64)
         if idx is not None:

@@ -156,3 +156,11 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
     @property
     def distribution(self):
         return self._dist
+
+    def fused_ops(self):
+        """HIP-kernel loss / gradient / Fisher-vector product (policies/fused_ops.py), or
+        None when this policy has no fused kernel (then torch autograd is used)."""
+        from rllab_amd.policies.fused_ops import FusedGaussianMLPOps
+        if not FusedGaussianMLPOps.supported(self):
+            return None
+        return FusedGaussianMLPOps(self)
