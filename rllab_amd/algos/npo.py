@@ -23,9 +23,10 @@ def npo_inputs(policy, samples_data):
     B = traj.B
     w = traj.valid.reshape(B).to(torch.float32)
     cnt = D.all_reduce_sum_(w.to(torch.float64).sum())
+    old_ls = traj.log_std.reshape(-1, 1) if traj.log_std_planes is None \
+        else traj.log_std_planes.reshape(traj.act_dim, B)
     return (traj.obs.reshape(traj.obs_dim, B), traj.actions.reshape(traj.act_dim, B),
-            traj.advantages.reshape(B), traj.means.reshape(traj.act_dim, B),
-            traj.log_std.reshape(-1, 1), w, (1.0 / cnt))
+            traj.advantages.reshape(B), traj.means.reshape(traj.act_dim, B), old_ls, w, (1.0 / cnt))
 
 
 class NPO(BatchPolopt):

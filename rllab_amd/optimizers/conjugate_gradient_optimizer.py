@@ -155,25 +155,29 @@ class ConjugateGradientOptimizer(Serializable):
             v = fn(self._target.flat_params, *inputs).to(torch.float64)
         return D.all_reduce_sum_(v)
 
+    def _fused_for(self, inputs):
+        f = self._fused
+        return f if (f is not None and f.accepts(inputs)) else None
+
     def loss(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
-        if self._fused is not None:
+        if self._fused_for(inputs) is not None:
             return float(self._fused.loss_and_kl(inputs)[0])
         return float(self._eval_scalar(self._loss, inputs))
 
     def constraint_val(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
-        if self._fused is not None:
+        if self._fused_for(inputs) is not None:
             return float(self._fused.loss_and_kl(inputs)[1])
         return float(self._eval_scalar(self._constraint, inputs))
 
     def _loss_constraint(self, inputs):
-        if self._fused is not None:
+        if self._fused_for(inputs) is not None:
             return self._fused.loss_and_kl(inputs)
         return (self._eval_scalar(self._loss, inputs), self._eval_scalar(self._constraint, inputs))
 
     def _flat_grad(self, inputs):
-        if self._fused is not None:
+        if self._fused_for(inputs) is not None:
             g = self._fused.loss_grad(inputs)
         else:
             flat = _flat_for_grad(self._target)
@@ -208,7 +212,11 @@ class ConjugateGradientOptimizer(Serializable):
         logger.log("performing update")
         logger.log("computing descent direction")
         flat_g = self._flat_grad(inputs)
-        Hx = self._hvp_approach.build_eval(subsample_inputs, idx)
+        hvp = self._hvp_approach
+        if self._fused is not None and not self._hvp_given and self._fused_for(inputs) is None:
+            hvp = PerlmutterHvp(self._num_slices)   # batch the fused kernels cannot take
+            hvp.update_opt(f=self._constraint, target=target, inputs=None, reg_coeff=self._reg_coeff)
+        Hx = hvp.build_eval(subsample_inputs, idx)
         descent_direction = krylov.cg(Hx, flat_g, cg_iters=self._cg_iters)
         initial_step_size = torch.sqrt(
             2.0 * self._max_constraint_val * (1. / (descent_direction.dot(Hx(descent_direction)) + 1e-8)))

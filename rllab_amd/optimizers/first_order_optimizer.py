@@ -76,7 +76,7 @@ class FirstOrderOptimizer(Serializable):
 
     def loss(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
-        if getattr(self, "_fused", None) is not None:
+        if getattr(self, "_fused", None) is not None and self._fused.accepts(inputs):
             return float(-self._fused.loss_stats(inputs)[2])
         with torch.no_grad():
             v = self._loss(self._target.flat_params, *inputs).to(torch.float64)
@@ -84,7 +84,7 @@ class FirstOrderOptimizer(Serializable):
 
     def _step(self, inputs):
         target = self._target
-        if getattr(self, "_fused", None) is not None:
+        if getattr(self, "_fused", None) is not None and self._fused.accepts(inputs):
             g = self._fused.loss_grad(inputs, vpg=True)
         else:
             flat = target.flat_params.detach().clone().requires_grad_(True)

@@ -31,6 +31,10 @@ class FusedGaussianMLPOps(object):
                 and policy.flat_params.is_cuda and policy.learn_std
                 and (policy.obs_dim, policy.action_dim) in ((4, 1), (6, 1), (13, 2), (20, 6)))
 
+    def accepts(self, inputs):
+        """The kernels take ONE old log_std row (state-independent std)."""
+        return inputs[4].numel() == self.dims[1] and inputs[0].is_cuda
+
     def _workspace(self, device):
         if self._ws is None or self._ws.device != device:
             n = _lib.lib.rl_policy_workspace_bytes(*self.dims)

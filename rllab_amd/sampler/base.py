@@ -69,7 +69,8 @@ class SamplesData(dict):
             val = vec(tr.advantages)
         elif key == "agent_infos":
             mean = rows(tr.means)
-            val = dict(mean=mean, log_std=tr.log_std.unsqueeze(0).expand_as(mean))
+            val = dict(mean=mean, log_std=rows(tr.log_std_planes) if tr.log_std_planes is not None
+                       else tr.log_std.unsqueeze(0).expand_as(mean))
         else:
             val = dict()
         self[key] = val
@@ -147,8 +148,16 @@ def process_dense(algo, itr, traj, log=True):
     mx = D.all_reduce_max_(undisc.max() if undisc.numel() else -inf)
     mn = D.all_reduce_min_(undisc.min() if undisc.numel() else inf)
 
-    ent = float(algo.policy.distribution.entropy_sym(dict(log_std=traj.log_std.to(torch.float64)), axis=0)) \
-        if hasattr(algo.policy.distribution, "entropy_sym") and traj.log_std is not None else float("nan")
+    # Entropy = mean over samples of the policy entropy (reference :93)
+    pdist = algo.policy.distribution
+    if traj.log_std_planes is not None and hasattr(pdist, "entropy_sym"):
+        e = pdist.entropy_sym(dict(log_std=traj.log_std_planes.to(torch.float64)), axis=0)
+        (es,) = D.sums((e * w).sum())
+        ent = float(es / cnt)
+    elif traj.log_std is not None and hasattr(pdist, "entropy_sym"):
+        ent = float(pdist.entropy_sym(dict(log_std=traj.log_std.to(torch.float64)), axis=0))
+    else:
+        ent = float("nan")
 
     samples_data = SamplesData(_traj=traj, paths=paths)
 
@@ -202,6 +211,8 @@ def pack_paths(paths, device=None):
     done = np.zeros((T, n), np.uint8)
     valid = np.zeros((T, n), bool)
     log_std = None
+    ls_planes = np.zeros((da, T, n), np.float32)
+    ls_const = True
     for i, p in enumerate(paths):
         L = lens[i]
         obs[:, :L, i] = np.asarray(p["observations"]).reshape(L, -1).T
@@ -210,14 +221,19 @@ def pack_paths(paths, device=None):
         ai = p.get("agent_infos", {})
         if "mean" in ai:
             mean[:, :L, i] = np.asarray(ai["mean"]).reshape(L, -1).T
-        if log_std is None and "log_std" in ai:
-            log_std = np.asarray(ai["log_std"]).reshape(L, -1)[0]
+        if "log_std" in ai:
+            ls = np.asarray(ai["log_std"]).reshape(L, -1)
+            ls_planes[:, :L, i] = ls.T
+            if log_std is None:
+                log_std = ls[0]
+            ls_const = ls_const and bool(np.all(ls == log_std[None, :]))
         done[L - 1:, i] = 1
         valid[:L, i] = True
     t = lambda x: torch.as_tensor(x, device=device)
     traj = Trajectories(t(obs), t(act), t(mean),
                         t(log_std.astype(np.float32)) if log_std is not None else None,
-                        t(rew), t(done), T)
+                        t(rew), t(done), T,
+                        log_std_planes=None if (ls_const or log_std is None) else t(ls_planes))
     traj.valid = t(valid)
     return traj
 

@@ -19,9 +19,12 @@ import torch
 
 
 class Trajectories(object):
-    def __init__(self, obs, actions, means, log_std, rewards, dones, max_path_length):
+    def __init__(self, obs, actions, means, log_std, rewards, dones, max_path_length, log_std_planes=None):
         self.obs, self.actions, self.means = obs, actions, means
         self.log_std, self.rewards, self.dones = log_std, rewards, dones
+        # [Da, T, N] per-sample log_std, only for batches packed from arbitrary user paths whose
+        # policy does not have a state-independent log_std (None for engine rollouts)
+        self.log_std_planes = log_std_planes
         self.max_path_length = max_path_length
         self.T, self.N = rewards.shape
         self.obs_dim, self.act_dim = obs.shape[0], actions.shape[0]
@@ -131,7 +134,8 @@ class PathList(object):
             actions=f64(tr.actions[:, a:b, n].t()),
             rewards=f64(tr.rewards[a:b, n]),
             agent_infos=dict(mean=f64(tr.means[:, a:b, n].t()),
-                             log_std=np.tile(f64(tr.log_std)[None, :], (L, 1))),
+                             log_std=(f64(tr.log_std_planes[:, a:b, n].t()) if tr.log_std_planes is not None
+                                      else np.tile(f64(tr.log_std)[None, :], (L, 1)))),
             env_infos=dict(),
         )
         if tr.advantages is not None:

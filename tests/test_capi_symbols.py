@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/rllab_amd.h
+declares; argument errors come back as status codes + rl_last_error (no compute)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rllab_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    from rllab_amd import _lib
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
+    assert sorted(_lib.SYMBOLS) == names
+    assert _lib.lib.rl_abi_version() == 1
+
+
+def test_env_query_and_errors():
+    from rllab_amd import _lib
+    assert _lib.env_query(_lib.ENV_CARTPOLE) == dict(obs_dim=4, act_dim=1, state_dim=16, reset_draws=4,
+                                                     reset_is_normal=False)
+    assert _lib.env_query(_lib.ENV_SWIMMER) == dict(obs_dim=13, act_dim=2, state_dim=10, reset_draws=10,
+                                                    reset_is_normal=True)
+    lb, ub = _lib.env_action_bounds(_lib.ENV_SWIMMER)
+    assert list(lb) == [-50, -50] and list(ub) == [50, 50]
+    assert _lib.lib.rl_env_query(99, None, None, None, None, None) == -1
+    assert b"env kind 99" in _lib.lib.rl_last_error()
+    assert _lib.lib.rl_vecenv_reset(0, 0, None, None, None, None, 0, 0, 0, None, None) == -1
+    assert _lib.lib.rl_gae(0, 0, None, None, None, 0.99, 1.0, None, None, None) == -1
+    assert _lib.lib.rl_rollout_gaussian_mlp(None, None) == -1
+    assert _lib.lib.rl_policy_fvp(None, None, None, 0, None, None) == -1
+    assert _lib.lib.rl_policy_workspace_bytes(13, 2, 32, 32) > 0
+
+
+def test_structs_match_header_layout():
+    """ctypes mirrors have the field order / count of the C structs."""
+    from rllab_amd import _lib
+    text = open(os.path.join(ROOT, "include", "rllab_amd.h")).read()
+    for cname, cls in (("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            first = names[0].split()[-1].lstrip("*")
+            fields.append(first)
+            fields += [n.strip().lstrip("*") for n in names[1:]]
+        assert fields == [f[0] for f in cls._fields_], (cname, fields)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: no module of the product may reference it."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "rllab_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or '#include "../../oracle' in src:
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

@@ -1,0 +1,298 @@
+"""Host-side logic of the product on CPU tensors (no kernel launches): API seams,
+parameter layout, optimizer control flow against the golden fixtures of the real
+reference."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load
+
+
+def _spec(do, da):
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.spaces import Box
+    return EnvSpec(Box(-np.ones(do), np.ones(do)), Box(-np.ones(da), np.ones(da)))
+
+
+def test_rllab_alias_is_same_module():
+    import rllab.algos.trpo as a
+    import rllab_amd.algos.trpo as b
+    from rllab.envs.normalized_env import normalize
+    from rllab_amd.envs.normalized_env import NormalizedEnv
+    assert a is b and normalize is NormalizedEnv
+    # every import path used by examples/trpo_cartpole.py and examples/trpo_swimmer.py
+    from rllab.algos.trpo import TRPO  # noqa: F401
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline  # noqa: F401
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv  # noqa: F401
+    from rllab.envs.mujoco.swimmer_env import SwimmerEnv  # noqa: F401
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy  # noqa: F401
+
+
+def test_policy_flat_layout_matches_reference_flatten_tensors():
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    g = load("flat_params")
+    pol = GaussianMLPPolicy(_spec(4, 1), hidden_sizes=(32, 32))
+    assert [p.shape for p in pol.get_params(trainable=True)] == [(4, 32), (32,), (32, 32), (32,), (32, 1), (1,), (1,)]
+    pol.set_param_values(g["flat"])
+    for p, key in zip(pol.get_params(), ["W0", "b0", "W1", "b1", "W2", "b2", "log_std"]):
+        assert np.allclose(p.get_value(), g[key], atol=1e-7)
+    assert pol.get_param_values().shape == (1250,)
+    vals = pol.flat_to_params(g["flat"], trainable=True)
+    assert np.array_equal(vals[2], g["W1"])
+    # forward against the numpy oracle policy with the same flat vector
+    from oracle import np_reference as R
+    ref = R.NumpyGaussianMLP(4, 1, (32, 32))
+    ref.set_param_values(g["flat"])
+    obs = np.random.RandomState(0).randn(17, 4)
+    mean, log_std = ref.dist_info(obs)
+    d = pol.dist_info(obs)
+    assert np.allclose(d["mean"], mean, atol=2e-6) and np.allclose(d["log_std"], log_std, atol=1e-7)
+
+
+def test_policy_init_and_pickle_roundtrip():
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    np.random.seed(3)
+    pol = GaussianMLPPolicy(_spec(13, 2), hidden_sizes=(32, 32), init_std=0.5)
+    th = pol.get_param_values()
+    assert th.shape == (1572,)
+    W0 = th[:13 * 32]
+    assert np.abs(W0).max() <= np.sqrt(6.0 / (13 + 32)) + 1e-6          # Glorot-uniform bound
+    assert np.allclose(th[13 * 32:13 * 32 + 32], 0) and np.allclose(th[-2:], np.log(0.5))
+    clone = pickle.loads(pickle.dumps(pol))
+    assert np.array_equal(clone.get_param_values(), th)
+    # learn_std=False removes log_std from the trainable set (Lasagne tag semantics)
+    fixed = GaussianMLPPolicy(_spec(13, 2), learn_std=False)
+    assert fixed.get_param_values(trainable=True).shape == (1570,)
+    fixed.set_param_values(np.ones(1570), trainable=True)
+    assert np.allclose(fixed.get_param_values()[:1570], 1) and np.allclose(fixed.get_param_values()[1570:], 0)
+    # entropy of the initial policy: 0.5*ln(2 pi e) per dim (docs/user/experiments.rst:81)
+    unit = GaussianMLPPolicy(_spec(4, 1))
+    ent = unit.distribution.entropy(dict(log_std=unit.dist_info(np.zeros((1, 4)))["log_std"]))
+    assert np.isclose(ent[0], 1.41894, atol=1e-5)
+
+
+def test_serializable_clone_and_spaces():
+    from rllab_amd.core.serializable import Serializable
+    from rllab_amd.envs.normalized_env import NormalizedEnv
+    from rllab_amd.spaces import Box
+
+    class E(object):
+        observation_space = Box(-np.ones(3), np.ones(3))
+        action_space = Box(np.array([-2.0]), np.array([4.0]))
+    ne = NormalizedEnv(E(), scale_reward=0.5)
+    c = Serializable.clone(ne, scale_reward=2.0)
+    assert c._scale_reward == 2.0 and ne._scale_reward == 0.5
+    b = Box(-1.0, 1.0, (3, 4))
+    assert b.flat_dim == 12 and b.flatten(np.zeros((3, 4))).shape == (12,)
+    assert b.flatten_n(np.zeros((5, 3, 4))).shape == (5, 12) and b.unflatten_n(np.zeros((5, 12))).shape == (5, 3, 4)
+    assert b.contains(np.zeros((3, 4))) and not b.contains(2 * np.ones((3, 4)))
+    assert ne.action_space == Box(-np.ones(1), np.ones(1))
+
+
+def test_normalized_env_numpy_path_vs_reference():
+    from rllab_amd.envs.base import Env, Step
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.spaces import Box
+    g = load("normalized_env")
+
+    class E(Env):
+        action_space = Box(g["lb"], g["ub"])
+        observation_space = Box(-np.ones(3), np.ones(3))
+
+        def reset(self):
+            return np.zeros(3)
+
+        def step(self, a):
+            self.last = np.array(a)
+            return Step(np.zeros(3), 2.5, False)
+    e = E()
+    ne = normalize(e, scale_reward=0.1)
+    for a, want, r in zip(g["acts"], g["scaled"], g["rews"]):
+        _, rew, _, _ = ne.step(a)
+        assert np.allclose(e.last, want) and np.isclose(rew, r)
+    assert not ne.vectorized
+
+
+def test_diagonal_gaussian_and_krylov_torch_vs_reference():
+    from rllab_amd.distributions.diagonal_gaussian import DiagonalGaussian
+    from rllab_amd.misc import krylov
+    g = load("diagonal_gaussian")
+    d = DiagonalGaussian(3)
+    assert np.allclose(d.kl(dict(mean=g["om"], log_std=g["ols"]), dict(mean=g["nm"], log_std=g["nls"])), g["kl"])
+    assert np.allclose(d.log_likelihood(g["xs"], dict(mean=g["nm"], log_std=g["nls"])), g["logli"])
+    assert np.allclose(d.entropy(dict(mean=g["nm"], log_std=g["nls"])), g["entropy"])
+    # planes layout (axis=0) gives the same numbers
+    t = lambda x: torch.as_tensor(x.T.copy())
+    kl0 = d.kl_sym(dict(mean=t(g["om"]), log_std=t(g["ols"])), dict(mean=t(g["nm"]), log_std=t(g["nls"])), axis=0)
+    assert np.allclose(kl0.numpy(), g["kl"])
+    k = load("krylov_cg")
+    A = torch.as_tensor(k["A"])
+    assert np.allclose(krylov.cg(lambda v: A @ v, k["b"], cg_iters=10).numpy(), k["x10"], rtol=1e-9)
+    assert np.allclose(krylov.cg(lambda v: A @ v, k["b"], cg_iters=3).numpy(), k["x3"], rtol=1e-9)
+    # early-exit branch (rdotr < 1e-10 after one iteration) realised by the `active` flag
+    assert np.allclose(krylov.cg(lambda v: 4.0 * v, k["b"], cg_iters=10).numpy(), k["x_early"], rtol=1e-12)
+
+
+class _Quad(object):
+    """Minimal Parameterized stand-in: a flat float64 vector on the CPU."""
+
+    def __init__(self, theta):
+        self.flat_params = torch.tensor(theta, dtype=torch.float64)
+
+    def _flat_index(self, **tags):
+        return None
+
+    def get_param_values(self, **tags):
+        return self.flat_params.numpy().copy()
+
+    def set_param_values(self, v, **tags):
+        self.flat_params.copy_(torch.as_tensor(np.asarray(v), dtype=torch.float64))
+
+
+@pytest.mark.parametrize("tag", ["easy", "backtrack", "reject"])
+def test_cg_optimizer_control_flow_vs_reference(tag, quiet_logger):
+    """ConjugateGradientOptimizer.optimize (device CG, torch closures) reproduces the parameter
+    vector the REAL reference optimizer produced on the same toy problem."""
+    from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+    g = load("cg_optimizer")
+    Hm, Cm, gvec = (torch.as_tensor(g[k]) for k in ("Hm", "Cm", "gvec"))
+    theta0 = torch.as_tensor(g["theta0_" + tag])
+    quartic, delta = float(g["quartic_" + tag]), float(g["delta_" + tag])
+
+    def loss(flat, dummy):
+        d = flat - theta0
+        if quartic < 0:
+            # value never improves, gradient is the reference's injected gvec
+            return (gvec.dot(d)) ** 2 + 1.0 + (gvec.dot(d) - gvec.dot(d).detach())
+        return gvec.dot(d) + 0.5 * d @ Hm @ d + quartic * (d ** 4).sum()
+
+    def cons(flat, dummy):
+        d = flat - theta0
+        return 0.5 * d @ Cm @ d
+    target = _Quad(g["theta0_" + tag])
+    opt = ConjugateGradientOptimizer()
+    opt.update_opt(loss=loss, target=target, leq_constraint=(cons, delta), inputs=None)
+    opt.optimize((torch.zeros(4, 1),))
+    assert np.allclose(target.get_param_values(), g["theta1_" + tag], rtol=1e-8, atol=1e-10)
+
+
+def test_first_order_optimizer_lasagne_adam_step(quiet_logger):
+    from rllab_amd.optimizers.first_order_optimizer import FirstOrderOptimizer
+    theta0 = np.array([1.0, -2.0, 0.5])
+    target = _Quad(theta0)
+    c = torch.tensor([3.0, -1.0, 2.0], dtype=torch.float64)
+    opt = FirstOrderOptimizer(batch_size=None, max_epochs=1, learning_rate=1e-3)
+    opt.update_opt(lambda flat, x: (c * flat).sum() + 0.0 * x.sum(), target=target)
+    x = torch.zeros(1, 5, dtype=torch.float64)
+    opt.optimize((x,))
+    # first Adam step: m = 0.1 g, v = 0.001 g^2, a_1 = lr*sqrt(1-b2)/(1-b1) => step = lr * g/(|g| + eps')
+    g = c.numpy()
+    a1 = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    want = theta0 - a1 * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+    assert np.allclose(target.get_param_values(), want, rtol=1e-12)
+    opt.optimize((x,))  # moments persist across calls (vpg: created once in update_opt)
+    assert opt._updater.t == 2
+
+
+def test_trajectories_segmentation_and_pathlist_cpu():
+    from rllab_amd.sampler.trajectories import PathList, Trajectories
+    T, N = 6, 3
+    done = torch.zeros(T, N, dtype=torch.uint8)
+    done[1, 0] = 1          # env 0: paths [0,1], [2..5] (incomplete)
+    done[5, 1] = 1          # env 1: one complete path
+    done[0, 2] = 1
+    done[3, 2] = 1          # env 2: [0], [1..3], [4,5] (incomplete)
+    obs = torch.arange(2 * T * N, dtype=torch.float32).reshape(2, T, N)
+    act = torch.zeros(1, T, N)
+    tr = Trajectories(obs, act, act.clone(), torch.zeros(1), torch.ones(T, N), done, 6)
+    env, t0, t1, complete = tr.segments()
+    assert list(zip(env.tolist(), t0.tolist(), t1.tolist(), complete.tolist())) == [
+        (0, 0, 1, True), (0, 2, 5, False), (1, 0, 5, True), (2, 0, 0, True), (2, 1, 3, True), (2, 4, 5, False)]
+    assert tr.time_in_path()[:, 2].tolist() == [0, 0, 1, 2, 0, 1]
+    v = tr.valid_mask(whole_paths=True)
+    assert v[:, 0].tolist() == [True, True, False, False, False, False]
+    assert v[:, 1].all() and v[:, 2].tolist() == [True, True, True, True, False, False]
+    assert tr.valid_mask(whole_paths=False).all()
+    tr.valid = v
+    paths = PathList(tr)
+    assert len(paths) == 4
+    p = paths[3]
+    assert p["observations"].shape == (3, 2) and p["rewards"].shape == (3,)
+    assert np.array_equal(p["observations"][:, 0], obs[0, 1:4, 2].numpy())
+    assert [len(q["rewards"]) for q in paths] == [2, 6, 1, 3]
+
+
+def test_rollout_and_truncate_paths_generic_env():
+    """rollout() / truncate_paths keep the reference semantics for arbitrary Python envs
+    (tests/test_sampler.py of the reference)."""
+    from rllab_amd.envs.base import Env, Step
+    from rllab_amd.sampler.utils import rollout, truncate_paths
+    from rllab_amd.spaces import Box
+    g = load("truncate_paths")
+
+    class Count(Env):
+        observation_space = Box(-np.ones(1), np.ones(1))
+        action_space = Box(-np.ones(1), np.ones(1))
+
+        def reset(self):
+            self.t = 0
+            return np.zeros(1)
+
+        def step(self, a):
+            self.t += 1
+            return Step(np.array([self.t / 10.0]), 1.0, self.t >= 7, k=self.t)
+
+    class Pol(object):
+        def reset(self):
+            pass
+
+        def get_action(self, o):
+            return np.array([0.5]), dict(mean=np.zeros(1), log_std=np.zeros(1))
+    p = rollout(Count(), Pol(), max_path_length=100)
+    assert len(p["rewards"]) == 7 and p["observations"].shape == (7, 1) and p["env_infos"]["k"].tolist() == list(range(1, 8))
+    assert len(rollout(Count(), Pol(), max_path_length=3)["rewards"]) == 3
+    mk = lambda n: dict(observations=np.zeros((n, 1)), actions=np.zeros((n, 1)), rewards=np.zeros(n),
+                        env_infos=dict(), agent_infos=dict(lala=np.zeros(n)))
+    paths = [mk(100), mk(50)]
+    assert [len(q["rewards"]) for q in truncate_paths(paths, 130)] == list(g["lens130"])
+    assert [len(q["rewards"]) for q in truncate_paths(paths, 90)] == list(g["lens90"])
+    assert len(paths[-1]["rewards"]) == 50
+
+
+def test_logger_tabular_and_csv(tmp_path):
+    from rllab_amd.misc import logger
+    logger.set_quiet(True)
+    f = str(tmp_path / "progress.csv")
+    logger.add_tabular_output(f)
+    logger.record_tabular("Iteration", 0)
+    logger.record_tabular("AverageReturn", 1.5)
+    with logger.prefix("itr #0 | "):
+        logger.log("hello")
+    logger.dump_tabular()
+    logger.record_tabular("Iteration", 1)
+    logger.record_tabular("AverageReturn", 2.5)
+    logger.dump_tabular()
+    logger.remove_tabular_output(f)
+    logger.set_quiet(False)
+    assert open(f).read().splitlines() == ["Iteration,AverageReturn", "0,1.5", "1,2.5"]
+
+
+def test_unsupported_options_fail_loudly():
+    from rllab_amd.algos.npo import NPO
+    from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    with pytest.raises(NotImplementedError):
+        CartpoleEnv(obs_noise=0.1)
+    with pytest.raises(NotImplementedError):
+        SwimmerEnv(action_noise=0.1)
+    with pytest.raises(NotImplementedError):
+        GaussianMLPPolicy(_spec(4, 1), adaptive_std=True)
+    with pytest.raises(NotImplementedError):
+        NPO(env=None, policy=None, baseline=None)
+    if not torch.cuda.is_available():
+        env = CartpoleEnv()
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            env.reset()  # no CPU fallback for env kernels
