@@ -14,7 +14,7 @@
 // MuJoCo 1.31 (third party, absent) and its tests hold no golden vectors for it
 //  => env dynamics are "parity unpinned" against the reference.
 //
-// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -mfma).
+// Build: see oracle/Makefile (the ROCm clang++, -O2 -ffp-contract=on -mfma).
 #include <stdint.h>
 #include <string.h>
 

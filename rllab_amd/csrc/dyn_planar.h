@@ -178,7 +178,7 @@ struct PlanarTree {
         }
         // --- solve M qacc = rhs by LDL^T on the lower triangle ------------------------
         // (entries Mm[r][c], r >= c; unrelated hinge pairs stay 0)
-        R Dg[NV];
+        R Dg[NV], Di[NV];   // D and 1/D of M = L D L^T
         RL_UNROLL
         for (int c = 0; c < NV; ++c) {
             R d = Mm[c][c];
@@ -186,6 +186,7 @@ struct PlanarTree {
             for (int t = 0; t < c; ++t) d = d - Mm[c][t] * Mm[c][t] * Dg[t];
             Dg[c] = d;
             const R inv = (R)1 / d;
+            Di[c] = inv;
             RL_UNROLL
             for (int r = c + 1; r < NV; ++r) {
                 R v = Mm[r][c];
@@ -202,7 +203,7 @@ struct PlanarTree {
             qacc[r] = v;
         }
         RL_UNROLL
-        for (int r = 0; r < NV; ++r) qacc[r] = qacc[r] / Dg[r];
+        for (int r = 0; r < NV; ++r) qacc[r] = qacc[r] * Di[r];
         RL_UNROLL
         for (int r = NV - 1; r >= 0; --r) {
             R v = qacc[r];

@@ -4,8 +4,8 @@
 // touched only for the SoA state planes (coalesced: lane i <-> env i) and for the
 // trajectory planes.  Envs never talk to each other, so there is no LDS traffic
 // besides the policy weights and no inter-workgroup synchronisation at all.
-// Build with -ffp-contract=off: the env arithmetic must match the host oracle
-// build bit for bit (rl_math.h); the policy MLP uses explicit FMAs.
+// Build with -ffp-contract=on (front-end contraction): the env arithmetic must match
+// the host oracle build bit for bit (rl_math.h); the policy MLP uses explicit FMAs.
 #include <hip/hip_runtime.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"

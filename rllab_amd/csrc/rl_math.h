@@ -1,12 +1,16 @@
 // rl_math.h -- arithmetic primitives shared by every env dynamics header.
 //
 // Everything in the env step path must produce the same bits when the header is
-// compiled by hipcc for gfx950 and by g++ for the host oracle build
+// compiled by hipcc for gfx950 and by the same clang for the x86 host oracle build
 // (oracle/env_host.cpp).  That rules out libm / ocml transcendentals (their
-// last-ulp behaviour differs), implicit FMA contraction (both builds use
-// -ffp-contract=off) and anything order-dependent.  What is left is IEEE-754
-// +,-,*,/ and sqrt (correctly rounded on both targets), float<->int conversion
-// and explicit rl_fma (one rounding on both targets).
+// last-ulp behaviour differs) and anything order-dependent.  Both builds use
+// -ffp-contract=on: the clang FRONTEND fuses a*b+c inside one expression into
+// llvm.fmuladd at the same source sites for both targets, and both back-ends lower
+// it to a hardware FMA (v_fma_f32 / vfmadd, one rounding), so contraction is
+// deterministic across the two builds -- unlike -ffp-contract=fast, where each
+// back-end picks its own fusion sites.  What is left is IEEE-754 +,-,*,/ and sqrt
+// (correctly rounded on both targets), fused multiply-add, float<->int conversion.
+// The GPU parity tests replay >1e5 env-steps bit for bit to hold this in place.
 #pragma once
 #include <stdint.h>
 #include <math.h>

@@ -102,13 +102,13 @@ def test_fused_rollout_injected_noise(kind, hidden):
     std = torch.exp(policy.effective_log_std().double())[:, None]
     act64 = got + torch.as_tensor(eps, device=got.device).reshape(q["act_dim"], -1).double() * std
     assert float((traj.actions.reshape(q["act_dim"], -1).double() - act64).abs().max()) <= 1e-6
-    # reset draws were consumed from the right slice: path-start observations of Cartpole are
-    # affine in the draws
-    if kind == 0:
-        b = np.array([2.4, 4.0, 0.2, 4.0], np.float32) * np.float32(0.05)
-        o0 = traj.obs[:, 0, :].cpu().numpy()
-        want = (-b[:, None] + draws[0] * (b[:, None] - (-b[:, None]))).astype(np.float32)
-        assert np.array_equal(o0.view(np.uint32), want.view(np.uint32))
+    # reset draws were consumed from the right slice: the first observation of every env is the
+    # host oracle's reset() of slice 0 (bit-exact)
+    from oracle import host_env as H
+    o0 = traj.obs[:, 0, :].cpu().numpy()
+    for i in range(0, n, 13):
+        want = H.HostEnv(kind, np.float32).reset(draws[0, :, i])
+        assert np.array_equal(o0[:, i].view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("kind", ENV_KINDS)
