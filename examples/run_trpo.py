@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Train TRPO (or VPG) on a HIP-native env with the lock-step GPU sampler.
+
+Equivalent of the reference's examples/trpo_cartpole.py / trpo_swimmer.py with the knobs
+that matter on an MI355X exposed (number of parallel envs, iterations).  The reference
+scripts themselves also run unchanged: put this repository first on PYTHONPATH.
+
+  python examples/run_trpo.py --env cartpole --n-envs 1024 --n-itr 30
+  python examples/run_trpo.py --env swimmer  --n-envs 4096 --n-itr 50
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from rllab.algos.trpo import TRPO  # noqa: E402
+from rllab.algos.vpg import VPG  # noqa: E402
+from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline  # noqa: E402
+from rllab.envs.normalized_env import normalize  # noqa: E402
+from rllab.misc import ext  # noqa: E402
+from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy  # noqa: E402
+
+
+def make_env(name):
+    if name == "cartpole":
+        from rllab.envs.box2d.cartpole_env import CartpoleEnv
+        return normalize(CartpoleEnv()), 100
+    if name == "swimmer":
+        from rllab.envs.mujoco.swimmer_env import SwimmerEnv
+        return normalize(SwimmerEnv()), 500
+    raise SystemExit("unknown env %r" % name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="cartpole")
+    ap.add_argument("--algo", default="trpo", choices=["trpo", "vpg"])
+    ap.add_argument("--n-envs", type=int, default=1024)
+    ap.add_argument("--n-itr", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--hidden", type=int, default=32)
+    args = ap.parse_args()
+    ext.set_seed(args.seed)
+    env, horizon = make_env(args.env)
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(args.hidden, args.hidden))
+    baseline = LinearFeatureBaseline(env_spec=env.spec)
+    kw = dict(env=env, policy=policy, baseline=baseline, batch_size=args.n_envs * horizon,
+              max_path_length=horizon, n_itr=args.n_itr, discount=0.99,
+              sampler_args=dict(n_envs=args.n_envs))
+    algo = TRPO(step_size=0.01, **kw) if args.algo == "trpo" else VPG(**kw)
+    algo.train()
+
+
+if __name__ == "__main__":
+    main()

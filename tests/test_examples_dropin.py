@@ -1,0 +1,112 @@
+"""Drop-in checks of the acceptance scripts.
+
+CPU (only where the reference tree is mounted): parse examples/trpo_cartpole.py and
+examples/trpo_swimmer.py of the reference with ``ast`` and verify that every import resolves
+in this package and that every constructor call binds to our signatures.
+GPU: actually learn -- TRPO on Cartpole must raise the average return, VPG must not blow up."""
+import ast
+import importlib
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+REF_EXAMPLES = "/root/reference/examples"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference tree not mounted")
+@pytest.mark.parametrize("script", ["trpo_cartpole.py", "trpo_swimmer.py"])
+def test_reference_example_binds_to_our_api(script):
+    tree = ast.parse(open(os.path.join(REF_EXAMPLES, script)).read())
+    names = {}
+    for node in tree.body:
+        if isinstance(node, ast.ImportFrom):
+            mod = importlib.import_module(node.module)       # rllab.* alias -> rllab_amd.*
+            assert mod.__name__.startswith("rllab_amd."), mod.__name__
+            for a in node.names:
+                names[a.asname or a.name] = getattr(mod, a.name)
+    calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)]
+    checked = 0
+    for c in calls:
+        fn = names.get(c.func.id)
+        if fn is None:
+            continue
+        sig = inspect.signature(fn.__init__ if inspect.isclass(fn) else fn)
+        kwargs = {k.arg: None for k in c.keywords}
+        args = [None] * (len(c.args) + (1 if inspect.isclass(fn) else 0))
+        try:
+            sig.bind(*args, **kwargs)
+        except TypeError:
+            # classes whose __init__ forwards **kwargs up the MRO (TRPO -> NPO -> BatchPolopt)
+            accepted = set()
+            for klass in fn.__mro__:
+                if "__init__" in klass.__dict__:
+                    accepted |= set(inspect.signature(klass.__init__).parameters)
+            assert set(kwargs) <= accepted, (c.func.id, set(kwargs) - accepted)
+        checked += 1
+    assert checked >= 4   # normalize, GaussianMLPPolicy, LinearFeatureBaseline, TRPO
+
+
+@pytest.mark.gpu
+def test_trpo_learns_cartpole(quiet_logger):
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(1)
+    env = normalize(CartpoleEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    baseline = LinearFeatureBaseline(env_spec=env.spec)
+    algo = TRPO(env=env, policy=policy, baseline=baseline, batch_size=256 * 100, max_path_length=100, n_itr=25,
+                discount=0.99, step_size=0.01, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    rets, kls = [], []
+    for itr in range(25):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.log_diagnostics(paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        rets.append(float(tab["AverageReturn"]))
+        kls.append(float(tab["MeanKL"]))
+        if itr == 0:
+            # iteration-0 sanity values of docs/user/experiments.rst:81-95
+            assert abs(float(tab["Entropy"]) - 1.41894) < 1e-4 and abs(float(tab["Perplexity"]) - 4.13273) < 1e-3
+            assert abs(float(tab["AveragePolicyStd"]) - 1.0) < 1e-6
+        logger.dump_tabular()
+    assert max(kls) <= 0.01 + 1e-6
+    assert rets[0] < 400 and np.mean(rets[-3:]) > 2.0 * rets[0] and np.mean(rets[-3:]) > 500, rets
+
+
+@pytest.mark.gpu
+def test_vpg_improves_swimmer_surrogate(quiet_logger):
+    from rllab.algos.vpg import VPG
+    from rllab.baselines.zero_baseline import ZeroBaseline
+    from rllab.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(2)
+    env = normalize(SwimmerEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    algo = VPG(env=env, policy=policy, baseline=ZeroBaseline(env_spec=env.spec), batch_size=128 * 500,
+               max_path_length=500, n_itr=3, sampler_args=dict(n_envs=128))
+    algo.train()
+    assert np.isfinite(policy.get_param_values()).all()
+    # the fused VPG gradient equals float64 autograd on the last batch
+    import torch
+    from rllab_amd.algos.npo import npo_inputs
+    sd = algo.sampler.process_samples(9, algo.sampler.obtain_samples(9))
+    inp = npo_inputs(policy, sd)
+    flat = policy.flat_params.detach().double().requires_grad_(True)
+    new = policy.dist_info_planes(inp[0].double(), flat)
+    ll = policy.distribution.log_likelihood_sym(inp[1].double(), new, axis=0)
+    l64 = -(ll * inp[2].double() * inp[5].double()).sum() * inp[6]
+    g64 = torch.autograd.grad(l64, flat)[0]
+    g = policy.fused_ops().loss_grad(inp, vpg=True)
+    assert float((g - g64).abs().max()) <= 2e-5 * max(1e-3, float(g64.abs().max()))
+    logger.dump_tabular()
