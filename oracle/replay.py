@@ -2,9 +2,10 @@
 recorded through the host float32 build of the same env dynamics and demand
 bit-identical observations, rewards and done flags.
 
-The state at each path start is rebuilt from the recorded observation (for every
-env here the observation determines the reset state), so the check also works for
-production rollouts that drew their resets from the in-kernel Philox stream.
+At each path start the host env is reset with the injected draws when the caller has
+them (parity mode); otherwise the state is rebuilt from the recorded observation (possible
+for Cartpole and Swimmer, whose observation determines the reset state), so the check also
+works for production rollouts that drew their resets from the in-kernel Philox stream.
 Persisted solver state (Cartpole joint impulses) is carried across resets exactly
 as the kernel carries it.
 """
@@ -13,7 +14,7 @@ import numpy as np
 from oracle import host_env as H
 
 
-def replay_check(vec_env, traj, max_envs=64, verbose=False):
+def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None):
     """Raises AssertionError on the first mismatching bit.  Returns the number of
     env-steps compared.  Only paths that start at t == 0 or after a recorded done
     are replayed; the first path of each env needs the env's state at the start of
@@ -26,13 +27,18 @@ def replay_check(vec_env, traj, max_envs=64, verbose=False):
     rew = traj.rewards[:, :n_chk].cpu().numpy()
     done = traj.dones[:, :n_chk].cpu().numpy()
     compared = 0
+    if reset_draws is not None:
+        reset_draws = np.asarray(reset_draws, np.float32)   # [T+1][R][N]: slice t = reset before step t
     for n in range(n_chk):
         env = H.HostEnv(kind, np.float32, normalize=vec_env.normalize)
         fresh = True
         ts = 0
         for t in range(T):
             if fresh:
-                set_state_from_obs(env, obs[:, t, n])
+                if reset_draws is not None:
+                    env.reset(reset_draws[t, :, n])        # exact path: the same reset() the kernel ran
+                else:
+                    set_state_from_obs(env, obs[:, t, n])
                 fresh = False
                 ts = 0
             o_host = env.observe()

@@ -27,6 +27,8 @@ def test_env_query_and_errors():
     from rllab_amd import _lib
     assert _lib.env_query(_lib.ENV_CARTPOLE) == dict(obs_dim=4, act_dim=1, state_dim=16, reset_draws=4,
                                                      reset_is_normal=False)
+    assert _lib.env_query(_lib.ENV_DOUBLE_PENDULUM) == dict(obs_dim=6, act_dim=1, state_dim=17, reset_draws=4,
+                                                            reset_is_normal=True)
     assert _lib.env_query(_lib.ENV_SWIMMER) == dict(obs_dim=13, act_dim=2, state_dim=10, reset_draws=10,
                                                     reset_is_normal=True)
     lb, ub = _lib.env_action_bounds(_lib.ENV_SWIMMER)

@@ -6,7 +6,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV_KINDS = [0, 2]
+ENV_KINDS = [0, 1, 2]
+OBS_INVERTIBLE = [0, 2]   # kinds whose reset state can be rebuilt from the observation
 
 
 def _dev():
@@ -91,7 +92,7 @@ def test_fused_rollout_injected_noise(kind, hidden):
     draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
     traj = v.rollout(policy, T, reset_at_start=True, eps=eps, reset_draws=draws)
     torch.cuda.synchronize()
-    assert replay_check(v, traj, max_envs=n) == n * T
+    assert replay_check(v, traj, max_envs=n, reset_draws=draws) == n * T
     assert int(traj.dones.sum()) > 0
     # policy parity
     obs64 = traj.obs.reshape(q["obs_dim"], -1).double()
@@ -111,7 +112,7 @@ def test_fused_rollout_injected_noise(kind, hidden):
         assert np.array_equal(o0[:, i].view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("kind", ENV_KINDS)
+@pytest.mark.parametrize("kind", OBS_INVERTIBLE)
 def test_fused_rollout_production_rng(kind):
     """Production mode (in-kernel Philox): dynamics still replay bit-exactly, the
     policy noise has the right moments, and two runs with the same seed / counter agree."""

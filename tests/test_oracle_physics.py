@@ -136,3 +136,53 @@ def test_cartpole_reward_done_and_reset_contract():
     a.reset(np.full(4, 0.5)); b.reset(np.full(4, 0.5))
     oa, ra, _ = a.step([5.0]); ob, rb, _ = b.step([1.0])
     assert np.array_equal(oa, ob) and ra == rb
+
+
+def test_double_pendulum_island_solver_tracks_lagrangian():
+    """Two hanging links + motor torque on the second joint: the Box2D-style step must follow
+    semi-implicit Euler on the Lagrange equations (autodiff, float64) to O(dt * w^2)."""
+    import torch
+    m, I, g, h = 0.5, 0.5 * 1.01 / 12, 10.0, 0.01
+
+    def energy_terms(q, qd):
+        a1, a2 = q
+        p1 = torch.stack([0.5 * torch.sin(a1), -0.5 * torch.cos(a1)])
+        o2 = torch.stack([torch.sin(a1), -torch.cos(a1)])
+        p2 = o2 + torch.stack([0.5 * torch.sin(a2), -0.5 * torch.cos(a2)])
+        return p1, p2
+
+    def acc(q, qd, tau):
+        q = torch.tensor(q, dtype=torch.float64)
+        qd = torch.tensor(qd, dtype=torch.float64)
+
+        def T(qq, v):
+            J = torch.autograd.functional.jacobian(lambda z: torch.cat(energy_terms(z, None)), qq, create_graph=True)
+            vel = J @ v
+            return 0.5 * m * (vel ** 2).sum() + 0.5 * I * (v ** 2).sum()
+
+        def V(qq):
+            p1, p2 = energy_terms(qq, None)
+            return m * g * (p1[1] + p2[1])
+        M = torch.autograd.functional.hessian(lambda v: T(q, v), qd)
+        mom = lambda qq: torch.autograd.functional.jacobian(lambda v: T(qq, v), qd, create_graph=True)
+        c = torch.autograd.functional.jacobian(mom, q) @ qd - torch.autograd.functional.jacobian(lambda z: T(z, qd), q)
+        Q = -torch.autograd.functional.jacobian(V, q) + torch.tensor([-tau, tau], dtype=torch.float64)
+        return torch.linalg.solve(M, Q - c).numpy()
+    e = H.HostEnv(1, np.float64)
+    e.reset(np.zeros(4))
+    q, qd = np.zeros(2), np.zeros(2)
+    for t in range(6):
+        o, r, d = e.step([1.0])             # 2 world steps of 0.01 s each
+        for _ in range(2):
+            a = acc(q, qd, 1.0)
+            qd = qd + h * a
+            q = q + h * qd
+        got = np.array([e.state[2], e.state[8], e.state[5], e.state[11]])
+        want = np.array([q[0], q[1], qd[0], qd[1]])
+        assert np.abs(got - want).max() < (2e-5 if t == 0 else 1e-3), (t, got, want)
+        assert not d
+    assert abs(q[1]) > 0.005                 # the torque moved the second link
+    # reward = -|tip - (0,2)| with the reference's tip formula (double_pendulum_env.py:43-58)
+    s = e.state
+    ox, oy = s[6] - np.sin(s[8]) * 0.5, s[7] + np.cos(s[8]) * 0.5
+    assert np.isclose(r, -np.hypot(ox - np.sin(s[8]), oy - np.cos(s[8]) - 2.0), atol=1e-12)
