@@ -41,6 +41,19 @@ WORKLOADS = {
                              flops_per_step=50 * 1100 + 3008),
     "cartpole4096_vpg": dict(env="cartpole", n_envs=4096, T=100, hidden=(32, 32), algo="vpg", lam=1.0,
                              step_bytes=153, record_bytes=28, flops_per_step=3000 + 2368),
+    # parity-config side lines (not the headline): DoublePendulum, and BASELINE config C5's per-GPU shard
+    # (8192 envs / 8 GPUs = 1024 envs per GPU, GaussianMLPPolicy(64,64), TRPO + GAE lambda 0.97)
+    "double_pendulum4096_trpo": dict(env="double_pendulum", n_envs=4096, T=100, hidden=(32, 32), algo="trpo",
+                                     lam=1.0, step_bytes=4 * (2 * 17 + 1 + 6 + 1) + 1, record_bytes=36,
+                                     flops_per_step=2 * 2500 + 2496),
+    "cheetah1024_trpo_gae": dict(env="half_cheetah", n_envs=1024, T=500, hidden=(64, 64), algo="trpo", lam=0.97,
+                                 step_bytes=253, record_bytes=132, flops_per_step=4 * 6000 + 11520),
+}
+ENVS = {  # name -> (module, class, rl_env_kind)
+    "cartpole": ("rllab_amd.envs.box2d.cartpole_env", "CartpoleEnv", 0),
+    "double_pendulum": ("rllab_amd.envs.box2d.double_pendulum_env", "DoublePendulumEnv", 1),
+    "swimmer": ("rllab_amd.envs.mujoco.swimmer_env", "SwimmerEnv", 2),
+    "half_cheetah": ("rllab_amd.envs.mujoco.half_cheetah_env", "HalfCheetahEnv", 3),
 }
 
 
@@ -92,10 +105,9 @@ def main():
     T = wl["T"]
     ext.set_seed(1)
     logger.set_quiet(True)
-    if wl["env"] == "swimmer":
-        from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv as EnvCls
-    else:
-        from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv as EnvCls
+    import importlib
+    mod, cls, env_kind = ENVS[wl["env"]]
+    EnvCls = getattr(importlib.import_module(mod), cls)
     env = normalize(EnvCls())
     policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=wl["hidden"])
     D.broadcast_(policy.flat_params)  # identical theta on every rank
@@ -174,8 +186,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_sampler
-        kind = 2 if wl["env"] == "swimmer" else 0
-        base = cpu_sampler.timed_baseline(kind, policy.get_param_values(), T, budget_s=args.cpu_budget,
+        base = cpu_sampler.timed_baseline(env_kind, policy.get_param_values(), T, budget_s=args.cpu_budget,
                                           hidden=wl["hidden"])
         out["cpu_baseline"] = {
             "value": base["steps_per_s"], "unit": "env_steps/s", "cores": base["cores"], "kind": "port",

@@ -1,0 +1,162 @@
+// dyn_cheetah.h -- HalfCheetahEnv-style env: planar 7-body / 9-DoF articulated tree with
+// joint springs, dampers, armature, geared motors, gravity and capsule-floor contacts; single
+// source for the gfx950 kernels and the host oracle build.
+//
+// Replaces, for one env copy:
+//   HalfCheetahEnv.step / get_current_obs   rllab/envs/mujoco/half_cheetah_env.py:22-46
+//   MujocoEnv.reset_mujoco / forward_dynamics   rllab/envs/mujoco/mujoco_env.py:109-116,184-191
+//   MjModel.step / forward / _compute_subtree   rllab/mujoco_py/mjcore.py:46-84
+//   model constants                         vendor/mujoco_models/half_cheetah.xml:36-93
+//                                           (through gen_cheetah_constants.py -> cheetah_constants.h)
+//   NormalizedEnv.step                      rllab/envs/normalized_env.py:78-92
+// "-style" (BASELINE.json): rigid-body tree, joint passive forces and actuation follow the
+// MJCF; what MuJoCo 1.31 (proprietary, absent) solves with its soft-constraint solver --
+// joint limits and the condim-3 capsule/plane contacts (friction 0.4, solref .02 1) -- is a
+// spring-damper penalty here: normal force k*depth - b*v_n (>= 0) per capsule end sphere,
+// viscous-regularised Coulomb friction |f_t| <= 0.4 f_n, limit torque k_l*viol + b_l*qd.
+// Explicit penalties on ~1 kg feet are stiff, so one 0.01 s MuJoCo step is integrated as
+// 4 semi-implicit Euler sub-steps of 0.0025 s (documented deviation).
+//
+// Plane coordinates (P1, P2) = (z, x) so that MuJoCo's +y hinge angle is CCW-positive.
+// State (18 reals): q[9] = [z (absolute height of the torso frame), x, rooty, bthigh, bshin,
+// bfoot, fthigh, fshin, ffoot], qd[9].  MuJoCo's qpos = [x, z - 0.7, rooty, ...].
+#pragma once
+#include "cheetah_constants.h"
+#include "dyn_planar.h"
+
+namespace rl {
+
+struct CheetahModel {
+    static constexpr int NB = cheetah::NB;
+    RL_HD static constexpr int parent(int i) { return cheetah::PARENT[i]; }
+    RL_HD static constexpr double jx(int i) { return cheetah::JX[i]; }
+    RL_HD static constexpr double jy(int i) { return cheetah::JY[i]; }
+    RL_HD static constexpr double cx(int i) { return cheetah::CX[i]; }
+    RL_HD static constexpr double cy(int i) { return cheetah::CY[i]; }
+    RL_HD static constexpr double mass(int i) { return cheetah::MASS[i]; }
+    RL_HD static constexpr double inertia(int i) { return cheetah::INERTIA[i]; }
+    RL_HD static constexpr double armature(int i) { return cheetah::ARMATURE[i]; }
+    RL_HD static constexpr double damping(int i) { return cheetah::DAMPING[i]; }
+    RL_HD static constexpr double stiffness(int i) { return cheetah::STIFFNESS[i]; }
+    RL_HD static constexpr bool limited(int i) { return i >= 1; }
+    RL_HD static constexpr double lo(int i) { return cheetah::LO[i]; }
+    RL_HD static constexpr double hi(int i) { return cheetah::HI[i]; }
+    RL_HD static constexpr double limit_k() { return 2.0e3; }
+    RL_HD static constexpr double limit_b() { return 15.0; }
+    RL_HD static constexpr double gx() { return -9.81; }  // gravity along -z = -P1
+    RL_HD static constexpr double gy() { return 0.0; }
+
+    static constexpr double CONTACT_K = 2.0e4;   // N/m per end sphere
+    static constexpr double CONTACT_B = 3.0e2;   // N s/m while penetrating
+    static constexpr double FRICTION_C = 3.0e2;  // N s/m tangential, clamped to mu * f_n
+    static constexpr double MU = 0.4;
+
+    // capsule end spheres against the floor z = 0
+    template <typename R>
+    RL_HD static void external(const R* q, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {
+        RL_UNROLL
+        for (int c = 0; c < cheetah::NC; ++c) {
+            const int b = cheetah::CBODY[c];
+            const R lx = (R)cheetah::CPX[c], ly = (R)cheetah::CPY[c];
+            // sphere centre relative to the body anchor / root origin
+            const R rx = k.cs[b] * lx - k.sn[b] * ly;
+            const R ry = k.sn[b] * lx + k.cs[b] * ly;
+            const R height = q[0] + k.ax[b] + rx;                 // P1 = z of the sphere centre
+            const R depth = (R)cheetah::CRAD - height;
+            if (depth > (R)0) {
+                // velocity of the sphere centre
+                const R vn = k.vax[b] - k.om[b] * ry;
+                const R vt = k.vay[b] + k.om[b] * rx;
+                R fn = (R)CONTACT_K * depth - (R)CONTACT_B * vn;
+                fn = rl_max(fn, (R)0);
+                const R ft = -rl_clamp((R)FRICTION_C * vt, -(R)MU * fn, (R)MU * fn);
+                // applied at the lowest point of the sphere; lever arm from the body COM
+                const R ax_ = (k.ax[b] + rx - (R)cheetah::CRAD) - k.px[b];
+                const R ay_ = (k.ay[b] + ry) - k.py[b];
+                fx[b] = fx[b] + fn;
+                fy[b] = fy[b] + ft;
+                tz[b] = tz[b] + (ax_ * ft - ay_ * fn);
+            }
+        }
+    }
+};
+
+struct HalfCheetah {
+    static constexpr int OBS = 20;
+    static constexpr int ACT = 6;
+    static constexpr int STATE = 18;
+    static constexpr int RESET_DRAWS = 18;  // N(0,1): 9 for qpos, 9 for qvel (MuJoCo order)
+    static constexpr bool RESET_NORMAL = true;
+    static constexpr int KIND = 3;
+    static constexpr int SUBSTEPS = 4;      // 4 x 0.0025 s = one 0.01 s MuJoCo step, frame_skip 1
+    using Tree = PlanarTree<CheetahModel>;
+
+    template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
+        RL_UNROLL
+        for (int k = 0; k < ACT; ++k) { lb[k] = (R)-1; ub[k] = (R)1; }
+    }
+
+    // qpos = init + 0.01 N(0,1), qvel = 0.1 N(0,1) in MuJoCo order [x, z, rooty, joints]
+    template <typename R> RL_HD static void reset(R* s, const R* z) {
+        s[0] = (R)0.7 + z[1] * (R)0.01;   // absolute torso height
+        s[1] = z[0] * (R)0.01;            // x
+        s[9] = z[10] * (R)0.1;            // zdot
+        s[10] = z[9] * (R)0.1;            // xdot
+        RL_UNROLL
+        for (int i = 2; i < 9; ++i) {
+            s[i] = z[i] * (R)0.01;
+            s[9 + i] = z[9 + i] * (R)0.1;
+        }
+    }
+
+    // obs = [qpos[1:], qvel, com_subtree(torso)] (half_cheetah_env.py:22-27)
+    template <typename R> RL_HD static void observe(const R* s, R* o) {
+        R cz, cx, vz, vx;
+        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        write_obs(s, cx, cz, o);
+    }
+
+    template <typename R> RL_HD static void write_obs(const R* s, R cx, R cz, R* o) {
+        o[0] = s[0] - (R)0.7;             // rootz (slide displacement)
+        RL_UNROLL
+        for (int i = 2; i < 9; ++i) o[i - 1] = s[i];
+        o[8] = s[10];                     // xdot
+        o[9] = s[9];                      // zdot
+        RL_UNROLL
+        for (int i = 2; i < 9; ++i) o[8 + i] = s[9 + i];
+        o[17] = cx; o[18] = (R)0; o[19] = cz;
+    }
+
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+        R act[ACT], tau[CheetahModel::NB];
+        tau[0] = (R)0;
+        RL_UNROLL
+        for (int k = 0; k < ACT; ++k) {
+            R v = a[k];
+            if (normalize) v = rl_clamp((R)-1 + (v + (R)1) * (R)0.5 * (R)2, (R)-1, (R)1);
+            act[k] = v;
+            tau[1 + k] = (R)cheetah::GEAR[1 + k] * rl_clamp(v, (R)-1, (R)1);  // ctrllimited motor
+        }
+        R q[9], qd[9];
+        RL_UNROLL
+        for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
+        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025);
+        RL_UNROLL
+        for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
+        R cz, cx, vz, vx;
+        Tree::template com<R>(q, qd, cz, cx, vz, vx);
+        write_obs(s, cx, cz, obs);
+        // reward = comvel_x - 0.1 * 0.5 * sum(clip(action)^2)   (half_cheetah_env.py:37-46)
+        R ctrl = (R)0;
+        RL_UNROLL
+        for (int k = 0; k < ACT; ++k) {
+            const R c = rl_clamp(act[k], (R)-1, (R)1);
+            ctrl = ctrl + c * c;
+        }
+        reward = vx - (R)0.1 * (R)0.5 * ctrl;
+        done = false;
+    }
+};
+
+}  // namespace rl

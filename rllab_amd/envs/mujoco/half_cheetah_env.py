@@ -1,0 +1,18 @@
+"""HalfCheetahEnv (API of rllab/envs/mujoco/half_cheetah_env.py:14-56); dynamics in
+csrc/dyn_cheetah.h (``rl::HalfCheetah``, a cheetah-style planar 7-body / 9-DoF tree built
+from the constants of vendor/mujoco_models/half_cheetah.xml)."""
+from rllab_amd import _lib
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.envs.mujoco.mujoco_env import MujocoEnv
+
+
+class HalfCheetahEnv(MujocoEnv, Serializable):
+    FILE = 'half_cheetah.xml'
+    KIND = _lib.ENV_HALF_CHEETAH
+
+    def __init__(self, *args, **kwargs):
+        super(HalfCheetahEnv, self).__init__(*args, **kwargs)
+        Serializable.__init__(self, *args, **kwargs)
+
+    def log_diagnostics(self, paths):
+        self._log_forward_progress(paths)

@@ -31,6 +31,10 @@ def test_env_query_and_errors():
                                                             reset_is_normal=True)
     assert _lib.env_query(_lib.ENV_SWIMMER) == dict(obs_dim=13, act_dim=2, state_dim=10, reset_draws=10,
                                                     reset_is_normal=True)
+    assert _lib.env_query(_lib.ENV_HALF_CHEETAH) == dict(obs_dim=20, act_dim=6, state_dim=18, reset_draws=18,
+                                                         reset_is_normal=True)
+    lb, ub = _lib.env_action_bounds(_lib.ENV_HALF_CHEETAH)
+    assert list(lb) == [-1] * 6 and list(ub) == [1] * 6
     lb, ub = _lib.env_action_bounds(_lib.ENV_SWIMMER)
     assert list(lb) == [-50, -50] and list(ub) == [50, 50]
     assert _lib.lib.rl_env_query(99, None, None, None, None, None) == -1

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV_KINDS = [0, 1, 2]
+ENV_KINDS = [0, 1, 2, 3]
 OBS_INVERTIBLE = [0, 2]   # kinds whose reset state can be rebuilt from the observation
 
 

@@ -186,3 +186,71 @@ def test_double_pendulum_island_solver_tracks_lagrangian():
     s = e.state
     ox, oy = s[6] - np.sin(s[8]) * 0.5, s[7] + np.cos(s[8]) * 0.5
     assert np.isclose(r, -np.hypot(ox - np.sin(s[8]), oy - np.cos(s[8]) - 2.0), atol=1e-12)
+
+
+def test_cheetah_constants_header_is_generated_from_the_mjcf_numbers():
+    """cheetah_constants.h is what gen_cheetah_constants.py emits, and its closed-form capsule
+    mass properties agree with the oracle's numerical quadrature of the same solids."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "rllab_amd", "csrc", "cheetah_constants.h")
+    before = open(hdr).read()
+    subprocess.check_output([sys.executable, os.path.join(root, "rllab_amd", "csrc", "gen_cheetah_constants.py")])
+    assert open(hdr).read() == before
+    from oracle import np_cheetah as C
+    masses = [float(x) for x in before.split("MASS[NB] = {")[1].split("}")[0].split(",")]
+    inertias = [float(x) for x in before.split("INERTIA[NB] = {")[1].split("}")[0].split(",")]
+    assert np.allclose(masses, [b[0] for b in C.BODY_CONST], rtol=1e-9) and abs(sum(masses) - 14.0) < 1e-12
+    assert np.allclose(inertias, [b[1] for b in C.BODY_CONST], rtol=1e-8)
+
+
+def test_cheetah_dynamics_vs_independent_lagrangian():
+    """One env step (4 sub-steps) of the product's dynamics source, float64 host build, equals
+    the autodiff-Lagrangian restatement written from the MJCF in MuJoCo's (x, z) coordinates --
+    with feet in ground contact (normal + friction), joints beyond their range, springs,
+    dampers, armature, gravity and clipped controls all active."""
+    from oracle import np_cheetah as C
+    rng = np.random.RandomState(0)
+    e = H.HostEnv(3, np.float64, normalize=True)
+    z = rng.randn(18)
+    o = e.reset(z)
+    qp, qv = C.reset(z)
+    assert np.abs(e.state - C.to_engine_state(qp, qv)).max() < 1e-15
+    assert np.abs(o - C.observe(qp, qv)).max() < 1e-10
+    n_contact = 0
+    for trial in range(3):
+        qp = np.concatenate([rng.randn(1), [rng.uniform(-0.25, -0.05)], rng.uniform(-.3, .3, 1),
+                             rng.uniform(-1.3, 1.2, 6)])
+        qv = rng.randn(9) * 2
+        import torch
+        pts, _ = C._contact_points(torch.as_tensor(qp))
+        n_contact += int((pts[1::2] < C.R_GEOM).sum())
+        e.state[:] = C.to_engine_state(qp, qv)
+        a = rng.randn(6) * (1.0 if trial == 0 else 3.0)
+        o, r, d = e.step(a)
+        qp2, qv2, o2, r2, d2 = C.step(qp, qv, a)
+        assert np.abs(e.state - C.to_engine_state(qp2, qv2)).max() < 2e-9
+        assert np.abs(o - o2).max() < 2e-9 and abs(r - r2) < 1e-9 and d is False and d2 is False
+    assert n_contact >= 2
+
+
+def test_cheetah_f32_tracks_f64_and_stays_bounded():
+    """BASELINE config C5's check: the fp32 dynamics track the float64 CPU rollout within
+    tolerance over a short horizon (contacts make long horizons chaotic), and 500 steps of
+    random torques keep the state bounded with the body resting on its feet."""
+    rng = np.random.RandomState(2)
+    e32, e64 = H.HostEnv(3, np.float32, normalize=True), H.HostEnv(3, np.float64, normalize=True)
+    z = rng.randn(18)
+    e32.reset(z.astype(np.float32))
+    e64.reset(z.astype(np.float32).astype(np.float64))
+    for t in range(10):
+        a = rng.randn(6).astype(np.float32)
+        o32, r32, _ = e32.step(a)
+        o64, r64, _ = e64.step(a.astype(np.float64))
+        assert np.abs(o32 - o64).max() < 2e-3 * max(1.0, np.abs(o64).max()) and abs(r32 - r64) < 2e-3, t
+    for t in range(500):
+        o32, r32, d = e32.step(rng.randn(6).astype(np.float32))
+    assert not d and np.isfinite(e32.state).all()
+    assert 0.3 < e32.state[0] < 0.9 and np.abs(e32.state[2:9]).max() < 2.0 and np.abs(e32.state[9:]).max() < 50.0
