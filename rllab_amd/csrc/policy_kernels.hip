@@ -1,5 +1,6 @@
 // policy_kernels.hip -- fused TRPO/VPG update kernels for GaussianMLPPolicy
-// (tanh MLP mean with two hidden layers + state-independent log_std).
+// (tanh MLP mean with two equal hidden layers + state-independent log_std) on the
+// gfx950 matrix cores.
 //
 // One pass over the dense batch per launch; what the reference evaluates as the
 // compiled Theano functions f_loss / f_constraint / f_loss_constraint, f_grad and
@@ -15,29 +16,42 @@
 //               theta_new == theta_old -- the only point where TRPO evaluates it
 //               (PerlmutterHvp, :27-55; reg_coeff * v is added by the caller).
 //
-// Mapping.  A workgroup is WAVES wavefronts; a wavefront owns tiles of 64 samples,
-// lane <-> sample for the per-sample network passes (weights broadcast from LDS,
-// activations in registers / per-lane LDS columns).  The parameter gradient is a
-// batch reduction of outer products (gW1 = sum_b h0_b (x) gz1_b ...): for that phase
-// the roles flip, lane <-> (column, row-group) of the weight matrix, and each lane
-// walks the 64 samples of the tile reading activations from LDS (row stride 65 floats:
-// conflict-free in both roles).  Per-lane accumulators live in registers across the
-// whole grid-stride loop; every wavefront then writes ONE partial gradient row, and a
-// second kernel sums the partial rows in float64 in a fixed order (deterministic).
+// Mapping (v_mfma_f32_32x32x2_f32: exact f32, D[32x32] += A[32x2] B[2x32]).
+// A wavefront owns tiles of 32 samples.  Every dense layer is evaluated TRANSPOSED,
+//     Z^T[unit][sample] = W^T[unit][k] * X^T[k][sample],
+// so that the MFMA output fragment (lane = sample + 32*half, register r = unit
+// u(r, half) = (r&3) + 8*(r>>2) + 4*half) is, after the element-wise tanh, directly the B
+// operand of the next layer: k-step m of that layer multiplies register m of this one, and
+// the weight fragment staged in LDS for step m holds rows u(m, half) of W.  Activations
+// therefore never leave registers between layers and there is no per-FMA weight fetch:
+// each MFMA (2048 FMAs) costs one conflict-free ds_read_b32 of its weight fragment.
+// The same holds for the tangent pass (J v) and the back-propagation W1 * gz1.
+// The batch reduction of outer products gW1 = sum_s h0_s (x) gz1_s is an MFMA with the
+// SAMPLE axis as K: both operands are transposed through a wave-private LDS tile
+// (stride H+1, conflict-free both ways).  The thin products (gW0: DO+1 rows, gW2: DA
+// columns) would waste most of a 32x32 tile and run on the VALU against LDS-broadcast
+// operands instead, filling issue slots next to the matrix pipe.
+// Persistent accumulators live in registers for the whole grid-stride loop; the waves of a
+// workgroup then fold their partials in a fixed order through LDS, every workgroup writes
+// ONE partial row, and reduce_rows_kernel sums the rows in float64 in a fixed order
+// (deterministic, identical on all ranks).
 //
-// All kernels are VALU-bound by design (arithmetic intensity ~ 6*fwd_flops / 80 B
-// >> the 20 flop/B ridge); HBM sees each sample once per pass.
+// Roofline: MFMA-bound.  FVP = 94 MFMAs (H = 32, swimmer) per 32-sample tile = 6016 matrix
+// cycles per SIMD; HBM sees each sample's 80 B once per pass.
 #include <hip/hip_runtime.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
 
 namespace rl {
 
-constexpr int WV = 64;   // wavefront
-constexpr int LS = 65;   // LDS row stride (floats) of activation tiles
+constexpr int WV = 64;        // wavefront
+constexpr int TS = 32;        // samples per MFMA tile
+constexpr int WAVES = 4;      // wavefronts per workgroup (one per SIMD)
 
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_FVP = 2, MODE_VPG = 3 };
 constexpr int LOSS_COLS = 4;  // sum w*lr*adv, sum w*kl, sum w*logp*adv, max kl
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float ftanh(float x) {
     float xc = fminf(fmaxf(x, -10.0f), 10.0f);
@@ -45,47 +59,69 @@ __device__ __forceinline__ float ftanh(float x) {
     return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-template <int DO_, int DA_, int H0_, int H1_>
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// unit held by register r of the 32x32 output fragment in lane half `half`
+__host__ __device__ constexpr int frag_unit(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// compiler-level ordering of wave-private LDS traffic between lanes (the LDS queue of one
+// wavefront is in order, so no s_barrier is needed -- only the compiler must not move
+// accesses across the hand-over)
+__device__ __forceinline__ void wave_sync() {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_wave_barrier();
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
+template <int DO_, int DA_, int H_>
 struct Net {
-    static constexpr int DO = DO_, DA = DA_, H0 = H0_, H1 = H1_;
+    static constexpr int DO = DO_, DA = DA_, H = H_;
+    static constexpr int HT = H / 32;                 // 32-unit tiles per hidden layer
+    static constexpr int KS0 = (DO + 2) / 2;          // k-steps of layer 0 (inputs + the bias slot)
+    static constexpr int KS1 = 16 * HT;               // k-steps of layer 1
     static constexpr int W0 = 0;
-    static constexpr int B0 = W0 + DO * H0;
-    static constexpr int W1 = B0 + H0;
-    static constexpr int B1 = W1 + H0 * H1;
-    static constexpr int W2 = B1 + H1;
-    static constexpr int B2 = W2 + H1 * DA;
+    static constexpr int B0 = W0 + DO * H;
+    static constexpr int W1 = B0 + H;
+    static constexpr int B1 = W1 + H * H;
+    static constexpr int W2 = B1 + H;
+    static constexpr int B2 = W2 + H * DA;
     static constexpr int LSTD = B2 + DA;
     static constexpr int P = LSTD + DA;
-    static constexpr int PP = (P + 3) & ~3;
-    // outer-product ownership: lane owns column (lane % H), row group (lane / H)
-    static constexpr int NG1 = WV / H1, R1 = H0 / NG1;               // gW1: R1 rows per lane
-    static constexpr int NG0 = WV / H0, R0 = (DO + NG0 - 1) / NG0;   // gW0: R0 rows per lane
-    static constexpr int DOP = R0 * NG0;                             // padded obs rows (zeros)
-    static constexpr int E2 = (H1 * DA + WV - 1) / WV;               // gW2 entries per lane
-    static constexpr int HMAX = (H0 > H1 ? H0 : H1) > DOP ? (H0 > H1 ? H0 : H1) : DOP;
-    static constexpr int TILE = HMAX * LS;
-    static_assert(WV % H0 == 0 && WV % H1 == 0 && H0 % NG1 == 0, "hidden sizes must divide 64");
+    static constexpr int TAIL = P - B1;               // b1, W2, b2, log_std: VALU-side parameters
+    static constexpr int TAILP = (TAIL + 3) & ~3;
+    static constexpr int TSTR = H + 1;                // transposition tile stride (odd)
+    static constexpr int XS = (2 * KS0) | 1;          // x tile stride (odd)
+    static constexpr int GS = DA | 1;                 // gmu tile stride (odd)
+    static constexpr int FA0 = HT * KS0 * WV;         // floats per layer-0 weight fragment set
+    static constexpr int FA1 = HT * KS1 * WV;         // floats per layer-1 weight fragment set
+    static constexpr int WAVE_LDS = TS * TSTR + TS * XS + TS * GS;
+    // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
+    static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
+    static_assert(H % 32 == 0 && HT <= 2, "hidden size must be 32 or 64");
+    static_assert(DO + 1 <= 32, "obs_dim + 1 must fit one 32-row tile");
+
+    // k index (unit of the previous layer) that lane half `half` contributes at k-step m of layer 1
+    __host__ __device__ static constexpr int k1(int m, int half) { return 32 * (m / 16) + frag_unit(m % 16, half); }
 };
 
-// y[j] += sum_d W[d][j] * x[d]; W row-major [IN][OUT] in LDS (broadcast reads),
-// x in this lane's LDS column (stride LS).  The d loop stays rolled (see env_kernels.hip).
-template <int IN, int OUT>
-__device__ __forceinline__ void dense_acc(const float* __restrict__ w, const float* __restrict__ xcol,
-                                          float* y) {
-#pragma unroll 2
-    for (int d = 0; d < IN; ++d) {
-        const float xd = xcol[d * LS];
-        const float* __restrict__ row = w + d * OUT;
-#pragma unroll
-        for (int j = 0; j < OUT; ++j) y[j] = __builtin_fmaf(xd, row[j], y[j]);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void store_col(float* col, const float* v) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) col[j * LS] = v[j];
-}
+template <class N, int MODE>
+struct Smem {
+    static constexpr bool GRADLIKE = (MODE != MODE_LOSS);
+    static constexpr bool FVP = (MODE == MODE_FVP);
+    static constexpr int A0 = 0;
+    static constexpr int A1 = A0 + N::FA0;
+    static constexpr int A1T = A1 + N::FA1;                       // backward fragments (W1 untransposed)
+    static constexpr int DA0 = A1T + (GRADLIKE ? N::FA1 : 0);     // tangent fragments
+    static constexpr int DA1 = DA0 + (FVP ? N::FA0 : 0);
+    static constexpr int TAIL = DA1 + (FVP ? N::FA1 : 0);
+    static constexpr int DTAIL = TAIL + N::TAILP;
+    static constexpr int WAVE0 = DTAIL + (FVP ? N::TAILP : 0);
+    static constexpr int TOTAL = WAVE0 + WAVES * N::WAVE_LDS;
+    static constexpr int RED = 0;                                 // [P] cross-wave fold, aliases the fragments
+    static_assert(TOTAL >= N::P, "LDS fold buffer must fit");
+};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -102,6 +138,8 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WV));
     return v;
 }
+// value + the value held by the same sample / unit in the other lane half
+__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, WV); }
 
 struct PolicyBatch {
     int B;                     // samples
@@ -115,112 +153,155 @@ struct PolicyBatch {
     const float* weight;       // [B] 0/1
     float inv_count;
     float log_min_std;
-    float* partial;            // [waves_total][P]   (grad-like modes)
-    double* partial_loss;      // [waves_total][LOSS_COLS] (MODE_LOSS)
+    float* partial;            // [grid][P]          (grad-like modes)
+    double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS)
 };
 
-template <class N, int MODE, int WAVES>
-__global__ void __launch_bounds__(WAVES* WV) policy_pass_kernel(PolicyBatch a) {
-    constexpr int DO = N::DO, DA = N::DA, H0 = N::H0, H1 = N::H1, P = N::P;
-    constexpr bool GRADLIKE = (MODE != MODE_LOSS);
-    constexpr int R1 = N::R1, R0 = N::R0, E2 = N::E2;
+// stage one parameter vector as MFMA A-operand fragments (see the file header)
+template <class N>
+__device__ __forceinline__ void stage_fragments(const float* __restrict__ th, float* fa0, float* fa1,
+                                                float* fa1t) {
+    constexpr int H = N::H;
+    for (int e = threadIdx.x; e < N::FA0; e += WAVES * WV) {
+        const int l = e % WV, m = (e / WV) % N::KS0, t = e / (WV * N::KS0);
+        const int i = 32 * t + (l & 31), d = 2 * m + (l >> 5);
+        fa0[e] = d < N::DO ? th[N::W0 + d * H + i] : (d == N::DO ? th[N::B0 + i] : 0.0f);
+    }
+    for (int e = threadIdx.x; e < N::FA1; e += WAVES * WV) {
+        const int l = e % WV, m = (e / WV) % N::KS1, t = e / (WV * N::KS1);
+        const int i = 32 * t + (l & 31), k = N::k1(m, l >> 5);
+        fa1[e] = th[N::W1 + k * H + i];                     // A[i][k] = W1[k][i]   (forward: W1^T)
+        if (fa1t) fa1t[e] = th[N::W1 + i * H + k];          // A[i][k] = W1[i][k]   (backward: W1)
+    }
+}
+
+template <class N, int MODE>
+__global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
+    using S = Smem<N, MODE>;
+    constexpr int DO = N::DO, DA = N::DA, H = N::H, HT = N::HT, KS0 = N::KS0, KS1 = N::KS1, P = N::P;
+    constexpr bool GRADLIKE = S::GRADLIKE, FVP = S::FVP;
+    constexpr int TSTR = N::TSTR, XS = N::XS, GS = N::GS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sw = smem;                                              // [P] weights
-    float* sv = sw + N::PP;                                        // [P] tangent (FVP only)
-    float* sw1t = sv + ((MODE == MODE_FVP) ? N::PP : 0);           // [H1][H0] = W1^T (grad-like)
-    float* tiles = sw1t + (GRADLIKE ? H0 * H1 : 0);
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
-    float* bufA = tiles + wave * (2 * N::TILE + DA * LS);
-    float* bufB = bufA + N::TILE;
-    float* gmu_t = bufB + N::TILE;                                 // [DA][LS]
+    const int lj = lane & 31, lh = lane >> 5;
+    float* const fa0 = smem + S::A0;
+    float* const fa1 = smem + S::A1;
+    float* const fa1t = smem + S::A1T;
+    float* const fda0 = smem + S::DA0;
+    float* const fda1 = smem + S::DA1;
+    float* const tail = smem + S::TAIL;      // theta[B1 .. P)
+    float* const dtail = smem + S::DTAIL;    // vec[B1 .. P)
+    float* const tb = smem + S::WAVE0 + wave * N::WAVE_LDS;   // [32][TSTR] transposition tile
+    float* const tbx = tb + TS * TSTR;                        // [32][XS]   x (+1) rows
+    float* const tbg = tbx + TS * XS;                         // [32][GS]   gmu rows
 
-    for (int k = threadIdx.x; k < P; k += WAVES * WV) {
-        sw[k] = a.theta[k];
-        if (MODE == MODE_FVP) sv[k] = a.vec[k];
+    stage_fragments<N>(a.theta, fa0, fa1, GRADLIKE ? fa1t : nullptr);
+    if (FVP) stage_fragments<N>(a.vec, fda0, fda1, nullptr);
+    for (int k = threadIdx.x; k < N::TAIL; k += WAVES * WV) {
+        tail[k] = a.theta[N::B1 + k];
+        if (FVP) dtail[k] = a.vec[N::B1 + k];
     }
-    if (GRADLIKE) {
-        for (int k = threadIdx.x; k < H0 * H1; k += WAVES * WV) {
-            const int i = k / H1, j = k % H1;                      // W1[i][j]
-            sw1t[j * H0 + i] = a.theta[N::W1 + k];
-        }
-    }
+    for (int k = lane; k < N::WAVE_LDS; k += WV) tb[k] = 0.0f;
     __syncthreads();
+    constexpr int T_B1 = 0, T_W2 = N::W2 - N::B1, T_B2 = N::B2 - N::B1, T_LS = N::LSTD - N::B1;
 
     // effective log_std / std (state independent)
-    float lstd[DA], inv_var[DA], inv_std[DA], var_[DA];
+    float lstd[DA], inv_std[DA], var_[DA];
     bool floored[DA];
 #pragma unroll
     for (int k = 0; k < DA; ++k) {
-        const float raw = sw[N::LSTD + k];
+        const float raw = tail[T_LS + k];
         floored[k] = raw < a.log_min_std;
         lstd[k] = fmaxf(raw, a.log_min_std);
         inv_std[k] = __expf(-lstd[k]);
-        inv_var[k] = inv_std[k] * inv_std[k];
         var_[k] = __expf(2.0f * lstd[k]);
     }
 
-    // accumulators (registers, whole launch)
+    // ---- accumulators (registers, whole launch) ------------------------------------------
     double acc_loss = 0.0, acc_kl = 0.0, acc_vpg = 0.0;
     float max_kl = -INFINITY;
-    float gW1[R1], gW0[R0], gW2[E2];
-    float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f, gls[DA];
+    f32x16 gW1[HT][HT];                 // [row tile][col tile] fragments of sum h0 (x) gz1
+    float gW0[DO + 1][HT];              // lane = column, rows d (DO = bias row); half = sample parity
+    float gW2[HT][DA];                  // lane = row (unit), half = sample parity
+    float gb1[HT], gb2[DA], gls[DA];
     float wsum = 0.0f;
 #pragma unroll
-    for (int r = 0; r < R1; ++r) gW1[r] = 0.0f;
+    for (int ti = 0; ti < HT; ++ti) {
 #pragma unroll
-    for (int r = 0; r < R0; ++r) gW0[r] = 0.0f;
+        for (int tj = 0; tj < HT; ++tj)
 #pragma unroll
-    for (int r = 0; r < E2; ++r) gW2[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) gW1[ti][tj][r] = 0.0f;
+        gb1[ti] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < DA; ++k) gls[k] = 0.0f;
+        for (int k = 0; k < DA; ++k) gW2[ti][k] = 0.0f;
+    }
+#pragma unroll
+    for (int d = 0; d <= DO; ++d)
+#pragma unroll
+        for (int tj = 0; tj < HT; ++tj) gW0[d][tj] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DA; ++k) { gb2[k] = 0.0f; gls[k] = 0.0f; }
 
     const int B = a.B;
-    const int n_tiles = (B + WV - 1) / WV;
+    const int n_tiles = (B + TS - 1) / TS;
     const int wave_global = blockIdx.x * WAVES + wave;
     const int waves_total = gridDim.x * WAVES;
-    float* colA = bufA + lane;
-    float* colB = bufB + lane;
-    const int j1 = lane % H1, g1 = lane / H1;   // owned column / row group of gW1
-    const int j0 = lane % H0, g0 = lane / H0;   // owned column / row group of gW0
 
     for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
-        const int b = tile * WV + lane;
+        asm volatile("" ::: "memory");   // keep the weight-fragment reads inside the loop
+        const int b = tile * TS + lj;
         const bool live = b < B;
         const int bi = live ? b : (B - 1);
         const float wgt = live ? a.weight[bi] : 0.0f;
-        float x[N::DOP];
-#pragma unroll
-        for (int d = 0; d < N::DOP; ++d) x[d] = (d < DO) ? a.obs[(size_t)d * B + bi] : 0.0f;
 
-        // ---- forward ------------------------------------------------------------
-        store_col<N::DOP>(colA, x);                            // bufA = x (zero padded)
-        float h0[H0];
+        // ---- B operands of layer 0: x_ext[sample][2m + half] (slot DO = 1 carries the bias) -----
+        float xb[KS0];
 #pragma unroll
-        for (int j = 0; j < H0; ++j) h0[j] = sw[N::B0 + j];
-        dense_acc<DO, H0>(sw + N::W0, colA, h0);
-#pragma unroll
-        for (int j = 0; j < H0; ++j) h0[j] = ftanh(h0[j]);
-        store_col<H0>(colB, h0);                               // bufB = h0
-        float h1[H1];
-#pragma unroll
-        for (int j = 0; j < H1; ++j) h1[j] = sw[N::B1 + j];
-        dense_acc<H0, H1>(sw + N::W1, colB, h1);
-#pragma unroll
-        for (int j = 0; j < H1; ++j) h1[j] = ftanh(h1[j]);
-        float mean[DA];
-#pragma unroll
-        for (int k = 0; k < DA; ++k) mean[k] = sw[N::B2 + k];
-#pragma unroll
-        for (int i = 0; i < H1; ++i)
-#pragma unroll
-            for (int k = 0; k < DA; ++k) mean[k] = __builtin_fmaf(h1[i], sw[N::W2 + i * DA + k], mean[k]);
+        for (int m = 0; m < KS0; ++m) {
+            const int d = 2 * m + lh;
+            xb[m] = d < DO ? a.obs[(size_t)d * B + bi] : (d == DO ? 1.0f : 0.0f);
+        }
 
-        // ---- per-sample scalars -> cotangent on the mean --------------------------
+        // ---- forward ------------------------------------------------------------------------
+        f32x16 h0[HT], h1[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h0[t][r] = ftanh(acc[r]);
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
+#pragma unroll
+            for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[t][r] = ftanh(acc[r]);
+        }
+
+        // ---- per-sample cotangent on the mean ----------------------------------------------------
         float gmu[DA];
 #pragma unroll
         for (int k = 0; k < DA; ++k) gmu[k] = 0.0f;
-        if (MODE != MODE_FVP) {
+        if (!FVP) {
+            float mean[DA];
+#pragma unroll
+            for (int k = 0; k < DA; ++k) {
+                float pm = 0.0f;
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pm = __builtin_fmaf(h1[t][r], tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], pm);
+                mean[k] = tail[T_B2 + k] + half_sum(pm);
+            }
             const float advb = a.adv[bi];
             float zz_new = 0.0f, zz_old = 0.0f, sls_new = 0.0f, sls_old = 0.0f, kl = 0.0f;
             float znew[DA];
@@ -244,252 +325,350 @@ __global__ void __launch_bounds__(WAVES* WV) policy_pass_kernel(PolicyBatch a) {
             const float logp_new = -sls_new - 0.5f * zz_new;
             const float dlog = logp_new - (-sls_old - 0.5f * zz_old);
             const float lr = __expf(dlog);
+            const float w1 = (lh == 0) ? wgt : 0.0f;        // both halves hold the sample: count it once
             if (MODE == MODE_LOSS) {
-                acc_loss += (double)(wgt * lr * advb);
-                acc_kl += (double)(wgt * kl);
-                acc_vpg += (double)(wgt * (logp_new - 0.5f * (float)DA * 1.8378770664093453f) * advb);
-                if (wgt > 0.0f) max_kl = fmaxf(max_kl, kl);
+                acc_loss += (double)(w1 * lr * advb);
+                acc_kl += (double)(w1 * kl);
+                acc_vpg += (double)(w1 * (logp_new - 0.5f * (float)DA * 1.8378770664093453f) * advb);
+                if (w1 > 0.0f) max_kl = fmaxf(max_kl, kl);
             } else {
                 // d(-w adv lr)/dmu_k = -w adv lr z_k / sigma_k ; VPG: lr -> 1 (d logp)
                 const float c = -wgt * advb * (MODE == MODE_GRAD ? lr : 1.0f) * a.inv_count;
+                const float c1 = (lh == 0) ? c : 0.0f;
 #pragma unroll
                 for (int k = 0; k < DA; ++k) {
                     gmu[k] = c * znew[k] * inv_std[k];
-                    if (!floored[k]) gls[k] += c * (znew[k] * znew[k] - 1.0f);
+                    if (!floored[k]) gls[k] += c1 * (znew[k] * znew[k] - 1.0f);
                 }
             }
         } else {
             // tangent forward: dmu = J v
-            float d0[H0];
+            f32x16 dh0[HT], dh1[HT];
 #pragma unroll
-            for (int j = 0; j < H0; ++j) d0[j] = sv[N::B0 + j];
-            dense_acc<DO, H0>(sv + N::W0, colA, d0);               // dW0^T x + db0   (bufA = x)
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
 #pragma unroll
-            for (int j = 0; j < H0; ++j) d0[j] *= (1.0f - h0[j] * h0[j]);   // dh0
-            float d1[H1];
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < H1; ++j) d1[j] = sv[N::B1 + j];
-            dense_acc<H0, H1>(sv + N::W1, colB, d1);               // dW1^T h0        (bufB = h0)
-            store_col<H0>(colA, d0);                               // bufA = dh0
-            dense_acc<H0, H1>(sw + N::W1, colA, d1);               // + W1^T dh0
+                for (int m = 0; m < KS0; ++m) acc = mfma(fda0[(t * KS0 + m) * WV + lane], xb[m], acc);   // dW0^T x + db0
 #pragma unroll
-            for (int j = 0; j < H1; ++j) d1[j] *= (1.0f - h1[j] * h1[j]);   // dh1
-            float dmu[DA];
+                for (int r = 0; r < 16; ++r) dh0[t][r] = acc[r] * (1.0f - h0[t][r] * h0[t][r]);
+            }
 #pragma unroll
-            for (int k = 0; k < DA; ++k) dmu[k] = sv[N::B2 + k];
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < H1; ++i)
+                for (int r = 0; r < 16; ++r) acc[r] = dtail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
 #pragma unroll
-                for (int k = 0; k < DA; ++k) {
-                    dmu[k] = __builtin_fmaf(h1[i], sv[N::W2 + i * DA + k], dmu[k]);
-                    dmu[k] = __builtin_fmaf(d1[i], sw[N::W2 + i * DA + k], dmu[k]);
+                for (int m = 0; m < KS1; ++m) {
+                    acc = mfma(fda1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);                // dW1^T h0
+                    acc = mfma(fa1[(t * KS1 + m) * WV + lane], dh0[m / 16][m % 16], acc);                // W1^T dh0
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh1[t][r] = acc[r] * (1.0f - h1[t][r] * h1[t][r]);
+            }
             const float c = wgt * a.inv_count;
 #pragma unroll
-            for (int k = 0; k < DA; ++k) gmu[k] = c * dmu[k] * (2.0f / (2.0f * var_[k] + 1e-8f));
-            wsum += c;
-            // restore bufA = x for the gW0 outer product below
-            store_col<N::DOP>(colA, x);
+            for (int k = 0; k < DA; ++k) {
+                float pd = 0.0f;
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int u = (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k;
+                        pd = __builtin_fmaf(h1[t][r], dtail[T_W2 + u], pd);
+                        pd = __builtin_fmaf(dh1[t][r], tail[T_W2 + u], pd);
+                    }
+                const float dmu = dtail[T_B2 + k] + half_sum(pd);
+                gmu[k] = c * dmu * (2.0f / (2.0f * var_[k] + 1e-8f));
+            }
+            if (lh == 0) wsum += c;
         }
 
         if (GRADLIKE) {
-            // ---- layer 2: gW2 = h1 (x) gmu, gb2 = sum gmu ---------------------------
-            // bufA holds x, bufB holds h0.  gW2 needs h1 in a tile: stage it in bufA after
-            // saving nothing -- x is still in registers and is re-stored for layer 0.
-            store_col<H1>(colA, h1);                               // bufA = h1
+            // ---- back-propagation: gz1 = (W2 gmu) (1 - h1^2); gz0 = (W1 gz1) (1 - h0^2) ----------------
+            f32x16 gz1[HT], gz0[HT];
 #pragma unroll
-            for (int k = 0; k < DA; ++k) gmu_t[k * LS + lane] = gmu[k];
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-            for (int r = 0; r < E2; ++r) {
-                const int e = r * WV + lane;
-                if (e < H1 * DA) {
-                    const int i = e / DA, k = e % DA;
-                    float acc = 0.0f;
-#pragma unroll 4
-                    for (int s = 0; s < WV; ++s) acc = __builtin_fmaf(bufA[i * LS + s], gmu_t[k * LS + s], acc);
-                    gW2[r] += acc;
+                for (int r = 0; r < 16; ++r) {
+                    float g = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < DA; ++k)
+                        g = __builtin_fmaf(tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], gmu[k], g);
+                    gz1[t][r] = g * (1.0f - h1[t][r] * h1[t][r]);
+                }
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < KS1; ++m) acc = mfma(fa1t[(t * KS1 + m) * WV + lane], gz1[m / 16][m % 16], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gz0[t][r] = acc[r] * (1.0f - h0[t][r] * h0[t][r]);
+            }
+
+            // ---- gb2, gmu / x rows for the broadcast (VALU) products -------------------------------------
+            if (lh == 0) {
+#pragma unroll
+                for (int k = 0; k < DA; ++k) {
+                    gb2[k] += gmu[k];
+                    tbg[lj * GS + k] = gmu[k];
                 }
             }
-            if (lane < DA) {
-                float acc = 0.0f;
-#pragma unroll 4
-                for (int s = 0; s < WV; ++s) acc += gmu_t[lane * LS + s];
-                gb2 += acc;
-            }
-            // ---- layer 1: gz1 = (W2 gmu) * (1 - h1^2); gW1 = h0 (x) gz1 -------------------
-            float gz1[H1];
 #pragma unroll
-            for (int i = 0; i < H1; ++i) {
-                float g = 0.0f;
+            for (int m = 0; m < KS0; ++m) tbx[lj * XS + 2 * m + lh] = xb[m];
+
+            // ---- layer 1: gW1 += h0^T gz1 (samples are K), gb1 += column sums of gz1 -------------------
+            // in the transposed role lane (c, half) owns unit c of a 32-unit tile and the samples of
+            // parity `half`: operand m is sample 2m + half
+            wave_sync();
 #pragma unroll
-                for (int k = 0; k < DA; ++k) g = __builtin_fmaf(sw[N::W2 + i * DA + k], gmu[k], g);
-                gz1[i] = g * (1.0f - h1[i] * h1[i]);
-            }
-            store_col<H1>(colA, gz1);                              // bufA = gz1, bufB = h0
-            {
-                float gbl = 0.0f;
-#pragma unroll 2
-                for (int s = 0; s < WV; ++s) {
-                    const float bval = bufA[j1 * LS + s];
-                    gbl += bval;
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-                    for (int r = 0; r < R1; ++r)
-                        gW1[r] = __builtin_fmaf(bufB[(g1 * R1 + r) * LS + s], bval, gW1[r]);
+                for (int r = 0; r < 16; ++r) tb[lj * TSTR + 32 * t + frag_unit(r, 0) + 4 * lh] = gz1[t][r];
+            wave_sync();
+            float bop[HT][16];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                float s = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    bop[t][m] = tb[(2 * m + lh) * TSTR + 32 * t + lj];
+                    s += bop[t][m];
                 }
-                gb1 += gbl;
+                gb1[t] += s;
             }
-            // ---- layer 0: gz0 = (W1 gz1) * (1 - h0^2); gW0 = x (x) gz0 ---------------------
-            float gz0[H0];
+            wave_sync();
 #pragma unroll
-            for (int i = 0; i < H0; ++i) gz0[i] = 0.0f;
-            dense_acc<H1, H0>(sw1t, colA, gz0);                    // sum_j W1[i][j] gz1[j]
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-            for (int i = 0; i < H0; ++i) gz0[i] *= (1.0f - h0[i] * h0[i]);
-            store_col<H0>(colB, gz0);                              // bufB = gz0
-            store_col<N::DOP>(colA, x);                            // bufA = x
-            {
-                float gbl = 0.0f;
-#pragma unroll 2
-                for (int s = 0; s < WV; ++s) {
-                    const float bval = bufB[j0 * LS + s];
-                    gbl += bval;
+                for (int r = 0; r < 16; ++r) tb[lj * TSTR + 32 * t + frag_unit(r, 0) + 4 * lh] = h0[t][r];
+            wave_sync();
 #pragma unroll
-                    for (int r = 0; r < R0; ++r)
-                        gW0[r] = __builtin_fmaf(bufA[(g0 * R0 + r) * LS + s], bval, gW0[r]);
+            for (int ti = 0; ti < HT; ++ti) {
+                float aop[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) aop[m] = tb[(2 * m + lh) * TSTR + 32 * ti + lj];
+#pragma unroll
+                for (int tj = 0; tj < HT; ++tj)
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) gW1[ti][tj] = mfma(aop[m], bop[tj][m], gW1[ti][tj]);
+            }
+
+            // ---- layer 2: gW2[u][k] += sum_s h1[s][u] gmu[s][k]  (lane = unit, gmu broadcast) ------------
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[lj * TSTR + 32 * t + frag_unit(r, 0) + 4 * lh] = h1[t][r];
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                float g[DA];
+#pragma unroll
+                for (int k = 0; k < DA; ++k) g[k] = tbg[(2 * m + lh) * GS + k];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    const float hv = tb[(2 * m + lh) * TSTR + 32 * t + lj];
+#pragma unroll
+                    for (int k = 0; k < DA; ++k) gW2[t][k] = __builtin_fmaf(hv, g[k], gW2[t][k]);
                 }
-                gb0 += gbl;
             }
+
+            // ---- layer 0: gW0[d][j] += sum_s x_ext[s][d] gz0[s][j]  (lane = column j, x broadcast) ------
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[lj * TSTR + 32 * t + frag_unit(r, 0) + 4 * lh] = gz0[t][r];
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                float gz[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) gz[t] = tb[(2 * m + lh) * TSTR + 32 * t + lj];
+#pragma unroll
+                for (int d = 0; d <= DO; ++d) {
+                    const float xv = tbx[(2 * m + lh) * XS + d];
+#pragma unroll
+                    for (int t = 0; t < HT; ++t) gW0[d][t] = __builtin_fmaf(xv, gz[t], gW0[d][t]);
+                }
+            }
+            wave_sync();
         }
     }
 
-    // ---- write this wavefront's partial row ------------------------------------------
+    // ---- fold the wavefronts of this workgroup in a fixed order, write ONE partial row --------
+    __syncthreads();   // every wave is done with the weight fragments: the fold buffer aliases them
     if (MODE == MODE_LOSS) {
+        double* red = reinterpret_cast<double*>(smem);
         const double l = wave_sum(acc_loss), k = wave_sum(acc_kl), v = wave_sum(acc_vpg);
         const float mk = wave_max(max_kl);
         if (lane == 0) {
-            double* row = a.partial_loss + (size_t)wave_global * LOSS_COLS;
-            row[0] = l; row[1] = k; row[2] = v; row[3] = (double)mk;
+            red[wave * LOSS_COLS + 0] = l; red[wave * LOSS_COLS + 1] = k;
+            red[wave * LOSS_COLS + 2] = v; red[wave * LOSS_COLS + 3] = (double)mk;
+        }
+        __syncthreads();
+        if (threadIdx.x < LOSS_COLS) {
+            const int c = threadIdx.x;
+            double s = red[c];
+            for (int w = 1; w < WAVES; ++w) s = (c == 3) ? fmax(s, red[w * LOSS_COLS + c]) : s + red[w * LOSS_COLS + c];
+            a.partial_loss[(size_t)blockIdx.x * LOSS_COLS + c] = s;
         }
     } else {
-        float* row = a.partial + (size_t)wave_global * P;
+        float* red = smem + S::RED;
+        for (int k = threadIdx.x; k < P; k += WAVES * WV) red[k] = 0.0f;
+        __syncthreads();
+        // half-pair sums (both sample parities of the transposed-role accumulators)
+        float w0s[DO + 1][HT], w2s[HT][DA], b1s[HT];
 #pragma unroll
-        for (int r = 0; r < R0; ++r) {
-            const int i = g0 * R0 + r;
-            if (i < DO) row[N::W0 + i * H0 + j0] = gW0[r];
+        for (int t = 0; t < HT; ++t) {
+            b1s[t] = half_sum(gb1[t]);
+#pragma unroll
+            for (int d = 0; d <= DO; ++d) w0s[d][t] = half_sum(gW0[d][t]);
+#pragma unroll
+            for (int k = 0; k < DA; ++k) w2s[t][k] = half_sum(gW2[t][k]);
         }
-        if (g0 == 0) row[N::B0 + j0] = gb0;
+        float b2s[DA], lss[DA];
 #pragma unroll
-        for (int r = 0; r < R1; ++r) row[N::W1 + (g1 * R1 + r) * H1 + j1] = gW1[r];
-        if (g1 == 0) row[N::B1 + j1] = gb1;
+        for (int k = 0; k < DA; ++k) { b2s[k] = wave_sum(gb2[k]); lss[k] = wave_sum(gls[k]); }
+        const float ws = wave_sum(wsum);
+        for (int w = 0; w < WAVES; ++w) {
+            if (wave == w) {
 #pragma unroll
-        for (int r = 0; r < E2; ++r) {
-            const int e = r * WV + lane;
-            if (e < H1 * DA) row[N::W2 + e] = gW2[r];
-        }
-        if (lane < DA) row[N::B2 + lane] = gb2;
-        if (MODE == MODE_FVP) {
-            // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
-            const float ws = wave_sum(wsum);
-            if (lane < DA) {
-                float c = 0.0f;
+                for (int ti = 0; ti < HT; ++ti)
 #pragma unroll
-                for (int k = 0; k < DA; ++k)
-                    if (k == lane) {
-                        const float vv = var_[k], e = 1e-8f;
-                        c = floored[k] ? 0.0f
-                                       : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+                    for (int tj = 0; tj < HT; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            red[N::W1 + (32 * ti + frag_unit(r, 0) + 4 * lh) * H + 32 * tj + lj] += gW1[ti][tj][r];
+                if (lh == 0) {
+#pragma unroll
+                    for (int t = 0; t < HT; ++t) {
+#pragma unroll
+                        for (int d = 0; d < DO; ++d) red[N::W0 + d * H + 32 * t + lj] += w0s[d][t];
+                        red[N::B0 + 32 * t + lj] += w0s[DO][t];
+                        red[N::B1 + 32 * t + lj] += b1s[t];
+#pragma unroll
+                        for (int k = 0; k < DA; ++k) red[N::W2 + (32 * t + lj) * DA + k] += w2s[t][k];
                     }
-                row[N::LSTD + lane] = c * sv[N::LSTD + lane] * ws;
-            }
-        } else {
+                }
+                if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < DA; ++k) {
-                const float s = wave_sum(gls[k]);
-                if (lane == 0) row[N::LSTD + k] = s;
+                    for (int k = 0; k < DA; ++k) {
+                        red[N::B2 + k] += b2s[k];
+                        if (FVP) {
+                            // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
+                            const float vv = var_[k], e = 1e-8f;
+                            const float c = floored[k] ? 0.0f
+                                                       : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+                            red[N::LSTD + k] += c * a.vec[N::LSTD + k] * ws;
+                        } else {
+                            red[N::LSTD + k] += lss[k];
+                        }
+                    }
+                }
             }
+            __syncthreads();
         }
+        float* row = a.partial + (size_t)blockIdx.x * P;
+        for (int k = threadIdx.x; k < P; k += WAVES * WV) row[k] = red[k];
     }
 }
 
-// out[c] = sum_r partial[r][c] in float64, fixed order (deterministic).
-__global__ void reduce_rows_f32_kernel(const float* __restrict__ partial, int rows, int cols,
-                                       double* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// out[c] = sum_r partial[r][c] in float64, fixed order (deterministic): a workgroup owns 64
+// columns, 16 wavefronts take interleaved rows, their partials meet in LDS in wave order.
+constexpr int RR_WAVES = 16;
+__global__ void __launch_bounds__(RR_WAVES * WV) reduce_rows_kernel(const float* __restrict__ partial, int rows,
+                                                                     int cols, double* __restrict__ out) {
+    __shared__ double part[RR_WAVES][WV];
+    const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
+    const int c = blockIdx.x * WV + lane;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int r = wave; r < rows; r += RR_WAVES) s += (double)partial[(size_t)r * cols + c];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        double t = part[0][lane];
+        for (int w = 1; w < RR_WAVES; ++w) t += part[w][lane];
+        out[c] = t;
+    }
 }
 
-// loss partials: columns 0..2 summed, column 3 maxed
-__global__ void reduce_loss_kernel(const double* __restrict__ partial, int rows, double* __restrict__ out) {
-    const int c = threadIdx.x;
-    if (c >= LOSS_COLS) return;
+// loss partials: columns 0..2 summed, column 3 maxed; one wavefront per column
+__global__ void __launch_bounds__(LOSS_COLS * WV) reduce_loss_kernel(const double* __restrict__ partial, int rows,
+                                                                     double* __restrict__ out) {
+    const int c = threadIdx.x / WV, lane = threadIdx.x % WV;
     double s = (c == 3) ? -INFINITY : 0.0;
-    for (int r = 0; r < rows; ++r) {
+    for (int r = lane; r < rows; r += WV) {
         const double v = partial[(size_t)r * LOSS_COLS + c];
         s = (c == 3) ? fmax(s, v) : s + v;
     }
-    out[c] = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v = __shfl_xor(s, o, WV);
+        s = (c == 3) ? fmax(s, v) : s + v;
+    }
+    if (lane == 0) out[c] = s;
 }
 
-template <class N, int MODE, int WAVES>
-static size_t pass_lds_bytes() {
-    size_t f = N::PP + (MODE == MODE_FVP ? N::PP : 0) + (MODE != MODE_LOSS ? N::H0 * N::H1 : 0) +
-               (size_t)WAVES * (2 * N::TILE + N::DA * LS);
-    return f * sizeof(float);
-}
+constexpr int MAX_GRID = 256 * 3;   // workgroups of a pass: <= 3 per CU
 
-template <class N, int MODE, int WAVES>
+template <class N, int MODE>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
                        double* out, hipStream_t st) {
+    using S = Smem<N, MODE>;
     PolicyBatch a;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
-    const int n_tiles = (a.B + WV - 1) / WV;
-    const size_t lds = pass_lds_bytes<N, MODE, WAVES>();
+    const int n_tiles = (a.B + TS - 1) / TS;
+    const size_t lds = (size_t)S::TOTAL * sizeof(float);
+    if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "policy pass needs %zu B of LDS", lds);
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu < 1) return set_error(RL_ERR_UNSUPPORTED, "policy pass needs %zu B of LDS", lds);
-    if (blocks_per_cu > 8) blocks_per_cu = 8;
+    if (blocks_per_cu > N::WPS) blocks_per_cu = N::WPS;
     int grid = 256 * blocks_per_cu;
     const int need = (n_tiles + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    const int rows = grid * WAVES;
-    const size_t need_bytes = (MODE == MODE_LOSS) ? (size_t)rows * LOSS_COLS * sizeof(double)
-                                                  : (size_t)rows * N::P * sizeof(float);
+    if (grid > MAX_GRID) grid = MAX_GRID;
+    const size_t need_bytes = (MODE == MODE_LOSS) ? (size_t)grid * LOSS_COLS * sizeof(double)
+                                                  : (size_t)grid * N::P * sizeof(float);
     if (workspace_bytes < need_bytes)
         return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", workspace_bytes,
                          need_bytes);
     a.partial = (float*)workspace;
     a.partial_loss = (double*)workspace;
-    auto kern = policy_pass_kernel<N, MODE, WAVES>;
+    auto kern = policy_pass_kernel<N, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * WV), lds, st, a);
     int rc = check_launch("policy_pass_kernel");
     if (rc) return rc;
     if (MODE == MODE_LOSS) {
-        hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(64), 0, st, a.partial_loss, rows, out);
+        hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(LOSS_COLS * WV), 0, st, a.partial_loss, grid, out);
     } else {
-        hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((N::P + 255) / 256), dim3(256), 0, st, a.partial, rows,
-                           N::P, out);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((N::P + WV - 1) / WV), dim3(RR_WAVES * WV), 0, st, a.partial,
+                           grid, N::P, out);
     }
     return check_launch("policy reduce kernel");
 }
 
-template <class N, int WAVES>
+template <class N>
 static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
                          double* out, hipStream_t st) {
     switch (mode) {
-        case MODE_LOSS: return launch_pass<N, MODE_LOSS, WAVES>(g, vec, ws, ws_bytes, out, st);
-        case MODE_GRAD: return launch_pass<N, MODE_GRAD, WAVES>(g, vec, ws, ws_bytes, out, st);
-        case MODE_FVP: return launch_pass<N, MODE_FVP, WAVES>(g, vec, ws, ws_bytes, out, st);
-        case MODE_VPG: return launch_pass<N, MODE_VPG, WAVES>(g, vec, ws, ws_bytes, out, st);
+        case MODE_LOSS: return launch_pass<N, MODE_LOSS>(g, vec, ws, ws_bytes, out, st);
+        case MODE_GRAD: return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st);
+        case MODE_FVP: return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st);
+        case MODE_VPG: return launch_pass<N, MODE_VPG>(g, vec, ws, ws_bytes, out, st);
     }
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
 }
@@ -497,16 +676,16 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
                         double* out, hipStream_t st) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
-#define NETCASE(DO, DA, H, WAVES) \
-    if (d == DO && k == DA && h0 == H && h1 == H) return dispatch_mode<Net<DO, DA, H, H>, WAVES>(mode, g, vec, ws, ws_bytes, out, st);
-    NETCASE(4, 1, 32, 2)    // Cartpole
-    NETCASE(6, 1, 32, 2)    // DoublePendulum
-    NETCASE(13, 2, 32, 2)   // Swimmer
-    NETCASE(20, 6, 32, 2)   // HalfCheetah
-    NETCASE(4, 1, 64, 2)
-    NETCASE(6, 1, 64, 2)
-    NETCASE(13, 2, 64, 2)
-    NETCASE(20, 6, 64, 2)
+#define NETCASE(DO, DA, H) \
+    if (d == DO && k == DA && h0 == H && h1 == H) return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st);
+    NETCASE(4, 1, 32)    // Cartpole
+    NETCASE(6, 1, 32)    // DoublePendulum
+    NETCASE(13, 2, 32)   // Swimmer
+    NETCASE(20, 6, 32)   // HalfCheetah
+    NETCASE(4, 1, 64)
+    NETCASE(6, 1, 64)
+    NETCASE(13, 2, 64)
+    NETCASE(20, 6, 64)
 #undef NETCASE
     return set_error(RL_ERR_UNSUPPORTED,
                      "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d); the torch autograd "
@@ -525,10 +704,10 @@ static int check_batch(const rl_policy_batch* g, const char* who) {
 }
 
 extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1) {
-    // rows <= 256 CUs * 8 blocks * 2 waves; row = P floats (or LOSS_COLS doubles)
+    // one partial row per workgroup: P floats (or LOSS_COLS doubles)
     const size_t P = (size_t)obs_dim * hidden0 + hidden0 + (size_t)hidden0 * hidden1 + hidden1 +
                      (size_t)hidden1 * act_dim + 2 * (size_t)act_dim;
-    const size_t rows = 256 * 8 * 2;
+    const size_t rows = MAX_GRID;
     const size_t a = rows * P * sizeof(float), b = rows * LOSS_COLS * sizeof(double);
     return a > b ? a : b;
 }
