@@ -185,6 +185,20 @@ int rl_policy_grad(const rl_policy_batch* batch, int vpg, void* workspace, size_
 int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspace,
                   size_t workspace_bytes, double* fvp_out, void* stream);
 
+/* Vector algebra of krylov.cg (rllab/misc/krylov.py:7-39) for the TRPO descent direction
+ * (conjugate_gradient_optimizer.py:253-256), one launch per iteration, float64 like the reference.
+ *   rl_cg_init : x = 0, r = p = b, p32 = (float)p, scal = {r.r, active = 1, 0, 0}
+ *   rl_cg_step : given fvp = F p (rl_policy_fvp output, already summed over ranks):
+ *                z = fvp + reg_coeff p; v = rdotr / p.z; x += v p; r -= v z; mu = r.r / rdotr;
+ *                p = r + mu p; p32 = (float)p; the `rdotr < residual_tol: break` of the reference
+ *                freezes x, r, p from then on (scal[1] = 0) instead of returning to the host.
+ * n <= 16384; b, x, r, p, fvp: double[n]; p32: float[n]; scal: double[4] = {rdotr, active,
+ * last p.Ap, steps taken}.  All device pointers. */
+int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p32, double* scal,
+               void* stream);
+int rl_cg_step(int n, const double* fvp, double reg_coeff, double residual_tol, double* x, double* r,
+               double* p, float* p32, double* scal, void* stream);
+
 /* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
  * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */
 int rl_debug_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

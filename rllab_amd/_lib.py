@@ -24,7 +24,7 @@ SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_rollout_gaussian_mlp", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_loss_kl",
-    "rl_policy_grad", "rl_policy_fvp",
+    "rl_policy_grad", "rl_policy_fvp", "rl_cg_init", "rl_cg_step",
 ]
 
 
@@ -81,6 +81,8 @@ def _load():
     lib.rl_policy_loss_kl.argtypes = [pb, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_grad.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]
+    lib.rl_cg_init.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.rl_cg_step.argtypes = [i32, vp, f64, f64, vp, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = header / library mismatch
     return lib

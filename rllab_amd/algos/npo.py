@@ -84,6 +84,9 @@ class NPO(BatchPolopt):
         logger.record_tabular('MeanKLBefore', mean_kl_before)
         logger.record_tabular('MeanKL', mean_kl)
         logger.record_tabular('dLoss', loss_before - loss_after)
+        fused = getattr(self.optimizer, "_fused", None)
+        if fused is not None:
+            fused.release()   # drop the cached batch descriptor (it keeps the batch tensors alive)
         return dict()
 
     def get_itr_snapshot(self, itr, samples_data):

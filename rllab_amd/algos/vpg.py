@@ -65,6 +65,9 @@ class VPG(BatchPolopt, Serializable):
         mean_kl, max_kl = self.opt_info['f_kl'](inputs)
         logger.record_tabular('MeanKL', mean_kl)
         logger.record_tabular('MaxKL', max_kl)
+        fused = getattr(self.optimizer, "_fused", None)
+        if fused is not None:
+            fused.release()
 
     def get_itr_snapshot(self, itr, samples_data):
         return dict(itr=itr, policy=self.policy, baseline=self.baseline, env=self.env)

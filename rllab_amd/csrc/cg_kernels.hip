@@ -1,0 +1,124 @@
+// cg_kernels.hip -- the vector algebra of one conjugate-gradient iteration as ONE launch.
+//
+// Replaces the NumPy body of krylov.cg (rllab/misc/krylov.py:7-39) as called from
+// ConjugateGradientOptimizer.optimize (rllab/optimizers/conjugate_gradient_optimizer.py:253-256):
+//     z = f_Ax(p);  v = rdotr / p.z;  x += v p;  r -= v z;  newrdotr = r.r;
+//     mu = newrdotr / rdotr;  p = r + mu p;  rdotr = newrdotr;  if rdotr < tol: break
+// with f_Ax(p) = F p + reg_coeff * p, where F p (the Fisher-vector product summed over all
+// ranks) is produced by rl_policy_fvp.  Everything is float64, as in the reference; the next
+// search direction is also emitted in float32 because that is what rl_policy_fvp consumes.
+// The early exit is a device-side `active` flag: once the residual test fires, x / r / p are
+// frozen, so the host never has to look at rdotr inside the loop (no synchronisation).
+// P <= a few thousand: one workgroup, each thread owns a fixed strided set of elements, dot
+// products are reduced through LDS in a fixed order (deterministic, identical on all ranks).
+#include <hip/hip_runtime.h>
+#include "../../include/rllab_amd.h"
+#include "capi_util.h"
+
+namespace rl {
+
+constexpr int CG_THREADS = 1024;
+constexpr int CG_MAX_PER_THREAD = 16;   // n <= 16384 parameters
+
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    // wavefront butterfly, then the 16 wave sums in order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < CG_THREADS / 64; ++w) s += scratch[w];
+    return s;
+}
+
+// scal[0] = rdotr, scal[1] = active (1 / 0), scal[2] = p.Ap of the last step, scal[3] = steps taken
+__global__ void __launch_bounds__(CG_THREADS) cg_init_kernel(int n, const double* __restrict__ b,
+                                                             double* __restrict__ x, double* __restrict__ r,
+                                                             double* __restrict__ p, float* __restrict__ p32,
+                                                             double* __restrict__ scal) {
+    __shared__ double scratch[CG_THREADS / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += CG_THREADS) {
+        const double bi = b[i];
+        x[i] = 0.0; r[i] = bi; p[i] = bi; p32[i] = (float)bi;
+        acc += bi * bi;
+    }
+    const double rdotr = block_sum(acc, scratch);
+    if (threadIdx.x == 0) { scal[0] = rdotr; scal[1] = 1.0; scal[2] = 0.0; scal[3] = 0.0; }
+}
+
+__global__ void __launch_bounds__(CG_THREADS) cg_step_kernel(int n, const double* __restrict__ fp, double reg,
+                                                             double tol, double* __restrict__ x,
+                                                             double* __restrict__ r, double* __restrict__ p,
+                                                             float* __restrict__ p32, double* __restrict__ scal) {
+    __shared__ double scratch[CG_THREADS / 64];
+    const double rdotr = scal[0];
+    const bool active = scal[1] != 0.0;
+    double z[CG_MAX_PER_THREAD], pv[CG_MAX_PER_THREAD];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CG_THREADS;
+        if (i < n) {
+            pv[k] = p[i];
+            z[k] = fp[i] + reg * pv[k];      // Hx = F p + reg_coeff * p
+            acc += pv[k] * z[k];
+        }
+    }
+    const double pz = block_sum(acc, scratch);
+    if (!active) return;                     // wave-uniform: scal[1] is one value for the whole grid
+    const double v = rdotr / pz;
+    double rn[CG_MAX_PER_THREAD];
+    acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CG_THREADS;
+        if (i < n) {
+            x[i] += v * pv[k];
+            rn[k] = r[i] - v * z[k];
+            r[i] = rn[k];
+            acc += rn[k] * rn[k];
+        }
+    }
+    const double newrdotr = block_sum(acc, scratch);
+    const double mu = newrdotr / rdotr;
+#pragma unroll
+    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CG_THREADS;
+        if (i < n) {
+            const double pn = rn[k] + mu * pv[k];
+            p[i] = pn;
+            p32[i] = (float)pn;
+        }
+    }
+    if (threadIdx.x == 0) {
+        scal[0] = newrdotr;
+        scal[1] = (newrdotr >= tol) ? 1.0 : 0.0;
+        scal[2] = pz;
+        scal[3] += 1.0;
+    }
+}
+
+}  // namespace rl
+
+using namespace rl;
+
+extern "C" int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p32, double* scal,
+                          void* stream) {
+    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !b || !x || !r || !p || !p32 || !scal)
+        return set_error(RL_ERR_ARG, "rl_cg_init: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, b, x, r, p, p32, scal);
+    return check_launch("cg_init_kernel");
+}
+
+extern "C" int rl_cg_step(int n, const double* fvp, double reg_coeff, double residual_tol, double* x, double* r,
+                          double* p, float* p32, double* scal, void* stream) {
+    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !fvp || !x || !r || !p || !p32 || !scal)
+        return set_error(RL_ERR_ARG, "rl_cg_step: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
+    hipLaunchKernelGGL(cg_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, fvp, reg_coeff,
+                       residual_tol, x, r, p, p32, scal);
+    return check_launch("cg_step_kernel");
+}

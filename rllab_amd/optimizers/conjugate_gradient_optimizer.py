@@ -216,10 +216,17 @@ class ConjugateGradientOptimizer(Serializable):
         if self._fused is not None and not self._hvp_given and self._fused_for(inputs) is None:
             hvp = PerlmutterHvp(self._num_slices)   # batch the fused kernels cannot take
             hvp.update_opt(f=self._constraint, target=target, inputs=None, reg_coeff=self._reg_coeff)
-        Hx = hvp.build_eval(subsample_inputs, idx)
-        descent_direction = krylov.cg(Hx, flat_g, cg_iters=self._cg_iters)
-        initial_step_size = torch.sqrt(
-            2.0 * self._max_constraint_val * (1. / (descent_direction.dot(Hx(descent_direction)) + 1e-8)))
+        from rllab_amd.policies.fused_ops import FusedFisherHvp
+        fused_cg = (self._fused_for(subsample_inputs) is not None and isinstance(hvp, FusedFisherHvp)
+                    and idx is None)
+        if fused_cg:
+            # device-side CG: FVP kernel + one vector-algebra kernel per iteration (policies/fused_ops.py)
+            descent_direction, dHd = self._fused.cg(subsample_inputs, flat_g, self._cg_iters, self._reg_coeff)
+        else:
+            Hx = hvp.build_eval(subsample_inputs, idx)
+            descent_direction = krylov.cg(Hx, flat_g, cg_iters=self._cg_iters)
+            dHd = descent_direction.dot(Hx(descent_direction))
+        initial_step_size = torch.sqrt(2.0 * self._max_constraint_val * (1. / (dHd + 1e-8)))
         initial_step_size = torch.where(torch.isnan(initial_step_size),
                                         torch.ones_like(initial_step_size), initial_step_size)
         flat_descent_step = initial_step_size * descent_direction

@@ -21,8 +21,7 @@ class FusedGaussianMLPOps(object):
         assert len(hs) == 2 and policy.fusable
         self.dims = (policy.obs_dim, policy.action_dim, hs[0], hs[1])
         self._ws = None
-        self._cache_key = None
-        self._cache_val = None
+        self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
 
     @staticmethod
     def supported(policy):
@@ -41,29 +40,47 @@ class FusedGaussianMLPOps(object):
             self._ws = torch.empty(n, dtype=torch.uint8, device=device)
         return self._ws
 
-    def _batch(self, inputs, theta=None):
+    def _batch(self, inputs):
+        """The C-ABI batch descriptor of an input tuple.  Built once per tuple (one update uses
+        the same tuple for ~30 passes): contiguity fix-ups, pointer extraction and the one
+        host read of 1/W happen here, not per pass."""
+        key = tuple(id(t) for t in inputs)
+        hit = self._bound.get(key)
+        if hit is not None:
+            return hit
         obs, act, adv, old_mean, old_log_std, w, inv_count = inputs
-        theta = self.policy.flat_params.detach() if theta is None else theta
+        theta = self.policy.flat_params.detach()
         keep = [t.contiguous() for t in (obs, act, adv, old_mean, old_log_std.reshape(-1).float(), w, theta)]
         obs, act, adv, old_mean, old_ls, w, theta = keep
+        assert theta.data_ptr() == self.policy.flat_params.data_ptr()   # updates are in place
         pol = self.policy
+        inv = float(inv_count)
         b = _lib.PolicyBatch(
             n_samples=obs.shape[-1], obs_dim=self.dims[0], act_dim=self.dims[1], hidden0=self.dims[2],
-            hidden1=self.dims[3], inv_count=float(inv_count),
+            hidden1=self.dims[3], inv_count=inv,
             log_min_std=math.log(pol.min_std) if pol.min_std is not None else -1e30,
             theta=theta.data_ptr(), obs=obs.data_ptr(), actions=act.data_ptr(), advantages=adv.data_ptr(),
             old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(), weights=w.data_ptr())
-        return b, keep
+        if len(self._bound) >= 2:   # full batch + (optionally) its FVP subsample
+            self._bound.clear()
+        self._bound[key] = (b, keep + list(inputs), inv)
+        return self._bound[key]
+
+    def release(self):
+        """Drop the cached descriptor (and the batch tensors it keeps alive)."""
+        self._bound.clear()
 
     def loss_stats(self, inputs):
         """[sum w lr adv, sum w KL, sum w logp adv] * inv_count (global) and max KL, as a
         float64 device tensor of 4."""
-        b, keep = self._batch(inputs)
+        b, keep, inv = self._batch(inputs)
         ws = self._workspace(keep[0].device)
         out = torch.empty(4, dtype=torch.float64, device=keep[0].device)
         _lib.check(_lib.lib.rl_policy_loss_kl(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
                                               _lib.stream_ptr()), "rl_policy_loss_kl")
-        sums = out[:3] * float(inputs[-1])
+        if not D.is_distributed():
+            return torch.cat([out[:3] * inv, out[3:4]])
+        sums = out[:3] * inv
         D.all_reduce_sum_(sums)
         mx = D.all_reduce_max_(out[3:4].clone())
         return torch.cat([sums, mx])
@@ -73,21 +90,52 @@ class FusedGaussianMLPOps(object):
         return -s[0], s[1]
 
     def loss_grad(self, inputs, vpg=False):
-        b, keep = self._batch(inputs)
+        b, keep, _ = self._batch(inputs)
         ws = self._workspace(keep[0].device)
         out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
         _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
                                            _lib.stream_ptr()), "rl_policy_grad")
         return D.all_reduce_sum_(out)
 
+    def _fvp_into(self, b, ws, vec32, out):
+        _lib.check(_lib.lib.rl_policy_fvp(ctypes.byref(b), _lib.ptr(vec32), _lib.ptr(ws), ws.numel(),
+                                          _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
+        return D.all_reduce_sum_(out)
+
     def fvp(self, inputs, vec):
-        b, keep = self._batch(inputs)
+        b, keep, _ = self._batch(inputs)
         ws = self._workspace(keep[0].device)
         v = vec.to(torch.float32).contiguous()
         out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
-        _lib.check(_lib.lib.rl_policy_fvp(ctypes.byref(b), _lib.ptr(v), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
-                                          _lib.stream_ptr()), "rl_policy_fvp")
-        return D.all_reduce_sum_(out)
+        return self._fvp_into(b, ws, v, out)
+
+    def cg(self, inputs, g, cg_iters, reg_coeff, residual_tol=1e-10):
+        """krylov.cg (rllab/misc/krylov.py:7-39) on Hx = F x + reg_coeff x with the vector algebra of
+        each iteration in ONE launch (rl_cg_step) between the Fisher-vector-product passes: two
+        kernels + one all-reduce per iteration, no host synchronisation.
+        Returns (x, x^T H x) as float64 device tensors."""
+        b, keep, _ = self._batch(inputs)
+        dev = keep[0].device
+        ws = self._workspace(dev)
+        n = self.policy.flat_params.numel()
+        f64 = dict(dtype=torch.float64, device=dev)
+        g = g.to(torch.float64).contiguous()
+        x, r, p, z = (torch.empty(n, **f64) for _ in range(4))
+        p32 = torch.empty(n, dtype=torch.float32, device=dev)
+        scal = torch.empty(4, **f64)
+        st = _lib.stream_ptr()
+        _lib.check(_lib.lib.rl_cg_init(n, _lib.ptr(g), _lib.ptr(x), _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32),
+                                       _lib.ptr(scal), st), "rl_cg_init")
+        for _ in range(cg_iters):
+            self._fvp_into(b, ws, p32, z)
+            _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
+                                           _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
+                       "rl_cg_step")
+        # x^T H x for the initial step size (conjugate_gradient_optimizer.py:258-260)
+        x32 = x.to(torch.float32)
+        self._fvp_into(b, ws, x32, z)
+        xHx = x.dot(z + float(reg_coeff) * x)
+        return x, xHx
 
     def hvp_approach(self):
         return FusedFisherHvp(self)

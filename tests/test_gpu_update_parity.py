@@ -178,3 +178,46 @@ def test_trpo_step_fused_matches_oracle_control_flow(quiet_logger):
     assert step > 0 and not info["rejected"]
     assert np.abs(got - want).max() <= 2e-3 * step
     assert opt.last_backtrack_iters == info["backtrack_iters"]
+
+
+def test_device_cg_matches_krylov_and_oracle():
+    """rl_cg_init / rl_cg_step + rl_policy_fvp (FusedGaussianMLPOps.cg) == krylov.cg on the same
+    operator == the numpy restatement of the reference krylov.cg (oracle) on the float64
+    autograd Hessian-vector product."""
+    from oracle import np_reference as R
+    from rllab_amd.misc import krylov
+    pol = _policy(13, 2, 32)
+    ops = pol.fused_ops()
+    inp = _inputs(pol, 30000, old_equals_new=True)
+    rng = np.random.RandomState(5)
+    n = pol.flat_params.numel()
+    g = torch.as_tensor(rng.randn(n) * 1e-2, device="cuda")
+    reg = 1e-5
+    x_dev, xHx = ops.cg(inp, g, 10, reg)
+    hx = ops.hvp_approach()
+    hx.update_opt(None, pol, None, reg)
+    f = hx.build_eval(inp)
+    x_t = krylov.cg(f, g, cg_iters=10)
+    assert float((x_dev - x_t).abs().max()) <= 1e-9 * float(x_t.abs().max())
+    assert abs(float(xHx) - float(x_t.dot(f(x_t)))) <= 1e-6 * abs(float(xHx))
+    # oracle: reference CG loop in numpy on the float64 autograd HVP
+    _, kl, _ = _closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    with torch.no_grad():
+        om64 = pol.mean_planes(inp[0].double(), flat64.detach())
+    inp64 = (inp[0], inp[1], inp[2], om64, pol.effective_log_std().detach().double().reshape(-1, 1), inp[5], inp[6])
+    gk = torch.autograd.grad(kl(flat64, *inp64), flat64, create_graph=True)[0]
+
+    def f_Ax(v):
+        vt = torch.as_tensor(v, device="cuda")
+        return (torch.autograd.grad((gk * vt).sum(), flat64, retain_graph=True)[0] + reg * vt).cpu().numpy()
+    x_np = R.cg(f_Ax, g.cpu().numpy(), cg_iters=10)
+    assert np.abs(x_dev.cpu().numpy() - x_np).max() <= 2e-3 * np.abs(x_np).max()
+    # early exit: a tiny right-hand side trips `rdotr < residual_tol` after the first iteration; the
+    # device loop freezes x there, exactly where the reference breaks out
+    g_small = g * 1e-6
+    x1, _ = ops.cg(inp, g_small, 10, reg)
+    x1_np = R.cg(f_Ax, g_small.cpu().numpy(), cg_iters=10)
+    x1_one = R.cg(f_Ax, g_small.cpu().numpy(), cg_iters=1)
+    assert np.array_equal(x1_np, x1_one)                      # the oracle did stop after one iteration
+    assert np.abs(x1.cpu().numpy() - x1_np).max() <= 2e-3 * np.abs(x1_np).max()
