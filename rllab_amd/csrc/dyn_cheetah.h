@@ -55,6 +55,8 @@ struct CheetahModel {
     template <typename R>
     RL_HD static void external(const R* q, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {
         RL_UNROLL
+        for (int i = 0; i < NB; ++i) { fx[i] = (R)0; fy[i] = (R)0; tz[i] = (R)0; }
+        RL_UNROLL
         for (int c = 0; c < cheetah::NC; ++c) {
             const int b = cheetah::CBODY[c];
             const R lx = (R)cheetah::CPX[c], ly = (R)cheetah::CPY[c];
@@ -141,7 +143,9 @@ struct HalfCheetah {
         R q[9], qd[9];
         RL_UNROLL
         for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
-        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025);
+        R sn[CheetahModel::NB], cs[CheetahModel::NB];
+        Tree::template angles<R>(q, sn, cs);
+        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025, sn, cs);
         RL_UNROLL
         for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
         R cz, cx, vz, vx;

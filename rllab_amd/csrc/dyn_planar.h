@@ -27,6 +27,7 @@
 // plus a static `external(...)` hook adding per-body world forces / torques
 // (fluid drag, ground contact).
 #pragma once
+#include <type_traits>
 #include "rl_math.h"
 
 #if defined(__HIPCC__)
@@ -36,6 +37,41 @@
 #endif
 
 namespace rl {
+
+// Compile-time loops: the body sees the index as a constant expression, so model constants
+// (joint offsets, COM offsets, gravity, armature ...) can be tested with `if constexpr` and
+// structurally-zero terms vanish from the instruction stream.  IEEE arithmetic forbids the
+// optimiser from folding x*0 or x+0 itself, and one env is one dependent instruction chain
+// per wavefront, so every such term costs issue slots on the critical path.
+template <int I, int N, class F>
+RL_HD void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int I, int N, class F>   // I-1, I-2, ..., N
+RL_HD void static_for_down(F&& f) {
+    if constexpr (I > N) {
+        f(std::integral_constant<int, I - 1>{});
+        static_for_down<I - 1, N>(f);
+    }
+}
+
+// (ox, oy) = R(cs, sn) * (CX, CY) for compile-time constants CX, CY
+#define RL_ROTC(cs_, sn_, CX, CY, ox, oy)                 \
+    do {                                                  \
+        if constexpr ((CY) == 0.0) {                      \
+            ox = (cs_) * (R)(CX);                         \
+            oy = (sn_) * (R)(CX);                         \
+        } else if constexpr ((CX) == 0.0) {               \
+            ox = -((sn_) * (R)(CY));                      \
+            oy = (cs_) * (R)(CY);                         \
+        } else {                                          \
+            ox = (cs_) * (R)(CX) - (sn_) * (R)(CY);       \
+            oy = (sn_) * (R)(CX) + (cs_) * (R)(CY);       \
+        }                                                 \
+    } while (0)
 
 template <typename R, int NB>
 struct PlanarKin {
@@ -51,41 +87,141 @@ template <class Mdl>
 struct PlanarTree {
     static constexpr int NB = Mdl::NB;
     static constexpr int NV = NB + 2;
+    static constexpr bool HAS_GRAVITY = (Mdl::gx() != 0.0) || (Mdl::gy() != 0.0);
+
+    // is body A an ancestor of (or equal to) body B?
+    static constexpr bool is_ancestor(int a, int b) {
+        while (b > a) b = Mdl::parent(b);
+        return a == b;
+    }
+    static constexpr double total_mass() {
+        double m = 0.0;
+        for (int i = 0; i < NB; ++i) m += Mdl::mass(i);
+        return m;
+    }
+
+    // exact sin / cos of every absolute body angle
+    template <typename R>
+    RL_HD static void angles(const R* q, R* sn, R* cs) {
+        R phi[NB];
+        phi[0] = q[2];
+        static_for<1, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
+            phi[i] = phi[p] + q[2 + i];
+        });
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            rl_sincos(phi[i], sn[i], cs[i]);
+        });
+    }
 
     // positions / velocities of every body from (q, qd)
     template <typename R>
     RL_HD static void kinematics(const R* q, const R* qd, PlanarKin<R, NB>& k) {
-        R phi[NB];
-        phi[0] = q[2];
+        angles(q, k.sn, k.cs);
+        kinematics_sc(qd, k);
+    }
+
+    // the same with k.sn / k.cs already filled in
+    template <typename R>
+    RL_HD static void kinematics_sc(const R* qd, PlanarKin<R, NB>& k) {
         k.om[0] = qd[2];
-        RL_UNROLL
-        for (int i = 1; i < NB; ++i) {
-            phi[i] = phi[Mdl::parent(i)] + q[2 + i];
-            k.om[i] = k.om[Mdl::parent(i)] + qd[2 + i];
-        }
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) rl_sincos(phi[i], k.sn[i], k.cs[i]);
+        static_for<1, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
+            k.om[i] = k.om[p] + qd[2 + i];
+        });
         k.ax[0] = (R)0; k.ay[0] = (R)0;
         k.vax[0] = qd[0]; k.vay[0] = qd[1];
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            if (i > 0) {
-                const int p = Mdl::parent(i);
-                const R jx = (R)Mdl::jx(i), jy = (R)Mdl::jy(i);
-                const R dx = k.cs[p] * jx - k.sn[p] * jy;   // R(phi_p) * joint offset
-                const R dy = k.sn[p] * jx + k.cs[p] * jy;
-                k.ax[i] = k.ax[p] + dx;
-                k.ay[i] = k.ay[p] + dy;
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i > 0) {
+                constexpr int p = Mdl::parent(i);
+                constexpr double JX = Mdl::jx(i), JY = Mdl::jy(i);
+                R dx, dy;                                   // R(phi_p) * joint offset
+                RL_ROTC(k.cs[p], k.sn[p], JX, JY, dx, dy);
+                if constexpr (p == 0) {                     // the root anchor is the origin
+                    k.ax[i] = dx;
+                    k.ay[i] = dy;
+                } else {
+                    k.ax[i] = k.ax[p] + dx;
+                    k.ay[i] = k.ay[p] + dy;
+                }
                 k.vax[i] = k.vax[p] - k.om[p] * dy;         // + Omega_p x d
                 k.vay[i] = k.vay[p] + k.om[p] * dx;
             }
-            const R cx = (R)Mdl::cx(i), cy = (R)Mdl::cy(i);
-            const R ex = k.cs[i] * cx - k.sn[i] * cy;       // R(phi_i) * com offset
-            const R ey = k.sn[i] * cx + k.cs[i] * cy;
-            k.px[i] = k.ax[i] + ex;
-            k.py[i] = k.ay[i] + ey;
+            constexpr double CX = Mdl::cx(i), CY = Mdl::cy(i);
+            R ex, ey;                                       // R(phi_i) * com offset
+            RL_ROTC(k.cs[i], k.sn[i], CX, CY, ex, ey);
+            if constexpr (i == 0) {
+                k.px[i] = ex;
+                k.py[i] = ey;
+            } else {
+                k.px[i] = k.ax[i] + ex;
+                k.py[i] = k.ay[i] + ey;
+            }
             k.vpx[i] = k.vax[i] - k.om[i] * ey;
             k.vpy[i] = k.vay[i] + k.om[i] * ex;
+        });
+    }
+
+    // Solve the symmetric positive definite system S x = b (S given by its lower triangle,
+    // destroyed).  N == 3 (a 3-link chain): closed-form adjugate solve -- ONE division on the
+    // critical path instead of three sequential pivots; otherwise LDL^T.
+    template <typename R, int N>
+    RL_HD static void solve_spd(R (&S)[N][N], const R* b, R* x) {
+        if constexpr (N == 3) {
+            const R a = S[0][0], bb = S[1][0], c = S[2][0], d = S[1][1], e = S[2][1], f = S[2][2];
+            const R A = d * f - e * e, B = c * e - bb * f, C = bb * e - c * d;
+            const R D = a * f - c * c, E = bb * c - a * e, F = a * d - bb * bb;
+            const R det = a * A + (bb * B + c * C);
+            const R inv = (R)1 / det;
+            x[0] = (A * b[0] + (B * b[1] + C * b[2])) * inv;
+            x[1] = (B * b[0] + (D * b[1] + E * b[2])) * inv;
+            x[2] = (C * b[0] + (E * b[1] + F * b[2])) * inv;
+        } else {
+            R Dg[N], Di[N];   // D and 1/D of S = L D L^T
+            static_for<0, N>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                R d = S[c][c];
+                static_for<0, c>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    d = d - S[c][t] * S[c][t] * Dg[t];
+                });
+                Dg[c] = d;
+                const R inv = (R)1 / d;
+                Di[c] = inv;
+                static_for<c + 1, N>([&](auto Rr) {
+                    constexpr int r = decltype(Rr)::value;
+                    R v = S[r][c];
+                    static_for<0, c>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        v = v - S[r][t] * S[c][t] * Dg[t];
+                    });
+                    S[r][c] = v * inv;
+                });
+            });
+            static_for<0, N>([&](auto Rr) {
+                constexpr int r = decltype(Rr)::value;
+                R v = b[r];
+                static_for<0, r>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    v = v - S[r][t] * x[t];
+                });
+                x[r] = v;
+            });
+            static_for<0, N>([&](auto Rr) {
+                constexpr int r = decltype(Rr)::value;
+                x[r] = x[r] * Di[r];
+            });
+            static_for_down<N, 0>([&](auto Rr) {
+                constexpr int r = decltype(Rr)::value;
+                R v = x[r];
+                static_for<r + 1, N>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    v = v - S[t][r] * x[t];
+                });
+                x[r] = v;
+            });
         }
     }
 
@@ -95,154 +231,183 @@ struct PlanarTree {
     RL_HD static void forward_dynamics(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
                                        const R* fy, const R* tz, R* qacc) {
         // --- velocity-product (bias) accelerations with qacc = 0 ---------------------
-        R aax[NB], aay[NB];  // anchor acceleration
+        R aax[NB], aay[NB];  // anchor acceleration (the root anchor does not accelerate)
         R Fx[NB], Fy[NB], Nz[NB];
-        aax[0] = (R)0; aay[0] = (R)0;
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            if (i > 0) {
-                const int p = Mdl::parent(i);
-                const R w2 = k.om[p] * k.om[p];
-                aax[i] = aax[p] - w2 * (k.ax[i] - k.ax[p]);
-                aay[i] = aay[p] - w2 * (k.ay[i] - k.ay[p]);
-            }
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
             const R w2 = k.om[i] * k.om[i];
-            const R ex = k.px[i] - k.ax[i], ey = k.py[i] - k.ay[i];
-            const R acx = aax[i] - w2 * ex, acy = aay[i] - w2 * ey;
-            const R m = (R)Mdl::mass(i);
+            R ex, ey;                                         // COM relative to the body's own anchor
+            if constexpr (i == 0) { ex = k.px[0]; ey = k.py[0]; }
+            else { ex = k.px[i] - k.ax[i]; ey = k.py[i] - k.ay[i]; }
+            R acx, acy;
+            if constexpr (i == 0) {
+                acx = -(w2 * ex);
+                acy = -(w2 * ey);
+            } else {
+                constexpr int p = Mdl::parent(i);
+                const R wp2 = k.om[p] * k.om[p];
+                if constexpr (p == 0) {
+                    aax[i] = -(wp2 * k.ax[i]);
+                    aay[i] = -(wp2 * k.ay[i]);
+                } else {
+                    aax[i] = aax[p] - wp2 * (k.ax[i] - k.ax[p]);
+                    aay[i] = aay[p] - wp2 * (k.ay[i] - k.ay[p]);
+                }
+                acx = aax[i] - w2 * ex;
+                acy = aay[i] - w2 * ey;
+            }
+            constexpr double M_I = Mdl::mass(i);
             // net force on body i after moving m*a_bias to the right-hand side
-            Fx[i] = fx[i] + m * ((R)Mdl::gx() - acx);
-            Fy[i] = fy[i] + m * ((R)Mdl::gy() - acy);
+            if constexpr (HAS_GRAVITY) {
+                Fx[i] = fx[i] + (R)M_I * ((R)Mdl::gx() - acx);
+                Fy[i] = fy[i] + (R)M_I * ((R)Mdl::gy() - acy);
+            } else {
+                Fx[i] = fx[i] - (R)M_I * acx;
+                Fy[i] = fy[i] - (R)M_I * acy;
+            }
             // moment of that force about the body's own anchor, plus pure torque
             Nz[i] = (ex * Fy[i] - ey * Fx[i]) + tz[i];
-        }
+        });
         // --- accumulate subtree wrenches (leaves -> root) ----------------------------
-        RL_UNROLL
-        for (int i = NB - 1; i > 0; --i) {
-            const int p = Mdl::parent(i);
-            const R dx = k.ax[i] - k.ax[p], dy = k.ay[i] - k.ay[p];
+        static_for_down<NB, 1>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
+            R dx, dy;
+            if constexpr (p == 0) { dx = k.ax[i]; dy = k.ay[i]; }
+            else { dx = k.ax[i] - k.ax[p]; dy = k.ay[i] - k.ay[p]; }
             Nz[p] = Nz[p] + Nz[i] + (dx * Fy[i] - dy * Fx[i]);
             Fx[p] = Fx[p] + Fx[i];
             Fy[p] = Fy[p] + Fy[i];
-        }
-        R rhs[NV];
-        rhs[0] = Fx[0];
-        rhs[1] = Fy[0];
-        rhs[2] = Nz[0];
-        RL_UNROLL
-        for (int i = 1; i < NB; ++i) rhs[2 + i] = Nz[i] + tau_j[i];
-
-        // --- composite bodies: mass, first moment, inertia about the ROOT origin ------
-        R mc[NB], hx[NB], hy[NB], J[NB];
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) {
-            const R m = (R)Mdl::mass(i);
-            mc[i] = m;
-            hx[i] = m * k.px[i];
-            hy[i] = m * k.py[i];
-            J[i] = (R)Mdl::inertia(i) + m * (k.px[i] * k.px[i] + k.py[i] * k.py[i]);
-        }
-        RL_UNROLL
-        for (int i = NB - 1; i > 0; --i) {
-            const int p = Mdl::parent(i);
-            mc[p] = mc[p] + mc[i];
+        });
+        // --- composite bodies: mass (compile-time), first moment, inertia about the ROOT origin ----
+        R hx[NB], hy[NB], J[NB];
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr double M_I = Mdl::mass(i);
+            hx[i] = (R)M_I * k.px[i];
+            hy[i] = (R)M_I * k.py[i];
+            J[i] = (R)Mdl::inertia(i) + (R)M_I * (k.px[i] * k.px[i] + k.py[i] * k.py[i]);
+        });
+        static_for_down<NB, 1>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
             hx[p] = hx[p] + hx[i];
             hy[p] = hy[p] + hy[i];
             J[p] = J[p] + J[i];
-        }
-        // --- joint-space inertia (symmetric, lower triangle used) --------------------
-        R Mm[NV][NV];
-        RL_UNROLL
-        for (int r = 0; r < NV; ++r)
-            RL_UNROLL
-            for (int c = 0; c < NV; ++c) Mm[r][c] = (R)0;
-        Mm[0][0] = mc[0];
-        Mm[1][1] = mc[0];
-        RL_UNROLL
-        for (int kk = 0; kk < NB; ++kk) {          // hinge of body kk (kk = 0: root rotation)
-            const int col = 2 + kk;
-            // translation rows: e_x . perp(h_k - mc_k a_k), e_y . perp(...)
-            Mm[col][0] = -(hy[kk] - mc[kk] * k.ay[kk]);
-            Mm[col][1] = (hx[kk] - mc[kk] * k.ax[kk]);
-            // ancestors-or-self j of kk
-            int j = kk;
-            RL_UNROLL
-            for (int depth = 0; depth < NB; ++depth) {
-                if (j < 0) break;
-                const R v = J[kk] - ((k.ax[j] + k.ax[kk]) * hx[kk] + (k.ay[j] + k.ay[kk]) * hy[kk]) +
-                            mc[kk] * (k.ax[j] * k.ax[kk] + k.ay[j] * k.ay[kk]);
-                Mm[col][2 + j] = v;
-                j = (j == 0) ? -1 : Mdl::parent(j);
+        });
+        // --- joint-space inertia.  Translation rows: M_tt = m_total I_2 (constant); coupling
+        // Bx[k], By[k] = e_x / e_y . perp(h_k - mc_k a_k); rotational block C (lower triangle,
+        // entries of unrelated hinge pairs are 0).
+        R Bx[NB], By[NB];
+        R C[NB][NB];
+        static_for<0, NB>([&](auto Kk) {
+            constexpr int kk = decltype(Kk)::value;
+            constexpr double MC = subtree_mass(kk);
+            if constexpr (kk == 0) {
+                Bx[0] = -hy[0];
+                By[0] = hx[0];
+            } else {
+                Bx[kk] = -(hy[kk] - (R)MC * k.ay[kk]);
+                By[kk] = (hx[kk] - (R)MC * k.ax[kk]);
             }
-            if (kk > 0) Mm[col][col] = Mm[col][col] + (R)Mdl::armature(kk);
-        }
-        // --- solve M qacc = rhs by LDL^T on the lower triangle ------------------------
-        // (entries Mm[r][c], r >= c; unrelated hinge pairs stay 0)
-        R Dg[NV], Di[NV];   // D and 1/D of M = L D L^T
-        RL_UNROLL
-        for (int c = 0; c < NV; ++c) {
-            R d = Mm[c][c];
-            RL_UNROLL
-            for (int t = 0; t < c; ++t) d = d - Mm[c][t] * Mm[c][t] * Dg[t];
-            Dg[c] = d;
-            const R inv = (R)1 / d;
-            Di[c] = inv;
-            RL_UNROLL
-            for (int r = c + 1; r < NV; ++r) {
-                R v = Mm[r][c];
-                RL_UNROLL
-                for (int t = 0; t < c; ++t) v = v - Mm[r][t] * Mm[c][t] * Dg[t];
-                Mm[r][c] = v * inv;
-            }
-        }
-        RL_UNROLL
-        for (int r = 0; r < NV; ++r) {
-            R v = rhs[r];
-            RL_UNROLL
-            for (int t = 0; t < r; ++t) v = v - Mm[r][t] * qacc[t];
-            qacc[r] = v;
-        }
-        RL_UNROLL
-        for (int r = 0; r < NV; ++r) qacc[r] = qacc[r] * Di[r];
-        RL_UNROLL
-        for (int r = NV - 1; r >= 0; --r) {
-            R v = qacc[r];
-            RL_UNROLL
-            for (int t = r + 1; t < NV; ++t) v = v - Mm[t][r] * qacc[t];
-            qacc[r] = v;
-        }
+            static_for<0, kk + 1>([&](auto Jj) {
+                constexpr int j = decltype(Jj)::value;
+                if constexpr (!is_ancestor(j, kk)) {
+                    C[kk][j] = (R)0;
+                } else if constexpr (kk == 0) {
+                    C[0][0] = J[0];
+                } else if constexpr (j == 0) {
+                    C[kk][0] = J[kk] - (k.ax[kk] * hx[kk] + k.ay[kk] * hy[kk]);
+                } else {
+                    R v = J[kk] - ((k.ax[j] + k.ax[kk]) * hx[kk] + (k.ay[j] + k.ay[kk]) * hy[kk]) +
+                          (R)MC * (k.ax[j] * k.ax[kk] + k.ay[j] * k.ay[kk]);
+                    if constexpr (j == kk && Mdl::armature(kk) != 0.0) v = v + (R)Mdl::armature(kk);
+                    C[kk][j] = v;
+                }
+            });
+        });
+        // --- eliminate the translations: S = C - B^T B / m,  b = rhs_rot - B^T rhs_xy / m -------------
+        constexpr double INV_M = 1.0 / total_mass();
+        const R gx_ = Fx[0] * (R)INV_M, gy_ = Fy[0] * (R)INV_M;   // rhs_xy / m
+        R S[NB][NB], b[NB], th[NB];
+        static_for<0, NB>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            R rhs = Nz[r];
+            if constexpr (r > 0) rhs = rhs + tau_j[r];
+            b[r] = rhs - (Bx[r] * gx_ + By[r] * gy_);
+            const R bxm = Bx[r] * (R)INV_M, bym = By[r] * (R)INV_M;
+            static_for<0, r + 1>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                if constexpr (is_ancestor(c, r)) S[r][c] = C[r][c] - (bxm * Bx[c] + bym * By[c]);
+                else S[r][c] = -(bxm * Bx[c] + bym * By[c]);
+            });
+        });
+        solve_spd<R, NB>(S, b, th);
+        // translations: xdd = (rhs_xy - B th) / m
+        R sx = (R)0, sy = (R)0;
+        static_for<0, NB>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            if constexpr (r == 0) { sx = Bx[0] * th[0]; sy = By[0] * th[0]; }
+            else { sx = sx + Bx[r] * th[r]; sy = sy + By[r] * th[r]; }
+        });
+        qacc[0] = gx_ - sx * (R)INV_M;
+        qacc[1] = gy_ - sy * (R)INV_M;
+        static_for<0, NB>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            qacc[2 + r] = th[r];
+        });
+    }
+
+    static constexpr double subtree_mass(int kk) {
+        double m = 0.0;
+        for (int i = kk; i < NB; ++i)
+            if (is_ancestor(kk, i)) m += Mdl::mass(i);
+        return m;
     }
 
     // passive joint torques: spring (ref 0), damper, soft range limits
     template <typename R>
     RL_HD static void joint_passive(const R* q, const R* qd, R* tau_j) {
-        RL_UNROLL
-        for (int i = 1; i < NB; ++i) {
+        static_for<1, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
             const R x = q[2 + i], v = qd[2 + i];
-            R t = -(R)Mdl::stiffness(i) * x - (R)Mdl::damping(i) * v;
-            if (Mdl::limited(i)) {
+            R t;
+            if constexpr (Mdl::stiffness(i) != 0.0 && Mdl::damping(i) != 0.0)
+                t = -(R)Mdl::stiffness(i) * x - (R)Mdl::damping(i) * v;
+            else if constexpr (Mdl::stiffness(i) != 0.0)
+                t = -(R)Mdl::stiffness(i) * x;
+            else if constexpr (Mdl::damping(i) != 0.0)
+                t = -(R)Mdl::damping(i) * v;
+            else
+                t = (R)0;
+            if constexpr (Mdl::limited(i)) {
                 const R lo = (R)Mdl::lo(i), hi = (R)Mdl::hi(i);
                 if (x < lo) t = t - (R)Mdl::limit_k() * (x - lo) - (R)Mdl::limit_b() * v;
                 if (x > hi) t = t - (R)Mdl::limit_k() * (x - hi) - (R)Mdl::limit_b() * v;
             }
             tau_j[i] = t;
-        }
+        });
         tau_j[0] = (R)0;
     }
 
-    // one mj_step-style substep: q, qd advanced by h with hinge actuation act_j[NB]
+    // One mj_step-style substep: q, qd advanced by h with hinge actuation act_j[NB].
+    // (sn, cs) carry sin / cos of the absolute body angles from sub-step to sub-step: instead of
+    // three range reductions + two polynomials per body and sub-step (a quarter of the sub-step's
+    // instructions, at the head of its dependency chain) they are rotated by the small angle
+    // h * omega_i -- exactly the increment the integrator applies to the angle itself.  The caller
+    // seeds them with angles() at the start of every env step, so the state between env steps is
+    // (q, qd) alone and rounding drift is bounded by one env step's worth of sub-steps.
     template <typename R>
-    RL_HD static void substep(R* q, R* qd, const R* act_j, R h) {
+    RL_HD static void substep(R* q, R* qd, const R* act_j, R h, R* sn, R* cs) {
         PlanarKin<R, NB> k;
-        kinematics(q, qd, k);
+        RL_UNROLL
+        for (int i = 0; i < NB; ++i) { k.sn[i] = sn[i]; k.cs[i] = cs[i]; }
+        kinematics_sc(qd, k);
         R tau_j[NB], fx[NB], fy[NB], tz[NB];
         joint_passive(q, qd, tau_j);
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) {
+        static_for<1, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
             tau_j[i] = tau_j[i] + act_j[i];
-            fx[i] = (R)0; fy[i] = (R)0; tz[i] = (R)0;
-        }
-        Mdl::template external<R>(q, k, fx, fy, tz);
+        });
+        Mdl::template external<R>(q, k, fx, fy, tz);   // SETS fx, fy, tz of every body
         R qacc[NV];
         forward_dynamics(k, tau_j, fx, fy, tz, qacc);
         RL_UNROLL
@@ -250,6 +415,14 @@ struct PlanarTree {
             qd[r] = qd[r] + h * qacc[r];
             q[r] = q[r] + h * qd[r];
         }
+        R om[NB];
+        om[0] = qd[2];
+        static_for<1, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
+            om[i] = om[p] + qd[2 + i];
+        });
+        RL_UNROLL
+        for (int i = 0; i < NB; ++i) rl_rotate_small(sn[i], cs[i], h * om[i]);
     }
 
     // subtree(root) centre of mass (world) and its velocity

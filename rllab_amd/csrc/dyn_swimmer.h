@@ -73,9 +73,9 @@ struct SwimmerModel {
             const R w = k.om[i];
             const R fl = -(R)VISC_LIN * vl - (R)DRAG_AX * rl_abs(vl) * vl;
             const R ft = -(R)VISC_LIN * vt - (R)DRAG_PERP * rl_abs(vt) * vt;
-            fx[i] = fx[i] + (k.cs[i] * fl - k.sn[i] * ft);
-            fy[i] = fy[i] + (k.sn[i] * fl + k.cs[i] * ft);
-            tz[i] = tz[i] - (R)VISC_ANG * w - (R)DRAG_ANG * rl_abs(w) * w;
+            fx[i] = k.cs[i] * fl - k.sn[i] * ft;
+            fy[i] = k.sn[i] * fl + k.cs[i] * ft;
+            tz[i] = -(R)VISC_ANG * w - (R)DRAG_ANG * rl_abs(w) * w;
         }
     }
 };
@@ -132,7 +132,9 @@ struct Swimmer {
         R q[5], qd[5];
         RL_UNROLL
         for (int i = 0; i < 5; ++i) { q[i] = s[i]; qd[i] = s[5 + i]; }
-        for (int it = 0; it < FRAME_SKIP; ++it) Tree::template substep<R>(q, qd, ctrl, (R)0.001);
+        R sn[3], cs[3];
+        Tree::template angles<R>(q, sn, cs);
+        for (int it = 0; it < FRAME_SKIP; ++it) Tree::template substep<R>(q, qd, ctrl, (R)0.001, sn, cs);
         RL_UNROLL
         for (int i = 0; i < 5; ++i) { s[i] = q[i]; s[5 + i] = qd[i]; }
         R cx, cy, vx, vy;

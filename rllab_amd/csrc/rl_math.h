@@ -64,6 +64,28 @@ RL_HD void rl_sincos(float x, float& s, float& c) {
     c = cv;
 }
 
+// (sn, cs) <- rotation of (sn, cs) by the small angle d (|d| < ~0.2): Taylor sin / cos of d,
+// truncated below the rounding error of the type (float: d^7 / 5040 < 3e-9 * d, double: d^13).
+// Used by the articulated-body sub-step to carry sin / cos of the body angles.
+template <typename R>
+RL_HD void rl_rotate_small(R& sn, R& cs, R d) {
+    const R d2 = d * d;
+    R sd, cd;
+    if constexpr (sizeof(R) == 4) {
+        sd = d * ((R)1 + d2 * ((R)(-1.0 / 6) + d2 * (R)(1.0 / 120)));
+        cd = (R)1 + d2 * ((R)-0.5 + d2 * ((R)(1.0 / 24) + d2 * (R)(-1.0 / 720)));
+    } else {
+        sd = d * ((R)1 + d2 * ((R)(-1.0 / 6) + d2 * ((R)(1.0 / 120) + d2 * ((R)(-1.0 / 5040) +
+             d2 * ((R)(1.0 / 362880) + d2 * (R)(-1.0 / 39916800))))));
+        cd = (R)1 + d2 * ((R)-0.5 + d2 * ((R)(1.0 / 24) + d2 * ((R)(-1.0 / 720) + d2 * ((R)(1.0 / 40320) +
+             d2 * ((R)(-1.0 / 3628800) + d2 * (R)(1.0 / 479001600))))));
+    }
+    const R s = sn * cd + cs * sd;
+    const R c = cs * cd - sn * sd;
+    sn = s;
+    cs = c;
+}
+
 // The double instantiation is host-only (independent physics checks at 1e-10);
 // it may use libm.
 RL_HD void rl_sincos(double x, double& s, double& c) {
