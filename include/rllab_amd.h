@@ -135,15 +135,61 @@ int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);
  * BaseSampler.process_samples (rllab/sampler/base.py:57-66) and
  * special.discount_cumsum (rllab/misc/special.py:107-111).
  *   values: f64 plane [T][n] of baseline predictions (the reference predicts in
- *   float64), may be NULL (ZeroBaseline / LinearFeatureBaseline before first fit). */
+ *   float64), may be NULL (ZeroBaseline / LinearFeatureBaseline before first fit).
+ *   undiscounted: optional [T][n] plane of the undiscounted return-to-go (its value at a path
+ *   start is the path's total return, the "AverageReturn" statistic of base.py:93-103). */
 int rl_gae(int T, int n, const float* rewards, const double* values, const uint8_t* dones,
-           double gamma, double lambda, float* adv, float* ret, void* stream);
+           double gamma, double lambda, float* adv, float* ret, float* undiscounted, void* stream);
 
 /* y[t] = x[t] + discount * (1 - end[t]) * y[t+1] on a [T][n] plane
  * (special.discount_cumsum with path boundaries; dones may be NULL = one path
  * per column). */
 int rl_discount_cumsum(int T, int n, const float* x, const uint8_t* dones, double discount,
                        float* y, void* stream);
+
+/* ---- BaseSampler.process_samples / LinearFeatureBaseline on dense [T][n] planes ----------------
+ * (rllab/sampler/base.py:48-104, rllab/baselines/linear_feature_baseline.py:6-43) */
+
+/* Path indexing + baseline prediction in one pass over the columns.
+ *   tin    int32[T][n]  step index inside its path (the arange(l) of linear_feature_baseline.py:18)
+ *   valid  uint8[T][n]  1 unless whole_paths != 0 and no done flag follows in the column (the
+ *                       trailing incomplete path the reference's samplers drop,
+ *                       batch_polopt.py:30-34, vectorized_sampler.py:72-97)
+ *   values double[T][n] or NULL: phi(obs, tin) . coeffs, coeffs = double[2*obs_dim+4] in the
+ *                       reference's feature order, or zeros when coeffs == NULL (before the first fit)
+ *   obs    float[obs_dim][T][n]; obs_dim <= 20. */
+int rl_path_scan(int T, int n, int obs_dim, const uint8_t* dones, const float* obs, const double* coeffs,
+                 int whole_paths, int32_t* tin, uint8_t* valid, double* values, void* stream);
+
+/* Scratch (device bytes) for rl_sample_stats / rl_lfb_normal_eq. */
+size_t rl_process_workspace_bytes(int obs_dim);
+
+/* Number of doubles rl_sample_stats writes. */
+int rl_sample_stats_cols(void);
+
+/* One-pass float64 statistics over the valid samples (deterministic two-level reduction):
+ *   out[0] count, [1..2] sum / sum^2 of (return - ret_shift), [3..4] of (baseline - ret_shift),
+ *   [5..6] of (return - baseline), [7..8] of the advantage, [9] valid paths (tin == 0),
+ *   [10..11] sum / sum^2 of (undiscounted path return - und_shift), [12] sum of discounted
+ *   returns at path starts, [13] min advantage, [14] max path return, [15] min path return.
+ * Feeds explained_variance_1d (misc/special.py:51-59), center / shift_advantages
+ * (algos/util.py:7-12) and the return statistics of base.py:93-103.  The shifts only
+ * condition the one-pass variances; pass any value near the respective means. */
+int rl_sample_stats(size_t n_samples, const float* returns, const double* baselines,
+                    const float* advantages, const float* undiscounted, const int32_t* tin,
+                    const uint8_t* valid, double ret_shift, double und_shift, void* workspace,
+                    size_t workspace_bytes, double* out, void* stream);
+
+/* adv_out = valid ? (adv_in - mean) / denom + shift : 0   (algos/util.py:7-12). */
+int rl_adv_finish(size_t n_samples, const float* adv_in, const uint8_t* valid, double mean, double denom,
+                  double shift, float* adv_out, void* stream);
+
+/* Normal equations of LinearFeatureBaseline.fit (linear_feature_baseline.py:25-36) over the valid
+ * samples, float64, without materialising the feature matrix:
+ *   out = [ Phi^T Phi (F*F, row-major) | Phi^T returns (F) ],  F = 2*obs_dim + 4. */
+int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs, const int32_t* tin,
+                     const float* returns, const uint8_t* valid, void* workspace, size_t workspace_bytes,
+                     double* out, void* stream);
 
 /* One dense batch for the fused GaussianMLPPolicy update kernels.  Per-sample arrays
  * are planes with the sample axis last (B = n_samples). */

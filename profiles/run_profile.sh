@@ -1,0 +1,26 @@
+#!/bin/bash
+# Profile recipe (run on the GPU box through gpurun):  profiles/run_profile.sh <tag>
+#   kernel-trace/stats pass and SEPARATE --pmc passes of the same bench command, condensed
+#   into gpurun_out/<tag>_*.csv by profiles/summarize.py (raw traces are too large to keep).
+TAG=${1:-r01}
+set -x
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+P=/tmp/prof_$TAG
+rm -rf $P && mkdir -p $P gpurun_out
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $BENCH > gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
+python profiles/summarize.py stats $P/stats gpurun_out/${TAG}_kernel_stats.csv
+head -12 gpurun_out/${TAG}_kernel_stats.csv
+BENCH2="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -- $BENCH2 > /dev/null 2>&1
+python profiles/summarize.py pmc $P/fetch gpurun_out/${TAG}_pmc_fetch_size.csv
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -- $BENCH2 > /dev/null 2>&1
+python profiles/summarize.py pmc $P/write gpurun_out/${TAG}_pmc_write_size.csv
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $P/sq -- $BENCH2 > /dev/null 2>&1
+python profiles/summarize.py pmc $P/sq gpurun_out/${TAG}_pmc_sq.csv
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $P/sq2 -- $BENCH2 > /dev/null 2>&1
+python profiles/summarize.py pmc $P/sq2 gpurun_out/${TAG}_pmc_sq2.csv
+head -6 gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv
+tail -2 gpurun_out/${TAG}_bench_under_rocprof.log
+ls -la gpurun_out

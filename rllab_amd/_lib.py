@@ -25,6 +25,8 @@ SYMBOLS = [
     "rl_vecenv_reset", "rl_vecenv_step", "rl_rollout_gaussian_mlp", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_fvp", "rl_cg_init", "rl_cg_step",
+    "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
+    "rl_lfb_normal_eq",
 ]
 
 
@@ -72,7 +74,7 @@ def _load():
     lib.rl_vecenv_reset.argtypes = [i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp]
     lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp, vp, vp]
     lib.rl_rollout_gaussian_mlp.argtypes = [ctypes.POINTER(RolloutArgs), vp]
-    lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp]
+    lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp, vp]
     lib.rl_discount_cumsum.argtypes = [i32, i32, vp, vp, f64, vp, vp]
     lib.rl_debug_philox.argtypes = [u32, u32, u32, u32, u32, u32, i32, vp, vp]
     pb = ctypes.POINTER(PolicyBatch)
@@ -83,6 +85,14 @@ def _load():
     lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]
     lib.rl_cg_init.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.rl_cg_step.argtypes = [i32, vp, f64, f64, vp, vp, vp, vp, vp, vp]
+    sz = ctypes.c_size_t
+    lib.rl_path_scan.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.rl_process_workspace_bytes.restype = sz
+    lib.rl_process_workspace_bytes.argtypes = [i32]
+    lib.rl_sample_stats_cols.restype = i32
+    lib.rl_sample_stats.argtypes = [sz, vp, vp, vp, vp, vp, vp, f64, f64, vp, sz, vp, vp]
+    lib.rl_adv_finish.argtypes = [sz, vp, vp, f64, f64, f64, vp, vp]
+    lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = header / library mismatch
     return lib

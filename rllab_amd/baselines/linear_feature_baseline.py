@@ -55,9 +55,14 @@ class LinearFeatureBaseline(Baseline):
         return self._features(path).dot(self._coeffs)
 
     # -- dense device forms ------------------------------------------------------------
+    def dense_coeffs(self):
+        """Coefficients for the fused prediction inside rl_path_scan (None before the first fit:
+        the reference predicts zeros, linear_feature_baseline.py:39-40)."""
+        return self._coeffs
+
     @staticmethod
     def _features_dense(traj):
-        """[F, T*N] float64 feature planes, F = 2*Do + 4."""
+        """[F, T*N] float64 feature planes, F = 2*Do + 4 (torch form, for obs_dim > 20)."""
         o = traj.obs.reshape(traj.obs_dim, -1).to(torch.float64).clamp(-10, 10)
         al = (traj.time_in_path().reshape(1, -1).to(torch.float64)) / 100.0
         return torch.cat([o, o ** 2, al, al ** 2, al ** 3, torch.ones_like(al)], dim=0)
@@ -66,22 +71,37 @@ class LinearFeatureBaseline(Baseline):
         """[T, N] float64 baseline plane, or None before the first fit (== zeros)."""
         if self._coeffs is None:
             return None
+        if traj.obs_dim <= 20 and traj.device.type == "cuda":
+            from rllab_amd.sampler.base import path_scan
+            return path_scan(traj, True, self._coeffs)[2]
         w = torch.as_tensor(self._coeffs, dtype=torch.float64, device=traj.device)
         return (w @ self._features_dense(traj)).reshape(traj.T, traj.N)
 
     def fit_dense(self, traj, all_reduce=None):
-        phi = self._features_dense(traj)
-        w = traj.valid.reshape(1, -1).to(torch.float64) if traj.valid is not None else None
-        y = traj.returns.reshape(-1).to(torch.float64)
-        if w is not None:
-            phi_w = phi * w
+        F = 2 * traj.obs_dim + 4
+        if traj.obs_dim <= 20 and traj.device.type == "cuda":
+            # Phi^T W Phi and Phi^T W y by rl_lfb_normal_eq: one pass, features rebuilt in LDS
+            from rllab_amd import _lib
+            from rllab_amd.sampler.base import _workspace, path_scan
+            tin = getattr(traj, "tin", None)
+            if tin is None:
+                tin = path_scan(traj, True, None, want_values=False)[0]
+            valid = traj.valid if traj.valid is not None else torch.ones((traj.T, traj.N), dtype=torch.bool,
+                                                                         device=traj.device)
+            valid_u8 = valid.to(torch.uint8).contiguous()
+            ws = _workspace(traj.device, traj.obs_dim)
+            packed = torch.empty((F + 1) * F, dtype=torch.float64, device=traj.device)
+            _lib.check(_lib.lib.rl_lfb_normal_eq(traj.B, traj.obs_dim, _lib.ptr(traj.obs), _lib.ptr(tin),
+                                                 _lib.ptr(traj.returns), _lib.ptr(valid_u8), _lib.ptr(ws),
+                                                 ws.numel(), _lib.ptr(packed), _lib.stream_ptr()),
+                       "rl_lfb_normal_eq")
         else:
-            phi_w = phi
-        gram = phi_w @ phi.t()
-        rhs = phi_w @ y
+            phi = self._features_dense(traj)
+            w = traj.valid.reshape(1, -1).to(torch.float64) if traj.valid is not None else None
+            y = traj.returns.reshape(-1).to(torch.float64)
+            phi_w = phi * w if w is not None else phi
+            packed = torch.cat([(phi_w @ phi.t()).reshape(-1), phi_w @ y])
         if all_reduce is not None:
-            packed = torch.cat([gram.reshape(-1), rhs])
             all_reduce(packed)
-            F = gram.shape[0]
-            gram, rhs = packed[:F * F].reshape(F, F), packed[F * F:]
-        self._coeffs = self._solve(gram.cpu().numpy(), rhs.cpu().numpy())
+        host = packed.cpu().numpy()
+        self._coeffs = self._solve(host[:F * F].reshape(F, F), host[F * F:])

@@ -1,0 +1,369 @@
+// process_kernels.hip -- BaseSampler.process_samples (rllab/sampler/base.py:48-104) and
+// LinearFeatureBaseline (rllab/baselines/linear_feature_baseline.py:6-43) on dense [T][n]
+// planes: path indexing, baseline prediction, batch statistics and the ridge-regression
+// normal equations, each as one pass over the batch.
+//
+//   rl_path_scan     : per column, forward max-scan of path starts and backward or-scan of done
+//                      flags -> step index inside its path (the `arange(l)` of
+//                      linear_feature_baseline.py:16-19), whole-path validity
+//                      (batch_polopt.py:30-34 / vectorized_sampler.py:72-97) and, fused into
+//                      the same pass, the baseline prediction  phi(o, t) . w  (:38-43).
+//   rl_sample_stats  : every moment process_samples needs (explained variance :68-71,
+//                      advantage centring algos/util.py:7-12, per-path return statistics
+//                      :93-103) in ONE read of the batch, float64, deterministic.
+//   rl_adv_finish    : (a - mean) / (std + 1e-8) [+ shift to positive], zero on invalid samples.
+//   rl_lfb_normal_eq : Phi^T W Phi and Phi^T W y in float64 without materialising Phi
+//                      (2*Do+4 features x B samples x 8 B = 0.5 GB at the headline config):
+//                      features are rebuilt per 64-sample tile in LDS, every lane owns a
+//                      register block of the Gram matrix, f64 FMAs run at the vector rate.
+// All four are HBM-/issue-bound single passes; none survives in a profile next to the rollout.
+#include <hip/hip_runtime.h>
+#include "../../include/rllab_amd.h"
+#include "capi_util.h"
+
+namespace rl {
+
+constexpr int PS_EW = 32;   // envs per workgroup
+constexpr int PS_KB = 32;   // time chunks per workgroup
+constexpr int MAX_DO = 20;  // observation sizes the feature kernels are built for (2*Do+5 <= 64)
+
+// features of one sample, reference order: clip(o), clip(o)^2, al, al^2, al^3, 1 with al = t/100
+template <class F>
+__device__ __forceinline__ void lfb_features(int Do, const float* __restrict__ obs, size_t plane, size_t off,
+                                             int tin, F&& emit) {
+    for (int d = 0; d < Do; ++d) {
+        double o = (double)obs[(size_t)d * plane + off];
+        o = fmin(fmax(o, -10.0), 10.0);
+        emit(d, o);
+        emit(Do + d, o * o);
+    }
+    const double al = (double)tin / 100.0;
+    emit(2 * Do, al);
+    emit(2 * Do + 1, al * al);
+    emit(2 * Do + 2, al * al * al);
+    emit(2 * Do + 3, 1.0);
+}
+
+__global__ void __launch_bounds__(PS_EW* PS_KB)
+path_scan_kernel(int T, int n, int Do, const uint8_t* __restrict__ done, const float* __restrict__ obs,
+                 const double* __restrict__ coeffs, int whole_paths, int32_t* __restrict__ tin,
+                 uint8_t* __restrict__ valid, double* __restrict__ values) {
+    __shared__ int s_start[PS_KB][PS_EW];     // last path start inside the chunk, or -1
+    __shared__ int s_done[PS_KB][PS_EW];      // any done flag inside the chunk
+    __shared__ double s_w[2 * MAX_DO + 4];
+    const int e = threadIdx.x, k = threadIdx.y;
+    const int i = blockIdx.x * PS_EW + e;
+    const int L = (T + PS_KB - 1) / PS_KB;
+    const int t0 = k * L, t1 = min(T, t0 + L);
+    const bool live = (i < n) && (t0 < T);
+    const int F = 2 * Do + 4;
+    if (coeffs)
+        for (int f = threadIdx.y * PS_EW + threadIdx.x; f < F; f += PS_EW * PS_KB) s_w[f] = coeffs[f];
+    int last = -1, any = 0;
+    if (live) {
+        for (int t = t0; t < t1; ++t) {
+            const bool start = (t == 0) || done[(size_t)(t - 1) * n + i];
+            if (start) last = t;
+            any |= done[(size_t)t * n + i];
+        }
+    }
+    s_start[k][e] = last;
+    s_done[k][e] = any;
+    __syncthreads();
+    if (!live) return;
+    int cur = -1;                      // last start before this chunk
+    for (int j = 0; j < k; ++j) cur = max(cur, s_start[j][e]);
+    int later = 0;                     // any done after this chunk
+    for (int j = k + 1; j < PS_KB; ++j) later |= s_done[j][e];
+    // suffix-or inside the chunk needs a backward walk; do it first into a bit mask (L <= 32 * 8)
+    // -- chunks are short (T / 32 steps), so a second forward walk with a running count suffices:
+    int remaining = 0;                 // number of done flags at or after t inside the chunk
+    for (int t = t0; t < t1; ++t) remaining += done[(size_t)t * n + i] ? 1 : 0;
+    const size_t plane = (size_t)T * n;
+    for (int t = t0; t < t1; ++t) {
+        const size_t off = (size_t)t * n + i;
+        if ((t == 0) || done[(size_t)(t - 1) * n + i]) cur = t;
+        const int ti = t - cur;
+        tin[off] = ti;
+        valid[off] = (!whole_paths || remaining > 0 || later) ? 1 : 0;
+        if (done[off]) remaining -= 1;
+        if (values) {
+            double acc = 0.0;
+            if (coeffs) lfb_features(Do, obs, plane, off, ti, [&](int f, double v) { acc = fma(s_w[f], v, acc); });
+            values[off] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-pass batch statistics
+// ---------------------------------------------------------------------------------------------
+enum {
+    ST_COUNT = 0,      // valid samples
+    ST_RET, ST_RET2,   // sum / sum of squares of returns (shifted by ret_shift)
+    ST_BASE, ST_BASE2, // baseline predictions (shifted by ret_shift)
+    ST_RES, ST_RES2,   // returns - baseline
+    ST_ADV, ST_ADV2,   // advantages
+    ST_NPATH,          // valid paths (starts)
+    ST_UND, ST_UND2,   // undiscounted path return (shifted by und_shift) at path starts
+    ST_DISC,           // discounted return at path starts
+    ST_NSUM,           // number of summed columns
+    ST_ADVMIN = ST_NSUM, ST_UNDMAX, ST_UNDMIN,
+    ST_NCOLS
+};
+constexpr int ST_BLOCK = 256;
+
+struct StatAcc {
+    double s[ST_NSUM];
+    double adv_min, und_max, und_min;
+};
+
+__global__ void __launch_bounds__(ST_BLOCK)
+sample_stats_kernel(size_t B, const float* __restrict__ ret, const double* __restrict__ base,
+                    const float* __restrict__ adv, const float* __restrict__ undisc,
+                    const int32_t* __restrict__ tin, const uint8_t* __restrict__ valid, double ret_shift,
+                    double und_shift, double* __restrict__ partial) {
+    StatAcc a;
+#pragma unroll
+    for (int c = 0; c < ST_NSUM; ++c) a.s[c] = 0.0;
+    a.adv_min = INFINITY; a.und_max = -INFINITY; a.und_min = INFINITY;
+    for (size_t b = (size_t)blockIdx.x * ST_BLOCK + threadIdx.x; b < B; b += (size_t)gridDim.x * ST_BLOCK) {
+        if (!valid[b]) continue;
+        const double r = (double)ret[b] - ret_shift;
+        const double v = (base ? base[b] : 0.0) - ret_shift;
+        const double res = r - v;
+        const double ad = (double)adv[b];
+        a.s[ST_COUNT] += 1.0;
+        a.s[ST_RET] += r; a.s[ST_RET2] += r * r;
+        a.s[ST_BASE] += v; a.s[ST_BASE2] += v * v;
+        a.s[ST_RES] += res; a.s[ST_RES2] += res * res;
+        a.s[ST_ADV] += ad; a.s[ST_ADV2] += ad * ad;
+        a.adv_min = fmin(a.adv_min, ad);
+        if (tin[b] == 0) {
+            const double u = (double)undisc[b];
+            a.s[ST_NPATH] += 1.0;
+            a.s[ST_UND] += u - und_shift; a.s[ST_UND2] += (u - und_shift) * (u - und_shift);
+            a.s[ST_DISC] += (double)ret[b];
+            a.und_max = fmax(a.und_max, u);
+            a.und_min = fmin(a.und_min, u);
+        }
+    }
+    __shared__ double sm[ST_BLOCK / 64][ST_NCOLS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double cols[ST_NCOLS];
+#pragma unroll
+    for (int c = 0; c < ST_NSUM; ++c) cols[c] = a.s[c];
+    cols[ST_ADVMIN] = a.adv_min; cols[ST_UNDMAX] = a.und_max; cols[ST_UNDMIN] = a.und_min;
+#pragma unroll
+    for (int c = 0; c < ST_NCOLS; ++c) {
+        double v = cols[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(v, o, 64);
+            v = (c < ST_NSUM) ? v + w : ((c == ST_UNDMAX) ? fmax(v, w) : fmin(v, w));
+        }
+        if (lane == 0) sm[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ST_NCOLS) {
+        const int c = threadIdx.x;
+        double v = sm[0][c];
+        for (int w = 1; w < ST_BLOCK / 64; ++w)
+            v = (c < ST_NSUM) ? v + sm[w][c] : ((c == ST_UNDMAX) ? fmax(v, sm[w][c]) : fmin(v, sm[w][c]));
+        partial[(size_t)blockIdx.x * ST_NCOLS + c] = v;
+    }
+}
+
+// fold the per-workgroup rows (one wavefront per column, fixed order)
+__global__ void __launch_bounds__(64) stats_reduce_kernel(const double* __restrict__ partial, int rows,
+                                                          double* __restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const bool is_sum = c < ST_NSUM, is_max = (c == ST_UNDMAX);
+    double v = is_sum ? 0.0 : (is_max ? -INFINITY : INFINITY);
+    for (int r = lane; r < rows; r += 64) {
+        const double w = partial[(size_t)r * ST_NCOLS + c];
+        v = is_sum ? v + w : (is_max ? fmax(v, w) : fmin(v, w));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o, 64);
+        v = is_sum ? v + w : (is_max ? fmax(v, w) : fmin(v, w));
+    }
+    if (lane == 0) out[c] = v;
+}
+
+__global__ void __launch_bounds__(256)
+adv_finish_kernel(size_t B, const float* __restrict__ adv_in, const uint8_t* __restrict__ valid, double mean,
+                  double denom, double shift, float* __restrict__ adv_out) {
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const double a = ((double)adv_in[b] - mean) / denom + shift;
+    adv_out[b] = valid[b] ? (float)a : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// normal equations of the linear feature baseline
+// ---------------------------------------------------------------------------------------------
+constexpr int NE_TILE = 64;   // samples per tile (one per lane)
+constexpr int NE_WAVES = 4;   // wavefronts per workgroup
+
+// FB = side of the register block per lane; FE = 8 * FB extended features (phi, y, zero padding)
+template <int FB>
+__global__ void __launch_bounds__(NE_WAVES * 64)
+lfb_normal_eq_kernel(size_t B, int Do, const float* __restrict__ obs, const int32_t* __restrict__ tin,
+                     const float* __restrict__ ret, const uint8_t* __restrict__ valid,
+                     double* __restrict__ partial) {
+    constexpr int FE = 8 * FB;
+    constexpr int STR = FE + 2;                       // row stride (f64), keeps 16-byte alignment
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* tile = sm + (size_t)wave * NE_TILE * STR;  // [sample][feature]
+    const int bi = lane >> 3, bj = lane & 7;           // block row / column of this lane
+    const int F = 2 * Do + 4;
+    double acc[FB][FB];
+#pragma unroll
+    for (int r = 0; r < FB; ++r)
+#pragma unroll
+        for (int c = 0; c < FB; ++c) acc[r][c] = 0.0;
+    const size_t n_tiles = (B + NE_TILE - 1) / NE_TILE;
+    for (size_t tl = (size_t)blockIdx.x * NE_WAVES + wave; tl < n_tiles; tl += (size_t)gridDim.x * NE_WAVES) {
+        const size_t b = tl * NE_TILE + lane;
+        const bool use = (b < B) && valid[b];
+        double* row = tile + (size_t)lane * STR;
+        if (use) {
+            lfb_features(Do, obs, B, b, tin[b], [&](int f, double v) { row[f] = v; });
+            row[F] = (double)ret[b];
+            for (int f = F + 1; f < FE; ++f) row[f] = 0.0;
+        } else {
+            for (int f = 0; f < FE; ++f) row[f] = 0.0;
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_wave_barrier();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll 4
+        for (int s = 0; s < NE_TILE; ++s) {
+            const double* rs = tile + (size_t)s * STR;
+            double a[FB], bb[FB];
+#pragma unroll
+            for (int r = 0; r < FB; ++r) { a[r] = rs[bi * FB + r]; bb[r] = rs[bj * FB + r]; }
+#pragma unroll
+            for (int r = 0; r < FB; ++r)
+#pragma unroll
+                for (int c = 0; c < FB; ++c) acc[r][c] = fma(a[r], bb[c], acc[r][c]);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_wave_barrier();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    }
+    // fold the wavefronts of the workgroup in order, one partial [FE][FE] per workgroup
+    __syncthreads();
+    double* red = sm;   // [FE][FE], aliases the tiles
+    for (int w = 0; w < NE_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int r = 0; r < FB; ++r)
+#pragma unroll
+                for (int c = 0; c < FB; ++c) {
+                    double* p = red + (size_t)(bi * FB + r) * FE + bj * FB + c;
+                    *p = (w == 0) ? acc[r][c] : *p + acc[r][c];
+                }
+        }
+        __syncthreads();
+    }
+    double* out = partial + (size_t)blockIdx.x * FE * FE;
+    for (int k = threadIdx.x; k < FE * FE; k += NE_WAVES * 64) out[k] = red[k];
+}
+
+// out[(F+1) x F] = [Gram | rhs]^T laid out as gram (F*F) followed by rhs (F), summed over rows in order
+__global__ void __launch_bounds__(256)
+lfb_reduce_kernel(const double* __restrict__ partial, int rows, int FE, int F, double* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= (F + 1) * F) return;
+    const int i = (k < F * F) ? k / F : k - F * F;   // feature row
+    const int j = (k < F * F) ? k % F : F;           // feature column (F = the y column)
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += partial[(size_t)r * FE * FE + (size_t)i * FE + j];
+    out[k] = s;
+}
+
+}  // namespace rl
+
+using namespace rl;
+
+extern "C" int rl_path_scan(int T, int n, int obs_dim, const uint8_t* dones, const float* obs,
+                            const double* coeffs, int whole_paths, int32_t* tin, uint8_t* valid,
+                            double* values, void* stream) {
+    if (T <= 0 || n <= 0 || !dones || !tin || !valid || obs_dim < 0 || obs_dim > MAX_DO ||
+        (values && coeffs && !obs))
+        return set_error(RL_ERR_ARG, "rl_path_scan: bad argument (obs_dim <= %d)", MAX_DO);
+    dim3 grid((n + PS_EW - 1) / PS_EW), block(PS_EW, PS_KB);
+    hipLaunchKernelGGL(path_scan_kernel, grid, block, 0, (hipStream_t)stream, T, n, obs_dim, dones, obs, coeffs,
+                       whole_paths, tin, valid, values);
+    return check_launch("path_scan_kernel");
+}
+
+extern "C" int rl_sample_stats_cols(void) { return ST_NCOLS; }
+
+extern "C" size_t rl_process_workspace_bytes(int obs_dim) {
+    const int FE = (2 * obs_dim + 5 <= 32) ? 32 : 64;
+    const size_t a = (size_t)1024 * ST_NCOLS * sizeof(double);
+    const size_t b = (size_t)512 * FE * FE * sizeof(double);
+    return a > b ? a : b;
+}
+
+extern "C" int rl_sample_stats(size_t n_samples, const float* returns, const double* baselines,
+                               const float* advantages, const float* undiscounted, const int32_t* tin,
+                               const uint8_t* valid, double ret_shift, double und_shift, void* workspace,
+                               size_t workspace_bytes, double* out, void* stream) {
+    if (n_samples == 0 || !returns || !advantages || !undiscounted || !tin || !valid || !workspace || !out)
+        return set_error(RL_ERR_ARG, "rl_sample_stats: bad argument");
+    int grid = (int)((n_samples + ST_BLOCK * 8 - 1) / (ST_BLOCK * 8));
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    if (workspace_bytes < (size_t)grid * ST_NCOLS * sizeof(double))
+        return set_error(RL_ERR_ARG, "rl_sample_stats: workspace too small");
+    hipLaunchKernelGGL(sample_stats_kernel, dim3(grid), dim3(ST_BLOCK), 0, (hipStream_t)stream, n_samples, returns,
+                       baselines, advantages, undiscounted, tin, valid, ret_shift, und_shift, (double*)workspace);
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(ST_NCOLS), dim3(64), 0, (hipStream_t)stream,
+                       (const double*)workspace, grid, out);
+    return check_launch("sample_stats_kernel");
+}
+
+extern "C" int rl_adv_finish(size_t n_samples, const float* adv_in, const uint8_t* valid, double mean,
+                             double denom, double shift, float* adv_out, void* stream) {
+    if (n_samples == 0 || !adv_in || !valid || !adv_out) return set_error(RL_ERR_ARG, "rl_adv_finish: bad argument");
+    hipLaunchKernelGGL(adv_finish_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n_samples, adv_in, valid, mean, denom, shift, adv_out);
+    return check_launch("adv_finish_kernel");
+}
+
+extern "C" int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs, const int32_t* tin,
+                                const float* returns, const uint8_t* valid, void* workspace,
+                                size_t workspace_bytes, double* out, void* stream) {
+    if (n_samples == 0 || obs_dim <= 0 || obs_dim > MAX_DO || !obs || !tin || !returns || !valid || !workspace || !out)
+        return set_error(RL_ERR_ARG, "rl_lfb_normal_eq: bad argument (obs_dim <= %d)", MAX_DO);
+    const int F = 2 * obs_dim + 4;
+    const int FE = (F + 1 <= 32) ? 32 : 64;
+    const size_t n_tiles = (n_samples + NE_TILE - 1) / NE_TILE;
+    int grid = (int)((n_tiles + NE_WAVES - 1) / NE_WAVES);
+    if (grid > 512) grid = 512;
+    if (workspace_bytes < (size_t)grid * FE * FE * sizeof(double))
+        return set_error(RL_ERR_ARG, "rl_lfb_normal_eq: workspace too small");
+    const size_t lds = (size_t)NE_WAVES * NE_TILE * (FE + 2) * sizeof(double);
+    hipError_t e = hipSuccess;
+    if (FE == 32) {
+        static bool set32 = false;
+        if (!set32) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set32 = true; }
+        hipLaunchKernelGGL(lfb_normal_eq_kernel<4>, dim3(grid), dim3(NE_WAVES * 64), lds, (hipStream_t)stream, n_samples,
+                           obs_dim, obs, tin, returns, valid, (double*)workspace);
+    } else {
+        static bool set64 = false;
+        if (!set64) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set64 = true; }
+        hipLaunchKernelGGL(lfb_normal_eq_kernel<8>, dim3(grid), dim3(NE_WAVES * 64), lds, (hipStream_t)stream, n_samples,
+                           obs_dim, obs, tin, returns, valid, (double*)workspace);
+    }
+    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(lfb_reduce_kernel, dim3(((F + 1) * F + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)workspace, grid, FE, F, out);
+    return check_launch("lfb_normal_eq_kernel");
+}

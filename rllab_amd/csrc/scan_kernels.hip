@@ -27,9 +27,10 @@ struct Affine {
 __global__ void __launch_bounds__(SCAN_EW* SCAN_KB)
 gae_kernel(int T, int n, const float* __restrict__ r, const double* __restrict__ v,
            const uint8_t* __restrict__ done, double gamma, double gl, float* __restrict__ adv,
-           float* __restrict__ ret) {
+           float* __restrict__ ret, float* __restrict__ und) {
     __shared__ Affine s_adv[SCAN_KB][SCAN_EW];
     __shared__ Affine s_ret[SCAN_KB][SCAN_EW];
+    __shared__ Affine s_und[SCAN_KB][SCAN_EW];   // undiscounted return-to-go (discount 1)
     const int e = threadIdx.x, k = threadIdx.y;
     const int i = blockIdx.x * SCAN_EW + e;
     const int L = (T + SCAN_KB - 1) / SCAN_KB;
@@ -37,11 +38,11 @@ gae_kernel(int T, int n, const float* __restrict__ r, const double* __restrict__
     const int t1 = min(T, t0 + L);  // exclusive
     const bool live = (i < n) && (t0 < T);
 
-    Affine sa{0.0, 1.0}, sr{0.0, 1.0};
+    Affine sa{0.0, 1.0}, sr{0.0, 1.0}, su{0.0, 1.0};
     if (live) {
         // pass 1: chunk summary.  V[t+1] inside the chunk comes from the previous
         // loop iteration; across the chunk boundary it is read directly.
-        double ya = 0.0, ba = 1.0, yr = 0.0, br = 1.0;
+        double ya = 0.0, ba = 1.0, yr = 0.0, br = 1.0, yu = 0.0, bu = 1.0;
         double vnext = 0.0;
         if (v && t1 < T) vnext = v[(size_t)t1 * n + i];
         for (int t = t1 - 1; t >= t0; --t) {
@@ -55,24 +56,29 @@ gae_kernel(int T, int n, const float* __restrict__ r, const double* __restrict__
             ba = gl * keep * ba;
             yr = rt + gamma * keep * yr;
             br = gamma * keep * br;
+            yu = rt + keep * yu;
+            bu = keep * bu;
             vnext = vt;
         }
         sa = Affine{ya, ba};
         sr = Affine{yr, br};
+        su = Affine{yu, bu};
     }
     s_adv[k][e] = sa;
     s_ret[k][e] = sr;
+    s_und[k][e] = su;
     __syncthreads();
     if (!live) return;
 
     // carry-in = value at t1 = fold of chunks k+1 .. KB-1 (last chunk has carry 0)
-    double ca = 0.0, cr = 0.0;
+    double ca = 0.0, cr = 0.0, cu = 0.0;
     for (int j = SCAN_KB - 1; j > k; --j) {
         ca = s_adv[j][e].a + s_adv[j][e].b * ca;
         cr = s_ret[j][e].a + s_ret[j][e].b * cr;
+        cu = s_und[j][e].a + s_und[j][e].b * cu;
     }
     // pass 2: true values
-    double ya = ca, yr = cr;
+    double ya = ca, yr = cr, yu = cu;
     double vnext = 0.0;
     if (v && t1 < T) vnext = v[(size_t)t1 * n + i];
     for (int t = t1 - 1; t >= t0; --t) {
@@ -84,8 +90,10 @@ gae_kernel(int T, int n, const float* __restrict__ r, const double* __restrict__
         const double delta = rt + gamma * vnext * keep - vt;
         ya = delta + gl * keep * ya;
         yr = rt + gamma * keep * yr;
+        yu = rt + keep * yu;
         adv[off] = (float)ya;
         ret[off] = (float)yr;
+        if (und) und[off] = (float)yu;
         vnext = vt;
     }
 }
@@ -133,12 +141,12 @@ discount_cumsum_kernel(int T, int n, const float* __restrict__ x, const uint8_t*
 using namespace rl;
 
 extern "C" int rl_gae(int T, int n, const float* rewards, const double* values, const uint8_t* dones,
-                      double gamma, double lambda, float* adv, float* ret, void* stream) {
+                      double gamma, double lambda, float* adv, float* ret, float* undiscounted, void* stream) {
     if (T <= 0 || n <= 0 || !rewards || !dones || !adv || !ret)
         return set_error(RL_ERR_ARG, "rl_gae: bad argument");
     dim3 grid((n + SCAN_EW - 1) / SCAN_EW), block(SCAN_EW, SCAN_KB);
     hipLaunchKernelGGL(gae_kernel, grid, block, 0, (hipStream_t)stream, T, n, rewards, values, dones,
-                       gamma, gamma * lambda, adv, ret);
+                       gamma, gamma * lambda, adv, ret, undiscounted);
     return check_launch("gae_kernel");
 }
 

@@ -77,88 +77,135 @@ class SamplesData(dict):
         return val
 
 
-def _two_pass_var(x, w, cnt):
-    """Population variance of x over weights w (0/1), global across ranks.
-    Returns (mean, var) as 0-d float64 tensors."""
-    (s,) = D.sums((x * w).sum())
-    mean = s / cnt
-    (ss,) = D.sums((((x - mean) ** 2) * w).sum())
-    return mean, ss / cnt
+_WS = {}
+
+
+def _workspace(device, obs_dim):
+    key = (device, obs_dim)
+    if key not in _WS:
+        n = _lib.lib.rl_process_workspace_bytes(int(obs_dim))
+        _WS[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return _WS[key]
+
+
+# column indices of rl_sample_stats (include/rllab_amd.h)
+(_COUNT, _RET, _RET2, _BASE, _BASE2, _RES, _RES2, _ADV, _ADV2, _NPATH, _UND, _UND2, _DISC,
+ _ADVMIN, _UNDMAX, _UNDMIN) = range(16)
+_N_SUM = 13
+
+
+def path_scan(traj, whole_paths, coeffs=None, want_values=True):
+    """rl_path_scan: (tin int32 [T,N], valid bool [T,N], values f64 [T,N] or None)."""
+    dev = traj.device
+    T, N = traj.T, traj.N
+    tin = torch.empty((T, N), dtype=torch.int32, device=dev)
+    valid = torch.empty((T, N), dtype=torch.uint8, device=dev)
+    values = torch.empty((T, N), dtype=torch.float64, device=dev) if (want_values and coeffs is not None) else None
+    cf = None
+    if coeffs is not None:
+        cf = torch.as_tensor(np.asarray(coeffs, dtype=np.float64), device=dev).contiguous()
+        assert cf.numel() == 2 * traj.obs_dim + 4
+    _lib.check(_lib.lib.rl_path_scan(T, N, traj.obs_dim, _lib.ptr(traj.dones), _lib.ptr(traj.obs), _lib.ptr(cf),
+                                     int(bool(whole_paths)), _lib.ptr(tin), _lib.ptr(valid), _lib.ptr(values),
+                                     _lib.stream_ptr()), "rl_path_scan")
+    return tin, valid.bool(), values
+
+
+def merge_stats(st):
+    """Combine the rl_sample_stats rows of all env shards: two collectives (sum columns; min / max
+    columns folded into one MAX by negating the minima)."""
+    if not D.is_distributed():
+        return st
+    sums = st[:_N_SUM].clone()
+    D.all_reduce_sum_(sums)
+    ext = torch.stack([-st[_ADVMIN], st[_UNDMAX], -st[_UNDMIN]])
+    D.all_reduce_max_(ext)
+    return torch.cat([sums, torch.stack([-ext[0], ext[1], -ext[2]])])
+
+
+_SHIFT = dict(ret=0.0, und=0.0)   # last iteration's means: they only condition the one-pass variances
 
 
 def process_dense(algo, itr, traj, log=True):
-    """Post-process one dense rollout in place and return ``SamplesData``."""
+    """Post-process one dense rollout in place and return ``SamplesData``.
+
+    Launches: rl_path_scan (path index + validity + baseline prediction), rl_gae (advantages,
+    returns, undiscounted returns), rl_sample_stats (every moment below in one read),
+    rl_adv_finish, then the baseline fit (rl_lfb_normal_eq for LinearFeatureBaseline)."""
     dev = traj.device
     T, N = traj.T, traj.N
+    B = T * N
     gamma, lam = float(algo.discount), float(algo.gae_lambda)
-    valid = traj.valid_mask(algo.whole_paths) if traj.valid is None else traj.valid
-    traj.valid = valid
-    w = valid.to(torch.float64)
-    (cnt,) = D.sums(w.sum())
-
     baseline = algo.baseline
-    if hasattr(baseline, "predict_dense"):
-        base = baseline.predict_dense(traj)
-    else:  # arbitrary user baseline: per-path predict on host, scattered back
-        base = _predict_by_path(baseline, traj)
+    dense_lfb = hasattr(baseline, "dense_coeffs") and traj.obs_dim <= 20
+    preset_valid = traj.valid
+    tin, valid, base = path_scan(traj, algo.whole_paths, baseline.dense_coeffs() if dense_lfb else None)
+    if preset_valid is not None:          # batches packed from path lists carry their own padding mask
+        valid = preset_valid
+    traj.valid, traj.tin = valid, tin
+    if not dense_lfb:
+        if hasattr(baseline, "predict_dense"):
+            base = baseline.predict_dense(traj)
+        else:  # arbitrary user baseline: per-path predict on host, scattered back
+            base = _predict_by_path(baseline, traj)
     adv = torch.empty((T, N), dtype=torch.float32, device=dev)
     ret = torch.empty((T, N), dtype=torch.float32, device=dev)
+    und = torch.empty((T, N), dtype=torch.float32, device=dev)
     base_c = base.contiguous() if base is not None else None
     _lib.check(_lib.lib.rl_gae(T, N, _lib.ptr(traj.rewards), _lib.ptr(base_c), _lib.ptr(traj.dones),
-                               gamma, lam, _lib.ptr(adv), _lib.ptr(ret), _lib.stream_ptr()), "rl_gae")
+                               gamma, lam, _lib.ptr(adv), _lib.ptr(ret), _lib.ptr(und), _lib.stream_ptr()), "rl_gae")
     traj.returns = ret
     traj.baselines = base
 
+    valid_u8 = valid.to(torch.uint8)
+    ws = _workspace(dev, traj.obs_dim)
+    st = torch.empty(16, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib.rl_sample_stats(B, _lib.ptr(ret), _lib.ptr(base_c), _lib.ptr(adv), _lib.ptr(und),
+                                        _lib.ptr(tin), _lib.ptr(valid_u8), _SHIFT["ret"], _SHIFT["und"],
+                                        _lib.ptr(ws), ws.numel(), _lib.ptr(st), _lib.stream_ptr()), "rl_sample_stats")
+    s = merge_stats(st).cpu().numpy()         # the iteration's one host read of batch statistics
+    cnt, n_paths = s[_COUNT], s[_NPATH]
+
+    def moments(i_sum, i_sq, n):
+        m = s[i_sum] / n
+        return m, max(s[i_sq] / n - m * m, 0.0)
+    m_ret, var_y = moments(_RET, _RET2, cnt)
+    _, var_pred = moments(_BASE, _BASE2, cnt)
+    _, var_res = moments(_RES, _RES2, cnt)
     # explained variance of the baseline (special.explained_variance_1d, reference :68-71)
-    ret64 = ret.to(torch.float64)
-    base64 = base if base is not None else torch.zeros_like(ret64)
-    _, var_y = _two_pass_var(ret64, w, cnt)
-    _, var_res = _two_pass_var(ret64 - base64, w, cnt)
-    _, var_pred = _two_pass_var(base64, w, cnt)
-    var_y_f = float(var_y)
-    if np.isclose(var_y_f, 0):
-        ev = 0 if float(var_pred) > 0 else 1
+    if np.isclose(var_y, 0):
+        ev = 0 if var_pred > 0 else 1
     else:
-        ev = 1 - float(var_res) / (var_y_f + 1e-8)
+        ev = 1 - var_res / (var_y + 1e-8)
 
     # advantage centring / shifting (algos/util.py:7-12), statistics over valid samples
-    adv64 = adv.to(torch.float64)
+    mean_a, denom, shift = 0.0, 1.0, 0.0
     if algo.center_adv:
-        mean, var = _two_pass_var(adv64, w, cnt)
-        adv64 = (adv64 - mean) / (torch.sqrt(var) + 1e-8)
+        mean_a, var_a = moments(_ADV, _ADV2, cnt)
+        denom = float(np.sqrt(var_a)) + 1e-8
     if algo.positive_adv:
-        big = torch.full_like(adv64, float("inf"))
-        mn = D.all_reduce_min_(torch.where(valid, adv64, big).min())
-        adv64 = (adv64 - mn) + 1e-8
-    traj.advantages = torch.where(valid, adv64, torch.zeros_like(adv64)).to(torch.float32)
+        shift = -((s[_ADVMIN] - mean_a) / denom) + 1e-8
+    adv_out = torch.empty((T, N), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.rl_adv_finish(B, _lib.ptr(adv), _lib.ptr(valid_u8), float(mean_a), float(denom),
+                                      float(shift), _lib.ptr(adv_out), _lib.stream_ptr()), "rl_adv_finish")
+    traj.advantages = adv_out
 
-    # per-path statistics
-    paths = PathList(traj)
-    env, t0, t1 = paths.index()
-    r64 = traj.rewards.to(torch.float64)
-    csum = torch.cumsum(r64, dim=0)
-    before = torch.where(t0 > 0, csum[(t0 - 1).clamp(min=0), env], torch.zeros_like(csum[t0, env]))
-    undisc = csum[t1, env] - before
-    disc0 = ret64[t0, env]
-    n_local = torch.as_tensor(float(env.numel()), dtype=torch.float64, device=dev)
-    n_paths, s_disc, s_und = D.sums(n_local, disc0.sum(), undisc.sum())
-    mean_und = s_und / n_paths
-    (ss_und,) = D.sums(((undisc - mean_und) ** 2).sum())
-    inf = torch.as_tensor(float("inf"), dtype=torch.float64, device=dev)
-    mx = D.all_reduce_max_(undisc.max() if undisc.numel() else -inf)
-    mn = D.all_reduce_min_(undisc.min() if undisc.numel() else inf)
+    m_und_s, var_und = moments(_UND, _UND2, n_paths) if n_paths > 0 else (np.nan, np.nan)
+    mean_und = m_und_s + _SHIFT["und"]
+    _SHIFT["ret"], _SHIFT["und"] = float(m_ret + _SHIFT["ret"]), (float(mean_und) if n_paths > 0 else 0.0)
 
     # Entropy = mean over samples of the policy entropy (reference :93)
     pdist = algo.policy.distribution
     if traj.log_std_planes is not None and hasattr(pdist, "entropy_sym"):
         e = pdist.entropy_sym(dict(log_std=traj.log_std_planes.to(torch.float64)), axis=0)
-        (es,) = D.sums((e * w).sum())
-        ent = float(es / cnt)
+        (es,) = D.sums((e * valid.to(torch.float64)).sum())
+        ent = float(es) / cnt
     elif traj.log_std is not None and hasattr(pdist, "entropy_sym"):
         ent = float(pdist.entropy_sym(dict(log_std=traj.log_std.to(torch.float64)), axis=0))
     else:
         ent = float("nan")
 
+    paths = PathList(traj)
     samples_data = SamplesData(_traj=traj, paths=paths)
 
     if log:
@@ -172,15 +219,15 @@ def process_dense(algo, itr, traj, log=True):
     if log:
         logger.log("fitted")
         logger.record_tabular('Iteration', itr)
-        logger.record_tabular('AverageDiscountedReturn', float(s_disc / n_paths))
+        logger.record_tabular('AverageDiscountedReturn', float(s[_DISC] / n_paths) if n_paths > 0 else np.nan)
         logger.record_tabular('AverageReturn', float(mean_und))
         logger.record_tabular('ExplainedVariance', ev)
         logger.record_tabular('NumTrajs', int(round(float(n_paths))))
         logger.record_tabular('Entropy', ent)
         logger.record_tabular('Perplexity', float(np.exp(ent)))
-        logger.record_tabular('StdReturn', float(torch.sqrt(ss_und / n_paths)))
-        logger.record_tabular('MaxReturn', float(mx))
-        logger.record_tabular('MinReturn', float(mn))
+        logger.record_tabular('StdReturn', float(np.sqrt(var_und)) if n_paths > 0 else np.nan)
+        logger.record_tabular('MaxReturn', float(s[_UNDMAX]))
+        logger.record_tabular('MinReturn', float(s[_UNDMIN]))
     return samples_data
 
 

@@ -34,6 +34,7 @@ class Trajectories(object):
         self.advantages = None
         self.returns = None
         self.baselines = None
+        self.tin = None          # [T, N] int32 step index inside its path (rl_path_scan)
 
     @property
     def device(self):

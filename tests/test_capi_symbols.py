@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.rl_abi_version() == 1
+    assert _lib.lib.rl_abi_version() == 2
 
 
 def test_env_query_and_errors():
@@ -40,7 +40,7 @@ def test_env_query_and_errors():
     assert _lib.lib.rl_env_query(99, None, None, None, None, None) == -1
     assert b"env kind 99" in _lib.lib.rl_last_error()
     assert _lib.lib.rl_vecenv_reset(0, 0, None, None, None, None, 0, 0, 0, None, None) == -1
-    assert _lib.lib.rl_gae(0, 0, None, None, None, 0.99, 1.0, None, None, None) == -1
+    assert _lib.lib.rl_gae(0, 0, None, None, None, 0.99, 1.0, None, None, None, None) == -1
     assert _lib.lib.rl_rollout_gaussian_mlp(None, None) == -1
     assert _lib.lib.rl_policy_fvp(None, None, None, 0, None, None) == -1
     assert _lib.lib.rl_policy_workspace_bytes(13, 2, 32, 32) > 0

@@ -114,17 +114,19 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
     from rllab_amd.sampler import dist as D
-    from rllab_amd.sampler.base import _two_pass_var
+    from rllab_amd.sampler.base import merge_stats
     assert D.is_distributed() and D.world_size() == world and D.rank() == rank
     # statistics
     s, = D.sums(torch.tensor(float(rank + 1)))
     assert float(s) == 3.0
     assert float(D.all_reduce_min_(torch.tensor(float(rank)))) == 0.0
     assert float(D.all_reduce_max_(torch.tensor(float(rank)))) == 1.0
-    x = torch.arange(10, dtype=torch.float64) + 10 * rank
-    mean, var = _two_pass_var(x, torch.ones(10, dtype=torch.float64), D.sums(torch.tensor(10.0))[0])
-    full = np.concatenate([np.arange(10), np.arange(10) + 10]).astype(np.float64)
-    assert np.isclose(float(mean), full.mean()) and np.isclose(float(var), full.var())
+    # rl_sample_stats rows of two shards -> global row: 13 sum columns, then min / max / min
+    row = torch.arange(16, dtype=torch.float64) + 100.0 * rank
+    row[13], row[14], row[15] = -5.0 - rank, 7.0 + rank, -3.0 + rank
+    got = merge_stats(row).numpy()
+    assert np.array_equal(got[:13], 2 * np.arange(13) + 100.0)
+    assert got[13] == -6.0 and got[14] == 8.0 and got[15] == -3.0
     # TRPO update on half of the batch
     pol, inputs = _make_problem()
     theta, before, after = _run_trpo(pol, _shard(inputs, rank, world))

@@ -158,7 +158,7 @@ def test_gae_kernel_vs_float64_loop(T, n):
     ret = torch.empty((T, n), dtype=torch.float32, device=dev)
     tr, tv, td = (torch.as_tensor(x, device=dev) for x in (r, v, done))
     _lib.check(_lib.lib.rl_gae(T, n, _lib.ptr(tr), _lib.ptr(tv), _lib.ptr(td), gamma, lam, _lib.ptr(adv),
-                               _lib.ptr(ret), _lib.stream_ptr()))
+                               _lib.ptr(ret), None, _lib.stream_ptr()))
     end = done.astype(bool).copy()
     end[-1] = True
     keep = 1.0 - end
@@ -171,7 +171,7 @@ def test_gae_kernel_vs_float64_loop(T, n):
     assert np.abs(ret.cpu().numpy() - want_ret).max() <= 1e-5 * max(1.0, np.abs(want_ret).max())
     # values=None path
     _lib.check(_lib.lib.rl_gae(T, n, _lib.ptr(tr), None, _lib.ptr(td), gamma, 1.0, _lib.ptr(adv),
-                               _lib.ptr(ret), _lib.stream_ptr()))
+                               _lib.ptr(ret), None, _lib.stream_ptr()))
     assert np.abs(adv.cpu().numpy() - want_ret).max() <= 1e-5 * max(1.0, np.abs(want_ret).max())
 
 

@@ -80,7 +80,7 @@ def test_gae_full_size_properties():
 
     def gae(r, v, d, lam=1.0):
         _lib.check(_lib.lib.rl_gae(T, n, _lib.ptr(r), _lib.ptr(v), _lib.ptr(d), gamma, lam, _lib.ptr(adv),
-                                   _lib.ptr(ret), _lib.stream_ptr()))
+                                   _lib.ptr(ret), None, _lib.stream_ptr()))
         return adv.clone(), ret.clone()
     _, r1 = gae(ones, None, done)
     k = torch.arange(T, 0, -1, device=dev, dtype=torch.float64)
@@ -180,3 +180,109 @@ def test_cartpole_whole_paths_drop_incomplete_tails(quiet_logger):
         algo.optimize_policy(0, sd)
         assert np.isfinite(pol.get_param_values()).all() and np.abs(pol.get_param_values() - theta0).max() > 0
         logger.dump_tabular()
+
+
+def _np_tin_valid(done, whole_paths=True):
+    T, n = done.shape
+    tin = np.zeros((T, n), np.int64)
+    valid = np.zeros((T, n), bool)
+    for i in range(n):
+        start = 0
+        for t in range(T):
+            if t > 0 and done[t - 1, i]:
+                start = t
+            tin[t, i] = t - start
+        seen = False
+        for t in range(T - 1, -1, -1):
+            seen = seen or bool(done[t, i])
+            valid[t, i] = seen or not whole_paths
+    return tin, valid
+
+
+def _np_features(obs, tin):
+    """[B, F] float64 features in the reference's order (linear_feature_baseline.py:16-19)."""
+    o = np.clip(obs.astype(np.float64), -10, 10)
+    al = tin.astype(np.float64)[:, None] / 100.0
+    return np.concatenate([o, o ** 2, al, al ** 2, al ** 3, np.ones_like(al)], axis=1)
+
+
+@pytest.mark.parametrize("T,n,do", [(1, 1, 4), (7, 3, 6), (100, 257, 13), (513, 64, 20)])
+@pytest.mark.parametrize("whole_paths", [True, False])
+def test_path_scan_and_normal_equations_vs_numpy(T, n, do, whole_paths):
+    """rl_path_scan (path index, validity, fused baseline prediction) and rl_lfb_normal_eq
+    (Phi^T W Phi, Phi^T W y) against per-column numpy loops / a float64 feature matrix."""
+    from rllab_amd import _lib
+    from rllab_amd.sampler.base import _workspace
+    rng = np.random.RandomState(T * 100 + n)
+    dev = torch.device("cuda", 0)
+    done = (rng.rand(T, n) < 0.07).astype(np.uint8)
+    obs = (rng.randn(do, T, n) * 6).astype(np.float32)          # some values beyond the +-10 clip
+    F = 2 * do + 4
+    coeffs = rng.randn(F)
+    t_done, t_obs = torch.as_tensor(done, device=dev), torch.as_tensor(obs, device=dev)
+    tin = torch.empty((T, n), dtype=torch.int32, device=dev)
+    valid = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    values = torch.empty((T, n), dtype=torch.float64, device=dev)
+    cf = torch.as_tensor(coeffs, device=dev)
+    _lib.check(_lib.lib.rl_path_scan(T, n, do, _lib.ptr(t_done), _lib.ptr(t_obs), _lib.ptr(cf), int(whole_paths),
+                                     _lib.ptr(tin), _lib.ptr(valid), _lib.ptr(values), _lib.stream_ptr()))
+    want_tin, want_valid = _np_tin_valid(done, whole_paths)
+    assert np.array_equal(tin.cpu().numpy(), want_tin)
+    assert np.array_equal(valid.cpu().numpy().astype(bool), want_valid)
+    phi = _np_features(obs.reshape(do, -1).T, want_tin.reshape(-1))
+    want_v = phi.dot(coeffs)
+    assert np.abs(values.cpu().numpy().reshape(-1) - want_v).max() <= 1e-11 * max(1.0, np.abs(want_v).max())
+    # normal equations over the valid samples
+    ret = rng.randn(T, n).astype(np.float32) * 30
+    t_ret = torch.as_tensor(ret, device=dev)
+    ws = _workspace(dev, do)
+    out = torch.empty((F + 1) * F, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib.rl_lfb_normal_eq(T * n, do, _lib.ptr(t_obs), _lib.ptr(tin), _lib.ptr(t_ret), _lib.ptr(valid),
+                                         _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()))
+    w = want_valid.reshape(-1).astype(np.float64)
+    gram = (phi * w[:, None]).T.dot(phi)
+    rhs = (phi * w[:, None]).T.dot(ret.reshape(-1).astype(np.float64))
+    got = out.cpu().numpy()
+    assert np.abs(got[:F * F].reshape(F, F) - gram).max() <= 1e-11 * max(1.0, np.abs(gram).max())
+    assert np.abs(got[F * F:] - rhs).max() <= 1e-11 * max(1.0, np.abs(rhs).max())
+
+
+@pytest.mark.parametrize("B", [1, 63, 5000, 2048000])
+def test_sample_stats_and_adv_finish_vs_numpy(B):
+    from rllab_amd import _lib
+    from rllab_amd.sampler.base import _workspace
+    rng = np.random.RandomState(B % 1000)
+    dev = torch.device("cuda", 0)
+    ret = (rng.randn(B) * 20 + 300).astype(np.float32)
+    base = rng.randn(B) * 20 + 290
+    adv = (rng.randn(B) * 3 + 1).astype(np.float32)
+    und = (rng.randn(B) * 50 + 500).astype(np.float32)
+    tin = (rng.rand(B) < 0.9).astype(np.int32) * rng.randint(1, 50, B).astype(np.int32)
+    valid = (rng.rand(B) < 0.8).astype(np.uint8)
+    valid[0] = 1
+    tin[0] = 0
+    t = lambda x: torch.as_tensor(x, device=dev)
+    ws = _workspace(dev, 13)
+    out = torch.empty(16, dtype=torch.float64, device=dev)
+    args = [t(ret), t(base), t(adv), t(und), t(tin), t(valid)]
+    _lib.check(_lib.lib.rl_sample_stats(B, *[_lib.ptr(a) for a in args], 280.0, 450.0, _lib.ptr(ws), ws.numel(),
+                                        _lib.ptr(out), _lib.stream_ptr()))
+    s = out.cpu().numpy()
+    m = valid.astype(bool)
+    st = m & (tin == 0)
+    r64, a64, u64 = ret.astype(np.float64), adv.astype(np.float64), und.astype(np.float64)
+    want = [m.sum(), (r64[m] - 280).sum(), ((r64[m] - 280) ** 2).sum(), (base[m] - 280).sum(), ((base[m] - 280) ** 2).sum(),
+            (r64[m] - base[m]).sum(), ((r64[m] - base[m]) ** 2).sum(), a64[m].sum(), (a64[m] ** 2).sum(), st.sum(),
+            (u64[st] - 450).sum(), ((u64[st] - 450) ** 2).sum(), r64[st].sum(), a64[m].min(), u64[st].max(), u64[st].min()]
+    for i, (g_, w_) in enumerate(zip(s, want)):
+        assert abs(g_ - w_) <= 1e-10 * max(1.0, abs(w_)), (i, g_, w_)
+    # the variances process_samples derives from these sums equal numpy's two-pass np.var
+    cnt = s[0]
+    assert np.isclose(s[2] / cnt - (s[1] / cnt) ** 2, r64[m].var(), rtol=1e-9)
+    assert np.isclose(s[8] / cnt - (s[7] / cnt) ** 2, a64[m].var(), rtol=1e-9)
+    mean, denom = a64[m].mean(), a64[m].std() + 1e-8
+    o = torch.empty(B, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.rl_adv_finish(B, _lib.ptr(args[2]), _lib.ptr(args[5]), mean, denom, 0.25, _lib.ptr(o),
+                                      _lib.stream_ptr()))
+    want_o = np.where(m, (a64 - mean) / denom + 0.25, 0.0)
+    assert np.abs(o.cpu().numpy() - want_o).max() <= 1e-6
