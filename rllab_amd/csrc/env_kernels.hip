@@ -11,6 +11,7 @@
 #include "capi_util.h"
 #include "device_rng.h"
 #include "envs.h"
+#include "policy_mfma.h"
 
 namespace rl {
 
@@ -102,67 +103,90 @@ vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length
 // Fused rollout: GaussianMLPPolicy.get_actions + env.step + record + auto-reset,
 // T times, one launch.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = (e^{2x} - 1) / (e^{2x} + 1); clamp keeps e^{2x} finite.  Absolute
-    // error < 2e-7 on the whole range, far inside the 1e-5 policy tolerance.
-    float xc = fminf(fmaxf(x, -10.0f), 10.0f);
-    float e = __expf(2.0f * xc);
-    return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
-}
-
-template <class Env, int H0, int H1>
-struct PolicyLayout {
-    static constexpr int DO = Env::OBS, DA = Env::ACT;
-    static constexpr int W0 = 0;
-    static constexpr int B0 = W0 + DO * H0;
-    static constexpr int W1 = B0 + H0;
-    static constexpr int B1 = W1 + H0 * H1;
-    static constexpr int W2 = B1 + H1;
-    static constexpr int B2 = W2 + H1 * DA;
-    static constexpr int LS = B2 + DA;
-    static constexpr int P = LS + DA;
-    static constexpr int P_PAD = (P + 3) & ~3;
-    // H0, H1 multiples of 4 => W0, B0, W1, B1, W2 are all 16-byte aligned in LDS
-    static_assert(H0 % 4 == 0 && H1 % 4 == 0, "hidden sizes must be multiples of 4");
-};
-
 // mean = Wout^T tanh(W1^T tanh(W0^T o + b0) + b1) + bout   (network.py:36-101)
 //
-// One thread evaluates the MLP of its own env.  Weight rows are read from LDS
-// with wave-uniform addresses (broadcast, 16 B per read); the layer input lives
-// in a per-thread LDS column x[d][lane] (conflict-free) so that the loop over
-// input units can stay ROLLED: with a fully unrolled layer LLVM clusters all P
-// weight reads ahead of the FMAs and spills thousands of bytes per lane.
-template <int IN, int OUT>
-__device__ __forceinline__ void dense_layer(const float* __restrict__ w_lds, int w_off, int b_off,
-                                            const float* __restrict__ x_col, float* y) {
-#pragma unroll
-    for (int j = 0; j < OUT; ++j) y[j] = w_lds[b_off + j];
-#pragma unroll 2
-    for (int d = 0; d < IN; ++d) {
-        const float xd = x_col[d * BLOCK];
-        const float* __restrict__ row = w_lds + w_off + d * OUT;
-#pragma unroll
-        for (int j = 0; j < OUT; ++j) y[j] = __builtin_fmaf(xd, row[j], y[j]);
-    }
-}
+// The policy GEMMs of the 64 envs of a wavefront run on the matrix cores (policy_mfma.h): the
+// observations are handed over through a [input][lane] LDS tile, two blocks of 32 envs go
+// through v_mfma_f32_32x32x2_f32 chains (layer 0: (DO+2)/2 steps, layer 1: 16*H/32 steps per
+// 32-unit tile) with the activations staying in the output-fragment registers, the thin output
+// layer (DA columns) is a per-lane dot product folded across the two lane halves, and lane l
+// picks the mean of its own env from block l/32.  One env-step of policy costs 2*HT*(KS0+KS1)
+// matrix instructions instead of ~(DO*H + H*H + H*DA) VALU FMAs + LDS weight reads per lane --
+// with a single wavefront per SIMD the rollout is bound by instruction issue, so the policy's
+// share of the step shrinks by the ratio of those counts.
+template <class Env, int H>
+struct RolloutPolicy {
+    using N = Net<Env::OBS, Env::ACT, H>;
+    static constexpr int XROWS = 2 * N::KS0;                       // inputs + bias row + zero padding
+    static constexpr int LDS_FLOATS = N::FA0 + N::FA1 + N::TAILP + XROWS * WV;
+    static constexpr int T_B1 = 0, T_W2 = N::W2 - N::B1, T_B2 = N::B2 - N::B1, T_LS = N::LSTD - N::B1;
 
-// x_col: per-thread LDS column (stride BLOCK) with room for max(DO, H0, H1) values;
-// on entry it holds the observation.
-template <class Env, int H0, int H1>
-__device__ __forceinline__ void policy_mean(const float* __restrict__ w, float* __restrict__ x_col,
-                                            float* mean) {
-    using L = PolicyLayout<Env, H0, H1>;
-    float h0[H0];
-    dense_layer<L::DO, H0>(w, L::W0, L::B0, x_col, h0);
+    float* fa0;
+    float* fa1;
+    float* tail;
+    float* xbuf;
+
+    __device__ __forceinline__ void init(float* smem, const float* __restrict__ theta) {
+        fa0 = smem;
+        fa1 = fa0 + N::FA0;
+        tail = fa1 + N::FA1;
+        xbuf = tail + N::TAILP;
+        stage_fragments<N, BLOCK>(theta, fa0, fa1, nullptr);
+        for (int k = threadIdx.x; k < N::TAIL; k += BLOCK) tail[k] = theta[N::B1 + k];
+        for (int k = threadIdx.x; k < XROWS * WV; k += BLOCK) xbuf[k] = (k / WV == Env::OBS) ? 1.0f : 0.0f;
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ float log_std(int k) const { return tail[T_LS + k]; }
+
+    // o: this lane's observation; mean: this lane's action mean
+    __device__ __forceinline__ void forward(const float* o, float* mean) const {
+        constexpr int DO = Env::OBS, DA = Env::ACT, HT = N::HT, KS0 = N::KS0, KS1 = N::KS1;
+        const int lane = threadIdx.x, lj = lane & 31, lh = lane >> 5;
+        wave_sync();                                          // the previous step's reads are done
 #pragma unroll
-    for (int j = 0; j < H0; ++j) x_col[j * BLOCK] = fast_tanh(h0[j]);
-    float h1[H1];
-    dense_layer<H0, H1>(w, L::W1, L::B1, x_col, h1);
+        for (int d = 0; d < DO; ++d) xbuf[d * WV + lane] = o[d];
+        wave_sync();
 #pragma unroll
-    for (int j = 0; j < H1; ++j) x_col[j * BLOCK] = fast_tanh(h1[j]);
-    dense_layer<H1, L::DA>(w, L::W2, L::B2, x_col, mean);
-}
+        for (int blk = 0; blk < 2; ++blk) {
+            float xb[KS0];
+#pragma unroll
+            for (int m = 0; m < KS0; ++m) xb[m] = xbuf[(2 * m + lh) * WV + 32 * blk + lj];
+            f32x16 h0[HT], h1[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h0[t][r] = ftanh(acc[r]);
+            }
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
+#pragma unroll
+                for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1[t][r] = ftanh(acc[r]);
+            }
+#pragma unroll
+            for (int k = 0; k < DA; ++k) {
+                float pm = 0.0f;
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pm = __builtin_fmaf(h1[t][r], tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], pm);
+                const float mk = tail[T_B2 + k] + half_sum(pm);
+                if (lh == blk) mean[k] = mk;
+            }
+        }
+    }
+};
 
 struct RolloutDev {
     int n, T, max_path_length, normalize, reset_at_start, env_offset;
@@ -183,23 +207,24 @@ struct RolloutDev {
 
 template <class Env, int H0, int H1>
 __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
-    using L = PolicyLayout<Env, H0, H1>;
-    constexpr int XMAX = (L::DO > H0 ? (L::DO > H1 ? L::DO : H1) : (H0 > H1 ? H0 : H1));
-    __shared__ __attribute__((aligned(16))) float w[L::P_PAD];
-    __shared__ float xbuf[XMAX * BLOCK];
-    for (int k = threadIdx.x; k < L::P; k += BLOCK) w[k] = a.theta[k];
-    __syncthreads();
-    float* x_col = xbuf + threadIdx.x;
+    static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
+    using Pol = RolloutPolicy<Env, H0>;
+    __shared__ __attribute__((aligned(16))) float smem[Pol::LDS_FLOATS];
+    Pol pol;
+    pol.init(smem, a.theta);
 
     const int n = a.n, T = a.T;
-    int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    // every lane stays alive (the matrix instructions and the cross-half exchange need the whole
+    // wavefront); lanes past the last env shadow env n-1 and only their stores are masked
+    const int i_raw = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i_raw < n;
+    const int i = live ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
     const size_t plane = (size_t)T * n;
 
     float std_[Env::ACT];
 #pragma unroll
-    for (int k = 0; k < Env::ACT; ++k) std_[k] = __expf(fmaxf(w[L::LS + k], a.log_min_std));
+    for (int k = 0; k < Env::ACT; ++k) std_[k] = __expf(fmaxf(pol.log_std(k), a.log_min_std));
 
     float s[Env::STATE];
     load_state<Env>(a.state, n, i, s);
@@ -214,13 +239,12 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
 
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
+        if (live) {
 #pragma unroll
-        for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
-
+            for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
+        }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
-#pragma unroll
-        for (int k = 0; k < Env::OBS; ++k) x_col[k * BLOCK] = o[k];
-        policy_mean<Env, H0, H1>(w, x_col, mean);
+        pol.forward(o, mean);
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
@@ -230,8 +254,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
 #pragma unroll
         for (int k = 0; k < Env::ACT; ++k) {
             act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
-            a.actions[k * plane + off] = act[k];
-            a.means[k * plane + off] = mean[k];
+            if (live) {
+                a.actions[k * plane + off] = act[k];
+                a.means[k * plane + off] = mean[k];
+            }
         }
 
         float r;
@@ -239,8 +265,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
         Env::template step<float>(s, act, a.normalize, o, r, d);
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
-        a.rewards[off] = r * a.scale_reward;
-        a.dones[off] = d ? 1 : 0;
+        if (live) {
+            a.rewards[off] = r * a.scale_reward;
+            a.dones[off] = d ? 1 : 0;
+        }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
             reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1);
@@ -248,11 +276,13 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
             ts = 0;
         }
     }
-    store_state<Env>(a.state, n, i, s);
-    a.ts[i] = ts;
-    if (a.last_obs) {
+    if (live) {
+        store_state<Env>(a.state, n, i, s);
+        a.ts[i] = ts;
+        if (a.last_obs) {
 #pragma unroll
-        for (int k = 0; k < Env::OBS; ++k) a.last_obs[(size_t)k * n + i] = o[k];
+            for (int k = 0; k < Env::OBS; ++k) a.last_obs[(size_t)k * n + i] = o[k];
+        }
     }
 }
 

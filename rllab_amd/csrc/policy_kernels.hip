@@ -41,70 +41,14 @@
 #include <hip/hip_runtime.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
+#include "policy_mfma.h"
 
 namespace rl {
 
-constexpr int WV = 64;        // wavefront
-constexpr int TS = 32;        // samples per MFMA tile
 constexpr int WAVES = 4;      // wavefronts per workgroup (one per SIMD)
 
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_FVP = 2, MODE_VPG = 3 };
 constexpr int LOSS_COLS = 4;  // sum w*lr*adv, sum w*kl, sum w*logp*adv, max kl
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-__device__ __forceinline__ float ftanh(float x) {
-    float xc = fminf(fmaxf(x, -10.0f), 10.0f);
-    float e = __expf(2.0f * xc);
-    return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
-}
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// unit held by register r of the 32x32 output fragment in lane half `half`
-__host__ __device__ constexpr int frag_unit(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// compiler-level ordering of wave-private LDS traffic between lanes (the LDS queue of one
-// wavefront is in order, so no s_barrier is needed -- only the compiler must not move
-// accesses across the hand-over)
-__device__ __forceinline__ void wave_sync() {
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_wave_barrier();
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
-
-template <int DO_, int DA_, int H_>
-struct Net {
-    static constexpr int DO = DO_, DA = DA_, H = H_;
-    static constexpr int HT = H / 32;                 // 32-unit tiles per hidden layer
-    static constexpr int KS0 = (DO + 2) / 2;          // k-steps of layer 0 (inputs + the bias slot)
-    static constexpr int KS1 = 16 * HT;               // k-steps of layer 1
-    static constexpr int W0 = 0;
-    static constexpr int B0 = W0 + DO * H;
-    static constexpr int W1 = B0 + H;
-    static constexpr int B1 = W1 + H * H;
-    static constexpr int W2 = B1 + H;
-    static constexpr int B2 = W2 + H * DA;
-    static constexpr int LSTD = B2 + DA;
-    static constexpr int P = LSTD + DA;
-    static constexpr int TAIL = P - B1;               // b1, W2, b2, log_std: VALU-side parameters
-    static constexpr int TAILP = (TAIL + 3) & ~3;
-    static constexpr int TSTR = H + 1;                // transposition tile stride (odd)
-    static constexpr int XS = (2 * KS0) | 1;          // x tile stride (odd)
-    static constexpr int GS = DA | 1;                 // gmu tile stride (odd)
-    static constexpr int FA0 = HT * KS0 * WV;         // floats per layer-0 weight fragment set
-    static constexpr int FA1 = HT * KS1 * WV;         // floats per layer-1 weight fragment set
-    static constexpr int WAVE_LDS = TS * TSTR + TS * XS + TS * GS;
-    // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
-    static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
-    static_assert(H % 32 == 0 && HT <= 2, "hidden size must be 32 or 64");
-    static_assert(DO + 1 <= 32, "obs_dim + 1 must fit one 32-row tile");
-
-    // k index (unit of the previous layer) that lane half `half` contributes at k-step m of layer 1
-    __host__ __device__ static constexpr int k1(int m, int half) { return 32 * (m / 16) + frag_unit(m % 16, half); }
-};
 
 template <class N, int MODE>
 struct Smem {
@@ -123,24 +67,6 @@ struct Smem {
     static_assert(TOTAL >= N::P, "LDS fold buffer must fit");
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WV));
-    return v;
-}
-// value + the value held by the same sample / unit in the other lane half
-__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, WV); }
-
 struct PolicyBatch {
     int B;                     // samples
     const float* theta;        // [P]
@@ -156,24 +82,6 @@ struct PolicyBatch {
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS)
 };
-
-// stage one parameter vector as MFMA A-operand fragments (see the file header)
-template <class N>
-__device__ __forceinline__ void stage_fragments(const float* __restrict__ th, float* fa0, float* fa1,
-                                                float* fa1t) {
-    constexpr int H = N::H;
-    for (int e = threadIdx.x; e < N::FA0; e += WAVES * WV) {
-        const int l = e % WV, m = (e / WV) % N::KS0, t = e / (WV * N::KS0);
-        const int i = 32 * t + (l & 31), d = 2 * m + (l >> 5);
-        fa0[e] = d < N::DO ? th[N::W0 + d * H + i] : (d == N::DO ? th[N::B0 + i] : 0.0f);
-    }
-    for (int e = threadIdx.x; e < N::FA1; e += WAVES * WV) {
-        const int l = e % WV, m = (e / WV) % N::KS1, t = e / (WV * N::KS1);
-        const int i = 32 * t + (l & 31), k = N::k1(m, l >> 5);
-        fa1[e] = th[N::W1 + k * H + i];                     // A[i][k] = W1[k][i]   (forward: W1^T)
-        if (fa1t) fa1t[e] = th[N::W1 + i * H + k];          // A[i][k] = W1[i][k]   (backward: W1)
-    }
-}
 
 template <class N, int MODE>
 __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
@@ -196,8 +104,8 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     float* const tbx = tb + TS * TSTR;                        // [32][XS]   x (+1) rows
     float* const tbg = tbx + TS * XS;                         // [32][GS]   gmu rows
 
-    stage_fragments<N>(a.theta, fa0, fa1, GRADLIKE ? fa1t : nullptr);
-    if (FVP) stage_fragments<N>(a.vec, fda0, fda1, nullptr);
+    stage_fragments<N, WAVES * WV>(a.theta, fa0, fa1, GRADLIKE ? fa1t : nullptr);
+    if (FVP) stage_fragments<N, WAVES * WV>(a.vec, fda0, fda1, nullptr);
     for (int k = threadIdx.x; k < N::TAIL; k += WAVES * WV) {
         tail[k] = a.theta[N::B1 + k];
         if (FVP) dtail[k] = a.vec[N::B1 + k];

@@ -1,0 +1,109 @@
+// policy_mfma.h -- GaussianMLPPolicy mean network on v_mfma_f32_32x32x2_f32: the pieces shared by
+// the update kernels (policy_kernels.hip) and the fused rollout (env_kernels.hip).
+//
+// Every dense layer is evaluated TRANSPOSED,  Z^T[unit][sample] = W^T[unit][k] * X^T[k][sample],
+// so the MFMA output fragment (lane = sample + 32*half, register r = unit
+// u(r, half) = (r&3) + 8*(r>>2) + 4*half) is, after the element-wise tanh, directly the B operand
+// of the next layer: k-step m of that layer multiplies register m of this one, and the weight
+// fragment staged in LDS for step m holds rows u(m, half) of W.  Layer 0's bias rides in the
+// spare input slot (x[DO] = 1), layer 1's bias initialises the accumulator.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rl {
+
+constexpr int WV = 64;        // wavefront
+constexpr int TS = 32;        // samples per MFMA tile
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float ftanh(float x) {
+    float xc = fminf(fmaxf(x, -10.0f), 10.0f);
+    float e = __expf(2.0f * xc);
+    return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// unit held by register r of the 32x32 output fragment in lane half `half`
+__host__ __device__ constexpr int frag_unit(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// compiler-level ordering of wave-private LDS traffic between lanes (the LDS queue of one
+// wavefront is in order, so no s_barrier is needed -- only the compiler must not move
+// accesses across the hand-over)
+__device__ __forceinline__ void wave_sync() {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_wave_barrier();
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
+template <int DO_, int DA_, int H_>
+struct Net {
+    static constexpr int DO = DO_, DA = DA_, H = H_;
+    static constexpr int HT = H / 32;                 // 32-unit tiles per hidden layer
+    static constexpr int KS0 = (DO + 2) / 2;          // k-steps of layer 0 (inputs + the bias slot)
+    static constexpr int KS1 = 16 * HT;               // k-steps of layer 1
+    static constexpr int W0 = 0;
+    static constexpr int B0 = W0 + DO * H;
+    static constexpr int W1 = B0 + H;
+    static constexpr int B1 = W1 + H * H;
+    static constexpr int W2 = B1 + H;
+    static constexpr int B2 = W2 + H * DA;
+    static constexpr int LSTD = B2 + DA;
+    static constexpr int P = LSTD + DA;
+    static constexpr int TAIL = P - B1;               // b1, W2, b2, log_std: VALU-side parameters
+    static constexpr int TAILP = (TAIL + 3) & ~3;
+    static constexpr int TSTR = H + 1;                // transposition tile stride (odd)
+    static constexpr int XS = (2 * KS0) | 1;          // x tile stride (odd)
+    static constexpr int GS = DA | 1;                 // gmu tile stride (odd)
+    static constexpr int FA0 = HT * KS0 * WV;         // floats per layer-0 weight fragment set
+    static constexpr int FA1 = HT * KS1 * WV;         // floats per layer-1 weight fragment set
+    static constexpr int WAVE_LDS = TS * TSTR + TS * XS + TS * GS;
+    // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
+    static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
+    static_assert(H % 32 == 0 && HT <= 2, "hidden size must be 32 or 64");
+    static_assert(DO + 1 <= 32, "obs_dim + 1 must fit one 32-row tile");
+
+    // k index (unit of the previous layer) that lane half `half` contributes at k-step m of layer 1
+    __host__ __device__ static constexpr int k1(int m, int half) { return 32 * (m / 16) + frag_unit(m % 16, half); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WV));
+    return v;
+}
+// value + the value held by the same sample / unit in the other lane half
+__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, WV); }
+
+// stage one parameter vector as MFMA A-operand fragments (see the file header)
+template <class N, int NT>
+__device__ __forceinline__ void stage_fragments(const float* __restrict__ th, float* fa0, float* fa1,
+                                                float* fa1t) {
+    constexpr int H = N::H;
+    for (int e = threadIdx.x; e < N::FA0; e += NT) {
+        const int l = e % WV, m = (e / WV) % N::KS0, t = e / (WV * N::KS0);
+        const int i = 32 * t + (l & 31), d = 2 * m + (l >> 5);
+        fa0[e] = d < N::DO ? th[N::W0 + d * H + i] : (d == N::DO ? th[N::B0 + i] : 0.0f);
+    }
+    for (int e = threadIdx.x; e < N::FA1; e += NT) {
+        const int l = e % WV, m = (e / WV) % N::KS1, t = e / (WV * N::KS1);
+        const int i = 32 * t + (l & 31), k = N::k1(m, l >> 5);
+        fa1[e] = th[N::W1 + k * H + i];                     // A[i][k] = W1[k][i]   (forward: W1^T)
+        if (fa1t) fa1t[e] = th[N::W1 + i * H + k];          // A[i][k] = W1[i][k]   (backward: W1)
+    }
+}
+
+}  // namespace rl
