@@ -37,8 +37,8 @@ WORKLOADS = {
     # name: (env module, env class, horizon T, hidden, algo, gae_lambda, algorithmic bytes / env-step, flops / env-step)
     "swimmer4096_trpo": dict(env="swimmer", n_envs=4096, T=500, hidden=(32, 32), algo="trpo", lam=1.0,
                              step_bytes=145, record_bytes=72,
-                             # 50 sub-steps x ~1.1 kflop articulated-body pass + 3008 flop policy (8d)
-                             flops_per_step=50 * 1100 + 3008),
+                             # 50 sub-steps x ~0.55 kflop articulated-body pass + 3008 flop policy (8d)
+                             flops_per_step=50 * 550 + 3008),
     "cartpole4096_vpg": dict(env="cartpole", n_envs=4096, T=100, hidden=(32, 32), algo="vpg", lam=1.0,
                              step_bytes=153, record_bytes=28, flops_per_step=3000 + 2368),
     # parity-config side lines (not the headline): DoublePendulum, and BASELINE config C5's per-GPU shard
@@ -121,6 +121,8 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase_ms = dict(sample=0.0, process=0.0, update=0.0)
     rollout_ms = []
+    last = {}
+    per_iter = []
 
     def iteration(itr, timed):
         e = [ev() for _ in range(4)]
@@ -132,6 +134,7 @@ def main():
         e[2].record()
         algo.optimize_policy(itr, samples)
         e[3].record()
+        last["samples"] = samples
         logger.dump_tabular()
         if timed:
             torch.cuda.synchronize()
@@ -139,9 +142,15 @@ def main():
             phase_ms["sample"] += e[0].elapsed_time(e[1])
             phase_ms["process"] += e[1].elapsed_time(e[2])
             phase_ms["update"] += e[2].elapsed_time(e[3])
+            per_iter.append((round(e[2].elapsed_time(e[3]), 3), getattr(algo.optimizer, "last_backtrack_iters", None)))
 
     for w in range(args.warmup):
         iteration(w, False)
+    # a generation-2 pass of Python's cyclic GC walks every object torch has created (~35 ms here)
+    # and would land inside one timed iteration: collect now and freeze the survivors
+    import gc
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -163,6 +172,37 @@ def main():
     avg_rollout_s = (sum(rollout_ms) / len(rollout_ms)) * 1e-3
     alg_bytes = (wl["step_bytes"] + wl["record_bytes"]) * n_envs * T
     achieved = alg_bytes / avg_rollout_s / 1e9
+    # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary of this command
+    # (profiles/run_profile.sh; separate FETCH_SIZE / WRITE_SIZE passes), bytes per launch
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        rec = json.load(open(tpath)).get(args.workload)
+        if rec and rec.get("n_envs") == n_envs:
+            traffic, traffic_src = rec["rollout_bytes_per_launch"], rec["source"]
+
+    # second roofline: the matrix-core kernel of the update (Fisher-vector product), timed live
+    do, da, h = policy.obs_dim, policy.action_dim, wl["hidden"][0]
+    ht, ks0, ks1 = h // 32, (do + 2) // 2, 16 * (h // 32)
+    mfma_per_tile = ht * (ks0 + ks1) + ht * (ks0 + 2 * ks1) + ht * ks1 + ht * ht * 16
+    fvp_ms = None
+    ops = policy.fused_ops() if wl["algo"] == "trpo" else None
+    if ops is not None:
+        from rllab_amd.algos.npo import npo_inputs
+        inp = npo_inputs(policy, last["samples"])
+        v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
+        for _ in range(3):
+            ops.fvp(inp, v)
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(20):
+            ops.fvp(inp, v)
+        e1.record()
+        torch.cuda.synchronize()
+        fvp_ms = e0.elapsed_time(e1) / 20
+        ops.release()
+    n_waves = (n_envs + 63) // 64
     out = {
         "metric": "env steps/sec over full TRPO iterations (sample + process + update), 4096 envs per MI355X",
         "value": value, "unit": "env_steps/s", "n_gpus": world, "steps": args.steps,
@@ -174,16 +214,28 @@ def main():
                    "parallelism": "env-sharded dp%d" % world},
         "trpo_iter_ms": elapsed / args.steps * 1e3,
         "phase_ms": {k: v / args.steps for k, v in phase_ms.items()},
+        "update_ms_and_backtracks_per_iteration": per_iter,
         "sampler_env_steps_per_s": world * n_envs * T / avg_rollout_s,
         "roofline": {"kernel": "rollout_kernel (fused policy + env step + record)", "bound": "hbm",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                     "avg_launch_ms": avg_rollout_s * 1e3,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_rollout_s * 1e3,
                      "valu_tflops": wl["flops_per_step"] * n_envs * T / avg_rollout_s / 1e12,
-                     "valu_peak_tflops": 157.3,
-                     "note": "kernel is VALU/latency bound (50 fused sub-steps per env-step); "
-                             "HBM fraction is small by construction, see DESIGN.md"},
+                     "valu_peak_tflops": 157.3, "wavefronts": n_waves, "simds": 1024,
+                     "note": "issue-bound, not HBM-bound: one env per lane => %d wavefronts on 1024 SIMDs, each "
+                             "a single dependent instruction stream (physics sub-steps fused in registers); a lone "
+                             "wavefront issues ~1 VALU op per 4.4 cycles (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = "
+                             "0.85), so launch time = instructions per env x 4.4 cycles x T and the HBM fraction is "
+                             "small by construction (SURVEY.md 8d, DESIGN.md 3.1)" % n_waves},
     }
+    if fvp_ms is not None:
+        tiles = (n_envs * T + 31) // 32
+        tf = tiles * mfma_per_tile * 4096 / (fvp_ms * 1e-3) / 1e12
+        out["roofline_mfma"] = {"kernel": "policy_pass_kernel<FVP> (Fisher-vector product, v_mfma_f32_32x32x2_f32)",
+                                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                                "frac": tf / 157.3, "avg_launch_ms": fvp_ms, "mfma_per_32_samples": mfma_per_tile,
+                                "note": "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); time "
+                                        "includes the partial-row reduce kernel"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_sampler
         base = cpu_sampler.timed_baseline(env_kind, policy.get_param_values(), T, budget_s=args.cpu_budget,

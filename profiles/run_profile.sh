@@ -21,6 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
 python profiles/summarize.py pmc $P/sq gpurun_out/${TAG}_pmc_sq.csv
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $P/sq2 -- $BENCH2 > /dev/null 2>&1
 python profiles/summarize.py pmc $P/sq2 gpurun_out/${TAG}_pmc_sq2.csv
+python profiles/summarize.py traffic gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/pmc_traffic.json swimmer4096_trpo 4096 ${TAG}
 head -6 gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv
 tail -2 gpurun_out/${TAG}_bench_under_rocprof.log
 ls -la gpurun_out

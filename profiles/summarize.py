@@ -43,5 +43,28 @@ def pmc(d, out):
             w.writerow([short(k), n] + ["%.6g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k][c] else "" for c in counters])
 
 
+def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=4096, tag=""):
+    """HBM bytes per launch of the rollout kernel from the FETCH_SIZE / WRITE_SIZE summaries (KB).
+    Reads are 4 B/lane plane loads (not the 16 B/lane streams MI355X_MICROARCH.md's x2 correction
+    was calibrated on) and are < 1 % of the total here, so they are taken as reported."""
+    import json
+
+    def pick(path, col):
+        for r in csv.DictReader(open(path)):
+            if "rollout_kernel" in r["kernel"]:
+                return float(r[col]) * 1024.0
+        return None
+    rd, wr = pick(fetch_csv, "mean_FETCH_SIZE"), pick(write_csv, "mean_WRITE_SIZE")
+    rec = {}
+    if os.path.exists(out_json):
+        rec = json.load(open(out_json))
+    rec[workload] = dict(n_envs=int(n_envs), rollout_bytes_per_launch=rd + wr, fetch_bytes=rd, write_bytes=wr,
+                         source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (%s)" % tag)
+    json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:])
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -83,6 +83,11 @@ class BatchPolopt(RLAlgorithm):
     def train(self):
         self.start_worker()
         self.init_opt()
+        # everything allocated so far lives for the whole run: keep it out of the cyclic GC's
+        # generation-2 walks, which otherwise stall one iteration in ~10 by tens of milliseconds
+        import gc
+        gc.collect()
+        gc.freeze()
         for itr in range(self.current_itr, self.n_itr):
             self.train_iteration(itr)
         self.shutdown_worker()

@@ -17,10 +17,11 @@ constexpr int TS = 32;        // samples per MFMA tile
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// tanh(x) = 1 - 2 / (e^{2x} + 1): exp2, add, rcp, fma.  Saturates correctly without a clamp
+// (e -> inf gives 1, e -> 0 gives -1); absolute error < 2e-7, inside the 1e-5 policy tolerance.
 __device__ __forceinline__ float ftanh(float x) {
-    float xc = fminf(fmaxf(x, -10.0f), 10.0f);
-    float e = __expf(2.0f * xc);
-    return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // e^{2x}
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {

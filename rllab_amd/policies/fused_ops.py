@@ -21,6 +21,7 @@ class FusedGaussianMLPOps(object):
         assert len(hs) == 2 and policy.fusable
         self.dims = (policy.obs_dim, policy.action_dim, hs[0], hs[1])
         self._ws = None
+        self._loss_cache = None
         self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
 
     @staticmethod
@@ -69,21 +70,31 @@ class FusedGaussianMLPOps(object):
     def release(self):
         """Drop the cached descriptor (and the batch tensors it keeps alive)."""
         self._bound.clear()
+        self._loss_cache = None
 
     def loss_stats(self, inputs):
         """[sum w lr adv, sum w KL, sum w logp adv] * inv_count (global) and max KL, as a
         float64 device tensor of 4."""
         b, keep, inv = self._batch(inputs)
+        # NPO / VPG ask for loss and KL before and after the step through separate calls
+        # (npo.py:100-111): same batch, same parameters -> same pass.  flat_params._version counts
+        # in-place updates, so (batch, version) identifies the evaluation point.
+        tag = (tuple(id(t) for t in inputs), self.policy.flat_params._version)
+        if self._loss_cache is not None and self._loss_cache[0] == tag:
+            return self._loss_cache[1]
         ws = self._workspace(keep[0].device)
         out = torch.empty(4, dtype=torch.float64, device=keep[0].device)
         _lib.check(_lib.lib.rl_policy_loss_kl(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
                                               _lib.stream_ptr()), "rl_policy_loss_kl")
         if not D.is_distributed():
-            return torch.cat([out[:3] * inv, out[3:4]])
-        sums = out[:3] * inv
-        D.all_reduce_sum_(sums)
-        mx = D.all_reduce_max_(out[3:4].clone())
-        return torch.cat([sums, mx])
+            res = torch.cat([out[:3] * inv, out[3:4]])
+        else:
+            sums = out[:3] * inv
+            D.all_reduce_sum_(sums)
+            mx = D.all_reduce_max_(out[3:4].clone())
+            res = torch.cat([sums, mx])
+        self._loss_cache = (tag, res)
+        return res
 
     def loss_and_kl(self, inputs):
         s = self.loss_stats(inputs)
