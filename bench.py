@@ -80,11 +80,13 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)"
                      % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RLLAB_DIST_BACKEND", "nccl")   # nccl == RCCL over xGMI; gloo only for tests
+        kw = dict(device_id=torch.device("cuda", device_index)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     import __graft_entry__
     if rank == 0:

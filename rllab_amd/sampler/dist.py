@@ -22,28 +22,44 @@ def rank():
     return dist.get_rank() if is_distributed() else 0
 
 
+def _via_host(t):
+    """gloo (CPU tests, or two ranks sharing one GPU in tests/) moves device tensors through the
+    host; nccl (= RCCL, the production backend) reduces them in place over xGMI."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce(t, op):
+    if is_distributed():
+        if _via_host(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+    return t
+
+
 def all_reduce_sum_(t):
     """In-place sum all-reduce (no-op on a single process).  Returns ``t``."""
-    if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
+    return _all_reduce(t, dist.ReduceOp.SUM)
 
 
 def all_reduce_min_(t):
-    if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return t
+    return _all_reduce(t, dist.ReduceOp.MIN)
 
 
 def all_reduce_max_(t):
-    if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t
+    return _all_reduce(t, dist.ReduceOp.MAX)
 
 
 def broadcast_(t, src=0):
     if is_distributed():
-        dist.broadcast(t, src=src)
+        if _via_host(t):
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
     return t
 
 

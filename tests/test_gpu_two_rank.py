@@ -1,0 +1,120 @@
+"""Env-sharded data parallelism on the REAL kernels: two ranks (gloo, both on cuda:0 -- the GPU box
+has one device; the production backend is nccl = RCCL) each roll out half of the envs and run one
+TRPO iteration; parameters, logged statistics and baseline coefficients must equal a single process
+that owns all the envs.  Philox counters are keyed by the GLOBAL env index, so the union of the two
+shards' trajectories is the single-process batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["AverageReturn", "AverageDiscountedReturn", "ExplainedVariance", "NumTrajs", "StdReturn", "MaxReturn",
+        "MinReturn", "LossBefore", "LossAfter", "MeanKLBefore", "MeanKL"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(n_envs, n_itr=2, env_name="swimmer"):
+    from rllab_amd.algos.trpo import TRPO
+    from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.misc import ext, logger
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.sampler import dist as D
+    ext.set_seed(3)
+    logger.set_quiet(True)
+    env = normalize(SwimmerEnv() if env_name == "swimmer" else CartpoleEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    D.broadcast_(policy.flat_params)
+    baseline = LinearFeatureBaseline(env_spec=env.spec)
+    T = 40
+    algo = TRPO(env=env, policy=policy, baseline=baseline, batch_size=n_envs * T, max_path_length=T, n_itr=n_itr,
+                discount=0.99, step_size=0.01, sampler_args=dict(n_envs=n_envs, seed=17))
+    algo.start_worker()
+    algo.init_opt()
+    stats = []
+    probes = None
+    for itr in range(n_itr):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        if itr == 0:
+            # the all-reduced building blocks of the update at a fixed evaluation point
+            from rllab_amd.algos.npo import npo_inputs
+            ops = policy.fused_ops()
+            inp = npo_inputs(policy, sd)
+            v = torch.as_tensor(np.random.RandomState(0).randn(policy.flat_params.numel()), device="cuda")
+            probes = np.concatenate([ops.loss_stats(inp).cpu().numpy(), ops.loss_grad(inp).cpu().numpy(),
+                                     ops.fvp(inp, v).cpu().numpy()])
+            ops.release()
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        stats.append([float(tab[k]) for k in KEYS])
+        logger.dump_tabular()
+    torch.cuda.synchronize()
+    return policy.get_param_values(), np.array(stats), np.asarray(baseline.get_param_values()), probes
+
+
+def _worker(rank, world, port, outdir, env_name):
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    theta, stats, coef, probes = _run(64, env_name=env_name)
+    np.save(os.path.join(outdir, "probes_%d.npy" % rank), probes)
+    np.save(os.path.join(outdir, "theta_%d.npy" % rank), theta)
+    np.save(os.path.join(outdir, "stats_%d.npy" % rank), stats)
+    np.save(os.path.join(outdir, "coef_%d.npy" % rank), coef)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("env_name", ["swimmer", "cartpole"])
+def test_two_ranks_on_the_kernels_equal_one_process(tmp_path, env_name):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), env_name), nprocs=world, join=True)
+    want_theta, want_stats, want_coef, want_probes = _run(128, env_name=env_name)
+    t0, t1 = (np.load(str(tmp_path / ("theta_%d.npy" % r))) for r in range(2))
+    assert np.array_equal(t0, t1)                                  # identical parameters on every rank, no broadcast
+    s0 = np.load(str(tmp_path / "stats_0.npy"))
+    # iteration 0: both runs sample with the same parameters -> the same trajectories; sampling
+    # statistics agree to float64 reduction order, the update to the f32 partial-sum order
+    n_samp = KEYS.index("LossBefore")
+    assert np.allclose(s0[0, :n_samp], want_stats[0, :n_samp], rtol=1e-9, atol=1e-9), (s0[0], want_stats[0])
+    # loss / KL, flat gradient and a Fisher-vector product: sums of per-rank terms, one all-reduce each
+    p0, p1 = (np.load(str(tmp_path / ("probes_%d.npy" % r))) for r in range(2))
+    assert np.array_equal(p0, p1)
+    assert np.abs(p0 - want_probes).max() <= 2e-5 * np.abs(want_probes).max(), np.abs(p0 - want_probes).max()
+    # the accepted step itself goes through 10 CG iterations on an ill-conditioned Fisher matrix, which
+    # amplifies the f32 summation-order difference between the two batch partitions: sanity band only
+    assert np.allclose(s0[0, n_samp:], want_stats[0, n_samp:], rtol=0.1, atol=1e-6), (s0[0], want_stats[0])
+    c0 = np.load(str(tmp_path / "coef_0.npy"))
+    assert np.all(np.isfinite(s0)) and np.all(np.isfinite(c0))
+    # parameters after two updates: the second rollout already runs on (slightly) different
+    # parameters, so only closeness relative to the update size is meaningful
+    theta_init = _initial_theta(env_name)
+    step = np.abs(want_theta - theta_init).max()
+    assert step > 0 and np.abs(t0 - want_theta).max() <= 0.5 * step
+
+
+def _initial_theta(env_name):
+    from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.misc import ext
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(3)
+    env = normalize(SwimmerEnv() if env_name == "swimmer" else CartpoleEnv())
+    return GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32)).get_param_values()
