@@ -33,9 +33,8 @@ class NPO(BatchPolopt):
     def __init__(self, optimizer=None, optimizer_args=None, step_size=0.01,
                  truncate_local_is_ratio=None, **kwargs):
         if optimizer is None:
-            raise NotImplementedError(
-                "NPO's default PenaltyLbfgsOptimizer is outside the TRPO/VPG hot path "
-                "(SURVEY.md section 2, row 6); pass optimizer= or use TRPO")
+            from rllab_amd.optimizers.penalty_lbfgs_optimizer import PenaltyLbfgsOptimizer
+            optimizer = PenaltyLbfgsOptimizer(**(optimizer_args or dict()))   # reference default (npo.py:27-30)
         self.optimizer = optimizer
         self.step_size = step_size
         self.truncate_local_is_ratio = truncate_local_is_ratio

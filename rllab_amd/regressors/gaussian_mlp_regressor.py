@@ -1,0 +1,171 @@
+"""GaussianMLPRegressor (API of rllab/regressors/gaussian_mlp_regressor.py:20-260): regression by
+fitting a diagonal Gaussian to the outputs -- mean = MLP(rectify hidden layers), log_std a free
+trainable vector -- by minimising the negative log-likelihood of whitened targets, by default under a
+mean-KL trust region with PenaltyLbfgsOptimizer (:68-72).  Inputs / outputs are whitened with the
+batch statistics recomputed at every fit (:196-208).  Data stay on the device as planes
+([dim, B]); statistics, loss and KL are sums over env shards (all-reduced), so every rank runs the same
+L-BFGS trajectory.
+"""
+import numpy as np
+import torch
+
+from rllab_amd.core.network import MLP, rectify
+from rllab_amd.core.parameterized import Param, Parameterized
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.distributions.diagonal_gaussian import DiagonalGaussian
+from rllab_amd.misc import logger
+from rllab_amd.sampler import dist as D
+
+
+def _default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+        else torch.device("cpu")
+
+
+class GaussianMLPRegressor(Parameterized):
+    def __init__(self, input_shape, output_dim, mean_network=None, hidden_sizes=(32, 32),
+                 hidden_nonlinearity=rectify, optimizer=None, use_trust_region=True, step_size=0.01,
+                 learn_std=True, init_std=1.0, adaptive_std=False, std_share_network=False,
+                 std_hidden_sizes=(32, 32), std_nonlinearity=None, normalize_inputs=True, normalize_outputs=True,
+                 name=None, batchsize=None, subsample_factor=1.):
+        Serializable.quick_init(self, locals())
+        Parameterized.__init__(self)
+        if adaptive_std or mean_network is not None:
+            raise NotImplementedError("GaussianMLPRegressor: adaptive_std / custom mean_network are not built")
+        self._batchsize = batchsize
+        self._subsample_factor = subsample_factor
+        if optimizer is None:
+            if use_trust_region:
+                from rllab_amd.optimizers.penalty_lbfgs_optimizer import PenaltyLbfgsOptimizer
+                optimizer = PenaltyLbfgsOptimizer()
+            else:
+                from rllab_amd.optimizers.lbfgs_optimizer import LbfgsOptimizer
+                optimizer = LbfgsOptimizer()
+        self._optimizer = optimizer
+        self.input_dim, self.output_dim = int(np.prod(input_shape)), int(output_dim)
+        self._mean_network = MLP(input_shape, output_dim, hidden_sizes, hidden_nonlinearity, None)
+        off = self._mean_network.end_offset
+        self._log_std_param = Param("output_log_std.param", (output_dim,), off, trainable=learn_std,
+                                    regularizable=False)
+        self._params = self._mean_network.params + [self._log_std_param]
+        for p in self._params:
+            p._owner = self
+        flat = np.zeros(off + output_dim, dtype=np.float32)
+        self._mean_network.init_values(flat)
+        flat[off:] = np.log(init_std)
+        dev = _default_device()
+        self.flat_params = torch.tensor(flat, dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._x_mean, self._x_std = torch.zeros(self.input_dim, 1, **f32), torch.ones(self.input_dim, 1, **f32)
+        self._y_mean, self._y_std = torch.zeros(output_dim, 1, **f32), torch.ones(output_dim, 1, **f32)
+        self._dist = DiagonalGaussian(output_dim)
+        self._use_trust_region = use_trust_region
+        self._name = name
+        self._normalize_inputs, self._normalize_outputs = normalize_inputs, normalize_outputs
+        dist = self._dist
+
+        # inputs: (xs [Din,B], ys [Dout,B], old_means, old_log_stds, weights [B], inv_count)
+        def normalized_dist(flat_p, xs):
+            nx = (xs - self._x_mean) / self._x_std
+            return dict(mean=self._mean_network.forward_planes(nx, flat_p),
+                        log_std=self._log_std_param.view(flat_p)[:, None])
+
+        def loss(flat_p, xs, ys, old_means, old_log_stds, w, inv):
+            nd = normalized_dist(flat_p, xs)
+            ny = (ys - self._y_mean) / self._y_std
+            return -(dist.log_likelihood_sym(ny, nd, axis=0) * w).sum() * inv
+
+        def mean_kl(flat_p, xs, ys, old_means, old_log_stds, w, inv):
+            nd = normalized_dist(flat_p, xs)
+            old = dict(mean=(old_means - self._y_mean) / self._y_std,
+                       log_std=old_log_stds - torch.log(self._y_std))
+            return (dist.kl_sym(old, nd, axis=0) * w).sum() * inv
+        self._normalized_dist = normalized_dist
+        if use_trust_region:
+            self._optimizer.update_opt(loss=loss, target=self, leq_constraint=(mean_kl, step_size), inputs=None)
+        else:
+            self._optimizer.update_opt(loss=loss, target=self, inputs=None)
+
+    def get_params_internal(self, **tags):
+        return [p for p in self._params if all(p.tags.get(k, False) == v for k, v in tags.items())]
+
+    # -- planes API (device) ------------------------------------------------------------------------
+    def pdists_planes(self, xs):
+        """(means [Dout,B], log_stds [Dout,B]) in output units (reference _f_pdists, :158)."""
+        with torch.no_grad():
+            nd = self._normalized_dist(self.flat_params, xs)
+            means = nd["mean"] * self._y_std + self._y_mean
+            log_stds = (nd["log_std"] + torch.log(self._y_std)).expand_as(means)
+        return means, log_stds
+
+    def predict_planes(self, xs):
+        return self.pdists_planes(xs)[0]
+
+    def fit_planes(self, xs, ys, weights=None):
+        """xs [Din,B], ys [Dout,B] device planes; ``weights`` [B] 0/1 marks the valid samples."""
+        xs, ys = xs.to(torch.float32), ys.to(torch.float32)
+        B = xs.shape[-1]
+        w = torch.ones(B, dtype=torch.float32, device=xs.device) if weights is None else weights.to(torch.float32)
+        if self._subsample_factor < 1:
+            idx = torch.as_tensor(np.random.randint(0, B, int(B * self._subsample_factor)), device=xs.device)
+            xs, ys, w = xs[:, idx], ys[:, idx], w[idx]
+        w64 = w.to(torch.float64)
+        (cnt,) = D.sums(w64.sum())
+
+        def mean_std(v):
+            v64 = v.to(torch.float64)
+            s = D.all_reduce_sum_((v64 * w64).sum(dim=1))
+            m = s / cnt
+            ss = D.all_reduce_sum_((((v64 - m[:, None]) ** 2) * w64).sum(dim=1))
+            return m.to(torch.float32)[:, None], (torch.sqrt(ss / cnt) + 1e-8).to(torch.float32)[:, None]
+        if self._normalize_inputs:
+            self._x_mean, self._x_std = mean_std(xs)
+        if self._normalize_outputs:
+            self._y_mean, self._y_std = mean_std(ys)
+        prefix = (self._name + "_") if self._name else ""
+        inv = (1.0 / cnt).to(torch.float32)
+        if self._batchsize is not None:
+            raise NotImplementedError("GaussianMLPRegressor: minibatched fits are not built (batchsize=None)")
+        if self._use_trust_region:
+            old_means, old_log_stds = self.pdists_planes(xs)
+        else:
+            old_means = old_log_stds = torch.zeros_like(ys)
+        inputs = (xs, ys, old_means, old_log_stds, w, inv)
+        loss_before = self._optimizer.loss(inputs)
+        self._optimizer.optimize(inputs)
+        loss_after = self._optimizer.loss(inputs)
+        logger.record_tabular(prefix + 'LossBefore', loss_before)
+        logger.record_tabular(prefix + 'LossAfter', loss_after)
+        logger.record_tabular(prefix + 'dLoss', loss_before - loss_after)
+        if self._use_trust_region:
+            logger.record_tabular(prefix + 'MeanKL', self._optimizer.constraint_val(inputs))
+
+    # -- reference numpy API ([B, D] arrays) -----------------------------------------------------------
+    def _planes(self, a):
+        a = np.asarray(a, dtype=np.float32)
+        return torch.as_tensor(a.reshape(a.shape[0], -1).T.copy(), device=self.flat_params.device)
+
+    def fit(self, xs, ys):
+        self.fit_planes(self._planes(xs), self._planes(ys))
+
+    def predict(self, xs):
+        return self.predict_planes(self._planes(xs)).t().cpu().numpy().astype(np.float64)
+
+    def sample_predict(self, xs):
+        means, log_stds = self.pdists_planes(self._planes(xs))
+        return self._dist.sample(dict(mean=means.t().cpu().numpy(), log_std=log_stds.t().cpu().numpy()))
+
+    def predict_log_likelihood(self, xs, ys):
+        means, log_stds = self.pdists_planes(self._planes(xs))
+        return self._dist.log_likelihood(np.asarray(ys), dict(mean=means.t().cpu().numpy().astype(np.float64),
+                                                              log_std=log_stds.t().cpu().numpy().astype(np.float64)))
+
+    def __getstate__(self):
+        d = Parameterized.__getstate__(self)
+        d["norm"] = [t.cpu().numpy() for t in (self._x_mean, self._x_std, self._y_mean, self._y_std)]
+        return d
+
+    def __setstate__(self, d):
+        Parameterized.__setstate__(self, d)
+        dev = self.flat_params.device
+        self._x_mean, self._x_std, self._y_mean, self._y_std = (torch.as_tensor(a, device=dev) for a in d["norm"])

@@ -110,3 +110,44 @@ def test_vpg_improves_swimmer_surrogate(quiet_logger):
     g = policy.fused_ops().loss_grad(inp, vpg=True)
     assert float((g - g64).abs().max()) <= 2e-5 * max(1e-3, float(g64.abs().max()))
     logger.dump_tabular()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo_name", ["tnpg", "ppo", "trpo_mlp_baseline"])
+def test_npo_variants_run_and_stay_finite(algo_name, quiet_logger):
+    """The NPO family beyond TRPO (reference tests/algos/test_trpo.py-style: runs, no NaNs):
+    TNPG (one line-search step), PPO (PenaltyLbfgsOptimizer, the NPO default) and TRPO with the
+    neural value function GaussianMLPBaseline on a HalfCheetah-style env."""
+    from rllab.algos.ppo import PPO
+    from rllab.algos.tnpg import TNPG
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.gaussian_mlp_baseline import GaussianMLPBaseline
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.mujoco.half_cheetah_env import HalfCheetahEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(4)
+    env = normalize(HalfCheetahEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(64, 64))
+    common = dict(env=env, policy=policy, batch_size=64 * 100, max_path_length=100, n_itr=3, discount=0.99,
+                  gae_lambda=0.97, step_size=0.01, sampler_args=dict(n_envs=64))
+    if algo_name == "tnpg":
+        algo = TNPG(baseline=LinearFeatureBaseline(env_spec=env.spec), **common)
+    elif algo_name == "ppo":
+        algo = PPO(baseline=LinearFeatureBaseline(env_spec=env.spec), optimizer_args=dict(max_opt_itr=5, max_penalty_itr=3),
+                   **common)
+    else:
+        algo = TRPO(baseline=GaussianMLPBaseline(env_spec=env.spec, regressor_args=dict(step_size=0.1)), **common)
+    theta0 = policy.get_param_values()
+    algo.train()
+    theta1 = policy.get_param_values()
+    assert np.isfinite(theta1).all()
+    if algo_name == "tnpg":
+        # one full natural-gradient step per iteration; like the reference it is rejected whenever the
+        # realised KL lands on or above the bound (conjugate_gradient_optimizer.py:279-281)
+        assert algo.optimizer.last_backtrack_iters == 0
+    else:
+        assert np.abs(theta1 - theta0).max() > 0
+    if algo_name == "trpo_mlp_baseline":
+        assert np.isfinite(algo.baseline.get_param_values()).all()

@@ -296,3 +296,86 @@ def test_unsupported_options_fail_loudly():
         env = CartpoleEnv()
         with pytest.raises(RuntimeError, match="no HIP device"):
             env.reset()  # no CPU fallback for env kernels
+
+
+def _lbfgs_problem(g, theta0):
+    A, C, b = (torch.as_tensor(g[k]) for k in ("A", "C", "b"))
+    th0 = torch.as_tensor(theta0)
+
+    def loss(flat, dummy):
+        d = flat - th0
+        return b.dot(d) + 0.5 * d @ A @ d + 0.1 * (d ** 4).sum()
+
+    def cons(flat, dummy):
+        d = flat - th0
+        return 0.5 * d @ C @ d
+    return loss, cons
+
+
+def test_lbfgs_optimizer_vs_reference(quiet_logger):
+    """LbfgsOptimizer.optimize == the REAL reference optimizer on the same toy problem (same
+    scipy fmin_l_bfgs_b trajectory, including the last-evaluation quirk)."""
+    from rllab_amd.optimizers.lbfgs_optimizer import LbfgsOptimizer
+    g = load("lbfgs_optimizers")
+    loss, _ = _lbfgs_problem(g, g["lbfgs_theta0"])
+    target = _Quad(g["lbfgs_theta0"])
+    opt = LbfgsOptimizer(max_opt_itr=20)
+    opt.update_opt(loss=loss, target=target, inputs=None)
+    opt.optimize((torch.zeros(1),))
+    assert np.allclose(target.get_param_values(), g["lbfgs_theta1"], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,kw", [("tight", {}), ("loose", {}), ("fixed", dict(adapt_penalty=False)),
+                                    ("few", dict(max_penalty_itr=3))])
+def test_penalty_lbfgs_optimizer_control_flow_vs_reference(tag, kw, quiet_logger):
+    """The adaptive-penalty search (grow until the constraint holds / shrink until it is crossed /
+    give up and restore) lands on the parameters and the penalty of the REAL reference."""
+    from rllab_amd.optimizers.penalty_lbfgs_optimizer import PenaltyLbfgsOptimizer
+    g = load("lbfgs_optimizers")
+    loss, cons = _lbfgs_problem(g, g["pen_theta0_" + tag])
+    target = _Quad(g["pen_theta0_" + tag])
+    opt = PenaltyLbfgsOptimizer(**kw)
+    opt.update_opt(loss=loss, target=target, leq_constraint=(cons, float(g["pen_eps_" + tag])), inputs=None)
+    x = (torch.zeros(1),)
+    opt.optimize(x)
+    assert np.allclose(target.get_param_values(), g["pen_theta1_" + tag], rtol=1e-6, atol=1e-8)
+    assert opt._penalty == float(g["pen_penalty_" + tag])
+    assert np.isclose(opt.constraint_val(x), float(g["pen_cons_" + tag]), rtol=1e-5, atol=1e-12)
+
+
+def test_gaussian_mlp_regressor_and_baseline_fit(quiet_logger):
+    """GaussianMLPRegressor (rectify MLP + free log_std, whitened inputs / outputs, trust-region
+    PenaltyLbfgs fit) learns a smooth function; GaussianMLPBaseline maps paths to it.  Repeated fits
+    move the prediction towards the targets while each fit stays inside its KL bound."""
+    from rllab_amd.baselines.gaussian_mlp_baseline import GaussianMLPBaseline
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.misc import logger
+    from rllab_amd.regressors.gaussian_mlp_regressor import GaussianMLPRegressor
+    from rllab_amd.spaces import Box
+    np.random.seed(0)
+    rng = np.random.RandomState(0)
+    xs = rng.randn(2000, 3)
+    ys = (np.sin(xs[:, :1]) + 0.5 * xs[:, 1:2] * xs[:, 2:3]) * 10 + 50
+    reg = GaussianMLPRegressor(input_shape=(3,), output_dim=1, name="vf", step_size=0.05)
+    err = []
+    for _ in range(12):
+        reg.fit(xs, ys)
+        tab = logger.get_tabular()
+        assert float(tab["vf_LossAfter"]) <= float(tab["vf_LossBefore"]) + 1e-9
+        assert float(tab["vf_MeanKL"]) <= 0.05 + 1e-6
+        logger.dump_tabular()
+        err.append(float(np.mean((reg.predict(xs) - ys) ** 2)))
+    assert err[-1] < 0.25 * err[0] and err[-1] < 0.5 * np.var(ys)
+    assert reg.predict(xs[:5]).shape == (5, 1) and reg.predict_log_likelihood(xs[:5], ys[:5]).shape == (5,)
+    # flat parameter round trip (Parameterized contract) and the baseline wrapper
+    theta = reg.get_param_values()
+    assert theta.shape == (3 * 32 + 32 + 32 * 32 + 32 + 32 + 1 + 1,)
+    spec = EnvSpec(Box(-np.ones(3), np.ones(3)), Box(-np.ones(1), np.ones(1)))
+    b = GaussianMLPBaseline(spec, regressor_args=dict(use_trust_region=False))
+    paths = [dict(observations=xs[i:i + 100], returns=ys[i:i + 100, 0], rewards=np.zeros(100)) for i in range(0, 2000, 100)]
+    b.fit(paths)
+    logger.dump_tabular()
+    p = b.predict(paths[3])
+    assert p.shape == (100,) and np.mean((p - paths[3]["returns"]) ** 2) < np.var(ys)
+    b.set_param_values(b.get_param_values() * 0.0)
+    assert np.all(b.get_param_values() == 0.0)
