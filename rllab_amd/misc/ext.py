@@ -70,3 +70,8 @@ def sliced_fun(f, n_slices):
             return ret_vals[0]
         return tuple(ret_vals) if was_tuple else ret_vals
     return sliced_f
+
+
+def is_iterable(obj):
+    """rllab/misc/ext.py:209-210."""
+    return isinstance(obj, str) or getattr(obj, '__iter__', False)

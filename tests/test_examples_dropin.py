@@ -151,3 +151,90 @@ def test_npo_variants_run_and_stay_finite(algo_name, quiet_logger):
         assert np.abs(theta1 - theta0).max() > 0
     if algo_name == "trpo_mlp_baseline":
         assert np.isfinite(algo.baseline.get_param_values()).all()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference tree not mounted")
+def test_pickled_example_binds_to_our_api():
+    """examples/trpo_cartpole_pickled.py: imports resolve (incl. rllab.misc.instrument) and
+    run_experiment_lite accepts the script's keyword arguments."""
+    tree = ast.parse(open(os.path.join(REF_EXAMPLES, "trpo_cartpole_pickled.py")).read())
+    for node in tree.body:
+        if isinstance(node, ast.ImportFrom):
+            mod = importlib.import_module(node.module)
+            for a in node.names:
+                assert hasattr(mod, a.name), (node.module, a.name)
+    from rllab.misc.instrument import run_experiment_lite
+    call = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "run_experiment_lite"][0]
+    inspect.signature(run_experiment_lite).bind(None, **{k.arg: None for k in call.keywords})
+
+
+def test_stub_machinery_and_local_runner(tmp_path, quiet_logger):
+    """stub(globals()) builds a lazy call graph; run_experiment_lite concretises and runs it in-process
+    with the reference's bookkeeping (progress.csv, params.json, snapshot dir / mode restored after)."""
+    from rllab_amd.misc import instrument, logger
+
+    class Thing(object):
+        built = 0
+
+        def __init__(self, a, b=2):
+            Thing.built += 1
+            self.a, self.b = a, b
+
+        def work(self, k):
+            logger.record_tabular("Value", self.a * self.b * k)
+            logger.dump_tabular()
+            logger.save_itr_params(0, dict(itr=0, value=self.a))
+            return None
+    g = dict(Thing=Thing)
+    instrument.stub(g)
+    call = g["Thing"](3, b=5).work(2)
+    assert isinstance(call, instrument.StubMethodCall) and Thing.built == 0
+    d = instrument.run_experiment_lite(call, exp_prefix="unit_test", log_dir=str(tmp_path / "exp"), snapshot_mode="last",
+                                       seed=3)
+    assert Thing.built == 1 and logger.get_snapshot_dir() is None
+    rows = open(os.path.join(d, "progress.csv")).read().strip().splitlines()
+    assert rows == ["Value", "30"]
+    assert os.path.exists(os.path.join(d, "params.pkl")) and os.path.exists(os.path.join(d, "params.json"))
+    # plain callable with a variant (the reference's cloudpickle path)
+    seen = {}
+    instrument.run_experiment_lite(lambda v: seen.update(lr=v.lr), variant=dict(lr=0.5), log_dir=str(tmp_path / "e2"))
+    assert seen == dict(lr=0.5)
+    with pytest.raises(NotImplementedError):
+        instrument.run_experiment_lite(call, mode="ec2")
+
+
+@pytest.mark.gpu
+def test_snapshot_resume_and_sim_policy(tmp_path, quiet_logger):
+    """Snapshot format (joblib pickles of ctor args + flat params, logger.py:216-232): a TRPO run
+    snapshotted by run_experiment_lite resumes from its saved iteration with identical parameters,
+    and the saved policy rolls out through the single-env Env API (scripts/sim_policy.py)."""
+    import joblib
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc.instrument import run_experiment_lite
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.sampler.utils import rollout
+    holder = {}
+
+    def run_task(*_):
+        env = normalize(CartpoleEnv())
+        policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+        algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=64 * 50,
+                    max_path_length=50, n_itr=3, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=64))
+        holder["policy"] = policy
+        algo.train()
+    d = run_experiment_lite(run_task, n_parallel=2, snapshot_mode="last", seed=1, log_dir=str(tmp_path / "run"))
+    snap = joblib.load(os.path.join(d, "params.pkl"))
+    assert snap["itr"] == 2 and snap["algo"].current_itr == 3
+    assert np.array_equal(snap["policy"].get_param_values(), holder["policy"].get_param_values())
+    assert len(open(os.path.join(d, "progress.csv")).read().strip().splitlines()) == 4   # header + 3 iterations
+    # resume: two more iterations continue at itr 3
+    snap["algo"].n_itr = 5
+    joblib.dump(snap, os.path.join(d, "resume.pkl"))
+    d2 = run_experiment_lite(resume_from=os.path.join(d, "resume.pkl"), snapshot_mode="last", log_dir=str(tmp_path / "run2"))
+    snap2 = joblib.load(os.path.join(d2, "params.pkl"))
+    assert snap2["itr"] == 4 and np.abs(snap2["policy"].get_param_values() - snap["policy"].get_param_values()).max() > 0
+    path = rollout(snap2["env"], snap2["policy"], max_path_length=30)
+    assert 1 <= len(path["rewards"]) <= 30 and np.isfinite(path["rewards"]).all()

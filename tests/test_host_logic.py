@@ -290,8 +290,9 @@ def test_unsupported_options_fail_loudly():
         SwimmerEnv(action_noise=0.1)
     with pytest.raises(NotImplementedError):
         GaussianMLPPolicy(_spec(4, 1), adaptive_std=True)
-    with pytest.raises(NotImplementedError):
-        NPO(env=None, policy=None, baseline=None)
+    # NPO's default optimizer is the reference's PenaltyLbfgsOptimizer (npo.py:27-30)
+    from rllab_amd.optimizers.penalty_lbfgs_optimizer import PenaltyLbfgsOptimizer
+    assert isinstance(NPO(env=None, policy=None, baseline=None).optimizer, PenaltyLbfgsOptimizer)
     if not torch.cuda.is_available():
         env = CartpoleEnv()
         with pytest.raises(RuntimeError, match="no HIP device"):
