@@ -77,6 +77,8 @@ template <typename R, int NB>
 struct PlanarKin {
     R sn[NB], cs[NB];        // sin / cos of absolute body angle
     R ax[NB], ay[NB];        // hinge anchor (body frame origin) relative to the root origin
+    R lx[NB], ly[NB];        // world vector parent anchor -> own anchor  (R(phi_parent) * joint offset)
+    R ex[NB], ey[NB];        // world vector own anchor -> own COM         (R(phi_i) * com offset)
     R px[NB], py[NB];        // COM relative to the root origin
     R om[NB];                // absolute angular velocity
     R vax[NB], vay[NB];      // anchor velocity (world)
@@ -139,6 +141,8 @@ struct PlanarTree {
                 constexpr double JX = Mdl::jx(i), JY = Mdl::jy(i);
                 R dx, dy;                                   // R(phi_p) * joint offset
                 RL_ROTC(k.cs[p], k.sn[p], JX, JY, dx, dy);
+                k.lx[i] = dx;
+                k.ly[i] = dy;
                 if constexpr (p == 0) {                     // the root anchor is the origin
                     k.ax[i] = dx;
                     k.ay[i] = dy;
@@ -152,6 +156,8 @@ struct PlanarTree {
             constexpr double CX = Mdl::cx(i), CY = Mdl::cy(i);
             R ex, ey;                                       // R(phi_i) * com offset
             RL_ROTC(k.cs[i], k.sn[i], CX, CY, ex, ey);
+            k.ex[i] = ex;
+            k.ey[i] = ey;
             if constexpr (i == 0) {
                 k.px[i] = ex;
                 k.py[i] = ey;
@@ -225,10 +231,168 @@ struct PlanarTree {
         }
     }
 
-    // qacc from (q, qd, hinge torques tau_j[NB] incl. actuation, per-body external
-    // force (fx, fy) at the COM and torque tz, world frame)
+    // ---- compile-time geometry of the tree in ABSOLUTE body angles --------------------------------
+    // COM_i = r + sum_{k in path(i)} R(phi_k) d_ik with constant vectors d_ik: the joint offset of the
+    // child of k on the way to i (k a strict ancestor of i), or the COM offset (k == i).
+    struct V2 { double x, y; };
+    static constexpr V2 dvec(int i, int k) {
+        if (k == i) return V2{Mdl::cx(i), Mdl::cy(i)};
+        if (!is_ancestor(k, i)) return V2{0.0, 0.0};
+        int n = i;
+        while (Mdl::parent(n) != k) n = Mdl::parent(n);
+        return V2{Mdl::jx(n), Mdl::jy(n)};
+    }
+    // D_k = sum_i m_i d_ik: first moment of the subtree hanging on phi_k
+    static constexpr V2 Dvec(int k) {
+        V2 s{0.0, 0.0};
+        for (int i = 0; i < NB; ++i) { const V2 d = dvec(i, k); s.x += Mdl::mass(i) * d.x; s.y += Mdl::mass(i) * d.y; }
+        return s;
+    }
+    // M_{phi_k phi_l} = Ac_kl cos(phi_l - phi_k) - As_kl sin(phi_l - phi_k) + Kc_kl
+    static constexpr double Ac(int k, int l) {
+        double s = 0.0;
+        for (int i = 0; i < NB; ++i) { const V2 a = dvec(i, k), b = dvec(i, l); s += Mdl::mass(i) * (a.x * b.x + a.y * b.y); }
+        return s;
+    }
+    static constexpr double As(int k, int l) {
+        double s = 0.0;
+        for (int i = 0; i < NB; ++i) { const V2 a = dvec(i, k), b = dvec(i, l); s += Mdl::mass(i) * (a.x * b.y - a.y * b.x); }
+        return s;
+    }
+    // configuration-independent part: body inertia on the diagonal; armature acts on the RELATIVE
+    // joint rate (phi_j' - phi_p'), i.e. +arm_j on (j,j) and (p,p), -arm_j on (j,p)
+    static constexpr double Kc(int k, int l) {
+        double s = (k == l) ? Mdl::inertia(k) : 0.0;
+        for (int j = 1; j < NB; ++j) {
+            const int p = Mdl::parent(j);
+            if (k == l && (k == j || k == p)) s += Mdl::armature(j);
+            if ((k == j && l == p) || (k == p && l == j)) s -= Mdl::armature(j);
+        }
+        return s;
+    }
+    // Schur complement with the translation block (m_total I_2): S_kl = Sc_kl cos - Ss_kl sin + Kc_kl
+    static constexpr double Sc(int k, int l) {
+        const V2 a = Dvec(k), b = Dvec(l);
+        return Ac(k, l) - (a.x * b.x + a.y * b.y) / total_mass();
+    }
+    static constexpr double Ss(int k, int l) {
+        const V2 a = Dvec(k), b = Dvec(l);
+        return As(k, l) - (a.x * b.y - a.y * b.x) / total_mass();
+    }
+
+    // qacc from (kinematics, hinge torques tau_j[NB] incl. actuation, per-body external force (fx, fy) at
+    // the COM and torque tz, world frame).
+    //
+    // Formulated in absolute body angles phi_k: every configuration dependence of the joint-space
+    // inertia, of its Schur complement with the translations and of the velocity-product terms is a
+    // compile-time coefficient times cos / sin of an angle DIFFERENCE,
+    //     S_kl   = Sc_kl cos(phi_l - phi_k) - Ss_kl sin(phi_l - phi_k) + Kc_kl
+    //     bias_k = - sum_l w_l^2 [As_kl cos(phi_l - phi_k) + Ac_kl sin(phi_l - phi_k)]
+    // so there is no composite-inertia pass, no matrix assembly and no B^T B product at run time
+    // (for the collinear swimmer chain all As / Ss vanish at compile time as well).
     template <typename R>
-    RL_HD static void forward_dynamics(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
+    RL_HD static void forward_dynamics_abs(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
+                                           const R* fy, const R* tz, R* qacc) {
+        constexpr double INV_M = 1.0 / total_mass();
+        // --- subtree force sums (leaves -> root) and generalised forces on the absolute angles -------
+        R Fsx[NB], Fsy[NB], Q[NB];
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            Fsx[i] = fx[i];
+            Fsy[i] = fy[i];
+            Q[i] = (k.ex[i] * fy[i] - k.ey[i] * fx[i]) + tz[i];       // own force at the own COM + pure torque
+        });
+        static_for_down<NB, 1>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
+            // everything beyond joint i translates with anchor i when phi_p alone varies
+            Q[p] = Q[p] + (k.lx[i] * Fsy[i] - k.ly[i] * Fsx[i]);
+            Fsx[p] = Fsx[p] + Fsx[i];
+            Fsy[p] = Fsy[p] + Fsy[i];
+        });
+        static_for<1, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
+            Q[i] = Q[i] + tau_j[i];                                    // hinge torque: +tau on the child,
+            Q[p] = Q[p] - tau_j[i];                                    // -tau on the parent
+        });
+        // --- rotated first moments G_k = R(phi_k) D_k (gravity, translation coupling, centripetal) ------
+        R Gx[NB], Gy[NB], w2[NB];
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr V2 D = Dvec(i);
+            RL_ROTC(k.cs[i], k.sn[i], D.x, D.y, Gx[i], Gy[i]);
+            w2[i] = k.om[i] * k.om[i];
+            if constexpr (HAS_GRAVITY) Q[i] = Q[i] + (Gx[i] * (R)Mdl::gy() - Gy[i] * (R)Mdl::gx());
+        });
+        // translation rows: m r'' + sum_k G_k^perp phi_k'' - sum_l w_l^2 G_l = Q_r
+        R qrx = Fsx[0], qry = Fsy[0];
+        if constexpr (HAS_GRAVITY) {
+            qrx = qrx + (R)(total_mass() * Mdl::gx());
+            qry = qry + (R)(total_mass() * Mdl::gy());
+        }
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            qrx = qrx + w2[i] * Gx[i];
+            qry = qry + w2[i] * Gy[i];
+        });
+        const R grx = qrx * (R)INV_M, gry = qry * (R)INV_M;           // (Q_r - c_r) / m
+        // --- pairwise angle differences: Schur matrix and velocity-product terms -----------------------
+        R S[NB][NB], b[NB], th[NB];
+        static_for<0, NB>([&](auto Kk) {
+            constexpr int kk = decltype(Kk)::value;
+            S[kk][kk] = (R)(Sc(kk, kk) + Kc(kk, kk));
+            // rhs: Q_k - G_k^perp . (Q_r - c_r)/m     with G^perp = (-Gy, Gx)
+            b[kk] = Q[kk] - (Gx[kk] * gry - Gy[kk] * grx);
+        });
+        static_for<0, NB>([&](auto Kk) {
+            constexpr int kk = decltype(Kk)::value;
+            static_for<kk + 1, NB>([&](auto Ll) {
+                constexpr int l = decltype(Ll)::value;
+                constexpr double AC = Ac(kk, l), AS = As(kk, l), SC = Sc(kk, l), SS = Ss(kk, l), KC = Kc(kk, l);
+                constexpr bool NEED_C = (SC != 0.0) || (AS != 0.0), NEED_S = (SS != 0.0) || (AC != 0.0);
+                R cd = (R)0, sd = (R)0;                                // cos / sin of (phi_l - phi_k)
+                if constexpr (NEED_C) cd = k.cs[kk] * k.cs[l] + k.sn[kk] * k.sn[l];
+                if constexpr (NEED_S) sd = k.sn[l] * k.cs[kk] - k.cs[l] * k.sn[kk];
+                // S[l][kk] (lower triangle)
+                if constexpr (SC != 0.0 && SS != 0.0) S[l][kk] = (R)SC * cd - (R)SS * sd + (R)KC;
+                else if constexpr (SC != 0.0 && KC != 0.0) S[l][kk] = (R)SC * cd + (R)KC;
+                else if constexpr (SC != 0.0) S[l][kk] = (R)SC * cd;
+                else if constexpr (SS != 0.0) S[l][kk] = (R)KC - (R)SS * sd;
+                else S[l][kk] = (R)KC;
+                // t = As cos + Ac sin:  bias_k -= w_l^2 t,  bias_l += w_k^2 t   (bias moves to the rhs)
+                if constexpr (AC != 0.0 || AS != 0.0) {
+                    R t;
+                    if constexpr (AC != 0.0 && AS != 0.0) t = (R)AS * cd + (R)AC * sd;
+                    else if constexpr (AC != 0.0) t = (R)AC * sd;
+                    else t = (R)AS * cd;
+                    b[kk] = b[kk] + w2[l] * t;
+                    b[l] = b[l] - w2[kk] * t;
+                }
+            });
+        });
+        solve_spd<R, NB>(S, b, th);
+        // translations: r'' = (Q_r - c_r)/m - sum_k G_k^perp phi_k'' / m
+        R sx = (R)0, sy = (R)0;
+        static_for<0, NB>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            if constexpr (r == 0) { sx = -(Gy[0] * th[0]); sy = Gx[0] * th[0]; }
+            else { sx = sx - Gy[r] * th[r]; sy = sy + Gx[r] * th[r]; }
+        });
+        qacc[0] = grx - sx * (R)INV_M;
+        qacc[1] = gry - sy * (R)INV_M;
+        // back to the joint coordinates: root angle, then hinge = child angle - parent angle
+        qacc[2] = th[0];
+        static_for<1, NB>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            qacc[2 + r] = th[r] - th[Mdl::parent(r)];
+        });
+    }
+
+    // The same accelerations by composite rigid bodies (joint-space inertia assembled from subtree
+    // mass / first moment / inertia about the root origin, bias forces by a recursive pass, translation
+    // block eliminated by a Schur complement): O(NB * depth) work where the pairwise form above is
+    // O(NB^2), so it wins for the larger trees (7-body cheetah: ~1100 vs ~1400 instructions).
+    template <typename R>
+    RL_HD static void forward_dynamics_crb(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
                                        const R* fy, const R* tz, R* qacc) {
         // --- velocity-product (bias) accelerations with qacc = 0 ---------------------
         R aax[NB], aay[NB];  // anchor acceleration (the root anchor does not accelerate)
@@ -361,6 +525,15 @@ struct PlanarTree {
         for (int i = kk; i < NB; ++i)
             if (is_ancestor(kk, i)) m += Mdl::mass(i);
         return m;
+    }
+
+    // pairwise absolute-angle form for small trees, composite rigid bodies for large ones
+    static constexpr bool USE_PAIRWISE = (NB <= 4);
+    template <typename R>
+    RL_HD static void forward_dynamics(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
+                                       const R* fy, const R* tz, R* qacc) {
+        if constexpr (USE_PAIRWISE) forward_dynamics_abs(k, tau_j, fx, fy, tz, qacc);
+        else forward_dynamics_crb(k, tau_j, fx, fy, tz, qacc);
     }
 
     // passive joint torques: spring (ref 0), damper, soft range limits
