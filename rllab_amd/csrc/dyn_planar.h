@@ -552,9 +552,10 @@ struct PlanarTree {
             else
                 t = (R)0;
             if constexpr (Mdl::limited(i)) {
-                const R lo = (R)Mdl::lo(i), hi = (R)Mdl::hi(i);
-                if (x < lo) t = t - (R)Mdl::limit_k() * (x - lo) - (R)Mdl::limit_b() * v;
-                if (x > hi) t = t - (R)Mdl::limit_k() * (x - hi) - (R)Mdl::limit_b() * v;
+                // penalty beyond the range: -K * (x - clamp(x)) and, only while beyond, -B * v
+                const R viol = x - rl_clamp(x, (R)Mdl::lo(i), (R)Mdl::hi(i));
+                const R damp = (viol != (R)0) ? (R)Mdl::limit_b() * v : (R)0;
+                t = t - (R)Mdl::limit_k() * viol - damp;
             }
             tau_j[i] = t;
         });

@@ -71,11 +71,11 @@ struct SwimmerModel {
             const R vl = k.cs[i] * k.vpx[i] + k.sn[i] * k.vpy[i];
             const R vt = -k.sn[i] * k.vpx[i] + k.cs[i] * k.vpy[i];
             const R w = k.om[i];
-            const R fl = -(R)VISC_LIN * vl - (R)DRAG_AX * rl_abs(vl) * vl;
-            const R ft = -(R)VISC_LIN * vt - (R)DRAG_PERP * rl_abs(vt) * vt;
+            const R fl = -(vl * ((R)VISC_LIN + (R)DRAG_AX * rl_abs(vl)));
+            const R ft = -(vt * ((R)VISC_LIN + (R)DRAG_PERP * rl_abs(vt)));
             fx[i] = k.cs[i] * fl - k.sn[i] * ft;
             fy[i] = k.sn[i] * fl + k.cs[i] * ft;
-            tz[i] = -(R)VISC_ANG * w - (R)DRAG_ANG * rl_abs(w) * w;
+            tz[i] = -(w * ((R)VISC_ANG + (R)DRAG_ANG * rl_abs(w)));
         }
     }
 };

@@ -274,16 +274,19 @@ lfb_normal_eq_kernel(size_t B, int Do, const float* __restrict__ obs, const int3
     for (int k = threadIdx.x; k < FE * FE; k += NE_WAVES * 64) out[k] = red[k];
 }
 
-// out[(F+1) x F] = [Gram | rhs]^T laid out as gram (F*F) followed by rhs (F), summed over rows in order
+// out = gram (F*F, row-major) followed by rhs (F): sum of the per-workgroup partials, one wavefront per
+// output entry (lanes take interleaved rows, butterfly at the end: fixed order, deterministic)
 __global__ void __launch_bounds__(256)
 lfb_reduce_kernel(const double* __restrict__ partial, int rows, int FE, int F, double* __restrict__ out) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= (F + 1) * F) return;
     const int i = (k < F * F) ? k / F : k - F * F;   // feature row
     const int j = (k < F * F) ? k % F : F;           // feature column (F = the y column)
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += partial[(size_t)r * FE * FE + (size_t)i * FE + j];
-    out[k] = s;
+    for (int r = lane; r < rows; r += 64) s += partial[(size_t)r * FE * FE + (size_t)i * FE + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[k] = s;
 }
 
 }  // namespace rl
@@ -363,7 +366,7 @@ extern "C" int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs,
                            obs_dim, obs, tin, returns, valid, (double*)workspace);
     }
     if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(lfb_reduce_kernel, dim3(((F + 1) * F + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lfb_reduce_kernel, dim3(((F + 1) * F + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const double*)workspace, grid, FE, F, out);
     return check_launch("lfb_normal_eq_kernel");
 }
