@@ -30,7 +30,8 @@ enum rl_env_kind {
     RL_ENV_CARTPOLE = 0,         /* rllab/envs/box2d/cartpole_env.py:10-56 */
     RL_ENV_DOUBLE_PENDULUM = 1,  /* rllab/envs/box2d/double_pendulum_env.py:11-61 */
     RL_ENV_SWIMMER = 2,          /* rllab/envs/mujoco/swimmer_env.py:10-62 (swimmer-style planar chain) */
-    RL_ENV_HALF_CHEETAH = 3      /* rllab/envs/mujoco/half_cheetah_env.py:14-56 (cheetah-style planar tree) */
+    RL_ENV_HALF_CHEETAH = 3,     /* rllab/envs/mujoco/half_cheetah_env.py:14-56 (cheetah-style planar tree) */
+    RL_ENV_CARTPOLE_SWINGUP = 4  /* rllab/envs/box2d/cartpole_swingup_env.py:14-61 */
 };
 
 enum rl_status {

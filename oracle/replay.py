@@ -66,7 +66,7 @@ def set_state_from_obs(env, o):
     quantities are computed by the dynamics source itself."""
     kind = env.kind
     o = np.asarray(o, np.float32)
-    if kind == 0:
+    if kind in (0, 4):   # Cartpole / CartpoleSwingup: same bodies, same observation
         # Cartpole.reset maps u -> lo + u*(hi-lo); instead of inverting that affine map
         # in float (not exactly invertible) we reset with any draws and then overwrite
         # the four reset values and the pole centre the same way reset() derives it.

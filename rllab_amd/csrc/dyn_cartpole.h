@@ -248,4 +248,48 @@ struct Cartpole {
     }
 };
 
+// CartpoleSwingupEnv (rllab/envs/box2d/cartpole_swingup_env.py:14-61): the same Box2D world
+// (cartpole.xml.mako) and island solver, started hanging down.
+//   reset   U([-1,-2,pi-1,-3], [1,2,pi+1,3]) on cart x / vx and pole angle / w, pole body origin left
+//           at the XML pose (:29-41)
+//   reward  -100 when done, else -1 beyond max_reward_cart_pos (= max_cart_pos, so unreachable),
+//           else cos(pole angle)  (:43-52);   done = |cart x| > 3  (:54-56)
+struct CartpoleSwingup : Cartpole {
+    static constexpr int KIND = 4;
+
+    template <typename R> RL_HD static void reset(R* s, const R* u) {
+        const R PI_ = (R)3.14159265358979323846;
+        const R lo0 = (R)-1, lo1 = (R)-2, lo2 = PI_ - (R)1, lo3 = (R)-3;
+        const R hi0 = (R)1, hi1 = (R)2, hi2 = PI_ + (R)1, hi3 = (R)3;
+        R xpos = lo0 + u[0] * (hi0 - lo0);
+        R xvel = lo1 + u[1] * (hi1 - lo1);
+        R apos = lo2 + u[2] * (hi2 - lo2);
+        R avel = lo3 + u[3] * (hi3 - lo3);
+        s[0] = xpos; s[1] = C<R>::cart_cy; s[2] = (R)0; s[3] = xvel; s[4] = (R)0; s[5] = (R)0;
+        R sn, cs;
+        rl_sincos(apos, sn, cs);
+        s[6] = -sn * C<R>::pole_lc;
+        s[7] = C<R>::cart_h + cs * C<R>::pole_lc;
+        s[8] = apos; s[9] = (R)0; s[10] = (R)0; s[11] = avel;
+    }
+
+    template <typename R> RL_HD static bool is_done(const R* s) { return rl_abs(s[0]) > (R)3; }
+
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+        using K = C<R>;
+        R act = a[0];
+        if (normalize) {
+            act = K::act_lb + (act + (R)1) * (R)0.5 * (K::act_ub - K::act_lb);
+            act = rl_clamp(act, K::act_lb, K::act_ub);
+        }
+        world_step(s, rl_clamp(act, K::act_lb, K::act_ub));
+        done = is_done(s);
+        R sn, cs;
+        rl_sincos(s[8], sn, cs);
+        reward = done ? (R)-100 : cs;
+        observe(s, obs);
+    }
+};
+
 }  // namespace rl

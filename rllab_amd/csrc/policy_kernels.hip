@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     double acc_loss = 0.0, acc_kl = 0.0, acc_vpg = 0.0;
     float max_kl = -INFINITY;
     f32x16 gW1[HT][HT];                 // [row tile][col tile] fragments of sum h0 (x) gz1
-    float gW0[DO + 1][HT];              // lane = column, rows d (DO = bias row); half = sample parity
+    f32x16 gW0[HT];                     // fragments of sum x_ext (x) gz0: rows d <= DO (DO = bias row) used
     float gW2[HT][DA];                  // lane = row (unit), half = sample parity
     float gb1[HT], gb2[DA], gls[DA];
     float wsum = 0.0f;
@@ -145,9 +145,9 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         for (int k = 0; k < DA; ++k) gW2[ti][k] = 0.0f;
     }
 #pragma unroll
-    for (int d = 0; d <= DO; ++d)
+    for (int tj = 0; tj < HT; ++tj)
 #pragma unroll
-        for (int tj = 0; tj < HT; ++tj) gW0[d][tj] = 0.0f;
+        for (int r = 0; r < 16; ++r) gW0[tj][r] = 0.0f;
 #pragma unroll
     for (int k = 0; k < DA; ++k) { gb2[k] = 0.0f; gls[k] = 0.0f; }
 
@@ -385,24 +385,25 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                 }
             }
 
-            // ---- layer 0: gW0[d][j] += sum_s x_ext[s][d] gz0[s][j]  (lane = column j, x broadcast) ------
+            // ---- layer 0: gW0 += x_ext^T gz0 (samples are K).  Only DO+1 of the 32 rows are real (the x
+            // tile's other columns hold stale finite values whose rows are never stored), but the matrix
+            // pipe has the slack and the VALU does not: as 16 MFMAs this product costs 32 LDS reads
+            // instead of ~450 VALU + LDS instructions.
             wave_sync();
 #pragma unroll
             for (int t = 0; t < HT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tb[lj * TSTR + 32 * t + frag_unit(r, 0) + 4 * lh] = gz0[t][r];
             wave_sync();
+            {
+                float ax[16];
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                float gz[HT];
+                for (int m = 0; m < 16; ++m) ax[m] = tbx[(2 * m + lh) * XS + (lj < XS ? lj : 0)];
 #pragma unroll
-                for (int t = 0; t < HT; ++t) gz[t] = tb[(2 * m + lh) * TSTR + 32 * t + lj];
+                for (int t = 0; t < HT; ++t)
 #pragma unroll
-                for (int d = 0; d <= DO; ++d) {
-                    const float xv = tbx[(2 * m + lh) * XS + d];
-#pragma unroll
-                    for (int t = 0; t < HT; ++t) gW0[d][t] = __builtin_fmaf(xv, gz[t], gW0[d][t]);
-                }
+                    for (int m = 0; m < 16; ++m)
+                        gW0[t] = mfma(ax[m], tb[(2 * m + lh) * TSTR + 32 * t + lj], gW0[t]);
             }
             wave_sync();
         }
@@ -430,12 +431,10 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         for (int k = threadIdx.x; k < P; k += WAVES * WV) red[k] = 0.0f;
         __syncthreads();
         // half-pair sums (both sample parities of the transposed-role accumulators)
-        float w0s[DO + 1][HT], w2s[HT][DA], b1s[HT];
+        float w2s[HT][DA], b1s[HT];
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
             b1s[t] = half_sum(gb1[t]);
-#pragma unroll
-            for (int d = 0; d <= DO; ++d) w0s[d][t] = half_sum(gW0[d][t]);
 #pragma unroll
             for (int k = 0; k < DA; ++k) w2s[t][k] = half_sum(gW2[t][k]);
         }
@@ -452,12 +451,17 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             red[N::W1 + (32 * ti + frag_unit(r, 0) + 4 * lh) * H + 32 * tj + lj] += gW1[ti][tj][r];
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int d = frag_unit(r, 0) + 4 * lh;          // row of x_ext^T gz0
+                        if (d < DO) red[N::W0 + d * H + 32 * t + lj] += gW0[t][r];
+                        else if (d == DO) red[N::B0 + 32 * t + lj] += gW0[t][r];
+                    }
                 if (lh == 0) {
 #pragma unroll
                     for (int t = 0; t < HT; ++t) {
-#pragma unroll
-                        for (int d = 0; d < DO; ++d) red[N::W0 + d * H + 32 * t + lj] += w0s[d][t];
-                        red[N::B0 + 32 * t + lj] += w0s[DO][t];
                         red[N::B1 + 32 * t + lj] += b1s[t];
 #pragma unroll
                         for (int k = 0; k < DA; ++k) red[N::W2 + (32 * t + lj) * DA + k] += w2s[t][k];

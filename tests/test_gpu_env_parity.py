@@ -6,8 +6,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV_KINDS = [0, 1, 2, 3]
-OBS_INVERTIBLE = [0, 2]   # kinds whose reset state can be rebuilt from the observation
+ENV_KINDS = [0, 1, 2, 3, 4]
+OBS_INVERTIBLE = [0, 2, 4]   # kinds whose reset state can be rebuilt from the observation
 
 
 def _dev():

@@ -254,3 +254,28 @@ def test_cheetah_f32_tracks_f64_and_stays_bounded():
         o32, r32, d = e32.step(rng.randn(6).astype(np.float32))
     assert not d and np.isfinite(e32.state).all()
     assert 0.3 < e32.state[0] < 0.9 and np.abs(e32.state[2:9]).max() < 2.0 and np.abs(e32.state[9:]).max() < 50.0
+
+
+def test_cartpole_swingup_contract():
+    """CartpoleSwingupEnv (cartpole_swingup_env.py:29-56): reset box around the hanging pole, reward
+    cos(angle) / -100, done only beyond |x| = 3, same island solver as CartpoleEnv."""
+    e = H.HostEnv(4, np.float64, normalize=True)
+    o = e.reset(np.array([0.5, 0.5, 0.5, 0.5]))
+    assert np.allclose(o, [0.0, 0.0, np.pi, 0.0])
+    o = e.reset(np.array([0.0, 1.0, 1.0, 0.0]))
+    assert np.allclose(o, [-1.0, 2.0, np.pi + 1.0, -3.0])
+    o, r, d = e.step([0.2])
+    assert not d and np.isclose(r, np.cos(o[2]), atol=1e-12)
+    e.reset(np.array([0.5, 0.5, 0.5, 0.5]))
+    done = False
+    for _ in range(400):
+        o, r, done = e.step([1.0])
+        if done:
+            break
+    assert done and r == -100.0 and abs(o[0]) > 3.0
+    # identical physics to CartpoleEnv from the same state and force
+    a, b = H.HostEnv(0, np.float64), H.HostEnv(4, np.float64)
+    a.reset(np.full(4, 0.5)); b.reset(np.full(4, 0.5))
+    b.state[:] = a.state
+    oa, _, _ = a.step([3.0]); ob, _, _ = b.step([3.0])
+    assert np.array_equal(oa, ob)
