@@ -156,20 +156,34 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     const int wave_global = blockIdx.x * WAVES + wave;
     const int waves_total = gridDim.x * WAVES;
 
+    // Per-sample inputs of a tile (observation slots, weight) are fetched one tile AHEAD: the HBM
+    // round trip (~1 us) of tile t+1 overlaps the matrix chains of tile t instead of stalling the
+    // head of every tile.
+    auto fetch = [&](int tile, float* xq, float& wq) {
+        const int b = tile * TS + lj;
+        const bool live = b < B;
+        const int bi = live ? b : (B - 1);
+        wq = live ? a.weight[bi] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < KS0; ++m) {
+            const int d = 2 * m + lh;
+            xq[m] = d < DO ? a.obs[(size_t)d * B + bi] : (d == DO ? 1.0f : 0.0f);
+        }
+    };
+    float xb[KS0], xb_next[KS0];
+    float wgt = 0.0f, wgt_next = 0.0f;
+    if (wave_global < n_tiles) fetch(wave_global, xb_next, wgt_next);
+
     for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
         asm volatile("" ::: "memory");   // keep the weight-fragment reads inside the loop
         const int b = tile * TS + lj;
         const bool live = b < B;
         const int bi = live ? b : (B - 1);
-        const float wgt = live ? a.weight[bi] : 0.0f;
-
         // ---- B operands of layer 0: x_ext[sample][2m + half] (slot DO = 1 carries the bias) -----
-        float xb[KS0];
 #pragma unroll
-        for (int m = 0; m < KS0; ++m) {
-            const int d = 2 * m + lh;
-            xb[m] = d < DO ? a.obs[(size_t)d * B + bi] : (d == DO ? 1.0f : 0.0f);
-        }
+        for (int m = 0; m < KS0; ++m) xb[m] = xb_next[m];
+        wgt = wgt_next;
+        if (tile + waves_total < n_tiles) fetch(tile + waves_total, xb_next, wgt_next);
 
         // ---- forward ------------------------------------------------------------------------
         f32x16 h0[HT], h1[HT];
