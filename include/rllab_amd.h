@@ -172,14 +172,18 @@ int rl_sample_stats_cols(void);
  *   out[0] count, [1..2] sum / sum^2 of (return - ret_shift), [3..4] of (baseline - ret_shift),
  *   [5..6] of (return - baseline), [7..8] of the advantage, [9] valid paths (tin == 0),
  *   [10..11] sum / sum^2 of (undiscounted path return - und_shift), [12] sum of discounted
- *   returns at path starts, [13] min advantage, [14] max path return, [15] min path return.
+ *   returns at path starts, [13..14] sum / sum^2 of the per-path progress, [15] min advantage,
+ *   [16] max / [17] min path return, [18] max / [19] min progress.
  * Feeds explained_variance_1d (misc/special.py:51-59), center / shift_advantages
- * (algos/util.py:7-12) and the return statistics of base.py:93-103.  The shifts only
- * condition the one-pass variances; pass any value near the respective means. */
+ * (algos/util.py:7-12), the return statistics of base.py:93-103 and the envs' forward-progress
+ * diagnostics (swimmer_env.py:48-62).  The shifts only condition the one-pass variances; pass any
+ * value near the respective means.
+ *   progress: NULL, or a float[T][n_cols] plane x (e.g. one observation component): a path's progress is
+ *   x[its last step] - x[its first step]; n_cols = n (envs per row of the [T][n] planes). */
 int rl_sample_stats(size_t n_samples, const float* returns, const double* baselines,
                     const float* advantages, const float* undiscounted, const int32_t* tin,
-                    const uint8_t* valid, double ret_shift, double und_shift, void* workspace,
-                    size_t workspace_bytes, double* out, void* stream);
+                    const uint8_t* valid, double ret_shift, double und_shift, const float* progress,
+                    int n_cols, void* workspace, size_t workspace_bytes, double* out, void* stream);
 
 /* adv_out = valid ? (adv_in - mean) / denom + shift : 0   (algos/util.py:7-12). */
 int rl_adv_finish(size_t n_samples, const float* adv_in, const uint8_t* valid, double mean, double denom,

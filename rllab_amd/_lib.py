@@ -91,7 +91,7 @@ def _load():
     lib.rl_process_workspace_bytes.restype = sz
     lib.rl_process_workspace_bytes.argtypes = [i32]
     lib.rl_sample_stats_cols.restype = i32
-    lib.rl_sample_stats.argtypes = [sz, vp, vp, vp, vp, vp, vp, f64, f64, vp, sz, vp, vp]
+    lib.rl_sample_stats.argtypes = [sz, vp, vp, vp, vp, vp, vp, f64, f64, vp, i32, vp, sz, vp, vp]
     lib.rl_adv_finish.argtypes = [sz, vp, vp, f64, f64, f64, vp, vp]
     lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, vp]
     for name in SYMBOLS:

@@ -107,26 +107,30 @@ enum {
     ST_NPATH,          // valid paths (starts)
     ST_UND, ST_UND2,   // undiscounted path return (shifted by und_shift) at path starts
     ST_DISC,           // discounted return at path starts
+    ST_PROG, ST_PROG2, // per-path progress x[last step] - x[first step] of one observation component
     ST_NSUM,           // number of summed columns
-    ST_ADVMIN = ST_NSUM, ST_UNDMAX, ST_UNDMIN,
+    ST_ADVMIN = ST_NSUM, ST_UNDMAX, ST_UNDMIN, ST_PROGMAX, ST_PROGMIN,
     ST_NCOLS
 };
 constexpr int ST_BLOCK = 256;
 
 struct StatAcc {
     double s[ST_NSUM];
-    double adv_min, und_max, und_min;
+    double adv_min, und_max, und_min, prog_max, prog_min;
 };
+
+__device__ __forceinline__ bool stat_is_max(int c) { return c == ST_UNDMAX || c == ST_PROGMAX; }
 
 __global__ void __launch_bounds__(ST_BLOCK)
 sample_stats_kernel(size_t B, const float* __restrict__ ret, const double* __restrict__ base,
                     const float* __restrict__ adv, const float* __restrict__ undisc,
                     const int32_t* __restrict__ tin, const uint8_t* __restrict__ valid, double ret_shift,
-                    double und_shift, double* __restrict__ partial) {
+                    double und_shift, const float* __restrict__ prog, int n_cols, double* __restrict__ partial) {
     StatAcc a;
 #pragma unroll
     for (int c = 0; c < ST_NSUM; ++c) a.s[c] = 0.0;
     a.adv_min = INFINITY; a.und_max = -INFINITY; a.und_min = INFINITY;
+    a.prog_max = -INFINITY; a.prog_min = INFINITY;
     for (size_t b = (size_t)blockIdx.x * ST_BLOCK + threadIdx.x; b < B; b += (size_t)gridDim.x * ST_BLOCK) {
         if (!valid[b]) continue;
         const double r = (double)ret[b] - ret_shift;
@@ -147,6 +151,16 @@ sample_stats_kernel(size_t B, const float* __restrict__ ret, const double* __res
             a.und_max = fmax(a.und_max, u);
             a.und_min = fmin(a.und_min, u);
         }
+        if (prog) {
+            // last step of a path: the next step of this column starts a new path (or there is none)
+            const bool last = (b + (size_t)n_cols >= B) || (tin[b + (size_t)n_cols] == 0);
+            if (last) {
+                const double p = (double)prog[b] - (double)prog[b - (size_t)tin[b] * (size_t)n_cols];
+                a.s[ST_PROG] += p; a.s[ST_PROG2] += p * p;
+                a.prog_max = fmax(a.prog_max, p);
+                a.prog_min = fmin(a.prog_min, p);
+            }
+        }
     }
     __shared__ double sm[ST_BLOCK / 64][ST_NCOLS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -154,13 +168,14 @@ sample_stats_kernel(size_t B, const float* __restrict__ ret, const double* __res
 #pragma unroll
     for (int c = 0; c < ST_NSUM; ++c) cols[c] = a.s[c];
     cols[ST_ADVMIN] = a.adv_min; cols[ST_UNDMAX] = a.und_max; cols[ST_UNDMIN] = a.und_min;
+    cols[ST_PROGMAX] = a.prog_max; cols[ST_PROGMIN] = a.prog_min;
 #pragma unroll
     for (int c = 0; c < ST_NCOLS; ++c) {
         double v = cols[c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double w = __shfl_xor(v, o, 64);
-            v = (c < ST_NSUM) ? v + w : ((c == ST_UNDMAX) ? fmax(v, w) : fmin(v, w));
+            v = (c < ST_NSUM) ? v + w : (stat_is_max(c) ? fmax(v, w) : fmin(v, w));
         }
         if (lane == 0) sm[wave][c] = v;
     }
@@ -169,7 +184,7 @@ sample_stats_kernel(size_t B, const float* __restrict__ ret, const double* __res
         const int c = threadIdx.x;
         double v = sm[0][c];
         for (int w = 1; w < ST_BLOCK / 64; ++w)
-            v = (c < ST_NSUM) ? v + sm[w][c] : ((c == ST_UNDMAX) ? fmax(v, sm[w][c]) : fmin(v, sm[w][c]));
+            v = (c < ST_NSUM) ? v + sm[w][c] : (stat_is_max(c) ? fmax(v, sm[w][c]) : fmin(v, sm[w][c]));
         partial[(size_t)blockIdx.x * ST_NCOLS + c] = v;
     }
 }
@@ -178,7 +193,7 @@ sample_stats_kernel(size_t B, const float* __restrict__ ret, const double* __res
 __global__ void __launch_bounds__(64) stats_reduce_kernel(const double* __restrict__ partial, int rows,
                                                           double* __restrict__ out) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    const bool is_sum = c < ST_NSUM, is_max = (c == ST_UNDMAX);
+    const bool is_sum = c < ST_NSUM, is_max = stat_is_max(c);
     double v = is_sum ? 0.0 : (is_max ? -INFINITY : INFINITY);
     for (int r = lane; r < rows; r += 64) {
         const double w = partial[(size_t)r * ST_NCOLS + c];
@@ -316,9 +331,10 @@ extern "C" size_t rl_process_workspace_bytes(int obs_dim) {
 
 extern "C" int rl_sample_stats(size_t n_samples, const float* returns, const double* baselines,
                                const float* advantages, const float* undiscounted, const int32_t* tin,
-                               const uint8_t* valid, double ret_shift, double und_shift, void* workspace,
-                               size_t workspace_bytes, double* out, void* stream) {
-    if (n_samples == 0 || !returns || !advantages || !undiscounted || !tin || !valid || !workspace || !out)
+                               const uint8_t* valid, double ret_shift, double und_shift, const float* progress,
+                               int n_cols, void* workspace, size_t workspace_bytes, double* out, void* stream) {
+    if (n_samples == 0 || !returns || !advantages || !undiscounted || !tin || !valid || !workspace || !out ||
+        (progress && n_cols <= 0))
         return set_error(RL_ERR_ARG, "rl_sample_stats: bad argument");
     int grid = (int)((n_samples + ST_BLOCK * 8 - 1) / (ST_BLOCK * 8));
     if (grid > 1024) grid = 1024;
@@ -326,7 +342,8 @@ extern "C" int rl_sample_stats(size_t n_samples, const float* returns, const dou
     if (workspace_bytes < (size_t)grid * ST_NCOLS * sizeof(double))
         return set_error(RL_ERR_ARG, "rl_sample_stats: workspace too small");
     hipLaunchKernelGGL(sample_stats_kernel, dim3(grid), dim3(ST_BLOCK), 0, (hipStream_t)stream, n_samples, returns,
-                       baselines, advantages, undiscounted, tin, valid, ret_shift, und_shift, (double*)workspace);
+                       baselines, advantages, undiscounted, tin, valid, ret_shift, und_shift, progress, n_cols,
+                       (double*)workspace);
     hipLaunchKernelGGL(stats_reduce_kernel, dim3(ST_NCOLS), dim3(64), 0, (hipStream_t)stream,
                        (const double*)workspace, grid, out);
     return check_launch("sample_stats_kernel");

@@ -10,6 +10,9 @@ from rllab_amd.envs.hip_env import HipEnv
 
 class MujocoEnv(HipEnv):
     FILE = None
+    # observation component whose change over a path is the "ForwardProgress" diagnostic
+    # (obs[-3] = x of the subtree COM: swimmer_env.py:48-62, half_cheetah_env.py:48-56)
+    progress_obs_index = -3
 
     def __init__(self, action_noise=0.0, file_path=None, template_args=None):
         unsupported = []
@@ -33,7 +36,9 @@ class MujocoEnv(HipEnv):
         from rllab_amd.misc import logger
         from rllab_amd.sampler import dist as D
         from rllab_amd.sampler.trajectories import PathList
-        if isinstance(paths, PathList):
+        if isinstance(paths, PathList) and paths.traj.progress_stats is not None:
+            vals = paths.traj.progress_stats      # computed by rl_sample_stats inside process_samples
+        elif isinstance(paths, PathList):
             env, t0, t1 = paths.index()
             comx = paths.traj.obs[paths.traj.obs_dim - 3]
             progs = (comx[t1, env] - comx[t0, env]).to(torch.float64)

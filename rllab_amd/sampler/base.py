@@ -89,9 +89,9 @@ def _workspace(device, obs_dim):
 
 
 # column indices of rl_sample_stats (include/rllab_amd.h)
-(_COUNT, _RET, _RET2, _BASE, _BASE2, _RES, _RES2, _ADV, _ADV2, _NPATH, _UND, _UND2, _DISC,
- _ADVMIN, _UNDMAX, _UNDMIN) = range(16)
-_N_SUM = 13
+(_COUNT, _RET, _RET2, _BASE, _BASE2, _RES, _RES2, _ADV, _ADV2, _NPATH, _UND, _UND2, _DISC, _PROG, _PROG2,
+ _ADVMIN, _UNDMAX, _UNDMIN, _PROGMAX, _PROGMIN) = range(20)
+_N_SUM = 15
 
 
 def path_scan(traj, whole_paths, coeffs=None, want_values=True):
@@ -118,9 +118,9 @@ def merge_stats(st):
         return st
     sums = st[:_N_SUM].clone()
     D.all_reduce_sum_(sums)
-    ext = torch.stack([-st[_ADVMIN], st[_UNDMAX], -st[_UNDMIN]])
+    ext = torch.stack([-st[_ADVMIN], st[_UNDMAX], -st[_UNDMIN], st[_PROGMAX], -st[_PROGMIN]])
     D.all_reduce_max_(ext)
-    return torch.cat([sums, torch.stack([-ext[0], ext[1], -ext[2]])])
+    return torch.cat([sums, torch.stack([-ext[0], ext[1], -ext[2], ext[3], -ext[4]])])
 
 
 _SHIFT = dict(ret=0.0, und=0.0)   # last iteration's means: they only condition the one-pass variances
@@ -159,10 +159,17 @@ def process_dense(algo, itr, traj, log=True):
 
     valid_u8 = valid.to(torch.uint8)
     ws = _workspace(dev, traj.obs_dim)
-    st = torch.empty(16, dtype=torch.float64, device=dev)
+    st = torch.empty(20, dtype=torch.float64, device=dev)
+    # envs that log forward progress name the observation component to difference over each path
+    inner = getattr(algo, "env", None)
+    while hasattr(inner, "wrapped_env"):
+        inner = inner.wrapped_env
+    prog_idx = getattr(inner, "progress_obs_index", None)
+    prog = traj.obs[prog_idx % traj.obs_dim] if prog_idx is not None else None
     _lib.check(_lib.lib.rl_sample_stats(B, _lib.ptr(ret), _lib.ptr(base_c), _lib.ptr(adv), _lib.ptr(und),
                                         _lib.ptr(tin), _lib.ptr(valid_u8), _SHIFT["ret"], _SHIFT["und"],
-                                        _lib.ptr(ws), ws.numel(), _lib.ptr(st), _lib.stream_ptr()), "rl_sample_stats")
+                                        _lib.ptr(prog), N, _lib.ptr(ws), ws.numel(), _lib.ptr(st),
+                                        _lib.stream_ptr()), "rl_sample_stats")
     s = merge_stats(st).cpu().numpy()         # the iteration's one host read of batch statistics
     cnt, n_paths = s[_COUNT], s[_NPATH]
 
@@ -190,6 +197,9 @@ def process_dense(algo, itr, traj, log=True):
                                       float(shift), _lib.ptr(adv_out), _lib.stream_ptr()), "rl_adv_finish")
     traj.advantages = adv_out
 
+    if prog is not None and n_paths > 0:
+        m_prog, var_prog = moments(_PROG, _PROG2, n_paths)
+        traj.progress_stats = (float(m_prog), float(s[_PROGMAX]), float(s[_PROGMIN]), float(np.sqrt(var_prog)))
     m_und_s, var_und = moments(_UND, _UND2, n_paths) if n_paths > 0 else (np.nan, np.nan)
     mean_und = m_und_s + _SHIFT["und"]
     _SHIFT["ret"], _SHIFT["und"] = float(m_ret + _SHIFT["ret"]), (float(mean_und) if n_paths > 0 else 0.0)

@@ -35,6 +35,7 @@ class Trajectories(object):
         self.returns = None
         self.baselines = None
         self.tin = None          # [T, N] int32 step index inside its path (rl_path_scan)
+        self.progress_stats = None   # (mean, max, min, std) of the env's per-path progress (rl_sample_stats)
 
     @property
     def device(self):

@@ -121,12 +121,12 @@ def _worker(rank, world, port, outdir):
     assert float(s) == 3.0
     assert float(D.all_reduce_min_(torch.tensor(float(rank)))) == 0.0
     assert float(D.all_reduce_max_(torch.tensor(float(rank)))) == 1.0
-    # rl_sample_stats rows of two shards -> global row: 13 sum columns, then min / max / min
-    row = torch.arange(16, dtype=torch.float64) + 100.0 * rank
-    row[13], row[14], row[15] = -5.0 - rank, 7.0 + rank, -3.0 + rank
+    # rl_sample_stats rows of two shards -> global row: 15 sum columns, then min / max / min / max / min
+    row = torch.arange(20, dtype=torch.float64) + 100.0 * rank
+    row[15], row[16], row[17], row[18], row[19] = -5.0 - rank, 7.0 + rank, -3.0 + rank, 2.0 - rank, 4.0 + rank
     got = merge_stats(row).numpy()
-    assert np.array_equal(got[:13], 2 * np.arange(13) + 100.0)
-    assert got[13] == -6.0 and got[14] == 8.0 and got[15] == -3.0
+    assert np.array_equal(got[:15], 2 * np.arange(15) + 100.0)
+    assert got[15] == -6.0 and got[16] == 8.0 and got[17] == -3.0 and got[18] == 2.0 and got[19] == 4.0
     # TRPO update on half of the batch
     pol, inputs = _make_problem()
     theta, before, after = _run_trpo(pol, _shard(inputs, rank, world))

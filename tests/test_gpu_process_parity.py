@@ -247,42 +247,98 @@ def test_path_scan_and_normal_equations_vs_numpy(T, n, do, whole_paths):
     assert np.abs(got[F * F:] - rhs).max() <= 1e-11 * max(1.0, np.abs(rhs).max())
 
 
-@pytest.mark.parametrize("B", [1, 63, 5000, 2048000])
-def test_sample_stats_and_adv_finish_vs_numpy(B):
+@pytest.mark.parametrize("T,n", [(1, 1), (9, 7), (50, 100), (500, 4096)])
+def test_sample_stats_and_adv_finish_vs_numpy(T, n):
     from rllab_amd import _lib
     from rllab_amd.sampler.base import _workspace
+    B = T * n
     rng = np.random.RandomState(B % 1000)
     dev = torch.device("cuda", 0)
     ret = (rng.randn(B) * 20 + 300).astype(np.float32)
     base = rng.randn(B) * 20 + 290
     adv = (rng.randn(B) * 3 + 1).astype(np.float32)
     und = (rng.randn(B) * 50 + 500).astype(np.float32)
-    tin = (rng.rand(B) < 0.9).astype(np.int32) * rng.randint(1, 50, B).astype(np.int32)
-    valid = (rng.rand(B) < 0.8).astype(np.uint8)
-    valid[0] = 1
-    tin[0] = 0
-    t = lambda x: torch.as_tensor(x, device=dev)
+    x = (rng.randn(B) * 2).astype(np.float32)                  # the "progress" observation component
+    done = (rng.rand(T, n) < 0.1).astype(np.uint8)
+    tin2, valid2 = _np_tin_valid(done, True)
+    if valid2.sum() == 0:
+        done[-1, 0] = 1
+        tin2, valid2 = _np_tin_valid(done, True)
+    tin, valid = tin2.reshape(-1).astype(np.int32), valid2.reshape(-1).astype(np.uint8)
+    t = lambda a: torch.as_tensor(a, device=dev)
     ws = _workspace(dev, 13)
-    out = torch.empty(16, dtype=torch.float64, device=dev)
+    out = torch.empty(20, dtype=torch.float64, device=dev)
     args = [t(ret), t(base), t(adv), t(und), t(tin), t(valid)]
-    _lib.check(_lib.lib.rl_sample_stats(B, *[_lib.ptr(a) for a in args], 280.0, 450.0, _lib.ptr(ws), ws.numel(),
-                                        _lib.ptr(out), _lib.stream_ptr()))
+    tx = t(x)
+    _lib.check(_lib.lib.rl_sample_stats(B, *[_lib.ptr(a) for a in args], 280.0, 450.0, _lib.ptr(tx), n, _lib.ptr(ws),
+                                        ws.numel(), _lib.ptr(out), _lib.stream_ptr()))
     s = out.cpu().numpy()
     m = valid.astype(bool)
     st = m & (tin == 0)
     r64, a64, u64 = ret.astype(np.float64), adv.astype(np.float64), und.astype(np.float64)
+    # per-path progress: x at the path's last step minus x at its first step, valid paths only
+    x2 = x.reshape(T, n).astype(np.float64)
+    progs = []
+    for i in range(n):
+        for tt in range(T):
+            last = (tt == T - 1) or tin2[tt + 1, i] == 0
+            if valid2[tt, i] and last:
+                progs.append(x2[tt, i] - x2[tt - tin2[tt, i], i])
+    progs = np.array(progs)
     want = [m.sum(), (r64[m] - 280).sum(), ((r64[m] - 280) ** 2).sum(), (base[m] - 280).sum(), ((base[m] - 280) ** 2).sum(),
             (r64[m] - base[m]).sum(), ((r64[m] - base[m]) ** 2).sum(), a64[m].sum(), (a64[m] ** 2).sum(), st.sum(),
-            (u64[st] - 450).sum(), ((u64[st] - 450) ** 2).sum(), r64[st].sum(), a64[m].min(), u64[st].max(), u64[st].min()]
+            (u64[st] - 450).sum(), ((u64[st] - 450) ** 2).sum(), r64[st].sum(), progs.sum(), (progs ** 2).sum(),
+            a64[m].min(), u64[st].max(), u64[st].min(), progs.max(), progs.min()]
+    assert len(progs) == st.sum()
     for i, (g_, w_) in enumerate(zip(s, want)):
         assert abs(g_ - w_) <= 1e-10 * max(1.0, abs(w_)), (i, g_, w_)
     # the variances process_samples derives from these sums equal numpy's two-pass np.var
     cnt = s[0]
-    assert np.isclose(s[2] / cnt - (s[1] / cnt) ** 2, r64[m].var(), rtol=1e-9)
-    assert np.isclose(s[8] / cnt - (s[7] / cnt) ** 2, a64[m].var(), rtol=1e-9)
+    assert np.isclose(s[2] / cnt - (s[1] / cnt) ** 2, r64[m].var(), rtol=1e-9, atol=1e-9)
+    assert np.isclose(s[8] / cnt - (s[7] / cnt) ** 2, a64[m].var(), rtol=1e-9, atol=1e-9)
+    # progress == NULL leaves its columns at the identities
+    _lib.check(_lib.lib.rl_sample_stats(B, *[_lib.ptr(a) for a in args], 280.0, 450.0, None, 0, _lib.ptr(ws),
+                                        ws.numel(), _lib.ptr(out), _lib.stream_ptr()))
+    s2 = out.cpu().numpy()
+    assert s2[13] == 0.0 and s2[14] == 0.0 and s2[18] == -np.inf and s2[19] == np.inf
     mean, denom = a64[m].mean(), a64[m].std() + 1e-8
     o = torch.empty(B, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib.rl_adv_finish(B, _lib.ptr(args[2]), _lib.ptr(args[5]), mean, denom, 0.25, _lib.ptr(o),
                                       _lib.stream_ptr()))
     want_o = np.where(m, (a64 - mean) / denom + 0.25, 0.0)
-    assert np.abs(o.cpu().numpy() - want_o).max() <= 1e-6
+    assert np.abs(o.cpu().numpy() - want_o).max() <= 1e-6 * max(1.0, np.abs(want_o).max())
+
+
+def test_forward_progress_from_stats_kernel_matches_path_index(quiet_logger):
+    """AverageForwardProgress & co. (swimmer_env.py:48-62) as computed inside rl_sample_stats equal the
+    per-path gather over the path index (torch nonzero / indexing) on a real Swimmer rollout."""
+    from rllab_amd.algos.trpo import TRPO
+    from rllab_amd.baselines.zero_baseline import ZeroBaseline
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.misc import ext, logger
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(7)
+    env = normalize(SwimmerEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    algo = TRPO(env=env, policy=policy, baseline=ZeroBaseline(env_spec=env.spec), batch_size=100 * 60, max_path_length=37,
+                n_itr=1, sampler_args=dict(n_envs=100))
+    algo.start_worker()
+    paths = algo.sampler.obtain_samples(0)
+    # horizon 37 inside 37-step rollouts: make the rollout longer than a path so several paths per column exist
+    traj = algo.sampler.vec_env.rollout(policy, 100, reset_at_start=True)
+    from rllab_amd.sampler.base import process_dense
+    from rllab_amd.sampler.trajectories import PathList
+    sd = process_dense(algo, 0, traj)
+    logger.dump_tabular()
+    got = traj.progress_stats
+    e, t0, t1 = PathList(traj).index()
+    comx = traj.obs[traj.obs_dim - 3].double()
+    progs = (comx[t1, e] - comx[t0, e]).cpu().numpy()
+    assert len(progs) == 200 and got is not None       # 2 complete 37-step paths per column, the tail dropped
+    want = (progs.mean(), progs.max(), progs.min(), progs.std())
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-12)
+    env.log_diagnostics(PathList(traj))
+    tab = logger.get_tabular()
+    assert np.isclose(float(tab["AverageForwardProgress"]), want[0]) and np.isclose(float(tab["StdForwardProgress"]), want[3])
+    logger.dump_tabular()
