@@ -31,7 +31,8 @@ enum rl_env_kind {
     RL_ENV_DOUBLE_PENDULUM = 1,  /* rllab/envs/box2d/double_pendulum_env.py:11-61 */
     RL_ENV_SWIMMER = 2,          /* rllab/envs/mujoco/swimmer_env.py:10-62 (swimmer-style planar chain) */
     RL_ENV_HALF_CHEETAH = 3,     /* rllab/envs/mujoco/half_cheetah_env.py:14-56 (cheetah-style planar tree) */
-    RL_ENV_CARTPOLE_SWINGUP = 4  /* rllab/envs/box2d/cartpole_swingup_env.py:14-61 */
+    RL_ENV_CARTPOLE_SWINGUP = 4, /* rllab/envs/box2d/cartpole_swingup_env.py:14-61 */
+    RL_ENV_WALKER2D = 5          /* rllab/envs/mujoco/walker2d_env.py:15-59 (walker-style planar biped) */
 };
 
 enum rl_status {
@@ -158,7 +159,7 @@ int rl_discount_cumsum(int T, int n, const float* x, const uint8_t* dones, doubl
  *                       batch_polopt.py:30-34, vectorized_sampler.py:72-97)
  *   values double[T][n] or NULL: phi(obs, tin) . coeffs, coeffs = double[2*obs_dim+4] in the
  *                       reference's feature order, or zeros when coeffs == NULL (before the first fit)
- *   obs    float[obs_dim][T][n]; obs_dim <= 20. */
+ *   obs    float[obs_dim][T][n]; obs_dim <= 21. */
 int rl_path_scan(int T, int n, int obs_dim, const uint8_t* dones, const float* obs, const double* coeffs,
                  int whole_paths, int32_t* tin, uint8_t* valid, double* values, void* stream);
 

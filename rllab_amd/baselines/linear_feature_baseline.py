@@ -71,7 +71,7 @@ class LinearFeatureBaseline(Baseline):
         """[T, N] float64 baseline plane, or None before the first fit (== zeros)."""
         if self._coeffs is None:
             return None
-        if traj.obs_dim <= 20 and traj.device.type == "cuda":
+        if traj.obs_dim <= 21 and traj.device.type == "cuda":
             from rllab_amd.sampler.base import path_scan
             return path_scan(traj, True, self._coeffs)[2]
         w = torch.as_tensor(self._coeffs, dtype=torch.float64, device=traj.device)
@@ -79,7 +79,7 @@ class LinearFeatureBaseline(Baseline):
 
     def fit_dense(self, traj, all_reduce=None):
         F = 2 * traj.obs_dim + 4
-        if traj.obs_dim <= 20 and traj.device.type == "cuda":
+        if traj.obs_dim <= 21 and traj.device.type == "cuda":
             # Phi^T W Phi and Phi^T W y by rl_lfb_normal_eq: one pass, features rebuilt in LDS
             from rllab_amd import _lib
             from rllab_amd.sampler.base import _workspace, path_scan

@@ -1,0 +1,163 @@
+// dyn_walker.h -- Walker2DEnv-style env: planar 7-body / 9-DoF biped (torso + two 3-link legs) with joint
+// dampers, armature, torque motors, gravity and capsule-floor contacts; single source for the gfx950
+// kernels and the host oracle build.
+//
+// Replaces, for one env copy:
+//   Walker2DEnv.step / get_current_obs      rllab/envs/mujoco/walker2d_env.py:28-49
+//   MujocoEnv.reset_mujoco / forward_dynamics   rllab/envs/mujoco/mujoco_env.py:109-116,184-191
+//   MjModel.step / forward / _compute_subtree   rllab/mujoco_py/mjcore.py:46-84
+//   model constants                         vendor/mujoco_models/walker2d.xml:3-59
+//                                           (through gen_planar_constants.py -> walker_constants.h)
+//   NormalizedEnv.step                      rllab/envs/normalized_env.py:78-92
+// "-style": rigid-body tree, joint passive forces and actuation follow the MJCF; joint limits and the
+// condim-3 capsule/plane contacts are the same spring-damper penalty model as dyn_cheetah.h (per-geom
+// radius and friction), and one 0.005 s MuJoCo step (frame_skip 1) is integrated as 2 semi-implicit
+// Euler sub-steps of 0.0025 s.
+//
+// Plane coordinates (P1, P2) = (z, x).  The leg hinges are declared about -y in the MJCF: MuJoCo's joint
+// coordinate, velocity and motor torque are the negatives of the tree's (walker::SIGN).
+// State (18 reals, tree convention): q[9] = [z (absolute torso height = MuJoCo's rootz, ref 1.25), x,
+// rooty, thigh, leg, foot, thigh_left, leg_left, foot_left], qd[9].
+#pragma once
+#include "dyn_planar.h"
+#include "walker_constants.h"
+
+namespace rl {
+
+struct WalkerModel {
+    static constexpr int NB = walker::NB;
+    RL_HD static constexpr int parent(int i) { return walker::PARENT[i]; }
+    RL_HD static constexpr double jx(int i) { return walker::JX[i]; }
+    RL_HD static constexpr double jy(int i) { return walker::JY[i]; }
+    RL_HD static constexpr double cx(int i) { return walker::CX[i]; }
+    RL_HD static constexpr double cy(int i) { return walker::CY[i]; }
+    RL_HD static constexpr double mass(int i) { return walker::MASS[i]; }
+    RL_HD static constexpr double inertia(int i) { return walker::INERTIA[i]; }
+    RL_HD static constexpr double armature(int i) { return walker::ARMATURE[i]; }
+    RL_HD static constexpr double damping(int i) { return walker::DAMPING[i]; }
+    RL_HD static constexpr double stiffness(int i) { return walker::STIFFNESS[i]; }
+    RL_HD static constexpr bool limited(int i) { return i >= 1; }
+    RL_HD static constexpr double lo(int i) { return walker::LO[i]; }
+    RL_HD static constexpr double hi(int i) { return walker::HI[i]; }
+    RL_HD static constexpr double limit_k() { return 2.0e3; }
+    RL_HD static constexpr double limit_b() { return 15.0; }
+    RL_HD static constexpr double gx() { return -9.81; }  // gravity along -z = -P1
+    RL_HD static constexpr double gy() { return 0.0; }
+
+    static constexpr double CONTACT_K = 2.0e4;   // N/m per end sphere
+    static constexpr double CONTACT_B = 3.0e2;   // N s/m while penetrating
+    static constexpr double FRICTION_C = 3.0e2;  // N s/m tangential, clamped to mu * f_n
+
+    // capsule end spheres against the floor z = 0
+    template <typename R>
+    RL_HD static void external(const R* q, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {
+        RL_UNROLL
+        for (int i = 0; i < NB; ++i) { fx[i] = (R)0; fy[i] = (R)0; tz[i] = (R)0; }
+        RL_UNROLL
+        for (int c = 0; c < walker::NC; ++c) {
+            const int b = walker::CBODY[c];
+            const R lx = (R)walker::CPX[c], ly = (R)walker::CPY[c], rad = (R)walker::CRADS[c];
+            const R rx = k.cs[b] * lx - k.sn[b] * ly;   // sphere centre relative to the body anchor
+            const R ry = k.sn[b] * lx + k.cs[b] * ly;
+            const R depth = rad - (q[0] + k.ax[b] + rx);
+            if (depth > (R)0) {
+                const R vn = k.vax[b] - k.om[b] * ry;   // velocity of the sphere centre
+                const R vt = k.vay[b] + k.om[b] * rx;
+                R fn = (R)CONTACT_K * depth - (R)CONTACT_B * vn;
+                fn = rl_max(fn, (R)0);
+                const R mu = (R)walker::CMU[c];
+                const R ft = -rl_clamp((R)FRICTION_C * vt, -mu * fn, mu * fn);
+                // applied at the lowest point of the sphere; lever arm from the body COM
+                const R ax_ = (k.ax[b] + rx - rad) - k.px[b];
+                const R ay_ = (k.ay[b] + ry) - k.py[b];
+                fx[b] = fx[b] + fn;
+                fy[b] = fy[b] + ft;
+                tz[b] = tz[b] + (ax_ * ft - ay_ * fn);
+            }
+        }
+    }
+};
+
+struct Walker2D {
+    static constexpr int OBS = 21;
+    static constexpr int ACT = 6;
+    static constexpr int STATE = 18;
+    static constexpr int RESET_DRAWS = 18;  // N(0,1): 9 for qpos, 9 for qvel (MuJoCo order)
+    static constexpr bool RESET_NORMAL = true;
+    static constexpr int KIND = 5;
+    static constexpr int SUBSTEPS = 2;      // 2 x 0.0025 s = one 0.005 s MuJoCo step, frame_skip 1
+    using Tree = PlanarTree<WalkerModel>;
+
+    template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
+        RL_UNROLL
+        for (int k = 0; k < ACT; ++k) { lb[k] = -(R)walker::GEAR[1 + k]; ub[k] = (R)walker::GEAR[1 + k]; }
+    }
+
+    // qpos = init + 0.01 N(0,1) with init_qpos = [1.25, 0, ...], qvel = 0.1 N(0,1), MuJoCo order
+    // [rootz, rootx, rooty, joints] and MuJoCo sign convention for the joints
+    template <typename R> RL_HD static void reset(R* s, const R* z) {
+        s[0] = (R)1.25 + z[0] * (R)0.01;
+        s[1] = z[1] * (R)0.01;
+        s[2] = z[2] * (R)0.01;
+        s[9] = z[9] * (R)0.1;
+        s[10] = z[10] * (R)0.1;
+        s[11] = z[11] * (R)0.1;
+        RL_UNROLL
+        for (int i = 3; i < 9; ++i) {
+            s[i] = (R)walker::SIGN[i - 2] * (z[i] * (R)0.01);
+            s[9 + i] = (R)walker::SIGN[i - 2] * (z[9 + i] * (R)0.1);
+        }
+    }
+
+    // obs = [qpos, qvel, com_subtree(torso)] in MuJoCo's convention (walker2d_env.py:28-33)
+    template <typename R> RL_HD static void observe(const R* s, R* o) {
+        R cz, cx, vz, vx;
+        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        write_obs(s, cx, cz, o);
+    }
+
+    template <typename R> RL_HD static void write_obs(const R* s, R cx, R cz, R* o) {
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+        o[9] = s[9]; o[10] = s[10]; o[11] = s[11];
+        RL_UNROLL
+        for (int i = 3; i < 9; ++i) {
+            o[i] = (R)walker::SIGN[i - 2] * s[i];
+            o[9 + i] = (R)walker::SIGN[i - 2] * s[9 + i];
+        }
+        o[18] = cx; o[19] = (R)0; o[20] = cz;
+    }
+
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+        R act[ACT], tau[WalkerModel::NB];
+        tau[0] = (R)0;
+        R ctrl_cost = (R)0;
+        RL_UNROLL
+        for (int k = 0; k < ACT; ++k) {
+            const R ub = (R)walker::GEAR[1 + k], lb = -ub;
+            R v = a[k];
+            if (normalize) v = rl_clamp(lb + (v + (R)1) * (R)0.5 * (ub - lb), lb, ub);
+            act[k] = rl_clamp(v, lb, ub);                        // action = clip(action, *bounds); ctrllimited motor
+            tau[1 + k] = (R)walker::SIGN[1 + k] * act[k];        // gear 1: torque = ctrl, about the MJCF axis
+            const R sc = act[k] / ((ub - lb) * (R)0.5);
+            ctrl_cost = ctrl_cost + sc * sc;
+        }
+        R q[9], qd[9];
+        RL_UNROLL
+        for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
+        R sn[WalkerModel::NB], cs[WalkerModel::NB];
+        Tree::template angles<R>(q, sn, cs);
+        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025, sn, cs);
+        RL_UNROLL
+        for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
+        R cz, cx, vz, vx;
+        Tree::template com<R>(q, qd, cz, cx, vz, vx);
+        write_obs(s, cx, cz, obs);
+        // reward = comvel_x - 0.5 * 1e-2 * sum((action / scaling)^2)      (walker2d_env.py:35-44)
+        reward = vx - (R)0.5 * (R)1e-2 * ctrl_cost;
+        // done = not (0.8 < qpos[0] < 2.0 and -1 < qpos[2] < 1)            (:46-48)
+        done = !(s[0] > (R)0.8 && s[0] < (R)2.0 && s[2] > (R)-1.0 && s[2] < (R)1.0);
+    }
+};
+
+}  // namespace rl

@@ -608,10 +608,12 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     NETCASE(6, 1, 32)    // DoublePendulum
     NETCASE(13, 2, 32)   // Swimmer
     NETCASE(20, 6, 32)   // HalfCheetah
+    NETCASE(21, 6, 32)   // Walker2D
     NETCASE(4, 1, 64)
     NETCASE(6, 1, 64)
     NETCASE(13, 2, 64)
     NETCASE(20, 6, 64)
+    NETCASE(21, 6, 64)
 #undef NETCASE
     return set_error(RL_ERR_UNSUPPORTED,
                      "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d); the torch autograd "

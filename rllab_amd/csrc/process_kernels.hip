@@ -25,7 +25,7 @@ namespace rl {
 
 constexpr int PS_EW = 32;   // envs per workgroup
 constexpr int PS_KB = 32;   // time chunks per workgroup
-constexpr int MAX_DO = 20;  // observation sizes the feature kernels are built for (2*Do+5 <= 64)
+constexpr int MAX_DO = 21;  // observation sizes the feature kernels are built for (2*Do+5 <= 64)
 
 // features of one sample, reference order: clip(o), clip(o)^2, al, al^2, al^3, 1 with al = t/100
 template <class F>

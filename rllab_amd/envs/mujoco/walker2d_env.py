@@ -1,0 +1,21 @@
+"""Walker2DEnv (API of rllab/envs/mujoco/walker2d_env.py:15-59); dynamics in csrc/dyn_walker.h
+(``rl::Walker2D``, a walker-style planar 7-body / 9-DoF biped built from the constants of
+vendor/mujoco_models/walker2d.xml)."""
+from rllab_amd import _lib
+from rllab_amd.core.serializable import Serializable
+from rllab_amd.envs.mujoco.mujoco_env import MujocoEnv
+
+
+class Walker2DEnv(MujocoEnv, Serializable):
+    FILE = 'walker2d.xml'
+    KIND = _lib.ENV_WALKER2D
+
+    def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
+        if ctrl_cost_coeff != 1e-2:
+            raise NotImplementedError("Walker2DEnv: ctrl_cost_coeff is compiled into the HIP kernel (1e-2)")
+        self.ctrl_cost_coeff = ctrl_cost_coeff
+        super(Walker2DEnv, self).__init__(*args, **kwargs)
+        Serializable.quick_init(self, locals())
+
+    def log_diagnostics(self, paths):
+        self._log_forward_progress(paths)

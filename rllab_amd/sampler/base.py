@@ -137,7 +137,7 @@ def process_dense(algo, itr, traj, log=True):
     B = T * N
     gamma, lam = float(algo.discount), float(algo.gae_lambda)
     baseline = algo.baseline
-    dense_lfb = hasattr(baseline, "dense_coeffs") and traj.obs_dim <= 20
+    dense_lfb = hasattr(baseline, "dense_coeffs") and traj.obs_dim <= 21
     preset_valid = traj.valid
     tin, valid, base = path_scan(traj, algo.whole_paths, baseline.dense_coeffs() if dense_lfb else None)
     if preset_valid is not None:          # batches packed from path lists carry their own padding mask

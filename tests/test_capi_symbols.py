@@ -34,6 +34,10 @@ def test_env_query_and_errors():
     assert _lib.env_query(_lib.ENV_HALF_CHEETAH) == dict(obs_dim=20, act_dim=6, state_dim=18, reset_draws=18,
                                                          reset_is_normal=True)
     assert _lib.env_query(_lib.ENV_CARTPOLE_SWINGUP) == _lib.env_query(_lib.ENV_CARTPOLE)
+    assert _lib.env_query(_lib.ENV_WALKER2D) == dict(obs_dim=21, act_dim=6, state_dim=18, reset_draws=18,
+                                                     reset_is_normal=True)
+    lb, ub = _lib.env_action_bounds(_lib.ENV_WALKER2D)
+    assert list(ub) == [150, 100, 100, 150, 100, 100] and list(lb) == [-150, -100, -100, -150, -100, -100]
     lb, ub = _lib.env_action_bounds(_lib.ENV_HALF_CHEETAH)
     assert list(lb) == [-1] * 6 and list(ub) == [1] * 6
     lb, ub = _lib.env_action_bounds(_lib.ENV_SWIMMER)

@@ -196,9 +196,10 @@ def test_cheetah_constants_header_is_generated_from_the_mjcf_numbers():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = os.path.join(root, "rllab_amd", "csrc", "cheetah_constants.h")
-    before = open(hdr).read()
-    subprocess.check_output([sys.executable, os.path.join(root, "rllab_amd", "csrc", "gen_cheetah_constants.py")])
-    assert open(hdr).read() == before
+    whdr = os.path.join(root, "rllab_amd", "csrc", "walker_constants.h")
+    before, wbefore = open(hdr).read(), open(whdr).read()
+    subprocess.check_output([sys.executable, os.path.join(root, "rllab_amd", "csrc", "gen_planar_constants.py")])
+    assert open(hdr).read() == before and open(whdr).read() == wbefore
     from oracle import np_cheetah as C
     masses = [float(x) for x in before.split("MASS[NB] = {")[1].split("}")[0].split(",")]
     inertias = [float(x) for x in before.split("INERTIA[NB] = {")[1].split("}")[0].split(",")]
@@ -279,3 +280,61 @@ def test_cartpole_swingup_contract():
     b.state[:] = a.state
     oa, _, _ = a.step([3.0]); ob, _, _ = b.step([3.0])
     assert np.array_equal(oa, ob)
+
+
+def test_walker_dynamics_vs_independent_lagrangian():
+    """Walker2D-style env: one env step (2 sub-steps) of the product's dynamics source, float64 host build,
+    equals the model-driven autodiff-Lagrangian oracle typed in from walker2d.xml in MuJoCo's coordinates
+    (hinges about -y, absolute root height) -- with feet on the floor (per-geom radius / friction), joints
+    beyond their range, dampers, armature, gravity and clipped torques; closed-form capsule mass properties of
+    walker_constants.h agree with the oracle's quadrature."""
+    import torch
+    from oracle import np_planar as P
+    rng = np.random.RandomState(0)
+    e = H.HostEnv(5, np.float64, normalize=True)
+    z = rng.randn(18)
+    o = e.reset(z)
+    qp, qv = P.walker_reset(z)
+    assert np.abs(e.state - P.walker_to_engine_state(qp, qv)).max() < 1e-15
+    assert np.abs(o - P.walker_observe(qp, qv)).max() < 1e-10
+    n_contact = 0
+    for trial in range(3):
+        qp = np.concatenate([[rng.uniform(1.12, 1.19)], rng.randn(1), rng.uniform(-.1, .1, 1), rng.uniform(-0.3, 0.2, 2),
+                             rng.uniform(-1, 1, 1), rng.uniform(-2.8, 0.1, 2), rng.uniform(-.3, .3, 1)])
+        qv = rng.randn(9) * 2
+        pts, _, rads, _ = P.WALKER.contact_points(torch.as_tensor(qp))
+        n_contact += int((pts[1::2].numpy() < np.array(rads)).sum())
+        e.state[:] = P.walker_to_engine_state(qp, qv)
+        a = rng.randn(6) * (1.0 if trial == 0 else 3.0)
+        o, r, d = e.step(a)
+        qp2, qv2, o2, r2, d2 = P.walker_step(qp, qv, a)
+        assert np.abs(e.state - P.walker_to_engine_state(qp2, qv2)).max() < 1e-8
+        assert np.abs(o - o2).max() < 1e-8 and abs(r - r2) < 1e-9 and d == d2
+    assert n_contact >= 2
+    hdr = open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
+        __import__("os").path.abspath(__file__))), "rllab_amd", "csrc", "walker_constants.h")).read()
+    masses = [float(x) for x in hdr.split("MASS[NB] = {")[1].split("}")[0].split(",")]
+    inertias = [float(x) for x in hdr.split("INERTIA[NB] = {")[1].split("}")[0].split(",")]
+    assert np.allclose(masses, [b[0] for b in P.WALKER.const], rtol=1e-9)
+    assert np.allclose(inertias, [b[1] for b in P.WALKER.const], rtol=1e-8)
+
+
+def test_walker_done_reward_and_f32_tracking():
+    rng = np.random.RandomState(3)
+    e32, e64 = H.HostEnv(5, np.float32, normalize=True), H.HostEnv(5, np.float64, normalize=True)
+    z = rng.randn(18).astype(np.float32)
+    e32.reset(z)
+    e64.reset(z.astype(np.float64))
+    for t in range(10):
+        a = (rng.randn(6) * 0.2).astype(np.float32)
+        o32, r32, d32 = e32.step(a)
+        o64, r64, d64 = e64.step(a.astype(np.float64))
+        assert np.abs(o32 - o64).max() < 2e-3 * max(1.0, np.abs(o64).max()) and abs(r32 - r64) < 2e-3 and d32 == d64, t
+    # a random policy falls: done = height outside (0.8, 2.0) or |pitch| >= 1 (walker2d_env.py:46-48)
+    d = False
+    for t in range(400):
+        o, r, d = e64.step(rng.randn(6))
+        if d:
+            break
+    assert d and not (0.8 < o[0] < 2.0 and -1.0 < o[2] < 1.0)
+    lb, ub = H.HostEnv(5, np.float64).q, None
