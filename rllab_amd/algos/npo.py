@@ -29,12 +29,20 @@ def npo_inputs(policy, samples_data):
             traj.advantages.reshape(B), traj.means.reshape(traj.act_dim, B), old_ls, w, (1.0 / cnt))
 
 
+def pick_optimizer(optimizer, optimizer_args, default_cls, **default_args):
+    """The optimizer an NPO variant runs with: the one handed in, else ``default_cls`` built from the
+    variant's defaults overridden by ``optimizer_args``."""
+    if optimizer is not None:
+        return optimizer
+    return default_cls(**dict(default_args, **(optimizer_args or {})))
+
+
 class NPO(BatchPolopt):
     def __init__(self, optimizer=None, optimizer_args=None, step_size=0.01,
                  truncate_local_is_ratio=None, **kwargs):
         if optimizer is None:
             from rllab_amd.optimizers.penalty_lbfgs_optimizer import PenaltyLbfgsOptimizer
-            optimizer = PenaltyLbfgsOptimizer(**(optimizer_args or dict()))   # reference default (npo.py:27-30)
+            optimizer = pick_optimizer(None, optimizer_args, PenaltyLbfgsOptimizer)   # reference default (npo.py:27-30)
         self.optimizer = optimizer
         self.step_size = step_size
         self.truncate_local_is_ratio = truncate_local_is_ratio

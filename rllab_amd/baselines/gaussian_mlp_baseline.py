@@ -16,39 +16,37 @@ class GaussianMLPBaseline(Baseline, Parameterized):
         Serializable.quick_init(self, locals())
         Baseline.__init__(self, env_spec)
         Parameterized.__init__(self)
-        if regressor_args is None:
-            regressor_args = dict()
-        self._regressor = GaussianMLPRegressor(
-            input_shape=(env_spec.observation_space.flat_dim * num_seq_inputs,), output_dim=1, name="vf",
-            **regressor_args)
+        obs_dim = env_spec.observation_space.flat_dim * num_seq_inputs
+        self._regressor = GaussianMLPRegressor(input_shape=(obs_dim,), output_dim=1, name="vf",
+                                               **(regressor_args or {}))
 
+    # -- per-path numpy face (reference semantics) -------------------------------------------------------
     def fit(self, paths):
-        if hasattr(paths, "traj"):
+        if hasattr(paths, "traj"):           # lazy PathList of a dense batch: stay on the device
             return self.fit_dense(paths.traj)
-        observations = np.concatenate([p["observations"] for p in paths])
-        returns = np.concatenate([p["returns"] for p in paths])
-        self._regressor.fit(observations, returns.reshape((-1, 1)))
+        xs = np.concatenate([p["observations"] for p in paths])
+        ys = np.concatenate([p["returns"] for p in paths])
+        self._regressor.fit(xs, ys[:, None])
 
     def predict(self, path):
-        return self._regressor.predict(path["observations"]).flatten()
+        return self._regressor.predict(path["observations"])[:, 0]
 
-    # -- dense device forms --------------------------------------------------------------------------------
+    # -- dense device face ------------------------------------------------------------------------------------
     def predict_dense(self, traj):
         """[T, N] float64 plane of value predictions."""
-        obs = traj.obs.reshape(traj.obs_dim, -1)
-        return self._regressor.predict_planes(obs).reshape(traj.T, traj.N).to(torch.float64)
+        values = self._regressor.predict_planes(traj.obs.reshape(traj.obs_dim, -1))
+        return values.reshape(traj.T, traj.N).to(torch.float64)
 
     def fit_dense(self, traj, all_reduce=None):
-        obs = traj.obs.reshape(traj.obs_dim, -1)
-        ret = traj.returns.reshape(1, -1)
-        w = traj.valid.reshape(-1) if traj.valid is not None else None
-        self._regressor.fit_planes(obs, ret, w)
+        weights = None if traj.valid is None else traj.valid.reshape(-1)
+        self._regressor.fit_planes(traj.obs.reshape(traj.obs_dim, -1), traj.returns.reshape(1, -1), weights)
+
+    # -- Parameterized: the regressor's parameters are the baseline's ---------------------------------------------
+    def get_params_internal(self, **tags):
+        return self._regressor.get_params_internal(**tags)
 
     def get_param_values(self, **tags):
         return self._regressor.get_param_values(**tags)
 
     def set_param_values(self, flattened_params, **tags):
         self._regressor.set_param_values(flattened_params, **tags)
-
-    def get_params_internal(self, **tags):
-        return self._regressor.get_params_internal(**tags)

@@ -1,49 +1,56 @@
-"""Constructor-argument pickling (mirrors rllab/core/serializable.py:5-65).
+"""Constructor-argument pickling (behaviour of rllab/core/serializable.py:5-65).
 
-An object records the arguments it was constructed with; pickling stores only
-those (``__args`` / ``__kwargs``) and unpickling re-runs the constructor.
+A ``Serializable`` object remembers the arguments it was built with; its pickle is just those arguments
+(``{"__args": ..., "__kwargs": ...}``) and unpickling runs the constructor again.  Classes opt in by
+calling ``Serializable.quick_init(self, locals())`` at the top of ``__init__`` (or
+``Serializable.__init__(self, *args, **kwargs)``).  ``Parameterized`` adds the flat parameter vector on top,
+which is the whole snapshot format of policies and baselines.
 """
 import inspect
 
 
+def _ctor_signature(obj):
+    spec = inspect.getfullargspec(obj.__init__)
+    return spec.args[1:], spec.varargs, spec.varkw          # positional names without `self`
+
+
 class Serializable(object):
     def __init__(self, *args, **kwargs):
-        self.__args = args
-        self.__kwargs = kwargs
+        self.__args, self.__kwargs = args, kwargs
 
     def quick_init(self, locals_):
-        """Capture ctor arguments from ``locals()`` (reference :11-34)."""
+        """Record the constructor call from the ``locals()`` of ``__init__``.  Only the first call counts:
+        a subclass's quick_init wins over the ones its bases issue later."""
         if getattr(self, "_serializable_initialized", False):
             return
-        spec = inspect.getfullargspec(self.__init__)
-        kwargs = locals_[spec.varkw] if spec.varkw else dict()
-        varargs = locals_[spec.varargs] if spec.varargs else tuple()
-        in_order_args = [locals_[arg] for arg in spec.args][1:]
-        self.__args = tuple(in_order_args) + tuple(varargs)
-        self.__kwargs = kwargs
-        setattr(self, "_serializable_initialized", True)
+        names, varargs, varkw = _ctor_signature(self)
+        positional = tuple(locals_[n] for n in names)
+        if varargs:
+            positional += tuple(locals_[varargs])
+        self.__args = positional
+        self.__kwargs = dict(locals_[varkw]) if varkw else dict()
+        self._serializable_initialized = True
 
     def __getstate__(self):
         return {"__args": self.__args, "__kwargs": self.__kwargs}
 
-    def __setstate__(self, d):
-        out = type(self)(*d["__args"], **d["__kwargs"])
-        self.__dict__.update(out.__dict__)
+    def __setstate__(self, state):
+        rebuilt = type(self)(*state["__args"], **state["__kwargs"])
+        self.__dict__.update(rebuilt.__dict__)
 
     @classmethod
-    def clone(cls, obj, **kwargs):
-        """Rebuild ``obj`` with some ctor arguments replaced (reference :44-65)."""
+    def clone(cls, obj, **overrides):
+        """A fresh object built like ``obj`` with some constructor arguments replaced."""
         assert isinstance(obj, Serializable)
-        d = obj.__getstate__()
-        spec = inspect.getfullargspec(obj.__init__)
-        in_order_args = spec.args[1:]
-        d["__args"] = list(d["__args"])
-        d["__kwargs"] = dict(d["__kwargs"])
-        for kw, val in kwargs.items():
-            if kw in in_order_args:
-                d["__args"][in_order_args.index(kw)] = val
+        state = dict(obj.__getstate__())          # subclasses may carry extra entries (e.g. running statistics)
+        args, kwargs = list(state["__args"]), dict(state["__kwargs"])
+        names, _, _ = _ctor_signature(obj)
+        for key, val in overrides.items():
+            if key in names:
+                args[names.index(key)] = val
             else:
-                d["__kwargs"][kw] = val
-        out = type(obj).__new__(type(obj))
-        out.__setstate__(d)
-        return out
+                kwargs[key] = val
+        twin = type(obj).__new__(type(obj))
+        state["__args"], state["__kwargs"] = tuple(args), kwargs
+        twin.__setstate__(state)
+        return twin

@@ -1,17 +1,17 @@
-"""EnvSpec (mirrors rllab/envs/env_spec.py:5-25)."""
+"""EnvSpec: the (observation space, action space) pair policies and baselines are built from
+(API of rllab/envs/env_spec.py:5-25)."""
 from rllab_amd.core.serializable import Serializable
 
 
 class EnvSpec(Serializable):
+    __slots__ = ()
+
     def __init__(self, observation_space, action_space):
         Serializable.quick_init(self, locals())
-        self._observation_space = observation_space
-        self._action_space = action_space
+        self._spaces = (observation_space, action_space)
 
-    @property
-    def observation_space(self):
-        return self._observation_space
+    observation_space = property(lambda self: self._spaces[0])
+    action_space = property(lambda self: self._spaces[1])
 
-    @property
-    def action_space(self):
-        return self._action_space
+    def __repr__(self):
+        return "EnvSpec(obs=%r, act=%r)" % self._spaces

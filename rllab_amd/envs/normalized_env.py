@@ -16,80 +16,88 @@ from rllab_amd.envs.proxy_env import ProxyEnv
 from rllab_amd.spaces.box import Box
 
 
+class _RunningMoments(object):
+    """Exponential moving estimates of mean and variance of a stream (the reference's
+    _update_*_estimate, normalized_env.py:33-49)."""
+
+    def __init__(self, shape, alpha):
+        self.alpha = alpha
+        self.mean = np.zeros(shape) if shape else 0.
+        self.var = np.ones(shape) if shape else 1.
+
+    def update(self, x):
+        a = self.alpha
+        self.mean = (1 - a) * self.mean + a * x
+        self.var = (1 - a) * self.var + a * np.square(x - self.mean)
+
+    @property
+    def std(self):
+        return np.sqrt(self.var) + 1e-8
+
+
+def unit_to_bounds(action, lb, ub):
+    """Map an action in [-1, 1]^n affinely onto [lb, ub] and clip (normalized_env.py:81-83)."""
+    return np.clip(lb + (np.asarray(action) + 1.) * 0.5 * (ub - lb), lb, ub)
+
+
 class NormalizedEnv(ProxyEnv, Serializable):
     def __init__(self, env, scale_reward=1., normalize_obs=False, normalize_reward=False,
                  obs_alpha=0.001, reward_alpha=0.001):
         Serializable.quick_init(self, locals())
         ProxyEnv.__init__(self, env)
         self._scale_reward = scale_reward
-        self._normalize_obs = normalize_obs
-        self._normalize_reward = normalize_reward
-        self._obs_alpha = obs_alpha
-        self._obs_mean = np.zeros(env.observation_space.flat_dim)
-        self._obs_var = np.ones(env.observation_space.flat_dim)
-        self._reward_alpha = reward_alpha
-        self._reward_mean = 0.
-        self._reward_var = 1.
+        self._normalize_obs, self._normalize_reward = normalize_obs, normalize_reward
+        self._obs_stats = _RunningMoments((env.observation_space.flat_dim,), obs_alpha)
+        self._reward_stats = _RunningMoments((), reward_alpha)
 
-    def _update_obs_estimate(self, obs):
-        flat_obs = self.wrapped_env.observation_space.flatten(obs)
-        a = self._obs_alpha
-        self._obs_mean = (1 - a) * self._obs_mean + a * flat_obs
-        self._obs_var = (1 - a) * self._obs_var + a * np.square(flat_obs - self._obs_mean)
+    # -- running normalisation (numpy path only) ---------------------------------------------------------
+    def _whiten_obs(self, obs):
+        self._obs_stats.update(self._wrapped_env.observation_space.flatten(obs))
+        return (obs - self._obs_stats.mean) / self._obs_stats.std
 
-    def _update_reward_estimate(self, reward):
-        a = self._reward_alpha
-        self._reward_mean = (1 - a) * self._reward_mean + a * reward
-        self._reward_var = (1 - a) * self._reward_var + a * np.square(reward - self._reward_mean)
-
-    def _apply_normalize_obs(self, obs):
-        self._update_obs_estimate(obs)
-        return (obs - self._obs_mean) / (np.sqrt(self._obs_var) + 1e-8)
-
-    def _apply_normalize_reward(self, reward):
-        self._update_reward_estimate(reward)
-        return reward / (np.sqrt(self._reward_var) + 1e-8)
-
-    def reset(self):
-        ret = self._wrapped_env.reset()
-        return self._apply_normalize_obs(ret) if self._normalize_obs else ret
+    def _rescale_reward(self, reward):
+        self._reward_stats.update(reward)
+        return reward / self._reward_stats.std
 
     def __getstate__(self):
         d = Serializable.__getstate__(self)
-        d["_obs_mean"] = self._obs_mean
-        d["_obs_var"] = self._obs_var
+        d["_obs_mean"], d["_obs_var"] = self._obs_stats.mean, self._obs_stats.var
         return d
 
     def __setstate__(self, d):
         Serializable.__setstate__(self, d)
-        self._obs_mean = d["_obs_mean"]
-        self._obs_var = d["_obs_var"]
+        self._obs_stats.mean, self._obs_stats.var = d["_obs_mean"], d["_obs_var"]
+
+    # -- Env interface -------------------------------------------------------------------------------------
+    def _inner_is_box(self):
+        return isinstance(self._wrapped_env.action_space, Box)
 
     @property
     def action_space(self):
-        if isinstance(self._wrapped_env.action_space, Box):
-            ub = np.ones(self._wrapped_env.action_space.shape)
-            return spaces.Box(-1 * ub, ub)
-        return self._wrapped_env.action_space
+        inner = self._wrapped_env.action_space
+        if self._inner_is_box():
+            ones = np.ones(inner.shape)
+            return spaces.Box(-ones, ones)
+        return inner
+
+    def reset(self):
+        obs = self._wrapped_env.reset()
+        return self._whiten_obs(obs) if self._normalize_obs else obs
 
     def step(self, action):
-        if isinstance(self._wrapped_env.action_space, Box):
-            lb, ub = self._wrapped_env.action_space.bounds
-            scaled_action = lb + (np.asarray(action) + 1.) * 0.5 * (ub - lb)
-            scaled_action = np.clip(scaled_action, lb, ub)
-        else:
-            scaled_action = action
-        next_obs, reward, done, info = self._wrapped_env.step(scaled_action)
+        if self._inner_is_box():
+            action = unit_to_bounds(action, *self._wrapped_env.action_space.bounds)
+        next_obs, reward, done, info = self._wrapped_env.step(action)
         if self._normalize_obs:
-            next_obs = self._apply_normalize_obs(next_obs)
+            next_obs = self._whiten_obs(next_obs)
         if self._normalize_reward:
-            reward = self._apply_normalize_reward(reward)
+            reward = self._rescale_reward(reward)
         return Step(next_obs, reward * self._scale_reward, done, **info)
 
     def __str__(self):
         return "Normalized: %s" % self._wrapped_env
 
-    # -- vectorised boundary --------------------------------------------------
+    # -- vectorised boundary: the affine action map and scale_reward are fused into the step kernels -------
     @property
     def vectorized(self):
         return bool(getattr(self._wrapped_env, "vectorized", False)) and \

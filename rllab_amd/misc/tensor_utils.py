@@ -1,56 +1,68 @@
-"""List-of-dicts <-> dict-of-arrays helpers (mirrors the functions of
-rllab/misc/tensor_utils.py:6-150 that sit on the sampler path).  These shuffle
-host-side containers for API users; the engine itself keeps trajectories as
-dense device planes and never calls them on the hot path."""
+"""Host-side container shuffling for API users: flat <-> shaped parameter lists, and the
+list-of-dicts <-> dict-of-arrays conversions of path data (API of rllab/misc/tensor_utils.py:6-150).
+Nested dicts are handled by one recursive mapper.  The engine keeps trajectories as dense device planes
+and never calls these on the hot path."""
 import numpy as np
 
 
+def _map_leaves(fn, tree):
+    """Apply ``fn`` to every non-dict leaf of a (possibly nested) dict."""
+    return {k: (_map_leaves(fn, v) if isinstance(v, dict) else fn(v)) for k, v in tree.items()}
+
+
+def _zip_leaves(fn, trees):
+    """Combine a list of identically-keyed nested dicts leaf by leaf: ``fn`` receives the list of leaves."""
+    first = trees[0]
+    return {k: (_zip_leaves(fn, [t[k] for t in trees]) if isinstance(first[k], dict) else fn([t[k] for t in trees]))
+            for k in first}
+
+
+# -- flat parameter vectors -----------------------------------------------------------------------
 def flatten_tensors(tensors):
-    if len(tensors) > 0:
-        return np.concatenate([np.reshape(x, [-1]) for x in tensors])
-    return np.asarray([])
+    tensors = list(tensors)
+    if not tensors:
+        return np.asarray([])
+    return np.concatenate([np.asarray(t).ravel() for t in tensors])
 
 
 def unflatten_tensors(flattened, tensor_shapes):
-    sizes = [int(np.prod(s)) for s in tensor_shapes]
-    indices = np.cumsum(sizes)[:-1]
-    return [np.reshape(chunk, shape) for chunk, shape in zip(np.split(flattened, indices), tensor_shapes)]
+    flattened = np.asarray(flattened)
+    out, start = [], 0
+    for shape in tensor_shapes:
+        n = int(np.prod(shape))
+        out.append(flattened[start:start + n].reshape(shape))
+        start += n
+    return out
 
 
+# -- padding --------------------------------------------------------------------------------------
 def pad_tensor(x, max_len, mode='zero'):
-    padding = np.zeros_like(x[0])
-    if mode == 'last':
-        padding = x[-1]
-    return np.concatenate([x, np.tile(padding, (max_len - len(x),) + (1,) * np.ndim(x[0]))])
+    x = np.asarray(x)
+    fill = x[-1] if mode == 'last' else np.zeros_like(x[0])
+    tail = np.broadcast_to(fill, (max_len - len(x),) + x.shape[1:])
+    return np.concatenate([x, tail])
 
 
 def pad_tensor_n(xs, max_len):
-    ret = np.zeros((len(xs), max_len) + xs[0].shape[1:], dtype=xs[0].dtype)
-    for idx, x in enumerate(xs):
-        ret[idx][:len(x)] = x
-    return ret
+    out = np.zeros((len(xs), max_len) + xs[0].shape[1:], dtype=xs[0].dtype)
+    for row, x in zip(out, xs):
+        row[:len(x)] = x
+    return out
 
 
 def pad_tensor_dict(tensor_dict, max_len, mode='zero'):
-    ret = dict()
-    for k, v in tensor_dict.items():
-        ret[k] = pad_tensor_dict(v, max_len, mode=mode) if isinstance(v, dict) else pad_tensor(v, max_len, mode=mode)
-    return ret
+    return _map_leaves(lambda v: pad_tensor(v, max_len, mode=mode), tensor_dict)
 
 
+# -- stacking / concatenating / splitting / truncating -----------------------------------------------
 def stack_tensor_list(tensor_list):
     return np.array(tensor_list)
 
 
 def stack_tensor_dict_list(tensor_dict_list):
-    ret = dict()
-    for k in list(tensor_dict_list[0].keys()):
-        example = tensor_dict_list[0][k]
-        if isinstance(example, dict):
-            ret[k] = stack_tensor_dict_list([x[k] for x in tensor_dict_list])
-        else:
-            ret[k] = stack_tensor_list([x[k] for x in tensor_dict_list])
-    return ret
+    if not tensor_dict_list:
+        return dict()
+    return _zip_leaves(stack_tensor_list, tensor_dict_list)
 
 
 def concat_tensor_list(tensor_list):
@@ -58,28 +70,16 @@ def concat_tensor_list(tensor_list):
 
 
 def concat_tensor_dict_list(tensor_dict_list):
-    ret = dict()
-    for k in list(tensor_dict_list[0].keys()):
-        example = tensor_dict_list[0][k]
-        if isinstance(example, dict):
-            ret[k] = concat_tensor_dict_list([x[k] for x in tensor_dict_list])
-        else:
-            ret[k] = concat_tensor_list([x[k] for x in tensor_dict_list])
-    return ret
+    return _zip_leaves(concat_tensor_list, tensor_dict_list)
 
 
 def split_tensor_dict_list(tensor_dict):
-    ret = None
-    for k in list(tensor_dict.keys()):
-        vals = tensor_dict[k]
-        if isinstance(vals, dict):
-            vals = split_tensor_dict_list(vals)
-        if ret is None:
-            ret = [{k: v} for v in vals]
-        else:
-            for v, cur in zip(vals, ret):
-                cur[k] = v
-    return ret
+    """dict of arrays (leading axis n) -> list of n dicts; ``None`` for an empty dict, as the reference."""
+    if not tensor_dict:
+        return None
+    columns = {k: (split_tensor_dict_list(v) if isinstance(v, dict) else v) for k, v in tensor_dict.items()}
+    n = len(next(iter(columns.values())))
+    return [{k: col[i] for k, col in columns.items()} for i in range(n)]
 
 
 def truncate_tensor_list(tensor_list, truncated_len):
@@ -87,7 +87,4 @@ def truncate_tensor_list(tensor_list, truncated_len):
 
 
 def truncate_tensor_dict(tensor_dict, truncated_len):
-    ret = dict()
-    for k, v in tensor_dict.items():
-        ret[k] = truncate_tensor_dict(v, truncated_len) if isinstance(v, dict) else truncate_tensor_list(v, truncated_len)
-    return ret
+    return _map_leaves(lambda v: v[:truncated_len], tensor_dict)

@@ -1,4 +1,5 @@
-"""Box space (mirrors rllab/spaces/box.py:8-77)."""
+"""Box: an axis-aligned box in R^n, possibly unbounded (API of rllab/spaces/box.py:8-77).
+``Box(low, high)`` takes two arrays of one shape, ``Box(lo, hi, shape)`` broadcasts two scalars."""
 import numpy as np
 
 from rllab_amd.spaces.base import Space
@@ -6,54 +7,50 @@ from rllab_amd.spaces.base import Space
 
 class Box(Space):
     def __init__(self, low, high, shape=None):
-        if shape is None:
-            low, high = np.asarray(low), np.asarray(high)
-            assert low.shape == high.shape
-            self.low, self.high = low, high
+        if shape is not None:
+            if not (np.isscalar(low) and np.isscalar(high)):
+                raise AssertionError("Box(low, high, shape): low / high must be scalars when a shape is given")
+            low, high = np.full(shape, low, dtype=np.float64), np.full(shape, high, dtype=np.float64)
         else:
-            assert np.isscalar(low) and np.isscalar(high)
-            self.low = low + np.zeros(shape)
-            self.high = high + np.zeros(shape)
+            low, high = np.asarray(low), np.asarray(high)
+            if low.shape != high.shape:
+                raise AssertionError("Box: low %s and high %s differ in shape" % (low.shape, high.shape))
+        self.low, self.high = low, high
+
+    # -- geometry -----------------------------------------------------------------------------------
+    shape = property(lambda self: self.low.shape)
+    bounds = property(lambda self: (self.low, self.high))
+    flat_dim = property(lambda self: int(np.prod(self.low.shape)))
 
     def sample(self):
-        return np.random.uniform(low=self.low, high=self.high, size=self.low.shape)
+        return np.random.uniform(low=self.low, high=self.high, size=self.shape)
 
     def contains(self, x):
         x = np.asarray(x)
-        return x.shape == self.shape and (x >= self.low).all() and (x <= self.high).all()
+        return x.shape == self.shape and bool(np.all((self.low <= x) & (x <= self.high)))
 
-    @property
-    def shape(self):
-        return self.low.shape
-
-    @property
-    def flat_dim(self):
-        return int(np.prod(self.low.shape))
-
-    @property
-    def bounds(self):
-        return self.low, self.high
-
+    # -- (un)flattening: one element, or a batch with the leading axis kept -----------------------------
     def flatten(self, x):
-        return np.asarray(x).flatten()
+        return np.asarray(x).reshape(-1)
 
     def unflatten(self, x):
         return np.asarray(x).reshape(self.shape)
 
     def flatten_n(self, xs):
         xs = np.asarray(xs)
-        return xs.reshape((xs.shape[0], -1))
+        return xs.reshape(len(xs), -1)
 
     def unflatten_n(self, xs):
         xs = np.asarray(xs)
-        return xs.reshape((xs.shape[0],) + self.shape)
+        return xs.reshape((len(xs),) + self.shape)
 
-    def __repr__(self):
-        return "Box" + str(self.shape)
-
+    # -- value semantics ------------------------------------------------------------------------------
     def __eq__(self, other):
-        return isinstance(other, Box) and np.allclose(self.low, other.low) and \
-            np.allclose(self.high, other.high)
+        return isinstance(other, Box) and self.shape == other.shape and \
+            np.allclose(self.low, other.low) and np.allclose(self.high, other.high)
 
     def __hash__(self):
         return hash((self.low.tobytes(), self.high.tobytes()))
+
+    def __repr__(self):
+        return "Box" + str(self.shape)
