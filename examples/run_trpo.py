@@ -29,6 +29,18 @@ def make_env(name):
     if name == "swimmer":
         from rllab.envs.mujoco.swimmer_env import SwimmerEnv
         return normalize(SwimmerEnv()), 500
+    if name == "half_cheetah":
+        from rllab.envs.mujoco.half_cheetah_env import HalfCheetahEnv
+        return normalize(HalfCheetahEnv()), 500
+    if name == "walker2d":
+        from rllab.envs.mujoco.walker2d_env import Walker2DEnv
+        return normalize(Walker2DEnv()), 500
+    if name == "double_pendulum":
+        from rllab.envs.box2d.double_pendulum_env import DoublePendulumEnv
+        return normalize(DoublePendulumEnv()), 100
+    if name == "cartpole_swingup":
+        from rllab.envs.box2d.cartpole_swingup_env import CartpoleSwingupEnv
+        return normalize(CartpoleSwingupEnv()), 500
     raise SystemExit("unknown env %r" % name)
 
 
@@ -40,13 +52,21 @@ def main():
     ap.add_argument("--n-itr", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--gae-lambda", type=float, default=1.0)
+    ap.add_argument("--csv", default=None, help="write the tabular log (one row per iteration) to this file")
+    ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
+    from rllab.misc import logger
+    if args.csv:
+        logger.add_tabular_output(args.csv)
+    if args.quiet:
+        logger.set_quiet(True)
     ext.set_seed(args.seed)
     env, horizon = make_env(args.env)
     policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(args.hidden, args.hidden))
     baseline = LinearFeatureBaseline(env_spec=env.spec)
     kw = dict(env=env, policy=policy, baseline=baseline, batch_size=args.n_envs * horizon,
-              max_path_length=horizon, n_itr=args.n_itr, discount=0.99,
+              max_path_length=horizon, n_itr=args.n_itr, discount=0.99, gae_lambda=args.gae_lambda,
               sampler_args=dict(n_envs=args.n_envs))
     algo = TRPO(step_size=0.01, **kw) if args.algo == "trpo" else VPG(**kw)
     algo.train()
