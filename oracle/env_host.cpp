@@ -18,6 +18,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <array>
+#include <vector>
+
 #include "../rllab_amd/csrc/envs.h"
 
 namespace {
@@ -156,4 +159,93 @@ void oracle_sincos_f32(int n, const float* x, float* s, float* c) {
     for (int i = 0; i < n; ++i) rl::rl_sincos(x[i], s[i], c[i]);
 }
 
+
+// ---- lock-step emulation of the four-lane ("quad") swimmer sub-step (rllab_amd/csrc/dyn_swimmer_chain.h) --------------
+// The quad program is a straight-line per-lane function whose only cross-lane operation is x.qp<CTRL>(v).  The
+// emulator runs it by replay: pass k executes every lane from the start, answers the first k exchange points from
+// the log of earlier passes and records point k; after as many passes as there are exchange points every lane's
+// result is exact.  Returns, for `nsub` sub-steps from the same (qpos, qvel, ctrl), the state of the scalar program
+// (out_scalar) and of the emulated quad program (out_quad): they must be bit-identical.
+}  // extern "C"
+
+namespace {
+template <typename R>
+struct ReplayCtx {
+    int lane, filled, counter;
+    std::vector<std::array<R, 4>>* log;
+    template <int CTRL> R qp(R v) {
+        const int k = counter++;
+        if (k < filled) return (*log)[k][(CTRL >> (2 * lane)) & 3];
+        if ((int)log->size() <= k) log->resize(k + 1);
+        if (k == filled) (*log)[k][lane] = v;
+        return v;   // beyond the recorded prefix: placeholder, this pass's result is discarded
+    }
+};
+
+template <typename R>
+void swim_compare(const R* state, const R* ctrl2, int nsub, R* out_scalar, R* out_quad) {
+    using Env = rl::Swimmer;
+    using Chain = Env::Chain;
+    const R h = (R)0.001;
+    R ctrl[3] = {(R)0, ctrl2[0], ctrl2[1]};
+    // scalar
+    {
+        R r4[4], th[3], om[3], sn[3], cs[3], q[5], qd[5];
+        Env::to_chain(state, state + 5, r4, th, om, sn, cs);
+        for (int it = 0; it < nsub; ++it) Chain::template substep_scalar<R>(r4, cs, sn, om, th, ctrl, h);
+        Env::from_chain(r4, th, om, q, qd);
+        for (int i = 0; i < 5; ++i) { out_scalar[i] = q[i]; out_scalar[5 + i] = qd[i]; }
+        for (int b = 0; b < 3; ++b) { out_scalar[10 + b] = sn[b]; out_scalar[13 + b] = cs[b]; }
+    }
+    // quad (emulated)
+    {
+        R r4[4], th[3], om[3], sn[3], cs[3];
+        Env::to_chain(state, state + 5, r4, th, om, sn, cs);
+        Chain::Lane<R> lanes[4];
+        Chain::LaneConst<R> consts[4];
+        for (int b = 0; b < 4; ++b) {
+            consts[b] = Chain::template lane_const<R>(b);
+            lanes[b].cs = b < 3 ? cs[b] : (R)1; lanes[b].sn = b < 3 ? sn[b] : (R)0;
+            lanes[b].om = b < 3 ? om[b] : (R)0; lanes[b].th = b < 3 ? th[b] : (R)0;
+            lanes[b].rx = r4[0]; lanes[b].ry = r4[1]; lanes[b].vx = r4[2]; lanes[b].vy = r4[3];
+        }
+        for (int it = 0; it < nsub; ++it) {
+            std::vector<std::array<R, 4>> log;
+            int n_points = -1;
+            Chain::Lane<R> result[4];
+            for (int pass = 0; n_points < 0 || pass <= n_points; ++pass) {
+                for (int b = 0; b < 4; ++b) {
+                    ReplayCtx<R> x{b, pass, 0, &log};
+                    Chain::Lane<R> s = lanes[b];
+                    Chain::template substep_quad<R>(x, consts[b], s, b < 3 ? ctrl[b] : (R)0, h);
+                    n_points = x.counter;
+                    result[b] = s;
+                }
+            }
+            for (int b = 0; b < 4; ++b) lanes[b] = result[b];
+        }
+        // back to (qpos, qvel) exactly as the rollout kernel does it
+        out_quad[0] = lanes[0].rx; out_quad[1] = lanes[0].ry; out_quad[5] = lanes[0].vx; out_quad[6] = lanes[0].vy;
+        for (int b = 0; b < 3; ++b) out_quad[2 + b] = lanes[b].th;
+        out_quad[7] = lanes[0].om;
+        out_quad[8] = lanes[1].om - lanes[0].om;
+        out_quad[9] = lanes[2].om - lanes[1].om;
+        for (int b = 0; b < 3; ++b) { out_quad[10 + b] = lanes[b].sn; out_quad[13 + b] = lanes[b].cs; }
+        // the replicated root translation must agree on every lane of the quad
+        for (int b = 1; b < 4; ++b)
+            if (!(lanes[b].rx == lanes[0].rx && lanes[b].ry == lanes[0].ry && lanes[b].vx == lanes[0].vx &&
+                  lanes[b].vy == lanes[0].vy)) out_quad[0] = out_quad[0] * (R)0 + (R)1e30;   // poison: caught by the test
+    }
+}
+}  // namespace
+
+extern "C" {
+int oracle_swim_quad_compare_f32(const float* state, const float* ctrl2, int nsub, float* out_scalar, float* out_quad) {
+    swim_compare<float>(state, ctrl2, nsub, out_scalar, out_quad);
+    return 0;
+}
+int oracle_swim_quad_compare_f64(const double* state, const double* ctrl2, int nsub, double* out_scalar, double* out_quad) {
+    swim_compare<double>(state, ctrl2, nsub, out_scalar, out_quad);
+    return 0;
+}
 }  // extern "C"

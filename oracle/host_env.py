@@ -127,3 +127,17 @@ def sincos_f32(x):
     s, c = np.zeros_like(x), np.zeros_like(x)
     lib.oracle_sincos_f32(x.size, x, s, c)
     return s, c
+
+
+lib.oracle_swim_quad_compare_f32.argtypes = [_f32p, _f32p, ctypes.c_int, _f32p, _f32p]
+lib.oracle_swim_quad_compare_f64.argtypes = [_f64p, _f64p, ctypes.c_int, _f64p, _f64p]
+
+
+def swim_quad_compare(state, ctrl, nsub, dtype=np.float32):
+    """(scalar, emulated-quad) results of ``nsub`` swimmer sub-steps from one state: 16 values each
+    (qpos 5, qvel 5, carried sin 3, cos 3)."""
+    dtype = np.dtype(dtype)
+    fn = lib.oracle_swim_quad_compare_f32 if dtype == np.float32 else lib.oracle_swim_quad_compare_f64
+    a, b = np.zeros(16, dtype), np.zeros(16, dtype)
+    fn(np.ascontiguousarray(state, dtype), np.ascontiguousarray(ctrl, dtype), int(nsub), a, b)
+    return a, b

@@ -23,6 +23,7 @@
 // State (10 reals per env): qpos[5] = x, y, torso angle, rot2, rot3; qvel[5].
 #pragma once
 #include "dyn_planar.h"
+#include "dyn_swimmer_chain.h"
 
 namespace rl {
 
@@ -89,6 +90,26 @@ struct Swimmer {
     static constexpr int KIND = 2;
     static constexpr int FRAME_SKIP = 50;
     using Tree = PlanarTree<SwimmerModel>;
+    using Chain = SwimChain<SwimmerModel>;
+
+    // (qpos, qvel) -> chain variables: absolute rates by prefix sums along the chain, exact sin / cos
+    template <typename R>
+    RL_HD static void to_chain(const R* q, const R* qd, R* r4, R* th, R* om, R* sn, R* cs) {
+        r4[0] = q[0]; r4[1] = q[1]; r4[2] = qd[0]; r4[3] = qd[1];
+        th[0] = q[2]; th[1] = q[3]; th[2] = q[4];
+        om[0] = qd[2];
+        om[1] = om[0] + qd[3];
+        om[2] = om[1] + qd[4];
+        Tree::template angles<R>(q, sn, cs);
+    }
+    template <typename R>
+    RL_HD static void from_chain(const R* r4, const R* th, const R* om, R* q, R* qd) {
+        q[0] = r4[0]; q[1] = r4[1]; qd[0] = r4[2]; qd[1] = r4[3];
+        q[2] = th[0]; q[3] = th[1]; q[4] = th[2];
+        qd[2] = om[0];
+        qd[3] = om[1] - om[0];
+        qd[4] = om[2] - om[1];
+    }
 
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
         lb[0] = (R)-50; lb[1] = (R)-50;
@@ -114,10 +135,13 @@ struct Swimmer {
         o[10] = cx; o[11] = cy; o[12] = (R)0;
     }
 
+    // Env.step in three parts, so that the fused rollout can run the sub-step loop on a lane group per env:
+    //   step_begin : NormalizedEnv action map + ctrl clamp           (normalized_env.py:78-92, ctrllimited motors)
+    //   sub-steps  : FRAME_SKIP x Chain::substep_*                   (mjcore.py:46-49 x frame_skip)
+    //   step_end   : observation, reward, done                       (swimmer_env.py:25-45)
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step_begin(const R* a, int normalize, R* act, R* ctrl) {
         const R lb = (R)-50, ub = (R)50;
-        R act[2], ctrl[3];
         ctrl[0] = (R)0;
         RL_UNROLL
         for (int k = 0; k < 2; ++k) {
@@ -129,16 +153,13 @@ struct Swimmer {
             act[k] = v;
             ctrl[1 + k] = rl_clamp(v, lb, ub);  // ctrllimited: MuJoCo clamps ctrl to ctrlrange
         }
-        R q[5], qd[5];
-        RL_UNROLL
-        for (int i = 0; i < 5; ++i) { q[i] = s[i]; qd[i] = s[5 + i]; }
-        R sn[3], cs[3];
-        Tree::template angles<R>(q, sn, cs);
-        for (int it = 0; it < FRAME_SKIP; ++it) Tree::template substep<R>(q, qd, ctrl, (R)0.001, sn, cs);
-        RL_UNROLL
-        for (int i = 0; i < 5; ++i) { s[i] = q[i]; s[5 + i] = qd[i]; }
+    }
+
+    template <typename R>
+    RL_HD static void step_end(const R* s, const R* act, R* obs, R& reward, bool& done) {
+        const R lb = (R)-50, ub = (R)50;
         R cx, cy, vx, vy;
-        Tree::template com<R>(q, qd, cx, cy, vx, vy);
+        Tree::template com<R>(s, s + 5, cx, cy, vx, vy);
         RL_UNROLL
         for (int i = 0; i < 10; ++i) obs[i] = s[i];
         obs[10] = cx; obs[11] = cy; obs[12] = (R)0;
@@ -148,6 +169,19 @@ struct Swimmer {
         const R ctrl_cost = (R)0.5 * (R)1e-2 * (a0 * a0 + a1 * a1);
         reward = vx - ctrl_cost;
         done = false;
+    }
+
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+        R act[2], ctrl[3];
+        step_begin(a, normalize, act, ctrl);
+        // 50 sub-steps in the chain program's variables (dyn_swimmer_chain.h): root translation, absolute body
+        // rates, joint angles, carried sin / cos of the absolute body angles
+        R r4[4], th[3], om[3], sn[3], cs[3];
+        to_chain(s, s + 5, r4, th, om, sn, cs);
+        for (int it = 0; it < FRAME_SKIP; ++it) Chain::template substep_scalar<R>(r4, cs, sn, om, th, ctrl, (R)0.001);
+        from_chain(r4, th, om, s, s + 5);
+        step_end(s, act, obs, reward, done);
     }
 };
 

@@ -1,0 +1,295 @@
+// dyn_swimmer_chain.h -- the sub-step of the 3-link swimmer chain, written twice with IDENTICAL expression trees:
+//
+//   swim_substep_scalar : one env per lane / host thread; the three bodies are unrolled in one instruction stream.
+//                         Used by the host oracle build, by the per-step VecEnv kernels and as the definition of the
+//                         env's arithmetic.
+//   swim_substep_quad   : four lanes per env (lane role b = body 0, 1, 2; lane 3 idles with zero constants).  Every
+//                         lane runs the same ~180-instruction stream on its own body, values cross lanes by
+//                         quad-permute moves, the 3x3 solve is replicated.  Used by the fused rollout, where a lone
+//                         wavefront per SIMD is bound by instruction issue: the per-env instruction stream shrinks
+//                         from ~260 to ~180 per sub-step and four times as many wavefronts share the work.
+//
+// Bit-exactness contract: every value the quad program computes is computed by the scalar program with the same
+// expression (same operands, same association, same statement boundaries -- the front-end contracts a*b+c only inside
+// one expression), apart from terms that are exactly +-0 (lane 3's contributions, masked exchanges), which the scalar
+// program omits; x + (+-0) == x for every non-zero x.  tests/ replay the quad program on the host (a lock-step emulator
+// of the four lanes) against the scalar program bit for bit, and the GPU rollout against the host build.
+//
+// Physics: dyn_planar.h's absolute-angle formulation (forward_dynamics_abs) for the collinear chain -- all As / Ss
+// coefficients vanish, the Schur complement of the translations is Sc_kl * cos(phi_l - phi_k) -- with the fluid model of
+// dyn_swimmer.h.  Integrated variables: root position / velocity, absolute body rates om_b, joint angles th_b
+// (th_0 = root angle) and the carried (sin, cos) of the absolute body angles.
+#pragma once
+#include "dyn_planar.h"
+
+namespace rl {
+
+template <class Mdl>
+struct SwimChain {
+    using Tree = PlanarTree<Mdl>;
+    static_assert(Mdl::NB == 3, "three-link chain");
+    static constexpr double INV_M = 1.0 / Tree::total_mass();
+    static constexpr double jxo(int b) { return b < 2 ? Mdl::jx(b + 1) : 0.0; }      // child joint offset along own x
+    static constexpr double cxb(int b) { return b < 3 ? Mdl::cx(b) : 0.0; }
+    static constexpr double db(int b) { return b < 3 ? Tree::Dvec(b).x : 0.0; }
+    static constexpr int pair_k(int p) { return p == 2 ? 1 : 0; }                    // pairs (0,1), (0,2), (1,2)
+    static constexpr int pair_l(int p) { return p == 0 ? 1 : 2; }
+    static constexpr double scp(int p) { return p < 3 ? Tree::Sc(pair_k(p), pair_l(p)) : 0.0; }
+    static constexpr double acp(int p) { return p < 3 ? Tree::Ac(pair_k(p), pair_l(p)) : 0.0; }
+    static constexpr double sdiag(int b) { return Tree::Sc(b, b) + Tree::Kc(b, b); }
+
+    // ---- leaf expressions shared verbatim by both programs -----------------------------------------------------
+    template <typename R>
+    RL_HD static void fluid(R cs, R sn, R vpx, R vpy, R om, R visc_lin, R drag_ax, R drag_perp, R visc_ang, R drag_ang,
+                            R& Fx, R& Fy, R& tz) {
+        const R vl = cs * vpx + sn * vpy;
+        const R vt = cs * vpy - sn * vpx;
+        const R fl = -(vl * (visc_lin + drag_ax * rl_abs(vl)));
+        const R ft = -(vt * (visc_lin + drag_perp * rl_abs(vt)));
+        Fx = cs * fl - sn * ft;
+        Fy = sn * fl + cs * ft;
+        tz = -(om * (visc_ang + drag_ang * rl_abs(om)));
+    }
+    // penalty joint-limit torque + actuation of one hinge
+    template <typename R>
+    RL_HD static R joint_torque(R th, R thd, R act) {
+        const R viol = th - rl_clamp(th, (R)Mdl::lo(1), (R)Mdl::hi(1));
+        const R damp = (viol != (R)0) ? (R)Mdl::limit_b() * thd : (R)0;
+        const R t = -((R)Mdl::limit_k() * viol) - damp;
+        return t + act;
+    }
+    template <typename R>
+    RL_HD static void pair_terms(R ck, R sk, R cl, R sl, R w2k, R w2l, R sc, R ac, R& Sp, R& cp, R& cm) {
+        const R cd = ck * cl + sk * sl;      // cos(phi_l - phi_k)
+        const R sd = sl * ck - cl * sk;      // sin(phi_l - phi_k)
+        Sp = sc * cd;
+        const R t = ac * sd;
+        cp = w2l * t;                        // rhs_k += cp
+        cm = w2k * t;                        // rhs_l -= cm
+    }
+    // symmetric 3x3 solve by the adjugate (one division)
+    template <typename R>
+    RL_HD static void solve3(R a, R bb, R c, R d, R e, R f, R r0, R r1, R r2, R& x0, R& x1, R& x2) {
+        const R A = d * f - e * e, B = c * e - bb * f, C = bb * e - c * d;
+        const R D = a * f - c * c, E = bb * c - a * e, F = a * d - bb * bb;
+        const R det = a * A + (bb * B + c * C);
+        const R inv = (R)1 / det;
+        x0 = (A * r0 + (B * r1 + C * r2)) * inv;
+        x1 = (B * r0 + (D * r1 + E * r2)) * inv;
+        x2 = (C * r0 + (E * r1 + F * r2)) * inv;
+    }
+
+    // ---- scalar program ---------------------------------------------------------------------------------------------
+    // r = [rx, ry, vx, vy]; per body b: cs, sn, om (absolute rate), th (th[0] = root angle, th[1..2] = hinge angles);
+    // act[b] = motor torque of hinge b (act[0] unused)
+    template <typename R>
+    RL_HD static void substep_scalar(R* r, R* cs, R* sn, R* om, R* th, const R* act, R h) {
+        const R VL = (R)Mdl::VISC_LIN, DAX = (R)Mdl::DRAG_AX, DPERP = (R)Mdl::DRAG_PERP, VA = (R)Mdl::VISC_ANG,
+                DANG = (R)Mdl::DRAG_ANG;
+        R lox[3], loy[3], wlx[3], wly[3], ex[3], ey[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            const R JXO = (R)jxo(b), CXB = (R)cxb(b);
+            lox[b] = cs[b] * JXO;
+            loy[b] = sn[b] * JXO;
+            wlx[b] = -(om[b] * loy[b]);
+            wly[b] = om[b] * lox[b];
+            ex[b] = cs[b] * CXB;
+            ey[b] = sn[b] * CXB;
+        }
+        R vax[3], vay[3];
+        vax[0] = r[2];                       vay[0] = r[3];
+        vax[1] = r[2] + wlx[0];              vay[1] = r[3] + wly[0];
+        vax[2] = (r[2] + wlx[1]) + wlx[0];   vay[2] = (r[3] + wly[1]) + wly[0];
+        R Fx[3], Fy[3], tz[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            const R vpx = vax[b] - om[b] * ey[b];
+            const R vpy = vay[b] + om[b] * ex[b];
+            fluid(cs[b], sn[b], vpx, vpy, om[b], VL, DAX, DPERP, VA, DANG, Fx[b], Fy[b], tz[b]);
+        }
+        R tau[3];
+        tau[0] = (R)0;
+        tau[1] = joint_torque(th[1], om[1] - om[0], act[1]);
+        tau[2] = joint_torque(th[2], om[2] - om[1], act[2]);
+        // subtree force sums and generalised forces on the absolute angles
+        R Fsx[3], Fsy[3], Q[3];
+        Fsx[2] = Fx[2];                      Fsy[2] = Fy[2];
+        Fsx[1] = Fx[1] + Fx[2];              Fsy[1] = Fy[1] + Fy[2];
+        Fsx[0] = (Fx[0] + Fx[1]) + Fx[2];    Fsy[0] = (Fy[0] + Fy[1]) + Fy[2];
+        Q[0] = (((ex[0] * Fy[0] - ey[0] * Fx[0]) + tz[0]) + (lox[0] * Fsy[1] - loy[0] * Fsx[1])) - tau[1];
+        Q[1] = (((ex[1] * Fy[1] - ey[1] * Fx[1]) + tz[1]) + (lox[1] * Fsy[2] - loy[1] * Fsx[2])) + (tau[1] - tau[2]);
+        Q[2] = ((ex[2] * Fy[2] - ey[2] * Fx[2]) + tz[2]) + tau[2];
+        // translation coupling and centripetal terms
+        R Gx[3], Gy[3], w2[3], wgx[3], wgy[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            const R DB = (R)db(b);
+            Gx[b] = cs[b] * DB;
+            Gy[b] = sn[b] * DB;
+            w2[b] = om[b] * om[b];
+            wgx[b] = w2[b] * Gx[b];
+            wgy[b] = w2[b] * Gy[b];
+        }
+        const R sgx = (wgx[0] + wgx[1]) + wgx[2];
+        const R sgy = (wgy[0] + wgy[1]) + wgy[2];
+        const R grx = (Fsx[0] + sgx) * (R)INV_M;
+        const R gry = (Fsy[0] + sgy) * (R)INV_M;
+        R bq[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) bq[b] = Q[b] - (Gx[b] * gry - Gy[b] * grx);
+        // pairs (0,1), (0,2), (1,2)
+        R Sp[3], cp[3], cm[3];
+        pair_terms(cs[0], sn[0], cs[1], sn[1], w2[0], w2[1], (R)scp(0), (R)acp(0), Sp[0], cp[0], cm[0]);
+        pair_terms(cs[0], sn[0], cs[2], sn[2], w2[0], w2[2], (R)scp(1), (R)acp(1), Sp[1], cp[1], cm[1]);
+        pair_terms(cs[1], sn[1], cs[2], sn[2], w2[1], w2[2], (R)scp(2), (R)acp(2), Sp[2], cp[2], cm[2]);
+        const R b0 = (bq[0] + cp[0]) + cp[1];
+        const R b1 = (bq[1] + (-cm[0])) + cp[2];
+        const R b2 = (bq[2] + (-cm[1])) + (-cm[2]);
+        R t0, t1, t2;
+        solve3((R)sdiag(0), Sp[0], Sp[1], (R)sdiag(1), Sp[2], (R)sdiag(2), b0, b1, b2, t0, t1, t2);
+        const R thb[3] = {t0, t1, t2};
+        // translations
+        R cxp[3], cyp[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            cxp[b] = -(Gy[b] * thb[b]);
+            cyp[b] = Gx[b] * thb[b];
+        }
+        const R sx = (cxp[0] + cxp[1]) + cxp[2];
+        const R sy = (cyp[0] + cyp[1]) + cyp[2];
+        const R ax = grx - sx * (R)INV_M;
+        const R ay = gry - sy * (R)INV_M;
+        r[2] = r[2] + h * ax;
+        r[3] = r[3] + h * ay;
+        r[0] = r[0] + h * r[2];
+        r[1] = r[1] + h * r[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) om[b] = om[b] + h * thb[b];
+        th[0] = th[0] + h * om[0];
+        th[1] = th[1] + h * (om[1] - om[0]);
+        th[2] = th[2] + h * (om[2] - om[1]);
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) rl_rotate_small(sn[b], cs[b], h * om[b]);
+    }
+
+    // ---- quad program ------------------------------------------------------------------------------------------------
+    // per-lane constants, selected by the lane's role b = lane & 3 (role 3: all zero)
+    template <typename R>
+    struct LaneConst {
+        R jxo, cxb, db, visc_lin, drag_ax, drag_perp, visc_ang, drag_ang;
+        R m1, m2, mj;        // 0/1 masks: b >= 1, b >= 2, b is a hinge (1 or 2)
+        R scp, acp;          // pair constants of pair p = b
+        int b;
+    };
+    template <typename R>
+    RL_HD static LaneConst<R> lane_const(int b) {
+        LaneConst<R> c;
+        c.b = b;
+        c.jxo = (R)(b == 0 ? jxo(0) : b == 1 ? jxo(1) : 0.0);
+        c.cxb = (R)(b == 0 ? cxb(0) : b == 1 ? cxb(1) : b == 2 ? cxb(2) : 0.0);
+        c.db = (R)(b == 0 ? db(0) : b == 1 ? db(1) : b == 2 ? db(2) : 0.0);
+        const bool body = b < 3;
+        c.visc_lin = body ? (R)Mdl::VISC_LIN : (R)0;
+        c.drag_ax = body ? (R)Mdl::DRAG_AX : (R)0;
+        c.drag_perp = body ? (R)Mdl::DRAG_PERP : (R)0;
+        c.visc_ang = body ? (R)Mdl::VISC_ANG : (R)0;
+        c.drag_ang = body ? (R)Mdl::DRAG_ANG : (R)0;
+        c.m1 = (b >= 1) ? (R)1 : (R)0;
+        c.m2 = (b >= 2) ? (R)1 : (R)0;
+        c.mj = (b == 1 || b == 2) ? (R)1 : (R)0;
+        c.scp = (R)(b == 0 ? scp(0) : b == 1 ? scp(1) : b == 2 ? scp(2) : 0.0);
+        c.acp = (R)(b == 0 ? acp(0) : b == 1 ? acp(1) : b == 2 ? acp(2) : 0.0);
+        return c;
+    }
+    template <typename R>
+    struct Lane {
+        R cs, sn, om, th;    // own body (role 3: cs = 1, everything else 0)
+        R rx, ry, vx, vy;    // root translation, replicated on the four lanes
+    };
+
+    // quad_perm controls: lane i of the quad reads lane P[i]
+    static constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+    static constexpr int SHR1 = QP(0, 0, 1, 2), SHR2 = QP(0, 0, 0, 1), SHL1 = QP(1, 2, 3, 3), SHL2 = QP(2, 3, 3, 3);
+    static constexpr int PK = QP(0, 0, 1, 1), PL = QP(1, 2, 2, 2);           // bodies k / l of pair p = lane
+    static constexpr int BC0 = QP(0, 0, 0, 0), BC1 = QP(1, 1, 1, 1), BC2 = QP(2, 2, 2, 2);
+    static constexpr int SW1 = QP(1, 0, 3, 2), SW2 = QP(2, 3, 0, 1);         // butterfly
+
+    template <typename R, class X>
+    RL_HD static R quad_sum(X& x, R v) {
+        const R v1 = v + x.template qp<SW1>(v);
+        return v1 + x.template qp<SW2>(v1);
+    }
+
+    // X: exchange context, x.template qp<CTRL>(v) = value of v in the lane selected by CTRL
+    template <typename R, class X>
+    RL_HD static void substep_quad(X& x, const LaneConst<R>& c, Lane<R>& s, R act, R h) {
+        const R lox = s.cs * c.jxo;
+        const R loy = s.sn * c.jxo;
+        const R wlx = -(s.om * loy);
+        const R wly = s.om * lox;
+        const R ex = s.cs * c.cxb;
+        const R ey = s.sn * c.cxb;
+        const R p1x = x.template qp<SHR1>(wlx), p1y = x.template qp<SHR1>(wly);
+        const R p2x = x.template qp<SHR2>(wlx), p2y = x.template qp<SHR2>(wly);
+        const R vax = (s.vx + c.m1 * p1x) + c.m2 * p2x;
+        const R vay = (s.vy + c.m1 * p1y) + c.m2 * p2y;
+        const R vpx = vax - s.om * ey;
+        const R vpy = vay + s.om * ex;
+        R Fx, Fy, tz;
+        fluid(s.cs, s.sn, vpx, vpy, s.om, c.visc_lin, c.drag_ax, c.drag_perp, c.visc_ang, c.drag_ang, Fx, Fy, tz);
+        const R omp = x.template qp<SHR1>(s.om);
+        const R tau = c.mj * joint_torque(s.th, s.om - c.m1 * omp, act);
+        const R taun = x.template qp<SHL1>(tau);
+        const R f1x = x.template qp<SHL1>(Fx), f1y = x.template qp<SHL1>(Fy);
+        const R f2x = x.template qp<SHL2>(Fx), f2y = x.template qp<SHL2>(Fy);
+        const R Fsx = (Fx + f1x) + f2x;
+        const R Fsy = (Fy + f1y) + f2y;
+        const R fnx = x.template qp<SHL1>(Fsx), fny = x.template qp<SHL1>(Fsy);
+        const R Q = (((ex * Fy - ey * Fx) + tz) + (lox * fny - loy * fnx)) + (tau - taun);
+        const R Gx = s.cs * c.db;
+        const R Gy = s.sn * c.db;
+        const R w2 = s.om * s.om;
+        const R wgx = w2 * Gx;
+        const R wgy = w2 * Gy;
+        const R sgx = quad_sum(x, wgx);
+        const R sgy = quad_sum(x, wgy);
+        const R fs0x = x.template qp<BC0>(Fsx), fs0y = x.template qp<BC0>(Fsy);
+        const R grx = (fs0x + sgx) * (R)INV_M;
+        const R gry = (fs0y + sgy) * (R)INV_M;
+        const R bq = Q - (Gx * gry - Gy * grx);
+        // pair p = lane
+        const R ck = x.template qp<PK>(s.cs), sk = x.template qp<PK>(s.sn);
+        const R cl = x.template qp<PL>(s.cs), sl = x.template qp<PL>(s.sn);
+        const R w2k = x.template qp<PK>(w2), w2l = x.template qp<PL>(w2);
+        R Sp, cp, cm;
+        pair_terms(ck, sk, cl, sl, w2k, w2l, c.scp, c.acp, Sp, cp, cm);
+        // body 0 collects +cp(0), +cp(1); body 1: -cm(0), +cp(2); body 2: -cm(1), -cm(2)
+        const R a1 = x.template qp<PK>(cp), a1m = x.template qp<PK>(cm);
+        const R a2 = x.template qp<PL>(cp), a2m = x.template qp<PL>(cm);
+        const R t1 = (c.b == 0) ? a1 : -a1m;
+        const R t2 = (c.b == 2) ? -a2m : a2;
+        const R bq2 = (bq + t1) + t2;
+        const R S10 = x.template qp<BC0>(Sp), S20 = x.template qp<BC1>(Sp), S21 = x.template qp<BC2>(Sp);
+        const R r0 = x.template qp<BC0>(bq2), r1 = x.template qp<BC1>(bq2), r2 = x.template qp<BC2>(bq2);
+        R t0_, t1_, t2_;
+        solve3((R)sdiag(0), S10, S20, (R)sdiag(1), S21, (R)sdiag(2), r0, r1, r2, t0_, t1_, t2_);
+        const R thb = (c.b == 0) ? t0_ : (c.b == 1) ? t1_ : (c.b == 2) ? t2_ : (R)0;
+        const R cxp = -(Gy * thb);
+        const R cyp = Gx * thb;
+        const R sx = quad_sum(x, cxp);
+        const R sy = quad_sum(x, cyp);
+        const R ax = grx - sx * (R)INV_M;
+        const R ay = gry - sy * (R)INV_M;
+        s.vx = s.vx + h * ax;
+        s.vy = s.vy + h * ay;
+        s.rx = s.rx + h * s.vx;
+        s.ry = s.ry + h * s.vy;
+        s.om = s.om + h * thb;
+        const R omp2 = x.template qp<SHR1>(s.om);
+        s.th = s.th + h * (s.om - c.m1 * omp2);
+        rl_rotate_small(s.sn, s.cs, h * s.om);
+    }
+};
+
+}  // namespace rl

@@ -7,6 +7,8 @@
 // Build with -ffp-contract=on (front-end contraction): the env arithmetic must match
 // the host oracle build bit for bit (rl_math.h); the policy MLP uses explicit FMAs.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
 #include "device_rng.h"
@@ -139,8 +141,15 @@ struct RolloutPolicy {
 
     __device__ __forceinline__ float log_std(int k) const { return tail[T_LS + k]; }
 
+    // Lane-group rollouts keep 16 envs per wavefront, replicated on lanes l and l + 16k: one block of 32
+    // "samples" (lanes 0..31) then covers every env and all four copies read the same result.
+    __device__ __forceinline__ void forward16(const float* o, float* mean) const { run<1>(o, mean); }
+
     // o: this lane's observation; mean: this lane's action mean
-    __device__ __forceinline__ void forward(const float* o, float* mean) const {
+    __device__ __forceinline__ void forward(const float* o, float* mean) const { run<2>(o, mean); }
+
+    template <int NBLK>
+    __device__ __forceinline__ void run(const float* o, float* mean) const {
         constexpr int DO = Env::OBS, DA = Env::ACT, HT = N::HT, KS0 = N::KS0, KS1 = N::KS1;
         const int lane = threadIdx.x, lj = lane & 31, lh = lane >> 5;
         wave_sync();                                          // the previous step's reads are done
@@ -148,7 +157,7 @@ struct RolloutPolicy {
         for (int d = 0; d < DO; ++d) xbuf[d * WV + lane] = o[d];
         wave_sync();
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NBLK; ++blk) {
             float xb[KS0];
 #pragma unroll
             for (int m = 0; m < KS0; ++m) xb[m] = xbuf[(2 * m + lh) * WV + 32 * blk + lj];
@@ -182,7 +191,7 @@ struct RolloutPolicy {
                     for (int r = 0; r < 16; ++r)
                         pm = __builtin_fmaf(h1[t][r], tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], pm);
                 const float mk = tail[T_B2 + k] + half_sum(pm);
-                if (lh == blk) mean[k] = mk;
+                if (NBLK == 1 || lh == blk) mean[k] = mk;
             }
         }
     }
@@ -286,6 +295,144 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Lane-group rollout of the Swimmer: 16 envs per wavefront.  Everything per env-step (policy on the matrix
+// cores, noise, action map, observation, reward, record, reset) runs env-per-lane exactly as in rollout_kernel
+// -- replicated on the four lanes l, l+16, l+32, l+48, which costs nothing: a lone wavefront is bound by its
+// instruction stream, not by lanes -- and only the 50 physics sub-steps switch to FOUR LANES PER ENV
+// (dyn_swimmer_chain.h: one body per lane, quad-permute DPP exchange, replicated 3x3 solve): ~180 instead of
+// ~280 instructions per sub-step, on four times as many wavefronts.
+// ---------------------------------------------------------------------------
+struct DppQuad {
+    template <int CTRL> __device__ __forceinline__ float qp(float v) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+    }
+};
+
+constexpr int QUAD_ENVS = 16;   // envs per wavefront
+
+template <int H>
+__global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev a) {
+    using Env = Swimmer;
+    using Chain = Env::Chain;
+    using Pol = RolloutPolicy<Env, H>;
+    __shared__ __attribute__((aligned(16))) float smem[Pol::LDS_FLOATS];
+    Pol pol;
+    pol.init(smem, a.theta);
+
+    const int n = a.n, T = a.T;
+    const int lane = threadIdx.x;
+    const int el = lane & (QUAD_ENVS - 1);            // env slot of this lane in the env-per-lane phases
+    const int i_raw = blockIdx.x * QUAD_ENVS + el;
+    const bool live = (i_raw < n) && (lane < QUAD_ENVS);   // one of the four copies stores
+    const int i = (i_raw < n) ? i_raw : n - 1;
+    const uint32_t env_global = (uint32_t)(a.env_offset + i);
+    const size_t plane = (size_t)T * n;
+    // lane-group phase: quad q_env = lane / 4 works on the env held by lane q_env, role b = lane % 4
+    const int q_src = lane >> 2, b = lane & 3;
+    const Chain::LaneConst<float> kc = Chain::lane_const<float>(b);
+    const DppQuad dpp;
+
+    float std_[Env::ACT];
+#pragma unroll
+    for (int k = 0; k < Env::ACT; ++k) std_[k] = __expf(fmaxf(pol.log_std(k), a.log_min_std));
+
+    float s[Env::STATE];
+    load_state<Env>(a.state, n, i, s);
+    int ts = a.ts[i];
+    const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
+    if (a.reset_at_start) {
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter);
+        ts = 0;
+    }
+    float o[Env::OBS];
+    Env::template observe<float>(s, o);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t off = (size_t)t * n + i;
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
+        }
+        float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
+        pol.forward16(o, mean);
+        if (a.eps) {
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
+        } else {
+            philox_draws<Env::ACT, true>(z, a.seed, env_global, a.step_counter + (uint64_t)t, RNG_POLICY);
+        }
+#pragma unroll
+        for (int k = 0; k < Env::ACT; ++k) {
+            act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
+            if (live) {
+                a.actions[k * plane + off] = act[k];
+                a.means[k * plane + off] = mean[k];
+            }
+        }
+
+        // ---- Env.step: begin (env per lane) -> 50 sub-steps (lane group per env) -> end (env per lane) ----
+        float eact[2], ctrl[3];
+        Env::template step_begin<float>(act, a.normalize, eact, ctrl);
+        {
+            // hand the env of lane q_src to its quad: each lane derives the variables of ITS body with the same
+            // expressions as Swimmer::to_chain
+            float g[12];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) g[k] = __shfl(s[k], q_src, BLOCK);
+            g[10] = __shfl(ctrl[1], q_src, BLOCK);
+            g[11] = __shfl(ctrl[2], q_src, BLOCK);
+            Chain::Lane<float> ls;
+            ls.rx = g[0]; ls.ry = g[1]; ls.vx = g[5]; ls.vy = g[6];
+            const float phi1 = g[2] + g[3], om1 = g[7] + g[8];
+            const float phi2 = phi1 + g[4], om2 = om1 + g[9];
+            const float phi = (b == 0) ? g[2] : (b == 1) ? phi1 : (b == 2) ? phi2 : 0.0f;
+            ls.om = (b == 0) ? g[7] : (b == 1) ? om1 : (b == 2) ? om2 : 0.0f;
+            ls.th = (b == 0) ? g[2] : (b == 1) ? g[3] : (b == 2) ? g[4] : 0.0f;
+            rl_sincos(phi, ls.sn, ls.cs);
+            const float lact = (b == 1) ? g[10] : (b == 2) ? g[11] : 0.0f;
+            for (int it = 0; it < Env::FRAME_SKIP; ++it)
+                Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
+            // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's)
+            const float qdj = ls.om - kc.m1 * dpp.template qp<Chain::SHR1>(ls.om);
+            const int base = 4 * el;
+            s[0] = __shfl(ls.rx, base, BLOCK);
+            s[1] = __shfl(ls.ry, base, BLOCK);
+            s[5] = __shfl(ls.vx, base, BLOCK);
+            s[6] = __shfl(ls.vy, base, BLOCK);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                s[2 + j] = __shfl(ls.th, base + j, BLOCK);
+                s[7 + j] = __shfl(qdj, base + j, BLOCK);
+            }
+        }
+        float r;
+        bool d;
+        Env::template step_end<float>(s, eact, o, r, d);
+
+        ts += 1;
+        if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
+        if (live) {
+            a.rewards[off] = r * a.scale_reward;
+            a.dones[off] = d ? 1 : 0;
+        }
+        if (d) {
+            const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1);
+            Env::template observe<float>(s, o);
+            ts = 0;
+        }
+    }
+    if (live) {
+        store_state<Env>(a.state, n, i, s);
+        a.ts[i] = ts;
+        if (a.last_obs) {
+#pragma unroll
+            for (int k = 0; k < Env::OBS; ++k) a.last_obs[(size_t)k * n + i] = o[k];
+        }
+    }
+}
+
 __global__ void philox_debug_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                     uint32_t k1, int count, uint32_t* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,6 +475,16 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     a.state = g->state; a.ts = g->ts; a.theta = g->theta; a.eps = g->eps; a.reset_draws = g->reset_draws;
     a.obs = g->obs; a.actions = g->actions; a.means = g->means; a.rewards = g->rewards; a.dones = g->dones;
     a.last_obs = g->last_obs;
+    if constexpr (std::is_same<Env, Swimmer>::value) {
+        // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
+        static const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;
+        if (!lane_kernel && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
+            dim3 qgrid((a.n + QUAD_ENVS - 1) / QUAD_ENVS);
+            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, dim3(BLOCK), 0, st, a);
+            else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), qgrid, dim3(BLOCK), 0, st, a);
+            return check_launch("rollout_swimmer_quad_kernel");
+        }
+    }
     dim3 grid((a.n + BLOCK - 1) / BLOCK);
     if (g->hidden0 == 32 && g->hidden1 == 32) {
         hipLaunchKernelGGL((rollout_kernel<Env, 32, 32>), grid, dim3(BLOCK), 0, st, a);

@@ -338,3 +338,21 @@ def test_walker_done_reward_and_f32_tracking():
             break
     assert d and not (0.8 < o[0] < 2.0 and -1.0 < o[2] < 1.0)
     lb, ub = H.HostEnv(5, np.float64).q, None
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("nsub", [1, 50])
+def test_swimmer_lane_group_program_is_bitwise_the_scalar_program(dtype, nsub):
+    """The four-lanes-per-env sub-step (dyn_swimmer_chain.h substep_quad, emulated on the host with an
+    array-backed quad permute) must reproduce the scalar program bit for bit: the GPU rollout runs the
+    lane-group program while vecenv_step / the host build run the scalar one."""
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        state = np.concatenate([rng.normal(0, 1.0, 2), rng.uniform(-np.pi, np.pi, 1),
+                                rng.uniform(-1.9, 1.9, 2),          # includes joints past the 100 deg limit
+                                rng.normal(0, 3.0, 5)])
+        ctrl = rng.uniform(-1, 1, 3)
+        ctrl[0] = 0.0
+        a, b = H.swim_quad_compare(state, ctrl, nsub, dtype)
+        assert np.all(np.isfinite(a))
+        assert a.tobytes() == b.tobytes(), (trial, a, b)
