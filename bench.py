@@ -204,7 +204,12 @@ def main():
         torch.cuda.synchronize()
         fvp_ms = e0.elapsed_time(e1) / 20
         ops.release()
-    n_waves = (n_envs + 63) // 64
+    lane_group = wl["env"] == "swimmer" and not os.environ.get("RLLAB_SWIMMER_LANE_KERNEL")
+    envs_per_wave = 16 if lane_group else 64
+    n_waves = (n_envs + envs_per_wave - 1) // envs_per_wave
+    rollout_name = ("rollout_swimmer_quad_kernel (fused policy + env step + record; 16 envs per wavefront, four "
+                    "lanes per env in the physics sub-steps)") if lane_group else \
+        "rollout_kernel (fused policy + env step + record; one env per lane)"
     out = {
         "metric": "env steps/sec over full TRPO iterations (sample + process + update), 4096 envs per MI355X",
         "value": value, "unit": "env_steps/s", "n_gpus": world, "steps": args.steps,
@@ -218,17 +223,18 @@ def main():
         "phase_ms": {k: v / args.steps for k, v in phase_ms.items()},
         "update_ms_and_backtracks_per_iteration": per_iter,
         "sampler_env_steps_per_s": world * n_envs * T / avg_rollout_s,
-        "roofline": {"kernel": "rollout_kernel (fused policy + env step + record)", "bound": "hbm",
+        "roofline": {"kernel": rollout_name, "bound": "hbm",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_rollout_s * 1e3,
                      "valu_tflops": wl["flops_per_step"] * n_envs * T / avg_rollout_s / 1e12,
                      "valu_peak_tflops": 157.3, "wavefronts": n_waves, "simds": 1024,
-                     "note": "issue-bound, not HBM-bound: one env per lane => %d wavefronts on 1024 SIMDs, each "
+                     "envs_per_wavefront": envs_per_wave,
+                     "note": "issue-bound, not HBM-bound: %d envs per wavefront => %d wavefronts on 1024 SIMDs, each "
                              "a single dependent instruction stream (physics sub-steps fused in registers); a lone "
                              "wavefront issues ~1 VALU op per 4.4 cycles (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = "
-                             "0.85), so launch time = instructions per env x 4.4 cycles x T and the HBM fraction is "
-                             "small by construction (SURVEY.md 8d, DESIGN.md 3.1)" % n_waves},
+                             "0.85), so launch time = instructions per wavefront x 4.4 cycles x T and the HBM fraction "
+                             "is small by construction (SURVEY.md 8d, DESIGN.md 3.1)" % (envs_per_wave, n_waves)},
     }
     if fvp_ms is not None:
         tiles = (n_envs * T + 31) // 32

@@ -51,7 +51,7 @@ def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=
 
     def pick(path, col):
         for r in csv.DictReader(open(path)):
-            if "rollout_kernel" in r["kernel"]:
+            if "rollout_" in r["kernel"]:
                 return float(r[col]) * 1024.0
         return None
     rd, wr = pick(fetch_csv, "mean_FETCH_SIZE"), pick(write_csv, "mean_WRITE_SIZE")
