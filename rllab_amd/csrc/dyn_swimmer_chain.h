@@ -32,11 +32,13 @@ struct SwimChain {
     static constexpr double jxo(int b) { return b < 2 ? Mdl::jx(b + 1) : 0.0; }      // child joint offset along own x
     static constexpr double cxb(int b) { return b < 3 ? Mdl::cx(b) : 0.0; }
     static constexpr double db(int b) { return b < 3 ? Tree::Dvec(b).x : 0.0; }
-    static constexpr int pair_k(int p) { return p == 2 ? 1 : 0; }                    // pairs (0,1), (0,2), (1,2)
-    static constexpr int pair_l(int p) { return p == 0 ? 1 : 2; }
-    static constexpr double scp(int p) { return p < 3 ? Tree::Sc(pair_k(p), pair_l(p)) : 0.0; }
-    static constexpr double acp(int p) { return p < 3 ? Tree::Ac(pair_k(p), pair_l(p)) : 0.0; }
+    // every body b couples to its two cyclic partners p = b + 1, q = b + 2 (mod 3); pair constants are symmetric
+    static constexpr int nxt(int b) { return (b + 1) % 3; }
+    static constexpr int nx2(int b) { return (b + 2) % 3; }
+    static constexpr double scc(int k, int l) { return k < l ? Tree::Sc(k, l) : Tree::Sc(l, k); }
+    static constexpr double acc(int k, int l) { return k < l ? Tree::Ac(k, l) : Tree::Ac(l, k); }
     static constexpr double sdiag(int b) { return Tree::Sc(b, b) + Tree::Kc(b, b); }
+    static constexpr double dpq(int b) { return sdiag(nxt(b)) * sdiag(nx2(b)); }
 
     // ---- leaf expressions shared verbatim by both programs -----------------------------------------------------
     template <typename R>
@@ -53,30 +55,31 @@ struct SwimChain {
     // penalty joint-limit torque + actuation of one hinge
     template <typename R>
     RL_HD static R joint_torque(R th, R thd, R act) {
-        const R viol = th - rl_clamp(th, (R)Mdl::lo(1), (R)Mdl::hi(1));
+        const R viol = th - rl_clamp_finite(th, (R)Mdl::lo(1), (R)Mdl::hi(1));
         const R damp = (viol != (R)0) ? (R)Mdl::limit_b() * thd : (R)0;
         const R t = -((R)Mdl::limit_k() * viol) - damp;
         return t + act;
     }
+    // coupling of body b (cb, sb) to a partner x (cx, sx):  S = Sc_bx cos(phi_x - phi_b)  (bitwise symmetric in b <-> x:
+    // the product and the fused product commute),  t = Ac_bx sin(phi_x - phi_b)  (rhs_b += w_x^2 t)
     template <typename R>
-    RL_HD static void pair_terms(R ck, R sk, R cl, R sl, R w2k, R w2l, R sc, R ac, R& Sp, R& cp, R& cm) {
-        const R cd = ck * cl + sk * sl;      // cos(phi_l - phi_k)
-        const R sd = sl * ck - cl * sk;      // sin(phi_l - phi_k)
-        Sp = sc * cd;
-        const R t = ac * sd;
-        cp = w2l * t;                        // rhs_k += cp
-        cm = w2k * t;                        // rhs_l -= cm
+    RL_HD static void couple(R cb, R sb, R cx, R sx, R sc, R ac, R& S, R& t) {
+        const R cd = cb * cx + sb * sx;
+        const R sd = sx * cb - cx * sb;
+        S = sc * cd;
+        t = ac * sd;
     }
-    // symmetric 3x3 solve by the adjugate (one division)
+    // row b of the symmetric 3x3 solve in the cyclic order (b, p, q): cofactors of row b are the cross product of rows
+    // p and q, every body divides by its own expansion of the determinant (equal up to rounding), so the four-lane
+    // program needs no replicated adjugate:  x_b = cof . (r_b, r_p, r_q) / (row_b . cof)
     template <typename R>
-    RL_HD static void solve3(R a, R bb, R c, R d, R e, R f, R r0, R r1, R r2, R& x0, R& x1, R& x2) {
-        const R A = d * f - e * e, B = c * e - bb * f, C = bb * e - c * d;
-        const R D = a * f - c * c, E = bb * c - a * e, F = a * d - bb * bb;
-        const R det = a * A + (bb * B + c * C);
-        const R inv = (R)1 / det;
-        x0 = (A * r0 + (B * r1 + C * r2)) * inv;
-        x1 = (B * r0 + (D * r1 + E * r2)) * inv;
-        x2 = (C * r0 + (E * r1 + F * r2)) * inv;
+    RL_HD static R solve_row(R d_b, R d_pq, R d_p, R d_q, R Sbp, R Sbq, R Spq, R rb, R rp, R rq) {
+        const R c0 = d_pq - Spq * Spq;
+        const R c1 = Spq * Sbq - Sbp * d_q;
+        const R c2 = Sbp * Spq - d_p * Sbq;
+        const R det = d_b * c0 + (Sbp * c1 + Sbq * c2);
+        const R num = c0 * rb + (c1 * rp + c2 * rq);
+        return num / det;
     }
 
     // ---- scalar program ---------------------------------------------------------------------------------------------
@@ -138,17 +141,23 @@ struct SwimChain {
         R bq[3];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) bq[b] = Q[b] - (Gx[b] * gry - Gy[b] * grx);
-        // pairs (0,1), (0,2), (1,2)
-        R Sp[3], cp[3], cm[3];
-        pair_terms(cs[0], sn[0], cs[1], sn[1], w2[0], w2[1], (R)scp(0), (R)acp(0), Sp[0], cp[0], cm[0]);
-        pair_terms(cs[0], sn[0], cs[2], sn[2], w2[0], w2[2], (R)scp(1), (R)acp(1), Sp[1], cp[1], cm[1]);
-        pair_terms(cs[1], sn[1], cs[2], sn[2], w2[1], w2[2], (R)scp(2), (R)acp(2), Sp[2], cp[2], cm[2]);
-        const R b0 = (bq[0] + cp[0]) + cp[1];
-        const R b1 = (bq[1] + (-cm[0])) + cp[2];
-        const R b2 = (bq[2] + (-cm[1])) + (-cm[2]);
-        R t0, t1, t2;
-        solve3((R)sdiag(0), Sp[0], Sp[1], (R)sdiag(1), Sp[2], (R)sdiag(2), b0, b1, b2, t0, t1, t2);
-        const R thb[3] = {t0, t1, t2};
+        // coupling to the cyclic partners and the rows of the 3x3 solve
+        R Sbp[3], Sbq[3], rb[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            const int p = nxt(b), q = nx2(b);
+            R tp, tq;
+            couple(cs[b], sn[b], cs[p], sn[p], (R)scc(b, p), (R)acc(b, p), Sbp[b], tp);
+            couple(cs[b], sn[b], cs[q], sn[q], (R)scc(b, q), (R)acc(b, q), Sbq[b], tq);
+            rb[b] = (bq[b] + w2[p] * tp) + w2[q] * tq;
+        }
+        R thb[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            const int p = nxt(b), q = nx2(b);
+            thb[b] = solve_row((R)sdiag(b), (R)dpq(b), (R)sdiag(p), (R)sdiag(q), Sbp[b], Sbq[b], Sbp[p], rb[b], rb[p],
+                               rb[q]);
+        }
         // translations
         R cxp[3], cyp[3];
         RL_UNROLL
@@ -179,7 +188,8 @@ struct SwimChain {
     struct LaneConst {
         R jxo, cxb, db, visc_lin, drag_ax, drag_perp, visc_ang, drag_ang;
         R m1, m2, mj;        // 0/1 masks: b >= 1, b >= 2, b is a hinge (1 or 2)
-        R scp, acp;          // pair constants of pair p = b
+        R scp, acp, scq, acq;        // coupling constants to the partners p = b + 1, q = b + 2 (mod 3)
+        R d_b, d_pq, d_p, d_q;       // diagonal of the 3x3 system in the cyclic order (role 3: identity)
         int b;
     };
     template <typename R>
@@ -198,8 +208,14 @@ struct SwimChain {
         c.m1 = (b >= 1) ? (R)1 : (R)0;
         c.m2 = (b >= 2) ? (R)1 : (R)0;
         c.mj = (b == 1 || b == 2) ? (R)1 : (R)0;
-        c.scp = (R)(b == 0 ? scp(0) : b == 1 ? scp(1) : b == 2 ? scp(2) : 0.0);
-        c.acp = (R)(b == 0 ? acp(0) : b == 1 ? acp(1) : b == 2 ? acp(2) : 0.0);
+        c.scp = (R)(b == 0 ? scc(0, 1) : b == 1 ? scc(1, 2) : b == 2 ? scc(2, 0) : 0.0);
+        c.acp = (R)(b == 0 ? acc(0, 1) : b == 1 ? acc(1, 2) : b == 2 ? acc(2, 0) : 0.0);
+        c.scq = (R)(b == 0 ? scc(0, 2) : b == 1 ? scc(1, 0) : b == 2 ? scc(2, 1) : 0.0);
+        c.acq = (R)(b == 0 ? acc(0, 2) : b == 1 ? acc(1, 0) : b == 2 ? acc(2, 1) : 0.0);
+        c.d_b = (R)(b == 0 ? sdiag(0) : b == 1 ? sdiag(1) : b == 2 ? sdiag(2) : 1.0);
+        c.d_pq = (R)(b == 0 ? dpq(0) : b == 1 ? dpq(1) : b == 2 ? dpq(2) : 1.0);
+        c.d_p = (R)(b == 0 ? sdiag(1) : b == 1 ? sdiag(2) : b == 2 ? sdiag(0) : 0.0);
+        c.d_q = (R)(b == 0 ? sdiag(2) : b == 1 ? sdiag(0) : b == 2 ? sdiag(1) : 0.0);
         return c;
     }
     template <typename R>
@@ -211,8 +227,8 @@ struct SwimChain {
     // quad_perm controls: lane i of the quad reads lane P[i]
     static constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
     static constexpr int SHR1 = QP(0, 0, 1, 2), SHR2 = QP(0, 0, 0, 1), SHL1 = QP(1, 2, 3, 3), SHL2 = QP(2, 3, 3, 3);
-    static constexpr int PK = QP(0, 0, 1, 1), PL = QP(1, 2, 2, 2);           // bodies k / l of pair p = lane
-    static constexpr int BC0 = QP(0, 0, 0, 0), BC1 = QP(1, 1, 1, 1), BC2 = QP(2, 2, 2, 2);
+    static constexpr int NX1 = QP(1, 2, 0, 3), NX2 = QP(2, 0, 1, 3);         // cyclic partners p, q of body = lane
+    static constexpr int BC0 = QP(0, 0, 0, 0);
     static constexpr int SW1 = QP(1, 0, 3, 2), SW2 = QP(2, 3, 0, 1);         // butterfly
 
     template <typename R, class X>
@@ -258,23 +274,16 @@ struct SwimChain {
         const R grx = (fs0x + sgx) * (R)INV_M;
         const R gry = (fs0y + sgy) * (R)INV_M;
         const R bq = Q - (Gx * gry - Gy * grx);
-        // pair p = lane
-        const R ck = x.template qp<PK>(s.cs), sk = x.template qp<PK>(s.sn);
-        const R cl = x.template qp<PL>(s.cs), sl = x.template qp<PL>(s.sn);
-        const R w2k = x.template qp<PK>(w2), w2l = x.template qp<PL>(w2);
-        R Sp, cp, cm;
-        pair_terms(ck, sk, cl, sl, w2k, w2l, c.scp, c.acp, Sp, cp, cm);
-        // body 0 collects +cp(0), +cp(1); body 1: -cm(0), +cp(2); body 2: -cm(1), -cm(2)
-        const R a1 = x.template qp<PK>(cp), a1m = x.template qp<PK>(cm);
-        const R a2 = x.template qp<PL>(cp), a2m = x.template qp<PL>(cm);
-        const R t1 = (c.b == 0) ? a1 : -a1m;
-        const R t2 = (c.b == 2) ? -a2m : a2;
-        const R bq2 = (bq + t1) + t2;
-        const R S10 = x.template qp<BC0>(Sp), S20 = x.template qp<BC1>(Sp), S21 = x.template qp<BC2>(Sp);
-        const R r0 = x.template qp<BC0>(bq2), r1 = x.template qp<BC1>(bq2), r2 = x.template qp<BC2>(bq2);
-        R t0_, t1_, t2_;
-        solve3((R)sdiag(0), S10, S20, (R)sdiag(1), S21, (R)sdiag(2), r0, r1, r2, t0_, t1_, t2_);
-        const R thb = (c.b == 0) ? t0_ : (c.b == 1) ? t1_ : (c.b == 2) ? t2_ : (R)0;
+        // coupling to the cyclic partners, own row of the solve
+        const R cp_ = x.template qp<NX1>(s.cs), sp_ = x.template qp<NX1>(s.sn), w2p = x.template qp<NX1>(w2);
+        const R cq_ = x.template qp<NX2>(s.cs), sq_ = x.template qp<NX2>(s.sn), w2q = x.template qp<NX2>(w2);
+        R Sbp, Sbq, tp, tq;
+        couple(s.cs, s.sn, cp_, sp_, c.scp, c.acp, Sbp, tp);
+        couple(s.cs, s.sn, cq_, sq_, c.scq, c.acq, Sbq, tq);
+        const R rb = (bq + w2p * tp) + w2q * tq;
+        const R Spq = x.template qp<NX1>(Sbp);
+        const R rp = x.template qp<NX1>(rb), rq = x.template qp<NX2>(rb);
+        const R thb = solve_row(c.d_b, c.d_pq, c.d_p, c.d_q, Sbp, Sbq, Spq, rb, rp, rq);
         const R cxp = -(Gy * thb);
         const R cyp = Gx * thb;
         const R sx = quad_sum(x, cxp);

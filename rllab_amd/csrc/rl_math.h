@@ -35,6 +35,16 @@ RL_HD double rl_abs(double x) { return __builtin_fabs(x); }
 template <typename R> RL_HD R rl_min(R a, R b) { return a < b ? a : b; }
 template <typename R> RL_HD R rl_max(R a, R b) { return a > b ? a : b; }
 template <typename R> RL_HD R rl_clamp(R x, R lo, R hi) { return rl_max(lo, rl_min(x, hi)); }
+// clamp of a finite x to [lo, hi] with lo < hi: one v_med3_f32 on the device; returns one of its arguments, so the
+// host form is bit-identical
+RL_HD float rl_clamp_finite(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return x < lo ? lo : (x > hi ? hi : x);
+#endif
+}
+RL_HD double rl_clamp_finite(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // Deterministic single-precision sin/cos.  Cody-Waite three-term reduction by
 // pi/4 followed by degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]
