@@ -235,6 +235,8 @@ void swim_compare(const R* state, const R* ctrl2, int nsub, R* out_scalar, R* ou
         for (int b = 1; b < 4; ++b)
             if (!(lanes[b].rx == lanes[0].rx && lanes[b].ry == lanes[0].ry && lanes[b].vx == lanes[0].vx &&
                   lanes[b].vy == lanes[0].vy)) out_quad[0] = out_quad[0] * (R)0 + (R)1e30;   // poison: caught by the test
+        // role 3 is the zero lane the bodies read "no parent" / "no child" from
+        if (!(lanes[3].om == (R)0)) out_quad[0] = out_quad[0] * (R)0 + (R)1e30;
     }
 }
 }  // namespace

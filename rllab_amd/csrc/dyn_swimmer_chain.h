@@ -43,7 +43,7 @@ struct SwimChain {
     // ---- leaf expressions shared verbatim by both programs -----------------------------------------------------
     template <typename R>
     RL_HD static void fluid(R cs, R sn, R vpx, R vpy, R om, R visc_lin, R drag_ax, R drag_perp, R visc_ang, R drag_ang,
-                            R& Fx, R& Fy, R& tz) {
+                            R& Fx, R& Fy, R& tz, R& ft_out) {
         const R vl = cs * vpx + sn * vpy;
         const R vt = cs * vpy - sn * vpx;
         const R fl = -(vl * (visc_lin + drag_ax * rl_abs(vl)));
@@ -51,13 +51,14 @@ struct SwimChain {
         Fx = cs * fl - sn * ft;
         Fy = sn * fl + cs * ft;
         tz = -(om * (visc_ang + drag_ang * rl_abs(om)));
+        ft_out = ft;      // moment of the fluid force about the body origin = cx_b * ft (the axial part has no arm)
     }
     // penalty joint-limit torque + actuation of one hinge
     template <typename R>
-    RL_HD static R joint_torque(R th, R thd, R act) {
+    RL_HD static R joint_torque(R th, R thd, R act, R lim_k, R lim_b) {
         const R viol = th - rl_clamp_finite(th, (R)Mdl::lo(1), (R)Mdl::hi(1));
-        const R damp = (viol != (R)0) ? (R)Mdl::limit_b() * thd : (R)0;
-        const R t = -((R)Mdl::limit_k() * viol) - damp;
+        const R damp = (viol != (R)0) ? lim_b * thd : (R)0;
+        const R t = -(lim_k * viol) - damp;
         return t + act;
     }
     // coupling of body b (cb, sb) to a partner x (cx, sx):  S = Sc_bx cos(phi_x - phi_b)  (bitwise symmetric in b <-> x:
@@ -79,7 +80,7 @@ struct SwimChain {
         const R c2 = Sbp * Spq - d_p * Sbq;
         const R det = d_b * c0 + (Sbp * c1 + Sbq * c2);
         const R num = c0 * rb + (c1 * rp + c2 * rq);
-        return num / det;
+        return rl_div_normal(num, det);
     }
 
     // ---- scalar program ---------------------------------------------------------------------------------------------
@@ -89,40 +90,38 @@ struct SwimChain {
     RL_HD static void substep_scalar(R* r, R* cs, R* sn, R* om, R* th, const R* act, R h) {
         const R VL = (R)Mdl::VISC_LIN, DAX = (R)Mdl::DRAG_AX, DPERP = (R)Mdl::DRAG_PERP, VA = (R)Mdl::VISC_ANG,
                 DANG = (R)Mdl::DRAG_ANG;
-        R lox[3], loy[3], wlx[3], wly[3], ex[3], ey[3];
+        const R LK = (R)Mdl::limit_k(), LB = (R)Mdl::limit_b();
+        R osn[3], ocs[3], wlx[3], wly[3];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) {
-            const R JXO = (R)jxo(b), CXB = (R)cxb(b);
-            lox[b] = cs[b] * JXO;
-            loy[b] = sn[b] * JXO;
-            wlx[b] = -(om[b] * loy[b]);
-            wly[b] = om[b] * lox[b];
-            ex[b] = cs[b] * CXB;
-            ey[b] = sn[b] * CXB;
+            osn[b] = om[b] * sn[b];
+            ocs[b] = om[b] * cs[b];
+            wlx[b] = -(osn[b] * (R)jxo(b));
+            wly[b] = ocs[b] * (R)jxo(b);
         }
         R vax[3], vay[3];
         vax[0] = r[2];                       vay[0] = r[3];
         vax[1] = r[2] + wlx[0];              vay[1] = r[3] + wly[0];
         vax[2] = (r[2] + wlx[1]) + wlx[0];   vay[2] = (r[3] + wly[1]) + wly[0];
-        R Fx[3], Fy[3], tz[3];
+        R Fx[3], Fy[3], tz[3], ft[3];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) {
-            const R vpx = vax[b] - om[b] * ey[b];
-            const R vpy = vay[b] + om[b] * ex[b];
-            fluid(cs[b], sn[b], vpx, vpy, om[b], VL, DAX, DPERP, VA, DANG, Fx[b], Fy[b], tz[b]);
+            const R vpx = vax[b] - osn[b] * (R)cxb(b);
+            const R vpy = vay[b] + ocs[b] * (R)cxb(b);
+            fluid(cs[b], sn[b], vpx, vpy, om[b], VL, DAX, DPERP, VA, DANG, Fx[b], Fy[b], tz[b], ft[b]);
         }
         R tau[3];
         tau[0] = (R)0;
-        tau[1] = joint_torque(th[1], om[1] - om[0], act[1]);
-        tau[2] = joint_torque(th[2], om[2] - om[1], act[2]);
+        tau[1] = joint_torque(th[1], om[1] - om[0], act[1], LK, LB);
+        tau[2] = joint_torque(th[2], om[2] - om[1], act[2], LK, LB);
         // subtree force sums and generalised forces on the absolute angles
         R Fsx[3], Fsy[3], Q[3];
         Fsx[2] = Fx[2];                      Fsy[2] = Fy[2];
         Fsx[1] = Fx[1] + Fx[2];              Fsy[1] = Fy[1] + Fy[2];
         Fsx[0] = (Fx[0] + Fx[1]) + Fx[2];    Fsy[0] = (Fy[0] + Fy[1]) + Fy[2];
-        Q[0] = (((ex[0] * Fy[0] - ey[0] * Fx[0]) + tz[0]) + (lox[0] * Fsy[1] - loy[0] * Fsx[1])) - tau[1];
-        Q[1] = (((ex[1] * Fy[1] - ey[1] * Fx[1]) + tz[1]) + (lox[1] * Fsy[2] - loy[1] * Fsx[2])) + (tau[1] - tau[2]);
-        Q[2] = ((ex[2] * Fy[2] - ey[2] * Fx[2]) + tz[2]) + tau[2];
+        Q[0] = (((R)cxb(0) * ft[0] + tz[0]) + (R)jxo(0) * (cs[0] * Fsy[1] - sn[0] * Fsx[1])) - tau[1];
+        Q[1] = (((R)cxb(1) * ft[1] + tz[1]) + (R)jxo(1) * (cs[1] * Fsy[2] - sn[1] * Fsx[2])) + (tau[1] - tau[2]);
+        Q[2] = ((R)cxb(2) * ft[2] + tz[2]) + tau[2];
         // translation coupling and centripetal terms
         R Gx[3], Gy[3], w2[3], wgx[3], wgy[3];
         RL_UNROLL
@@ -179,7 +178,7 @@ struct SwimChain {
         th[1] = th[1] + h * (om[1] - om[0]);
         th[2] = th[2] + h * (om[2] - om[1]);
         RL_UNROLL
-        for (int b = 0; b < 3; ++b) rl_rotate_small(sn[b], cs[b], h * om[b]);
+        for (int b = 0; b < 3; ++b) rl_rotate_tiny(sn[b], cs[b], h * om[b]);
     }
 
     // ---- quad program ------------------------------------------------------------------------------------------------
@@ -187,7 +186,7 @@ struct SwimChain {
     template <typename R>
     struct LaneConst {
         R jxo, cxb, db, visc_lin, drag_ax, drag_perp, visc_ang, drag_ang;
-        R m1, m2, mj;        // 0/1 masks: b >= 1, b >= 2, b is a hinge (1 or 2)
+        R lim_k, lim_b;      // joint-limit penalty of the hinge that carries body b (roles 0 and 3: none)
         R scp, acp, scq, acq;        // coupling constants to the partners p = b + 1, q = b + 2 (mod 3)
         R d_b, d_pq, d_p, d_q;       // diagonal of the 3x3 system in the cyclic order (role 3: identity)
         int b;
@@ -205,9 +204,9 @@ struct SwimChain {
         c.drag_perp = body ? (R)Mdl::DRAG_PERP : (R)0;
         c.visc_ang = body ? (R)Mdl::VISC_ANG : (R)0;
         c.drag_ang = body ? (R)Mdl::DRAG_ANG : (R)0;
-        c.m1 = (b >= 1) ? (R)1 : (R)0;
-        c.m2 = (b >= 2) ? (R)1 : (R)0;
-        c.mj = (b == 1 || b == 2) ? (R)1 : (R)0;
+        const bool hinge = (b == 1 || b == 2);
+        c.lim_k = hinge ? (R)Mdl::limit_k() : (R)0;
+        c.lim_b = hinge ? (R)Mdl::limit_b() : (R)0;
         c.scp = (R)(b == 0 ? scc(0, 1) : b == 1 ? scc(1, 2) : b == 2 ? scc(2, 0) : 0.0);
         c.acp = (R)(b == 0 ? acc(0, 1) : b == 1 ? acc(1, 2) : b == 2 ? acc(2, 0) : 0.0);
         c.scq = (R)(b == 0 ? scc(0, 2) : b == 1 ? scc(1, 0) : b == 2 ? scc(2, 1) : 0.0);
@@ -220,13 +219,15 @@ struct SwimChain {
     }
     template <typename R>
     struct Lane {
-        R cs, sn, om, th;    // own body (role 3: cs = 1, everything else 0)
+        R cs, sn, om, th;    // own body (role 3: cs = 1, om = 0 and stays 0 -- the other lanes read it as their zero)
         R rx, ry, vx, vy;    // root translation, replicated on the four lanes
     };
 
     // quad_perm controls: lane i of the quad reads lane P[i]
     static constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
-    static constexpr int SHR1 = QP(0, 0, 1, 2), SHR2 = QP(0, 0, 0, 1), SHL1 = QP(1, 2, 3, 3), SHL2 = QP(2, 3, 3, 3);
+    // role 3 holds exact zeros for everything a neighbour may fetch, so "the parent of body 0" and "nothing" are lane 3
+    static constexpr int PAR1 = QP(3, 0, 1, 2), PAR2 = QP(3, 3, 0, 3);       // parent, grandparent (or the zero lane)
+    static constexpr int SHL1 = QP(1, 2, 3, 3), SHL2 = QP(2, 3, 3, 3);       // child, grandchild (or the zero lane)
     static constexpr int NX1 = QP(1, 2, 0, 3), NX2 = QP(2, 0, 1, 3);         // cyclic partners p, q of body = lane
     static constexpr int BC0 = QP(0, 0, 0, 0);
     static constexpr int SW1 = QP(1, 0, 3, 2), SW2 = QP(2, 3, 0, 1);         // butterfly
@@ -240,29 +241,24 @@ struct SwimChain {
     // X: exchange context, x.template qp<CTRL>(v) = value of v in the lane selected by CTRL
     template <typename R, class X>
     RL_HD static void substep_quad(X& x, const LaneConst<R>& c, Lane<R>& s, R act, R h) {
-        const R lox = s.cs * c.jxo;
-        const R loy = s.sn * c.jxo;
-        const R wlx = -(s.om * loy);
-        const R wly = s.om * lox;
-        const R ex = s.cs * c.cxb;
-        const R ey = s.sn * c.cxb;
-        const R p1x = x.template qp<SHR1>(wlx), p1y = x.template qp<SHR1>(wly);
-        const R p2x = x.template qp<SHR2>(wlx), p2y = x.template qp<SHR2>(wly);
-        const R vax = (s.vx + c.m1 * p1x) + c.m2 * p2x;
-        const R vay = (s.vy + c.m1 * p1y) + c.m2 * p2y;
-        const R vpx = vax - s.om * ey;
-        const R vpy = vay + s.om * ex;
-        R Fx, Fy, tz;
-        fluid(s.cs, s.sn, vpx, vpy, s.om, c.visc_lin, c.drag_ax, c.drag_perp, c.visc_ang, c.drag_ang, Fx, Fy, tz);
-        const R omp = x.template qp<SHR1>(s.om);
-        const R tau = c.mj * joint_torque(s.th, s.om - c.m1 * omp, act);
+        const R osn = s.om * s.sn;
+        const R ocs = s.om * s.cs;
+        const R wlx = -(osn * c.jxo);
+        const R wly = ocs * c.jxo;
+        const R vax = (s.vx + x.template qp<PAR1>(wlx)) + x.template qp<PAR2>(wlx);
+        const R vay = (s.vy + x.template qp<PAR1>(wly)) + x.template qp<PAR2>(wly);
+        const R vpx = vax - osn * c.cxb;
+        const R vpy = vay + ocs * c.cxb;
+        R Fx, Fy, tz, ft;
+        fluid(s.cs, s.sn, vpx, vpy, s.om, c.visc_lin, c.drag_ax, c.drag_perp, c.visc_ang, c.drag_ang, Fx, Fy, tz, ft);
+        const R tau = joint_torque(s.th, s.om - x.template qp<PAR1>(s.om), act, c.lim_k, c.lim_b);
         const R taun = x.template qp<SHL1>(tau);
         const R f1x = x.template qp<SHL1>(Fx), f1y = x.template qp<SHL1>(Fy);
         const R f2x = x.template qp<SHL2>(Fx), f2y = x.template qp<SHL2>(Fy);
         const R Fsx = (Fx + f1x) + f2x;
         const R Fsy = (Fy + f1y) + f2y;
         const R fnx = x.template qp<SHL1>(Fsx), fny = x.template qp<SHL1>(Fsy);
-        const R Q = (((ex * Fy - ey * Fx) + tz) + (lox * fny - loy * fnx)) + (tau - taun);
+        const R Q = ((c.cxb * ft + tz) + c.jxo * (s.cs * fny - s.sn * fnx)) + (tau - taun);
         const R Gx = s.cs * c.db;
         const R Gy = s.sn * c.db;
         const R w2 = s.om * s.om;
@@ -295,9 +291,8 @@ struct SwimChain {
         s.rx = s.rx + h * s.vx;
         s.ry = s.ry + h * s.vy;
         s.om = s.om + h * thb;
-        const R omp2 = x.template qp<SHR1>(s.om);
-        s.th = s.th + h * (s.om - c.m1 * omp2);
-        rl_rotate_small(s.sn, s.cs, h * s.om);
+        s.th = s.th + h * (s.om - x.template qp<PAR1>(s.om));
+        rl_rotate_tiny(s.sn, s.cs, h * s.om);
     }
 };
 

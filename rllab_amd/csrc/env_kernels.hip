@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev 
             for (int it = 0; it < Env::FRAME_SKIP; ++it)
                 Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
             // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's)
-            const float qdj = ls.om - kc.m1 * dpp.template qp<Chain::SHR1>(ls.om);
+            const float qdj = ls.om - dpp.template qp<Chain::PAR1>(ls.om);   // role 3 keeps om = 0
             const int base = 4 * el;
             s[0] = __shfl(ls.rx, base, BLOCK);
             s[1] = __shfl(ls.ry, base, BLOCK);

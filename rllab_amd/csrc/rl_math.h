@@ -44,6 +44,25 @@ RL_HD float rl_clamp_finite(float x, float lo, float hi) {
     return x < lo ? lo : (x > hi ? hi : x);
 #endif
 }
+// n / d, correctly rounded, for operands whose quotient needs no range scaling (d and n / d normal and far from the
+// exponent limits).  On the device this is the core of the compiler's own IEEE division expansion -- v_rcp_f32 (1 ulp)
+// refined by the fma chain that makes the result independent of the seed's last bit -- without the v_div_scale /
+// v_div_fixup wrapping (8 instructions instead of 12); the host divides.
+RL_HD float rl_div_normal(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = n * r1;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e2, r1, q1);
+#else
+    return n / d;
+#endif
+}
+RL_HD double rl_div_normal(double n, double d) { return n / d; }
 RL_HD double rl_clamp_finite(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // Deterministic single-precision sin/cos.  Cody-Waite three-term reduction by
@@ -94,6 +113,24 @@ RL_HD void rl_rotate_small(R& sn, R& cs, R d) {
     const R c = cs * cd - sn * sd;
     sn = s;
     cs = c;
+}
+
+// Same rotation for |d| << 1 (one 1 ms sub-step of a swimmer link: |d| < 0.05): in single precision the series are cut
+// one term earlier (sin: d^5/120 < 3e-9, cos: d^6/720 < 3e-11 -- below half an ulp of the results).
+template <typename R>
+RL_HD void rl_rotate_tiny(R& sn, R& cs, R d) {
+    if constexpr (sizeof(R) == 4) {
+        const R d2 = d * d;
+        const R t = d2 * (R)(-1.0 / 6);
+        const R sd = d + d * t;
+        const R cd = (R)1 + d2 * ((R)-0.5 + d2 * (R)(1.0 / 24));
+        const R s = sn * cd + cs * sd;
+        const R c = cs * cd - sn * sd;
+        sn = s;
+        cs = c;
+    } else {
+        rl_rotate_small(sn, cs, d);
+    }
 }
 
 // The double instantiation is host-only (independent physics checks at 1e-10);
