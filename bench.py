@@ -186,13 +186,18 @@ def main():
     # second roofline: the matrix-core kernel of the update (Fisher-vector product), timed live
     do, da, h = policy.obs_dim, policy.action_dim, wl["hidden"][0]
     ht, ks0, ks1 = h // 32, (do + 2) // 2, 16 * (h // 32)
-    mfma_per_tile = ht * (ks0 + ks1) + ht * (ks0 + 2 * ks1) + ht * ks1 + ht * ht * 16
+    # algorithmic matrix instructions of one FVP per 32-sample tile: tangent forward + back-propagation + the
+    # W1 outer product; the forward pass itself only where the gradient pass cannot leave its activations
+    # behind (64-unit nets): what TRPO's CG loop actually launches
+    cached = ht == 1
+    mfma_per_tile = (0 if cached else ht * (ks0 + ks1)) + ht * (ks0 + 2 * ks1) + ht * ks1 + ht * ht * 16
     fvp_ms = None
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None
     if ops is not None:
         from rllab_amd.algos.npo import npo_inputs
         inp = npo_inputs(policy, last["samples"])
         v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
+        ops.loss_grad(inp, keep_activations=True)     # as ConjugateGradientOptimizer.optimize does before CG
         for _ in range(3):
             ops.fvp(inp, v)
         torch.cuda.synchronize()
@@ -242,6 +247,7 @@ def main():
         out["roofline_mfma"] = {"kernel": "policy_pass_kernel<FVP> (Fisher-vector product, v_mfma_f32_32x32x2_f32)",
                                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
                                 "frac": tf / 157.3, "avg_launch_ms": fvp_ms, "mfma_per_32_samples": mfma_per_tile,
+                                "activations": "read from the gradient pass's cache" if cached else "recomputed",
                                 "note": "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); time "
                                         "includes the partial-row reduce kernel"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -212,10 +212,19 @@ typedef struct rl_policy_batch {
     const float* old_means;    /* [Da][B]  agent_infos["mean"] */
     const float* old_log_std;  /* [Da]     agent_infos["log_std"] (one constant row) */
     const float* weights;      /* [B] 0/1 validity */
+    float* activations;        /* NULL, or rl_policy_activation_bytes() of device scratch: rl_policy_grad (vpg == 0)
+                                * leaves the hidden activations of every sample there and rl_policy_fvp reads them
+                                * instead of re-evaluating the forward pass.  The caller guarantees that an FVP call
+                                * which passes the buffer uses the same obs / theta as the gradient call that filled
+                                * it -- in ConjugateGradientOptimizer.optimize (conjugate_gradient_optimizer.py:
+                                * 229-296) the 11 f_Hx_plain evaluations follow f_grad at the same parameters. */
 } rl_policy_batch;
 
 /* Scratch the three calls below need (device memory, caller-owned, reusable). */
 size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1);
+
+/* Size of rl_policy_batch.activations for a batch of n_samples (2 * hidden floats per sample, tile padded). */
+size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1);
 
 /* out4 (device, 4 doubles) = [ sum_b w lr adv, sum_b w KL, sum_b w logp adv, max_b KL ] at theta:
  * surrogate loss = -out4[0]*inv_count, mean KL = out4[1]*inv_count.  Replaces the compiled

@@ -25,7 +25,7 @@ ENV_WALKER2D = 5
 SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_rollout_gaussian_mlp", "rl_gae",
-    "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_loss_kl",
+    "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_fvp", "rl_cg_init", "rl_cg_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
     "rl_lfb_normal_eq",
@@ -54,7 +54,7 @@ class PolicyBatch(ctypes.Structure):
         ("hidden0", ctypes.c_int32), ("hidden1", ctypes.c_int32), ("inv_count", ctypes.c_float),
         ("log_min_std", ctypes.c_float), ("theta", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
-        ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p),
+        ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
     ]
 
 
@@ -82,6 +82,8 @@ def _load():
     pb = ctypes.POINTER(PolicyBatch)
     lib.rl_policy_workspace_bytes.restype = ctypes.c_size_t
     lib.rl_policy_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.rl_policy_activation_bytes.restype = ctypes.c_size_t
+    lib.rl_policy_activation_bytes.argtypes = [i32, i32, i32]
     lib.rl_policy_loss_kl.argtypes = [pb, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_grad.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]

@@ -50,10 +50,11 @@ constexpr int WAVES = 4;      // wavefronts per workgroup (one per SIMD)
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_FVP = 2, MODE_VPG = 3 };
 constexpr int LOSS_COLS = 4;  // sum w*lr*adv, sum w*kl, sum w*logp*adv, max kl
 
-template <class N, int MODE>
+template <class N, int MODE, bool CACHE = false>
 struct Smem {
     static constexpr bool GRADLIKE = (MODE != MODE_LOSS);
     static constexpr bool FVP = (MODE == MODE_FVP);
+    static constexpr int ACT_FLOATS = 2 * N::H * TS;              // h0 | h1 fragments of one 32-sample tile
     static constexpr int A0 = 0;
     static constexpr int A1 = A0 + N::FA0;
     static constexpr int A1T = A1 + N::FA1;                       // backward fragments (W1 untransposed)
@@ -62,7 +63,8 @@ struct Smem {
     static constexpr int TAIL = DA1 + (FVP ? N::FA1 : 0);
     static constexpr int DTAIL = TAIL + N::TAILP;
     static constexpr int WAVE0 = DTAIL + (FVP ? N::TAILP : 0);
-    static constexpr int TOTAL = WAVE0 + WAVES * N::WAVE_LDS;
+    static constexpr int ACTQ = WAVE0 + WAVES * N::WAVE_LDS;      // [WAVES][ACT_FLOATS] landing zone (cached FVP)
+    static constexpr int TOTAL = ACTQ + ((FVP && CACHE) ? WAVES * ACT_FLOATS : 0);
     static constexpr int RED = 0;                                 // [P] cross-wave fold, aliases the fragments
     static_assert(TOTAL >= N::P, "LDS fold buffer must fit");
 };
@@ -71,6 +73,7 @@ struct PolicyBatch {
     int B;                     // samples
     const float* theta;        // [P]
     const float* vec;          // [P] tangent (MODE_FVP) or null
+    float* acts;               // hidden-activation cache (CACHE variants): written by MODE_GRAD, read by MODE_FVP
     const float* obs;          // [DO][B]
     const float* act;          // [DA][B]
     const float* adv;          // [B]
@@ -83,12 +86,17 @@ struct PolicyBatch {
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS)
 };
 
-template <class N, int MODE>
+template <class N, int MODE, bool CACHE>
 __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
-    using S = Smem<N, MODE>;
+    static_assert(!CACHE || MODE == MODE_GRAD || MODE == MODE_FVP, "activation cache: grad writes, FVP reads");
+    using S = Smem<N, MODE, CACHE>;
     constexpr int DO = N::DO, DA = N::DA, H = N::H, HT = N::HT, KS0 = N::KS0, KS1 = N::KS1, P = N::P;
     constexpr bool GRADLIKE = S::GRADLIKE, FVP = S::FVP;
+    constexpr bool LOAD_ACTS = CACHE && FVP, STORE_ACTS = CACHE && !FVP;
     constexpr int TSTR = N::TSTR, XS = N::XS, GS = N::GS;
+    // activation cache: per 32-sample tile, [h0 | h1][HT][4] rows of 64 lanes x float4 (registers 4q .. 4q+3 of a
+    // fragment), i.e. the fragments exactly as the matrix pipe produced them -- 1 KB per wavefront access
+    constexpr int ACT_ROWS = 2 * HT * 4;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
@@ -173,6 +181,19 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     float xb[KS0], xb_next[KS0];
     float wgt = 0.0f, wgt_next = 0.0f;
     if (wave_global < n_tiles) fetch(wave_global, xb_next, wgt_next);
+    // cached activations travel one tile ahead as well (FVP only), by LDS-direct loads into a wave-private landing
+    // zone: 8 KB per tile would not fit the register budget of two wavefronts per SIMD next to the accumulators
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    float* const hq = smem + S::ACTQ + wave * S::ACT_FLOATS;
+    auto fetch_acts = [&](int tile) {
+        const float* src = a.acts + ((size_t)tile * ACT_ROWS * WV + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < ACT_ROWS; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(hq + q * WV * 4), 16, 0, 0);
+    };
+    if (LOAD_ACTS && wave_global < n_tiles) fetch_acts(wave_global);
 
     for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
         asm volatile("" ::: "memory");   // keep the weight-fragment reads inside the loop
@@ -185,27 +206,55 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         wgt = wgt_next;
         if (tile + waves_total < n_tiles) fetch(tile + waves_total, xb_next, wgt_next);
 
-        // ---- forward ------------------------------------------------------------------------
+        // ---- forward (or the fragments the gradient pass left in HBM) ------------------------------
         f32x16 h0[HT], h1[HT];
+        if constexpr (LOAD_ACTS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tile fetched during the previous tile has landed
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            f32x16 acc;
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(hq + ((t * 4 + q) * WV + lane) * 4);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(hq + (((HT + t) * 4 + q) * WV + lane) * 4);
 #pragma unroll
-            for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
+                    for (int e = 0; e < 4; ++e) { h0[t][4 * q + e] = v0[e]; h1[t][4 * q + e] = v1[e]; }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and is in registers before the zone is refilled
+            if (tile + waves_total < n_tiles) fetch_acts(tile + waves_total);
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h0[t][r] = ftanh(acc[r]);
-        }
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            f32x16 acc;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
+                for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
 #pragma unroll
-            for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
+                for (int r = 0; r < 16; ++r) h0[t][r] = ftanh(acc[r]);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[t][r] = ftanh(acc[r]);
+            for (int t = 0; t < HT; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
+#pragma unroll
+                for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1[t][r] = ftanh(acc[r]);
+            }
+            if constexpr (STORE_ACTS) {
+                f32x4* dst = reinterpret_cast<f32x4*>(a.acts) + (size_t)tile * ACT_ROWS * WV + lane;
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = h0[t][4 * q + e]; v1[e] = h1[t][4 * q + e]; }
+                        __builtin_nontemporal_store(v0, dst + (t * 4 + q) * WV);
+                        __builtin_nontemporal_store(v1, dst + ((HT + t) * 4 + q) * WV);
+                    }
+            }
         }
 
         // ---- per-sample cotangent on the mean ----------------------------------------------------
@@ -543,11 +592,12 @@ __global__ void __launch_bounds__(LOSS_COLS * WV) reduce_loss_kernel(const doubl
 
 constexpr int MAX_GRID = 256 * 3;   // workgroups of a pass: <= 3 per CU
 
-template <class N, int MODE>
+template <class N, int MODE, bool CACHE = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
                        double* out, hipStream_t st) {
-    using S = Smem<N, MODE>;
+    using S = Smem<N, MODE, CACHE>;
     PolicyBatch a;
+    a.acts = g->activations;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
@@ -567,7 +617,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
                          need_bytes);
     a.partial = (float*)workspace;
     a.partial_loss = (double*)workspace;
-    auto kern = policy_pass_kernel<N, MODE>;
+    auto kern = policy_pass_kernel<N, MODE, CACHE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -592,8 +642,14 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
                          double* out, hipStream_t st) {
     switch (mode) {
         case MODE_LOSS: return launch_pass<N, MODE_LOSS>(g, vec, ws, ws_bytes, out, st);
-        case MODE_GRAD: return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st);
-        case MODE_FVP: return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st);
+        case MODE_GRAD:
+            if constexpr (N::ACT_CACHE)
+                if (g->activations) return launch_pass<N, MODE_GRAD, true>(g, vec, ws, ws_bytes, out, st);
+            return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st);
+        case MODE_FVP:
+            if constexpr (N::ACT_CACHE)
+                if (g->activations) return launch_pass<N, MODE_FVP, true>(g, vec, ws, ws_bytes, out, st);
+            return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st);
         case MODE_VPG: return launch_pass<N, MODE_VPG>(g, vec, ws, ws_bytes, out, st);
     }
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
@@ -638,6 +694,13 @@ extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden
     const size_t rows = MAX_GRID;
     const size_t a = rows * P * sizeof(float), b = rows * LOSS_COLS * sizeof(double);
     return a > b ? a : b;
+}
+
+extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1) {
+    // only the 32-unit nets keep a cache: at 64 units the landing zone no longer fits LDS next to the weight fragments
+    if (n_samples <= 0 || hidden0 != hidden1 || hidden0 != 32) return 0;
+    const size_t n_tiles = ((size_t)n_samples + TS - 1) / TS;
+    return n_tiles * 2 * (size_t)(hidden0 / 32) * 16 * WV * sizeof(float);
 }
 
 extern "C" int rl_policy_loss_kl(const rl_policy_batch* g, void* workspace, size_t workspace_bytes,

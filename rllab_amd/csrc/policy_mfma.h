@@ -64,6 +64,8 @@ struct Net {
     static constexpr int WAVE_LDS = TS * TSTR + TS * XS + TS * GS;
     // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
     static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
+    // the update kernels can keep the hidden activations of a batch in HBM between the gradient and the FVP passes
+    static constexpr bool ACT_CACHE = (HT == 1);
     static_assert(H % 32 == 0 && HT <= 2, "hidden size must be 32 or 64");
     static_assert(DO + 1 <= 32, "obs_dim + 1 must fit one 32-row tile");
 

@@ -176,9 +176,9 @@ class ConjugateGradientOptimizer(Serializable):
             return self._fused.loss_and_kl(inputs)
         return (self._eval_scalar(self._loss, inputs), self._eval_scalar(self._constraint, inputs))
 
-    def _flat_grad(self, inputs):
+    def _flat_grad(self, inputs, keep_activations=False):
         if self._fused_for(inputs) is not None:
-            g = self._fused.loss_grad(inputs)
+            g = self._fused.loss_grad(inputs, keep_activations=keep_activations)
         else:
             flat = _flat_for_grad(self._target)
             g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
@@ -211,7 +211,9 @@ class ConjugateGradientOptimizer(Serializable):
         loss_before = float(self._loss_constraint(inputs)[0])
         logger.log("performing update")
         logger.log("computing descent direction")
-        flat_g = self._flat_grad(inputs)
+        # the Fisher-vector products below run on the same batch at the same parameters: let the gradient
+        # pass leave its hidden activations for them (not when the products use a subsample)
+        flat_g = self._flat_grad(inputs, keep_activations=subsample_inputs is inputs)
         hvp = self._hvp_approach
         if self._fused is not None and not self._hvp_given and self._fused_for(inputs) is None:
             hvp = PerlmutterHvp(self._num_slices)   # batch the fused kernels cannot take

@@ -23,6 +23,8 @@ class FusedGaussianMLPOps(object):
         self._ws = None
         self._loss_cache = None
         self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
+        self._acts = None    # hidden-activation cache the gradient pass fills for the FVP passes
+        self._acts_tag = None
 
     @staticmethod
     def supported(policy):
@@ -71,6 +73,8 @@ class FusedGaussianMLPOps(object):
         """Drop the cached descriptor (and the batch tensors it keeps alive)."""
         self._bound.clear()
         self._loss_cache = None
+        self._acts = None
+        self._acts_tag = None
 
     def loss_stats(self, inputs):
         """[sum w lr adv, sum w KL, sum w logp adv] * inv_count (global) and max KL, as a
@@ -100,17 +104,41 @@ class FusedGaussianMLPOps(object):
         s = self.loss_stats(inputs)
         return -s[0], s[1]
 
-    def loss_grad(self, inputs, vpg=False):
+    def _eval_point(self, inputs):
+        """(batch, parameter version): flat_params._version counts the in-place updates."""
+        return (tuple(id(t) for t in inputs), self.policy.flat_params._version)
+
+    def loss_grad(self, inputs, vpg=False, keep_activations=False):
+        """Flat gradient of the surrogate loss.  ``keep_activations``: also leave the hidden activations of
+        the batch in device memory for the Fisher-vector products that follow at the same parameters (TRPO:
+        one gradient, then cg_iters + 1 products), which then skip the forward pass."""
         b, keep, _ = self._batch(inputs)
         ws = self._workspace(keep[0].device)
         out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
-        _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
-                                           _lib.stream_ptr()), "rl_policy_grad")
+        self._acts_tag = None
+        b.activations = None
+        if keep_activations and not vpg:
+            need = _lib.lib.rl_policy_activation_bytes(b.n_samples, self.dims[2], self.dims[3])
+            if self._acts is None or self._acts.numel() < need or self._acts.device != keep[0].device:
+                self._acts = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
+            b.activations = self._acts.data_ptr()
+        try:
+            _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
+                                               _lib.stream_ptr()), "rl_policy_grad")
+            if b.activations:
+                self._acts_tag = self._eval_point(inputs)
+        finally:
+            b.activations = None
         return D.all_reduce_sum_(out)
 
-    def _fvp_into(self, b, ws, vec32, out):
-        _lib.check(_lib.lib.rl_policy_fvp(ctypes.byref(b), _lib.ptr(vec32), _lib.ptr(ws), ws.numel(),
-                                          _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
+    def _fvp_into(self, b, ws, vec32, out, inputs=None):
+        cached = inputs is not None and self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
+        b.activations = self._acts.data_ptr() if cached else None
+        try:
+            _lib.check(_lib.lib.rl_policy_fvp(ctypes.byref(b), _lib.ptr(vec32), _lib.ptr(ws), ws.numel(),
+                                              _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
+        finally:
+            b.activations = None
         return D.all_reduce_sum_(out)
 
     def fvp(self, inputs, vec):
@@ -118,7 +146,7 @@ class FusedGaussianMLPOps(object):
         ws = self._workspace(keep[0].device)
         v = vec.to(torch.float32).contiguous()
         out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
-        return self._fvp_into(b, ws, v, out)
+        return self._fvp_into(b, ws, v, out, inputs)
 
     def cg(self, inputs, g, cg_iters, reg_coeff, residual_tol=1e-10):
         """krylov.cg (rllab/misc/krylov.py:7-39) on Hx = F x + reg_coeff x with the vector algebra of
@@ -138,13 +166,13 @@ class FusedGaussianMLPOps(object):
         _lib.check(_lib.lib.rl_cg_init(n, _lib.ptr(g), _lib.ptr(x), _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32),
                                        _lib.ptr(scal), st), "rl_cg_init")
         for _ in range(cg_iters):
-            self._fvp_into(b, ws, p32, z)
+            self._fvp_into(b, ws, p32, z, inputs)
             _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
                                            _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
                        "rl_cg_step")
         # x^T H x for the initial step size (conjugate_gradient_optimizer.py:258-260)
         x32 = x.to(torch.float32)
-        self._fvp_into(b, ws, x32, z)
+        self._fvp_into(b, ws, x32, z, inputs)
         xHx = x.dot(z + float(reg_coeff) * x)
         return x, xHx
 

@@ -117,6 +117,41 @@ def test_fvp_equals_kl_hessian_at_theta_old(do, da, h):
         assert float((hv - hv64).abs().max()) <= 5e-5 * float(hv64.abs().max())
 
 
+@pytest.mark.parametrize("do,da,h", [sh for sh in SHAPES if sh[2] == 32])
+@pytest.mark.parametrize("B", [1, 63, 1000, 70001])
+def test_fvp_on_cached_activations_is_the_same_product(do, da, h, B):
+    """rl_policy_grad with batch.activations set leaves the hidden activations in device memory and
+    rl_policy_fvp then skips the forward pass: the same gradient and the same product, bit for bit (the
+    fragments are stored exactly as the matrix pipe produced them); the cache is dropped as soon as the
+    parameters or the batch change."""
+    pol = _policy(do, da, h)
+    ops = pol.fused_ops()
+    inp = _inputs(pol, B, old_equals_new=True)
+    rng = np.random.RandomState(5)
+    v = torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda")
+    want_g, want_hv = ops.loss_grad(inp), ops.fvp(inp, v)
+    assert ops._acts_tag is None
+    g = ops.loss_grad(inp, keep_activations=True)
+    assert ops._acts_tag is not None and ops._acts.numel() == ((B + 31) // 32) * 2 * h * 32 * 4
+    hv = ops.fvp(inp, v)
+    assert torch.equal(g, want_g)
+    assert torch.equal(hv, want_hv)
+    x, xhx = ops.cg(inp, want_g, 4, 1e-5)
+    ops._acts_tag = None
+    x2, xhx2 = ops.cg(inp, want_g, 4, 1e-5)
+    assert torch.equal(x, x2) and torch.equal(xhx, xhx2)
+    # a parameter update invalidates the cache: the next product recomputes the forward pass
+    ops.loss_grad(inp, keep_activations=True)
+    with torch.no_grad():
+        pol.flat_params.add_(0.01)
+    hv_new = ops.fvp(inp, v)
+    ops._acts_tag = None
+    assert torch.equal(hv_new, ops.fvp(inp, v)) and not torch.equal(hv_new, want_hv)
+    # VPG gradients never keep activations
+    ops.loss_grad(inp, vpg=True, keep_activations=True)
+    assert ops._acts_tag is None
+
+
 def test_fvp_is_symmetric_psd():
     pol = _policy(13, 2, 32)
     ops = pol.fused_ops()
