@@ -35,6 +35,9 @@ def make_env(name):
     if name == "walker2d":
         from rllab.envs.mujoco.walker2d_env import Walker2DEnv
         return normalize(Walker2DEnv()), 500
+    if name == "hopper":
+        from rllab.envs.mujoco.hopper_env import HopperEnv
+        return normalize(HopperEnv()), 500
     if name == "double_pendulum":
         from rllab.envs.box2d.double_pendulum_env import DoublePendulumEnv
         return normalize(DoublePendulumEnv()), 100

@@ -1,11 +1,12 @@
 """Independent float64 restatement of the MuJoCo-style planar tree envs (TEST INFRASTRUCTURE):
 a model-driven version of oracle/np_cheetah.py's derivation (automatic differentiation of the Lagrangian
 written in MuJoCo's own (x, z) coordinates, capsule mass properties by numerical quadrature, penalty joint
-limits and floor contacts restated from DESIGN.md), used for the Walker2D-style env.  Nothing here shares
+limits and floor contacts restated from DESIGN.md), used for the Walker2D- and Hopper-style envs.  Nothing here shares
 code, constants or formulation with rllab_amd/csrc/dyn_planar.h / dyn_walker.h / walker_constants.h: bodies,
-joints and geoms are typed in again from vendor/mujoco_models/walker2d.xml (reference, lines 3-59).
+joints and geoms are typed in again from vendor/mujoco_models/walker2d.xml (reference, lines 3-59) and
+hopper.xml (lines 3-49).
 
-Follows: rllab/envs/mujoco/walker2d_env.py:28-49 (obs, reward, done),
+Follows: rllab/envs/mujoco/walker2d_env.py:28-49, hopper_env.py:38-62 (obs, reward, done),
 rllab/envs/mujoco/mujoco_env.py:109-116,184-191 (reset, step), rllab/mujoco_py/mjcore.py:58-81 (comvel).
 """
 import numpy as np
@@ -136,6 +137,33 @@ class PlanarModel(object):
                 Q = Q + Jc[2 * cidx] * ft + Jc[2 * cidx + 1] * fn + Jth[b] * (-rads[cidx] * ft)
         return torch.linalg.solve(M, Q - c)
 
+    def constraint_qfrc(self, q, qd):
+        """Generalised force (MuJoCo joint coordinates) of the penalty joint limits and floor contacts at (q, qd):
+        the quantity the engine reports where MuJoCo reports data.qfrc_constraint."""
+        q = torch.as_tensor(q, dtype=torch.float64)
+        qd = torch.as_tensor(qd, dtype=torch.float64)
+        nb = len(self.bodies)
+        Q = torch.zeros_like(q)
+        for k, name in enumerate(self.names[1:]):
+            j = 3 + k
+            lo, hi = self.joints[name][0], self.joints[name][1]
+            if q[j] < lo:
+                Q[j] = Q[j] - LIMIT_K * (q[j] - lo) - LIMIT_B * qd[j]
+            if q[j] > hi:
+                Q[j] = Q[j] - LIMIT_K * (q[j] - hi) - LIMIT_B * qd[j]
+        pts, owner, rads, mus = self.contact_points(q)
+        Jc = torch.autograd.functional.jacobian(lambda qq: self.contact_points(qq)[0], q)
+        Jth = torch.autograd.functional.jacobian(lambda qq: self.pose_vector(qq)[2 * nb:], q)
+        vel = Jc @ qd
+        for cidx, b in enumerate(owner):
+            depth = rads[cidx] - pts[2 * cidx + 1]
+            if depth > 0:
+                vx, vz = vel[2 * cidx], vel[2 * cidx + 1]
+                fn = torch.clamp(CONTACT_K * depth - CONTACT_B * vz, min=0.0)
+                ft = -torch.clamp(FRICTION_C * vx, -mus[cidx] * fn, mus[cidx] * fn)
+                Q = Q + Jc[2 * cidx] * ft + Jc[2 * cidx + 1] * fn + Jth[b] * (-rads[cidx] * ft)
+        return Q.numpy()
+
     def com_and_vel(self, q, qd):
         q = torch.as_tensor(q, dtype=torch.float64)
         qd = torch.as_tensor(qd, dtype=torch.float64)
@@ -206,4 +234,52 @@ def walker_step(qpos, qvel, action, normalize=True):
 def walker_to_engine_state(qpos, qvel):
     """Engine state (tree convention): hinges about -y carry the opposite sign."""
     sgn = np.concatenate([[1.0, 1.0, 1.0], WALKER.sign])
+    return np.concatenate([qpos * sgn, qvel * sgn])
+
+
+# hopper.xml:21-40 (coordinate="global"): offsets are differences of the file's absolute positions; every joint has
+# damping 1 and armature 1 (defaults, :4), hinges about -y, motors gear 1 with ctrlrange +-200 (:44-46); timestep 0.02
+HOPPER = PlanarModel(
+    bodies=[
+        ("torso", None, (0.0, 0.0), [(0.0, 0.0, 0.0, 0.2, 0.05, 0.9)]),
+        ("thigh", "torso", (0.0, 1.05 - 1.25), [(0.0, (1.05 + 0.6) / 2 - 1.05, 0.0, (1.05 - 0.6) / 2, 0.05, 0.9)]),
+        ("leg", "thigh", (0.0, 0.6 - 1.05), [(0.0, (0.6 + 0.1) / 2 - 0.6, 0.0, (0.6 - 0.1) / 2, 0.04, 0.9)]),
+        ("foot", "leg", (0.0, 0.1 - 0.6), [((0.26 - 0.13) / 2, 0.0, np.pi / 2, (0.26 + 0.13) / 2, 0.06, 2.0)]),
+    ],
+    joints={n: (lo * _D, hi * _D, 0.0, 1.0, 1.0, 1.0, -1.0) for n, lo, hi in
+            [("thigh", -150, 0), ("leg", -150, 0), ("foot", -45, 45)]},
+    root_height=1.25, dt=0.02, substeps=8)
+HOPPER_CTRL = np.array([200.0, 200.0, 200.0])
+
+
+def hopper_reset(draws):
+    z = np.asarray(draws, dtype=np.float64)
+    qpos = 0.01 * z[:6]
+    qpos[0] += 1.25
+    return qpos, 0.1 * z[6:]
+
+
+def hopper_observe(qpos, qvel):
+    com, _ = HOPPER.com_and_vel(qpos, qvel)
+    qf = HOPPER.constraint_qfrc(qpos, qvel)
+    return np.concatenate([qpos[0:1], qpos[2:], np.clip(qvel, -10, 10), np.clip(qf, -10, 10), [com[0], 0.0, com[1]]])
+
+
+def hopper_step(qpos, qvel, action, normalize=True):
+    """One HopperEnv.step (behind NormalizedEnv when ``normalize``) in MuJoCo's conventions."""
+    a = np.asarray(action, dtype=np.float64)
+    lb, ub = -HOPPER_CTRL, HOPPER_CTRL
+    if normalize:
+        a = np.clip(lb + (a + 1.0) * 0.5 * (ub - lb), lb, ub)
+    a = np.clip(a, lb, ub)
+    q, qd = HOPPER.advance(qpos, qvel, a)
+    _, comvel = HOPPER.com_and_vel(q, qd)
+    reward = comvel[0] + 1.0 - 0.5 * 0.01 * np.sum(np.square(a / ((ub - lb) * 0.5)))
+    state = np.concatenate([q, qd])
+    notdone = np.isfinite(state).all() and (np.abs(state[3:]) < 100).all() and state[0] > 0.7 and abs(state[2]) < 0.2
+    return q, qd, hopper_observe(q, qd), reward, not notdone
+
+
+def hopper_to_engine_state(qpos, qvel):
+    sgn = np.concatenate([[1.0, 1.0, 1.0], HOPPER.sign])
     return np.concatenate([qpos * sgn, qvel * sgn])

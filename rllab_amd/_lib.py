@@ -20,6 +20,7 @@ ENV_SWIMMER = 2
 ENV_HALF_CHEETAH = 3
 ENV_CARTPOLE_SWINGUP = 4
 ENV_WALKER2D = 5
+ENV_HOPPER = 6
 
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -599,6 +599,39 @@ struct PlanarTree {
         for (int i = 0; i < NB; ++i) rl_rotate_small(sn[i], cs[i], h * om[i]);
     }
 
+    // Generalised force of the model's CONSTRAINT-like terms (external contact wrenches + joint-limit penalties) on the
+    // tree's coordinates [P1, P2, root hinge, hinges 1..NB-1] at (q, qd): the analogue of MuJoCo's data.qfrc_constraint
+    // that some envs observe (hopper_env.py:44).  Hinge i collects the moment about its anchor of every wrench in its
+    // subtree; the translations collect the force sums.
+    template <typename R>
+    RL_HD static void constraint_forces(const R* q, const R* qd, R* qf) {
+        PlanarKin<R, NB> k;
+        kinematics(q, qd, k);
+        R fx[NB], fy[NB], tz[NB];
+        Mdl::template external<R>(q, k, fx, fy, tz);
+        R sx = (R)0, sy = (R)0;
+        RL_UNROLL
+        for (int b = 0; b < NB; ++b) { sx = sx + fx[b]; sy = sy + fy[b]; }
+        qf[0] = sx;
+        qf[1] = sy;
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            R m = (R)0;
+            static_for<i, NB>([&](auto B) {
+                constexpr int b = decltype(B)::value;
+                if constexpr (is_ancestor(i, b))
+                    m = m + (tz[b] + ((k.px[b] - k.ax[i]) * fy[b] - (k.py[b] - k.ay[i]) * fx[b]));
+            });
+            if constexpr (i >= 1 && Mdl::limited(i)) {
+                const R x = q[2 + i], v = qd[2 + i];
+                const R viol = x - rl_clamp(x, (R)Mdl::lo(i), (R)Mdl::hi(i));
+                const R damp = (viol != (R)0) ? (R)Mdl::limit_b() * v : (R)0;
+                m = m - (R)Mdl::limit_k() * viol - damp;
+            }
+            qf[2 + i] = m;
+        });
+    }
+
     // subtree(root) centre of mass (world) and its velocity
     template <typename R>
     RL_HD static void com(const R* q, const R* qd, R& cx, R& cy, R& vx, R& vy) {

@@ -19,64 +19,13 @@
 // State (18 reals, tree convention): q[9] = [z (absolute torso height = MuJoCo's rootz, ref 1.25), x,
 // rooty, thigh, leg, foot, thigh_left, leg_left, foot_left], qd[9].
 #pragma once
-#include "dyn_planar.h"
+#include "dyn_legged.h"
 #include "walker_constants.h"
 
 namespace rl {
 
-struct WalkerModel {
-    static constexpr int NB = walker::NB;
-    RL_HD static constexpr int parent(int i) { return walker::PARENT[i]; }
-    RL_HD static constexpr double jx(int i) { return walker::JX[i]; }
-    RL_HD static constexpr double jy(int i) { return walker::JY[i]; }
-    RL_HD static constexpr double cx(int i) { return walker::CX[i]; }
-    RL_HD static constexpr double cy(int i) { return walker::CY[i]; }
-    RL_HD static constexpr double mass(int i) { return walker::MASS[i]; }
-    RL_HD static constexpr double inertia(int i) { return walker::INERTIA[i]; }
-    RL_HD static constexpr double armature(int i) { return walker::ARMATURE[i]; }
-    RL_HD static constexpr double damping(int i) { return walker::DAMPING[i]; }
-    RL_HD static constexpr double stiffness(int i) { return walker::STIFFNESS[i]; }
-    RL_HD static constexpr bool limited(int i) { return i >= 1; }
-    RL_HD static constexpr double lo(int i) { return walker::LO[i]; }
-    RL_HD static constexpr double hi(int i) { return walker::HI[i]; }
-    RL_HD static constexpr double limit_k() { return 2.0e3; }
-    RL_HD static constexpr double limit_b() { return 15.0; }
-    RL_HD static constexpr double gx() { return -9.81; }  // gravity along -z = -P1
-    RL_HD static constexpr double gy() { return 0.0; }
-
-    static constexpr double CONTACT_K = 2.0e4;   // N/m per end sphere
-    static constexpr double CONTACT_B = 3.0e2;   // N s/m while penetrating
-    static constexpr double FRICTION_C = 3.0e2;  // N s/m tangential, clamped to mu * f_n
-
-    // capsule end spheres against the floor z = 0
-    template <typename R>
-    RL_HD static void external(const R* q, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) { fx[i] = (R)0; fy[i] = (R)0; tz[i] = (R)0; }
-        RL_UNROLL
-        for (int c = 0; c < walker::NC; ++c) {
-            const int b = walker::CBODY[c];
-            const R lx = (R)walker::CPX[c], ly = (R)walker::CPY[c], rad = (R)walker::CRADS[c];
-            const R rx = k.cs[b] * lx - k.sn[b] * ly;   // sphere centre relative to the body anchor
-            const R ry = k.sn[b] * lx + k.cs[b] * ly;
-            const R depth = rad - (q[0] + k.ax[b] + rx);
-            if (depth > (R)0) {
-                const R vn = k.vax[b] - k.om[b] * ry;   // velocity of the sphere centre
-                const R vt = k.vay[b] + k.om[b] * rx;
-                R fn = (R)CONTACT_K * depth - (R)CONTACT_B * vn;
-                fn = rl_max(fn, (R)0);
-                const R mu = (R)walker::CMU[c];
-                const R ft = -rl_clamp((R)FRICTION_C * vt, -mu * fn, mu * fn);
-                // applied at the lowest point of the sphere; lever arm from the body COM
-                const R ax_ = (k.ax[b] + rx - rad) - k.px[b];
-                const R ay_ = (k.ay[b] + ry) - k.py[b];
-                fx[b] = fx[b] + fn;
-                fy[b] = fy[b] + ft;
-                tz[b] = tz[b] + (ax_ * ft - ay_ * fn);
-            }
-        }
-    }
-};
+RL_LEGGED_CONSTANTS(WalkerK, walker);
+using WalkerModel = LeggedModel<WalkerK>;   // joint limits + capsule-floor contacts: dyn_legged.h
 
 struct Walker2D {
     static constexpr int OBS = 21;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Derive the rigid-body constants of the planar MuJoCo-style models from the numbers of their MJCF files
-(reference: vendor/mujoco_models/half_cheetah.xml, walker2d.xml) and write <name>_constants.h.
+(reference: vendor/mujoco_models/half_cheetah.xml, walker2d.xml, hopper.xml) and write <name>_constants.h.
 
 Plane mapping: the models move in MuJoCo's x-z plane.  The planar tree of dyn_planar.h uses CCW-positive
 angles, so plane coordinates are (P1, P2) = (z, x): a +y rotation takes z towards x, i.e. P1 towards
@@ -62,6 +62,26 @@ WALKER2D = dict(
     legacy_layout=False,
 )
 
+HOPPER = dict(
+    name="hopper", total_mass=None, density=1000.0, xml="hopper.xml",
+    # hopper.xml:3-7,21-40 (coordinate="global": torso origin (0, 1.25); hinges thigh (0, 1.05), leg (0, 0.6),
+    # foot (0, 0.1); capsules torso (0,1.45)-(0,1.05) r .05, thigh (0,1.05)-(0,.6) r .05, leg (0,.6)-(0,.1) r .04,
+    # foot (-.13,.1)-(.26,.1) r .06; friction .9, foot 2.0); joints: damping 1, armature 1, hinges about -y
+    bodies=[
+        ("torso", -1, (0.0, 0.0), [(0.0, 0.0, 0.0, 0.2, 0.05, 0.9)]),
+        ("thigh", 0, (0.0, -0.2), [(0.0, -0.225, 0.0, 0.225, 0.05, 0.9)]),
+        ("leg", 1, (0.0, -0.45), [(0.0, -0.25, 0.0, 0.25, 0.04, 0.9)]),
+        ("foot", 2, (0.0, -0.5), [(0.065, 0.0, "x", 0.195, 0.06, 2.0)]),
+    ],
+    # ranges -150..0 / -150..0 / -45..45 degrees and ctrlrange +-200 are MuJoCo's; the tree's coordinate is the
+    # negative (SIGN = -1), so lo/hi below are already mapped: [-hi_mj, -lo_mj]
+    joints={
+        "thigh": (0, 1.0, 0.0, 150 * _D, 200, 1.0, -1), "leg": (0, 1.0, 0.0, 150 * _D, 200, 1.0, -1),
+        "foot": (0, 1.0, -45 * _D, 45 * _D, 200, 1.0, -1),
+    },
+    legacy_layout=False,
+)
+
 
 def capsule(half_len, r, rho):
     L = 2 * half_len
@@ -109,7 +129,7 @@ def emit(model):
     def j(k, d):
         return ", ".join("%.17g" % (joints[n][k] if n in joints else d) for n in names)
     src = "gen_cheetah_constants.py" if model["legacy_layout"] else "gen_planar_constants.py"
-    xml = "half_cheetah.xml" if ns == "cheetah" else "walker2d.xml"
+    xml = model.get("xml") or ("half_cheetah.xml" if ns == "cheetah" else "walker2d.xml")
     lines = [
         "// GENERATED by %s from the numbers of vendor/mujoco_models/%s." % (src, xml),
         "// Plane coordinates (P1, P2) = (z, x): +y hinge rotation = CCW.  Do not edit by hand.",
@@ -156,7 +176,7 @@ def emit(model):
 
 
 def main():
-    for model in (HALF_CHEETAH, WALKER2D):
+    for model in (HALF_CHEETAH, WALKER2D, HOPPER):
         print(emit(model))
 
 

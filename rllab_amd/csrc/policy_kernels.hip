@@ -663,11 +663,13 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     NETCASE(4, 1, 32)    // Cartpole
     NETCASE(6, 1, 32)    // DoublePendulum
     NETCASE(13, 2, 32)   // Swimmer
+    NETCASE(20, 3, 32)   // Hopper
     NETCASE(20, 6, 32)   // HalfCheetah
     NETCASE(21, 6, 32)   // Walker2D
     NETCASE(4, 1, 64)
     NETCASE(6, 1, 64)
     NETCASE(13, 2, 64)
+    NETCASE(20, 3, 64)
     NETCASE(20, 6, 64)
     NETCASE(21, 6, 64)
 #undef NETCASE

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(4, 1, 32), (13, 2, 32), (13, 2, 64), (20, 6, 32), (20, 6, 64), (21, 6, 64)]
+SHAPES = [(4, 1, 32), (13, 2, 32), (13, 2, 64), (20, 3, 32), (20, 6, 32), (20, 6, 64), (21, 6, 64)]
 
 
 def _policy(do, da, h, seed=0):

@@ -356,3 +356,75 @@ def test_swimmer_lane_group_program_is_bitwise_the_scalar_program(dtype, nsub):
         a, b = H.swim_quad_compare(state, ctrl, nsub, dtype)
         assert np.all(np.isfinite(a))
         assert a.tobytes() == b.tobytes(), (trial, a, b)
+
+
+def test_hopper_dynamics_vs_independent_lagrangian():
+    """Hopper-style env (kind 6): one env step (8 sub-steps) of the product's dynamics source, float64 host build,
+    equals the model-driven autodiff-Lagrangian oracle typed in from hopper.xml in MuJoCo's coordinates -- foot on
+    the floor, joints beyond their range, armature 1, dampers, gravity, clipped torques -- including the observed
+    qfrc_constraint analogue (generalised force of the contact and joint-limit penalties)."""
+    import torch
+    from oracle import np_planar as P
+    rng = np.random.RandomState(0)
+    e = H.HostEnv(6, np.float64, normalize=True)
+    z = rng.randn(12)
+    o = e.reset(z)
+    qp, qv = P.hopper_reset(z)
+    assert o.shape == (20,)
+    assert np.abs(e.state - P.hopper_to_engine_state(qp, qv)).max() < 1e-15
+    assert np.abs(o - P.hopper_observe(qp, qv)).max() < 1e-10
+    n_contact = 0
+    for trial in range(4):
+        qp = np.concatenate([[rng.uniform(1.10, 1.22)], rng.randn(1), rng.uniform(-.1, .1, 1),
+                             rng.uniform(-0.3, 0.2, 2), rng.uniform(-1, 1, 1)])
+        qv = rng.randn(6) * 2
+        pts, _, rads, _ = P.HOPPER.contact_points(torch.as_tensor(qp))
+        n_contact += int((pts[1::2].numpy() < np.array(rads)).sum())
+        e.state[:] = P.hopper_to_engine_state(qp, qv)
+        a = rng.randn(3) * (0.2 if trial == 0 else 1.0)
+        o, r, d = e.step(a)
+        qp2, qv2, o2, r2, d2 = P.hopper_step(qp, qv, a)
+        assert np.abs(e.state - P.hopper_to_engine_state(qp2, qv2)).max() < 1e-8
+        assert np.abs(o - o2).max() < 1e-8 and abs(r - r2) < 1e-9 and d == d2
+    assert n_contact >= 2
+    # the constraint-force observation below its +-10 clip: a foot resting 0.1 mm inside the floor, a knee 1 mrad
+    # beyond its range
+    qp = np.array([1.25, 0.3, 0.0, 0.0, 0.001, 0.0])
+    pts, _, rads, _ = P.HOPPER.contact_points(torch.as_tensor(qp))
+    qp[0] -= float((pts[1::2].numpy() - np.array(rads)).min()) + 1e-4
+    qv = np.array([0.0, 0.01, 0.0, 0.0, 0.02, 0.0])
+    e.state[:] = P.hopper_to_engine_state(qp, qv)
+    o = e.observe()
+    want = P.hopper_observe(qp, qv)
+    assert np.abs(o - want).max() < 1e-9
+    assert 0.5 < np.abs(want[11:17]).max() < 10.0 and np.count_nonzero(want[11:17]) >= 4
+    hdr = open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
+        __import__("os").path.abspath(__file__))), "rllab_amd", "csrc", "hopper_constants.h")).read()
+    masses = [float(x) for x in hdr.split("MASS[NB] = {")[1].split("}")[0].split(",")]
+    inertias = [float(x) for x in hdr.split("INERTIA[NB] = {")[1].split("}")[0].split(",")]
+    assert np.allclose(masses, [b[0] for b in P.HOPPER.const], rtol=1e-9)
+    assert np.allclose(inertias, [b[1] for b in P.HOPPER.const], rtol=1e-8)
+
+
+def test_hopper_done_reward_and_f32_tracking():
+    rng = np.random.RandomState(3)
+    e32, e64 = H.HostEnv(6, np.float32, normalize=True), H.HostEnv(6, np.float64, normalize=True)
+    z = rng.randn(12).astype(np.float32)
+    e32.reset(z)
+    e64.reset(z.astype(np.float64))
+    for t in range(10):
+        a = (rng.randn(3) * 0.05).astype(np.float32)
+        o32, r32, d32 = e32.step(a)
+        o64, r64, d64 = e64.step(a.astype(np.float64))
+        # the clipped contact force switches on within one f32 ulp of penetration: compare it loosely
+        kin = np.r_[0:11, 17:20]
+        assert np.abs(o32[kin] - o64[kin]).max() < 2e-3 * max(1.0, np.abs(o64[kin]).max()), t
+        assert abs(r32 - r64) < 2e-3 and d32 == d64, t
+    # alive bonus: standing still earns ~1 per step; a random policy falls:
+    # done = height <= 0.7 or |pitch| >= 0.2 or a runaway coordinate (hopper_env.py:56-60)
+    d = False
+    for t in range(400):
+        o, r, d = e64.step(rng.randn(3))
+        if d:
+            break
+    assert d and not (o[0] > 0.7 and abs(o[1]) < 0.2)
