@@ -38,6 +38,9 @@ def make_env(name):
     if name == "hopper":
         from rllab.envs.mujoco.hopper_env import HopperEnv
         return normalize(HopperEnv()), 500
+    if name == "inverted_double_pendulum":
+        from rllab.envs.mujoco.inverted_double_pendulum_env import InvertedDoublePendulumEnv
+        return normalize(InvertedDoublePendulumEnv()), 100
     if name == "double_pendulum":
         from rllab.envs.box2d.double_pendulum_env import DoublePendulumEnv
         return normalize(DoublePendulumEnv()), 100

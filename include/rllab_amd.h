@@ -33,7 +33,8 @@ enum rl_env_kind {
     RL_ENV_HALF_CHEETAH = 3,     /* rllab/envs/mujoco/half_cheetah_env.py:14-56 (cheetah-style planar tree) */
     RL_ENV_CARTPOLE_SWINGUP = 4, /* rllab/envs/box2d/cartpole_swingup_env.py:14-61 */
     RL_ENV_WALKER2D = 5,         /* rllab/envs/mujoco/walker2d_env.py:15-59 (walker-style planar biped) */
-    RL_ENV_HOPPER = 6            /* rllab/envs/mujoco/hopper_env.py:19-62 (hopper-style planar monoped) */
+    RL_ENV_HOPPER = 6,           /* rllab/envs/mujoco/hopper_env.py:19-62 (hopper-style planar monoped) */
+    RL_ENV_INVERTED_DOUBLE_PENDULUM = 7  /* rllab/envs/mujoco/inverted_double_pendulum_env.py:10-58 */
 };
 
 enum rl_status {

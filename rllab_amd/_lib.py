@@ -21,6 +21,7 @@ ENV_HALF_CHEETAH = 3
 ENV_CARTPOLE_SWINGUP = 4
 ENV_WALKER2D = 5
 ENV_HOPPER = 6
+ENV_INVERTED_DOUBLE_PENDULUM = 7
 
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -662,12 +662,14 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     if (d == DO && k == DA && h0 == H && h1 == H) return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st);
     NETCASE(4, 1, 32)    // Cartpole
     NETCASE(6, 1, 32)    // DoublePendulum
+    NETCASE(11, 1, 32)   // InvertedDoublePendulum
     NETCASE(13, 2, 32)   // Swimmer
     NETCASE(20, 3, 32)   // Hopper
     NETCASE(20, 6, 32)   // HalfCheetah
     NETCASE(21, 6, 32)   // Walker2D
     NETCASE(4, 1, 64)
     NETCASE(6, 1, 64)
+    NETCASE(11, 1, 64)
     NETCASE(13, 2, 64)
     NETCASE(20, 3, 64)
     NETCASE(20, 6, 64)

@@ -31,7 +31,7 @@ class FusedGaussianMLPOps(object):
         hs = tuple(getattr(policy, "hidden_sizes", ()))
         return (getattr(policy, "fusable", False) and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (32, 64)
                 and policy.flat_params.is_cuda and policy.learn_std
-                and (policy.obs_dim, policy.action_dim) in ((4, 1), (6, 1), (13, 2), (20, 3), (20, 6), (21, 6)))
+                and (policy.obs_dim, policy.action_dim) in ((4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6)))
 
     def accepts(self, inputs):
         """The kernels take ONE old log_std row (state-independent std)."""

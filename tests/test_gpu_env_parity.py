@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV_KINDS = [0, 1, 2, 3, 4, 5, 6]
+ENV_KINDS = [0, 1, 2, 3, 4, 5, 6, 7]
 OBS_INVERTIBLE = [0, 2, 4]   # kinds whose reset state can be rebuilt from the observation
 
 

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(4, 1, 32), (13, 2, 32), (13, 2, 64), (20, 3, 32), (20, 6, 32), (20, 6, 64), (21, 6, 64)]
+SHAPES = [(4, 1, 32), (11, 1, 32), (13, 2, 32), (13, 2, 64), (20, 3, 32), (20, 6, 32), (20, 6, 64), (21, 6, 64)]
 
 
 def _policy(do, da, h, seed=0):
@@ -44,6 +44,7 @@ def _inputs(pol, B, seed=1, ragged=True, old_equals_new=False):
     w = torch.ones(B, dtype=torch.float32, device=dev)
     if ragged:
         w[torch.as_tensor(rng.rand(B) < 0.1, device=dev)] = 0.0
+        w[0] = 1.0          # never an all-masked batch (1 / count would be inf)
     inv = 1.0 / w.double().sum()
     return (obs, act, adv, old_mean, old_ls.reshape(-1, 1), w, inv)
 

@@ -428,3 +428,50 @@ def test_hopper_done_reward_and_f32_tracking():
         if d:
             break
     assert d and not (o[0] > 0.7 and abs(o[1]) < 0.2)
+
+
+def test_inverted_double_pendulum_vs_independent_lagrangian():
+    """InvertedDoublePendulum-style env (kind 7): the closed-form cart + two-pole equations of motion of
+    csrc/dyn_idp.h (float64 host build) against an autodiff Lagrangian typed in again from the MJCF bodies, over
+    whole env steps from random states; reset / obs / reward / done contract of
+    inverted_double_pendulum_env.py:24-58."""
+    from oracle import np_idp as P
+    rng = np.random.RandomState(1)
+    e = H.HostEnv(7, np.float64, normalize=True)
+    u = 0.8
+    o = e.reset(np.array([u]))
+    qp, qv = P.reset(u)
+    assert o.shape == (11,) and np.abs(e.state - np.concatenate([qp, qv])).max() < 1e-15
+    assert abs(qp[1] - 0.3 * 40 / 180 * np.pi) < 1e-15 and np.abs(o - P.observe(qp, qv)).max() < 1e-12
+    for trial in range(5):
+        qp = np.array([rng.uniform(-1, 1), rng.uniform(-0.6, 0.6), rng.uniform(-0.8, 0.8)])
+        qv = rng.randn(3) * np.array([1.0, 2.0, 3.0])
+        if trial == 4:
+            qp[0], qv[0] = 10.003, 0.2          # beyond the slider range: the limit force is observed
+        e.state[:] = np.concatenate([qp, qv])
+        a = rng.uniform(-1.5, 1.5, 1)
+        o, r, d = e.step(a)
+        qp2, qv2, o2, r2, d2 = P.step(qp, qv, a)
+        assert np.abs(e.state - np.concatenate([qp2, qv2])).max() < 1e-9, trial
+        # (the limit force multiplies the position error by LIMIT_K = 2e3)
+        assert np.abs(o - o2).max() < 1e-8 and abs(r - r2) < 1e-9 and d == d2
+    assert abs(o[8]) > 1.0 and o[9] == 0 and o[10] == 0
+    # balanced start: tip at 1.2 m -> reward = 10 - (1.2 - 2)^2 = 9.36; left alone the poles fall and the episode
+    # ends (tip <= 1)
+    e.reset(np.array([0.5]))
+    o, r, d = e.step(np.zeros(1))
+    assert 9.35 < r <= 9.36 + 1e-9 and not d
+    e.reset(np.array([0.9]))
+    for t in range(200):
+        o, r, d = e.step(np.zeros(1))
+        if d:
+            break
+    assert d and t < 100
+    # float32 build tracks float64
+    e32 = H.HostEnv(7, np.float32, normalize=True)
+    e32.reset(np.array([0.3], np.float32)); e.reset(np.array([0.3]))
+    for t in range(10):
+        a = rng.uniform(-1, 1, 1).astype(np.float32)
+        o32, r32, d32 = e32.step(a)
+        o64, r64, d64 = e.step(a.astype(np.float64))
+        assert np.abs(o32 - o64).max() < 1e-4 and abs(r32 - r64) < 1e-4 and d32 == d64
