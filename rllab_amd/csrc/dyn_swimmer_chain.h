@@ -133,28 +133,32 @@ struct SwimChain {
             wgx[b] = w2[b] * Gx[b];
             wgy[b] = w2[b] * Gy[b];
         }
-        const R sgx = (wgx[0] + wgx[1]) + wgx[2];
-        const R sgy = (wgy[0] + wgy[1]) + wgy[2];
-        const R grx = (Fsx[0] + sgx) * (R)INV_M;
-        const R gry = (Fsy[0] + sgy) * (R)INV_M;
+        // total force + centripetal term, summed per body first (the lane-group program folds this sum with one
+        // butterfly; its fourth lane adds an exact zero)
+        const R grx = (((Fx[0] + wgx[0]) + (Fx[1] + wgx[1])) + (Fx[2] + wgx[2])) * (R)INV_M;
+        const R gry = (((Fy[0] + wgy[0]) + (Fy[1] + wgy[1])) + (Fy[2] + wgy[2])) * (R)INV_M;
         R bq[3];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) bq[b] = Q[b] - (Gx[b] * gry - Gy[b] * grx);
         // coupling to the cyclic partners and the rows of the 3x3 solve
-        R Sbp[3], Sbq[3], rb[3];
+        // one coupling per pair: body b evaluates (b, p); its coupling to q is pair (q, b) seen from the other side --
+        // S is symmetric bit for bit, the sine term changes sign
+        R Sbp[3], tp[3], rb[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) {
+            const int p = nxt(b);
+            couple(cs[b], sn[b], cs[p], sn[p], (R)scc(b, p), (R)acc(b, p), Sbp[b], tp[b]);
+        }
         RL_UNROLL
         for (int b = 0; b < 3; ++b) {
             const int p = nxt(b), q = nx2(b);
-            R tp, tq;
-            couple(cs[b], sn[b], cs[p], sn[p], (R)scc(b, p), (R)acc(b, p), Sbp[b], tp);
-            couple(cs[b], sn[b], cs[q], sn[q], (R)scc(b, q), (R)acc(b, q), Sbq[b], tq);
-            rb[b] = (bq[b] + w2[p] * tp) + w2[q] * tq;
+            rb[b] = (bq[b] + w2[p] * tp[b]) - w2[q] * tp[q];
         }
         R thb[3];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) {
             const int p = nxt(b), q = nx2(b);
-            thb[b] = solve_row((R)sdiag(b), (R)dpq(b), (R)sdiag(p), (R)sdiag(q), Sbp[b], Sbq[b], Sbp[p], rb[b], rb[p],
+            thb[b] = solve_row((R)sdiag(b), (R)dpq(b), (R)sdiag(p), (R)sdiag(q), Sbp[b], Sbp[q], Sbp[p], rb[b], rb[p],
                                rb[q]);
         }
         // translations
@@ -187,7 +191,7 @@ struct SwimChain {
     struct LaneConst {
         R jxo, cxb, db, visc_lin, drag_ax, drag_perp, visc_ang, drag_ang;
         R lim_k, lim_b;      // joint-limit penalty of the hinge that carries body b (roles 0 and 3: none)
-        R scp, acp, scq, acq;        // coupling constants to the partners p = b + 1, q = b + 2 (mod 3)
+        R scp, acp;                  // coupling constants to the partner p = b + 1 (mod 3)
         R d_b, d_pq, d_p, d_q;       // diagonal of the 3x3 system in the cyclic order (role 3: identity)
         int b;
     };
@@ -209,8 +213,6 @@ struct SwimChain {
         c.lim_b = hinge ? (R)Mdl::limit_b() : (R)0;
         c.scp = (R)(b == 0 ? scc(0, 1) : b == 1 ? scc(1, 2) : b == 2 ? scc(2, 0) : 0.0);
         c.acp = (R)(b == 0 ? acc(0, 1) : b == 1 ? acc(1, 2) : b == 2 ? acc(2, 0) : 0.0);
-        c.scq = (R)(b == 0 ? scc(0, 2) : b == 1 ? scc(1, 0) : b == 2 ? scc(2, 1) : 0.0);
-        c.acq = (R)(b == 0 ? acc(0, 2) : b == 1 ? acc(1, 0) : b == 2 ? acc(2, 1) : 0.0);
         c.d_b = (R)(b == 0 ? sdiag(0) : b == 1 ? sdiag(1) : b == 2 ? sdiag(2) : 1.0);
         c.d_pq = (R)(b == 0 ? dpq(0) : b == 1 ? dpq(1) : b == 2 ? dpq(2) : 1.0);
         c.d_p = (R)(b == 0 ? sdiag(1) : b == 1 ? sdiag(2) : b == 2 ? sdiag(0) : 0.0);
@@ -229,7 +231,6 @@ struct SwimChain {
     static constexpr int PAR1 = QP(3, 0, 1, 2), PAR2 = QP(3, 3, 0, 3);       // parent, grandparent (or the zero lane)
     static constexpr int SHL1 = QP(1, 2, 3, 3), SHL2 = QP(2, 3, 3, 3);       // child, grandchild (or the zero lane)
     static constexpr int NX1 = QP(1, 2, 0, 3), NX2 = QP(2, 0, 1, 3);         // cyclic partners p, q of body = lane
-    static constexpr int BC0 = QP(0, 0, 0, 0);
     static constexpr int SW1 = QP(1, 0, 3, 2), SW2 = QP(2, 3, 0, 1);         // butterfly
 
     template <typename R, class X>
@@ -264,19 +265,16 @@ struct SwimChain {
         const R w2 = s.om * s.om;
         const R wgx = w2 * Gx;
         const R wgy = w2 * Gy;
-        const R sgx = quad_sum(x, wgx);
-        const R sgy = quad_sum(x, wgy);
-        const R fs0x = x.template qp<BC0>(Fsx), fs0y = x.template qp<BC0>(Fsy);
-        const R grx = (fs0x + sgx) * (R)INV_M;
-        const R gry = (fs0y + sgy) * (R)INV_M;
+        const R grx = quad_sum(x, Fx + wgx) * (R)INV_M;
+        const R gry = quad_sum(x, Fy + wgy) * (R)INV_M;
         const R bq = Q - (Gx * gry - Gy * grx);
-        // coupling to the cyclic partners, own row of the solve
+        // coupling to the cyclic partner p; the pair (b, q) is partner q's own pair seen from the other side
         const R cp_ = x.template qp<NX1>(s.cs), sp_ = x.template qp<NX1>(s.sn), w2p = x.template qp<NX1>(w2);
-        const R cq_ = x.template qp<NX2>(s.cs), sq_ = x.template qp<NX2>(s.sn), w2q = x.template qp<NX2>(w2);
-        R Sbp, Sbq, tp, tq;
+        const R w2q = x.template qp<NX2>(w2);
+        R Sbp, tp;
         couple(s.cs, s.sn, cp_, sp_, c.scp, c.acp, Sbp, tp);
-        couple(s.cs, s.sn, cq_, sq_, c.scq, c.acq, Sbq, tq);
-        const R rb = (bq + w2p * tp) + w2q * tq;
+        const R Sbq = x.template qp<NX2>(Sbp), tqn = x.template qp<NX2>(tp);
+        const R rb = (bq + w2p * tp) - w2q * tqn;
         const R Spq = x.template qp<NX1>(Sbp);
         const R rp = x.template qp<NX1>(rb), rq = x.template qp<NX2>(rb);
         const R thb = solve_row(c.d_b, c.d_pq, c.d_p, c.d_q, Sbp, Sbq, Spq, rb, rp, rq);

@@ -197,6 +197,147 @@ struct RolloutPolicy {
     }
 };
 
+// The same network for the lane-group rollouts (16 envs per wavefront, env e replicated on lanes e + 16 g):
+// v_mfma_f32_16x16x4_f32 tiles, Z^T[unit][env] = W^T[unit][k] X^T[k][env] with N = the 16 envs, so nothing is
+// computed twice across the four replicas -- lane group g supplies input row 4 m + g at k-step m and receives
+// units 16 t + 4 g + j (j = register) of output tile t, which after tanh are again one k-row per register of the
+// next layer.  Half the matrix passes and half the tanh of the 32x32x2 form; all weight fragments, biases and
+// output-layer columns are loop invariant and live in VGPRs (one wavefront per SIMD owns 512 registers), so the
+// policy touches no LDS at all.  The DA output columns are per-lane dot products over the lane's 4 NT units,
+// folded across the lane groups with v_permlane32_swap / v_permlane16_swap (two columns share one fold).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_permlane32_swap: lanes [32,64) of a <-> lanes [0,32) of b, i.e. a' = [a.lo | b.lo], b' = [a.hi | b.hi];
+// v_permlane16_swap: odd rows of a <-> even rows of b, a' = [a.r0 b.r0 a.r2 b.r2], b' = [a.r1 b.r1 a.r3 b.r3].
+// Inline asm: this compiler's __builtin_amdgcn_permlane{16,32}_swap returns element 0 for both results.  The
+// s_nop covers the VALU-write -> permlane-read hazard the assembler does not see inside an asm block.
+__device__ __forceinline__ void swap32(float a, float b, float& r0, float& r1) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r0 = a;
+    r1 = b;
+}
+__device__ __forceinline__ void swap16(float a, float b, float& r0, float& r1) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r0 = a;
+    r1 = b;
+}
+// sum over the four lanes e, e + 16, e + 32, e + 48, result on all of them
+__device__ __forceinline__ float group_sum(float v) {
+    float a, b;
+    swap32(v, v, a, b);
+    const float s = a + b;
+    swap16(s, s, a, b);
+    return a + b;
+}
+// the same for two values at the price of one: returns sum(v0) and sum(v1) on every lane
+__device__ __forceinline__ void group_sum2(float v0, float v1, float& s0, float& s1) {
+    float a, b;
+    swap32(v0, v1, a, b);            // a = [v0.lo | v1.lo], b = [v0.hi | v1.hi]
+    const float h = a + b;           // lanes < 32: v0 folded over the halves, lanes >= 32: v1
+    swap16(h, h, a, b);
+    const float q = a + b;           // folded over the rows of each half
+    swap32(q, q, s0, s1);            // low half everywhere, high half everywhere
+}
+
+template <class Env, int H>
+struct RolloutPolicy16 {
+    using N = Net<Env::OBS, Env::ACT, H>;
+    static constexpr int DO = Env::OBS, DA = Env::ACT;
+    static constexpr int NT = H / 16;                  // 16-unit tiles per hidden layer
+    static constexpr int KS0 = (DO + 1 + 3) / 4;       // k-steps of layer 0 (inputs + the bias slot)
+    static constexpr int KS1 = H / 4;                  // k-steps of layer 1: step 4 t + j feeds register j of tile t
+
+    float a0[NT][KS0];      // W0[4 m + g][16 t + n]  (row DO = b0, rows beyond = 0)
+    float a1[NT][KS1];      // W1[16 (s / 4) + 4 g + s % 4][16 t + n]
+    float b1[NT][4];        // b1[16 t + 4 g + j]
+    float w2[DA][NT][4];    // W2[16 t + 4 g + j][k]
+    float b2[DA], lstd[DA];
+    bool g0, g1, g2;
+
+    __device__ __forceinline__ void init(const float* __restrict__ th) {
+        const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
+        g0 = g == 0; g1 = g == 1; g2 = g == 2;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int m = 0; m < KS0; ++m) {
+                const int d = 4 * m + g, u = 16 * t + n;
+                a0[t][m] = d < DO ? th[N::W0 + d * H + u] : (d == DO ? th[N::B0 + u] : 0.0f);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KS1; ++s_)
+                a1[t][s_] = th[N::W1 + (16 * (s_ / 4) + 4 * g + s_ % 4) * H + 16 * t + n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b1[t][j] = th[N::B1 + 16 * t + 4 * g + j];
+#pragma unroll
+                for (int k = 0; k < DA; ++k) w2[k][t][j] = th[N::W2 + (16 * t + 4 * g + j) * DA + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            b2[k] = th[N::B2 + k];
+            lstd[k] = th[N::LSTD + k];
+        }
+    }
+
+    __device__ __forceinline__ float log_std(int k) const { return lstd[k]; }
+
+    __device__ __forceinline__ float pick(float c0, float c1, float c2, float c3) const {
+        return g0 ? c0 : g1 ? c1 : g2 ? c2 : c3;
+    }
+    static __device__ __forceinline__ float input(const float* o, int d) {
+        return d < DO ? o[d] : (d == DO ? 1.0f : 0.0f);
+    }
+
+    // o: the observation of this lane's env (identical on its four replicas); mean: its action mean, on all four
+    __device__ __forceinline__ void forward16(const float* o, float* mean) const {
+        float xb[KS0];
+#pragma unroll
+        for (int m = 0; m < KS0; ++m)
+            xb[m] = pick(input(o, 4 * m), input(o, 4 * m + 1), input(o, 4 * m + 2), input(o, 4 * m + 3));
+        f32x4 h0[NT], h1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < KS0; ++m) acc = mfma16(a0[t][m], xb[m], acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h0[t][j] = ftanh(acc[j]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 acc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = b1[t][j];
+#pragma unroll
+            for (int s_ = 0; s_ < KS1; ++s_) acc = mfma16(a1[t][s_], h0[s_ / 4][s_ % 4], acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h1[t][j] = ftanh(acc[j]);
+        }
+        float pm[DA];
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            pm[k] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pm[k] = __builtin_fmaf(h1[t][j], w2[k][t][j], pm[k]);
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < DA; k += 2) {
+            float s0, s1;
+            group_sum2(pm[k], pm[k + 1], s0, s1);
+            mean[k] = b2[k] + s0;
+            mean[k + 1] = b2[k + 1] + s1;
+        }
+        if (DA & 1) mean[DA - 1] = b2[DA - 1] + group_sum(pm[DA - 1]);
+    }
+};
+
 struct RolloutDev {
     int n, T, max_path_length, normalize, reset_at_start, env_offset;
     float scale_reward, log_min_std;
@@ -315,10 +456,9 @@ template <int H>
 __global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev a) {
     using Env = Swimmer;
     using Chain = Env::Chain;
-    using Pol = RolloutPolicy<Env, H>;
-    __shared__ __attribute__((aligned(16))) float smem[Pol::LDS_FLOATS];
+    using Pol = RolloutPolicy16<Env, H>;
     Pol pol;
-    pol.init(smem, a.theta);
+    pol.init(a.theta);
 
     const int n = a.n, T = a.T;
     const int lane = threadIdx.x;
@@ -391,6 +531,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev 
             ls.th = (b == 0) ? g[2] : (b == 1) ? g[3] : (b == 2) ? g[4] : 0.0f;
             rl_sincos(phi, ls.sn, ls.cs);
             const float lact = (b == 1) ? g[10] : (b == 2) ? g[11] : 0.0f;
+#pragma unroll 5
             for (int it = 0; it < Env::FRAME_SKIP; ++it)
                 Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
             // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's)
