@@ -262,6 +262,18 @@ int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p
 int rl_cg_step(int n, const double* fvp, double reg_coeff, double residual_tol, double* x, double* r,
                double* p, float* p32, double* scal, void* stream);
 
+/* The step ConjugateGradientOptimizer.optimize forms after CG
+ * (rllab/optimizers/conjugate_gradient_optimizer.py:257-262), float64, one launch:
+ *   xHx = x . (fvp_x + reg_coeff x);  beta = sqrt(2 max_constraint * (1 / (xHx + 1e-8)))  (NaN -> 1);
+ *   step = beta x;  out = {xHx, beta}.   fvp_x = F x from rl_policy_fvp (summed over ranks). */
+int rl_trpo_step(int n, const double* x, const double* fvp_x, double reg_coeff, double max_constraint,
+                 double* step, double* out, void* stream);
+
+/* One candidate of its backtracking line search (:266-274): theta = (float)(prev - ratio * step),
+ * prev: float[n] (the parameters before the update), step: double[n], theta: float[n]. */
+int rl_line_search_point(int n, const float* prev, const double* step, double ratio, float* theta,
+                         void* stream);
+
 /* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
  * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */
 int rl_debug_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

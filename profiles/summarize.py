@@ -3,6 +3,9 @@
 
 usage: summarize.py stats <dir> <out.csv>      -- kernel-trace: calls, total/avg/min/max ns per kernel
        summarize.py pmc   <dir> <out.csv>      -- counter collection: per-kernel mean of each counter
+       summarize.py timeline <dir> <out.csv>   -- kernel-trace: every dispatch of the LAST rollout-to-rollout
+                                                  interval (one iteration) with its start offset, duration
+                                                  and the idle gap before it
 """
 import csv
 import glob
@@ -27,6 +30,33 @@ def stats(d, out):
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"])
         for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([short(k), len(v), sum(v), sum(v) // len(v), min(v), max(v), "%.2f" % (100.0 * sum(v) / tot)])
+
+
+def timeline(d, out):
+    ev = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    ev.sort()
+    starts = [i for i, e in enumerate(ev) if "rollout_" in e[2]]
+    if len(starts) < 2:
+        return
+    # the last complete iteration the bench timed: second-to-last rollout .. last rollout
+    i0, i1 = starts[-2], starts[-1]
+    t0 = ev[i0][0]
+    busy = idle = 0
+    with open(out, "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["start_us", "dur_us", "gap_before_us", "kernel"])
+        prev_end = t0
+        for s_, e_, k in ev[i0:i1]:
+            gap = max(0, s_ - prev_end)
+            w.writerow(["%.1f" % ((s_ - t0) / 1e3), "%.1f" % ((e_ - s_) / 1e3), "%.1f" % (gap / 1e3), short(k)[:70]])
+            busy += e_ - s_
+            idle += gap
+            prev_end = max(prev_end, e_)
+        w.writerow(["%.1f" % ((ev[i1][0] - t0) / 1e3), "", "%.1f" % (max(0, ev[i1][0] - prev_end) / 1e3), "next rollout"])
+        w.writerow(["# busy_us=%.1f idle_us=%.1f" % (busy / 1e3, (idle + max(0, ev[i1][0] - prev_end)) / 1e3)])
 
 
 def pmc(d, out):
@@ -67,4 +97,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(*sys.argv[2:])
     else:
-        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+        {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -22,7 +22,12 @@ def npo_inputs(policy, samples_data):
     traj = samples_data["_traj"]
     B = traj.B
     w = traj.valid.reshape(B).to(torch.float32)
-    cnt = D.all_reduce_sum_(w.to(torch.float64).sum())
+    if getattr(traj, "count", None) is not None:
+        # process_samples already read the global number of valid samples (rl_sample_stats): no second
+        # reduction + blocking read for 1 / W
+        cnt = torch.tensor(float(traj.count), dtype=torch.float64)
+    else:
+        cnt = D.all_reduce_sum_(w.to(torch.float64).sum())
     old_ls = traj.log_std.reshape(-1, 1) if traj.log_std_planes is None \
         else traj.log_std_planes.reshape(traj.act_dim, B)
     return (traj.obs.reshape(traj.obs_dim, B), traj.actions.reshape(traj.act_dim, B),
@@ -81,9 +86,13 @@ class NPO(BatchPolopt):
 
     def optimize_policy(self, itr, samples_data):
         all_input_values = npo_inputs(self.policy, samples_data)
-        loss_before = self.optimizer.loss(all_input_values)
-        mean_kl_before = self.optimizer.constraint_val(all_input_values)
-        self.optimizer.optimize(all_input_values)
+        if getattr(self.optimizer, "reports_before_values", False):
+            self.optimizer.optimize(all_input_values)
+            loss_before, mean_kl_before = self.optimizer.last_before
+        else:
+            loss_before = self.optimizer.loss(all_input_values)
+            mean_kl_before = self.optimizer.constraint_val(all_input_values)
+            self.optimizer.optimize(all_input_values)
         mean_kl = self.optimizer.constraint_val(all_input_values)
         loss_after = self.optimizer.loss(all_input_values)
         logger.record_tabular('LossBefore', loss_before)

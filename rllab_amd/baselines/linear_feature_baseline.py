@@ -16,8 +16,40 @@ from rllab_amd.baselines.base import Baseline
 
 class LinearFeatureBaseline(Baseline):
     def __init__(self, env_spec, reg_coeff=1e-5):
-        self._coeffs = None
+        self._coeffs_value = None
+        self._pending = None       # (HostRead of the packed normal equations, F) of a dense fit not solved yet
         self._reg_coeff = reg_coeff
+
+    # The dense fit only LAUNCHES the normal-equation kernels and starts reading their (F + 1) x F result back; the
+    # small host solve runs when the coefficients are first asked for -- in the training loop that is the next
+    # iteration's prediction, i.e. while the next rollout occupies the device -- so neither the read nor the
+    # lstsq sits between process_samples and the policy update.
+    @property
+    def _coeffs(self):
+        if self._pending is not None:
+            read, F = self._pending
+            self._pending = None
+            host = read.get()
+            self._coeffs_value = self._solve(host[:F * F].reshape(F, F), host[F * F:])
+        return self._coeffs_value
+
+    @_coeffs.setter
+    def _coeffs(self, value):
+        self._pending = None
+        self._coeffs_value = value
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_coeffs_value"] = self._coeffs      # solve what is pending; handles do not pickle
+        d["_pending"] = None
+        return d
+
+    def __setstate__(self, d):
+        d = dict(d)
+        if "_coeffs" in d:                     # snapshots written before the fit became asynchronous
+            d["_coeffs_value"] = d.pop("_coeffs")
+        d.setdefault("_pending", None)
+        self.__dict__.update(d)
 
     def get_param_values(self, **tags):
         return self._coeffs
@@ -88,7 +120,7 @@ class LinearFeatureBaseline(Baseline):
                 tin = path_scan(traj, True, None, want_values=False)[0]
             valid = traj.valid if traj.valid is not None else torch.ones((traj.T, traj.N), dtype=torch.bool,
                                                                          device=traj.device)
-            valid_u8 = valid.to(torch.uint8).contiguous()
+            valid_u8 = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous()
             ws = _workspace(traj.device, traj.obs_dim)
             packed = torch.empty((F + 1) * F, dtype=torch.float64, device=traj.device)
             _lib.check(_lib.lib.rl_lfb_normal_eq(traj.B, traj.obs_dim, _lib.ptr(traj.obs), _lib.ptr(tin),
@@ -103,5 +135,6 @@ class LinearFeatureBaseline(Baseline):
             packed = torch.cat([(phi_w @ phi.t()).reshape(-1), phi_w @ y])
         if all_reduce is not None:
             all_reduce(packed)
-        host = packed.cpu().numpy()
-        self._coeffs = self._solve(host[:F * F].reshape(F, F), host[F * F:])
+        from rllab_amd.misc.device_io import read_async
+        self._coeffs_value = None
+        self._pending = (read_async(packed), F)

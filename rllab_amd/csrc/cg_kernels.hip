@@ -102,9 +102,62 @@ __global__ void __launch_bounds__(CG_THREADS) cg_step_kernel(int n, const double
     }
 }
 
+// After CG (conjugate_gradient_optimizer.py:257-262):  xHx = x . (F x + reg x),
+// beta = sqrt(2 delta * (1 / (xHx + 1e-8)))  (NaN -> 1),  step = beta x.   out = {xHx, beta}
+__global__ void __launch_bounds__(CG_THREADS) trpo_step_kernel(int n, const double* __restrict__ x,
+                                                               const double* __restrict__ fx, double reg,
+                                                               double delta, double* __restrict__ step,
+                                                               double* __restrict__ out) {
+    __shared__ double scratch[CG_THREADS / 64];
+    double xv[CG_MAX_PER_THREAD];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CG_THREADS;
+        if (i < n) {
+            xv[k] = x[i];
+            acc += xv[k] * (fx[i] + reg * xv[k]);
+        }
+    }
+    const double xHx = block_sum(acc, scratch);
+    double beta = sqrt(2.0 * delta * (1.0 / (xHx + 1e-8)));
+    if (beta != beta) beta = 1.0;
+#pragma unroll
+    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CG_THREADS;
+        if (i < n) step[i] = beta * xv[k];
+    }
+    if (threadIdx.x == 0) { out[0] = xHx; out[1] = beta; }
+}
+
+// one candidate of the backtracking line search (:266-274): theta = (float)(prev - ratio * step)
+__global__ void __launch_bounds__(256) line_search_point_kernel(int n, const float* __restrict__ prev,
+                                                                const double* __restrict__ step, double ratio,
+                                                                float* __restrict__ theta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) theta[i] = (float)((double)prev[i] - ratio * step[i]);
+}
+
 }  // namespace rl
 
 using namespace rl;
+
+extern "C" int rl_trpo_step(int n, const double* x, const double* fvp_x, double reg_coeff, double max_constraint,
+                            double* step, double* out, void* stream) {
+    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !x || !fvp_x || !step || !out)
+        return set_error(RL_ERR_ARG, "rl_trpo_step: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
+    hipLaunchKernelGGL(trpo_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, x, fvp_x, reg_coeff,
+                       max_constraint, step, out);
+    return check_launch("trpo_step_kernel");
+}
+
+extern "C" int rl_line_search_point(int n, const float* prev, const double* step, double ratio, float* theta,
+                                    void* stream) {
+    if (n <= 0 || !prev || !step || !theta) return set_error(RL_ERR_ARG, "rl_line_search_point: bad argument");
+    hipLaunchKernelGGL(line_search_point_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, prev,
+                       step, ratio, theta);
+    return check_launch("line_search_point_kernel");
+}
 
 extern "C" int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p32, double* scal,
                           void* stream) {

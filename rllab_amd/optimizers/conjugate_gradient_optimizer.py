@@ -107,6 +107,10 @@ class FiniteDifferenceHvp(Serializable):
 
 
 class ConjugateGradientOptimizer(Serializable):
+    # optimize() evaluates loss and constraint at the starting point anyway and keeps them in ``last_before``:
+    # NPO logs LossBefore / MeanKLBefore from there instead of paying two extra blocking reads up front
+    reports_before_values = True
+
     def __init__(self, cg_iters=10, reg_coeff=1e-5, subsample_factor=1., backtrack_ratio=0.8,
                  max_backtracks=15, accept_violation=False, hvp_approach=None, num_slices=1):
         Serializable.quick_init(self, locals())
@@ -128,6 +132,7 @@ class ConjugateGradientOptimizer(Serializable):
         self._hvp_approach = hvp_approach
         self._fused = None
         self.last_backtrack_iters = None
+        self.last_before = None      # (loss, constraint value) at the parameters optimize() started from
 
     def update_opt(self, loss, target, leq_constraint, inputs=None, extra_inputs=None,
                    constraint_name="constraint", fused=None, *args, **kwargs):
@@ -208,7 +213,13 @@ class ConjugateGradientOptimizer(Serializable):
             subsample_inputs = inputs
 
         logger.log("computing loss before")
-        loss_before = float(self._loss_constraint(inputs)[0])
+        # launched now, read at the first line-search comparison: the host goes on queueing the gradient and
+        # CG launches instead of waiting for this pass
+        if self._fused_for(inputs) is not None:
+            before = self._fused.loss_and_kl_deferred(inputs)
+        else:
+            l_b, c_b = self._loss_constraint(inputs)
+            before = lambda: (float(l_b), float(c_b))
         logger.log("performing update")
         logger.log("computing descent direction")
         # the Fisher-vector products below run on the same batch at the same parameters: let the gradient
@@ -221,30 +232,45 @@ class ConjugateGradientOptimizer(Serializable):
         from rllab_amd.policies.fused_ops import FusedFisherHvp
         fused_cg = (self._fused_for(subsample_inputs) is not None and isinstance(hvp, FusedFisherHvp)
                     and idx is None)
-        if fused_cg:
-            # device-side CG: FVP kernel + one vector-algebra kernel per iteration (policies/fused_ops.py)
-            descent_direction, dHd = self._fused.cg(subsample_inputs, flat_g, self._cg_iters, self._reg_coeff)
+        full_prev = target.flat_params.detach().clone()
+        step_vec = None
+        if fused_cg and self._fused_for(inputs) is not None:
+            # device-side CG: FVP kernel + one vector-algebra kernel per iteration, then the initial step
+            # sqrt(2 delta / (d^T H d + 1e-8)) d by rl_trpo_step (policies/fused_ops.py)
+            step_vec, _ = self._fused.cg_step_vector(subsample_inputs, flat_g, self._cg_iters, self._reg_coeff,
+                                                     self._max_constraint_val)
         else:
-            Hx = hvp.build_eval(subsample_inputs, idx)
-            descent_direction = krylov.cg(Hx, flat_g, cg_iters=self._cg_iters)
-            dHd = descent_direction.dot(Hx(descent_direction))
-        initial_step_size = torch.sqrt(2.0 * self._max_constraint_val * (1. / (dHd + 1e-8)))
-        initial_step_size = torch.where(torch.isnan(initial_step_size),
-                                        torch.ones_like(initial_step_size), initial_step_size)
-        flat_descent_step = initial_step_size * descent_direction
+            if fused_cg:
+                descent_direction, dHd = self._fused.cg(subsample_inputs, flat_g, self._cg_iters, self._reg_coeff)
+            else:
+                Hx = hvp.build_eval(subsample_inputs, idx)
+                descent_direction = krylov.cg(Hx, flat_g, cg_iters=self._cg_iters)
+                dHd = descent_direction.dot(Hx(descent_direction))
+            initial_step_size = torch.sqrt(2.0 * self._max_constraint_val * (1. / (dHd + 1e-8)))
+            initial_step_size = torch.where(torch.isnan(initial_step_size),
+                                            torch.ones_like(initial_step_size), initial_step_size)
+            flat_descent_step = initial_step_size * descent_direction
+            prev_param = (full_prev if idx is None else full_prev[idx]).to(torch.float64)
         logger.log("descent direction computed")
 
-        full_prev = target.flat_params.detach().clone()
-        prev_param = (full_prev if idx is None else full_prev[idx]).to(torch.float64)
         n_iter = 0
         loss = constraint_val = float("nan")
+        loss_before = None
         for n_iter, ratio in enumerate(self._backtrack_ratio ** np.arange(self._max_backtracks)):
-            cur_param = prev_param - float(ratio) * flat_descent_step
-            target.set_param_values(cur_param, trainable=True)
+            if step_vec is not None:
+                self._fused.line_search_point(full_prev, step_vec, float(ratio))   # prev - ratio * step, in place
+            else:
+                cur_param = prev_param - float(ratio) * flat_descent_step
+                target.set_param_values(cur_param, trainable=True)
             l_t, c_t = self._loss_constraint(inputs)
             loss, constraint_val = float(l_t), float(c_t)
+            if loss_before is None:
+                loss_before, constraint_before = before()
             if loss < loss_before and constraint_val <= self._max_constraint_val:
                 break
+        if loss_before is None:
+            loss_before, constraint_before = before()
+        self.last_before = (loss_before, constraint_before)
         if (np.isnan(loss) or np.isnan(constraint_val) or loss >= loss_before or
                 constraint_val >= self._max_constraint_val) and not self._accept_violation:
             logger.log("Line search condition violated. Rejecting the step!")

@@ -11,6 +11,7 @@ import torch
 
 from rllab_amd import _lib
 from rllab_amd.core.serializable import Serializable
+from rllab_amd.misc.device_io import read_async
 from rllab_amd.sampler import dist as D
 
 
@@ -25,6 +26,7 @@ class FusedGaussianMLPOps(object):
         self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
         self._acts = None    # hidden-activation cache the gradient pass fills for the FVP passes
         self._acts_tag = None
+        self._epoch = 0      # parameter updates written by our own kernels (see _eval_point)
 
     @staticmethod
     def supported(policy):
@@ -76,37 +78,69 @@ class FusedGaussianMLPOps(object):
         self._acts = None
         self._acts_tag = None
 
-    def loss_stats(self, inputs):
-        """[sum w lr adv, sum w KL, sum w logp adv] * inv_count (global) and max KL, as a
-        float64 device tensor of 4."""
-        b, keep, inv = self._batch(inputs)
+    def _loss_eval(self, inputs):
+        """Launch the loss / KL pass at the current parameters (unless this batch was already evaluated at
+        them) and start reading the four sums back; nothing here waits for the device."""
         # NPO / VPG ask for loss and KL before and after the step through separate calls
-        # (npo.py:100-111): same batch, same parameters -> same pass.  flat_params._version counts
-        # in-place updates, so (batch, version) identifies the evaluation point.
-        tag = (tuple(id(t) for t in inputs), self.policy.flat_params._version)
-        if self._loss_cache is not None and self._loss_cache[0] == tag:
-            return self._loss_cache[1]
+        # (npo.py:100-111): same batch, same parameters -> same pass.
+        tag = self._eval_point(inputs)
+        c = self._loss_cache
+        if c is not None and c["tag"] == tag:
+            return c
+        b, keep, inv = self._batch(inputs)
         ws = self._workspace(keep[0].device)
         out = torch.empty(4, dtype=torch.float64, device=keep[0].device)
         _lib.check(_lib.lib.rl_policy_loss_kl(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
                                               _lib.stream_ptr()), "rl_policy_loss_kl")
         if not D.is_distributed():
-            res = torch.cat([out[:3] * inv, out[3:4]])
+            c = dict(tag=tag, out=out, inv=inv, dev=None, read=read_async(out), host=None)
         else:
             sums = out[:3] * inv
             D.all_reduce_sum_(sums)
             mx = D.all_reduce_max_(out[3:4].clone())
-            res = torch.cat([sums, mx])
-        self._loss_cache = (tag, res)
-        return res
+            dev = torch.cat([sums, mx])
+            c = dict(tag=tag, out=out, inv=1.0, dev=dev, read=read_async(dev), host=None)
+        self._loss_cache = c
+        return c
+
+    @staticmethod
+    def _resolve(c):
+        """Host values of a ``_loss_eval`` record: (sum w lr adv, sum w KL, sum w logp adv) / W, max KL."""
+        if c["host"] is None:
+            h = c["read"].get()
+            c["host"] = (float(h[0] * c["inv"]), float(h[1] * c["inv"]), float(h[2] * c["inv"]), float(h[3]))
+        return c["host"]
+
+    def loss_stats(self, inputs):
+        """[sum w lr adv, sum w KL, sum w logp adv] * inv_count (global) and max KL, as a
+        float64 device tensor of 4."""
+        c = self._loss_eval(inputs)
+        if c["dev"] is None:
+            c["dev"] = torch.cat([c["out"][:3] * c["inv"], c["out"][3:4]])
+        return c["dev"]
+
+    def loss_stats_host(self, inputs):
+        """The same four numbers as Python floats: one device read per evaluation point."""
+        return self._resolve(self._loss_eval(inputs))
 
     def loss_and_kl(self, inputs):
-        s = self.loss_stats(inputs)
+        s = self.loss_stats_host(inputs)
         return -s[0], s[1]
 
+    def loss_and_kl_deferred(self, inputs):
+        """Launch the pass now, read later: returns ``f`` with ``f() -> (loss, mean KL)``.  The record stays
+        valid after the parameters move on (the optimizer needs loss_before only at its first comparison)."""
+        c = self._loss_eval(inputs)
+
+        def get():
+            s = self._resolve(c)
+            return -s[0], s[1]
+        return get
+
     def _eval_point(self, inputs):
-        """(batch, parameter version): flat_params._version counts the in-place updates."""
-        return (tuple(id(t) for t in inputs), self.policy.flat_params._version)
+        """(batch, parameter version): flat_params._version counts torch's in-place updates, _epoch the
+        ones written by rl_line_search_point straight into the parameter vector."""
+        return (tuple(id(t) for t in inputs), self.policy.flat_params._version, self._epoch)
 
     def loss_grad(self, inputs, vpg=False, keep_activations=False):
         """Flat gradient of the surrogate loss.  ``keep_activations``: also leave the hidden activations of
@@ -170,11 +204,47 @@ class FusedGaussianMLPOps(object):
             _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
                                            _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
                        "rl_cg_step")
-        # x^T H x for the initial step size (conjugate_gradient_optimizer.py:258-260)
+        # F x for the initial step size (conjugate_gradient_optimizer.py:258-260)
         x32 = x.to(torch.float32)
         self._fvp_into(b, ws, x32, z, inputs)
         xHx = x.dot(z + float(reg_coeff) * x)
         return x, xHx
+
+    def cg_step_vector(self, inputs, g, cg_iters, reg_coeff, max_constraint, residual_tol=1e-10):
+        """CG as in ``cg`` followed by rl_trpo_step: returns (step, stats) with step = beta x as a float64
+        device vector, stats = {x^T H x, beta} on the device -- no torch arithmetic in between."""
+        b, keep, _ = self._batch(inputs)
+        dev = keep[0].device
+        ws = self._workspace(dev)
+        n = self.policy.flat_params.numel()
+        f64 = dict(dtype=torch.float64, device=dev)
+        g = g.to(torch.float64).contiguous()
+        x, r, p, z, step = (torch.empty(n, **f64) for _ in range(5))
+        p32 = torch.empty(n, dtype=torch.float32, device=dev)
+        scal = torch.empty(4, **f64)
+        stats = torch.empty(2, **f64)
+        st = _lib.stream_ptr()
+        _lib.check(_lib.lib.rl_cg_init(n, _lib.ptr(g), _lib.ptr(x), _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32),
+                                       _lib.ptr(scal), st), "rl_cg_init")
+        for _ in range(cg_iters):
+            self._fvp_into(b, ws, p32, z, inputs)
+            _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
+                                           _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
+                       "rl_cg_step")
+        x32 = x.to(torch.float32)
+        self._fvp_into(b, ws, x32, z, inputs)
+        _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(z), float(reg_coeff), float(max_constraint),
+                                         _lib.ptr(step), _lib.ptr(stats), st), "rl_trpo_step")
+        return step, stats
+
+    def line_search_point(self, prev32, step, ratio):
+        """theta <- (float)(prev - ratio * step), written in place into the policy's parameter vector."""
+        theta = self.policy.flat_params
+        assert prev32.dtype == torch.float32 and step.dtype == torch.float64 and theta.is_contiguous()
+        _lib.check(_lib.lib.rl_line_search_point(theta.numel(), _lib.ptr(prev32), _lib.ptr(step), float(ratio),
+                                                 _lib.ptr(theta.detach()), _lib.stream_ptr()),
+                   "rl_line_search_point")
+        self._epoch += 1
 
     def hvp_approach(self):
         return FusedFisherHvp(self)

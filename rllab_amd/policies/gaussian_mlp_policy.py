@@ -94,7 +94,7 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
         flat = self.flat_params if flat is None else flat
         ls = self._log_std_param.view(flat)
         if self.min_std is not None:
-            ls = torch.maximum(ls, torch.as_tensor(np.log(self.min_std), dtype=ls.dtype, device=ls.device))
+            ls = ls.clamp_min(float(np.log(self.min_std)))   # scalar bound: no host -> device copy per call
         return ls
 
     def mean_planes(self, obs_planes, flat=None):
@@ -150,6 +150,11 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
     def log_diagnostics(self, paths):
         """AveragePolicyStd (reference :155-157).  log_std is state independent, so the
         per-sample mean of exp(log_std) equals the mean over action dims."""
+        traj = getattr(paths, "traj", None)
+        if traj is not None and getattr(traj, "log_std_host", None) is not None:
+            # the row the rollout recorded, already on the host (read with the batch statistics)
+            logger.record_tabular('AveragePolicyStd', float(np.mean(np.exp(traj.log_std_host))))
+            return
         ls = self.effective_log_std().detach()
         logger.record_tabular('AveragePolicyStd', float(torch.exp(ls.double()).mean()))
 

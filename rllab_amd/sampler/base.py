@@ -19,6 +19,7 @@ import torch
 import rllab_amd.misc.logger as logger
 from rllab_amd import _lib
 from rllab_amd.misc import special
+from rllab_amd.misc.device_io import read_async, upload_async
 from rllab_amd.sampler import dist as D
 from rllab_amd.sampler.trajectories import PathList, Trajectories
 
@@ -103,12 +104,15 @@ def path_scan(traj, whole_paths, coeffs=None, want_values=True):
     values = torch.empty((T, N), dtype=torch.float64, device=dev) if (want_values and coeffs is not None) else None
     cf = None
     if coeffs is not None:
-        cf = torch.as_tensor(np.asarray(coeffs, dtype=np.float64), device=dev).contiguous()
+        if torch.is_tensor(coeffs) and coeffs.device == dev:
+            cf = coeffs.to(torch.float64).contiguous()
+        else:   # through pinned memory: a pageable upload would hold the host until the rollout ahead of it is done
+            cf = upload_async(np.asarray(coeffs, dtype=np.float64), torch.float64, dev)
         assert cf.numel() == 2 * traj.obs_dim + 4
     _lib.check(_lib.lib.rl_path_scan(T, N, traj.obs_dim, _lib.ptr(traj.dones), _lib.ptr(traj.obs), _lib.ptr(cf),
                                      int(bool(whole_paths)), _lib.ptr(tin), _lib.ptr(valid), _lib.ptr(values),
                                      _lib.stream_ptr()), "rl_path_scan")
-    return tin, valid.bool(), values
+    return tin, valid.view(torch.bool), values     # 0 / 1 bytes: the same storage seen as bool
 
 
 def merge_stats(st):
@@ -157,7 +161,7 @@ def process_dense(algo, itr, traj, log=True):
     traj.returns = ret
     traj.baselines = base
 
-    valid_u8 = valid.to(torch.uint8)
+    valid_u8 = valid.contiguous().view(torch.uint8)
     ws = _workspace(dev, traj.obs_dim)
     st = torch.empty(20, dtype=torch.float64, device=dev)
     # envs that log forward progress name the observation component to difference over each path
@@ -170,8 +174,14 @@ def process_dense(algo, itr, traj, log=True):
                                         _lib.ptr(tin), _lib.ptr(valid_u8), _SHIFT["ret"], _SHIFT["und"],
                                         _lib.ptr(prog), N, _lib.ptr(ws), ws.numel(), _lib.ptr(st),
                                         _lib.stream_ptr()), "rl_sample_stats")
-    s = merge_stats(st).cpu().numpy()         # the iteration's one host read of batch statistics
+    # the iteration's one blocking host read: batch statistics and, riding along, the recorded log_std row
+    # (Entropy, AveragePolicyStd)
+    stats_read = read_async(merge_stats(st))
+    ls_read = read_async(traj.log_std) if (traj.log_std is not None and traj.log_std_planes is None) else None
+    s = stats_read.get()
+    traj.log_std_host = ls_read.get().astype(np.float64) if ls_read is not None else None
     cnt, n_paths = s[_COUNT], s[_NPATH]
+    traj.count = float(cnt)                   # global number of valid samples (npo_inputs: 1 / W)
 
     def moments(i_sum, i_sq, n):
         m = s[i_sum] / n
@@ -210,6 +220,8 @@ def process_dense(algo, itr, traj, log=True):
         e = pdist.entropy_sym(dict(log_std=traj.log_std_planes.to(torch.float64)), axis=0)
         (es,) = D.sums((e * valid.to(torch.float64)).sum())
         ent = float(es) / cnt
+    elif traj.log_std_host is not None and hasattr(pdist, "entropy"):
+        ent = float(np.asarray(pdist.entropy(dict(log_std=traj.log_std_host[None, :]))).reshape(-1)[0])
     elif traj.log_std is not None and hasattr(pdist, "entropy_sym"):
         ent = float(pdist.entropy_sym(dict(log_std=traj.log_std.to(torch.float64)), axis=0))
     else:

@@ -36,6 +36,8 @@ class Trajectories(object):
         self.baselines = None
         self.tin = None          # [T, N] int32 step index inside its path (rl_path_scan)
         self.progress_stats = None   # (mean, max, min, std) of the env's per-path progress (rl_sample_stats)
+        self.count = None            # global number of valid samples, host float (read with the statistics)
+        self.log_std_host = None     # the recorded log_std row on the host (read with the statistics)
 
     @property
     def device(self):
