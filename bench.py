@@ -126,7 +126,11 @@ def main():
     last = {}
     per_iter = []
 
+    timed_events = []
+
     def iteration(itr, timed):
+        # events only: per-phase times are read after the timed region, so the loop carries no
+        # measurement synchronisation of its own
         e = [ev() for _ in range(4)]
         e[0].record()
         paths = algo.sampler.obtain_samples(itr)
@@ -139,12 +143,7 @@ def main():
         last["samples"] = samples
         logger.dump_tabular()
         if timed:
-            torch.cuda.synchronize()
-            rollout_ms.append(e[0].elapsed_time(e[1]))
-            phase_ms["sample"] += e[0].elapsed_time(e[1])
-            phase_ms["process"] += e[1].elapsed_time(e[2])
-            phase_ms["update"] += e[2].elapsed_time(e[3])
-            per_iter.append((round(e[2].elapsed_time(e[3]), 3), getattr(algo.optimizer, "last_backtrack_iters", None)))
+            timed_events.append((e, getattr(algo.optimizer, "last_backtrack_iters", None)))
 
     for w in range(args.warmup):
         iteration(w, False)
@@ -165,6 +164,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    for e, backtracks in timed_events:
+        rollout_ms.append(e[0].elapsed_time(e[1]))
+        phase_ms["sample"] += e[0].elapsed_time(e[1])
+        phase_ms["process"] += e[1].elapsed_time(e[2])
+        phase_ms["update"] += e[2].elapsed_time(e[3])
+        per_iter.append((round(e[2].elapsed_time(e[3]), 3), backtracks))
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     D.all_reduce_max_(el)
     elapsed = float(el)

@@ -178,6 +178,13 @@ def process_dense(algo, itr, traj, log=True):
     # (Entropy, AveragePolicyStd)
     stats_read = read_async(merge_stats(st))
     ls_read = read_async(traj.log_std) if (traj.log_std is not None and traj.log_std_planes is None) else None
+    # LinearFeatureBaseline's normal equations need nothing the host is about to compute (returns, path index,
+    # validity are on the device already): queue them behind the statistics so the device works through the wait
+    dense_fit = hasattr(baseline, "fit_dense")
+    if dense_fit:
+        if log:
+            logger.log("fitting baseline...")
+        baseline.fit_dense(traj, all_reduce=D.all_reduce_sum_ if D.is_distributed() else None)
     s = stats_read.get()
     traj.log_std_host = ls_read.get().astype(np.float64) if ls_read is not None else None
     cnt, n_paths = s[_COUNT], s[_NPATH]
@@ -230,14 +237,13 @@ def process_dense(algo, itr, traj, log=True):
     paths = PathList(traj)
     samples_data = SamplesData(_traj=traj, paths=paths)
 
-    if log:
-        logger.log("fitting baseline...")
-    if hasattr(baseline, "fit_dense"):
-        baseline.fit_dense(traj, all_reduce=D.all_reduce_sum_ if D.is_distributed() else None)
-    elif hasattr(baseline, 'fit_with_samples'):
-        baseline.fit_with_samples(paths, samples_data)
-    else:
-        baseline.fit(paths)
+    if not dense_fit:
+        if log:
+            logger.log("fitting baseline...")
+        if hasattr(baseline, 'fit_with_samples'):
+            baseline.fit_with_samples(paths, samples_data)
+        else:
+            baseline.fit(paths)
     if log:
         logger.log("fitted")
         logger.record_tabular('Iteration', itr)
