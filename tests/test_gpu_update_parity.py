@@ -257,3 +257,63 @@ def test_device_cg_matches_krylov_and_oracle():
     x1_one = R.cg(f_Ax, g_small.cpu().numpy(), cg_iters=1)
     assert np.array_equal(x1_np, x1_one)                      # the oracle did stop after one iteration
     assert np.abs(x1.cpu().numpy() - x1_np).max() <= 2e-3 * np.abs(x1_np).max()
+
+
+def test_trpo_step_and_line_search_point_kernels():
+    """rl_trpo_step / rl_line_search_point == the float64 formulas of
+    conjugate_gradient_optimizer.py:257-274 (numpy restatement), including the NaN -> 1 rule."""
+    from rllab_amd import _lib
+    rng = np.random.RandomState(3)
+    for n in (1, 7, 1572, 5900):
+        x = rng.randn(n)
+        fx = 0.3 * x + 0.01 * rng.randn(n)
+        reg, delta = 1e-5, 0.01
+        xd, fd = (torch.as_tensor(a, device="cuda") for a in (x, fx))
+        step = torch.empty(n, dtype=torch.float64, device="cuda")
+        out = torch.empty(2, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(xd), _lib.ptr(fd), reg, delta, _lib.ptr(step), _lib.ptr(out),
+                                         _lib.stream_ptr()))
+        xHx = float(x.dot(fx + reg * x))
+        beta = np.sqrt(2.0 * delta * (1.0 / (xHx + 1e-8)))
+        got = out.cpu().numpy()
+        assert abs(got[0] - xHx) <= 1e-12 * max(1.0, abs(xHx))
+        assert abs(got[1] - beta) <= 1e-12 * beta
+        assert np.allclose(step.cpu().numpy(), beta * x, rtol=1e-12, atol=0)
+        prev = rng.randn(n).astype(np.float32)
+        pd = torch.as_tensor(prev, device="cuda")
+        theta = torch.empty(n, dtype=torch.float32, device="cuda")
+        for ratio in (1.0, 0.8, 0.8 ** 7):
+            _lib.check(_lib.lib.rl_line_search_point(n, _lib.ptr(pd), _lib.ptr(step), ratio, _lib.ptr(theta),
+                                                     _lib.stream_ptr()))
+            want = (prev.astype(np.float64) - ratio * step.cpu().numpy()).astype(np.float32)
+            assert np.array_equal(theta.cpu().numpy(), want)
+    # negative curvature -> sqrt of a negative number -> NaN -> step size 1 (reference :260-261)
+    x = np.ones(4)
+    xd, fd = torch.as_tensor(x, device="cuda"), torch.as_tensor(-x, device="cuda")
+    step = torch.empty(4, dtype=torch.float64, device="cuda")
+    out = torch.empty(2, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib.rl_trpo_step(4, _lib.ptr(xd), _lib.ptr(fd), 0.0, 0.01, _lib.ptr(step), _lib.ptr(out),
+                                     _lib.stream_ptr()))
+    assert float(out[1]) == 1.0 and np.array_equal(step.cpu().numpy(), x)
+
+
+def test_deferred_reads_give_the_same_numbers(quiet_logger):
+    """The optimizer's asynchronous reads change when the host waits, not what it reads:
+    last_before == loss / constraint evaluated up front, loss()/constraint_val() after the step come
+    from the accepted candidate, and the cached values survive until the parameters change."""
+    from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+    pol = _policy(13, 2, 32)
+    inp = _inputs(pol, 20000, old_equals_new=True, ragged=True)
+    surr, kl, _ = _closures(pol)
+    opt = ConjugateGradientOptimizer()
+    ops = pol.fused_ops()
+    opt.update_opt(loss=surr, target=pol, leq_constraint=(kl, 0.01), fused=ops)
+    l0, k0 = opt.loss(inp), opt.constraint_val(inp)
+    assert abs(l0 - float(surr(pol.flat_params.double(), *inp))) <= 2e-5 * max(1.0, abs(l0))
+    ops.release()
+    opt.optimize(inp)
+    assert opt.last_before == (l0, k0)
+    l1, k1 = opt.loss(inp), opt.constraint_val(inp)
+    assert l1 < l0 and 0.0 < k1 <= 0.01
+    assert abs(l1 - float(surr(pol.flat_params.double(), *inp))) <= 2e-5 * max(1.0, abs(l1))
+    assert abs(k1 - float(kl(pol.flat_params.double(), *inp))) <= 2e-5 * max(1e-3, abs(k1))

@@ -380,3 +380,35 @@ def test_gaussian_mlp_regressor_and_baseline_fit(quiet_logger):
     assert p.shape == (100,) and np.mean((p - paths[3]["returns"]) ** 2) < np.var(ys)
     b.set_param_values(b.get_param_values() * 0.0)
     assert np.all(b.get_param_values() == 0.0)
+
+
+def test_linear_feature_baseline_dense_fit_is_deferred_but_identical():
+    """fit_dense only starts the read of the normal equations; the solve happens at the first access --
+    get_param_values, predict, pickling -- and gives the per-path fit's coefficients."""
+    from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab_amd.sampler.trajectories import Trajectories
+    rng = np.random.RandomState(0)
+    T, N, do = 12, 5, 3
+    obs = torch.as_tensor(rng.randn(do, T, N).astype(np.float32))
+    dones = torch.zeros((T, N), dtype=torch.uint8)
+    dones[T - 1] = 1
+    traj = Trajectories(obs, torch.zeros((1, T, N)), torch.zeros((1, T, N)), torch.zeros(1),
+                        torch.zeros((T, N)), dones, T)
+    traj.valid = torch.ones((T, N), dtype=torch.bool)
+    traj.returns = torch.as_tensor(rng.randn(T, N).astype(np.float32))
+    b = LinearFeatureBaseline(None)
+    b.fit_dense(traj)
+    assert b._pending is not None and b._coeffs_value is None          # nothing solved yet
+    clone = pickle.loads(pickle.dumps(b))                               # pickling resolves the pending fit
+    assert b._pending is None and clone._pending is None
+    paths = [dict(observations=obs[:, :, i].t().numpy().astype(np.float64), rewards=np.zeros(T),
+                  returns=traj.returns[:, i].numpy().astype(np.float64)) for i in range(N)]
+    ref = LinearFeatureBaseline(None)
+    ref.fit(paths)
+    assert np.allclose(b.get_param_values(), ref.get_param_values(), rtol=1e-6, atol=1e-8)
+    assert np.array_equal(clone.get_param_values(), b.get_param_values())
+    assert np.allclose(clone.predict(paths[0]), ref.predict(paths[0]), atol=1e-6)
+    # a snapshot written before the fit became asynchronous still loads
+    legacy = LinearFeatureBaseline(None)
+    legacy.__setstate__({"_coeffs": np.arange(3.0), "_reg_coeff": 1e-5})
+    assert np.array_equal(legacy.get_param_values(), np.arange(3.0))
