@@ -19,6 +19,9 @@ Extra objects on the JSON line:
                   launch stream.  The kernel fuses 50 physics sub-steps per env-step in
                   registers and is VALU/latency bound, so the HBM fraction is tiny by
                   construction; `valu_tflops` gives the other axis.
+  roofline_step_kernel -- rl_vecenv_step (the per-step boundary kernel, state through HBM every
+                  launch) at 4 M envs for Cartpole and for the workload's env: the HBM-bound
+                  regime of the step kernel, timed live.
   cpu_baseline -- the CPU port of the reference sampler (oracle/cpu_sampler.py:
                   rollout() + stateful_pool-style workers on all host cores) timed on
                   a bounded sample in the same run (rank 0, N == 1 only).
@@ -55,6 +58,39 @@ ENVS = {  # name -> (module, class, rl_env_kind)
     "swimmer": ("rllab_amd.envs.mujoco.swimmer_env", "SwimmerEnv", 2),
     "half_cheetah": ("rllab_amd.envs.mujoco.half_cheetah_env", "HalfCheetahEnv", 3),
 }
+
+
+def step_kernel_roofline(torch, kind, n=1 << 22, steps=20, warmup=3):
+    from rllab_amd import _lib
+    from rllab_amd.envs.hip_env import HipVecEnv
+    name = {v[2]: k for k, v in ENVS.items()}.get(kind, str(kind))
+    v = HipVecEnv(kind, n, 0, normalize=True, seed=1)
+    q = v.q
+    v.reset()
+    act = (torch.rand((q["act_dim"], n), device=v.device) * 2 - 1).contiguous()
+
+    def launch():
+        _lib.check(_lib.lib.rl_vecenv_step(
+            kind, n, 1, 1.0, 0, 1, _lib.ptr(v.state), _lib.ptr(v.ts), _lib.ptr(act), None, v.seed, v.step_counter, 0,
+            _lib.ptr(v._obs), _lib.ptr(v._reward), _lib.ptr(v._done), _lib.stream_ptr()), "rl_vecenv_step")
+        v.step_counter += 1
+    for _ in range(warmup):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    step_bytes = 4 * (2 * q["state_dim"] + q["act_dim"] + q["obs_dim"] + 1) + 1 + 8
+    gbs = step_bytes * n / (ms * 1e-3) / 1e9
+    del v, act
+    torch.cuda.empty_cache()
+    return {"kernel": "vecenv_step_kernel<%s> (rl_vecenv_step, one transition per launch)" % name, "n_envs": n,
+            "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+            "avg_launch_ms": ms, "bytes_per_env_step": step_bytes, "env_steps_per_s": n / (ms * 1e-3)}
 
 
 def main():
@@ -255,6 +291,12 @@ def main():
                                 "activations": "read from the gradient pass's cache" if cached else "recomputed",
                                 "note": "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); time "
                                         "includes the partial-row reduce kernel"}
+    if rank == 0 and world == 1:
+        # The per-step VecEnv boundary kernel (rl_vecenv_step) at a chip-filling size: the one kernel of the path
+        # the HBM roofline really applies to (the fused rollout keeps state in registers).  Timed live with HIP
+        # events, same recipe as tools/step_kernel_roofline.py; algorithmic bytes per env-step =
+        # 4 (2 S + Da + Do + 1) + 1 + 8 (ts read + write).
+        out["roofline_step_kernel"] = [step_kernel_roofline(torch, k) for k in sorted({0, env_kind})]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_sampler
         base = cpu_sampler.timed_baseline(env_kind, policy.get_param_values(), T, budget_s=args.cpu_budget,
