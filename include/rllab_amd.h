@@ -264,10 +264,14 @@ int rl_cg_step(int n, const double* fvp, double reg_coeff, double residual_tol, 
 
 /* The step ConjugateGradientOptimizer.optimize forms after CG
  * (rllab/optimizers/conjugate_gradient_optimizer.py:257-262), float64, one launch:
- *   xHx = x . (fvp_x + reg_coeff x);  beta = sqrt(2 max_constraint * (1 / (xHx + 1e-8)))  (NaN -> 1);
- *   step = beta x;  out = {xHx, beta}.   fvp_x = F x from rl_policy_fvp (summed over ranks). */
-int rl_trpo_step(int n, const double* x, const double* fvp_x, double reg_coeff, double max_constraint,
-                 double* step, double* out, void* stream);
+ *   xHx = x . (a - b + reg_coeff x);  beta = sqrt(2 max_constraint * (1 / (xHx + 1e-8)))  (NaN -> 1);
+ *   step = beta x;  out = {xHx, beta}.
+ * Two ways to supply H x = F x + reg_coeff x:
+ *   a = F x from rl_policy_fvp (summed over ranks), b = NULL         -- evaluated afresh, as the reference does;
+ *   a = CG's right-hand side g, b = CG's residual r, reg_coeff = 0   -- CG's invariant r = g - H x (rl_cg_step
+ *                                                                       iterates on H = F + reg I), no extra pass. */
+int rl_trpo_step(int n, const double* x, const double* a, const double* b, double reg_coeff,
+                 double max_constraint, double* step, double* out, void* stream);
 
 /* One candidate of its backtracking line search (:266-274): theta = (float)(prev - ratio * step),
  * prev: float[n] (the parameters before the update), step: double[n], theta: float[n]. */

@@ -91,7 +91,7 @@ def _load():
     lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]
     lib.rl_cg_init.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.rl_cg_step.argtypes = [i32, vp, f64, f64, vp, vp, vp, vp, vp, vp]
-    lib.rl_trpo_step.argtypes = [i32, vp, vp, f64, f64, vp, vp, vp]
+    lib.rl_trpo_step.argtypes = [i32, vp, vp, vp, f64, f64, vp, vp, vp]
     lib.rl_line_search_point.argtypes = [i32, vp, vp, f64, vp, vp]
     sz = ctypes.c_size_t
     lib.rl_path_scan.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]

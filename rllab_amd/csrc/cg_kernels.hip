@@ -102,10 +102,14 @@ __global__ void __launch_bounds__(CG_THREADS) cg_step_kernel(int n, const double
     }
 }
 
-// After CG (conjugate_gradient_optimizer.py:257-262):  xHx = x . (F x + reg x),
+// After CG (conjugate_gradient_optimizer.py:257-262):  xHx = x . (a - b + reg x),
 // beta = sqrt(2 delta * (1 / (xHx + 1e-8)))  (NaN -> 1),  step = beta x.   out = {xHx, beta}
+//   a = F x (rl_policy_fvp), b = null, reg = reg_coeff : H x evaluated afresh, as the reference does;
+//   a = g, b = CG's residual r, reg = 0                : the same H x from CG's invariant r = g - H x
+//                                                        (H = F + reg I is what rl_cg_step iterates on).
 __global__ void __launch_bounds__(CG_THREADS) trpo_step_kernel(int n, const double* __restrict__ x,
-                                                               const double* __restrict__ fx, double reg,
+                                                               const double* __restrict__ a,
+                                                               const double* __restrict__ b, double reg,
                                                                double delta, double* __restrict__ step,
                                                                double* __restrict__ out) {
     __shared__ double scratch[CG_THREADS / 64];
@@ -116,7 +120,8 @@ __global__ void __launch_bounds__(CG_THREADS) trpo_step_kernel(int n, const doub
         const int i = threadIdx.x + k * CG_THREADS;
         if (i < n) {
             xv[k] = x[i];
-            acc += xv[k] * (fx[i] + reg * xv[k]);
+            const double hx = (b ? a[i] - b[i] : a[i]) + reg * xv[k];
+            acc += xv[k] * hx;
         }
     }
     const double xHx = block_sum(acc, scratch);
@@ -142,11 +147,11 @@ __global__ void __launch_bounds__(256) line_search_point_kernel(int n, const flo
 
 using namespace rl;
 
-extern "C" int rl_trpo_step(int n, const double* x, const double* fvp_x, double reg_coeff, double max_constraint,
-                            double* step, double* out, void* stream) {
-    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !x || !fvp_x || !step || !out)
+extern "C" int rl_trpo_step(int n, const double* x, const double* a, const double* b, double reg_coeff,
+                            double max_constraint, double* step, double* out, void* stream) {
+    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !x || !a || !step || !out)
         return set_error(RL_ERR_ARG, "rl_trpo_step: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
-    hipLaunchKernelGGL(trpo_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, x, fvp_x, reg_coeff,
+    hipLaunchKernelGGL(trpo_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, x, a, b, reg_coeff,
                        max_constraint, step, out);
     return check_launch("trpo_step_kernel");
 }

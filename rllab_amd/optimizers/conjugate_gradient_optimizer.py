@@ -112,8 +112,13 @@ class ConjugateGradientOptimizer(Serializable):
     reports_before_values = True
 
     def __init__(self, cg_iters=10, reg_coeff=1e-5, subsample_factor=1., backtrack_ratio=0.8,
-                 max_backtracks=15, accept_violation=False, hvp_approach=None, num_slices=1):
+                 max_backtracks=15, accept_violation=False, hvp_approach=None, num_slices=1,
+                 reuse_cg_residual=True):
+        """``reuse_cg_residual`` (fused device CG only): d^T H d for the initial step size comes from CG's own
+        residual, H d = g - r, instead of the reference's extra Hx(d) evaluation (:258-260) -- the same number
+        to the rounding of one f32 Fisher-vector product, one pass over the batch less.  False = evaluate afresh."""
         Serializable.quick_init(self, locals())
+        self._reuse_cg_residual = reuse_cg_residual
         self._cg_iters = cg_iters
         self._reg_coeff = reg_coeff
         self._subsample_factor = subsample_factor
@@ -238,7 +243,8 @@ class ConjugateGradientOptimizer(Serializable):
             # device-side CG: FVP kernel + one vector-algebra kernel per iteration, then the initial step
             # sqrt(2 delta / (d^T H d + 1e-8)) d by rl_trpo_step (policies/fused_ops.py)
             step_vec, _ = self._fused.cg_step_vector(subsample_inputs, flat_g, self._cg_iters, self._reg_coeff,
-                                                     self._max_constraint_val)
+                                                     self._max_constraint_val,
+                                                     reuse_cg_residual=getattr(self, "_reuse_cg_residual", True))
         else:
             if fused_cg:
                 descent_direction, dHd = self._fused.cg(subsample_inputs, flat_g, self._cg_iters, self._reg_coeff)

@@ -210,9 +210,13 @@ class FusedGaussianMLPOps(object):
         xHx = x.dot(z + float(reg_coeff) * x)
         return x, xHx
 
-    def cg_step_vector(self, inputs, g, cg_iters, reg_coeff, max_constraint, residual_tol=1e-10):
+    def cg_step_vector(self, inputs, g, cg_iters, reg_coeff, max_constraint, residual_tol=1e-10,
+                       reuse_cg_residual=True):
         """CG as in ``cg`` followed by rl_trpo_step: returns (step, stats) with step = beta x as a float64
-        device vector, stats = {x^T H x, beta} on the device -- no torch arithmetic in between."""
+        device vector, stats = {x^T H x, beta} on the device -- no torch arithmetic in between.
+        ``reuse_cg_residual``: take H x from CG's invariant r = g - H x instead of one more Fisher-vector
+        product (the reference evaluates Hx(x) afresh, conjugate_gradient_optimizer.py:258-260; both are the
+        same quantity to the rounding of an f32 product, tests/test_gpu_update_parity.py)."""
         b, keep, _ = self._batch(inputs)
         dev = keep[0].device
         ws = self._workspace(dev)
@@ -231,10 +235,15 @@ class FusedGaussianMLPOps(object):
             _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
                                            _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
                        "rl_cg_step")
-        x32 = x.to(torch.float32)
-        self._fvp_into(b, ws, x32, z, inputs)
-        _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(z), float(reg_coeff), float(max_constraint),
-                                         _lib.ptr(step), _lib.ptr(stats), st), "rl_trpo_step")
+        if reuse_cg_residual:
+            _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(g), _lib.ptr(r), 0.0, float(max_constraint),
+                                             _lib.ptr(step), _lib.ptr(stats), st), "rl_trpo_step")
+        else:
+            x32 = x.to(torch.float32)
+            self._fvp_into(b, ws, x32, z, inputs)
+            _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(z), None, float(reg_coeff),
+                                             float(max_constraint), _lib.ptr(step), _lib.ptr(stats), st),
+                       "rl_trpo_step")
         return step, stats
 
     def line_search_point(self, prev32, step, ratio):

@@ -271,7 +271,7 @@ def test_trpo_step_and_line_search_point_kernels():
         xd, fd = (torch.as_tensor(a, device="cuda") for a in (x, fx))
         step = torch.empty(n, dtype=torch.float64, device="cuda")
         out = torch.empty(2, dtype=torch.float64, device="cuda")
-        _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(xd), _lib.ptr(fd), reg, delta, _lib.ptr(step), _lib.ptr(out),
+        _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(xd), _lib.ptr(fd), None, reg, delta, _lib.ptr(step), _lib.ptr(out),
                                          _lib.stream_ptr()))
         xHx = float(x.dot(fx + reg * x))
         beta = np.sqrt(2.0 * delta * (1.0 / (xHx + 1e-8)))
@@ -292,7 +292,7 @@ def test_trpo_step_and_line_search_point_kernels():
     xd, fd = torch.as_tensor(x, device="cuda"), torch.as_tensor(-x, device="cuda")
     step = torch.empty(4, dtype=torch.float64, device="cuda")
     out = torch.empty(2, dtype=torch.float64, device="cuda")
-    _lib.check(_lib.lib.rl_trpo_step(4, _lib.ptr(xd), _lib.ptr(fd), 0.0, 0.01, _lib.ptr(step), _lib.ptr(out),
+    _lib.check(_lib.lib.rl_trpo_step(4, _lib.ptr(xd), _lib.ptr(fd), None, 0.0, 0.01, _lib.ptr(step), _lib.ptr(out),
                                      _lib.stream_ptr()))
     assert float(out[1]) == 1.0 and np.array_equal(step.cpu().numpy(), x)
 
@@ -317,3 +317,28 @@ def test_deferred_reads_give_the_same_numbers(quiet_logger):
     assert l1 < l0 and 0.0 < k1 <= 0.01
     assert abs(l1 - float(surr(pol.flat_params.double(), *inp))) <= 2e-5 * max(1.0, abs(l1))
     assert abs(k1 - float(kl(pol.flat_params.double(), *inp))) <= 2e-5 * max(1e-3, abs(k1))
+
+
+def test_cg_residual_gives_the_same_step_as_a_fresh_product():
+    """d^T H d from CG's invariant (H d = g - r) vs from one more Fisher-vector product (what the reference
+    evaluates, conjugate_gradient_optimizer.py:258-260): same step vector to ~1e-6 relative."""
+    pol = _policy(13, 2, 32)
+    ops = pol.fused_ops()
+    inp = _inputs(pol, 50000, old_equals_new=True)
+    g = ops.loss_grad(inp, keep_activations=True)
+    s_res, st_res = ops.cg_step_vector(inp, g, 10, 1e-5, 0.01, reuse_cg_residual=True)
+    s_new, st_new = ops.cg_step_vector(inp, g, 10, 1e-5, 0.01, reuse_cg_residual=False)
+    a, b = st_res.cpu().numpy(), st_new.cpu().numpy()
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-5 * b[1]
+    assert float((s_res - s_new).abs().max()) <= 1e-5 * float(s_new.abs().max())
+    # and the rl_trpo_step (a - b) form itself
+    from rllab_amd import _lib
+    rng = np.random.RandomState(0)
+    n = 100
+    x, aa, bb = (torch.as_tensor(rng.randn(n), device="cuda") for _ in range(3))
+    step = torch.empty(n, dtype=torch.float64, device="cuda")
+    out = torch.empty(2, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(aa), _lib.ptr(bb), 0.25, 0.01, _lib.ptr(step),
+                                     _lib.ptr(out), _lib.stream_ptr()))
+    want = float(x.dot(aa - bb + 0.25 * x))
+    assert abs(float(out[0]) - want) <= 1e-12 * max(1.0, abs(want))
