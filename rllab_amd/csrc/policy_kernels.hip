@@ -83,7 +83,7 @@ struct PolicyBatch {
     float inv_count;
     float log_min_std;
     float* partial;            // [grid][P]          (grad-like modes)
-    double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS)
+    double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
 };
 
 template <class N, int MODE, bool CACHE>
@@ -297,12 +297,14 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
             const float dlog = logp_new - (-sls_old - 0.5f * zz_old);
             const float lr = __expf(dlog);
             const float w1 = (lh == 0) ? wgt : 0.0f;        // both halves hold the sample: count it once
-            if (MODE == MODE_LOSS) {
+            // the gradient pass can hand back the loss / KL sums of the same forward pass (rl_policy_grad_loss)
+            if (MODE == MODE_LOSS || (MODE == MODE_GRAD && a.partial_loss != nullptr)) {
                 acc_loss += (double)(w1 * lr * advb);
                 acc_kl += (double)(w1 * kl);
                 acc_vpg += (double)(w1 * (logp_new - 0.5f * (float)DA * 1.8378770664093453f) * advb);
                 if (w1 > 0.0f) max_kl = fmaxf(max_kl, kl);
-            } else {
+            }
+            if (MODE != MODE_LOSS) {
                 // d(-w adv lr)/dmu_k = -w adv lr z_k / sigma_k ; VPG: lr -> 1 (d logp)
                 const float c = -wgt * advb * (MODE == MODE_GRAD ? lr : 1.0f) * a.inv_count;
                 const float c1 = (lh == 0) ? c : 0.0f;
@@ -474,7 +476,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 
     // ---- fold the wavefronts of this workgroup in a fixed order, write ONE partial row --------
     __syncthreads();   // every wave is done with the weight fragments: the fold buffer aliases them
-    if (MODE == MODE_LOSS) {
+    auto fold_loss = [&]() {
         double* red = reinterpret_cast<double*>(smem);
         const double l = wave_sum(acc_loss), k = wave_sum(acc_kl), v = wave_sum(acc_vpg);
         const float mk = wave_max(max_kl);
@@ -489,6 +491,9 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
             for (int w = 1; w < WAVES; ++w) s = (c == 3) ? fmax(s, red[w * LOSS_COLS + c]) : s + red[w * LOSS_COLS + c];
             a.partial_loss[(size_t)blockIdx.x * LOSS_COLS + c] = s;
         }
+    };
+    if (MODE == MODE_LOSS) {
+        fold_loss();
     } else {
         float* red = smem + S::RED;
         for (int k = threadIdx.x; k < P; k += WAVES * WV) red[k] = 0.0f;
@@ -550,6 +555,10 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         }
         float* row = a.partial + (size_t)blockIdx.x * P;
         for (int k = threadIdx.x; k < P; k += WAVES * WV) row[k] = red[k];
+        if (MODE == MODE_GRAD && a.partial_loss != nullptr) {
+            __syncthreads();   // the fold buffer is read out
+            fold_loss();
+        }
     }
 }
 
@@ -594,7 +603,7 @@ constexpr int MAX_GRID = 256 * 3;   // workgroups of a pass: <= 3 per CU
 
 template <class N, int MODE, bool CACHE = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
-                       double* out, hipStream_t st) {
+                       double* out, hipStream_t st, double* loss_out = nullptr) {
     using S = Smem<N, MODE, CACHE>;
     PolicyBatch a;
     a.acts = g->activations;
@@ -610,13 +619,16 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     const int need = (n_tiles + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
     if (grid > MAX_GRID) grid = MAX_GRID;
+    const bool with_loss = (MODE == MODE_GRAD) && loss_out != nullptr;
+    const size_t row_bytes = (((size_t)grid * N::P * sizeof(float)) + 15) & ~(size_t)15;
     const size_t need_bytes = (MODE == MODE_LOSS) ? (size_t)grid * LOSS_COLS * sizeof(double)
-                                                  : (size_t)grid * N::P * sizeof(float);
+                                                  : row_bytes + (with_loss ? (size_t)grid * LOSS_COLS * sizeof(double) : 0);
     if (workspace_bytes < need_bytes)
         return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", workspace_bytes,
                          need_bytes);
     a.partial = (float*)workspace;
-    a.partial_loss = (double*)workspace;
+    a.partial_loss = (MODE == MODE_LOSS) ? (double*)workspace
+                                         : (with_loss ? (double*)((char*)workspace + row_bytes) : nullptr);
     auto kern = policy_pass_kernel<N, MODE, CACHE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -633,19 +645,21 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     } else {
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((N::P + WV - 1) / WV), dim3(RR_WAVES * WV), 0, st, a.partial,
                            grid, N::P, out);
+        if (with_loss)
+            hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(LOSS_COLS * WV), 0, st, a.partial_loss, grid, loss_out);
     }
     return check_launch("policy reduce kernel");
 }
 
 template <class N>
 static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
-                         double* out, hipStream_t st) {
+                         double* out, hipStream_t st, double* loss_out) {
     switch (mode) {
         case MODE_LOSS: return launch_pass<N, MODE_LOSS>(g, vec, ws, ws_bytes, out, st);
         case MODE_GRAD:
             if constexpr (N::ACT_CACHE)
-                if (g->activations) return launch_pass<N, MODE_GRAD, true>(g, vec, ws, ws_bytes, out, st);
-            return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st);
+                if (g->activations) return launch_pass<N, MODE_GRAD, true>(g, vec, ws, ws_bytes, out, st, loss_out);
+            return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st, loss_out);
         case MODE_FVP:
             if constexpr (N::ACT_CACHE)
                 if (g->activations) return launch_pass<N, MODE_FVP, true>(g, vec, ws, ws_bytes, out, st);
@@ -656,10 +670,11 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
 }
 
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
-                        double* out, hipStream_t st) {
+                        double* out, hipStream_t st, double* loss_out = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
 #define NETCASE(DO, DA, H) \
-    if (d == DO && k == DA && h0 == H && h1 == H) return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st);
+    if (d == DO && k == DA && h0 == H && h1 == H) \
+        return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out);
     NETCASE(4, 1, 32)    // Cartpole
     NETCASE(6, 1, 32)    // DoublePendulum
     NETCASE(11, 1, 32)   // InvertedDoublePendulum
@@ -696,8 +711,9 @@ extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden
     const size_t P = (size_t)obs_dim * hidden0 + hidden0 + (size_t)hidden0 * hidden1 + hidden1 +
                      (size_t)hidden1 * act_dim + 2 * (size_t)act_dim;
     const size_t rows = MAX_GRID;
-    const size_t a = rows * P * sizeof(float), b = rows * LOSS_COLS * sizeof(double);
-    return a > b ? a : b;
+    // rl_policy_grad_loss keeps both kinds of partial rows at once
+    const size_t a = (rows * P * sizeof(float) + 15) & ~(size_t)15, b = rows * LOSS_COLS * sizeof(double);
+    return a + b;
 }
 
 extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1) {
@@ -724,6 +740,15 @@ extern "C" int rl_policy_grad(const rl_policy_batch* g, int vpg, void* workspace
         return set_error(RL_ERR_ARG, "rl_policy_grad: bad argument");
     return dispatch_net(vpg ? MODE_VPG : MODE_GRAD, g, nullptr, workspace, workspace_bytes, grad_out,
                         (hipStream_t)stream);
+}
+
+extern "C" int rl_policy_grad_loss(const rl_policy_batch* g, void* workspace, size_t workspace_bytes,
+                                   double* grad_out, double* out4, void* stream) {
+    int rc = check_batch(g, "rl_policy_grad_loss");
+    if (rc) return rc;
+    if (!g->actions || !g->advantages || !g->old_means || !g->old_log_std || !grad_out || !out4)
+        return set_error(RL_ERR_ARG, "rl_policy_grad_loss: bad argument");
+    return dispatch_net(MODE_GRAD, g, nullptr, workspace, workspace_bytes, grad_out, (hipStream_t)stream, out4);
 }
 
 extern "C" int rl_policy_fvp(const rl_policy_batch* g, const float* vec, void* workspace,

@@ -186,9 +186,9 @@ class ConjugateGradientOptimizer(Serializable):
             return self._fused.loss_and_kl(inputs)
         return (self._eval_scalar(self._loss, inputs), self._eval_scalar(self._constraint, inputs))
 
-    def _flat_grad(self, inputs, keep_activations=False):
+    def _flat_grad(self, inputs, keep_activations=False, with_loss=False):
         if self._fused_for(inputs) is not None:
-            g = self._fused.loss_grad(inputs, keep_activations=keep_activations)
+            g = self._fused.loss_grad(inputs, keep_activations=keep_activations, with_loss=with_loss)
         else:
             flat = _flat_for_grad(self._target)
             g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
@@ -220,16 +220,18 @@ class ConjugateGradientOptimizer(Serializable):
         logger.log("computing loss before")
         # launched now, read at the first line-search comparison: the host goes on queueing the gradient and
         # CG launches instead of waiting for this pass
-        if self._fused_for(inputs) is not None:
-            before = self._fused.loss_and_kl_deferred(inputs)
-        else:
+        fused_here = self._fused_for(inputs) is not None
+        if not fused_here:
             l_b, c_b = self._loss_constraint(inputs)
             before = lambda: (float(l_b), float(c_b))
         logger.log("performing update")
         logger.log("computing descent direction")
         # the Fisher-vector products below run on the same batch at the same parameters: let the gradient
-        # pass leave its hidden activations for them (not when the products use a subsample)
-        flat_g = self._flat_grad(inputs, keep_activations=subsample_inputs is inputs)
+        # pass leave its hidden activations for them (not when the products use a subsample); the same pass
+        # hands back the loss / KL sums of this point (f_loss and f_grad share their forward pass)
+        flat_g = self._flat_grad(inputs, keep_activations=subsample_inputs is inputs, with_loss=True)
+        if fused_here:
+            before = self._fused.loss_and_kl_deferred(inputs)
         hvp = self._hvp_approach
         if self._fused is not None and not self._hvp_given and self._fused_for(inputs) is None:
             hvp = PerlmutterHvp(self._num_slices)   # batch the fused kernels cannot take

@@ -78,6 +78,19 @@ class FusedGaussianMLPOps(object):
         self._acts = None
         self._acts_tag = None
 
+    def _loss_record(self, tag, out, inv):
+        """Cache entry of one loss / KL evaluation whose four sums are in ``out`` (device); starts the host read."""
+        if not D.is_distributed():
+            c = dict(tag=tag, out=out, inv=inv, dev=None, read=read_async(out), host=None)
+        else:
+            sums = out[:3] * inv
+            D.all_reduce_sum_(sums)
+            mx = D.all_reduce_max_(out[3:4].clone())
+            dev = torch.cat([sums, mx])
+            c = dict(tag=tag, out=out, inv=1.0, dev=dev, read=read_async(dev), host=None)
+        self._loss_cache = c
+        return c
+
     def _loss_eval(self, inputs):
         """Launch the loss / KL pass at the current parameters (unless this batch was already evaluated at
         them) and start reading the four sums back; nothing here waits for the device."""
@@ -92,16 +105,7 @@ class FusedGaussianMLPOps(object):
         out = torch.empty(4, dtype=torch.float64, device=keep[0].device)
         _lib.check(_lib.lib.rl_policy_loss_kl(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
                                               _lib.stream_ptr()), "rl_policy_loss_kl")
-        if not D.is_distributed():
-            c = dict(tag=tag, out=out, inv=inv, dev=None, read=read_async(out), host=None)
-        else:
-            sums = out[:3] * inv
-            D.all_reduce_sum_(sums)
-            mx = D.all_reduce_max_(out[3:4].clone())
-            dev = torch.cat([sums, mx])
-            c = dict(tag=tag, out=out, inv=1.0, dev=dev, read=read_async(dev), host=None)
-        self._loss_cache = c
-        return c
+        return self._loss_record(tag, out, inv)
 
     @staticmethod
     def _resolve(c):
@@ -142,11 +146,13 @@ class FusedGaussianMLPOps(object):
         ones written by rl_line_search_point straight into the parameter vector."""
         return (tuple(id(t) for t in inputs), self.policy.flat_params._version, self._epoch)
 
-    def loss_grad(self, inputs, vpg=False, keep_activations=False):
+    def loss_grad(self, inputs, vpg=False, keep_activations=False, with_loss=False):
         """Flat gradient of the surrogate loss.  ``keep_activations``: also leave the hidden activations of
         the batch in device memory for the Fisher-vector products that follow at the same parameters (TRPO:
-        one gradient, then cg_iters + 1 products), which then skip the forward pass."""
-        b, keep, _ = self._batch(inputs)
+        one gradient, then cg_iters + 1 products), which then skip the forward pass.  ``with_loss``: the same
+        pass also produces the loss / KL sums at these parameters (rl_policy_grad_loss), so the loss evaluation
+        that belongs to this point costs no pass of its own."""
+        b, keep, inv = self._batch(inputs)
         ws = self._workspace(keep[0].device)
         out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
         self._acts_tag = None
@@ -156,11 +162,19 @@ class FusedGaussianMLPOps(object):
             if self._acts is None or self._acts.numel() < need or self._acts.device != keep[0].device:
                 self._acts = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
             b.activations = self._acts.data_ptr()
+        tag = self._eval_point(inputs)
+        have_loss = self._loss_cache is not None and self._loss_cache["tag"] == tag
         try:
-            _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
-                                               _lib.stream_ptr()), "rl_policy_grad")
+            if with_loss and not vpg and not have_loss:
+                out4 = torch.empty(4, dtype=torch.float64, device=keep[0].device)
+                _lib.check(_lib.lib.rl_policy_grad_loss(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
+                                                        _lib.ptr(out4), _lib.stream_ptr()), "rl_policy_grad_loss")
+                self._loss_record(tag, out4, inv)
+            else:
+                _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(),
+                                                   _lib.ptr(out), _lib.stream_ptr()), "rl_policy_grad")
             if b.activations:
-                self._acts_tag = self._eval_point(inputs)
+                self._acts_tag = tag
         finally:
             b.activations = None
         return D.all_reduce_sum_(out)

@@ -342,3 +342,18 @@ def test_cg_residual_gives_the_same_step_as_a_fresh_product():
                                      _lib.ptr(out), _lib.stream_ptr()))
     want = float(x.dot(aa - bb + 0.25 * x))
     assert abs(float(out[0]) - want) <= 1e-12 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("do,da,h", [(13, 2, 32), (20, 6, 64), (4, 1, 32)])
+def test_grad_pass_also_returns_the_loss_sums(do, da, h):
+    """rl_policy_grad_loss == rl_policy_grad + rl_policy_loss_kl at the same point (same per-sample
+    expressions; the sums differ at most by their association)."""
+    pol = _policy(do, da, h)
+    inp = _inputs(pol, 70001)
+    a, b = pol.fused_ops(), pol.fused_ops()
+    g1 = a.loss_grad(inp, keep_activations=(h == 32), with_loss=True)
+    s1 = np.array(a.loss_stats_host(inp))            # served from the gradient pass: no loss pass launched
+    s2 = np.array(b.loss_stats_host(inp))
+    g2 = b.loss_grad(inp)
+    assert torch.equal(g1, g2)
+    assert np.all(np.abs(s1[:3] - s2[:3]) <= 1e-12 * np.maximum(1.0, np.abs(s2[:3]))) and s1[3] == s2[3]
