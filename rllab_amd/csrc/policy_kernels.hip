@@ -139,6 +139,12 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     float max_kl = -INFINITY;
     f32x16 gW1[HT][HT];                 // [row tile][col tile] fragments of sum h0 (x) gz1
     f32x16 gW0[HT];                     // fragments of sum x_ext (x) gz0: rows d <= DO (DO = bias row) used
+    // narrow inputs (DO + 1 <= 16 rows): the same product on 16x16x4 tiles -- half the matrix passes, half the
+    // accumulator registers (rows d = 4 (lane / 16) + j, column unit 16 nt + lane % 16)
+    constexpr bool W0_NARROW = (DO + 1 <= 16);
+    constexpr int NT16 = H / 16;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t gW0n[NT16];
     float gW2[HT][DA];                  // lane = row (unit), half = sample parity
     float gb1[HT], gb2[DA], gls[DA];
     float wsum = 0.0f;
@@ -156,6 +162,10 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     for (int tj = 0; tj < HT; ++tj)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gW0[tj][r] = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gW0n[nt][j] = 0.0f;
 #pragma unroll
     for (int k = 0; k < DA; ++k) { gb2[k] = 0.0f; gls[k] = 0.0f; }
 
@@ -460,7 +470,20 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tb[lj * TSTR + 32 * t + frag_unit(r, 0) + 4 * lh] = gz0[t][r];
             wave_sync();
-            {
+            if constexpr (W0_NARROW) {
+                // A[m = input row][k = sample 4 s + kq], B[k = sample][n = unit]: lane = (m or n) + 16 kq.  Row 15 of
+                // the x tile does not exist for XS = 15 (the read lands on the next sample's first input: finite, and
+                // output row 15 is never stored).
+                const int lm = lane & 15, kq = lane >> 4;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const float av = tbx[(4 * sp + kq) * XS + lm];
+#pragma unroll
+                    for (int nt = 0; nt < NT16; ++nt)
+                        gW0n[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tb[(4 * sp + kq) * TSTR + 16 * nt + lm],
+                                                                        gW0n[nt], 0, 0, 0);
+                }
+            } else {
                 float ax[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) ax[m] = tbx[(2 * m + lh) * XS + (lj < XS ? lj : 0)];
@@ -519,14 +542,26 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             red[N::W1 + (32 * ti + frag_unit(r, 0) + 4 * lh) * H + 32 * tj + lj] += gW1[ti][tj][r];
+                if constexpr (W0_NARROW) {
+                    const int lm = lane & 15, kq = lane >> 4;
 #pragma unroll
-                for (int t = 0; t < HT; ++t)
+                    for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int d = frag_unit(r, 0) + 4 * lh;          // row of x_ext^T gz0
-                        if (d < DO) red[N::W0 + d * H + 32 * t + lj] += gW0[t][r];
-                        else if (d == DO) red[N::B0 + 32 * t + lj] += gW0[t][r];
-                    }
+                        for (int j = 0; j < 4; ++j) {
+                            const int d = 4 * kq + j;                        // row of x_ext^T gz0
+                            if (d < DO) red[N::W0 + d * H + 16 * nt + lm] += gW0n[nt][j];
+                            else if (d == DO) red[N::B0 + 16 * nt + lm] += gW0n[nt][j];
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int d = frag_unit(r, 0) + 4 * lh;          // row of x_ext^T gz0
+                            if (d < DO) red[N::W0 + d * H + 32 * t + lj] += gW0[t][r];
+                            else if (d == DO) red[N::B0 + 32 * t + lj] += gW0[t][r];
+                        }
+                }
                 if (lh == 0) {
 #pragma unroll
                     for (int t = 0; t < HT; ++t) {
