@@ -254,11 +254,9 @@ struct SwimChain {
         fluid(s.cs, s.sn, vpx, vpy, s.om, c.visc_lin, c.drag_ax, c.drag_perp, c.visc_ang, c.drag_ang, Fx, Fy, tz, ft);
         const R tau = joint_torque(s.th, s.om - x.template qp<PAR1>(s.om), act, c.lim_k, c.lim_b);
         const R taun = x.template qp<SHL1>(tau);
-        const R f1x = x.template qp<SHL1>(Fx), f1y = x.template qp<SHL1>(Fy);
-        const R f2x = x.template qp<SHL2>(Fx), f2y = x.template qp<SHL2>(Fy);
-        const R Fsx = (Fx + f1x) + f2x;
-        const R Fsy = (Fy + f1y) + f2y;
-        const R fnx = x.template qp<SHL1>(Fsx), fny = x.template qp<SHL1>(Fsy);
+        // force on the subtree hanging off this body's child joint = child's + grandchild's (the zero lane beyond)
+        const R fnx = x.template qp<SHL1>(Fx) + x.template qp<SHL2>(Fx);
+        const R fny = x.template qp<SHL1>(Fy) + x.template qp<SHL2>(Fy);
         const R Q = ((c.cxb * ft + tz) + c.jxo * (s.cs * fny - s.sn * fnx)) + (tau - taun);
         const R Gx = s.cs * c.db;
         const R Gy = s.sn * c.db;
