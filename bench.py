@@ -163,23 +163,31 @@ def main():
     per_iter = []
 
     timed_events = []
+    host_stamps = []   # host clock at the phase boundaries (enqueue side), for RLLAB_BENCH_HOSTTIMES=1
 
     def iteration(itr, timed):
         # events only: per-phase times are read after the timed region, so the loop carries no
         # measurement synchronisation of its own
+        h = [time.perf_counter()]
         e = [ev() for _ in range(4)]
         e[0].record()
+        h.append(time.perf_counter())
         paths = algo.sampler.obtain_samples(itr)
+        h.append(time.perf_counter())
         e[1].record()
         samples = algo.sampler.process_samples(itr, paths)
         algo.log_diagnostics(paths)
+        h.append(time.perf_counter())
         e[2].record()
         algo.optimize_policy(itr, samples)
+        h.append(time.perf_counter())
         e[3].record()
         last["samples"] = samples
         logger.dump_tabular()
+        h.append(time.perf_counter())
         if timed:
             timed_events.append((e, getattr(algo.optimizer, "last_backtrack_iters", None)))
+            host_stamps.append(h)
 
     for w in range(args.warmup):
         iteration(w, False)
@@ -291,6 +299,18 @@ def main():
                                 "activations": "read from the gradient pass's cache" if cached else "recomputed",
                                 "note": "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); time "
                                         "includes the partial-row reduce kernel"}
+    if os.environ.get("RLLAB_BENCH_HOSTTIMES") and rank == 0:
+        names = ["events", "obtain_samples (enqueue)", "process_samples (incl. its wait)", "optimize_policy (incl. waits)",
+                 "dump_tabular", "loop overhead to next iteration"]
+        n = len(host_stamps)
+        acc = [0.0] * 6
+        for i, h in enumerate(host_stamps):
+            for j in range(5):
+                acc[j] += h[j + 1] - h[j]
+            if i + 1 < n:
+                acc[5] += host_stamps[i + 1][0] - h[5]
+        for nm, v in zip(names, acc):
+            sys.stderr.write("host %-36s %8.1f us / iteration\n" % (nm, v / n * 1e6))
     if rank == 0 and world == 1:
         # The per-step VecEnv boundary kernel (rl_vecenv_step) at a chip-filling size: the one kernel of the path
         # the HBM roofline really applies to (the fused rollout keeps state in registers).  Timed live with HIP
