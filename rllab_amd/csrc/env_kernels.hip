@@ -355,20 +355,30 @@ struct RolloutDev {
     float* last_obs;
 };
 
-template <class Env, int H0, int H1>
+// EPW = envs per wavefront.  64: one env per lane, the throughput shape (every lane does useful physics).
+// 16: env e lives on lanes e, e+16, e+32, e+48 -- the physics is replicated (free: a lone wavefront is bound by its
+// instruction stream, not by lanes) and the policy runs on 16x16x4 tiles with nothing computed twice
+// (RolloutPolicy16): a quarter of the matrix passes and half the tanh per env-step, on four times as many
+// wavefronts.  The latency shape, chosen while n / 16 wavefronts still find a SIMD each.
+template <class Env, int H0, int H1, int EPW>
 __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
     static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
-    using Pol = RolloutPolicy<Env, H0>;
-    __shared__ __attribute__((aligned(16))) float smem[Pol::LDS_FLOATS];
+    static_assert(EPW == 64 || EPW == 16, "64 (env per lane) or 16 (four replicas)");
+    using Pol = typename std::conditional<EPW == 16, RolloutPolicy16<Env, H0>, RolloutPolicy<Env, H0>>::type;
     Pol pol;
-    pol.init(smem, a.theta);
+    if constexpr (EPW == 16) {
+        pol.init(a.theta);
+    } else {
+        __shared__ __attribute__((aligned(16))) float smem[RolloutPolicy<Env, H0>::LDS_FLOATS];
+        pol.init(smem, a.theta);
+    }
 
     const int n = a.n, T = a.T;
-    // every lane stays alive (the matrix instructions and the cross-half exchange need the whole
+    // every lane stays alive (the matrix instructions and the cross-lane exchanges need the whole
     // wavefront); lanes past the last env shadow env n-1 and only their stores are masked
-    const int i_raw = blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = i_raw < n;
-    const int i = live ? i_raw : n - 1;
+    const int i_raw = blockIdx.x * EPW + (threadIdx.x & (EPW - 1));
+    const bool live = (i_raw < n) && (threadIdx.x < EPW);      // one of the replicas stores
+    const int i = (i_raw < n) ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
     const size_t plane = (size_t)T * n;
 
@@ -394,7 +404,8 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
             for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
         }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
-        pol.forward(o, mean);
+        if constexpr (EPW == 16) pol.forward16(o, mean);
+        else pol.forward(o, mean);
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
@@ -626,11 +637,18 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             return check_launch("rollout_swimmer_quad_kernel");
         }
     }
-    dim3 grid((a.n + BLOCK - 1) / BLOCK);
+    // 16 envs per wavefront while that still leaves every wavefront a SIMD of its own (1024 SIMDs); beyond, the
+    // replicated physics would cost throughput.  RLLAB_ROLLOUT_EPW = 16 / 64 forces a shape (A/B timing).
+    const char* epw_str = getenv("RLLAB_ROLLOUT_EPW");      // read per launch: tests switch shapes inside one process
+    const int epw_env = epw_str ? atoi(epw_str) : 0;
+    const int epw = (epw_env == 16 || epw_env == 64) ? epw_env : (a.n <= 16 * 1024 ? 16 : 64);
+    dim3 grid((a.n + epw - 1) / epw);
     if (g->hidden0 == 32 && g->hidden1 == 32) {
-        hipLaunchKernelGGL((rollout_kernel<Env, 32, 32>), grid, dim3(BLOCK), 0, st, a);
+        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, dim3(BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, dim3(BLOCK), 0, st, a);
     } else if (g->hidden0 == 64 && g->hidden1 == 64) {
-        hipLaunchKernelGGL((rollout_kernel<Env, 64, 64>), grid, dim3(BLOCK), 0, st, a);
+        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, dim3(BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, dim3(BLOCK), 0, st, a);
     } else {
         return set_error(RL_ERR_UNSUPPORTED,
                          "rl_rollout_gaussian_mlp: hidden sizes (%d,%d) have no fused kernel "

@@ -74,9 +74,20 @@ def _make_policy(kind, hidden=(32, 32), seed=0):
     return GaussianMLPPolicy(spec, hidden_sizes=hidden)
 
 
+@pytest.fixture(params=["auto", "64"])
+def rollout_shape(request, monkeypatch):
+    """Both wavefront shapes of the fused rollout: "auto" = 16 envs per wavefront at these sizes (policy on
+    16x16x4 tiles, physics replicated on four lanes), "64" = one env per lane (csrc/env_kernels.hip)."""
+    if request.param != "auto":
+        monkeypatch.setenv("RLLAB_ROLLOUT_EPW", request.param)
+    else:
+        monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("kind", ENV_KINDS)
 @pytest.mark.parametrize("hidden", [(32, 32), (64, 64)])
-def test_fused_rollout_injected_noise(kind, hidden):
+def test_fused_rollout_injected_noise(kind, hidden, rollout_shape):
     """Fused rollout with injected policy noise and reset draws:
        * env dynamics replayed on the host oracle from the recorded actions: bit-exact;
        * recorded means vs a float64 torch forward of the same theta: <= 1e-5;
@@ -113,7 +124,7 @@ def test_fused_rollout_injected_noise(kind, hidden):
 
 
 @pytest.mark.parametrize("kind", OBS_INVERTIBLE)
-def test_fused_rollout_production_rng(kind):
+def test_fused_rollout_production_rng(kind, rollout_shape):
     """Production mode (in-kernel Philox): dynamics still replay bit-exactly, the
     policy noise has the right moments, and two runs with the same seed / counter agree."""
     from rllab_amd.envs.hip_env import HipVecEnv
