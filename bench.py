@@ -327,6 +327,22 @@ def main():
                       "workers, host build of the same dynamics, NumPy batch-1 policy); sampler only, "
                       "upper bound on the true reference stack" % (base["steps"], base["seconds"]),
             "one_core_env_steps_per_s": base["steps_per_s_1core"]}
+        if wl["algo"] == "trpo":
+            # the rest of the reference iteration on the CPU, on (a bounded prefix of) the paths just sampled:
+            # BaseSampler.process_samples and ConjugateGradientOptimizer.optimize as restated in oracle/
+            from oracle import cpu_iteration
+            it = cpu_iteration.timed_process_and_update(base["paths"], policy.get_param_values(), wl["hidden"],
+                                                        gae_lambda=wl["lam"])
+            scale = steps_per_iter / float(it["samples"])
+            out["cpu_baseline"]["iteration"] = {
+                "samples": it["samples"], "process_s": it["process_s"], "update_s": it["update_s"],
+                "torch_threads": it["torch_threads"],
+                "est_iteration_s_at_bench_batch": steps_per_iter / base["steps_per_s"]
+                + (it["process_s"] + it["update_s"]) * scale,
+                "note": "oracle/cpu_iteration.py: reference process_samples (numpy port) + TRPO update (reference "
+                        "control flow, float64 torch-CPU closures in place of the compiled Theano functions) on a "
+                        "prefix of the sampled paths; the estimate scales both linearly to the bench batch and adds "
+                        "the sampling time at the measured rate"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

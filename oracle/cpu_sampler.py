@@ -139,4 +139,4 @@ def timed_baseline(kind, theta, max_path_length, budget_s=15.0, hidden=(32, 32),
         target = int(rate * remaining * 0.8)
         paths, dt, n_par = sample_paths(kind, theta, target, max_path_length, n_parallel=n_parallel, hidden=hidden)
         n = sum(len(p["rewards"]) for p in paths)
-    return dict(steps=n, seconds=dt, steps_per_s=n / dt, cores=n_par, steps_per_s_1core=rate1)
+    return dict(steps=n, seconds=dt, steps_per_s=n / dt, cores=n_par, steps_per_s_1core=rate1, paths=paths)
