@@ -79,15 +79,9 @@ class FusedGaussianMLPOps(object):
         self._acts_tag = None
 
     def _loss_record(self, tag, out, inv):
-        """Cache entry of one loss / KL evaluation whose four sums are in ``out`` (device); starts the host read."""
-        if not D.is_distributed():
-            c = dict(tag=tag, out=out, inv=inv, dev=None, read=read_async(out), host=None)
-        else:
-            sums = out[:3] * inv
-            D.all_reduce_sum_(sums)
-            mx = D.all_reduce_max_(out[3:4].clone())
-            dev = torch.cat([sums, mx])
-            c = dict(tag=tag, out=out, inv=1.0, dev=dev, read=read_async(dev), host=None)
+        """Cache entry of one loss / KL evaluation whose four per-rank sums are in ``out`` (device); starts the
+        host read.  Sharded: ONE all-gather of the four numbers, folded on the host (sum of three, max of one)."""
+        c = dict(tag=tag, out=out, inv=inv, dev=None, read=read_async(D.all_gather_rows(out)), host=None)
         self._loss_cache = c
         return c
 
@@ -111,8 +105,9 @@ class FusedGaussianMLPOps(object):
     def _resolve(c):
         """Host values of a ``_loss_eval`` record: (sum w lr adv, sum w KL, sum w logp adv) / W, max KL."""
         if c["host"] is None:
-            h = c["read"].get()
-            c["host"] = (float(h[0] * c["inv"]), float(h[1] * c["inv"]), float(h[2] * c["inv"]), float(h[3]))
+            h = c["read"].get().reshape(-1, 4)            # one row per rank
+            sums = h[:, :3].sum(axis=0) * c["inv"]
+            c["host"] = (float(sums[0]), float(sums[1]), float(sums[2]), float(h[:, 3].max()))
         return c["host"]
 
     def loss_stats(self, inputs):
@@ -120,7 +115,7 @@ class FusedGaussianMLPOps(object):
         float64 device tensor of 4."""
         c = self._loss_eval(inputs)
         if c["dev"] is None:
-            c["dev"] = torch.cat([c["out"][:3] * c["inv"], c["out"][3:4]])
+            c["dev"] = torch.as_tensor(self._resolve(c), dtype=torch.float64, device=c["out"].device)
         return c["dev"]
 
     def loss_stats_host(self, inputs):

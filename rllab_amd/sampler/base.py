@@ -116,15 +116,22 @@ def path_scan(traj, whole_paths, coeffs=None, want_values=True):
 
 
 def merge_stats(st):
-    """Combine the rl_sample_stats rows of all env shards: two collectives (sum columns; min / max
-    columns folded into one MAX by negating the minima)."""
+    """Combine the rl_sample_stats rows of all env shards on the device (kept for callers that want a tensor):
+    one all-gather, then sum / min / max over the rank axis."""
     if not D.is_distributed():
         return st
-    sums = st[:_N_SUM].clone()
-    D.all_reduce_sum_(sums)
-    ext = torch.stack([-st[_ADVMIN], st[_UNDMAX], -st[_UNDMIN], st[_PROGMAX], -st[_PROGMIN]])
-    D.all_reduce_max_(ext)
-    return torch.cat([sums, torch.stack([-ext[0], ext[1], -ext[2], ext[3], -ext[4]])])
+    return torch.as_tensor(fold_stats(D.all_gather_rows(st).cpu().numpy()), device=st.device)
+
+
+def fold_stats(rows):
+    """[world, 20] host rows -> one row: additive columns summed in rank order, extrema folded."""
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, 20)
+    out = rows[:, :].sum(axis=0)
+    for c in (_ADVMIN, _UNDMIN, _PROGMIN):
+        out[c] = rows[:, c].min()
+    for c in (_UNDMAX, _PROGMAX):
+        out[c] = rows[:, c].max()
+    return out
 
 
 _SHIFT = dict(ret=0.0, und=0.0)   # last iteration's means: they only condition the one-pass variances
@@ -176,7 +183,7 @@ def process_dense(algo, itr, traj, log=True):
                                         _lib.stream_ptr()), "rl_sample_stats")
     # the iteration's one blocking host read: batch statistics and, riding along, the recorded log_std row
     # (Entropy, AveragePolicyStd)
-    stats_read = read_async(merge_stats(st))
+    stats_read = read_async(D.all_gather_rows(st))      # [world, 20]: one collective, folded on the host
     ls_read = read_async(traj.log_std) if (traj.log_std is not None and traj.log_std_planes is None) else None
     # LinearFeatureBaseline's normal equations need nothing the host is about to compute (returns, path index,
     # validity are on the device already): queue them behind the statistics so the device works through the wait
@@ -185,7 +192,7 @@ def process_dense(algo, itr, traj, log=True):
         if log:
             logger.log("fitting baseline...")
         baseline.fit_dense(traj, all_reduce=D.all_reduce_sum_ if D.is_distributed() else None)
-    s = stats_read.get()
+    s = fold_stats(stats_read.get())
     traj.log_std_host = ls_read.get().astype(np.float64) if ls_read is not None else None
     cnt, n_paths = s[_COUNT], s[_NPATH]
     traj.count = float(cnt)                   # global number of valid samples (npo_inputs: 1 / W)

@@ -63,6 +63,24 @@ def broadcast_(t, src=0):
     return t
 
 
+def all_gather_rows(t):
+    """[n] tensor -> [world, n] with row r = rank r's values (one collective; every rank sees the same rows in
+    the same order, so whatever is folded from them -- sums, minima, maxima -- is identical everywhere).  Used
+    where a quantity needs both a sum and a min / max: one all-gather instead of two all-reduces."""
+    t = t.reshape(-1)
+    if not is_distributed():
+        return t.unsqueeze(0)
+    w = dist.get_world_size()
+    if dist.get_backend() == "gloo":            # CPU tests, or ranks sharing one GPU in tests/: through the host
+        h = t.cpu()
+        rows = [torch.empty_like(h) for _ in range(w)]
+        dist.all_gather(rows, h)
+        return torch.stack(rows).to(t.device)
+    out = torch.empty(w * t.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out.view(w, t.numel())
+
+
 def sums(*scalars):
     """All-reduce a handful of 0-d float64 tensors in ONE message; returns a list of
     0-d tensors holding the global sums."""
