@@ -18,6 +18,7 @@
 //                      register block of the Gram matrix, f64 FMAs run at the vector rate.
 // All four are HBM-/issue-bound single passes; none survives in a profile next to the rollout.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
 
@@ -289,6 +290,87 @@ lfb_normal_eq_kernel(size_t B, int Do, const float* __restrict__ obs, const int3
     for (int k = threadIdx.x; k < FE * FE; k += NE_WAVES * 64) out[k] = red[k];
 }
 
+// The same normal equations on the f64 matrix pipe: Gram = Phi^T Phi is D[16x16] += A[16x4] B[4x16] with the
+// SAMPLE axis as K, A[m = feature i][k = sample] and B[k = sample][n = feature j] being the same numbers, so a lane
+// reads ONE double per 16-feature tile and k-step (4 samples) from the [sample][feature] LDS tile instead of the
+// 2 FB per sample of the register-blocked form above -- that kernel is bound by those LDS reads, not by its FMAs.
+// Only the upper triangle of 16x16 tiles is accumulated; the mirror is filled when the partial is written.
+// lane l: operand index (feature) l % 16, k = l / 16; accumulator register j holds row 4 j + l / 16, column l % 16
+// (the f64 instruction interleaves the rows of the lane groups; tools/ubench/mfma_f64_layout.hip prints the map).
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <int FE>
+__global__ void __launch_bounds__(NE_WAVES * 64)
+lfb_normal_eq_mfma_kernel(size_t B, int Do, const float* __restrict__ obs, const int32_t* __restrict__ tin,
+                          const float* __restrict__ ret, const uint8_t* __restrict__ valid,
+                          double* __restrict__ partial) {
+    constexpr int NT = FE / 16;
+    constexpr int STR = FE + 2;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* tile = sm + (size_t)wave * NE_TILE * STR;  // [sample][feature]
+    const int lm = lane & 15, kq = lane >> 4;
+    const int F = 2 * Do + 4;
+    f64x4 acc[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const size_t n_tiles = (B + NE_TILE - 1) / NE_TILE;
+    for (size_t tl = (size_t)blockIdx.x * NE_WAVES + wave; tl < n_tiles; tl += (size_t)gridDim.x * NE_WAVES) {
+        const size_t b = tl * NE_TILE + lane;
+        const bool use = (b < B) && valid[b];
+        double* row = tile + (size_t)lane * STR;
+        if (use) {
+            lfb_features(Do, obs, B, b, tin[b], [&](int f, double v) { row[f] = v; });
+            row[F] = (double)ret[b];
+            for (int f = F + 1; f < FE; ++f) row[f] = 0.0;
+        } else {
+            for (int f = 0; f < FE; ++f) row[f] = 0.0;
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_wave_barrier();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll 4
+        for (int s4 = 0; s4 < NE_TILE / 4; ++s4) {
+            const double* rs = tile + (size_t)(4 * s4 + kq) * STR + lm;
+            double op[NT];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) op[a] = rs[16 * a];
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int c = a; c < NT; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[a], op[c], acc[a][c], 0, 0, 0);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_wave_barrier();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    }
+    // fold the wavefronts of the workgroup in order, one partial [FE][FE] per workgroup (both triangles)
+    __syncthreads();
+    double* red = sm;   // [FE][FE], aliases the tiles
+    for (int w = 0; w < NE_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int c = a; c < NT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double* p = red + (size_t)(16 * a + 4 * j + kq) * FE + 16 * c + lm;
+                        *p = (w == 0) ? acc[a][c][j] : *p + acc[a][c][j];
+                    }
+        }
+        __syncthreads();
+    }
+    double* out = partial + (size_t)blockIdx.x * FE * FE;
+    for (int k = threadIdx.x; k < FE * FE; k += NE_WAVES * 64) {
+        const int i = k / FE, j = k % FE;
+        out[k] = (i / 16 <= j / 16) ? red[k] : red[(size_t)j * FE + i];     // lower tiles: mirror of the upper ones
+    }
+}
+
 // out = gram (F*F, row-major) followed by rhs (F): sum of the per-workgroup partials, one wavefront per
 // output entry (lanes take interleaved rows, butterfly at the end: fixed order, deterministic)
 __global__ void __launch_bounds__(256)
@@ -371,7 +453,19 @@ extern "C" int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs,
         return set_error(RL_ERR_ARG, "rl_lfb_normal_eq: workspace too small");
     const size_t lds = (size_t)NE_WAVES * NE_TILE * (FE + 2) * sizeof(double);
     hipError_t e = hipSuccess;
-    if (FE == 32) {
+    // RLLAB_LFB_VALU=1 selects the register-blocked vector kernel (A/B timing; same sums up to association)
+    static const bool valu = getenv("RLLAB_LFB_VALU") != nullptr;
+    if (FE == 32 && !valu) {
+        static bool set = false;
+        if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        hipLaunchKernelGGL(lfb_normal_eq_mfma_kernel<32>, dim3(grid), dim3(NE_WAVES * 64), lds, (hipStream_t)stream, n_samples,
+                           obs_dim, obs, tin, returns, valid, (double*)workspace);
+    } else if (!valu) {
+        static bool set = false;
+        if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        hipLaunchKernelGGL(lfb_normal_eq_mfma_kernel<64>, dim3(grid), dim3(NE_WAVES * 64), lds, (hipStream_t)stream, n_samples,
+                           obs_dim, obs, tin, returns, valid, (double*)workspace);
+    } else if (FE == 32) {
         static bool set32 = false;
         if (!set32) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set32 = true; }
         hipLaunchKernelGGL(lfb_normal_eq_kernel<4>, dim3(grid), dim3(NE_WAVES * 64), lds, (hipStream_t)stream, n_samples,
