@@ -80,8 +80,13 @@ def timed_process_and_update(paths, theta, hidden, discount=0.99, gae_lambda=1.0
         t = as_t(th).requires_grad_(True)
         g = torch.autograd.grad(kl(t), t, create_graph=True)[0]
         return torch.autograd.grad((g * as_t(x)).sum(), t)[0].numpy()
+    # [100k x 32] float64 matmuls: more threads than this only add synchronisation (measured on the 256-core bench host)
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads_before))
     t0 = time.time()
     _, info = R.cg_optimize(np.asarray(theta, dtype=np.float64).copy(), f_loss, f_grad, f_kl, f_hx, step_size)
     t_update = time.time() - t0
+    used = torch.get_num_threads()
+    torch.set_num_threads(threads_before)
     return dict(samples=int(obs.shape[0]), process_s=t_process, update_s=t_update,
-                backtrack_iters=int(info["backtrack_iters"]), torch_threads=torch.get_num_threads())
+                backtrack_iters=int(info["backtrack_iters"]), torch_threads=used)
