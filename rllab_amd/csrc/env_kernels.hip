@@ -258,7 +258,7 @@ struct RolloutPolicy16 {
     bool g0, g1, g2;
 
     __device__ __forceinline__ void init(const float* __restrict__ th) {
-        const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
+        const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
         g0 = g == 0; g1 = g == 1; g2 = g == 2;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -360,8 +360,14 @@ struct RolloutDev {
 // instruction stream, not by lanes) and the policy runs on 16x16x4 tiles with nothing computed twice
 // (RolloutPolicy16): a quarter of the matrix passes and half the tanh per env-step, on four times as many
 // wavefronts.  The latency shape, chosen while n / 16 wavefronts still find a SIMD each.
+// The lane-group shapes are compiled for workgroups of up to FOUR wavefronts, each with its own envs.  Up to 256
+// wavefronts are launched as single-wavefront workgroups (one per CU); beyond that, four per workgroup, which puts
+// one on each SIMD of a CU -- single-wavefront workgroups are not spread evenly over the SIMDs once a CU holds
+// several (16 384 Swimmer envs = 1024 wavefronts took 1.9x the time of 256).
+constexpr int LANE_TPB = 256;
+
 template <class Env, int H0, int H1, int EPW>
-__global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
+__global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(RolloutDev a) {
     static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
     static_assert(EPW == 64 || EPW == 16, "64 (env per lane) or 16 (four replicas)");
     using Pol = typename std::conditional<EPW == 16, RolloutPolicy16<Env, H0>, RolloutPolicy<Env, H0>>::type;
@@ -376,8 +382,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_kernel(RolloutDev a) {
     const int n = a.n, T = a.T;
     // every lane stays alive (the matrix instructions and the cross-lane exchanges need the whole
     // wavefront); lanes past the last env shadow env n-1 and only their stores are masked
-    const int i_raw = blockIdx.x * EPW + (threadIdx.x & (EPW - 1));
-    const bool live = (i_raw < n) && (threadIdx.x < EPW);      // one of the replicas stores
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int i_raw = wave_global * EPW + (lane & (EPW - 1));
+    const bool live = (i_raw < n) && (lane < EPW);              // one of the replicas stores
     const int i = (i_raw < n) ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
     const size_t plane = (size_t)T * n;
@@ -464,7 +472,7 @@ struct DppQuad {
 constexpr int QUAD_ENVS = 16;   // envs per wavefront
 
 template <int H>
-__global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev a) {
+__global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutDev a) {
     using Env = Swimmer;
     using Chain = Env::Chain;
     using Pol = RolloutPolicy16<Env, H>;
@@ -472,9 +480,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev 
     pol.init(a.theta);
 
     const int n = a.n, T = a.T;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int el = lane & (QUAD_ENVS - 1);            // env slot of this lane in the env-per-lane phases
-    const int i_raw = blockIdx.x * QUAD_ENVS + el;
+    const int i_raw = wave_global * QUAD_ENVS + el;
     const bool live = (i_raw < n) && (lane < QUAD_ENVS);   // one of the four copies stores
     const int i = (i_raw < n) ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
@@ -530,9 +539,9 @@ __global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev 
             // expressions as Swimmer::to_chain
             float g[12];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) g[k] = __shfl(s[k], q_src, BLOCK);
-            g[10] = __shfl(ctrl[1], q_src, BLOCK);
-            g[11] = __shfl(ctrl[2], q_src, BLOCK);
+            for (int k = 0; k < 10; ++k) g[k] = __shfl(s[k], q_src, 64);
+            g[10] = __shfl(ctrl[1], q_src, 64);
+            g[11] = __shfl(ctrl[2], q_src, 64);
             Chain::Lane<float> ls;
             ls.rx = g[0]; ls.ry = g[1]; ls.vx = g[5]; ls.vy = g[6];
             const float phi1 = g[2] + g[3], om1 = g[7] + g[8];
@@ -548,14 +557,14 @@ __global__ void __launch_bounds__(BLOCK) rollout_swimmer_quad_kernel(RolloutDev 
             // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's)
             const float qdj = ls.om - dpp.template qp<Chain::PAR1>(ls.om);   // role 3 keeps om = 0
             const int base = 4 * el;
-            s[0] = __shfl(ls.rx, base, BLOCK);
-            s[1] = __shfl(ls.ry, base, BLOCK);
-            s[5] = __shfl(ls.vx, base, BLOCK);
-            s[6] = __shfl(ls.vy, base, BLOCK);
+            s[0] = __shfl(ls.rx, base, 64);
+            s[1] = __shfl(ls.ry, base, 64);
+            s[5] = __shfl(ls.vx, base, 64);
+            s[6] = __shfl(ls.vy, base, 64);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                s[2 + j] = __shfl(ls.th, base + j, BLOCK);
-                s[7 + j] = __shfl(qdj, base + j, BLOCK);
+                s[2 + j] = __shfl(ls.th, base + j, 64);
+                s[7 + j] = __shfl(qdj, base + j, 64);
             }
         }
         float r;
@@ -617,6 +626,14 @@ static int launch_step(int n, int normalize, float scale_reward, int mpl, int au
     return check_launch("vecenv_step_kernel");
 }
 
+// wavefronts per workgroup of the lane-group shapes (RLLAB_ROLLOUT_WPB = 1 / 2 / 4 forces one, for A/B timing)
+static int lane_group_wpb(int waves) {
+    const char* e = getenv("RLLAB_ROLLOUT_WPB");
+    const int v = e ? atoi(e) : 0;
+    if (v == 1 || v == 2 || v == 4) return v;
+    return waves <= 256 ? 1 : LANE_TPB / 64;
+}
+
 template <class Env>
 static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     RolloutDev a;
@@ -631,9 +648,10 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
         static const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;
         if (!lane_kernel && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
-            dim3 qgrid((a.n + QUAD_ENVS - 1) / QUAD_ENVS);
-            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, dim3(BLOCK), 0, st, a);
-            else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), qgrid, dim3(BLOCK), 0, st, a);
+            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
+            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
+            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, qblock, 0, st, a);
+            else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), qgrid, qblock, 0, st, a);
             return check_launch("rollout_swimmer_quad_kernel");
         }
     }
@@ -642,13 +660,14 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     const char* epw_str = getenv("RLLAB_ROLLOUT_EPW");      // read per launch: tests switch shapes inside one process
     const int epw_env = epw_str ? atoi(epw_str) : 0;
     const int epw = (epw_env == 16 || epw_env == 64) ? epw_env : (a.n <= 16 * 1024 ? 16 : 64);
-    dim3 grid((a.n + epw - 1) / epw);
+    const int waves = (a.n + epw - 1) / epw, wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
+    dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
     if (g->hidden0 == 32 && g->hidden1 == 32) {
-        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, dim3(BLOCK), 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, dim3(BLOCK), 0, st, a);
+        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, block, 0, st, a);
     } else if (g->hidden0 == 64 && g->hidden1 == 64) {
-        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, dim3(BLOCK), 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, dim3(BLOCK), 0, st, a);
+        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, block, 0, st, a);
     } else {
         return set_error(RL_ERR_UNSUPPORTED,
                          "rl_rollout_gaussian_mlp: hidden sizes (%d,%d) have no fused kernel "

@@ -74,14 +74,18 @@ def _make_policy(kind, hidden=(32, 32), seed=0):
     return GaussianMLPPolicy(spec, hidden_sizes=hidden)
 
 
-@pytest.fixture(params=["auto", "64"])
+@pytest.fixture(params=["auto", "64", "wpb4"])
 def rollout_shape(request, monkeypatch):
-    """Both wavefront shapes of the fused rollout: "auto" = 16 envs per wavefront at these sizes (policy on
-    16x16x4 tiles, physics replicated on four lanes), "64" = one env per lane (csrc/env_kernels.hip)."""
-    if request.param != "auto":
-        monkeypatch.setenv("RLLAB_ROLLOUT_EPW", request.param)
-    else:
-        monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
+    """The launch shapes of the fused rollout: "auto" = 16 envs per wavefront at these sizes (policy on
+    16x16x4 tiles, physics replicated on four lanes) in single-wavefront workgroups, "64" = one env per lane,
+    "wpb4" = 16 envs per wavefront in workgroups of four wavefronts (what launches beyond 256 wavefronts
+    use; csrc/env_kernels.hip)."""
+    monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
+    monkeypatch.delenv("RLLAB_ROLLOUT_WPB", raising=False)
+    if request.param == "64":
+        monkeypatch.setenv("RLLAB_ROLLOUT_EPW", "64")
+    elif request.param == "wpb4":
+        monkeypatch.setenv("RLLAB_ROLLOUT_WPB", "4")
     return request.param
 
 
