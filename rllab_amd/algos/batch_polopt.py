@@ -4,37 +4,36 @@
 ``train()`` is the reference's loop: obtain_samples -> process_samples ->
 log_diagnostics -> optimize_policy -> snapshot -> dump_tabular.  The default
 ``sampler_cls`` is the lock-step GPU ``VectorizedSampler`` when the env is
-HIP-native (``env.vectorized``); otherwise the plain ``BatchSampler`` below, which
-rolls a Python env in-process exactly like the reference does at n_parallel = 1.
+HIP-native (``env.vectorized``); otherwise the ``BatchSampler`` below, which rolls a Python
+env through ``sampler/parallel_sampler.py`` (in-process, or on its CPU worker pool) like the reference.
 """
 import time
 
 import rllab_amd.misc.logger as logger
 from rllab_amd.algos.base import RLAlgorithm
 from rllab_amd.sampler.base import BaseSampler
-from rllab_amd.sampler.utils import rollout, truncate_paths
+from rllab_amd.sampler import parallel_sampler
+from rllab_amd.sampler.utils import truncate_paths
 
 
 class BatchSampler(BaseSampler):
-    """Single-process whole-path sampler for arbitrary Python envs
-    (reference: batch_polopt.py:9-34 + parallel_sampler.sample_paths with one worker)."""
+    """Whole-path sampler for arbitrary Python envs (reference: batch_polopt.py:9-34): through the CPU worker
+    pool when ``parallel_sampler.initialize(n_parallel > 1)`` was called, in-process otherwise."""
 
     def __init__(self, algo):
         self.algo = algo
 
     def start_worker(self):
-        pass
+        parallel_sampler.populate_task(self.algo.env, self.algo.policy, scope=self.algo.scope)
 
     def shutdown_worker(self):
-        pass
+        parallel_sampler.terminate_task(scope=self.algo.scope)
 
     def obtain_samples(self, itr):
         algo = self.algo
-        paths, n = [], 0
-        while n < algo.batch_size:
-            path = rollout(algo.env, algo.policy, algo.max_path_length)
-            paths.append(path)
-            n += len(path["rewards"])
+        paths = parallel_sampler.sample_paths(policy_params=algo.policy.get_param_values(),
+                                              max_samples=algo.batch_size, max_path_length=algo.max_path_length,
+                                              scope=algo.scope)
         if algo.whole_paths:
             return paths
         return truncate_paths(paths, algo.batch_size)

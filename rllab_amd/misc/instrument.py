@@ -8,8 +8,9 @@ gap, log prefix -- and then runs the task IN THIS PROCESS: either a plain callab
 ``task(variant)`` (the reference's cloudpickle path) or a stubbed method call built with
 ``stub(globals())``.  The reference serialises the call and spawns ``python
 scripts/run_experiment_lite.py`` so that it can also ship it to docker / EC2 / Kubernetes; those modes
-are outside the hot path and raise.  ``n_parallel`` sized the reference's CPU worker pool; the
-lock-step GPU sampler has no worker processes, so it is recorded and otherwise ignored.
+are outside the hot path and raise.  ``n_parallel`` sizes the CPU worker pool of the generic-env sampler
+(``sampler/parallel_sampler.py``), as in the reference; HIP-native envs are sampled by the lock-step GPU
+sampler and never touch it.
 """
 import datetime
 import inspect
@@ -210,6 +211,13 @@ def _run_local(call, exp_name, log_dir, variant, n_parallel, snapshot_mode, snap
                tabular_log_file, text_log_file, params_log_file, variant_log_file, log_tabular_only):
     if seed is not None:
         ext.set_seed(seed)
+    if n_parallel and n_parallel > 0:
+        # the CPU worker pool of the generic-env sampler (scripts/run_experiment_lite.py:73-77 of the reference);
+        # HIP-native envs never use it -- their rollouts are one kernel launch -- so one worker means "inline"
+        from rllab_amd.sampler import parallel_sampler
+        parallel_sampler.initialize(n_parallel=n_parallel)
+        if seed is not None:
+            parallel_sampler.set_seed(seed)
     os.makedirs(log_dir, exist_ok=True)
     tabular_log_file = osp.join(log_dir, tabular_log_file)
     text_log_file = osp.join(log_dir, text_log_file)
@@ -219,7 +227,8 @@ def _run_local(call, exp_name, log_dir, variant, n_parallel, snapshot_mode, snap
     with open(osp.join(log_dir, params_log_file), "w") as fh:
         json.dump(dict(exp_name=exp_name, n_parallel=n_parallel, snapshot_mode=snapshot_mode,
                        snapshot_gap=snapshot_gap, seed=seed, resume_from=resume_from,
-                       rollout_workers="none: lock-step GPU sampler (n_parallel is not used)"),
+                       rollout_workers="CPU pool of %d for generic Python envs; HIP-native envs use the lock-step GPU sampler"
+                                       % max(1, n_parallel or 1)),
                   fh, indent=2, sort_keys=True)
     logger.add_text_output(text_log_file)
     logger.add_tabular_output(tabular_log_file)
