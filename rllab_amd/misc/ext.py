@@ -75,3 +75,10 @@ def sliced_fun(f, n_slices):
 def is_iterable(obj):
     """rllab/misc/ext.py:209-210."""
     return isinstance(obj, str) or getattr(obj, '__iter__', False)
+
+
+def flatten_tensor_variables(ts):
+    """One flat vector from a list of tensors (rllab/misc/ext.py:297-299, which concatenates flattened Theano
+    variables; here torch tensors, order preserved, graph kept)."""
+    import torch
+    return torch.cat([torch.reshape(t, (-1,)) for t in ts])

@@ -14,6 +14,7 @@ import torch
 
 from rllab_amd.core.serializable import Serializable
 from rllab_amd.misc import logger
+from rllab_amd.optimizers.minibatch_dataset import BatchDataset
 from rllab_amd.sampler import dist as D
 
 
@@ -102,16 +103,10 @@ class FirstOrderOptimizer(Serializable):
             raise NotImplementedError
         last_loss = self.loss(inputs)
         start_time = time.time()
-        n = inputs[0].shape[-1]
+        dataset = BatchDataset(inputs, self._batch_size, sample_axis=-1)   # planes: the sample axis is last
         for epoch in range(self._max_epochs):
-            if self._batch_size is None:
-                self._step(inputs)
-            else:
-                ids = torch.as_tensor(np.random.permutation(n), device=inputs[0].device)
-                for s in range(0, n, self._batch_size):
-                    sel = ids[s:s + self._batch_size]
-                    self._step(tuple(x.index_select(-1, sel) if torch.is_tensor(x) and x.dim() > 0 and
-                                     x.shape[-1] == n else x for x in inputs))
+            for batch in dataset.iterate(update=True):
+                self._step(tuple(batch))
             new_loss = self.loss(inputs)
             if self._verbose:
                 logger.log("Epoch %d, loss %s" % (epoch, new_loss))

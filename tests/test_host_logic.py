@@ -412,3 +412,28 @@ def test_linear_feature_baseline_dense_fit_is_deferred_but_identical():
     legacy = LinearFeatureBaseline(None)
     legacy.__setstate__({"_coeffs": np.arange(3.0), "_reg_coeff": 1e-5})
     assert np.array_equal(legacy.get_param_values(), np.arange(3.0))
+
+
+def test_batch_dataset_and_flatten_tensor_variables():
+    """BatchDataset (minibatch_dataset.py:4-38): every sample once per pass, reshuffled between passes, extras
+    appended; planes with the sample axis last are sliced on that axis, per-batch items handed through."""
+    from rllab_amd.misc import ext
+    from rllab_amd.optimizers.minibatch_dataset import BatchDataset
+    x, y = np.arange(10).reshape(10, 1), np.arange(10) * 2
+    ds = BatchDataset([x, y], batch_size=4, extra_inputs=["e"])
+    assert ds.number_batches == 3
+    np.random.seed(0)
+    first = [b for b in ds.iterate()]
+    assert [len(b[1]) for b in first] == [4, 4, 2] and all(b[2] == "e" for b in first)
+    assert sorted(np.concatenate([b[1] for b in first]).tolist()) == list(range(0, 20, 2))
+    assert all(np.array_equal(b[0][:, 0] * 2, b[1]) for b in first)
+    second = [b for b in ds.iterate()]
+    assert not np.array_equal(np.concatenate([b[1] for b in first]), np.concatenate([b[1] for b in second]))
+    whole = list(BatchDataset([x, y], batch_size=None).iterate())
+    assert len(whole) == 1 and whole[0][0] is x
+    planes, row, inv = torch.arange(20.).reshape(2, 10), torch.ones(2, 1), torch.tensor(0.1)
+    b = next(BatchDataset([planes, torch.arange(10.), row, inv], batch_size=3, sample_axis=-1).iterate())
+    assert b[0].shape == (2, 3) and b[1].shape == (3,) and b[2] is row and b[3] is inv
+    assert torch.equal(b[0][0], b[1])
+    flat = ext.flatten_tensor_variables([torch.ones(2, 3), torch.zeros(4)])
+    assert flat.shape == (10,) and float(flat.sum()) == 6.0
