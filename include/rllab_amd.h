@@ -77,6 +77,11 @@ int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const uint8_t* m
                     const float* draws, uint64_t seed, uint64_t step_counter,
                     int env_offset, float* obs, void* stream);
 
+/* Observation of the state planes as they are, without a transition: obs[obs_dim][n] = observe(state).
+ * Env.get_current_obs of the reference env bases (rllab/envs/box2d/box2d_env.py:210-218,
+ * rllab/envs/mujoco/mujoco_env.py:118-131); used after a state was written from outside. */
+int rl_vecenv_observe(int kind, int n_envs, const float* state, float* obs, void* stream);
+
 /* One lock-step Env.step over n envs, with the VecEnvExecutor contract: ts += 1,
  * done |= ts >= max_path_length, done envs are reset inside the call and the
  * returned obs is the post-reset observation

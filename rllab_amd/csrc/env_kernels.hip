@@ -65,6 +65,21 @@ vecenv_reset_kernel(int n, float* __restrict__ state, int32_t* __restrict__ ts,
     for (int k = 0; k < Env::OBS; ++k) obs[(size_t)k * n + i] = o[k];
 }
 
+// get_current_obs (box2d_env.py:210-218, mujoco_env.py:118-131): the observation of the state as it is, no
+// transition -- after a set_state, or to look at an env between steps
+template <class Env>
+__global__ void __launch_bounds__(BLOCK)
+vecenv_observe_kernel(int n, const float* __restrict__ state, float* __restrict__ obs) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float s[Env::STATE];
+    load_state<Env>(state, n, i, s);
+    float o[Env::OBS];
+    Env::template observe<float>(s, o);
+#pragma unroll
+    for (int k = 0; k < Env::OBS; ++k) obs[(size_t)k * n + i] = o[k];
+}
+
 // ---------------------------------------------------------------------------
 // VecEnvExecutor.step
 // ---------------------------------------------------------------------------
@@ -616,6 +631,12 @@ static int launch_reset(int n, float* state, int32_t* ts, const uint8_t* mask, c
 }
 
 template <class Env>
+static int launch_observe(int n, const float* state, float* obs, hipStream_t st) {
+    hipLaunchKernelGGL(vecenv_observe_kernel<Env>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, n, state, obs);
+    return check_launch("vecenv_observe_kernel");
+}
+
+template <class Env>
 static int launch_step(int n, int normalize, float scale_reward, int mpl, int auto_reset, float* state,
                        int32_t* ts,
                        const float* actions, const float* reset_draws, uint64_t seed, uint64_t step,
@@ -710,6 +731,11 @@ extern "C" int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const
     if (n <= 0 || !state || !ts || !obs) return set_error(RL_ERR_ARG, "rl_vecenv_reset: bad argument");
     RL_DISPATCH_ENV(kind, launch_reset<E>(n, state, ts, mask, draws, seed, step_counter, env_offset, obs,
                                           (hipStream_t)stream))
+}
+
+extern "C" int rl_vecenv_observe(int kind, int n, const float* state, float* obs, void* stream) {
+    if (n <= 0 || !state || !obs) return set_error(RL_ERR_ARG, "rl_vecenv_observe: bad argument");
+    RL_DISPATCH_ENV(kind, launch_observe<E>(n, state, obs, (hipStream_t)stream))
 }
 
 extern "C" int rl_vecenv_step(int kind, int n, int normalize, float scale_reward, int max_path_length,

@@ -109,6 +109,23 @@ class HipVecEnv(object):
                     done.cpu().numpy(), dict())
         return obs, rew, done, dict()
 
+    # -- state access (single source of truth: the SoA planes on the device) ------
+    def observe(self):
+        """obs_n of the state planes as they are (no transition): rl_vecenv_observe."""
+        _lib.check(_lib.lib.rl_vecenv_observe(self.kind, self.n, _lib.ptr(self.state), _lib.ptr(self._obs),
+                                              _lib.stream_ptr()), "rl_vecenv_observe")
+        return self._obs.t()
+
+    def get_state(self):
+        """[n, S] host copy of the persisted state (layout per env kind: csrc/dyn_*.h)."""
+        return self.state.t().cpu().numpy().astype(np.float64)
+
+    def set_state(self, state):
+        """Overwrite the persisted state from an [n, S] (or [S] for one env) array; steps since reset -> 0."""
+        st = torch.as_tensor(np.asarray(state, dtype=np.float32).reshape(self.n, self.q["state_dim"]))
+        self.state.copy_(st.t().contiguous())
+        self.ts.zero_()
+
     # -- fused rollout ---------------------------------------------------------
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None):
         """``horizon`` lock-step iterations of get_actions -> step -> record ->
@@ -204,6 +221,17 @@ class HipEnv(Env, Serializable):
         a = np.asarray(action, dtype=np.float64).reshape(1, -1)
         obs, rew, done, _ = v.step(a)  # auto_reset off: terminal observation, caller resets
         return Step(observation=obs[0], reward=float(rew[0]), done=bool(done[0]))
+
+    def get_current_obs(self):
+        """Observation of the single env's present state (box2d_env.py:210-218, mujoco_env.py:118-131)."""
+        return self._one().observe()[0].cpu().numpy().astype(np.float64)
+
+    def get_state(self):
+        """The persisted state vector of the single env (kernel layout of this env kind, csrc/dyn_*.h)."""
+        return self._one().get_state()[0]
+
+    def set_state(self, state):
+        self._one().set_state(np.asarray(state).reshape(1, -1))
 
     def terminate(self):
         self._single = None

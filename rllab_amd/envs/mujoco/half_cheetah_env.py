@@ -9,6 +9,7 @@ from rllab_amd.envs.mujoco.mujoco_env import MujocoEnv
 class HalfCheetahEnv(MujocoEnv, Serializable):
     FILE = 'half_cheetah.xml'
     KIND = _lib.ENV_HALF_CHEETAH
+    OBS_ENDS_WITH_TORSO_COM = True     # obs = [..., com_subtree(torso)] (get_body_com)
 
     def __init__(self, *args, **kwargs):
         super(HalfCheetahEnv, self).__init__(*args, **kwargs)

@@ -5,6 +5,8 @@ The reference loads an MJCF into the proprietary MuJoCo 1.31 binary through ctyp
 compiled into a HIP kernel (csrc/dyn_planar.h + dyn_<task>.h).  Options that change
 the simulated world are rejected loudly.
 """
+import numpy as np
+
 from rllab_amd.envs.hip_env import HipEnv
 
 
@@ -26,6 +28,46 @@ class MujocoEnv(HipEnv):
                 (type(self).__name__, ", ".join(unsupported)))
         self.action_noise = action_noise
         HipEnv.__init__(self)
+
+    # -- state-level API of the reference base class (mujoco_env.py:109-238) --------------------------------------
+    @property
+    def _nq(self):
+        return self._q["state_dim"] // 2          # state = [qpos, qvel] for the planar MuJoCo-style envs
+
+    def reset_mujoco(self, init_state=None):
+        """qpos / qvel <- init + N(0, 0.01) / N(0, 0.1) drawn from np.random like the reference (:109-116), or the
+        leading [qpos, qvel] of ``init_state`` (qacc / ctrl entries, if present, carry no state here)."""
+        nq = self._nq
+        if init_state is None:
+            qpos = np.random.normal(size=nq) * 0.01
+            qvel = np.random.normal(size=nq) * 0.1
+            state = np.concatenate([qpos, qvel])
+        else:
+            state = np.asarray(init_state, dtype=np.float64).reshape(-1)[:2 * nq]
+        self.set_state(state)
+
+    def inject_action_noise(self, action):
+        """action + 0.5 (ub - lb) * action_noise * N(0, 1); the draw happens even at scale 0, as in the reference
+        (:175-185), so scripts that share np.random with the env see the same stream."""
+        action = np.asarray(action, dtype=np.float64)
+        noise = self.action_noise * np.random.normal(size=action.shape)
+        lb, ub = self.action_bounds
+        return action + 0.5 * (ub - lb) * noise
+
+    def get_body_com(self, body_name):
+        """Subtree centre of mass; the compiled envs expose the one their observation carries -- the torso's
+        (``com_subtree[0]``, the last three observation entries, swimmer_env.py:25-30)."""
+        if body_name != "torso":
+            raise NotImplementedError("%s: only the torso subtree COM is produced by the HIP kernel"
+                                      % type(self).__name__)
+        if not getattr(self, "OBS_ENDS_WITH_TORSO_COM", False):
+            raise NotImplementedError("%s: the observation does not carry the torso COM" % type(self).__name__)
+        return self.get_current_obs()[-3:]
+
+    def get_body_comvel(self, body_name):
+        raise NotImplementedError(
+            "%s: subtree COM velocities live inside the step kernel (they enter the reward) and are not exported"
+            % type(self).__name__)
 
     def _log_forward_progress(self, paths):
         """Average/Max/Min/StdForwardProgress = obs[-1][-3] - obs[0][-3] per path

@@ -10,6 +10,7 @@ class SwimmerEnv(MujocoEnv, Serializable):
     FILE = 'swimmer.xml'
     ORI_IND = 2
     KIND = _lib.ENV_SWIMMER
+    OBS_ENDS_WITH_TORSO_COM = True     # obs = [..., com_subtree(torso)] (get_body_com)
 
     def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
         if ctrl_cost_coeff != 1e-2:

@@ -9,6 +9,7 @@ from rllab_amd.envs.mujoco.mujoco_env import MujocoEnv
 class Walker2DEnv(MujocoEnv, Serializable):
     FILE = 'walker2d.xml'
     KIND = _lib.ENV_WALKER2D
+    OBS_ENDS_WITH_TORSO_COM = True     # obs = [..., com_subtree(torso)] (get_body_com)
 
     def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
         if ctrl_cost_coeff != 1e-2:
