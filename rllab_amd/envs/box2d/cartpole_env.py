@@ -16,3 +16,9 @@ class CartpoleEnv(Box2DEnv, Serializable):
         self.reset_range = 0.05
         super(CartpoleEnv, self).__init__(None, *args, **kwargs)
         Serializable.__init__(self, *args, **kwargs)
+
+    def is_current_done(self):
+        """abs(cart x) > max_cart_pos or abs(pole angle) > max_pole_angle (cartpole_env.py:54-56), read off the
+        present observation [x, x', theta, theta']."""
+        o = self.get_current_obs()
+        return bool(abs(o[0]) > self.max_cart_pos or abs(o[2]) > self.max_pole_angle)

@@ -19,5 +19,9 @@ class SwimmerEnv(MujocoEnv, Serializable):
         super(SwimmerEnv, self).__init__(*args, **kwargs)
         Serializable.quick_init(self, locals())
 
+    def get_ori(self):
+        """Heading of the first link: qpos[ORI_IND] (swimmer_env.py:32-33)."""
+        return float(self.get_current_obs()[self.ORI_IND])
+
     def log_diagnostics(self, paths):
         self._log_forward_progress(paths)

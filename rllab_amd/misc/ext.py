@@ -82,3 +82,96 @@ def flatten_tensor_variables(ts):
     variables; here torch tensors, order preserved, graph kept)."""
     import torch
     return torch.cat([torch.reshape(t, (-1,)) for t in ts])
+
+
+# -- small generic helpers scripts written against rllab/misc/ext.py use -----------------------------------------
+class AttrDict(dict):
+    """dict whose items are also attributes (ext.py:42-46)."""
+
+    def __init__(self, *args, **kwargs):
+        super(AttrDict, self).__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+def extract_dict(x, *keys):
+    return {k: x[k] for k in keys if k in x}
+
+
+def compact(x):
+    """Drop the None entries of a dict / list (ext.py:32-39)."""
+    if isinstance(x, dict):
+        return {k: v for k, v in x.items() if v is not None}
+    if isinstance(x, list):
+        return [v for v in x if v is not None]
+    return x
+
+
+def flatten(xs):
+    """One level of nesting removed."""
+    return [x for group in xs for x in group]
+
+
+def shuffled(sequence):
+    """Generator over a random permutation of the sequence (np.random)."""
+    import numpy as np
+    for i in np.random.permutation(len(sequence)):
+        yield sequence[i]
+
+
+def path_len(p):
+    return len(p["states"]) if "states" in p else len(p["rewards"])
+
+
+def concat_paths(p1, p2):
+    import numpy as np
+    return {k: np.concatenate([p1[k], p2[k]]) for k in p1.keys() if k in p2}
+
+
+def truncate_path(p, t):
+    return {k: v[:t] for k, v in p.items()}
+
+
+def iterate_minibatches_generic(input_lst=None, batchsize=None, shuffle=False):
+    """Aligned mini-batches of several arrays (ext.py:158-176); batchsize None = one batch of everything."""
+    import numpy as np
+    n = len(input_lst[0])
+    if batchsize is None:
+        batchsize = n
+    assert all(len(x) == n for x in input_lst)
+    order = np.random.permutation(n) if shuffle else np.arange(n)
+    for start in range(0, n, batchsize):
+        sel = order[start:start + batchsize]
+        yield [x[sel] for x in input_lst]
+
+
+def stdize(data, eps=1e-6):
+    import numpy as np
+    return (data - np.mean(data, axis=0)) / (np.std(data, axis=0) + eps)
+
+
+def scanl(f, xs, init):
+    """Running left fold: [init, f(init, x0), f(f(init, x0), x1), ...]."""
+    out = [init]
+    for x in xs:
+        out.append(f(out[-1], x))
+    return out
+
+
+def scanr(f, xs, init):
+    """Running right fold, aligned like the reference: result[i] folds xs[i:]; result[-1] = init."""
+    out = [init]
+    for x in reversed(list(xs)):
+        out.append(f(x, out[-1]))
+    return out[::-1]
+
+
+def unflatten_tensor_variables(flatarr, shapes, symb_arrs=None):
+    """Inverse of flatten_tensor_variables for torch tensors (ext.py:302-311)."""
+    out, n = [], 0
+    for shape in shapes:
+        size = 1
+        for s in shape:
+            size *= int(s)
+        out.append(flatarr[n:n + size].reshape(tuple(shape)))
+        n += size
+    return out

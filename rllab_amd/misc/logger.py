@@ -203,3 +203,37 @@ def save_itr_params(itr, params):
         pass
     else:
         raise NotImplementedError
+
+
+def record_tabular_misc_stat(key, values, placement='back'):
+    """Average / Std / Median / Min / Max of ``values`` under ``key`` (prefix, or suffix with placement='front');
+    NaNs for an empty list (rllab/misc/logger.py:330-348)."""
+    import numpy as np
+    label = (lambda stat: stat + key) if placement == 'front' else (lambda stat: key + stat)
+    stats = (("Average", np.average), ("Std", np.std), ("Median", np.median), ("Min", np.min), ("Max", np.max))
+    for name, fn in stats:
+        record_tabular(label(name), fn(values) if len(values) > 0 else np.nan)
+
+
+def log_variant(log_file, variant_data):
+    """variant.json of an experiment (rllab/misc/logger.py:321-327); values that JSON cannot carry are written as
+    their ``repr``."""
+    import json
+    if hasattr(variant_data, "dump"):
+        variant_data = variant_data.dump()
+    d = os.path.dirname(log_file)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(log_file, "w") as fh:
+        json.dump(variant_data, fh, indent=2, sort_keys=True, default=repr)
+
+
+def log_parameters_lite(log_file, args):
+    """params.json from an argparse namespace (rllab/misc/logger.py:301-318, without the stub decoding that only
+    the reference's subprocess launcher needs)."""
+    import json
+    d = os.path.dirname(log_file)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(log_file, "w") as fh:
+        json.dump(dict(vars(args)), fh, indent=2, sort_keys=True, default=repr)

@@ -88,3 +88,25 @@ def truncate_tensor_list(tensor_list, truncated_len):
 
 def truncate_tensor_dict(tensor_dict, truncated_len):
     return _map_leaves(lambda v: v[:truncated_len], tensor_dict)
+
+
+def flatten_first_axis_tensor_dict(tensor_dict):
+    """Merge the two leading axes of every leaf: [a, b, ...] -> [a * b, ...]."""
+    return _map_leaves(lambda v: v.reshape((-1,) + v.shape[2:]), tensor_dict)
+
+
+def concat_tensor_list_subsample(tensor_list, f):
+    """Concatenation of a random fraction ``f`` (rounded up, without replacement, np.random) of every tensor's rows."""
+    picks = [t[np.random.choice(len(t), int(np.ceil(len(t) * f)), replace=False)] for t in tensor_list]
+    return np.concatenate(picks, axis=0)
+
+
+def concat_tensor_dict_list_subsample(tensor_dict_list, f):
+    return _zip_leaves(lambda leaves: concat_tensor_list_subsample(leaves, f), tensor_dict_list)
+
+
+def high_res_normalize(probs):
+    """Probabilities rescaled to sum to one in Python float arithmetic (np.random.multinomial is picky)."""
+    vals = [float(p) for p in probs]
+    total = sum(vals)
+    return [v / total for v in vals]

@@ -437,3 +437,41 @@ def test_batch_dataset_and_flatten_tensor_variables():
     assert torch.equal(b[0][0], b[1])
     flat = ext.flatten_tensor_variables([torch.ones(2, 3), torch.zeros(4)])
     assert flat.shape == (10,) and float(flat.sum()) == 6.0
+
+
+def test_small_helper_apis(tmp_path):
+    """tensor_utils / logger / ext helpers that scripts written against the reference call."""
+    import json
+    from rllab_amd.misc import ext, logger, tensor_utils as tu
+    d = dict(a=np.arange(24.).reshape(2, 3, 4), b=dict(c=np.arange(6.).reshape(2, 3)))
+    f = tu.flatten_first_axis_tensor_dict(d)
+    assert f["a"].shape == (6, 4) and f["b"]["c"].shape == (6,)
+    np.random.seed(0)
+    sub = tu.concat_tensor_list_subsample([np.arange(10), np.arange(100, 104)], 0.5)
+    assert len(sub) == 5 + 2 and set(sub[:5]) <= set(range(10)) and set(sub[5:]) <= set(range(100, 104))
+    sd = tu.concat_tensor_dict_list_subsample([dict(x=np.arange(4), y=dict(z=np.arange(4)))] * 2, 0.5)
+    assert sd["x"].shape == (4,) and sd["y"]["z"].shape == (4,)
+    assert abs(sum(tu.high_res_normalize([0.1, 0.2, 0.3])) - 1.0) < 1e-15
+    logger.record_tabular_misc_stat("Ret", [1.0, 2.0, 6.0])
+    logger.record_tabular_misc_stat("Len", [], placement='front')
+    tab = logger.get_tabular()
+    assert float(tab["RetAverage"]) == 3.0 and float(tab["RetMedian"]) == 2.0 and float(tab["RetMax"]) == 6.0
+    assert np.isnan(float(tab["AverageLen"]))
+    logger.dump_tabular()
+    logger.log_variant(str(tmp_path / "v" / "variant.json"), dict(lr=0.1, env=object))
+    assert json.load(open(str(tmp_path / "v" / "variant.json")))["lr"] == 0.1
+    a = ext.AttrDict(x=1)
+    assert a.x == 1 and a["x"] == 1
+    assert ext.compact(dict(a=1, b=None)) == dict(a=1) and ext.compact([1, None, 2]) == [1, 2]
+    assert ext.flatten([[1, 2], [3]]) == [1, 2, 3] and ext.extract_dict(dict(a=1, b=2), "a", "z") == dict(a=1)
+    assert sorted(ext.shuffled([3, 1, 2])) == [1, 2, 3]
+    assert ext.scanl(lambda acc, x: acc + x, [1, 2, 3], 0) == [0, 1, 3, 6]
+    assert ext.scanr(lambda x, acc: acc + x, [1, 2, 3], 0) == [6, 5, 3, 0]
+    xs, ys = np.arange(10), np.arange(10) * 2
+    got = list(ext.iterate_minibatches_generic([xs, ys], batchsize=4))
+    assert [len(b[0]) for b in got] == [4, 4, 2] and all(np.array_equal(b[0] * 2, b[1]) for b in got)
+    parts = ext.unflatten_tensor_variables(torch.arange(10.), [(2, 3), (4,)])
+    assert parts[0].shape == (2, 3) and torch.equal(ext.flatten_tensor_variables(parts), torch.arange(10.))
+    p = dict(rewards=np.arange(5), observations=np.arange(10).reshape(5, 2))
+    assert ext.path_len(p) == 5 and len(ext.truncate_path(p, 3)["rewards"]) == 3
+    assert len(ext.concat_paths(p, p)["rewards"]) == 10
