@@ -98,15 +98,25 @@ class FirstOrderOptimizer(Serializable):
         target.set_param_values(self._updater.step(theta, g), trainable=True)
 
     def optimize(self, inputs, extra_inputs=None, callback=None, **kwargs):
+        for _ in self.optimize_gen(inputs, extra_inputs=extra_inputs, callback=callback, **kwargs):
+            pass
+
+    def optimize_gen(self, inputs, extra_inputs=None, callback=None, yield_itr=None, **kwargs):
+        """``optimize`` as a generator: with ``yield_itr`` set, control returns to the caller after every
+        ``yield_itr + 1`` mini-batch steps (first_order_optimizer.py:78-134)."""
         inputs = tuple(inputs) + tuple(extra_inputs or ())
         if len(inputs) == 0:
             raise NotImplementedError
         last_loss = self.loss(inputs)
         start_time = time.time()
         dataset = BatchDataset(inputs, self._batch_size, sample_axis=-1)   # planes: the sample axis is last
+        itr = 0
         for epoch in range(self._max_epochs):
             for batch in dataset.iterate(update=True):
                 self._step(tuple(batch))
+                if yield_itr is not None and itr % (yield_itr + 1) == 0:
+                    yield
+                itr += 1
             new_loss = self.loss(inputs)
             if self._verbose:
                 logger.log("Epoch %d, loss %s" % (epoch, new_loss))

@@ -147,6 +147,17 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
         rnd = np.random.normal(size=d["mean"].shape)
         return rnd * np.exp(d["log_std"]) + d["mean"], d
 
+    def get_reparam_action_sym(self, obs_var, action_var, old_dist_info_vars):
+        """The old actions re-expressed through the current parameters: mean_new + eps * exp(log_std_new) with
+        eps = (a - mean_old) / (exp(log_std_old) + 1e-8)   (gaussian_mlp_policy.py:138-152).  [B, .] tensors."""
+        new = self.dist_info_sym(obs_var, action_var)
+        dev, dt = new["mean"].device, new["mean"].dtype
+        action = torch.as_tensor(action_var, device=dev, dtype=dt)
+        old_mean = torch.as_tensor(old_dist_info_vars["mean"], device=dev, dtype=dt)
+        old_log_std = torch.as_tensor(old_dist_info_vars["log_std"], device=dev, dtype=dt)
+        eps = (action - old_mean) / (torch.exp(old_log_std) + 1e-8)
+        return new["mean"] + eps * torch.exp(new["log_std"])
+
     def log_diagnostics(self, paths):
         """AveragePolicyStd (reference :155-157).  log_std is state independent, so the
         per-sample mean of exp(log_std) equals the mean over action dims."""

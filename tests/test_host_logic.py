@@ -475,3 +475,29 @@ def test_small_helper_apis(tmp_path):
     p = dict(rewards=np.arange(5), observations=np.arange(10).reshape(5, 2))
     assert ext.path_len(p) == 5 and len(ext.truncate_path(p, 3)["rewards"]) == 3
     assert len(ext.concat_paths(p, p)["rewards"]) == 10
+
+
+def test_reparam_action_and_optimize_gen(quiet_logger):
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.optimizers.first_order_optimizer import FirstOrderOptimizer
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    np.random.seed(0)
+    pol = GaussianMLPPolicy(EnvSpec(Box(-np.ones(3), np.ones(3)), Box(-np.ones(2), np.ones(2))), hidden_sizes=(8, 8))
+    obs = np.random.randn(5, 3)
+    d = pol.dist_info(obs)
+    act = d["mean"] + np.exp(d["log_std"]) * np.random.randn(5, 2)
+    # at unchanged parameters the reparameterised action is the action itself
+    got = pol.get_reparam_action_sym(obs, act, d).detach().cpu().numpy()
+    assert np.allclose(got, act, atol=1e-5)
+    # optimize_gen yields between mini-batch steps; optimize() drains it
+    target = pol
+    x = torch.as_tensor(np.random.randn(3, 40), dtype=torch.float32, device=pol.flat_params.device)
+
+    def loss(flat, xs):
+        return (pol.mean_planes(xs, flat) ** 2).mean()
+    opt = FirstOrderOptimizer(max_epochs=2, batch_size=10, learning_rate=1e-2)
+    opt.update_opt(loss, target, [x])
+    l0 = opt.loss([x])
+    assert sum(1 for _ in opt.optimize_gen([x], yield_itr=0)) == 8     # 2 epochs x 4 mini-batches
+    assert opt.loss([x]) < l0
