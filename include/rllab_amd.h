@@ -290,6 +290,13 @@ int rl_trpo_step(int n, const double* x, const double* a, const double* b, doubl
 int rl_line_search_point(int n, const float* prev, const double* step, double ratio, float* theta,
                          void* stream);
 
+/* One Adam step of FirstOrderOptimizer (rllab/optimizers/first_order_optimizer.py:21-22,62-76: lasagne.updates.adam
+ * on the flat parameters), float64 arithmetic, in place:
+ *   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;  theta = (float)(theta - a_t m / (sqrt(v) + epsilon))
+ * with a_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) formed by the caller.  theta: float[n]; grad, m, v: double[n]. */
+int rl_adam_step(int n, float* theta, const double* grad, double* m, double* v, double a_t, double beta1,
+                 double beta2, double epsilon, void* stream);
+
 /* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
  * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */
 int rl_debug_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

@@ -49,8 +49,8 @@ class VPG(BatchPolopt, Serializable):
         fused = policy.fused_ops() if hasattr(policy, "fused_ops") and getattr(self, "use_fused", True) else None
         if fused is not None:
             def f_kl(inputs):  # noqa: F811  (HIP kernel version of the same statistic)
-                s = fused.loss_stats(inputs)
-                return float(s[1]), float(s[3])
+                s = fused.loss_stats_host(inputs)      # the evaluation's one host read (shared with loss())
+                return s[1], s[3]
         self.optimizer.update_opt(surr_obj, target=policy, inputs=None, fused=fused)
         self.opt_info = dict(f_kl=f_kl)
 

@@ -143,9 +143,33 @@ __global__ void __launch_bounds__(256) line_search_point_kernel(int n, const flo
     if (i < n) theta[i] = (float)((double)prev[i] - ratio * step[i]);
 }
 
+// One Adam step in Lasagne's form (lasagne.updates.adam, used by FirstOrderOptimizer, first_order_optimizer.py:21-22):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  theta = (float)(theta - a_t m / (sqrt(v) + eps)),
+//   a_t = lr sqrt(1 - b2^t) / (1 - b1^t) computed by the caller.  float64 arithmetic on the float32 parameters.
+__global__ void __launch_bounds__(256) adam_step_kernel(int n, float* __restrict__ theta, const double* __restrict__ g,
+                                                        double* __restrict__ m, double* __restrict__ v, double a_t,
+                                                        double b1, double b2, double eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double gi = g[i];
+    const double mi = b1 * m[i] + (1.0 - b1) * gi;
+    const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] = (float)((double)theta[i] - a_t * mi / (sqrt(vi) + eps));
+}
+
 }  // namespace rl
 
 using namespace rl;
+
+extern "C" int rl_adam_step(int n, float* theta, const double* grad, double* m, double* v, double a_t, double beta1,
+                            double beta2, double epsilon, void* stream) {
+    if (n <= 0 || !theta || !grad || !m || !v) return set_error(RL_ERR_ARG, "rl_adam_step: bad argument");
+    hipLaunchKernelGGL(adam_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, theta, grad, m, v,
+                       a_t, beta1, beta2, epsilon);
+    return check_launch("adam_step_kernel");
+}
 
 extern "C" int rl_trpo_step(int n, const double* x, const double* a, const double* b, double reg_coeff,
                             double max_constraint, double* step, double* out, void* stream) {

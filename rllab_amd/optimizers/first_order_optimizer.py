@@ -35,6 +35,20 @@ class _Adam(object):
         self.v = self.b2 * self.v + (1 - self.b2) * grad * grad
         return param - a_t * self.m / (torch.sqrt(self.v) + self.eps)
 
+    def step_in_place(self, theta32, grad):
+        """The same step written straight into the float32 device parameter vector by rl_adam_step (one launch
+        instead of ~10 small tensor kernels); float64 arithmetic and moments as in ``step``."""
+        from rllab_amd import _lib
+        grad = grad.to(torch.float64).contiguous()
+        if self.m is None:
+            self.m = torch.zeros_like(grad)
+            self.v = torch.zeros_like(grad)
+        self.t += 1
+        a_t = self.lr * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        _lib.check(_lib.lib.rl_adam_step(theta32.numel(), _lib.ptr(theta32), _lib.ptr(grad), _lib.ptr(self.m),
+                                         _lib.ptr(self.v), float(a_t), self.b1, self.b2, self.eps,
+                                         _lib.stream_ptr()), "rl_adam_step")
+
 
 class _SGD(object):
     def __init__(self, learning_rate=1e-3):
@@ -78,7 +92,7 @@ class FirstOrderOptimizer(Serializable):
     def loss(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
         if getattr(self, "_fused", None) is not None and self._fused.accepts(inputs):
-            return float(-self._fused.loss_stats(inputs)[2])
+            return -self._fused.loss_stats_host(inputs)[2]
         with torch.no_grad():
             v = self._loss(self._target.flat_params, *inputs).to(torch.float64)
         return float(D.all_reduce_sum_(v))
@@ -92,6 +106,15 @@ class FirstOrderOptimizer(Serializable):
             g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
             g = D.all_reduce_sum_(g.to(torch.float64))
         idx = target._flat_index(trainable=True)
+        flat = target.flat_params
+        if idx is None and flat.is_cuda and flat.dtype == torch.float32 and hasattr(self._updater, "step_in_place"):
+            self._updater.step_in_place(flat.detach(), g)
+            # the write bypassed torch: evaluation caches key on (tensor version, the fused ops' own epoch)
+            if getattr(self, "_fused", None) is not None:
+                self._fused._epoch += 1
+            else:
+                flat.add_(0)
+            return
         theta = target.flat_params.detach().to(torch.float64)
         if idx is not None:
             g, theta = g[idx], theta[idx]

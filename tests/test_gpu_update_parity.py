@@ -357,3 +357,23 @@ def test_grad_pass_also_returns_the_loss_sums(do, da, h):
     g2 = b.loss_grad(inp)
     assert torch.equal(g1, g2)
     assert np.all(np.abs(s1[:3] - s2[:3]) <= 1e-12 * np.maximum(1.0, np.abs(s2[:3]))) and s1[3] == s2[3]
+
+
+def test_adam_step_kernel_matches_the_tensor_form():
+    """rl_adam_step (in place on the float32 parameters) == the float64 tensor arithmetic of _Adam.step
+    (lasagne.updates.adam), step after step, moments included."""
+    from rllab_amd.optimizers.first_order_optimizer import _Adam
+    rng = np.random.RandomState(2)
+    n = 1250
+    theta0 = torch.as_tensor(rng.randn(n).astype(np.float32), device="cuda")
+    a, b = _Adam(learning_rate=1e-2), _Adam(learning_rate=1e-2)
+    ta, tb = theta0.clone(), theta0.clone()
+    for k in range(5):
+        g = torch.as_tensor(rng.randn(n), device="cuda")
+        ta = a.step(ta.double(), g).float()
+        b.step_in_place(tb, g)
+        # the kernel contracts b1 * m + (1 - b1) * g into an fma: float64 moments agree to rounding, the float32
+        # parameters to one unit in the last place
+        assert torch.allclose(a.m, b.m, rtol=1e-13, atol=1e-300) and torch.allclose(a.v, b.v, rtol=1e-13, atol=1e-300)
+        assert float((ta - tb).abs().max()) <= 2.4e-7 * float(ta.abs().max()), k
+        ta = tb.clone()
