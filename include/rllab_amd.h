@@ -247,11 +247,12 @@ int rl_policy_loss_kl(const rl_policy_batch* batch, void* workspace, size_t work
 int rl_policy_grad(const rl_policy_batch* batch, int vpg, void* workspace, size_t workspace_bytes,
                    double* grad_out, void* stream);
 
-/* rl_policy_grad (vpg == 0) and rl_policy_loss_kl in ONE pass over the batch: ConjugateGradientOptimizer.optimize
- * evaluates f_loss and f_grad back to back at the same parameters (conjugate_gradient_optimizer.py:247-251); the
- * forward pass, likelihood ratio and KL of the gradient pass are the ones the loss needs.
+/* rl_policy_grad and rl_policy_loss_kl in ONE pass over the batch: ConjugateGradientOptimizer.optimize evaluates
+ * f_loss and f_grad back to back at the same parameters (conjugate_gradient_optimizer.py:247-251), and so does
+ * FirstOrderOptimizer around its step (first_order_optimizer.py:96,109, vpg != 0); the forward pass, likelihood
+ * ratio and KL of the gradient pass are the ones the loss needs.
  * workspace: rl_policy_workspace_bytes (holds both kinds of partial rows). */
-int rl_policy_grad_loss(const rl_policy_batch* batch, void* workspace, size_t workspace_bytes,
+int rl_policy_grad_loss(const rl_policy_batch* batch, int vpg, void* workspace, size_t workspace_bytes,
                         double* grad_out, double* out4, void* stream);
 
 /* fvp_out (device, P doubles) = Fisher-vector product of the mean KL with `vec` [P] at

@@ -89,7 +89,7 @@ def _load():
     lib.rl_policy_activation_bytes.argtypes = [i32, i32, i32]
     lib.rl_policy_loss_kl.argtypes = [pb, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_grad.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp]
-    lib.rl_policy_grad_loss.argtypes = [pb, vp, ctypes.c_size_t, vp, vp, vp]
+    lib.rl_policy_grad_loss.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp, vp]
     lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]
     lib.rl_cg_init.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.rl_cg_step.argtypes = [i32, vp, f64, f64, vp, vp, vp, vp, vp, vp]

@@ -57,8 +57,14 @@ class VPG(BatchPolopt, Serializable):
     def optimize_policy(self, itr, samples_data):
         logger.log("optimizing policy")
         inputs = npo_inputs(self.policy, samples_data)
-        loss_before = self.optimizer.loss(inputs)
+        loss_before = None
+        if not getattr(self.optimizer, "reports_before_values", False):
+            loss_before = self.optimizer.loss(inputs)
         self.optimizer.optimize(inputs)
+        if loss_before is None:
+            before = getattr(self.optimizer, "last_before", None)
+            # (a mini-batch or non-fused run has evaluated the loss up front itself and cached nothing for us)
+            loss_before = before[0] if before is not None else float("nan")
         loss_after = self.optimizer.loss(inputs)
         logger.record_tabular("LossBefore", loss_before)
         logger.record_tabular("LossAfter", loss_after)

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
             const float lr = __expf(dlog);
             const float w1 = (lh == 0) ? wgt : 0.0f;        // both halves hold the sample: count it once
             // the gradient pass can hand back the loss / KL sums of the same forward pass (rl_policy_grad_loss)
-            if (MODE == MODE_LOSS || (MODE == MODE_GRAD && a.partial_loss != nullptr)) {
+            if (MODE == MODE_LOSS || ((MODE == MODE_GRAD || MODE == MODE_VPG) && a.partial_loss != nullptr)) {
                 acc_loss += (double)(w1 * lr * advb);
                 acc_kl += (double)(w1 * kl);
                 acc_vpg += (double)(w1 * (logp_new - 0.5f * (float)DA * 1.8378770664093453f) * advb);
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         }
         float* row = a.partial + (size_t)blockIdx.x * P;
         for (int k = threadIdx.x; k < P; k += WAVES * WV) row[k] = red[k];
-        if (MODE == MODE_GRAD && a.partial_loss != nullptr) {
+        if ((MODE == MODE_GRAD || MODE == MODE_VPG) && a.partial_loss != nullptr) {
             __syncthreads();   // the fold buffer is read out
             fold_loss();
         }
@@ -654,7 +654,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     const int need = (n_tiles + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
     if (grid > MAX_GRID) grid = MAX_GRID;
-    const bool with_loss = (MODE == MODE_GRAD) && loss_out != nullptr;
+    const bool with_loss = (MODE == MODE_GRAD || MODE == MODE_VPG) && loss_out != nullptr;
     const size_t row_bytes = (((size_t)grid * N::P * sizeof(float)) + 15) & ~(size_t)15;
     const size_t need_bytes = (MODE == MODE_LOSS) ? (size_t)grid * LOSS_COLS * sizeof(double)
                                                   : row_bytes + (with_loss ? (size_t)grid * LOSS_COLS * sizeof(double) : 0);
@@ -699,7 +699,7 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
             if constexpr (N::ACT_CACHE)
                 if (g->activations) return launch_pass<N, MODE_FVP, true>(g, vec, ws, ws_bytes, out, st);
             return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st);
-        case MODE_VPG: return launch_pass<N, MODE_VPG>(g, vec, ws, ws_bytes, out, st);
+        case MODE_VPG: return launch_pass<N, MODE_VPG>(g, vec, ws, ws_bytes, out, st, loss_out);
     }
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
 }
@@ -777,13 +777,14 @@ extern "C" int rl_policy_grad(const rl_policy_batch* g, int vpg, void* workspace
                         (hipStream_t)stream);
 }
 
-extern "C" int rl_policy_grad_loss(const rl_policy_batch* g, void* workspace, size_t workspace_bytes,
+extern "C" int rl_policy_grad_loss(const rl_policy_batch* g, int vpg, void* workspace, size_t workspace_bytes,
                                    double* grad_out, double* out4, void* stream) {
     int rc = check_batch(g, "rl_policy_grad_loss");
     if (rc) return rc;
     if (!g->actions || !g->advantages || !g->old_means || !g->old_log_std || !grad_out || !out4)
         return set_error(RL_ERR_ARG, "rl_policy_grad_loss: bad argument");
-    return dispatch_net(MODE_GRAD, g, nullptr, workspace, workspace_bytes, grad_out, (hipStream_t)stream, out4);
+    return dispatch_net(vpg ? MODE_VPG : MODE_GRAD, g, nullptr, workspace, workspace_bytes, grad_out,
+                        (hipStream_t)stream, out4);
 }
 
 extern "C" int rl_policy_fvp(const rl_policy_batch* g, const float* vec, void* workspace,

@@ -67,6 +67,8 @@ def sgd(learning_rate=1e-3, **kw):
 
 
 class FirstOrderOptimizer(Serializable):
+    reports_before_values = True     # optimize() leaves (loss, mean KL, max KL) at its starting point in last_before
+
     def __init__(self, update_method=adam, learning_rate=1e-3, max_epochs=1000, tolerance=1e-6,
                  batch_size=32, callback=None, verbose=False, **kwargs):
         Serializable.quick_init(self, locals())
@@ -97,10 +99,12 @@ class FirstOrderOptimizer(Serializable):
             v = self._loss(self._target.flat_params, *inputs).to(torch.float64)
         return float(D.all_reduce_sum_(v))
 
-    def _step(self, inputs):
+    def _step(self, inputs, with_loss=False):
         target = self._target
         if getattr(self, "_fused", None) is not None and self._fused.accepts(inputs):
-            g = self._fused.loss_grad(inputs, vpg=True)
+            g = self._fused.loss_grad(inputs, vpg=True, with_loss=with_loss)
+            if with_loss:
+                self._pre_step_stats = self._fused.loss_stats_deferred(inputs)   # served by the gradient pass
         else:
             flat = target.flat_params.detach().clone().requires_grad_(True)
             g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
@@ -130,17 +134,35 @@ class FirstOrderOptimizer(Serializable):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
         if len(inputs) == 0:
             raise NotImplementedError
-        last_loss = self.loss(inputs)
+        # Full batch on the fused kernels: the gradient pass of an epoch's single step also produces the loss at the
+        # parameters it starts from (rl_policy_grad_loss), read when the epoch's new loss is read -- no separate
+        # loss pass and no blocking read before the step.  ``last_before`` = (loss, mean KL, max KL) at the start.
+        fused_full = (self._batch_size is None and getattr(self, "_fused", None) is not None
+                      and self._fused.accepts(inputs))
+        self.last_before = None
+        last_loss = None if fused_full else self.loss(inputs)
+        if last_loss is not None:
+            self.last_before = (last_loss, None, None)
         start_time = time.time()
         dataset = BatchDataset(inputs, self._batch_size, sample_axis=-1)   # planes: the sample axis is last
         itr = 0
         for epoch in range(self._max_epochs):
             for batch in dataset.iterate(update=True):
-                self._step(tuple(batch))
+                before = None
+                if fused_full and last_loss is None:
+                    self._step(tuple(batch), with_loss=True)       # records the loss / KL sums of the old parameters
+                else:
+                    self._step(tuple(batch))
                 if yield_itr is not None and itr % (yield_itr + 1) == 0:
                     yield
                 itr += 1
+            if fused_full and last_loss is None:
+                before = self._pre_step_stats
             new_loss = self.loss(inputs)
+            if before is not None:
+                s0 = before()
+                last_loss = -s0[2]
+                self.last_before = (last_loss, s0[1], s0[3])
             if self._verbose:
                 logger.log("Epoch %d, loss %s" % (epoch, new_loss))
             if self._callback or callback:

@@ -126,6 +126,12 @@ class FusedGaussianMLPOps(object):
         s = self.loss_stats_host(inputs)
         return -s[0], s[1]
 
+    def loss_stats_deferred(self, inputs):
+        """Like ``loss_stats_host`` but read later: returns ``f`` with ``f() -> (sum lr adv, KL, logp adv) / W, max KL``
+        of the evaluation at the parameters as they are NOW, valid after they move on."""
+        c = self._loss_eval(inputs)
+        return lambda: self._resolve(c)
+
     def loss_and_kl_deferred(self, inputs):
         """Launch the pass now, read later: returns ``f`` with ``f() -> (loss, mean KL)``.  The record stays
         valid after the parameters move on (the optimizer needs loss_before only at its first comparison)."""
@@ -160,10 +166,11 @@ class FusedGaussianMLPOps(object):
         tag = self._eval_point(inputs)
         have_loss = self._loss_cache is not None and self._loss_cache["tag"] == tag
         try:
-            if with_loss and not vpg and not have_loss:
+            if with_loss and not have_loss:
                 out4 = torch.empty(4, dtype=torch.float64, device=keep[0].device)
-                _lib.check(_lib.lib.rl_policy_grad_loss(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
-                                                        _lib.ptr(out4), _lib.stream_ptr()), "rl_policy_grad_loss")
+                _lib.check(_lib.lib.rl_policy_grad_loss(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(),
+                                                        _lib.ptr(out), _lib.ptr(out4), _lib.stream_ptr()),
+                           "rl_policy_grad_loss")
                 self._loss_record(tag, out4, inv)
             else:
                 _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(),

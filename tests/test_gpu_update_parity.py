@@ -357,6 +357,12 @@ def test_grad_pass_also_returns_the_loss_sums(do, da, h):
     g2 = b.loss_grad(inp)
     assert torch.equal(g1, g2)
     assert np.all(np.abs(s1[:3] - s2[:3]) <= 1e-12 * np.maximum(1.0, np.abs(s2[:3]))) and s1[3] == s2[3]
+    # the VPG gradient pass (d log p) hands back the same sums
+    c = pol.fused_ops()
+    g3 = c.loss_grad(inp, vpg=True, with_loss=True)
+    s3 = np.array(c.loss_stats_host(inp))
+    assert torch.equal(g3, b.loss_grad(inp, vpg=True))
+    assert np.all(np.abs(s3[:3] - s2[:3]) <= 1e-12 * np.maximum(1.0, np.abs(s2[:3]))) and s3[3] == s2[3]
 
 
 def test_adam_step_kernel_matches_the_tensor_form():
