@@ -236,9 +236,9 @@ def main():
     do, da, h = policy.obs_dim, policy.action_dim, wl["hidden"][0]
     ht, ks0, ks1 = h // 32, (do + 2) // 2, 16 * (h // 32)
     # algorithmic matrix instructions of one FVP per 32-sample tile: tangent forward + back-propagation + the
-    # W1 outer product; the forward pass itself only where the gradient pass cannot leave its activations
-    # behind (64-unit nets): what TRPO's CG loop actually launches
-    cached = ht == 1
+    # W1 outer product (the forward pass is read back from the gradient pass's activation cache): what TRPO's
+    # CG loop actually launches
+    cached = True      # both net widths keep the activations (32 units: LDS-direct prefetch, 64: register prefetch)
     mfma_per_tile = (0 if cached else ht * (ks0 + ks1)) + ht * (ks0 + 2 * ks1) + ht * ks1 + ht * ht * 16
     fvp_ms = None
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None

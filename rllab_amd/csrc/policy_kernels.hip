@@ -64,7 +64,7 @@ struct Smem {
     static constexpr int DTAIL = TAIL + N::TAILP;
     static constexpr int WAVE0 = DTAIL + (FVP ? N::TAILP : 0);
     static constexpr int ACTQ = WAVE0 + WAVES * N::WAVE_LDS;      // [WAVES][ACT_FLOATS] landing zone (cached FVP)
-    static constexpr int TOTAL = ACTQ + ((FVP && CACHE) ? WAVES * ACT_FLOATS : 0);
+    static constexpr int TOTAL = ACTQ + ((FVP && CACHE && N::ACT_LDS_PREFETCH) ? WAVES * ACT_FLOATS : 0);
     static constexpr int RED = 0;                                 // [P] cross-wave fold, aliases the fragments
     static_assert(TOTAL >= N::P, "LDS fold buffer must fit");
 };
@@ -203,7 +203,18 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         for (int q = 0; q < ACT_ROWS; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(hq + q * WV * 4), 16, 0, 0);
     };
-    if (LOAD_ACTS && wave_global < n_tiles) fetch_acts(wave_global);
+    // register form of the same prefetch (64-unit nets)
+    constexpr bool ACTS_VIA_LDS = LOAD_ACTS && N::ACT_LDS_PREFETCH, ACTS_VIA_REGS = LOAD_ACTS && !N::ACT_LDS_PREFETCH;
+    f32x4 act_next[ACTS_VIA_REGS ? ACT_ROWS : 1];
+    auto fetch_acts_regs = [&](int tile) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.acts) + (size_t)tile * ACT_ROWS * WV + lane;
+#pragma unroll
+        for (int q = 0; q < ACT_ROWS; ++q) act_next[q] = __builtin_nontemporal_load(src + q * WV);
+    };
+    if (ACTS_VIA_LDS && wave_global < n_tiles) fetch_acts(wave_global);
+    if constexpr (ACTS_VIA_REGS) {
+        if (wave_global < n_tiles) fetch_acts_regs(wave_global);
+    }
 
     for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
         asm volatile("" ::: "memory");   // keep the weight-fragment reads inside the loop
@@ -218,7 +229,18 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 
         // ---- forward (or the fragments the gradient pass left in HBM) ------------------------------
         f32x16 h0[HT], h1[HT];
-        if constexpr (LOAD_ACTS) {
+        if constexpr (ACTS_VIA_REGS) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h0[t][4 * q + e] = act_next[t * 4 + q][e];
+                        h1[t][4 * q + e] = act_next[(HT + t) * 4 + q][e];
+                    }
+            if (tile + waves_total < n_tiles) fetch_acts_regs(tile + waves_total);
+        } else if constexpr (ACTS_VIA_LDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tile fetched during the previous tile has landed
 #pragma unroll
             for (int t = 0; t < HT; ++t)
@@ -752,8 +774,7 @@ extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden
 }
 
 extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1) {
-    // only the 32-unit nets keep a cache: at 64 units the landing zone no longer fits LDS next to the weight fragments
-    if (n_samples <= 0 || hidden0 != hidden1 || hidden0 != 32) return 0;
+    if (n_samples <= 0 || hidden0 != hidden1 || (hidden0 != 32 && hidden0 != 64)) return 0;
     const size_t n_tiles = ((size_t)n_samples + TS - 1) / TS;
     return n_tiles * 2 * (size_t)(hidden0 / 32) * 16 * WV * sizeof(float);
 }

@@ -65,7 +65,11 @@ struct Net {
     // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
     static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
     // the update kernels can keep the hidden activations of a batch in HBM between the gradient and the FVP passes
-    static constexpr bool ACT_CACHE = (HT == 1);
+    static constexpr bool ACT_CACHE = true;
+    // how the cached fragments of the NEXT tile travel to the FVP pass: LDS-direct loads into a wave-private landing
+    // zone (32-unit nets at two wavefronts per SIMD: no registers to spare), or plain loads into registers (64-unit
+    // nets run one wavefront per SIMD with 512 registers, and their landing zones would not fit LDS)
+    static constexpr bool ACT_LDS_PREFETCH = (HT == 1);
     static_assert(H % 32 == 0 && HT <= 2, "hidden size must be 32 or 64");
     static_assert(DO + 1 <= 32, "obs_dim + 1 must fit one 32-row tile");
 
