@@ -77,6 +77,16 @@ int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const uint8_t* m
                     const float* draws, uint64_t seed, uint64_t step_counter,
                     int env_offset, float* obs, void* stream);
 
+/* rl_vecenv_step for launches replayed from a hipGraph (the per-step loop of an arbitrary policy is launch-bound:
+ * policy kernels + one step kernel per transition, T times; captured once and replayed, it pays one graph launch per
+ * transition).  Kernel arguments are frozen at capture, so the RNG counter of the transition comes from a device
+ * word, advanced between replays by rl_counter_add (itself a node of the graph).  No injected reset draws. */
+int rl_vecenv_step_graph(int kind, int n_envs, int normalize, float scale_reward, int max_path_length,
+                         int auto_reset, float* state, int32_t* ts, const float* actions, uint64_t seed,
+                         const uint64_t* step_counter_dev, int env_offset, float* obs, float* reward,
+                         uint8_t* done, void* stream);
+int rl_counter_add(uint64_t* counter_dev, uint64_t increment, void* stream);
+
 /* Observation of the state planes as they are, without a transition: obs[obs_dim][n] = observe(state).
  * Env.get_current_obs of the reference env bases (rllab/envs/box2d/box2d_env.py:210-218,
  * rllab/envs/mujoco/mujoco_env.py:118-131); used after a state was written from outside. */

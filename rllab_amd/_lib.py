@@ -26,7 +26,7 @@ ENV_INVERTED_DOUBLE_PENDULUM = 7
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds",
-    "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_gae",
+    "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
@@ -77,6 +77,8 @@ def _load():
     lib.rl_env_action_bounds.argtypes = [i32, fp, fp]
     lib.rl_vecenv_reset.argtypes = [i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp]
     lib.rl_vecenv_observe.argtypes = [i32, i32, vp, vp, vp]
+    lib.rl_vecenv_step_graph.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, u64, vp, i32, vp, vp, vp, vp]
+    lib.rl_counter_add.argtypes = [vp, u64, vp]
     lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp, vp, vp]
     lib.rl_rollout_gaussian_mlp.argtypes = [ctypes.POINTER(RolloutArgs), vp]
     lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp, vp]

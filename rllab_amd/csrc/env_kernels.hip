@@ -88,10 +88,13 @@ __global__ void __launch_bounds__(BLOCK)
 vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length, int auto_reset,
                    float* __restrict__ state, int32_t* __restrict__ ts,
                    const float* __restrict__ actions, const float* __restrict__ reset_draws,
-                   uint64_t seed, uint64_t step, int env_offset, float* __restrict__ obs,
-                   float* __restrict__ reward, uint8_t* __restrict__ done) {
+                   uint64_t seed, uint64_t step_value, const uint64_t* __restrict__ step_dev, int env_offset,
+                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
+    // the RNG counter of this transition: an argument, or -- for launches replayed from a hipGraph, whose arguments
+    // are frozen at capture -- a device word that rl_counter_add advances between replays
+    const uint64_t step = step_dev ? *step_dev : step_value;
     float s[Env::STATE];
     load_state<Env>(state, n, i, s);
     float a[Env::ACT];
@@ -640,10 +643,12 @@ template <class Env>
 static int launch_step(int n, int normalize, float scale_reward, int mpl, int auto_reset, float* state,
                        int32_t* ts,
                        const float* actions, const float* reset_draws, uint64_t seed, uint64_t step,
-                       int env_offset, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+                       const uint64_t* step_dev, int env_offset, float* obs, float* reward, uint8_t* done,
+                       hipStream_t st) {
     dim3 grid((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(vecenv_step_kernel<Env>, grid, dim3(BLOCK), 0, st, n, normalize, scale_reward, mpl,
-                       auto_reset, state, ts, actions, reset_draws, seed, step, env_offset, obs, reward, done);
+                       auto_reset, state, ts, actions, reset_draws, seed, step, step_dev, env_offset, obs, reward,
+                       done);
     return check_launch("vecenv_step_kernel");
 }
 
@@ -746,8 +751,29 @@ extern "C" int rl_vecenv_step(int kind, int n, int normalize, float scale_reward
         return set_error(RL_ERR_ARG, "rl_vecenv_step: bad argument");
     RL_DISPATCH_ENV(kind, launch_step<E>(n, normalize, scale_reward, max_path_length, auto_reset, state, ts,
                                          actions,
-                                         reset_draws, seed, step_counter, env_offset, obs, reward, done,
+                                         reset_draws, seed, step_counter, nullptr, env_offset, obs, reward, done,
                                          (hipStream_t)stream))
+}
+
+extern "C" int rl_vecenv_step_graph(int kind, int n, int normalize, float scale_reward, int max_path_length,
+                                    int auto_reset, float* state, int32_t* ts, const float* actions, uint64_t seed,
+                                    const uint64_t* step_counter_dev, int env_offset, float* obs, float* reward,
+                                    uint8_t* done, void* stream) {
+    if (n <= 0 || !state || !ts || !actions || !obs || !reward || !done || !step_counter_dev)
+        return set_error(RL_ERR_ARG, "rl_vecenv_step_graph: bad argument");
+    RL_DISPATCH_ENV(kind, launch_step<E>(n, normalize, scale_reward, max_path_length, auto_reset, state, ts,
+                                         actions, nullptr, seed, 0, step_counter_dev, env_offset, obs, reward, done,
+                                         (hipStream_t)stream))
+}
+
+namespace rl {
+__global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
+}
+
+extern "C" int rl_counter_add(uint64_t* counter_dev, uint64_t increment, void* stream) {
+    if (!counter_dev) return set_error(RL_ERR_ARG, "rl_counter_add: null counter");
+    hipLaunchKernelGGL(rl::counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, increment);
+    return check_launch("counter_add_kernel");
 }
 
 extern "C" int rl_rollout_gaussian_mlp(const rl_rollout_args* g, void* stream) {

@@ -16,21 +16,24 @@ Plug in with ``TRPO(..., sampler_cls=VectorizedSampler, sampler_args=dict(n_envs
 each rank owns ``n_envs`` envs with global indices ``rank*n_envs ...`` (weak scaling).
 """
 import math
+import os
 import time
 
 import torch
 
 import rllab_amd.misc.logger as logger
+from rllab_amd import _lib
 from rllab_amd.sampler import dist as D
 from rllab_amd.sampler.base import BaseSampler
 from rllab_amd.sampler.trajectories import PathList, Trajectories
 
 
 class VectorizedSampler(BaseSampler):
-    def __init__(self, algo, n_envs=None, seed=None):
+    def __init__(self, algo, n_envs=None, seed=None, use_graph=True):
         super(VectorizedSampler, self).__init__(algo)
         self.n_envs = n_envs
         self.seed = seed
+        self.use_graph = use_graph     # hipGraph replay of the per-transition loop (policies without a fused rollout)
         self.vec_env = None
         self.last_sample_time = None
         self.last_num_samples = None
@@ -38,6 +41,7 @@ class VectorizedSampler(BaseSampler):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["vec_env"] = None
+        d.pop("_step_graph", None)
         return d
 
     def start_worker(self):
@@ -65,12 +69,87 @@ class VectorizedSampler(BaseSampler):
         if getattr(policy, "fusable", False) and len(getattr(policy, "hidden_sizes", ())) == 2 \
                 and tuple(policy.hidden_sizes) in ((32, 32), (64, 64)):
             traj = self.vec_env.rollout(policy, T, reset_at_start=True)
+        elif self.use_graph and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "effective_log_std"):
+            traj = self._stepwise_rollout_graph(policy, T)
         else:
             traj = self._stepwise_rollout(policy, T)
         self.last_traj = traj
         self.last_num_samples = traj.B
         self.last_sample_time = time.time() - t_start  # enqueue time only; bench syncs explicitly
         return PathList(traj)
+
+    # -- arbitrary vectorised policies: one transition at a time --------------------------------------------------
+    # T x (policy kernels, noise, copies, one env-step kernel) is a launch-bound loop: at 4096 envs every kernel in
+    # it runs for microseconds.  One transition is captured into a hipGraph (torch.cuda.CUDAGraph; the env step and
+    # the counter bump are nodes like any other because they are launched on the capturing stream) and replayed T
+    # times; what changes from replay to replay lives in device memory -- the write position t_idx, the RNG counter
+    # of the env step (rl_vecenv_step_graph reads it from a device word) and torch's own graph-safe generator state.
+    def _graph_for(self, policy, T):
+        v = self.vec_env
+        key = (id(policy), T, v.n)
+        g = getattr(self, "_step_graph", None)
+        if g is not None and g["key"] == key:
+            return g
+        n, do, da = v.n, v.q["obs_dim"], v.q["act_dim"]
+        dev = v.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = dict(key=key,
+                  obs_p=torch.empty((do, T, n), **f32), act_p=torch.empty((da, T, n), **f32),
+                  mean_p=torch.empty((da, T, n), **f32), rew_p=torch.empty((T, n), **f32),
+                  done_p=torch.empty((T, n), dtype=torch.uint8, device=dev),
+                  a_planes=torch.zeros((da, n), **f32),
+                  t_idx=torch.zeros(1, dtype=torch.int64, device=dev),
+                  counter=torch.zeros(1, dtype=torch.int64, device=dev))
+
+        def one_transition():
+            obs = v._obs.t()                                           # [n, Do] view of the executor's buffer
+            st["obs_p"].index_copy_(1, st["t_idx"], v._obs.unsqueeze(1))
+            actions, info = policy.get_actions(obs)
+            st["a_planes"].copy_(actions.t())
+            st["act_p"].index_copy_(1, st["t_idx"], st["a_planes"].unsqueeze(1))
+            st["mean_p"].index_copy_(1, st["t_idx"], info["mean"].t().unsqueeze(1))
+            _lib.check(_lib.lib.rl_vecenv_step_graph(
+                v.kind, n, int(v.normalize), v.scale_reward, v.max_path_length, int(v.auto_reset),
+                _lib.ptr(v.state), _lib.ptr(v.ts), _lib.ptr(st["a_planes"]), v.seed, _lib.ptr(st["counter"]),
+                v.env_offset, _lib.ptr(v._obs), _lib.ptr(v._reward), _lib.ptr(v._done), _lib.stream_ptr()),
+                "rl_vecenv_step_graph")
+            st["rew_p"].index_copy_(0, st["t_idx"], v._reward.unsqueeze(0))
+            st["done_p"].index_copy_(0, st["t_idx"], v._done.unsqueeze(0))
+            st["t_idx"].add_(1)
+            _lib.check(_lib.lib.rl_counter_add(_lib.ptr(st["counter"]), 1, _lib.stream_ptr()), "rl_counter_add")
+
+        # warm-up on a side stream (allocator pools, lazy initialisation), then the capture itself; neither may be
+        # counted as a transition, so position and env state are restored around them
+        snap = (v.state.clone(), v.ts.clone(), v._obs.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                st["t_idx"].zero_()
+                one_transition()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        st["t_idx"].zero_()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            one_transition()
+        v.state.copy_(snap[0]); v.ts.copy_(snap[1]); v._obs.copy_(snap[2])
+        st["graph"] = graph
+        self._step_graph = st
+        return st
+
+    def _stepwise_rollout_graph(self, policy, T):
+        v = self.vec_env
+        v.reset()
+        st = self._graph_for(policy, T)
+        st["t_idx"].zero_()
+        st["counter"].fill_(v.step_counter)
+        for _ in range(T):
+            st["graph"].replay()
+        v.step_counter += T
+        # the planes belong to the graph: hand out copies, as the eager path hands out fresh tensors
+        return Trajectories(st["obs_p"].clone(), st["act_p"].clone(), st["mean_p"].clone(),
+                            policy.effective_log_std().detach(), st["rew_p"].clone(), st["done_p"].clone(),
+                            v.max_path_length)
 
     def _stepwise_rollout(self, policy, T):
         """Generic vectorised path: one policy.get_actions + one rl_vecenv_step launch per step."""
