@@ -70,7 +70,17 @@ class VectorizedSampler(BaseSampler):
                 and tuple(policy.hidden_sizes) in ((32, 32), (64, 64)):
             traj = self.vec_env.rollout(policy, T, reset_at_start=True)
         elif self.use_graph and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "effective_log_std"):
-            traj = self._stepwise_rollout_graph(policy, T)
+            try:
+                traj = self._stepwise_rollout_graph(policy, T)
+            except RuntimeError as err:
+                # a policy whose get_actions cannot be captured (host round trips, data-dependent control flow):
+                # say so once and sample it with the eager loop from here on
+                logger.log("hipGraph capture of the per-transition loop failed (%s); using the eager loop"
+                           % str(err).split("\n")[0])
+                self.use_graph = False
+                self._step_graph = None
+                torch.cuda.synchronize()
+                traj = self._stepwise_rollout(policy, T)
         else:
             traj = self._stepwise_rollout(policy, T)
         self.last_traj = traj
