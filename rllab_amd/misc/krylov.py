@@ -37,3 +37,33 @@ def cg(f_Ax, b, cg_iters=10, callback=None, verbose=False, residual_tol=1e-10):
     if callback is not None:
         callback(x)
     return x
+
+
+def preconditioned_cg(f_Ax, f_Minvx, b, cg_iters=10, callback=None, verbose=False, residual_tol=1e-10):
+    """Preconditioned CG (rllab/misc/krylov.py:40-75, Demmel p.318): the direction is built from y = M^-1 r and the
+    stopping test is on y.r.  Same device-resident, sync-free form as ``cg``: the early exit freezes the iterates."""
+    b = torch.as_tensor(b).to(torch.float64)
+    x = torch.zeros_like(b)
+    r = b.clone()
+    p = f_Minvx(b).to(torch.float64)
+    ydotr = p.dot(r)
+    active = torch.ones((), dtype=torch.bool, device=b.device)
+    tol = torch.as_tensor(residual_tol, dtype=torch.float64, device=b.device)
+    for i in range(cg_iters):
+        if callback is not None:
+            callback(x, f_Ax)
+        if verbose:
+            print("%10i %10.3g %10.3g" % (i, float(ydotr), float(x.norm())))
+        z = f_Ax(p).to(torch.float64)
+        v = ydotr / p.dot(z)
+        x_new = x + v * p
+        r_new = r - v * z
+        y = f_Minvx(r_new).to(torch.float64)
+        newydotr = y.dot(r_new)
+        p_new = y + (newydotr / ydotr) * p
+        x = torch.where(active, x_new, x)
+        r = torch.where(active, r_new, r)
+        p = torch.where(active, p_new, p)
+        ydotr = torch.where(active, newydotr, ydotr)
+        active = active & (ydotr >= tol)
+    return x

@@ -501,3 +501,16 @@ def test_reparam_action_and_optimize_gen(quiet_logger):
     l0 = opt.loss([x])
     assert sum(1 for _ in opt.optimize_gen([x], yield_itr=0)) == 8     # 2 epochs x 4 mini-batches
     assert opt.loss([x]) < l0
+
+
+def test_preconditioned_cg_solves_and_matches_plain_cg_with_identity():
+    from rllab_amd.misc import krylov
+    rng = np.random.RandomState(0)
+    A = rng.randn(12, 12)
+    A = torch.as_tensor(A @ A.T + 12 * np.eye(12))
+    b = torch.as_tensor(rng.randn(12))
+    f = lambda v: A @ v
+    x = krylov.preconditioned_cg(f, lambda v: v / torch.diagonal(A), b, cg_iters=40)
+    assert float((A @ x - b).abs().max()) < 1e-8
+    same = krylov.preconditioned_cg(f, lambda v: v.clone(), b, cg_iters=5)
+    assert torch.allclose(same, krylov.cg(f, b, cg_iters=5), rtol=1e-12, atol=1e-14)
