@@ -514,3 +514,24 @@ def test_preconditioned_cg_solves_and_matches_plain_cg_with_identity():
     assert float((A @ x - b).abs().max()) < 1e-8
     same = krylov.preconditioned_cg(f, lambda v: v.clone(), b, cg_iters=5)
     assert torch.allclose(same, krylov.cg(f, b, cg_iters=5), rtol=1e-12, atol=1e-14)
+
+
+def test_device_io_and_fold_stats_on_cpu():
+    """read_async / upload_async degrade to immediate copies without a device; fold_stats sums the additive
+    statistics columns over ranks and folds the extrema columns."""
+    from rllab_amd.misc.device_io import read_async, upload_async
+    from rllab_amd.sampler import base as B
+    t = torch.arange(6.).reshape(2, 3)
+    r = read_async(t)
+    t += 1                                              # the handle holds its own copy
+    assert np.array_equal(r.get(), np.arange(6.).reshape(2, 3)) and r.get() is r.get()
+    u = upload_async(np.arange(4.), torch.float64, torch.device("cpu"))
+    assert u.dtype == torch.float64 and u.tolist() == [0.0, 1.0, 2.0, 3.0]
+    rows = np.zeros((2, 20))
+    rows[0, B._COUNT], rows[1, B._COUNT] = 10, 5
+    rows[0, B._ADVMIN], rows[1, B._ADVMIN] = -1.0, -3.0
+    rows[0, B._UNDMAX], rows[1, B._UNDMAX] = 7.0, 2.0
+    rows[0, B._PROGMIN], rows[1, B._PROGMIN] = 0.5, 0.25
+    out = B.fold_stats(rows)
+    assert out[B._COUNT] == 15 and out[B._ADVMIN] == -3.0 and out[B._UNDMAX] == 7.0 and out[B._PROGMIN] == 0.25
+    assert np.array_equal(B.fold_stats(rows[:1]), rows[0])
