@@ -628,8 +628,20 @@ __global__ void __launch_bounds__(RR_WAVES * WV) reduce_rows_kernel(const float*
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
     const int c = blockIdx.x * WV + lane;
     double s = 0.0;
-    if (c < cols)
-        for (int r = wave; r < rows; r += RR_WAVES) s += (double)partial[(size_t)r * cols + c];
+    if (c < cols) {
+        // four independent partial sums: the loads of a wavefront's rows are in flight together instead of one
+        // dependent load-add per row (fixed association, still deterministic)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = wave;
+        for (; r + 3 * RR_WAVES < rows; r += 4 * RR_WAVES) {
+            s0 += (double)partial[(size_t)r * cols + c];
+            s1 += (double)partial[(size_t)(r + RR_WAVES) * cols + c];
+            s2 += (double)partial[(size_t)(r + 2 * RR_WAVES) * cols + c];
+            s3 += (double)partial[(size_t)(r + 3 * RR_WAVES) * cols + c];
+        }
+        for (; r < rows; r += RR_WAVES) s0 += (double)partial[(size_t)r * cols + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && c < cols) {
