@@ -286,8 +286,8 @@ def main():
                      "envs_per_wavefront": envs_per_wave,
                      "note": "issue-bound, not HBM-bound: %d envs per wavefront => %d wavefronts on 1024 SIMDs, each "
                              "a single dependent instruction stream (physics sub-steps fused in registers); a lone "
-                             "wavefront issues ~1 VALU op per 4.4 cycles (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = "
-                             "0.85), so launch time = instructions per wavefront x 4.4 cycles x T and the HBM fraction "
+                             "wavefront issues 1 VALU op per 4 cycles nine tenths of the time (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = "
+                             "0.90), so launch time ~ instructions per wavefront x 4.5 cycles x T and the HBM fraction "
                              "is small by construction (SURVEY.md 8d, DESIGN.md 3.1)" % (envs_per_wave, n_waves)},
     }
     if fvp_ms is not None:
