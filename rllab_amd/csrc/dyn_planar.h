@@ -488,6 +488,10 @@ struct PlanarTree {
                 }
             });
         });
+        if constexpr (two_legs()) {
+            solve_two_legs<R>(Bx, By, C, Nz, tau_j, Fx[0], Fy[0], qacc);
+            return;
+        }
         // --- eliminate the translations: S = C - B^T B / m,  b = rhs_rot - B^T rhs_xy / m -------------
         constexpr double INV_M = 1.0 / total_mass();
         const R gx_ = Fx[0] * (R)INV_M, gy_ = Fy[0] * (R)INV_M;   // rhs_xy / m
@@ -517,6 +521,87 @@ struct PlanarTree {
         static_for<0, NB>([&](auto Rr) {
             constexpr int r = decltype(Rr)::value;
             qacc[2 + r] = th[r];
+        });
+    }
+
+    // A torso carrying two three-link legs (HalfCheetah, Walker2D): bodies 1-2-3 and 4-5-6 are chains off body 0.
+    static constexpr bool two_legs() {
+        if (NB != 7) return false;
+        constexpr int want[7] = {-1, 0, 1, 2, 0, 4, 5};
+        for (int i = 1; i < 7; ++i)
+            if (Mdl::parent(i) != want[i]) return false;
+        return true;
+    }
+
+    // x = K^-1 r for a symmetric positive definite 3x3 K given by (a, b, c, d, e, f) = (K00, K10, K20, K11, K21, K22):
+    // adjugate form, `adj` = the six cofactors times 1 / det, so several right-hand sides share ONE division
+    template <typename R>
+    RL_HD static void spd3_inverse(R a, R b, R c, R d, R e, R f, R* adj) {
+        const R A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
+        const R D = a * f - c * c, E = b * c - a * e, F = a * d - b * b;
+        const R det = a * A + (b * B + c * C);
+        const R inv = (R)1 / det;
+        adj[0] = A * inv; adj[1] = B * inv; adj[2] = C * inv; adj[3] = D * inv; adj[4] = E * inv; adj[5] = F * inv;
+    }
+    template <typename R>
+    RL_HD static void spd3_apply(const R* adj, R r0, R r1, R r2, R& x0, R& x1, R& x2) {
+        x0 = adj[0] * r0 + (adj[1] * r1 + adj[2] * r2);
+        x1 = adj[1] * r0 + (adj[3] * r1 + adj[4] * r2);
+        x2 = adj[2] * r0 + (adj[4] * r1 + adj[5] * r2);
+    }
+
+    // The joint-space system of a two-legged tree,
+    //     [ m I_2   B   ] [ a  ]   [ F   ]        B_r = (Bx[r], By[r]),  C tree-sparse: legs couple only through body 0,
+    //     [ B^T     C   ] [ th ] = [ rhs ]
+    // solved leaves first: each leg's 3x3 block K_L (closed form, one division, the two legs independent of each other)
+    // is eliminated onto the root block u = (a_x, a_y, th_0), whose 3x3 Schur complement is solved in closed form, then
+    // the legs are back-substituted: th_L = K_L^-1 rhs_L - (K_L^-1 G_L) u, G_L = rows (Bx, By, C[.][0]) of the leg.
+    // Eliminating the translations first (the generic path below) fills the 7x7 rotational block completely and then
+    // needs seven sequential pivots; this order keeps the tree's sparsity: three divisions, two of them in parallel.
+    template <typename R>
+    RL_HD static void solve_two_legs(const R* Bx, const R* By, const R (&C)[NB][NB], const R* Nz, const R* tau_j,
+                                     R Fx0, R Fy0, R* qacc) {
+        R Y[2][3][3];      // K_L^-1 G_L : [leg][row in leg][x, y, th0]
+        R y[2][3];         // K_L^-1 rhs_L
+        R Rm[6];           // root block, lower triangle (xx, yx, yy, tx, ty, tt), starts as [[m, 0, Bx0], [0, m, By0], [., ., C00]]
+        R ru[3];           // root right-hand side
+        Rm[0] = (R)total_mass(); Rm[1] = (R)0; Rm[2] = (R)total_mass();
+        Rm[3] = Bx[0]; Rm[4] = By[0]; Rm[5] = C[0][0];
+        ru[0] = Fx0; ru[1] = Fy0; ru[2] = Nz[0];
+        static_for<0, 2>([&](auto Ll) {
+            constexpr int L = decltype(Ll)::value, i1 = 1 + 3 * L, i2 = i1 + 1, i3 = i1 + 2;
+            R adj[6];
+            spd3_inverse<R>(C[i1][i1], C[i2][i1], C[i3][i1], C[i2][i2], C[i3][i2], C[i3][i3], adj);
+            const R r1 = Nz[i1] + tau_j[i1], r2 = Nz[i2] + tau_j[i2], r3 = Nz[i3] + tau_j[i3];
+            spd3_apply<R>(adj, r1, r2, r3, y[L][0], y[L][1], y[L][2]);
+            const R gx[3] = {Bx[i1], Bx[i2], Bx[i3]}, gy[3] = {By[i1], By[i2], By[i3]};
+            const R gt[3] = {C[i1][0], C[i2][0], C[i3][0]};
+            spd3_apply<R>(adj, gx[0], gx[1], gx[2], Y[L][0][0], Y[L][1][0], Y[L][2][0]);
+            spd3_apply<R>(adj, gy[0], gy[1], gy[2], Y[L][0][1], Y[L][1][1], Y[L][2][1]);
+            spd3_apply<R>(adj, gt[0], gt[1], gt[2], Y[L][0][2], Y[L][1][2], Y[L][2][2]);
+            // Schur complement of the leg on the root block (symmetric: lower triangle) and on its right-hand side
+            Rm[0] = Rm[0] - (gx[0] * Y[L][0][0] + (gx[1] * Y[L][1][0] + gx[2] * Y[L][2][0]));
+            Rm[1] = Rm[1] - (gy[0] * Y[L][0][0] + (gy[1] * Y[L][1][0] + gy[2] * Y[L][2][0]));
+            Rm[2] = Rm[2] - (gy[0] * Y[L][0][1] + (gy[1] * Y[L][1][1] + gy[2] * Y[L][2][1]));
+            Rm[3] = Rm[3] - (gt[0] * Y[L][0][0] + (gt[1] * Y[L][1][0] + gt[2] * Y[L][2][0]));
+            Rm[4] = Rm[4] - (gt[0] * Y[L][0][1] + (gt[1] * Y[L][1][1] + gt[2] * Y[L][2][1]));
+            Rm[5] = Rm[5] - (gt[0] * Y[L][0][2] + (gt[1] * Y[L][1][2] + gt[2] * Y[L][2][2]));
+            ru[0] = ru[0] - (gx[0] * y[L][0] + (gx[1] * y[L][1] + gx[2] * y[L][2]));
+            ru[1] = ru[1] - (gy[0] * y[L][0] + (gy[1] * y[L][1] + gy[2] * y[L][2]));
+            ru[2] = ru[2] - (gt[0] * y[L][0] + (gt[1] * y[L][1] + gt[2] * y[L][2]));
+        });
+        R adj[6], u0, u1, u2;
+        spd3_inverse<R>(Rm[0], Rm[1], Rm[3], Rm[2], Rm[4], Rm[5], adj);
+        spd3_apply<R>(adj, ru[0], ru[1], ru[2], u0, u1, u2);
+        qacc[0] = u0;
+        qacc[1] = u1;
+        qacc[2] = u2;
+        static_for<0, 2>([&](auto Ll) {
+            constexpr int L = decltype(Ll)::value, i1 = 1 + 3 * L;
+            static_for<0, 3>([&](auto Jj) {
+                constexpr int j = decltype(Jj)::value;
+                qacc[2 + i1 + j] = y[L][j] - (Y[L][j][0] * u0 + (Y[L][j][1] * u1 + Y[L][j][2] * u2));
+            });
         });
     }
 
