@@ -76,9 +76,15 @@ def all_gather_rows(t):
         rows = [torch.empty_like(h) for _ in range(w)]
         dist.all_gather(rows, h)
         return torch.stack(rows).to(t.device)
-    out = torch.empty(w * t.numel(), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
-    return out.view(w, t.numel())
+    t = t.contiguous()
+    try:
+        out = torch.empty(w * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out.view(w, t.numel())
+    except (RuntimeError, AttributeError):      # a backend without the flat form: the list form is universal
+        rows = [torch.empty_like(t) for _ in range(w)]
+        dist.all_gather(rows, t)
+        return torch.stack(rows)
 
 
 def sums(*scalars):
