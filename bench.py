@@ -3,7 +3,8 @@
 time of the batched rollout + TRPO update at 4096 Swimmer-style envs per MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either pre-launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
+   or plainly -- bench.py then re-executes itself under torch.distributed.run with N ranks on 127.0.0.1)
 
 One "step" = one full TRPO iteration of BatchPolopt.train (sampler.obtain_samples ->
 process_samples -> log_diagnostics -> optimize_policy) on a batch of
@@ -22,9 +23,14 @@ Extra objects on the JSON line:
   roofline_step_kernel -- rl_vecenv_step (the per-step boundary kernel, state through HBM every
                   launch) at 4 M envs for Cartpole and for the workload's env: the HBM-bound
                   regime of the step kernel, timed live.
-  cpu_baseline -- the CPU port of the reference sampler (oracle/cpu_sampler.py:
-                  rollout() + stateful_pool-style workers on all host cores) timed on
-                  a bounded sample in the same run (rank 0, N == 1 only).
+  cpu_baseline -- kind "reference": the reference's UNMODIFIED parallel_sampler / stateful_pool /
+                  rollout / NormalizedEnv (staged byte for byte under oracle/_ref by
+                  oracle/make_ref.py, driven by oracle/ref_sampler.py) on all host cores and
+                  on one, timed on a bounded sample in the same run (rank 0, N == 1 only); the
+                  re-typed port (oracle/cpu_sampler.py) rides along as a cross-check.
+  ranks / backend / collectives_per_iter / collective_ms_per_iter -- what torch.distributed
+                  actually saw (N > 1), the collectives one iteration issues and their
+                  host-bracketed cost measured on extra iterations after the timed region.
 """
 import argparse
 import json
@@ -93,6 +99,30 @@ def step_kernel_roofline(torch, kind, n=1 << 22, steps=20, warmup=3):
             "avg_launch_ms": ms, "bytes_per_env_step": step_bytes, "env_steps_per_s": n / (ms * 1e-3)}
 
 
+def self_launch_argv(n_gpus, argv, port=None):
+    """The command a plain `python bench.py --gpus N` turns itself into: one rank per GPU of this node
+    under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources the library is built from: stamps profiles/pmc_traffic.json so a counter
+    reading can never be quoted for a kernel it was not taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rllab_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,15 +141,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)"
-                     % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.gpus > torch.cuda.device_count():
+            sys.exit("bench.py --gpus %d: this node has %d GPUs" % (args.gpus, torch.cuda.device_count()))
+        cmd = self_launch_argv(args.gpus, sys.argv[1:])
+        sys.stderr.write("[bench] launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        sys.stderr.flush()
+        os.execv(cmd[0], cmd)
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d under WORLD_SIZE=%d" % (args.gpus, world))
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    if world > 1:
+    if world > 1 or os.environ.get("RLLAB_DIST_FORCE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("RLLAB_DIST_BACKEND", "nccl")   # nccl == RCCL over xGMI; gloo only for tests
         kw = dict(device_id=torch.device("cuda", device_index)) if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
@@ -148,7 +184,7 @@ def main():
     EnvCls = getattr(importlib.import_module(mod), cls)
     env = normalize(EnvCls())
     policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=wl["hidden"])
-    D.broadcast_(policy.flat_params)  # identical theta on every rank
+    # identical theta on every rank: BatchPolopt.start_worker broadcasts rank 0's (algos/batch_polopt.py)
     baseline = LinearFeatureBaseline(env_spec=env.spec)
     common = dict(env=env, policy=policy, baseline=baseline, batch_size=n_envs * T, max_path_length=T,
                   n_itr=10 ** 9, discount=0.99, gae_lambda=wl["lam"], sampler_args=dict(n_envs=n_envs))
@@ -200,6 +236,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    D.reset_accounting(timing=False)
     t0 = time.perf_counter()
     for k in range(args.steps):
         iteration(args.warmup + k, True)
@@ -208,6 +245,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    acct = D.accounting()
+    collectives_per_iter = acct["count"] / float(args.steps)
+    collective_bytes_per_iter = acct["bytes"] / float(args.steps)
+    collective_ms_per_iter = None
+    if D.is_distributed():
+        # a few extra iterations with every collective bracketed by a device synchronise (host clock):
+        # what the exchange family costs per iteration, outside the timed region
+        D.reset_accounting(timing=True)
+        extra = 3
+        for k in range(extra):
+            iteration(args.warmup + args.steps + k, False)
+        torch.cuda.synchronize()
+        collective_ms_per_iter = D.accounting()["seconds"] * 1e3 / extra
+        D.reset_accounting(timing=False)
     for e, backtracks in timed_events:
         rollout_ms.append(e[0].elapsed_time(e[1]))
         phase_ms["sample"] += e[0].elapsed_time(e[1])
@@ -230,7 +281,11 @@ def main():
     if os.path.exists(tpath):
         rec = json.load(open(tpath)).get(args.workload)
         if rec and rec.get("n_envs") == n_envs:
-            traffic, traffic_src = rec["rollout_bytes_per_launch"], rec["source"]
+            if rec.get("kernel_source_hash") == kernel_source_hash():
+                traffic, traffic_src = rec["rollout_bytes_per_launch"], rec["source"]
+            else:
+                traffic_src = ("stale: profiles/pmc_traffic.json was taken from kernel sources %s, this build is %s "
+                               "(re-run profiles/run_profile.sh)" % (rec.get("kernel_source_hash"), kernel_source_hash()))
 
     # second roofline: the matrix-core kernel of the update (Fisher-vector product), timed live
     do, da, h = policy.obs_dim, policy.action_dim, wl["hidden"][0]
@@ -273,6 +328,11 @@ def main():
                    "max_path_length": T, "policy": "GaussianMLPPolicy%s" % (wl["hidden"],),
                    "algo": wl["algo"], "samples_per_iteration": steps_per_iter,
                    "parallelism": "env-sharded dp%d" % world},
+        "ranks": D.world_size() if dist.is_initialized() else 1,
+        "backend": ("%s (RCCL)" % D.backend() if D.backend() == "nccl" else D.backend()) if dist.is_initialized()
+        else None,
+        "collectives_per_iter": collectives_per_iter, "collective_bytes_per_iter": collective_bytes_per_iter,
+        "collective_ms_per_iter": collective_ms_per_iter,
         "trpo_iter_ms": elapsed / args.steps * 1e3,
         "phase_ms": {k: v / args.steps for k, v in phase_ms.items()},
         "update_ms_and_backtracks_per_iteration": per_iter,
@@ -318,31 +378,49 @@ def main():
         # 4 (2 S + Da + Do + 1) + 1 + 8 (ts read + write).
         out["roofline_step_kernel"] = [step_kernel_roofline(torch, k) for k in sorted({0, env_kind})]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (1) the reference's own sampler, unmodified, in a child process (rllab must resolve to the reference there)
+        from oracle import ref_sampler
+        theta_host = policy.get_param_values()
+        ref = ref_sampler.timed_reference(env_kind, theta_host, T, budget_s=args.cpu_budget, hidden=wl["hidden"])
+        # (2) cross-check: the re-typed port of the same sampler on the same cores (short)
         from oracle import cpu_sampler
-        base = cpu_sampler.timed_baseline(env_kind, policy.get_param_values(), T, budget_s=args.cpu_budget,
+        base = cpu_sampler.timed_baseline(env_kind, theta_host, T, budget_s=min(6.0, args.cpu_budget),
                                           hidden=wl["hidden"])
+        ratio = base["steps_per_s"] / ref["steps_per_s"]
         out["cpu_baseline"] = {
-            "value": base["steps_per_s"], "unit": "env_steps/s", "cores": base["cores"], "kind": "port",
-            "sample": "%d env steps in %.1f s: oracle/cpu_sampler.py (rollout + stateful_pool-style "
-                      "workers, host build of the same dynamics, NumPy batch-1 policy); sampler only, "
-                      "upper bound on the true reference stack" % (base["steps"], base["seconds"]),
-            "one_core_env_steps_per_s": base["steps_per_s_1core"]}
+            "value": ref["steps_per_s"], "unit": "env_steps/s", "cores": ref["cores"], "kind": "reference",
+            "cpu_model": ref["cpu_model"],
+            "sample": "%d env steps (%d paths) in %.1f s of the reference's unmodified parallel_sampler.sample_paths "
+                      "/ StatefulPool.run_collect / rollout / NormalizedEnv (%s, staged by oracle/make_ref.py) with "
+                      "n_parallel = %d worker processes; env = float64 host build of this repo's dynamics behind the "
+                      "reference Env interface, policy = batch-1 NumPy MLP behind the reference Policy interface "
+                      "(pybox2d / MuJoCo 1.31 / Theano are absent): sampler only, an upper bound on the true "
+                      "reference stack" % (ref["steps"], ref["n_paths"], ref["seconds"], ref["ref_root"], ref["cores"]),
+            "one_core_env_steps_per_s": ref["steps_per_s_1core"],
+            "reference_modules": ref["modules"],
+            "port_cross_check": {
+                "value": base["steps_per_s"], "one_core_env_steps_per_s": base["steps_per_s_1core"],
+                "cores": base["cores"], "port_over_reference": ratio,
+                "note": "oracle/cpu_sampler.py (the same sampler re-typed: mp.Pool + Manager counter, one ctypes "
+                        "call per step with the action map in C)" + ("" if 0.5 <= ratio <= 2.0 else
+                        "; differs from the reference by more than 2x: the port skips the reference's per-step "
+                        "Python layers (NormalizedEnv.step, Box.flatten, Step namedtuple, tensor_utils stacking)")}}
         if wl["algo"] == "trpo":
             # the rest of the reference iteration on the CPU, on (a bounded prefix of) the paths just sampled:
             # BaseSampler.process_samples and ConjugateGradientOptimizer.optimize as restated in oracle/
             from oracle import cpu_iteration
-            it = cpu_iteration.timed_process_and_update(base["paths"], policy.get_param_values(), wl["hidden"],
+            it = cpu_iteration.timed_process_and_update(base["paths"], theta_host, wl["hidden"],
                                                         gae_lambda=wl["lam"])
             scale = steps_per_iter / float(it["samples"])
             out["cpu_baseline"]["iteration"] = {
                 "samples": it["samples"], "process_s": it["process_s"], "update_s": it["update_s"],
                 "torch_threads": it["torch_threads"],
-                "est_iteration_s_at_bench_batch": steps_per_iter / base["steps_per_s"]
+                "est_iteration_s_at_bench_batch": steps_per_iter / ref["steps_per_s"]
                 + (it["process_s"] + it["update_s"]) * scale,
                 "note": "oracle/cpu_iteration.py: reference process_samples (numpy port) + TRPO update (reference "
                         "control flow, float64 torch-CPU closures in place of the compiled Theano functions) on a "
                         "prefix of the sampled paths; the estimate scales both linearly to the bench batch and adds "
-                        "the sampling time at the measured rate"}
+                        "the sampling time at the reference sampler's measured rate"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -40,6 +40,9 @@ int step_t(R* s, const R* a, int normalize, R* obs, R* reward, int* done) {
 }
 
 template <class E>
+int bounds_t(double* lb, double* ub) { E::template action_bounds<double>(lb, ub); return 0; }
+
+template <class E>
 int query_t(int* obs_dim, int* act_dim, int* state_dim, int* reset_draws, int* reset_is_normal) {
     *obs_dim = E::OBS; *act_dim = E::ACT; *state_dim = E::STATE;
     *reset_draws = E::RESET_DRAWS; *reset_is_normal = E::RESET_NORMAL ? 1 : 0;
@@ -119,6 +122,9 @@ extern "C" {
 int oracle_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim, int* reset_draws, int* reset_is_normal) {
     ORACLE_DISPATCH(kind, query_t, obs_dim, act_dim, state_dim, reset_draws, reset_is_normal)
 }
+
+// raw action bounds of the env (what the reference reads from env.action_space.bounds)
+int oracle_env_action_bounds(int kind, double* lb, double* ub) { ORACLE_DISPATCH(kind, bounds_t, lb, ub) }
 
 // single env, array-of-struct state (state_dim contiguous values)
 int oracle_env_reset_f32(int kind, float* s, const float* draws) { ORACLE_DISPATCH_R(kind, reset_t, float, s, draws) }

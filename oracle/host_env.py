@@ -30,6 +30,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _ip = ctypes.POINTER(ctypes.c_int)
 lib.oracle_env_query.argtypes = [ctypes.c_int, _ip, _ip, _ip, _ip, _ip]
+lib.oracle_env_action_bounds.argtypes = [ctypes.c_int, _f64p, _f64p]
 lib.oracle_env_reset_f32.argtypes = [ctypes.c_int, _f32p, _f32p]
 lib.oracle_env_reset_f64.argtypes = [ctypes.c_int, _f64p, _f64p]
 lib.oracle_env_observe_f32.argtypes = [ctypes.c_int, _f32p, _f32p]
@@ -49,6 +50,13 @@ def query(kind):
     assert lib.oracle_env_query(kind, *[ctypes.byref(v) for v in vals]) == 0, "unknown env kind %d" % kind
     o, a, s, r, nrm = [v.value for v in vals]
     return dict(obs_dim=o, act_dim=a, state_dim=s, reset_draws=r, reset_is_normal=bool(nrm))
+
+
+def action_bounds(kind):
+    q = query(kind)
+    lb, ub = np.zeros(q["act_dim"]), np.zeros(q["act_dim"])
+    assert lib.oracle_env_action_bounds(kind, lb, ub) == 0
+    return lb, ub
 
 
 class HostEnv(object):

@@ -23,40 +23,9 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def install_shims():
-    import _ast
-    import ast
-    if not hasattr(_ast, "Num"):
-        _ast.Num = ast.Constant
-
-    class _Anything(types.ModuleType):
-        def __getattr__(self, name):
-            if name.startswith("__"):
-                raise AttributeError(name)
-            sub = _Anything(self.__name__ + "." + name)
-            setattr(self, name, sub)
-            return sub
-
-        def __call__(self, *a, **k):
-            return _Anything("call")
-
-    for name in ["theano", "theano.tensor", "theano.tensor.nnet", "theano.tensor.signal",
-                 "theano.tensor.signal.pool", "theano.tensor.extra_ops", "theano.ifelse",
-                 "theano.sandbox", "theano.sandbox.rng_mrg", "theano.gradient", "theano.compile",
-                 "theano.tensor.shared_randomstreams",
-                 "lasagne", "lasagne.layers", "lasagne.nonlinearities", "lasagne.init",
-                 "lasagne.updates", "lasagne.utils", "lasagne.random",
-                 "Box2D", "pygame", "pygame.locals", "mako", "mako.template", "mako.lookup", "pyprind",
-                 "path"]:
-        if name not in sys.modules:
-            sys.modules[name] = _Anything(name)
-    cp = types.ModuleType("cached_property")
-    cp.cached_property = property
-    sys.modules["cached_property"] = cp
-    import joblib.pool
-    if not hasattr(joblib.pool, "MemmapingPool"):
-        joblib.pool.MemmapingPool = joblib.pool.MemmappingPool
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_shim
+    ref_shim.install(REF)
 
 
 def synth_paths(rng, n_paths, obs_dim, act_dim, max_len):

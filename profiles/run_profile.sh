@@ -2,7 +2,7 @@
 # Profile recipe (run on the GPU box through gpurun):  profiles/run_profile.sh <tag>
 #   kernel-trace/stats pass and SEPARATE --pmc passes of the same bench command, condensed
 #   into gpurun_out/<tag>_*.csv by profiles/summarize.py (raw traces are too large to keep).
-TAG=${1:-r01}
+TAG=${1:-r02}
 set -x
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

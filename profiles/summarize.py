@@ -88,7 +88,10 @@ def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=
     rec = {}
     if os.path.exists(out_json):
         rec = json.load(open(out_json))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     rec[workload] = dict(n_envs=int(n_envs), rollout_bytes_per_launch=rd + wr, fetch_bytes=rd, write_bytes=wr,
+                         kernel_source_hash=bench.kernel_source_hash(),
                          source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (%s)" % tag)
     json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
 

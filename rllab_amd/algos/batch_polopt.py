@@ -74,7 +74,34 @@ class BatchPolopt(RLAlgorithm):
         self.itr_times = []
 
     def start_worker(self):
+        self.sync_initial_parameters()
         self.sampler.start_worker()
+
+    def sync_initial_parameters(self):
+        """One process per GPU, every process runs the same script: the example scripts set no seed and the
+        policy initialises from np.random, so rank 0's parameters (policy, and a parametric baseline's) are
+        broadcast once.  From here on every rank applies the identical all-reduced update and no further
+        broadcast is needed.  Logging and snapshots are rank 0's alone (misc/logger.py)."""
+        from rllab_amd.sampler import dist as D
+        if not D.is_distributed():
+            return
+        import torch
+        for owner in (self.policy, self.baseline):
+            flat = getattr(owner, "flat_params", None)
+            if isinstance(flat, torch.Tensor):
+                D.broadcast_(flat)
+            elif hasattr(owner, "get_param_values") and hasattr(owner, "set_param_values"):
+                try:
+                    val = owner.get_param_values()
+                except NotImplementedError:
+                    continue
+                if val is None or getattr(val, "size", 0) == 0:
+                    continue
+                t = torch.as_tensor(val, dtype=torch.float64)
+                if torch.cuda.is_available() and D.backend() == "nccl":
+                    t = t.cuda()
+                D.broadcast_(t)
+                owner.set_param_values(t.cpu().numpy())
 
     def shutdown_worker(self):
         self.sampler.shutdown_worker()

@@ -167,7 +167,7 @@ class HipVecEnv(object):
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1
-        return Trajectories(obs, act, mean, policy.effective_log_std().detach(), rew, done,
+        return Trajectories(obs, act, mean, policy.recorded_log_std(), rew, done,
                             self.max_path_length)
 
 

@@ -1,5 +1,5 @@
-"""Experiment launching, local mode (API of rllab/misc/instrument.py:30-163, 290-297, 338-470,
-1340-1395 + scripts/run_experiment_lite.py:21-139).
+"""Experiment launching, local mode (public entry points of rllab/misc/instrument.py: ``stub``, ``concretize``,
+``run_experiment_lite``; :30-163, 290-297, 338-470, 1340-1395 + scripts/run_experiment_lite.py:21-139).
 
 ``run_experiment_lite(task, n_parallel=..., snapshot_mode=..., seed=...)`` sets up what the
 reference's ``scripts/run_experiment_lite.py`` sets up -- seed, ``data/local/<prefix>/<name>/``
@@ -20,151 +20,142 @@ import os.path as osp
 import uuid
 
 from rllab_amd import config
-from rllab_amd.core.serializable import Serializable
 from rllab_amd.misc import ext, logger
 
 
-class StubBase(object):
-    def __getitem__(self, item):
-        return StubMethodCall(self, "__getitem__", args=[item], kwargs=dict())
+# ---- lazy experiment descriptions ---------------------------------------------------------------------------
+# ``stub(globals())`` swaps every class of a script for a ``LazyClass``; "constructing" objects and "calling"
+# methods on them then only records a small expression tree, which ``concretize`` evaluates later (here: in this
+# process, right before the run).  Four node types:
+#     LazyClass(cls)                       the class itself
+#     LazyObject(cls, kwargs)              cls(**kwargs), built once and memoised
+#     LazyAttr(target, name)               getattr(target, name)
+#     LazyCall(target, method, args, kw)   getattr(target, method)(*args, **kw)
+# (the reference's counterpart: rllab/misc/instrument.py:30-163,1340-1395; only the public entry points ``stub``,
+# ``concretize`` and ``run_experiment_lite`` are contract)
+class Lazy(object):
+    """Base of the expression nodes.  Unknown attributes become LazyAttr nodes; a LazyAttr that is called
+    becomes a LazyCall; a few operators are recorded the same way."""
+    _own = ()
 
-    def __getattr__(self, item):
-        try:
-            return super(self.__class__, self).__getattribute__(item)
-        except AttributeError:
-            if item.startswith("__") and item.endswith("__"):
-                raise
-            return StubAttr(self, item)
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return LazyAttr(self, name)
 
-    def __call__(self, *args, **kwargs):
-        return StubMethodCall(self.obj, self.attr_name, args, kwargs)
+    def _record(self, method, *args):
+        return LazyCall(self, method, list(args), {})
+
+    def __getitem__(self, key):
+        return self._record("__getitem__", key)
 
     def __add__(self, other):
-        return StubMethodCall(self, "__add__", [other], dict())
+        return self._record("__add__", other)
 
     def __rmul__(self, other):
-        return StubMethodCall(self, "__rmul__", [other], dict())
+        return self._record("__rmul__", other)
 
     def __pow__(self, power, modulo=None):
-        return StubMethodCall(self, "__pow__", [power, modulo], dict())
+        return self._record("__pow__", power, modulo)
+
+    def __getstate__(self):
+        return {k: self.__dict__[k] for k in self._own}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def __repr__(self):
+        return "%s(%s)" % (type(self).__name__, ", ".join(repr(self.__dict__[k]) for k in self._own))
 
 
-class StubAttr(StubBase):
-    def __init__(self, obj, attr_name):
-        self.__dict__["_obj"] = obj
-        self.__dict__["_attr_name"] = attr_name
-
-    @property
-    def obj(self):
-        return self.__dict__["_obj"]
-
-    @property
-    def attr_name(self):
-        return self.__dict__["_attr_name"]
-
-    def __str__(self):
-        return "StubAttr(%s, %s)" % (str(self.obj), str(self.attr_name))
+def _ctor_kwargs(cls, args, kwargs):
+    """Fold positional constructor arguments into keywords (snapshots and variants are keyed by name)."""
+    if not args:
+        return dict(kwargs)
+    names = inspect.getfullargspec(cls.__init__).args[1:]
+    return dict(zip(names, args), **kwargs)
 
 
-class StubMethodCall(StubBase, Serializable):
-    def __init__(self, obj, method_name, args, kwargs):
-        self._serializable_initialized = False
-        Serializable.quick_init(self, locals())
-        self.obj = obj
-        self.method_name = method_name
-        self.args = args
-        self.kwargs = kwargs
+class LazyClass(Lazy):
+    _own = ("cls",)
 
-    def __str__(self):
-        return "StubMethodCall(%s, %s, %s, %s)" % (str(self.obj), str(self.method_name), str(self.args),
-                                                   str(self.kwargs))
-
-
-def _positional_to_kwargs(cls, args, kwargs):
-    if len(args) > 0:
-        spec = inspect.getfullargspec(cls.__init__)
-        kwargs = dict(list(zip(spec.args[1:], args)), **kwargs)
-    return kwargs
-
-
-class StubClass(StubBase):
-    def __init__(self, proxy_class):
-        self.proxy_class = proxy_class
+    def __init__(self, cls):
+        self.__dict__["cls"] = cls
 
     def __call__(self, *args, **kwargs):
-        return StubObject(self.proxy_class, **_positional_to_kwargs(self.proxy_class, args, kwargs))
+        return LazyObject(self.cls, _ctor_kwargs(self.cls, args, kwargs))
 
-    def __getstate__(self):
-        return dict(proxy_class=self.proxy_class)
-
-    def __setstate__(self, d):
-        self.proxy_class = d["proxy_class"]
-
-    def __getattr__(self, item):
-        if hasattr(self.proxy_class, item):
-            return StubAttr(self, item)
-        raise AttributeError(item)
-
-    def __str__(self):
-        return "StubClass(%s)" % self.proxy_class
+    def __getattr__(self, name):
+        if not hasattr(self.__dict__["cls"], name):
+            raise AttributeError(name)
+        return Lazy.__getattr__(self, name)
 
 
-class StubObject(StubBase):
-    def __init__(self, __proxy_class, *args, **kwargs):
-        self.proxy_class = __proxy_class
-        self.args = tuple()
-        self.kwargs = _positional_to_kwargs(__proxy_class, args, kwargs)
+class LazyObject(Lazy):
+    _own = ("cls", "kwargs")
 
-    def __getstate__(self):
-        return dict(args=self.args, kwargs=self.kwargs, proxy_class=self.proxy_class)
+    def __init__(self, cls, kwargs):
+        self.__dict__.update(cls=cls, kwargs=kwargs)
 
-    def __setstate__(self, d):
-        self.args, self.kwargs, self.proxy_class = d["args"], d["kwargs"], d["proxy_class"]
+    def __getattr__(self, name):
+        if not hasattr(self.__dict__["cls"], name):
+            raise AttributeError("%s has no attribute %r" % (self.__dict__["cls"].__name__, name))
+        return Lazy.__getattr__(self, name)
 
-    def __getattr__(self, item):
-        if hasattr(self.proxy_class, item):
-            return StubAttr(self, item)
-        raise AttributeError('Cannot get attribute %s from %s' % (item, self.proxy_class))
 
-    def __str__(self):
-        return "StubObject(%s, *%s, **%s)" % (str(self.proxy_class), str(self.args), str(self.kwargs))
+class LazyAttr(Lazy):
+    _own = ("target", "name")
+
+    def __init__(self, target, name):
+        self.__dict__.update(target=target, name=name)
+
+    def __call__(self, *args, **kwargs):
+        return LazyCall(self.target, self.name, list(args), kwargs)
+
+
+class LazyCall(Lazy):
+    _own = ("target", "method", "args", "kwargs")
+
+    def __init__(self, target, method, args, kwargs):
+        self.__dict__.update(target=target, method=method, args=args, kwargs=kwargs)
 
 
 def stub(glbs):
-    """Replace every class in ``glbs`` by a StubClass: constructor calls then build a lazy
-    description of the experiment instead of the objects themselves."""
-    for k, v in list(glbs.items()):
-        if isinstance(v, type) and v != StubClass:
-            glbs[k] = StubClass(v)
+    """Replace every class in ``glbs`` by a LazyClass: constructor calls then build a lazy description of the
+    experiment instead of the objects themselves."""
+    for name, value in list(glbs.items()):
+        if isinstance(value, type) and not issubclass(value, Lazy):
+            glbs[name] = LazyClass(value)
 
 
-def concretize(maybe_stub):
-    if isinstance(maybe_stub, StubMethodCall):
-        obj = concretize(maybe_stub.obj)
-        method = getattr(obj, maybe_stub.method_name)
-        return method(*concretize(maybe_stub.args), **concretize(maybe_stub.kwargs))
-    elif isinstance(maybe_stub, StubClass):
-        return maybe_stub.proxy_class
-    elif isinstance(maybe_stub, StubAttr):
-        return concretize(getattr(concretize(maybe_stub.obj), maybe_stub.attr_name))
-    elif isinstance(maybe_stub, StubObject):
-        if "_stub_cache" not in maybe_stub.__dict__:
-            maybe_stub.__dict__["_stub_cache"] = maybe_stub.proxy_class(*concretize(maybe_stub.args),
-                                                                       **concretize(maybe_stub.kwargs))
-        return maybe_stub.__dict__["_stub_cache"]
-    elif isinstance(maybe_stub, dict):
-        return {concretize(k): concretize(v) for k, v in maybe_stub.items()}
-    elif isinstance(maybe_stub, (list, tuple)):
-        return maybe_stub.__class__(list(map(concretize, maybe_stub)))
-    return maybe_stub
+def concretize(node):
+    """Evaluate a lazy description (recursing through containers); anything else is returned as is."""
+    if isinstance(node, LazyCall):
+        fn = getattr(concretize(node.target), node.method)
+        return fn(*concretize(node.args), **concretize(node.kwargs))
+    if isinstance(node, LazyAttr):
+        return concretize(getattr(concretize(node.target), node.name))
+    if isinstance(node, LazyObject):
+        memo = node.__dict__
+        if "_built" not in memo:
+            memo["_built"] = node.cls(**concretize(node.kwargs))
+        return memo["_built"]
+    if isinstance(node, LazyClass):
+        return node.cls
+    if isinstance(node, dict):
+        return {concretize(k): concretize(v) for k, v in node.items()}
+    if isinstance(node, (list, tuple)):
+        return type(node)(concretize(x) for x in node)
+    return node
 
 
 class VariantDict(dict):
+    """A variant whose entries also read as attributes (``v.lr``)."""
+
     def __getattr__(self, k):
-        try:
+        if k in self:
             return self[k]
-        except KeyError:
-            raise AttributeError(k)
+        raise AttributeError(k)
 
 
 exp_count = 0
@@ -245,7 +236,7 @@ def _run_local(call, exp_name, log_dir, variant, n_parallel, snapshot_mode, snap
             data = joblib.load(resume_from)
             assert 'algo' in data
             data['algo'].train()
-        elif isinstance(call, StubBase):
+        elif isinstance(call, Lazy):
             maybe_iter = concretize(call)
             if ext.is_iterable(maybe_iter):
                 for _ in maybe_iter:

@@ -1,239 +1,283 @@
-"""Prefix / tabular logger with the reference's call surface
-(rllab/misc/logger.py:113-232): ``log``, ``prefix``, ``record_tabular``,
-``dump_tabular``, ``add_tabular_output`` (CSV), ``save_itr_params`` (joblib
-snapshots by mode all/last/gap/none).  Tabular keys emitted by the hot path are
-the user-visible parity surface and keep the reference's names."""
+"""Run logger behind the reference's module-level call surface
+(public names of rllab/misc/logger.py:113-348: ``log``, ``prefix``, ``record_tabular``,
+``dump_tabular``, ``add_tabular_output`` ..., ``save_itr_params``).
+
+The engine's own structure: one ``Logger`` object owning
+  * a stack of text prefixes and a stack of tabular-key prefixes,
+  * the pending table row (ordered key -> string),
+  * a set of sinks -- ``TextSink`` (append-mode log files) and ``CsvSink`` (one CSV per
+    experiment, header written with the first row) -- keyed by file name,
+  * the snapshot policy (dir, mode all / last / gap / none, gap),
+and, because the data-parallel run has one process per GPU that all execute the same
+``train()`` loop, a *primary* flag: only the primary process (rank 0) prints, writes
+sinks and snapshots; every rank still records its table row so ``get_tabular`` works
+everywhere.  The module functions below are bound methods of the singleton ``_L``.
+
+Tabular keys emitted by the hot path are the user-visible parity surface and keep the
+reference's names.
+"""
 import csv
 import datetime
+import json
 import os
 import sys
 from contextlib import contextmanager
 
-_prefixes = []
-_prefix_str = ''
-_tabular_prefixes = []
-_tabular_prefix_str = ''
-_tabular = []
-_text_outputs = []
-_tabular_outputs = []
-_text_fds = {}
-_tabular_fds = {}
-_tabular_header_written = set()
-_snapshot_dir = None
-_snapshot_mode = 'all'
-_snapshot_gap = 1
-_log_tabular_only = False
-_quiet = False
+
+class TextSink(object):
+    def __init__(self, path):
+        _ensure_parent(path)
+        self.fh = open(path, "a")
+
+    def write_line(self, line):
+        self.fh.write(line + "\n")
+        self.fh.flush()
+
+    def close(self):
+        self.fh.close()
 
 
-def set_quiet(q=True):
-    global _quiet
-    _quiet = q
+class CsvSink(object):
+    def __init__(self, path):
+        _ensure_parent(path)
+        self.fh = open(path, "w")
+        self.columns = None
+
+    def write_row(self, row):
+        if self.columns is None:
+            self.columns = list(row)
+            csv.writer(self.fh).writerow(self.columns)
+        writer = csv.DictWriter(self.fh, fieldnames=self.columns, extrasaction="ignore", restval="")
+        writer.writerow(row)
+        self.fh.flush()
+
+    def close(self):
+        self.fh.close()
 
 
-def _add_output(file_name, arr, fds, mode='a'):
-    if file_name not in arr:
-        os.makedirs(os.path.dirname(os.path.abspath(file_name)), exist_ok=True)
-        arr.append(file_name)
-        fds[file_name] = open(file_name, mode)
+def _ensure_parent(path):
+    parent = os.path.dirname(os.path.abspath(path))
+    os.makedirs(parent, exist_ok=True)
 
 
-def _remove_output(file_name, arr, fds):
-    if file_name in arr:
-        fds[file_name].close()
-        del fds[file_name]
-        arr.remove(file_name)
+class Logger(object):
+    SNAPSHOT_MODES = ("all", "last", "gap", "none")
+
+    def __init__(self):
+        self.text_prefixes, self.key_prefixes = [], []
+        self.row = {}                       # pending table row, insertion ordered
+        self.text_sinks, self.csv_sinks = {}, {}
+        self.snapshot_dir, self.snapshot_mode, self.snapshot_gap = None, "all", 1
+        self.tabular_only = False
+        self.quiet = False
+        self.primary = None                 # None: decide lazily from torch.distributed
+
+    # -- who writes -------------------------------------------------------------------------------------------
+    def is_primary(self):
+        if self.primary is not None:
+            return self.primary
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_rank() == 0
+        except ImportError:
+            pass
+        return True
+
+    def set_primary(self, flag):
+        self.primary = flag
+
+    def set_quiet(self, q=True):
+        self.quiet = q
+
+    # -- sinks ------------------------------------------------------------------------------------------------
+    def add_text_output(self, file_name):
+        if file_name not in self.text_sinks and self.is_primary():
+            self.text_sinks[file_name] = TextSink(file_name)
+
+    def remove_text_output(self, file_name):
+        sink = self.text_sinks.pop(file_name, None)
+        if sink is not None:
+            sink.close()
+
+    def add_tabular_output(self, file_name):
+        if file_name not in self.csv_sinks and self.is_primary():
+            self.csv_sinks[file_name] = CsvSink(file_name)
+
+    def remove_tabular_output(self, file_name):
+        sink = self.csv_sinks.pop(file_name, None)
+        if sink is not None:
+            sink.close()
+
+    # -- text -------------------------------------------------------------------------------------------------
+    def push_prefix(self, p):
+        self.text_prefixes.append(p)
+
+    def pop_prefix(self):
+        self.text_prefixes.pop()
+
+    @contextmanager
+    def prefix(self, key):
+        self.push_prefix(key)
+        try:
+            yield
+        finally:
+            self.pop_prefix()
+
+    def log(self, s, with_prefix=True, with_timestamp=True, color=None):
+        if not self.is_primary():
+            return
+        line = ("".join(self.text_prefixes) if with_prefix else "") + s
+        if with_timestamp:
+            line = datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S.%f") + " | " + line
+        if not (self.tabular_only or self.quiet):
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+        for sink in self.text_sinks.values():
+            sink.write_line(line)
+
+    # -- table ------------------------------------------------------------------------------------------------
+    def push_tabular_prefix(self, key):
+        self.key_prefixes.append(key)
+
+    def pop_tabular_prefix(self):
+        self.key_prefixes.pop()
+
+    @contextmanager
+    def tabular_prefix(self, key):
+        self.push_tabular_prefix(key)
+        try:
+            yield
+        finally:
+            self.pop_tabular_prefix()
+
+    def record_tabular(self, key, val):
+        self.row["".join(self.key_prefixes) + str(key)] = str(val)
+
+    def get_tabular(self):
+        """Current (not yet dumped) table row as a dict key -> string value."""
+        return dict(self.row)
+
+    def render_row(self):
+        kw = max(len(k) for k in self.row)
+        vw = max(len(v) for v in self.row.values())
+        rule = "-" * (kw + vw + 5)
+        return [rule] + ["%s  %s" % (k.ljust(kw), v.rjust(vw)) for k, v in self.row.items()] + [rule]
+
+    def dump_tabular(self, *args, **kwargs):
+        if not self.row:
+            return
+        if self.is_primary():
+            if not self.quiet:
+                lines = self.render_row()
+                if self.tabular_only:
+                    sys.stdout.write("\n".join(lines) + "\n")
+                else:
+                    for line in lines:
+                        self.log(line, *args, **kwargs)
+            for sink in self.csv_sinks.values():
+                sink.write_row(self.row)
+        self.row = {}
+
+    def record_tabular_misc_stat(self, key, values, placement="back"):
+        """Average / Std / Median / Min / Max of ``values`` under ``key`` (suffix, or prefix with placement='front');
+        NaNs for an empty list (rllab/misc/logger.py:330-348)."""
+        import numpy as np
+        for stat, fn in (("Average", np.average), ("Std", np.std), ("Median", np.median), ("Min", np.min),
+                         ("Max", np.max)):
+            name = stat + key if placement == "front" else key + stat
+            self.record_tabular(name, fn(values) if len(values) > 0 else np.nan)
+
+    # -- snapshots --------------------------------------------------------------------------------------------
+    def snapshot_path(self, itr):
+        """File the snapshot of iteration ``itr`` goes to under the current mode, or None (reference modes,
+        rllab/misc/logger.py:216-232)."""
+        mode = self.snapshot_mode
+        if mode not in self.SNAPSHOT_MODES:
+            raise NotImplementedError("snapshot mode %r" % (mode,))
+        if mode == "none" or (mode == "gap" and itr % self.snapshot_gap != 0):
+            return None
+        name = "params.pkl" if mode == "last" else "itr_%d.pkl" % itr
+        return os.path.join(self.snapshot_dir, name)
+
+    def save_itr_params(self, itr, params):
+        if not self.snapshot_dir or not self.is_primary():
+            return                         # plain example scripts set no snapshot dir
+        path = self.snapshot_path(itr)
+        if path is not None:
+            import joblib
+            joblib.dump(params, path, compress=3)
 
 
-def push_prefix(prefix):
-    global _prefix_str
-    _prefixes.append(prefix)
-    _prefix_str = ''.join(_prefixes)
+_L = Logger()
 
-
-def pop_prefix():
-    global _prefix_str
-    del _prefixes[-1]
-    _prefix_str = ''.join(_prefixes)
-
-
-def add_text_output(file_name):
-    _add_output(file_name, _text_outputs, _text_fds, mode='a')
-
-
-def remove_text_output(file_name):
-    _remove_output(file_name, _text_outputs, _text_fds)
-
-
-def add_tabular_output(file_name):
-    _add_output(file_name, _tabular_outputs, _tabular_fds, mode='w')
-
-
-def remove_tabular_output(file_name):
-    if file_name in _tabular_outputs and _tabular_fds[file_name] in _tabular_header_written:
-        _tabular_header_written.remove(_tabular_fds[file_name])
-    _remove_output(file_name, _tabular_outputs, _tabular_fds)
+log = _L.log
+prefix = _L.prefix
+push_prefix = _L.push_prefix
+pop_prefix = _L.pop_prefix
+tabular_prefix = _L.tabular_prefix
+push_tabular_prefix = _L.push_tabular_prefix
+pop_tabular_prefix = _L.pop_tabular_prefix
+record_tabular = _L.record_tabular
+record_tabular_misc_stat = _L.record_tabular_misc_stat
+get_tabular = _L.get_tabular
+dump_tabular = _L.dump_tabular
+add_text_output = _L.add_text_output
+remove_text_output = _L.remove_text_output
+add_tabular_output = _L.add_tabular_output
+remove_tabular_output = _L.remove_tabular_output
+save_itr_params = _L.save_itr_params
+set_quiet = _L.set_quiet
+set_primary = _L.set_primary
+is_primary = _L.is_primary
 
 
 def set_snapshot_dir(dir_name):
-    global _snapshot_dir
-    _snapshot_dir = dir_name
+    _L.snapshot_dir = dir_name
 
 
 def get_snapshot_dir():
-    return _snapshot_dir
-
-
-def get_snapshot_mode():
-    return _snapshot_mode
+    return _L.snapshot_dir
 
 
 def set_snapshot_mode(mode):
-    global _snapshot_mode
-    _snapshot_mode = mode
+    _L.snapshot_mode = mode
 
 
-def get_snapshot_gap():
-    return _snapshot_gap
+def get_snapshot_mode():
+    return _L.snapshot_mode
 
 
 def set_snapshot_gap(gap):
-    global _snapshot_gap
-    _snapshot_gap = gap
+    _L.snapshot_gap = gap
 
 
-def set_log_tabular_only(log_tabular_only):
-    global _log_tabular_only
-    _log_tabular_only = log_tabular_only
+def get_snapshot_gap():
+    return _L.snapshot_gap
+
+
+def set_log_tabular_only(flag):
+    _L.tabular_only = flag
 
 
 def get_log_tabular_only():
-    return _log_tabular_only
+    return _L.tabular_only
 
 
-def log(s, with_prefix=True, with_timestamp=True, color=None):
-    out = s
-    if with_prefix:
-        out = _prefix_str + out
-    if with_timestamp:
-        now = datetime.datetime.now()
-        out = "%s | %s" % (now.strftime('%Y-%m-%d %H:%M:%S.%f'), out)
-    if not _log_tabular_only and not _quiet:
-        print(out)
-        sys.stdout.flush()
-    for fd in list(_text_fds.values()):
-        fd.write(out + '\n')
-        fd.flush()
-
-
-def record_tabular(key, val):
-    _tabular.append((_tabular_prefix_str + str(key), str(val)))
-
-
-def push_tabular_prefix(key):
-    global _tabular_prefix_str
-    _tabular_prefixes.append(key)
-    _tabular_prefix_str = ''.join(_tabular_prefixes)
-
-
-def pop_tabular_prefix():
-    global _tabular_prefix_str
-    del _tabular_prefixes[-1]
-    _tabular_prefix_str = ''.join(_tabular_prefixes)
-
-
-@contextmanager
-def prefix(key):
-    push_prefix(key)
-    try:
-        yield
-    finally:
-        pop_prefix()
-
-
-@contextmanager
-def tabular_prefix(key):
-    push_tabular_prefix(key)
-    yield
-    pop_tabular_prefix()
-
-
-def get_tabular():
-    """Current (not yet dumped) tabular rows as a dict key -> string value."""
-    return dict(_tabular)
-
-
-def dump_tabular(*args, **kwargs):
-    if len(_tabular) > 0:
-        if not _quiet:
-            width = max(len(k) for k, _ in _tabular)
-            vwidth = max(len(v) for _, v in _tabular)
-            bar = '-' * (width + vwidth + 5)
-            lines = [bar] + ["%s  %s" % (k.ljust(width), v.rjust(vwidth)) for k, v in _tabular] + [bar]
-            if _log_tabular_only:
-                print('\n'.join(lines))
-            else:
-                for line in lines:
-                    log(line, *args, **kwargs)
-        tabular_dict = dict(_tabular)
-        for tabular_fd in list(_tabular_fds.values()):
-            writer = csv.DictWriter(tabular_fd, fieldnames=list(tabular_dict.keys()))
-            if tabular_fd not in _tabular_header_written:
-                writer.writeheader()
-                _tabular_header_written.add(tabular_fd)
-            writer.writerow(tabular_dict)
-            tabular_fd.flush()
-        del _tabular[:]
-
-
-def save_itr_params(itr, params):
-    """joblib snapshots, reference modes (logger.py:216-232); no-op without a
-    snapshot dir (plain example scripts set none)."""
-    if not _snapshot_dir:
-        return
-    import joblib
-    if _snapshot_mode == 'all':
-        joblib.dump(params, os.path.join(_snapshot_dir, 'itr_%d.pkl' % itr), compress=3)
-    elif _snapshot_mode == 'last':
-        joblib.dump(params, os.path.join(_snapshot_dir, 'params.pkl'), compress=3)
-    elif _snapshot_mode == 'gap':
-        if itr % _snapshot_gap == 0:
-            joblib.dump(params, os.path.join(_snapshot_dir, 'itr_%d.pkl' % itr), compress=3)
-    elif _snapshot_mode == 'none':
-        pass
-    else:
-        raise NotImplementedError
-
-
-def record_tabular_misc_stat(key, values, placement='back'):
-    """Average / Std / Median / Min / Max of ``values`` under ``key`` (prefix, or suffix with placement='front');
-    NaNs for an empty list (rllab/misc/logger.py:330-348)."""
-    import numpy as np
-    label = (lambda stat: stat + key) if placement == 'front' else (lambda stat: key + stat)
-    stats = (("Average", np.average), ("Std", np.std), ("Median", np.median), ("Min", np.min), ("Max", np.max))
-    for name, fn in stats:
-        record_tabular(label(name), fn(values) if len(values) > 0 else np.nan)
+def _dump_json(log_file, payload):
+    _ensure_parent(log_file)
+    with open(log_file, "w") as fh:
+        json.dump(payload, fh, indent=2, sort_keys=True, default=repr)
 
 
 def log_variant(log_file, variant_data):
-    """variant.json of an experiment (rllab/misc/logger.py:321-327); values that JSON cannot carry are written as
-    their ``repr``."""
-    import json
+    """variant.json of an experiment (rllab/misc/logger.py:321-327); values JSON cannot carry go in as ``repr``."""
     if hasattr(variant_data, "dump"):
         variant_data = variant_data.dump()
-    d = os.path.dirname(log_file)
-    if d:
-        os.makedirs(d, exist_ok=True)
-    with open(log_file, "w") as fh:
-        json.dump(variant_data, fh, indent=2, sort_keys=True, default=repr)
+    _dump_json(log_file, variant_data)
 
 
 def log_parameters_lite(log_file, args):
     """params.json from an argparse namespace (rllab/misc/logger.py:301-318, without the stub decoding that only
     the reference's subprocess launcher needs)."""
-    import json
-    d = os.path.dirname(log_file)
-    if d:
-        os.makedirs(d, exist_ok=True)
-    with open(log_file, "w") as fh:
-        json.dump(dict(vars(args)), fh, indent=2, sort_keys=True, default=repr)
+    _dump_json(log_file, dict(vars(args)))

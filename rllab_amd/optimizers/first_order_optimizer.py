@@ -149,6 +149,13 @@ class FirstOrderOptimizer(Serializable):
         for epoch in range(self._max_epochs):
             for batch in dataset.iterate(update=True):
                 before = None
+                if self._batch_size is not None and len(batch) >= 2 and torch.is_tensor(batch[-2]):
+                    # input convention (algos/npo.py, algos/vpg.py): [..., weights, 1 / W].  A mini-batch is
+                    # normalised by ITS OWN (global, all-reduced) weight sum -- the reference's compiled loss is
+                    # the mean over whatever slice it is given (first_order_optimizer.py:112-114)
+                    cnt = D.all_reduce_sum_(batch[-2].to(torch.float64).sum())
+                    batch[-1] = (1.0 / cnt.clamp_min(1.0)).to(batch[-1].dtype if torch.is_tensor(batch[-1])
+                                                               else torch.float64)
                 if fused_full and last_loss is None:
                     self._step(tuple(batch), with_loss=True)       # records the loss / KL sums of the old parameters
                 else:

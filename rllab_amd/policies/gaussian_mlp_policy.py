@@ -97,6 +97,12 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
             ls = ls.clamp_min(float(np.log(self.min_std)))   # scalar bound: no host -> device copy per call
         return ls
 
+    def recorded_log_std(self):
+        """The log_std row a rollout records as agent_info (the "old" distribution of the update): always a
+        COPY -- with ``min_std=None`` ``effective_log_std`` is a view into ``flat_params``, and the line search /
+        Adam step rewrite that vector in place, which would make old and new log_std the same tensor."""
+        return self.effective_log_std().detach().clone()
+
     def mean_planes(self, obs_planes, flat=None):
         """obs [Do, B] -> mean [Da, B] ("planes": feature axis first, the engine's layout)."""
         flat = self.flat_params if flat is None else flat

@@ -6,12 +6,57 @@ statistics, normal equations, the flat gradient and each Fisher-vector product
 (SURVEY.md section 8e).  Every rank applies the identical parameter update, so no
 broadcast is needed after the initial parameter sync.
 """
+import os
+import time
+
 import torch
 import torch.distributed as dist
 
+# RLLAB_DIST_FORCE=1: treat an initialised world of ONE rank as distributed, so a 1-GPU box drives every
+# collective of the path through the real backend (RCCL) -- tests/test_gpu_rccl.py
+_FORCE = bool(os.environ.get("RLLAB_DIST_FORCE"))
+
+# Collective accounting (bench.py's "collectives_per_iter" / "collective_ms_per_iter").  Counting is
+# free; timing brackets every collective with a device synchronise on both sides, so it is only ever
+# switched on for a few extra iterations AFTER the timed region.
+_acct = dict(count=0, seconds=0.0, timing=False, bytes=0)
+
+
+def reset_accounting(timing=False):
+    _acct.update(count=0, seconds=0.0, timing=bool(timing), bytes=0)
+
+
+def accounting():
+    return dict(_acct)
+
+
+class _account(object):
+    __slots__ = ("t", "cuda")
+
+    def __init__(self, t):
+        _acct["count"] += 1
+        _acct["bytes"] += t.numel() * t.element_size()
+        self.cuda = t.is_cuda
+
+    def __enter__(self):
+        if _acct["timing"]:
+            if self.cuda:
+                torch.cuda.synchronize()
+            self.t = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if _acct["timing"]:
+            if self.cuda:
+                torch.cuda.synchronize()
+            _acct["seconds"] += time.perf_counter() - self.t
+
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
+def backend():
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
 
 
 def world_size():
@@ -30,12 +75,13 @@ def _via_host(t):
 
 def _all_reduce(t, op):
     if is_distributed():
-        if _via_host(t):
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=op)
+        with _account(t):
+            if _via_host(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=op)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op)
     return t
 
 
@@ -54,12 +100,13 @@ def all_reduce_max_(t):
 
 def broadcast_(t, src=0):
     if is_distributed():
-        if _via_host(t):
-            h = t.cpu()
-            dist.broadcast(h, src=src)
-            t.copy_(h)
-        else:
-            dist.broadcast(t, src=src)
+        with _account(t):
+            if _via_host(t):
+                h = t.cpu()
+                dist.broadcast(h, src=src)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src)
     return t
 
 
@@ -71,20 +118,18 @@ def all_gather_rows(t):
     if not is_distributed():
         return t.unsqueeze(0)
     w = dist.get_world_size()
-    if dist.get_backend() == "gloo":            # CPU tests, or ranks sharing one GPU in tests/: through the host
-        h = t.cpu()
-        rows = [torch.empty_like(h) for _ in range(w)]
-        dist.all_gather(rows, h)
-        return torch.stack(rows).to(t.device)
-    t = t.contiguous()
-    try:
+    with _account(t):
+        if dist.get_backend() == "gloo":        # CPU tests, or ranks sharing one GPU in tests/: through the host
+            h = t.cpu()
+            rows = [torch.empty_like(h) for _ in range(w)]
+            dist.all_gather(rows, h)
+            return torch.stack(rows).to(t.device)
+        # nccl (= RCCL): the flat form, one launch.  No fallback around the collective itself: a rank that
+        # caught an error here and issued a different collective would leave its peers hanging.
+        t = t.contiguous()
         out = torch.empty(w * t.numel(), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t)
         return out.view(w, t.numel())
-    except (RuntimeError, AttributeError):      # a backend without the flat form: the list form is universal
-        rows = [torch.empty_like(t) for _ in range(w)]
-        dist.all_gather(rows, t)
-        return torch.stack(rows)
 
 
 def sums(*scalars):

@@ -69,7 +69,7 @@ class VectorizedSampler(BaseSampler):
         if getattr(policy, "fusable", False) and len(getattr(policy, "hidden_sizes", ())) == 2 \
                 and tuple(policy.hidden_sizes) in ((32, 32), (64, 64)):
             traj = self.vec_env.rollout(policy, T, reset_at_start=True)
-        elif self.use_graph and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "effective_log_std"):
+        elif self.use_graph and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "recorded_log_std"):
             try:
                 traj = self._stepwise_rollout_graph(policy, T)
             except RuntimeError as err:
@@ -83,7 +83,6 @@ class VectorizedSampler(BaseSampler):
                 traj = self._stepwise_rollout(policy, T)
         else:
             traj = self._stepwise_rollout(policy, T)
-        self.last_traj = traj
         self.last_num_samples = traj.B
         self.last_sample_time = time.time() - t_start  # enqueue time only; bench syncs explicitly
         return PathList(traj)
@@ -158,7 +157,7 @@ class VectorizedSampler(BaseSampler):
         v.step_counter += T
         # the planes belong to the graph: hand out copies, as the eager path hands out fresh tensors
         return Trajectories(st["obs_p"].clone(), st["act_p"].clone(), st["mean_p"].clone(),
-                            policy.effective_log_std().detach(), st["rew_p"].clone(), st["done_p"].clone(),
+                            policy.recorded_log_std(), st["rew_p"].clone(), st["done_p"].clone(),
                             v.max_path_length)
 
     def _stepwise_rollout(self, policy, T):
@@ -180,5 +179,5 @@ class VectorizedSampler(BaseSampler):
             obs, rew, done, _ = v.step(actions)
             rew_p[t] = rew
             done_p[t] = done.to(torch.uint8)
-        return Trajectories(obs_p, act_p, mean_p, policy.effective_log_std().detach(), rew_p, done_p,
+        return Trajectories(obs_p, act_p, mean_p, policy.recorded_log_std(), rew_p, done_p,
                             v.max_path_length)

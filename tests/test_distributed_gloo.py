@@ -139,6 +139,23 @@ def _worker(rank, world, port, outdir):
     b = LinearFeatureBaseline(None)
     b.fit_dense(_traj_from(rng, 30, 8, 3), all_reduce=D.all_reduce_sum_)
     np.save(os.path.join(outdir, "coef_%d.npy" % rank), b.get_param_values())
+    # initial parameter sync of BatchPolopt.start_worker: ranks start from DIFFERENT np.random states (the
+    # example scripts set no seed) and must leave with rank 0's parameters; collectives are counted
+    from rllab_amd.algos.batch_polopt import BatchPolopt
+    from rllab_amd.baselines.zero_baseline import ZeroBaseline
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    np.random.seed(1000 + rank)
+    pol3 = GaussianMLPPolicy(_spec(5, 2), hidden_sizes=(8, 8))
+
+    class _Algo(object):
+        policy, baseline = pol3, ZeroBaseline(None)
+    np.save(os.path.join(outdir, "init_before_%d.npy" % rank), pol3.get_param_values())
+    D.reset_accounting()
+    BatchPolopt.sync_initial_parameters(_Algo())
+    assert D.accounting()["count"] == 1 and D.accounting()["bytes"] == 4 * pol3.flat_params.numel()
+    np.save(os.path.join(outdir, "init_after_%d.npy" % rank), pol3.get_param_values())
+    from rllab_amd.misc import logger
+    assert logger.is_primary() == (rank == 0)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -172,3 +189,7 @@ def test_two_rank_gloo_update_equals_single_process(tmp_path):
     y = torch.cat([t.returns.reshape(-1).double() for t in trs])
     ref = LinearFeatureBaseline(None)._solve((phi @ phi_raw.t()).numpy(), (phi @ y).numpy())
     assert np.allclose(c0, ref, rtol=1e-8, atol=1e-10)
+    # initial parameter broadcast
+    b0, b1 = (np.load(str(tmp_path / ("init_before_%d.npy" % r))) for r in range(2))
+    a0, a1 = (np.load(str(tmp_path / ("init_after_%d.npy" % r))) for r in range(2))
+    assert not np.array_equal(b0, b1) and np.array_equal(a0, b0) and np.array_equal(a1, b0)

@@ -188,7 +188,7 @@ def test_stub_machinery_and_local_runner(tmp_path, quiet_logger):
     g = dict(Thing=Thing)
     instrument.stub(g)
     call = g["Thing"](3, b=5).work(2)
-    assert isinstance(call, instrument.StubMethodCall) and Thing.built == 0
+    assert isinstance(call, instrument.LazyCall) and Thing.built == 0
     d = instrument.run_experiment_lite(call, exp_prefix="unit_test", log_dir=str(tmp_path / "exp"), snapshot_mode="last",
                                        seed=3)
     assert Thing.built == 1 and logger.get_snapshot_dir() is None

@@ -1,0 +1,42 @@
+"""The exchange family of the path through the REAL backend on a 1-GPU box: ``RLLAB_DIST_FORCE=1`` makes a
+world of one rank count as distributed, so ``bench.py`` initialises ``torch.distributed`` with backend
+``nccl`` (= RCCL) bound to the device and every all-reduce / all-gather / broadcast of an iteration is an
+RCCL call (a one-rank collective is the identity, so results must not change).  What an 8-GPU run adds is
+only peers; the API surface, stream semantics and the accounting fields of the JSON line are exercised here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--n-envs", "512"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, cwd=ROOT, universal_newlines=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_iteration_over_rccl_single_rank():
+    plain = _bench({})
+    assert plain["ranks"] == 1 and plain["backend"] is None and plain["collectives_per_iter"] == 0
+    forced = _bench({"RLLAB_DIST_FORCE": "1"})
+    assert forced["ranks"] == 1 and forced["backend"].startswith("nccl")
+    # per TRPO iteration: statistics all-gather, normal equations, gradient (+ its loss sums), 10 FVPs,
+    # 1-2 line-search evaluations
+    assert 12 <= forced["collectives_per_iter"] <= 40, forced["collectives_per_iter"]
+    assert forced["collective_bytes_per_iter"] < 1 << 20
+    assert forced["collective_ms_per_iter"] is not None and 0 < forced["collective_ms_per_iter"] < 50
+    assert forced["value"] > 0 and forced["config"]["n_envs_per_gpu"] == 512
