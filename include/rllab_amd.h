@@ -62,6 +62,49 @@ int rl_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim,
  * MujocoEnv.action_space (mujoco_env.py:85-90). */
 int rl_env_action_bounds(int kind, float* lb_host, float* ub_host);
 
+/* Constructor options of the reference's env classes that the kernels honour at run time.  A HOST struct;
+ * NULL wherever an `rl_env_cfg*` is taken means "the env's defaults" (what rl_env_default_cfg writes).
+ *   ctrl_cost_coeff  SwimmerEnv / Walker2DEnv / HopperEnv(ctrl_cost_coeff=..)
+ *                    (rllab/envs/mujoco/swimmer_env.py:15-21, walker2d_env.py:21-27, hopper_env.py:27-35)
+ *   alive_coeff      HopperEnv(alive_coeff=..)                          (hopper_env.py:27-35)
+ *   action_noise     Box2DEnv / MujocoEnv(action_noise=..): applied = action + 0.5 (ub - lb) * action_noise * N(0,1),
+ *                    after the reward captured the action (box2d_env.py:163-175,219-226, mujoco_env.py:175-187)
+ *   obs_noise        Box2DEnv(obs_noise=..): observation + obs_noise * N(0,1) entry-wise (box2d_env.py:194-218)
+ *   frame_skip       Box2DEnv(frame_skip=..): world steps per env step; 0 = the env's default
+ *   flags            RL_CFG_* below
+ *   action_noise_z   DEVICE pointer or NULL: injected N(0,1) draws of the action noise (parity runs);
+ *                    rl_vecenv_step: float[act_dim][n], rl_rollout_gaussian_mlp: float[T][act_dim][n].
+ *                    NULL = Philox4x32-10 keyed (seed; env, step, ACT_NOISE)
+ *   obs_noise_z      the same for the observation noise: float[obs_dim][n] (step / reset),
+ *                    float[T+1][obs_dim][n] (rollout; slice 0 = first observation, t + 1 = after step t) */
+typedef struct rl_env_cfg {
+    float ctrl_cost_coeff;
+    float alive_coeff;
+    float action_noise;
+    float obs_noise;
+    int32_t frame_skip;
+    int32_t flags;
+    const float* action_noise_z;
+    const float* obs_noise_z;
+} rl_env_cfg;
+
+enum rl_env_cfg_flags {
+    RL_CFG_POLE_FOLLOWS_CART = 1, /* CartpoleEnv / CartpoleSwingupEnv: reset moves the pole body with the cart, so
+                                   * the hinge starts closed (engine option; the reference's reset leaves the pole
+                                   * origin at the XML pose, cartpole_env.py:28-43 -- DESIGN.md section 5) */
+    RL_CFG_FIXED_START = 2        /* InvertedDoublePendulumEnv(random_start=False)
+                                   * (inverted_double_pendulum_env.py:20,47-58) */
+};
+
+/* The options env `kind` runs with by default (host struct out). */
+int rl_env_default_cfg(int kind, rl_env_cfg* cfg_host);
+
+/* MujocoEnv.get_body_com("torso") / get_body_comvel("torso") (rllab/envs/mujoco/mujoco_env.py:232-238,
+ * rllab/mujoco_py/mjcore.py:58-81: subtree linear momentum / subtree mass) from the persisted state planes:
+ *   com4  float[4][n] = (forward, up) position and (forward, up) velocity of the torso subtree's centre of mass
+ * RL_ERR_UNSUPPORTED for the Box2D-style env kinds. */
+int rl_vecenv_com(int kind, int n, const float* state, float* com4, void* stream);
+
 /* Env.reset for the envs selected by `mask` (NULL = all).
  *   state   float[state_dim][n]   in/out (persisted solver state survives reset
  *                                 where the reference's does)
@@ -75,7 +118,7 @@ int rl_env_action_bounds(int kind, float* lb_host, float* ub_host);
  * VecEnvExecutor.reset (sandbox/rocky/tf/envs/vec_env_executor.py:30-33). */
 int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const uint8_t* mask,
                     const float* draws, uint64_t seed, uint64_t step_counter,
-                    int env_offset, float* obs, void* stream);
+                    int env_offset, const rl_env_cfg* cfg, float* obs, void* stream);
 
 /* rl_vecenv_step for launches replayed from a hipGraph (the per-step loop of an arbitrary policy is launch-bound:
  * policy kernels + one step kernel per transition, T times; captured once and replayed, it pays one graph launch per
@@ -83,8 +126,8 @@ int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const uint8_t* m
  * word, advanced between replays by rl_counter_add (itself a node of the graph).  No injected reset draws. */
 int rl_vecenv_step_graph(int kind, int n_envs, int normalize, float scale_reward, int max_path_length,
                          int auto_reset, float* state, int32_t* ts, const float* actions, uint64_t seed,
-                         const uint64_t* step_counter_dev, int env_offset, float* obs, float* reward,
-                         uint8_t* done, void* stream);
+                         const uint64_t* step_counter_dev, int env_offset, const rl_env_cfg* cfg, float* obs,
+                         float* reward, uint8_t* done, void* stream);
 int rl_counter_add(uint64_t* counter_dev, uint64_t increment, void* stream);
 
 /* Observation of the state planes as they are, without a transition: obs[obs_dim][n] = observe(state).
@@ -105,7 +148,8 @@ int rl_vecenv_observe(int kind, int n_envs, const float* state, float* obs, void
 int rl_vecenv_step(int kind, int n, int normalize, float scale_reward, int max_path_length,
                    int auto_reset, float* state, int32_t* ts, const float* actions,
                    const float* reset_draws, uint64_t seed, uint64_t step_counter,
-                   int env_offset, float* obs, float* reward, uint8_t* done, void* stream);
+                   int env_offset, const rl_env_cfg* cfg, float* obs, float* reward, uint8_t* done,
+                   void* stream);
 
 /* Arguments of the fused rollout: T lock-step iterations of
  *   policy.get_actions -> env.step -> record -> auto-reset
@@ -140,6 +184,7 @@ typedef struct rl_rollout_args {
     float* rewards;           /* float[T][n] */
     uint8_t* dones;           /* uint8[T][n]  env done OR ts == max_path_length */
     float* last_obs;          /* NULL or float[obs_dim][n]: observation after the last step (post-reset) */
+    const rl_env_cfg* cfg;    /* host; NULL = the env's defaults */
 } rl_rollout_args;
 
 int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);

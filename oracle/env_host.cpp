@@ -39,6 +39,57 @@ int step_t(R* s, const R* a, int normalize, R* obs, R* reward, int* done) {
     return 0;
 }
 
+// ---- env options (rl_env_cfg of the C ABI; doubles here so that the float64 leg sees them unrounded) -------------
+struct OracleCfg {
+    double ctrl_cost_coeff, alive_coeff, action_noise, obs_noise;
+    int frame_skip, flags;
+};
+
+template <class E, typename R>
+rl::EnvCfgT<R> cfg_of(const OracleCfg* c) {
+    rl::EnvCfgT<R> o = rl::default_cfg<E, R>();
+    if (c) {
+        o.ctrl_cost_coeff = (R)c->ctrl_cost_coeff; o.alive_coeff = (R)c->alive_coeff;
+        o.action_noise = (R)c->action_noise; o.obs_noise = (R)c->obs_noise;
+        if (c->frame_skip > 0) o.frame_skip = c->frame_skip;
+        o.flags = c->flags;
+    }
+    return o;
+}
+
+template <class E>
+int default_cfg_t(OracleCfg* c) {
+    const rl::EnvCfgT<double> d = rl::default_cfg<E, double>();
+    c->ctrl_cost_coeff = d.ctrl_cost_coeff; c->alive_coeff = d.alive_coeff; c->action_noise = 0.0; c->obs_noise = 0.0;
+    c->frame_skip = d.frame_skip; c->flags = 0;
+    return 0;
+}
+
+template <class E, typename R>
+int reset_cfg_t(R* s, const R* draws, const OracleCfg* c) { E::template reset<R>(s, draws, c ? c->flags : 0); return 0; }
+
+// Env.step under options: zact = the N(0,1) draws of the action noise (read only when action_noise != 0)
+template <class E, typename R>
+int step_cfg_t(R* s, const R* a, int normalize, const OracleCfg* c, const R* zact, R* obs, R* reward, int* done) {
+    bool d;
+    rl::step_cfg<E, R>(s, a, normalize, cfg_of<E, R>(c), zact, obs, *reward, d);
+    *done = d ? 1 : 0;
+    return 0;
+}
+
+template <class E, typename R>
+int obs_noise_t(const OracleCfg* c, const R* z, R* obs) {
+    const rl::EnvCfgT<R> k = cfg_of<E, R>(c);
+    if (k.obs_noise != (R)0) rl::add_obs_noise<E, R>(k, z, obs);
+    return 0;
+}
+
+template <class E, typename R>
+int com_t(const R* s, R* c4) {
+    if constexpr (E::HAS_COM) { E::template com<R>(s, c4); return 0; }
+    else return -2;
+}
+
 template <class E>
 int bounds_t(double* lb, double* ub) { E::template action_bounds<double>(lb, ub); return 0; }
 
@@ -56,20 +107,28 @@ int query_t(int* obs_dim, int* act_dim, int* state_dim, int* reset_draws, int* r
 template <class E>
 int vec_step_t(int n, int normalize, float scale_reward, int max_path_length, int auto_reset, float* state,
                int32_t* ts, const float* actions, const float* reset_draws, float* obs, float* reward,
-               uint8_t* done) {
+               uint8_t* done, const OracleCfg* c = nullptr, const float* act_z = nullptr,
+               const float* obs_z = nullptr) {
+    const rl::EnvCfgT<float> cfg = cfg_of<E, float>(c);
     for (int i = 0; i < n; ++i) {
-        float s[E::STATE], a[E::ACT], o[E::OBS], d[E::RESET_DRAWS], r;
+        float s[E::STATE], a[E::ACT], o[E::OBS], d[E::RESET_DRAWS], r, za[E::ACT], zo[E::OBS];
         for (int k = 0; k < E::STATE; ++k) s[k] = state[(size_t)k * n + i];
         for (int k = 0; k < E::ACT; ++k) a[k] = actions[(size_t)k * n + i];
+        if (cfg.action_noise != 0.0f)
+            for (int k = 0; k < E::ACT; ++k) za[k] = act_z[(size_t)k * n + i];
         bool dn;
-        E::template step<float>(s, a, normalize, o, r, dn);
+        rl::step_cfg<E, float>(s, a, normalize, cfg, za, o, r, dn);
         int t = ts[i] + 1;
         if (max_path_length > 0 && t >= max_path_length) dn = true;
         if (dn && auto_reset) {
             for (int k = 0; k < E::RESET_DRAWS; ++k) d[k] = reset_draws[(size_t)k * n + i];
-            E::template reset<float>(s, d);
+            E::template reset<float>(s, d, cfg.flags);
             E::template observe<float>(s, o);
             t = 0;
+        }
+        if (cfg.obs_noise != 0.0f) {
+            for (int k = 0; k < E::OBS; ++k) zo[k] = obs_z[(size_t)k * n + i];
+            rl::add_obs_noise<E, float>(cfg, zo, o);
         }
         for (int k = 0; k < E::STATE; ++k) state[(size_t)k * n + i] = s[k];
         ts[i] = t;
@@ -81,14 +140,20 @@ int vec_step_t(int n, int normalize, float scale_reward, int max_path_length, in
 }
 
 template <class E>
-int vec_reset_t(int n, float* state, int32_t* ts, const uint8_t* mask, const float* draws, float* obs) {
+int vec_reset_t(int n, float* state, int32_t* ts, const uint8_t* mask, const float* draws, float* obs,
+                const OracleCfg* c = nullptr, const float* obs_z = nullptr) {
+    const rl::EnvCfgT<float> cfg = cfg_of<E, float>(c);
     for (int i = 0; i < n; ++i) {
         if (mask && !mask[i]) continue;
-        float s[E::STATE], o[E::OBS], d[E::RESET_DRAWS];
+        float s[E::STATE], o[E::OBS], d[E::RESET_DRAWS], zo[E::OBS];
         for (int k = 0; k < E::STATE; ++k) s[k] = state[(size_t)k * n + i];
         for (int k = 0; k < E::RESET_DRAWS; ++k) d[k] = draws[(size_t)k * n + i];
-        E::template reset<float>(s, d);
+        E::template reset<float>(s, d, cfg.flags);
         E::template observe<float>(s, o);
+        if (cfg.obs_noise != 0.0f) {
+            for (int k = 0; k < E::OBS; ++k) zo[k] = obs_z[(size_t)k * n + i];
+            rl::add_obs_noise<E, float>(cfg, zo, o);
+        }
         for (int k = 0; k < E::STATE; ++k) state[(size_t)k * n + i] = s[k];
         ts[i] = 0;
         for (int k = 0; k < E::OBS; ++k) obs[(size_t)k * n + i] = o[k];
@@ -125,6 +190,42 @@ int oracle_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim, int* 
 
 // raw action bounds of the env (what the reference reads from env.action_space.bounds)
 int oracle_env_action_bounds(int kind, double* lb, double* ub) { ORACLE_DISPATCH(kind, bounds_t, lb, ub) }
+
+// ---- the same calls under env options (OracleCfg; null = the env's defaults) ------------------------------------
+int oracle_env_default_cfg(int kind, OracleCfg* c) { ORACLE_DISPATCH(kind, default_cfg_t, c) }
+int oracle_env_reset_cfg_f32(int kind, float* s, const float* draws, const OracleCfg* c) {
+    ORACLE_DISPATCH_R(kind, reset_cfg_t, float, s, draws, c)
+}
+int oracle_env_reset_cfg_f64(int kind, double* s, const double* draws, const OracleCfg* c) {
+    ORACLE_DISPATCH_R(kind, reset_cfg_t, double, s, draws, c)
+}
+int oracle_env_step_cfg_f32(int kind, float* s, const float* a, int normalize, const OracleCfg* c, const float* zact,
+                            float* obs, float* reward, int* done) {
+    ORACLE_DISPATCH_R(kind, step_cfg_t, float, s, a, normalize, c, zact, obs, reward, done)
+}
+int oracle_env_step_cfg_f64(int kind, double* s, const double* a, int normalize, const OracleCfg* c, const double* zact,
+                            double* obs, double* reward, int* done) {
+    ORACLE_DISPATCH_R(kind, step_cfg_t, double, s, a, normalize, c, zact, obs, reward, done)
+}
+int oracle_env_obs_noise_f32(int kind, const OracleCfg* c, const float* z, float* obs) {
+    ORACLE_DISPATCH_R(kind, obs_noise_t, float, c, z, obs)
+}
+int oracle_env_obs_noise_f64(int kind, const OracleCfg* c, const double* z, double* obs) {
+    ORACLE_DISPATCH_R(kind, obs_noise_t, double, c, z, obs)
+}
+int oracle_env_com_f32(int kind, const float* s, float* c4) { ORACLE_DISPATCH_R(kind, com_t, float, s, c4) }
+int oracle_env_com_f64(int kind, const double* s, double* c4) { ORACLE_DISPATCH_R(kind, com_t, double, s, c4) }
+int oracle_vecenv_step_cfg_f32(int kind, int n, int normalize, float scale_reward, int max_path_length,
+                               int auto_reset, float* state, int32_t* ts, const float* actions,
+                               const float* reset_draws, float* obs, float* reward, uint8_t* done,
+                               const OracleCfg* c, const float* act_z, const float* obs_z) {
+    ORACLE_DISPATCH(kind, vec_step_t, n, normalize, scale_reward, max_path_length, auto_reset, state, ts,
+                    actions, reset_draws, obs, reward, done, c, act_z, obs_z)
+}
+int oracle_vecenv_reset_cfg_f32(int kind, int n, float* state, int32_t* ts, const uint8_t* mask,
+                                const float* draws, float* obs, const OracleCfg* c, const float* obs_z) {
+    ORACLE_DISPATCH(kind, vec_reset_t, n, state, ts, mask, draws, obs, c, obs_z)
+}
 
 // single env, array-of-struct state (state_dim contiguous values)
 int oracle_env_reset_f32(int kind, float* s, const float* draws) { ORACLE_DISPATCH_R(kind, reset_t, float, s, draws) }

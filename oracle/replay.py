@@ -14,11 +14,13 @@ import numpy as np
 from oracle import host_env as H
 
 
-def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None):
+def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None, action_noise_z=None, obs_noise_z=None):
     """Raises AssertionError on the first mismatching bit.  Returns the number of
     env-steps compared.  Only paths that start at t == 0 or after a recorded done
     are replayed; the first path of each env needs the env's state at the start of
-    the rollout, which for reset_at_start rollouts is a reset state."""
+    the rollout, which for reset_at_start rollouts is a reset state.
+    The host env runs under the executor's options (``vec_env.cfg_overrides``); with action / observation noise on,
+    the N(0,1) draws the rollout was given must be passed here too ([T, Da, N] / [T+1, Do, N])."""
     kind = vec_env.kind
     T, N = traj.T, traj.N
     n_chk = min(N, max_envs)
@@ -29,22 +31,31 @@ def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None):
     compared = 0
     if reset_draws is not None:
         reset_draws = np.asarray(reset_draws, np.float32)   # [T+1][R][N]: slice t = reset before step t
+    cfg = {k: v for k, v in getattr(vec_env, "cfg_overrides", {}).items()}
+    if action_noise_z is not None:
+        action_noise_z = np.asarray(action_noise_z, np.float32)
+    if obs_noise_z is not None:
+        obs_noise_z = np.asarray(obs_noise_z, np.float32)
+    noisy_obs = H.make_cfg(kind, cfg).obs_noise != 0.0
     for n in range(n_chk):
-        env = H.HostEnv(kind, np.float32, normalize=vec_env.normalize)
+        env = H.HostEnv(kind, np.float32, normalize=vec_env.normalize, cfg=cfg)
         fresh = True
         ts = 0
         for t in range(T):
             if fresh:
                 if reset_draws is not None:
-                    env.reset(reset_draws[t, :, n])        # exact path: the same reset() the kernel ran
+                    env.reset(reset_draws[t, :, n], zobs=obs_noise_z[t, :, n] if noisy_obs else None)
                 else:
+                    assert not noisy_obs, "a noisy observation does not determine the reset state"
                     set_state_from_obs(env, obs[:, t, n])
                 fresh = False
                 ts = 0
-            o_host = env.observe()
+            # the observation recorded at step t carries noise slice t (slice 0 = the first, t = after step t - 1)
+            o_host = env.observe(obs_noise_z[t, :, n] if noisy_obs else None)
             assert np.array_equal(o_host.view(np.uint32), obs[:, t, n].view(np.uint32)), \
                 "obs mismatch env %d t %d: host %r gpu %r" % (n, t, o_host, obs[:, t, n])
-            _, r, d = env.step(act[:, t, n])
+            _, r, d = env.step(act[:, t, n], zact=None if action_noise_z is None else action_noise_z[t, :, n],
+                               zobs=obs_noise_z[t + 1, :, n] if noisy_obs else None)
             ts += 1
             if vec_env.max_path_length > 0 and ts >= vec_env.max_path_length:
                 d = True
@@ -76,6 +87,8 @@ def set_state_from_obs(env, o):
         sn, cs = H.sincos_f32(np.array([o[2]], np.float32))
         s[6] = -sn[0] * np.float32(0.5)
         s[7] = np.float32(0.86602540378443864676) + cs[0] * np.float32(0.5)
+        if env.cfg.flags & H.CFG_POLE_FOLLOWS_CART:
+            s[6] = np.float32(s[6] + np.float32(o[0]))
         return
     if kind == 2:  # Swimmer: obs[:10] = (qpos, qvel) is the whole state
         env.state[:] = o[:10]

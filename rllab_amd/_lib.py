@@ -25,13 +25,25 @@ ENV_INVERTED_DOUBLE_PENDULUM = 7
 
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds",
+    "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
     "rl_lfb_normal_eq",
 ]
+
+
+class EnvCfg(ctypes.Structure):
+    """Mirror of ``rl_env_cfg`` (include/rllab_amd.h): constructor options of the reference's env classes."""
+    _fields_ = [
+        ("ctrl_cost_coeff", ctypes.c_float), ("alive_coeff", ctypes.c_float), ("action_noise", ctypes.c_float),
+        ("obs_noise", ctypes.c_float), ("frame_skip", ctypes.c_int32), ("flags", ctypes.c_int32),
+        ("action_noise_z", ctypes.c_void_p), ("obs_noise_z", ctypes.c_void_p),
+    ]
+
+
+CFG_POLE_FOLLOWS_CART, CFG_FIXED_START = 1, 2
 
 
 class RolloutArgs(ctypes.Structure):
@@ -45,7 +57,7 @@ class RolloutArgs(ctypes.Structure):
         ("state", ctypes.c_void_p), ("ts", ctypes.c_void_p), ("theta", ctypes.c_void_p),
         ("eps", ctypes.c_void_p), ("reset_draws", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("means", ctypes.c_void_p), ("rewards", ctypes.c_void_p),
-        ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p),
+        ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p), ("cfg", ctypes.POINTER(EnvCfg)),
     ]
 
 
@@ -75,11 +87,14 @@ def _load():
     lib.rl_abi_version.restype = i32
     lib.rl_env_query.argtypes = [i32, ip, ip, ip, ip, ip]
     lib.rl_env_action_bounds.argtypes = [i32, fp, fp]
-    lib.rl_vecenv_reset.argtypes = [i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp]
+    cfgp = ctypes.POINTER(EnvCfg)
+    lib.rl_env_default_cfg.argtypes = [i32, cfgp]
+    lib.rl_vecenv_com.argtypes = [i32, i32, vp, vp, vp]
+    lib.rl_vecenv_reset.argtypes = [i32, i32, vp, vp, vp, vp, u64, u64, i32, cfgp, vp, vp]
     lib.rl_vecenv_observe.argtypes = [i32, i32, vp, vp, vp]
-    lib.rl_vecenv_step_graph.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, u64, vp, i32, vp, vp, vp, vp]
+    lib.rl_vecenv_step_graph.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, u64, vp, i32, cfgp, vp, vp, vp, vp]
     lib.rl_counter_add.argtypes = [vp, u64, vp]
-    lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, vp, vp, vp, vp]
+    lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, cfgp, vp, vp, vp, vp]
     lib.rl_rollout_gaussian_mlp.argtypes = [ctypes.POINTER(RolloutArgs), vp]
     lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp, vp]
     lib.rl_discount_cumsum.argtypes = [i32, i32, vp, vp, f64, vp, vp]
@@ -139,6 +154,18 @@ def env_query(kind):
                            ctypes.byref(nrm)), "rl_env_query")
     return dict(obs_dim=o.value, act_dim=a.value, state_dim=s.value, reset_draws=r.value,
                 reset_is_normal=bool(nrm.value))
+
+
+def env_default_cfg(kind, **overrides):
+    """``EnvCfg`` of env ``kind``: its defaults (rl_env_default_cfg) with ``overrides`` (field = value) applied."""
+    c = EnvCfg()
+    check(lib.rl_env_default_cfg(kind, ctypes.byref(c)), "rl_env_default_cfg")
+    names = dict(EnvCfg._fields_)
+    for k, v in overrides.items():
+        if k not in names:
+            raise TypeError("unknown env option %r" % (k,))
+        setattr(c, k, v)
+    return c
 
 
 def env_action_bounds(kind):

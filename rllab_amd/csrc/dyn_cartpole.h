@@ -37,6 +37,7 @@ struct Cartpole {
     static constexpr int RESET_DRAWS = 4;     // uniform [0,1) draws per reset
     static constexpr bool RESET_NORMAL = false;
     static constexpr int KIND = 0;
+    static constexpr bool HAS_COM = false;   // no subtree-COM export (get_body_com is a MujocoEnv method)
 
     template <typename R> struct C {
         static constexpr R cart_h = (R)0.86602540378443864676;   // 3/sqrt(12)
@@ -75,7 +76,9 @@ struct Cartpole {
     // then cart x/vx and pole angle/w overwritten with U(-0.05*b, 0.05*b),
     // b = [2.4, 4, 0.2, 4].  The pole body origin stays at (0, cart_h): the
     // joint starts violated by |x| and is pulled together by the position solver.
-    template <typename R> RL_HD static void reset(R* s, const R* u) {
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, 1); }
+
+    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0) {
         const R b0 = (R)2.4, b1 = (R)4.0, b2 = (R)0.2, b3 = (R)4.0, rr = (R)0.05;
         R lo0 = -rr * b0, lo1 = -rr * b1, lo2 = -rr * b2, lo3 = -rr * b3;
         R xpos = lo0 + u[0] * (rr * b0 - lo0);
@@ -89,6 +92,9 @@ struct Cartpole {
         s[6] = -sn * C<R>::pole_lc;
         s[7] = C<R>::cart_h + cs * C<R>::pole_lc;
         s[8] = apos; s[9] = (R)0; s[10] = (R)0; s[11] = avel;
+        // engine option (not the reference's code path): the pole origin follows the cart,
+        // so the hinge starts closed instead of being pulled together by the first position solve
+        if (flags & CFG_POLE_FOLLOWS_CART) s[6] = s[6] + xpos;
     }
 
     // xml <state> list: cart xpos, cart xvel, pole apos, pole avel (cartpole.xml.mako:41-44)
@@ -227,16 +233,21 @@ struct Cartpole {
     // otherwise used as given.  Box2DEnv.forward_dynamics clips again
     // (box2d_env.py:123-124).  Reward is evaluated after the step with the action
     // handed to the inner env (cartpole_env.py:46-51).
+    // `o.dact`: Box2DEnv._inject_action_noise adds its noise after the reward generator captured the action
+    // (box2d_env.py:163-175); `o.frame_skip` world steps per env step, reward evaluated after the last (:171-179).
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         using K = C<R>;
         R act = a[0];
         if (normalize) {
             act = K::act_lb + (act + (R)1) * (R)0.5 * (K::act_ub - K::act_lb);
             act = rl_clamp(act, K::act_lb, K::act_ub);
         }
-        R force = rl_clamp(act, K::act_lb, K::act_ub);
-        world_step(s, force);
+        R applied = act;
+        if (o.dact) applied = act + o.dact[0];
+        R force = rl_clamp(applied, K::act_lb, K::act_ub);
+        for (int f = 0; f < o.frame_skip; ++f) world_step(s, force);
         done = is_done(s);
         R notdone = done ? (R)0 : (R)1;
         R sn, cs;
@@ -257,7 +268,7 @@ struct Cartpole {
 struct CartpoleSwingup : Cartpole {
     static constexpr int KIND = 4;
 
-    template <typename R> RL_HD static void reset(R* s, const R* u) {
+    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0) {
         const R PI_ = (R)3.14159265358979323846;
         const R lo0 = (R)-1, lo1 = (R)-2, lo2 = PI_ - (R)1, lo3 = (R)-3;
         const R hi0 = (R)1, hi1 = (R)2, hi2 = PI_ + (R)1, hi3 = (R)3;
@@ -271,19 +282,24 @@ struct CartpoleSwingup : Cartpole {
         s[6] = -sn * C<R>::pole_lc;
         s[7] = C<R>::cart_h + cs * C<R>::pole_lc;
         s[8] = apos; s[9] = (R)0; s[10] = (R)0; s[11] = avel;
+        if (flags & CFG_POLE_FOLLOWS_CART) s[6] = s[6] + xpos;
     }
 
     template <typename R> RL_HD static bool is_done(const R* s) { return rl_abs(s[0]) > (R)3; }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         using K = C<R>;
         R act = a[0];
         if (normalize) {
             act = K::act_lb + (act + (R)1) * (R)0.5 * (K::act_ub - K::act_lb);
             act = rl_clamp(act, K::act_lb, K::act_ub);
         }
-        world_step(s, rl_clamp(act, K::act_lb, K::act_ub));
+        R applied = act;
+        if (o.dact) applied = act + o.dact[0];
+        const R force = rl_clamp(applied, K::act_lb, K::act_ub);
+        for (int f = 0; f < o.frame_skip; ++f) world_step(s, force);
         done = is_done(s);
         R sn, cs;
         rl_sincos(s[8], sn, cs);

@@ -99,7 +99,9 @@ struct HalfCheetah {
     }
 
     // qpos = init + 0.01 N(0,1), qvel = 0.1 N(0,1) in MuJoCo order [x, z, rooty, joints]
-    template <typename R> RL_HD static void reset(R* s, const R* z) {
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, 1); }
+
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
         s[0] = (R)0.7 + z[1] * (R)0.01;   // absolute torso height
         s[1] = z[0] * (R)0.01;            // x
         s[9] = z[10] * (R)0.1;            // zdot
@@ -130,7 +132,8 @@ struct HalfCheetah {
     }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         R act[ACT], tau[CheetahModel::NB];
         tau[0] = (R)0;
         RL_UNROLL
@@ -138,7 +141,9 @@ struct HalfCheetah {
             R v = a[k];
             if (normalize) v = rl_clamp((R)-1 + (v + (R)1) * (R)0.5 * (R)2, (R)-1, (R)1);
             act[k] = v;
-            tau[1 + k] = (R)cheetah::GEAR[1 + k] * rl_clamp(v, (R)-1, (R)1);  // ctrllimited motor
+            R applied = v;
+            if (o.dact) applied = v + o.dact[k];       // ctrl = inject_action_noise(action) (mujoco_env.py:175-187)
+            tau[1 + k] = (R)cheetah::GEAR[1 + k] * rl_clamp(applied, (R)-1, (R)1);  // ctrllimited motor
         }
         R q[9], qd[9];
         RL_UNROLL
@@ -161,6 +166,14 @@ struct HalfCheetah {
         reward = vx - (R)0.1 * (R)0.5 * ctrl;
         done = false;
     }
+
+    // (x, z) of the torso subtree COM and its velocity, in the order get_body_com / get_body_comvel report them
+    template <typename R> RL_HD static void com(const R* s, R* c4) {
+        R cz, cx, vz, vx;
+        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        c4[0] = cx; c4[1] = cz; c4[2] = vx; c4[3] = vz;
+    }
+    static constexpr bool HAS_COM = true;
 };
 
 }  // namespace rl

@@ -32,6 +32,7 @@ struct DoublePendulum {
     static constexpr int RESET_DRAWS = 4;  // N(0,1): angle1, angle2, w1, w2
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 1;
+    static constexpr bool HAS_COM = false;   // no subtree-COM export (get_body_com is a MujocoEnv method)
     static constexpr int VEL_ITERS = 20;
     static constexpr int POS_ITERS = 20;
     static constexpr int FRAME_SKIP = 2;
@@ -65,7 +66,9 @@ struct DoublePendulum {
     // reset: bodies back to the XML pose, then angles / angular velocities overwritten with
     // N(0, [0.1, 0.1, 0.01, 0.01]) (double_pendulum_env.py:32-41).  Body origins stay at
     // (0,0) and (0,-1): joint 2 starts violated and is pulled together by the position solver.
-    template <typename R> RL_HD static void reset(R* s, const R* z) {
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, FRAME_SKIP); }
+
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
         const R a1 = z[0] * (R)0.1, a2 = z[1] * (R)0.1, w1 = z[2] * (R)0.01, w2 = z[3] * (R)0.01;
         R s1, c1, s2, c2;
         rl_sincos(a1, s1, c1);
@@ -226,15 +229,18 @@ struct DoublePendulum {
     }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         using K = C<R>;
         R act = a[0];
         if (normalize) {
             act = K::act_lb + (act + (R)1) * (R)0.5 * (K::act_ub - K::act_lb);
             act = rl_clamp(act, K::act_lb, K::act_ub);
         }
-        const R torque = rl_clamp(act, K::act_lb, K::act_ub);   // forward_dynamics clips (box2d_env.py:123-124)
-        for (int f = 0; f < FRAME_SKIP; ++f) world_step(s, torque);
+        R applied = act;
+        if (o.dact) applied = act + o.dact[0];                      // _inject_action_noise (box2d_env.py:219-226)
+        const R torque = rl_clamp(applied, K::act_lb, K::act_ub);   // forward_dynamics clips (box2d_env.py:123-124)
+        for (int f = 0; f < o.frame_skip; ++f) world_step(s, torque);
         // reward = -|tip - (0, 2)|, tip = link2.position - link_len*(sin a2, cos a2)
         // (double_pendulum_env.py:43-58); link2.position = centre - R(a2)*(0,-0.5)
         R s2, c2;

@@ -44,7 +44,9 @@ struct Hopper {
 
     // qpos = init + 0.01 N(0,1) with init_qpos = [1.25, 0, ...], qvel = 0.1 N(0,1), MuJoCo order
     // [rootz, rootx, rooty, joints] and MuJoCo sign convention for the joints
-    template <typename R> RL_HD static void reset(R* s, const R* z) {
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.01, 1.0, 1); }
+
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
         s[0] = (R)1.25 + z[0] * (R)0.01;
         s[1] = z[1] * (R)0.01;
         s[2] = z[2] * (R)0.01;
@@ -83,7 +85,8 @@ struct Hopper {
     }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         R act[ACT], tau[HopperModel::NB];
         tau[0] = (R)0;
         R ctrl_cost = (R)0;
@@ -93,7 +96,9 @@ struct Hopper {
             R v = a[k];
             if (normalize) v = rl_clamp(lb + (v + (R)1) * (R)0.5 * (ub - lb), lb, ub);
             act[k] = rl_clamp(v, lb, ub);                        // action = clip(action, *bounds); ctrllimited motor
-            tau[1 + k] = (R)hopper::SIGN[1 + k] * act[k];        // gear 1: torque = ctrl, about the MJCF axis
+            R applied = act[k];
+            if (o.dact) applied = rl_clamp(act[k] + o.dact[k], lb, ub);   // ctrl = action + noise, ctrllimited
+            tau[1 + k] = (R)hopper::SIGN[1 + k] * applied;       // gear 1: torque = ctrl, about the MJCF axis
             const R sc = act[k] / ((ub - lb) * (R)0.5);
             ctrl_cost = ctrl_cost + sc * sc;
         }
@@ -110,7 +115,7 @@ struct Hopper {
         write_obs(s, cx, cz, obs);
         // reward = comvel_x + alive_coeff - 0.5 * ctrl_cost_coeff * sum((action / scaling)^2), alive_coeff 1,
         // ctrl_cost_coeff 0.01                                                    (hopper_env.py:27-28,53-55)
-        reward = vx + (R)1 - (R)0.5 * (R)0.01 * ctrl_cost;
+        reward = vx + o.alive_coeff - (R)0.5 * o.ctrl_cost_coeff * ctrl_cost;
         // notdone = isfinite(state).all() and (|state[3:]| < 100).all() and state[0] > .7 and |state[2]| < .2,
         // state = [qpos, qvel]                                                    (:56-60)
         bool ok = (s[0] > (R)0.7) && (rl_abs(s[2]) < (R)0.2) && (rl_abs(s[0]) < (R)1e30) &&
@@ -119,6 +124,13 @@ struct Hopper {
         for (int i = 3; i < 2 * NQ; ++i) ok = ok && (rl_abs(s[i]) < (R)100);
         done = !ok;
     }
+
+    template <typename R> RL_HD static void com(const R* s, R* c4) {
+        R cz, cx, vz, vx;
+        Tree::template com<R>(s, s + NQ, cz, cx, vz, vx);
+        c4[0] = cx; c4[1] = cz; c4[2] = vx; c4[3] = vz;
+    }
+    static constexpr bool HAS_COM = true;
 };
 
 }  // namespace rl

@@ -49,6 +49,7 @@ struct InvertedDoublePendulum {
     static constexpr int RESET_DRAWS = 1;      // one uniform [0,1) draw: the first pole's start angle
     static constexpr bool RESET_NORMAL = false;
     static constexpr int KIND = 7;
+    static constexpr bool HAS_COM = false;   // no subtree-COM export (get_body_com is a MujocoEnv method)
     static constexpr int SUBSTEPS = 8;         // 8 x 0.0025 s = frame_skip 2 x timestep 0.01
 
     static constexpr double PI = idp::PI, L1 = idp::L1, LC = idp::LC, L2 = idp::L2, MT = idp::MT, A_ = idp::A_,
@@ -59,10 +60,13 @@ struct InvertedDoublePendulum {
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) { lb[0] = (R)-1; ub[0] = (R)1; }
 
     // random_start: qpos[1] = (U[0,1) - 0.5) * 40 / 180 * pi, everything else 0   (:47-58)
-    template <typename R> RL_HD static void reset(R* s, const R* u) {
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, 1); }
+
+    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0) {
         RL_UNROLL
         for (int i = 0; i < STATE; ++i) s[i] = (R)0;
-        s[1] = (u[0] - (R)0.5) * (R)(40.0 / 180.0 * PI);
+        // random_start=False keeps the model's initial pose (inverted_double_pendulum_env.py:20,47-58)
+        if (!(flags & CFG_FIXED_START)) s[1] = (u[0] - (R)0.5) * (R)(40.0 / 180.0 * PI);
     }
 
     template <typename R> RL_HD static R limit_force(R x, R xd) {
@@ -111,10 +115,13 @@ struct InvertedDoublePendulum {
     }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         R v = a[0];
         if (normalize) v = rl_clamp((R)-1 + (v + (R)1) * (R)0.5 * (R)2, (R)-1, (R)1);   // lb + (a + 1) * 0.5 * (ub - lb)
-        const R ctrl = rl_clamp(v, (R)-1, (R)1);        // action = clip(action, *bounds); ctrllimited motor
+        R applied = rl_clamp(v, (R)-1, (R)1);           // action = clip(action, *bounds)
+        if (o.dact) applied = applied + o.dact[0];      // ctrl = inject_action_noise(action)
+        const R ctrl = rl_clamp(applied, (R)-1, (R)1);  // ctrllimited motor
         const R force = (R)GEAR * ctrl;
         for (int it = 0; it < SUBSTEPS; ++it) substep<R>(s, force, (R)0.0025);
         observe<R>(s, obs);

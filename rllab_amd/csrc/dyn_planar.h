@@ -30,12 +30,6 @@
 #include <type_traits>
 #include "rl_math.h"
 
-#if defined(__HIPCC__)
-#define RL_UNROLL _Pragma("unroll")
-#else
-#define RL_UNROLL
-#endif
-
 namespace rl {
 
 // Compile-time loops: the body sees the index as a constant expression, so model constants

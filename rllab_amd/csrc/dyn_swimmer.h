@@ -116,9 +116,11 @@ struct Swimmer {
         ub[0] = (R)50; ub[1] = (R)50;
     }
 
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(1e-2, 0.0, 1); }
+
     // MujocoEnv.reset_mujoco: qpos = init_qpos + 0.01*N(0,1), qvel = init_qvel + 0.1*N(0,1),
     // init_qpos = init_qvel = 0 (mujoco_env.py:109-116)
-    template <typename R> RL_HD static void reset(R* s, const R* z) {
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
         RL_UNROLL
         for (int i = 0; i < 5; ++i) {
             s[i] = z[i] * (R)0.01;
@@ -140,7 +142,7 @@ struct Swimmer {
     //   sub-steps  : FRAME_SKIP x Chain::substep_*                   (mjcore.py:46-49 x frame_skip)
     //   step_end   : observation, reward, done                       (swimmer_env.py:25-45)
     template <typename R>
-    RL_HD static void step_begin(const R* a, int normalize, R* act, R* ctrl) {
+    RL_HD static void step_begin(const R* a, int normalize, R* act, R* ctrl, const R* dact = nullptr) {
         const R lb = (R)-50, ub = (R)50;
         ctrl[0] = (R)0;
         RL_UNROLL
@@ -151,38 +153,49 @@ struct Swimmer {
                 v = rl_clamp(v, lb, ub);
             }
             act[k] = v;
-            ctrl[1 + k] = rl_clamp(v, lb, ub);  // ctrllimited: MuJoCo clamps ctrl to ctrlrange
+            R applied = v;
+            if (dact) applied = v + dact[k];           // ctrl = inject_action_noise(action) (mujoco_env.py:175-187)
+            ctrl[1 + k] = rl_clamp(applied, lb, ub);   // ctrllimited: MuJoCo clamps ctrl to ctrlrange
         }
     }
 
     template <typename R>
-    RL_HD static void step_end(const R* s, const R* act, R* obs, R& reward, bool& done) {
+    RL_HD static void step_end(const R* s, const R* act, R* obs, R& reward, bool& done,
+                               R ctrl_cost_coeff = (R)1e-2) {
         const R lb = (R)-50, ub = (R)50;
         R cx, cy, vx, vy;
         Tree::template com<R>(s, s + 5, cx, cy, vx, vy);
         RL_UNROLL
         for (int i = 0; i < 10; ++i) obs[i] = s[i];
         obs[10] = cx; obs[11] = cy; obs[12] = (R)0;
-        // reward = comvel_x - 0.5 * 1e-2 * sum((action / scaling)^2), scaling = (ub - lb)/2
+        // reward = comvel_x - 0.5 * ctrl_cost_coeff * sum((action / scaling)^2), scaling = (ub - lb)/2; coefficient 1e-2
+        // unless SwimmerEnv(ctrl_cost_coeff=..) says otherwise (0.5 * c is exact, so the default keeps its bits)
         const R scaling = (ub - lb) * (R)0.5;
         const R a0 = act[0] / scaling, a1 = act[1] / scaling;
-        const R ctrl_cost = (R)0.5 * (R)1e-2 * (a0 * a0 + a1 * a1);
+        const R ctrl_cost = (R)0.5 * ctrl_cost_coeff * (a0 * a0 + a1 * a1);
         reward = vx - ctrl_cost;
         done = false;
     }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         R act[2], ctrl[3];
-        step_begin(a, normalize, act, ctrl);
+        step_begin(a, normalize, act, ctrl, o.dact);
         // 50 sub-steps in the chain program's variables (dyn_swimmer_chain.h): root translation, absolute body
         // rates, joint angles, carried sin / cos of the absolute body angles
         R r4[4], th[3], om[3], sn[3], cs[3];
         to_chain(s, s + 5, r4, th, om, sn, cs);
         for (int it = 0; it < FRAME_SKIP; ++it) Chain::template substep_scalar<R>(r4, cs, sn, om, th, ctrl, (R)0.001);
         from_chain(r4, th, om, s, s + 5);
-        step_end(s, act, obs, reward, done);
+        step_end(s, act, obs, reward, done, o.ctrl_cost_coeff);
     }
+
+    // subtree COM of the torso = of the whole chain: position and velocity (get_body_com / get_body_comvel)
+    template <typename R> RL_HD static void com(const R* s, R* c4) {
+        Tree::template com<R>(s, s + 5, c4[0], c4[1], c4[2], c4[3]);
+    }
+    static constexpr bool HAS_COM = true;
 };
 
 }  // namespace rl

@@ -44,7 +44,9 @@ struct Walker2D {
 
     // qpos = init + 0.01 N(0,1) with init_qpos = [1.25, 0, ...], qvel = 0.1 N(0,1), MuJoCo order
     // [rootz, rootx, rooty, joints] and MuJoCo sign convention for the joints
-    template <typename R> RL_HD static void reset(R* s, const R* z) {
+    template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(1e-2, 0.0, 1); }
+
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
         s[0] = (R)1.25 + z[0] * (R)0.01;
         s[1] = z[1] * (R)0.01;
         s[2] = z[2] * (R)0.01;
@@ -77,7 +79,8 @@ struct Walker2D {
     }
 
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done) {
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
         R act[ACT], tau[WalkerModel::NB];
         tau[0] = (R)0;
         R ctrl_cost = (R)0;
@@ -87,7 +90,9 @@ struct Walker2D {
             R v = a[k];
             if (normalize) v = rl_clamp(lb + (v + (R)1) * (R)0.5 * (ub - lb), lb, ub);
             act[k] = rl_clamp(v, lb, ub);                        // action = clip(action, *bounds); ctrllimited motor
-            tau[1 + k] = (R)walker::SIGN[1 + k] * act[k];        // gear 1: torque = ctrl, about the MJCF axis
+            R applied = act[k];
+            if (o.dact) applied = rl_clamp(act[k] + o.dact[k], lb, ub);   // ctrl = action + noise, ctrllimited
+            tau[1 + k] = (R)walker::SIGN[1 + k] * applied;       // gear 1: torque = ctrl, about the MJCF axis
             const R sc = act[k] / ((ub - lb) * (R)0.5);
             ctrl_cost = ctrl_cost + sc * sc;
         }
@@ -103,10 +108,17 @@ struct Walker2D {
         Tree::template com<R>(q, qd, cz, cx, vz, vx);
         write_obs(s, cx, cz, obs);
         // reward = comvel_x - 0.5 * 1e-2 * sum((action / scaling)^2)      (walker2d_env.py:35-44)
-        reward = vx - (R)0.5 * (R)1e-2 * ctrl_cost;
+        reward = vx - (R)0.5 * o.ctrl_cost_coeff * ctrl_cost;
         // done = not (0.8 < qpos[0] < 2.0 and -1 < qpos[2] < 1)            (:46-48)
         done = !(s[0] > (R)0.8 && s[0] < (R)2.0 && s[2] > (R)-1.0 && s[2] < (R)1.0);
     }
+
+    template <typename R> RL_HD static void com(const R* s, R* c4) {
+        R cz, cx, vz, vx;
+        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        c4[0] = cx; c4[1] = cz; c4[2] = vx; c4[3] = vz;
+    }
+    static constexpr bool HAS_COM = true;
 };
 
 }  // namespace rl

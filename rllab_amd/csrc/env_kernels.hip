@@ -32,7 +32,7 @@ __device__ __forceinline__ void store_state(float* __restrict__ state, int n, in
 
 template <class Env>
 __device__ __forceinline__ void reset_one(float* s, const float* __restrict__ draws, int n, int i,
-                                          uint64_t seed, uint32_t env_global, uint64_t step) {
+                                          uint64_t seed, uint32_t env_global, uint64_t step, int flags) {
     float d[Env::RESET_DRAWS];
     if (draws) {
 #pragma unroll
@@ -40,7 +40,40 @@ __device__ __forceinline__ void reset_one(float* s, const float* __restrict__ dr
     } else {
         philox_draws<Env::RESET_DRAWS, Env::RESET_NORMAL>(d, seed, env_global, step, RNG_RESET);
     }
-    Env::template reset<float>(s, d);
+    Env::template reset<float>(s, d, flags);
+}
+
+// N(0,1) draws of one env for one transition: slice `z` (a [COUNT][n] plane set injected by the caller -- parity
+// runs) or the Philox stream under `purpose`
+template <int COUNT>
+__device__ __forceinline__ void noise_draws(float* d, const float* __restrict__ z, int n, int i, uint64_t seed,
+                                            uint32_t env_global, uint64_t step, uint32_t purpose) {
+    if (z) {
+#pragma unroll
+        for (int k = 0; k < COUNT; ++k) d[k] = z[(size_t)k * n + i];
+    } else {
+        philox_draws<COUNT, true>(d, seed, env_global, step, purpose);
+    }
+}
+// the observation a caller sees: raw observation + obs_noise * N(0,1) (Box2DEnv.get_current_obs, box2d_env.py:210-218).
+// Wave-uniform branch: a launch without obs noise pays one scalar compare.
+template <class Env>
+__device__ __forceinline__ void observed(float* o, const EnvCfg& cfg, const float* __restrict__ z, int n, int i,
+                                         uint64_t seed, uint32_t env_global, uint64_t step) {
+    if (cfg.obs_noise != 0.0f) {
+        float zn[Env::OBS];
+        noise_draws<Env::OBS>(zn, z, n, i, seed, env_global, step, RNG_OBS_NOISE);
+        add_obs_noise<Env, float>(cfg, zn, o);
+    }
+}
+// Env.step with the launch's options; draws its action-noise variates only when the option is on
+template <class Env>
+__device__ __forceinline__ void step_one(float* s, const float* a, int normalize, const EnvCfg& cfg,
+                                         const float* __restrict__ z, int n, int i, uint64_t seed, uint32_t env_global,
+                                         uint64_t step, float* o, float& r, bool& d) {
+    float zn[Env::ACT];
+    if (cfg.action_noise != 0.0f) noise_draws<Env::ACT>(zn, z, n, i, seed, env_global, step, RNG_ACT_NOISE);
+    step_cfg<Env, float>(s, a, normalize, cfg, zn, o, r, d);
 }
 
 // ---------------------------------------------------------------------------
@@ -50,17 +83,19 @@ template <class Env>
 __global__ void __launch_bounds__(BLOCK)
 vecenv_reset_kernel(int n, float* __restrict__ state, int32_t* __restrict__ ts,
                     const uint8_t* __restrict__ mask, const float* __restrict__ draws, uint64_t seed,
-                    uint64_t step, int env_offset, float* __restrict__ obs) {
+                    uint64_t step, int env_offset, EnvCfg cfg, const float* __restrict__ obs_z,
+                    float* __restrict__ obs) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
     float s[Env::STATE];
     load_state<Env>(state, n, i, s);  // persisted solver state survives reset
-    reset_one<Env>(s, draws, n, i, seed, (uint32_t)(env_offset + i), step);
+    reset_one<Env>(s, draws, n, i, seed, (uint32_t)(env_offset + i), step, cfg.flags);
     store_state<Env>(state, n, i, s);
     ts[i] = 0;
     float o[Env::OBS];
     Env::template observe<float>(s, o);
+    observed<Env>(o, cfg, obs_z, n, i, seed, (uint32_t)(env_offset + i), step);
 #pragma unroll
     for (int k = 0; k < Env::OBS; ++k) obs[(size_t)k * n + i] = o[k];
 }
@@ -80,6 +115,21 @@ vecenv_observe_kernel(int n, const float* __restrict__ state, float* __restrict_
     for (int k = 0; k < Env::OBS; ++k) obs[(size_t)k * n + i] = o[k];
 }
 
+// MujocoEnv.get_body_com / get_body_comvel of the torso subtree (mujoco_env.py:232-238, mjcore.py:58-81):
+// com4 [4][n] = position (2) and velocity (2) of the subtree centre of mass in the env's (forward, up) axes
+template <class Env>
+__global__ void __launch_bounds__(BLOCK)
+vecenv_com_kernel(int n, const float* __restrict__ state, float* __restrict__ com4) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float s[Env::STATE];
+    load_state<Env>(state, n, i, s);
+    float c[4];
+    Env::template com<float>(s, c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) com4[(size_t)k * n + i] = c[k];
+}
+
 // ---------------------------------------------------------------------------
 // VecEnvExecutor.step
 // ---------------------------------------------------------------------------
@@ -89,6 +139,7 @@ vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length
                    float* __restrict__ state, int32_t* __restrict__ ts,
                    const float* __restrict__ actions, const float* __restrict__ reset_draws,
                    uint64_t seed, uint64_t step_value, const uint64_t* __restrict__ step_dev, int env_offset,
+                   EnvCfg cfg, const float* __restrict__ act_z, const float* __restrict__ obs_z,
                    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -103,14 +154,16 @@ vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length
     float o[Env::OBS];
     float r;
     bool d;
-    Env::template step<float>(s, a, normalize, o, r, d);
+    const uint32_t env_global = (uint32_t)(env_offset + i);
+    step_one<Env>(s, a, normalize, cfg, act_z, n, i, seed, env_global, step, o, r, d);
     int t = ts[i] + 1;
     if (max_path_length > 0 && t >= max_path_length) d = true;
     if (d && auto_reset) {
-        reset_one<Env>(s, reset_draws, n, i, seed, (uint32_t)(env_offset + i), step);
+        reset_one<Env>(s, reset_draws, n, i, seed, env_global, step, cfg.flags);
         Env::template observe<float>(s, o);
         t = 0;
     }
+    observed<Env>(o, cfg, obs_z, n, i, seed, env_global, step);
     store_state<Env>(state, n, i, s);
     ts[i] = t;
 #pragma unroll
@@ -371,6 +424,9 @@ struct RolloutDev {
     float* rewards;
     uint8_t* dones;
     float* last_obs;
+    EnvCfg cfg;
+    const float* act_noise_z;   // [T][Da][n] injected N(0,1) draws of the env's action noise, or null (Philox)
+    const float* obs_noise_z;   // [T+1][Do][n]: slice 0 = the first observation, slice t + 1 = the one after step t
 };
 
 // EPW = envs per wavefront.  64: one env per lane, the throughput shape (every lane does useful physics).
@@ -417,11 +473,13 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
     int ts = a.ts[i];
     const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
     if (a.reset_at_start) {
-        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter);
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg.flags);
         ts = 0;
     }
     float o[Env::OBS];
     Env::template observe<float>(s, o);
+    const size_t obs_z_slice = (size_t)Env::OBS * n;
+    observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
 
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
@@ -449,7 +507,9 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
 
         float r;
         bool d;
-        Env::template step<float>(s, act, a.normalize, o, r, d);
+        step_one<Env>(s, act, a.normalize, a.cfg,
+                      a.act_noise_z ? a.act_noise_z + (size_t)t * Env::ACT * n : nullptr, n, i, a.seed, env_global,
+                      a.step_counter + (uint64_t)t, o, r, d);
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
         if (live) {
@@ -458,10 +518,12 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
-            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1);
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg.flags);
             Env::template observe<float>(s, o);
             ts = 0;
         }
+        observed<Env>(o, a.cfg, a.obs_noise_z ? a.obs_noise_z + (size_t)(t + 1) * obs_z_slice : nullptr, n, i, a.seed,
+                      env_global, a.step_counter + (uint64_t)t + 1);
     }
     if (live) {
         store_state<Env>(a.state, n, i, s);
@@ -520,11 +582,13 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     int ts = a.ts[i];
     const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
     if (a.reset_at_start) {
-        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter);
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg.flags);
         ts = 0;
     }
     float o[Env::OBS];
     Env::template observe<float>(s, o);
+    const size_t obs_z_slice = (size_t)Env::OBS * n;
+    observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
 
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
@@ -551,7 +615,15 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
 
         // ---- Env.step: begin (env per lane) -> 50 sub-steps (lane group per env) -> end (env per lane) ----
         float eact[2], ctrl[3];
-        Env::template step_begin<float>(act, a.normalize, eact, ctrl);
+        if (a.cfg.action_noise != 0.0f) {      // wave-uniform: MujocoEnv(action_noise=..) (mujoco_env.py:175-187)
+            float zn[Env::ACT], dact[Env::ACT];
+            noise_draws<Env::ACT>(zn, a.act_noise_z ? a.act_noise_z + (size_t)t * Env::ACT * n : nullptr, n, i, a.seed,
+                                  env_global, a.step_counter + (uint64_t)t, RNG_ACT_NOISE);
+            action_perturbation<Env, float>(a.cfg, zn, dact);
+            Env::template step_begin<float>(act, a.normalize, eact, ctrl, dact);
+        } else {
+            Env::template step_begin<float>(act, a.normalize, eact, ctrl);
+        }
         {
             // hand the env of lane q_src to its quad: each lane derives the variables of ITS body with the same
             // expressions as Swimmer::to_chain
@@ -587,7 +659,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
         }
         float r;
         bool d;
-        Env::template step_end<float>(s, eact, o, r, d);
+        Env::template step_end<float>(s, eact, o, r, d, a.cfg.ctrl_cost_coeff);
 
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
@@ -597,10 +669,12 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
-            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1);
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg.flags);
             Env::template observe<float>(s, o);
             ts = 0;
         }
+        observed<Env>(o, a.cfg, a.obs_noise_z ? a.obs_noise_z + (size_t)(t + 1) * obs_z_slice : nullptr, n, i, a.seed,
+                      env_global, a.step_counter + (uint64_t)t + 1);
     }
     if (live) {
         store_state<Env>(a.state, n, i, s);
@@ -624,12 +698,42 @@ __global__ void philox_debug_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint3
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
+// rl_env_cfg (host, may be null = the env's defaults) -> the by-value kernel argument.  frame_skip 0 = env default.
+template <class Env>
+static int device_cfg(const rl_env_cfg* cfg, EnvCfg& c) {
+    c = default_cfg<Env, float>();
+    if (!cfg) return 0;
+    if (cfg->frame_skip < 0 || cfg->frame_skip > 64)
+        return set_error(RL_ERR_ARG, "rl_env_cfg.frame_skip = %d (0 = env default, 1..64)", cfg->frame_skip);
+    if (cfg->action_noise < 0.0f || cfg->obs_noise < 0.0f)
+        return set_error(RL_ERR_ARG, "rl_env_cfg: negative noise scale");
+    c.ctrl_cost_coeff = cfg->ctrl_cost_coeff; c.alive_coeff = cfg->alive_coeff;
+    c.action_noise = cfg->action_noise; c.obs_noise = cfg->obs_noise;
+    if (cfg->frame_skip > 0) c.frame_skip = cfg->frame_skip;
+    c.flags = cfg->flags;
+    return 0;
+}
+
+template <class Env>
+static int launch_com(int n, const float* state, float* com4, hipStream_t st) {
+    if constexpr (Env::HAS_COM) {
+        hipLaunchKernelGGL(vecenv_com_kernel<Env>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, n, state, com4);
+        return check_launch("vecenv_com_kernel");
+    } else {
+        return set_error(RL_ERR_UNSUPPORTED, "rl_vecenv_com: env kind %d has no subtree centre of mass", Env::KIND);
+    }
+}
+
 template <class Env>
 static int launch_reset(int n, float* state, int32_t* ts, const uint8_t* mask, const float* draws,
-                        uint64_t seed, uint64_t step, int env_offset, float* obs, hipStream_t st) {
+                        uint64_t seed, uint64_t step, int env_offset, const rl_env_cfg* cfg, float* obs,
+                        hipStream_t st) {
     dim3 grid((n + BLOCK - 1) / BLOCK);
+    EnvCfg c;
+    int rc = device_cfg<Env>(cfg, c);
+    if (rc) return rc;
     hipLaunchKernelGGL(vecenv_reset_kernel<Env>, grid, dim3(BLOCK), 0, st, n, state, ts, mask, draws, seed,
-                       step, env_offset, obs);
+                       step, env_offset, c, cfg ? cfg->obs_noise_z : nullptr, obs);
     return check_launch("vecenv_reset_kernel");
 }
 
@@ -643,12 +747,15 @@ template <class Env>
 static int launch_step(int n, int normalize, float scale_reward, int mpl, int auto_reset, float* state,
                        int32_t* ts,
                        const float* actions, const float* reset_draws, uint64_t seed, uint64_t step,
-                       const uint64_t* step_dev, int env_offset, float* obs, float* reward, uint8_t* done,
-                       hipStream_t st) {
+                       const uint64_t* step_dev, int env_offset, const rl_env_cfg* cfg, float* obs, float* reward,
+                       uint8_t* done, hipStream_t st) {
     dim3 grid((n + BLOCK - 1) / BLOCK);
+    EnvCfg c;
+    int rc = device_cfg<Env>(cfg, c);
+    if (rc) return rc;
     hipLaunchKernelGGL(vecenv_step_kernel<Env>, grid, dim3(BLOCK), 0, st, n, normalize, scale_reward, mpl,
-                       auto_reset, state, ts, actions, reset_draws, seed, step, step_dev, env_offset, obs, reward,
-                       done);
+                       auto_reset, state, ts, actions, reset_draws, seed, step, step_dev, env_offset, c,
+                       cfg ? cfg->action_noise_z : nullptr, cfg ? cfg->obs_noise_z : nullptr, obs, reward, done);
     return check_launch("vecenv_step_kernel");
 }
 
@@ -670,6 +777,10 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     a.state = g->state; a.ts = g->ts; a.theta = g->theta; a.eps = g->eps; a.reset_draws = g->reset_draws;
     a.obs = g->obs; a.actions = g->actions; a.means = g->means; a.rewards = g->rewards; a.dones = g->dones;
     a.last_obs = g->last_obs;
+    int rc = device_cfg<Env>(g->cfg, a.cfg);
+    if (rc) return rc;
+    a.act_noise_z = g->cfg ? g->cfg->action_noise_z : nullptr;
+    a.obs_noise_z = g->cfg ? g->cfg->obs_noise_z : nullptr;
     if constexpr (std::is_same<Env, Swimmer>::value) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
         static const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;
@@ -707,6 +818,14 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
 
 using namespace rl;
 
+template <class Env>
+static void fill_default_cfg(rl_env_cfg* cfg) {
+    const EnvCfg c = default_cfg<Env, float>();
+    cfg->ctrl_cost_coeff = c.ctrl_cost_coeff; cfg->alive_coeff = c.alive_coeff;
+    cfg->action_noise = 0.0f; cfg->obs_noise = 0.0f; cfg->frame_skip = c.frame_skip; cfg->flags = 0;
+    cfg->action_noise_z = nullptr; cfg->obs_noise_z = nullptr;
+}
+
 #define RL_DISPATCH_ENV(kind, CALL)                                                         \
     switch (kind) {                                                                         \
         case RL_ENV_CARTPOLE: { using E = rl::Cartpole; return CALL; }                      \
@@ -730,11 +849,23 @@ extern "C" int rl_env_action_bounds(int kind, float* lb, float* ub) {
 #undef Q
 }
 
+extern "C" int rl_env_default_cfg(int kind, rl_env_cfg* cfg) {
+    if (!cfg) return set_error(RL_ERR_ARG, "rl_env_default_cfg: null output");
+#define Q (fill_default_cfg<E>(cfg), (int)RL_OK)
+    RL_DISPATCH_ENV(kind, Q)
+#undef Q
+}
+
+extern "C" int rl_vecenv_com(int kind, int n, const float* state, float* com4, void* stream) {
+    if (n <= 0 || !state || !com4) return set_error(RL_ERR_ARG, "rl_vecenv_com: bad argument");
+    RL_DISPATCH_ENV(kind, launch_com<E>(n, state, com4, (hipStream_t)stream))
+}
+
 extern "C" int rl_vecenv_reset(int kind, int n, float* state, int32_t* ts, const uint8_t* mask,
                                const float* draws, uint64_t seed, uint64_t step_counter, int env_offset,
-                               float* obs, void* stream) {
+                               const rl_env_cfg* cfg, float* obs, void* stream) {
     if (n <= 0 || !state || !ts || !obs) return set_error(RL_ERR_ARG, "rl_vecenv_reset: bad argument");
-    RL_DISPATCH_ENV(kind, launch_reset<E>(n, state, ts, mask, draws, seed, step_counter, env_offset, obs,
+    RL_DISPATCH_ENV(kind, launch_reset<E>(n, state, ts, mask, draws, seed, step_counter, env_offset, cfg, obs,
                                           (hipStream_t)stream))
 }
 
@@ -745,25 +876,25 @@ extern "C" int rl_vecenv_observe(int kind, int n, const float* state, float* obs
 
 extern "C" int rl_vecenv_step(int kind, int n, int normalize, float scale_reward, int max_path_length,
                               int auto_reset, float* state, int32_t* ts, const float* actions, const float* reset_draws,
-                              uint64_t seed, uint64_t step_counter, int env_offset, float* obs,
-                              float* reward, uint8_t* done, void* stream) {
+                              uint64_t seed, uint64_t step_counter, int env_offset, const rl_env_cfg* cfg,
+                              float* obs, float* reward, uint8_t* done, void* stream) {
     if (n <= 0 || !state || !ts || !actions || !obs || !reward || !done)
         return set_error(RL_ERR_ARG, "rl_vecenv_step: bad argument");
     RL_DISPATCH_ENV(kind, launch_step<E>(n, normalize, scale_reward, max_path_length, auto_reset, state, ts,
                                          actions,
-                                         reset_draws, seed, step_counter, nullptr, env_offset, obs, reward, done,
+                                         reset_draws, seed, step_counter, nullptr, env_offset, cfg, obs, reward, done,
                                          (hipStream_t)stream))
 }
 
 extern "C" int rl_vecenv_step_graph(int kind, int n, int normalize, float scale_reward, int max_path_length,
                                     int auto_reset, float* state, int32_t* ts, const float* actions, uint64_t seed,
-                                    const uint64_t* step_counter_dev, int env_offset, float* obs, float* reward,
-                                    uint8_t* done, void* stream) {
+                                    const uint64_t* step_counter_dev, int env_offset, const rl_env_cfg* cfg,
+                                    float* obs, float* reward, uint8_t* done, void* stream) {
     if (n <= 0 || !state || !ts || !actions || !obs || !reward || !done || !step_counter_dev)
         return set_error(RL_ERR_ARG, "rl_vecenv_step_graph: bad argument");
     RL_DISPATCH_ENV(kind, launch_step<E>(n, normalize, scale_reward, max_path_length, auto_reset, state, ts,
-                                         actions, nullptr, seed, 0, step_counter_dev, env_offset, obs, reward, done,
-                                         (hipStream_t)stream))
+                                         actions, nullptr, seed, 0, step_counter_dev, env_offset, cfg, obs, reward,
+                                         done, (hipStream_t)stream))
 }
 
 namespace rl {

@@ -17,8 +17,10 @@
 
 #if defined(__HIPCC__)
 #define RL_HD __host__ __device__ __forceinline__
+#define RL_UNROLL _Pragma("unroll")
 #else
 #define RL_HD inline __attribute__((always_inline))
+#define RL_UNROLL
 #endif
 
 namespace rl {
@@ -181,6 +183,87 @@ RL_HD float u32_to_unit_open(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.
 enum RngPurpose : uint32_t {
     RNG_RESET = 0x52455345u,   // reset draws
     RNG_POLICY = 0x504f4c49u,  // policy action noise
+    RNG_ACT_NOISE = 0x414e4f49u,  // env action noise (Box2DEnv / MujocoEnv action_noise)
+    RNG_OBS_NOISE = 0x4f4e4f49u,  // env observation noise (Box2DEnv obs_noise)
 };
+
+// ---- env options ------------------------------------------------------------------------------------------------
+// What the reference's env constructors take and the kernels honour at run time (include/rllab_amd.h: rl_env_cfg):
+//   SwimmerEnv / Walker2DEnv / HopperEnv(ctrl_cost_coeff=..)   swimmer_env.py:15-21, walker2d_env.py:21-27, hopper_env.py:27-35
+//   HopperEnv(alive_coeff=..)
+//   Box2DEnv(frame_skip=.., obs_noise=.., action_noise=..)     box2d_env.py:30-58,194-230
+//   MujocoEnv(action_noise=..)                                  mujoco_env.py:40-43,175-185
+// EnvCfg travels by value into every env kernel; StepOpts is what one Env::step sees of it (plus the additive action
+// perturbation the noise amounts to for this transition).  Defaults come from each env (Env::default_opts), so a
+// launch without options runs the same arithmetic, bit for bit, as before the options existed.
+template <typename R>
+struct EnvCfgT {
+    R ctrl_cost_coeff, alive_coeff, action_noise, obs_noise;
+    int frame_skip, flags;
+};
+using EnvCfg = EnvCfgT<float>;
+enum EnvCfgFlags : int {
+    CFG_POLE_FOLLOWS_CART = 1,   // CartpoleEnv.reset moves the pole with the cart (hinge starts closed)
+    CFG_FIXED_START = 2,         // InvertedDoublePendulumEnv(random_start=False)
+};
+template <typename R>
+struct StepOpts {
+    R ctrl_cost_coeff, alive_coeff;
+    int frame_skip;
+    const R* dact;               // per-dimension additive perturbation of the applied action, or null
+};
+template <typename R>
+RL_HD StepOpts<R> make_opts(double ctrl_cost_coeff, double alive_coeff, int frame_skip) {
+    StepOpts<R> o;
+    o.ctrl_cost_coeff = (R)ctrl_cost_coeff; o.alive_coeff = (R)alive_coeff; o.frame_skip = frame_skip; o.dact = nullptr;
+    return o;
+}
+// the options an env runs with when the caller gives none
+template <class Env, typename R>
+RL_HD EnvCfgT<R> default_cfg() {
+    const StepOpts<R> o = Env::template default_opts<R>();
+    EnvCfgT<R> c;
+    c.ctrl_cost_coeff = o.ctrl_cost_coeff; c.alive_coeff = o.alive_coeff; c.action_noise = (R)0; c.obs_noise = (R)0;
+    c.frame_skip = o.frame_skip; c.flags = 0;
+    return c;
+}
+template <typename R>
+RL_HD StepOpts<R> opts_from_cfg(const EnvCfgT<R>& c) {
+    StepOpts<R> o;
+    o.ctrl_cost_coeff = c.ctrl_cost_coeff; o.alive_coeff = c.alive_coeff; o.frame_skip = c.frame_skip; o.dact = nullptr;
+    return o;
+}
+// Box2DEnv._inject_action_noise / MujocoEnv.inject_action_noise (box2d_env.py:219-226, mujoco_env.py:175-182):
+//   noise = action_noise * N(0,1);  noise = 0.5 * (ub - lb) * noise;  applied = action + noise.   z = the N(0,1) draws
+template <class Env, typename R>
+RL_HD void action_perturbation(const EnvCfgT<R>& c, const R* z, R* dact) {
+    R lb[Env::ACT], ub[Env::ACT];
+    Env::template action_bounds<R>(lb, ub);
+    RL_UNROLL
+    for (int k = 0; k < Env::ACT; ++k) {
+        const R noise = c.action_noise * z[k];
+        dact[k] = (R)0.5 * (ub[k] - lb[k]) * noise;
+    }
+}
+// Box2DEnv._inject_obs_noise (box2d_env.py:194-201): obs + 1 * obs_noise * N(0,1), entry-wise
+template <class Env, typename R>
+RL_HD void add_obs_noise(const EnvCfgT<R>& c, const R* z, R* obs) {
+    RL_UNROLL
+    for (int k = 0; k < Env::OBS; ++k) {
+        const R noise = c.obs_noise * z[k];
+        obs[k] = obs[k] + noise;
+    }
+}
+// Env.step under a cfg: options + (if action_noise != 0) the perturbation from the draws `zact`
+template <class Env, typename R>
+RL_HD void step_cfg(R* s, const R* a, int normalize, const EnvCfgT<R>& c, const R* zact, R* obs, R& reward, bool& done) {
+    StepOpts<R> o = opts_from_cfg<R>(c);
+    R dact[Env::ACT];
+    if (c.action_noise != (R)0) {
+        action_perturbation<Env, R>(c, zact, dact);
+        o.dact = dact;
+    }
+    Env::template step<R>(s, a, normalize, obs, reward, done, o);
+}
 
 }  // namespace rl

@@ -1,39 +1,41 @@
 """Box2DEnv base (API of rllab/envs/box2d/box2d_env.py:30-321).
 
-The reference builds a pybox2d ``b2World`` from an XML template and steps it
-through SWIG; here the world of each task is compiled into a HIP kernel
-(csrc/dyn_*.h) and this class only carries the constructor surface.  Options
-that change the simulated world (frame_skip other than the task default,
-position_only, obs/action noise, custom templates) are rejected loudly instead
-of being silently ignored.
+The reference builds a pybox2d ``b2World`` from an XML template and steps it through SWIG; here the world of each
+task is compiled into a HIP kernel (csrc/dyn_*.h).  The constructor options that act on a given world are honoured
+at run time through the kernels' option block (``rl_env_cfg``, include/rllab_amd.h):
+
+  frame_skip      world steps per env step, reward after the last                     (box2d_env.py:52,171-179)
+  action_noise    applied = action + 0.5 (ub - lb) * action_noise * N(0,1), after the reward generator captured
+                  the action, clipped by forward_dynamics                              (:163-175,219-226,123-124)
+  obs_noise       observation + obs_noise * N(0,1), entry-wise                        (:194-201,210-218)
+  position_only   keep the position-typed entries of the XML <state> list             (:185-192,228-237)
+
+Noise draws come from the in-kernel Philox stream (keyed by seed, env, step and purpose) instead of the reference's
+process-global ``np.random``; parity runs inject the draws (``HipVecEnv.step(.., action_noise_z=, obs_noise_z=)``).
+Options that would need a different world (custom XML templates / template_args) have no kernel and raise.
 """
 from rllab_amd.envs.hip_env import HipEnv
 
 
 class Box2DEnv(HipEnv):
     DEFAULT_FRAME_SKIP = 1
+    POSITION_IDS = None        # indices of the "xpos/ypos/apos/dist/angle" entries of the XML <state> list
 
     def __init__(self, model_path=None, frame_skip=None, position_only=False, obs_noise=0.0,
-                 action_noise=0.0, template_string=None, template_args=None):
+                 action_noise=0.0, template_string=None, template_args=None, **engine_cfg):
         if frame_skip is None:
             frame_skip = self.DEFAULT_FRAME_SKIP
-        unsupported = []
-        if frame_skip != self.DEFAULT_FRAME_SKIP:
-            unsupported.append("frame_skip=%r" % (frame_skip,))
-        if position_only:
-            unsupported.append("position_only")
-        if obs_noise != 0.0:
-            unsupported.append("obs_noise")
-        if action_noise != 0.0:
-            unsupported.append("action_noise")
         if template_string is not None or template_args not in (None, {}):
-            unsupported.append("template_string/template_args")
-        if unsupported:
             raise NotImplementedError(
-                "%s: options %s are not compiled into the HIP kernel of this env" %
-                (type(self).__name__, ", ".join(unsupported)))
-        self.frame_skip = frame_skip
-        self.position_only = position_only
-        self.obs_noise = obs_noise
-        self.action_noise = action_noise
-        HipEnv.__init__(self)
+                "%s: template_string / template_args describe a different Box2D world; only the task's own XML "
+                "is compiled into a HIP kernel" % type(self).__name__)
+        if int(frame_skip) != frame_skip or not 1 <= frame_skip <= 64:
+            raise ValueError("frame_skip must be an integer in 1..64, got %r" % (frame_skip,))
+        if obs_noise < 0 or action_noise < 0:
+            raise ValueError("noise scales must be >= 0")
+        self.frame_skip = int(frame_skip)
+        self.position_only = bool(position_only)
+        self.obs_noise = float(obs_noise)
+        self.action_noise = float(action_noise)
+        cfg = dict(engine_cfg, frame_skip=self.frame_skip, obs_noise=self.obs_noise, action_noise=self.action_noise)
+        HipEnv.__init__(self, cfg=cfg, position_ids=self.POSITION_IDS if self.position_only else None)

@@ -7,18 +7,26 @@ from rllab_amd.envs.box2d.box2d_env import Box2DEnv
 
 class CartpoleEnv(Box2DEnv, Serializable):
     KIND = _lib.ENV_CARTPOLE
+    POSITION_IDS = (0, 2)      # <state> list: xpos(cart), xvel, apos(pole), avel (cartpole.xml.mako:41-44)
 
     def __init__(self, *args, **kwargs):
+        """Reference options (frame_skip, position_only, obs_noise, action_noise) plus one engine option:
+        ``reset_pole_follows_cart`` (default False = the reference's reset, which moves the cart but leaves the pole
+        body at its XML pose so that the first position solve pulls the hinge together; True = the pole is moved
+        with the cart.  DESIGN.md section 5 discusses which of the two the reference's documented log shows)."""
         self.max_pole_angle = .2
         self.max_cart_pos = 2.4
         self.max_cart_speed = 4.
         self.max_pole_speed = 4.
         self.reset_range = 0.05
-        super(CartpoleEnv, self).__init__(None, *args, **kwargs)
-        Serializable.__init__(self, *args, **kwargs)
+        Serializable.quick_init(self, locals())        # before the engine option is taken out of kwargs
+        kwargs = dict(kwargs)
+        follows = bool(kwargs.pop("reset_pole_follows_cart", False))
+        self.reset_pole_follows_cart = follows
+        super(CartpoleEnv, self).__init__(None, *args, flags=_lib.CFG_POLE_FOLLOWS_CART if follows else 0, **kwargs)
 
     def is_current_done(self):
         """abs(cart x) > max_cart_pos or abs(pole angle) > max_pole_angle (cartpole_env.py:54-56), read off the
-        present observation [x, x', theta, theta']."""
-        o = self.get_current_obs()
-        return bool(abs(o[0]) > self.max_cart_pos or abs(o[2]) > self.max_pole_angle)
+        present (noise-free, unfiltered) state."""
+        st = self.get_state()
+        return bool(abs(st[0]) > self.max_cart_pos or abs(st[8]) > self.max_pole_angle)

@@ -7,13 +7,16 @@ from rllab_amd.envs.box2d.box2d_env import Box2DEnv
 
 class DoublePendulumEnv(Box2DEnv, Serializable):
     KIND = _lib.ENV_DOUBLE_PENDULUM
-    DEFAULT_FRAME_SKIP = 2   # "make sure mdp-level step is 100ms long" -- 2 x 0.01 s world steps ... as the reference sets it
+    DEFAULT_FRAME_SKIP = 2     # "make sure mdp-level step is 100ms long" (double_pendulum_env.py:15-16)
+    POSITION_IDS = (0, 1, 3, 4)   # sin / cos of the two link angles are "apos" entries (double_pendulum.xml.mako:32-37)
 
     def __init__(self, *args, **kwargs):
+        Serializable.quick_init(self, locals())
+        kwargs = dict(kwargs)
         kwargs["frame_skip"] = kwargs.get("frame_skip", 2)
         if kwargs.get("template_args", {}) and kwargs["template_args"].get("noise", False):
-            raise NotImplementedError("DoublePendulumEnv: randomised link length is not compiled into the kernel")
+            raise NotImplementedError("DoublePendulumEnv: a randomised link length (template_args noise) changes the "
+                                      "world's masses and anchors; only link_len = 1 is compiled into the kernel")
         kwargs.pop("template_args", None)
         self.link_len = 1
         super(DoublePendulumEnv, self).__init__(None, *args, **kwargs)
-        Serializable.__init__(self, *args, **kwargs)

@@ -39,8 +39,16 @@ class HipVecEnv(object):
     """n lock-step copies of one env kind on the current HIP device."""
 
     def __init__(self, kind, n_envs, max_path_length, normalize=False, scale_reward=1.0, seed=None,
-                 env_offset=0, action_space=None, observation_space=None, auto_reset=True):
+                 env_offset=0, action_space=None, observation_space=None, auto_reset=True, cfg=None,
+                 position_ids=None):
+        """``cfg``: dict of env options (fields of ``rl_env_cfg``: ctrl_cost_coeff, alive_coeff, action_noise,
+        obs_noise, frame_skip, flags) on top of the env's defaults.  ``position_ids``: Box2DEnv(position_only=True)
+        -- the observation rows callers see (box2d_env.py:185-192,228-230); the kernels always produce the full
+        observation, the filter is a row selection of their output."""
         self.kind = kind
+        self.cfg_overrides = dict(cfg or {})
+        self.cfg = _lib.env_default_cfg(kind, **self.cfg_overrides)
+        self.position_ids = None if position_ids is None else [int(i) for i in position_ids]
         self.n = int(n_envs)
         self.max_path_length = int(max_path_length) if max_path_length is not None else 0
         self.normalize = bool(normalize)
@@ -57,11 +65,46 @@ class HipVecEnv(object):
         self._done = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
         self.step_counter = 0  # global step index: RNG counter base
         self._action_space, self._observation_space = action_space, observation_space
+        self._pos_index = None if self.position_ids is None else torch.as_tensor(self.position_ids, device=self.device)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["cfg"] = None                    # ctypes structs with pointers do not pickle: rebuilt from the overrides
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.cfg = _lib.env_default_cfg(self.kind, **self.cfg_overrides)
+
+    def _cfg_with(self, action_noise_z=None, obs_noise_z=None):
+        """The launch's rl_env_cfg: the env's options plus (parity runs) injected noise draws."""
+        c = self.cfg
+        c.action_noise_z = action_noise_z.data_ptr() if action_noise_z is not None else None
+        c.obs_noise_z = obs_noise_z.data_ptr() if obs_noise_z is not None else None
+        return ctypes.byref(c)
+
+    def _filtered(self, obs_rows):
+        """[Do, n] observation planes -> what the caller sees ([n, Do'] view; position rows only when filtering)."""
+        if self._pos_index is not None:
+            obs_rows = obs_rows.index_select(0, self._pos_index)
+        return obs_rows.t()
+
+    def _plane(self, z, shape):
+        if z is None:
+            return None
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device).contiguous()
+        assert tuple(z.shape) == tuple(shape), (tuple(z.shape), tuple(shape))
+        return z
 
     # -- VecEnvExecutor surface ------------------------------------------------
     @property
     def num_envs(self):
         return self.n
+
+    @property
+    def obs_rows(self):
+        """Observation dimension callers see (the position rows only under position_only)."""
+        return self.q["obs_dim"] if self.position_ids is None else len(self.position_ids)
 
     @property
     def action_space(self):
@@ -74,36 +117,41 @@ class HipVecEnv(object):
     def terminate(self):
         pass
 
-    def reset(self, mask=None, draws=None):
-        """Reset all envs (or those in ``mask``); returns obs_n as an [n, Do] view."""
+    def reset(self, mask=None, draws=None, obs_noise_z=None):
+        """Reset all envs (or those in ``mask``); returns obs_n as an [n, Do] view.  ``obs_noise_z`` [Do, n]:
+        injected N(0,1) draws of the observation noise (parity runs; otherwise the in-kernel Philox stream)."""
         if draws is not None:
             draws = torch.as_tensor(draws, dtype=torch.float32, device=self.device).contiguous()
             assert draws.shape == (self.q["reset_draws"], self.n)
         if mask is not None:
             mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        oz = self._plane(obs_noise_z, (self.q["obs_dim"], self.n))
         _lib.check(_lib.lib.rl_vecenv_reset(
             self.kind, self.n, _lib.ptr(self.state), _lib.ptr(self.ts), _lib.ptr(mask), _lib.ptr(draws),
-            self.seed, self.step_counter, self.env_offset, _lib.ptr(self._obs), _lib.stream_ptr()),
-            "rl_vecenv_reset")
+            self.seed, self.step_counter, self.env_offset, self._cfg_with(None, oz), _lib.ptr(self._obs),
+            _lib.stream_ptr()), "rl_vecenv_reset")
         self.step_counter += 1
-        return self._obs.t()
+        return self._filtered(self._obs)
 
-    def step(self, action_n, reset_draws=None):
+    def step(self, action_n, reset_draws=None, action_noise_z=None, obs_noise_z=None):
         """One lock-step transition.  ``action_n``: [n, Da] numpy array or tensor.
         numpy in -> numpy out; tensor in -> device tensors out (views of buffers
-        that the next call overwrites)."""
+        that the next call overwrites).  ``action_noise_z`` [Da, n] / ``obs_noise_z`` [Do, n]: injected
+        N(0,1) draws of the env's own noises (parity runs)."""
         is_np = not torch.is_tensor(action_n)
         a = torch.as_tensor(np.asarray(action_n) if is_np else action_n)
         a = a.to(device=self.device, dtype=torch.float32).reshape(self.n, self.q["act_dim"]).t().contiguous()
         if reset_draws is not None:
             reset_draws = torch.as_tensor(reset_draws, dtype=torch.float32, device=self.device).contiguous()
+        az = self._plane(action_noise_z, (self.q["act_dim"], self.n))
+        oz = self._plane(obs_noise_z, (self.q["obs_dim"], self.n))
         _lib.check(_lib.lib.rl_vecenv_step(
             self.kind, self.n, int(self.normalize), self.scale_reward, self.max_path_length,
             int(self.auto_reset), _lib.ptr(self.state), _lib.ptr(self.ts), _lib.ptr(a), _lib.ptr(reset_draws), self.seed,
-            self.step_counter, self.env_offset, _lib.ptr(self._obs), _lib.ptr(self._reward),
+            self.step_counter, self.env_offset, self._cfg_with(az, oz), _lib.ptr(self._obs), _lib.ptr(self._reward),
             _lib.ptr(self._done), _lib.stream_ptr()), "rl_vecenv_step")
         self.step_counter += 1
-        obs, rew, done = self._obs.t(), self._reward, self._done.bool()
+        obs, rew, done = self._filtered(self._obs), self._reward, self._done.bool()
         if is_np:
             return (obs.cpu().numpy().astype(np.float64), rew.cpu().numpy().astype(np.float64),
                     done.cpu().numpy(), dict())
@@ -114,7 +162,15 @@ class HipVecEnv(object):
         """obs_n of the state planes as they are (no transition): rl_vecenv_observe."""
         _lib.check(_lib.lib.rl_vecenv_observe(self.kind, self.n, _lib.ptr(self.state), _lib.ptr(self._obs),
                                               _lib.stream_ptr()), "rl_vecenv_observe")
-        return self._obs.t()
+        return self._filtered(self._obs)
+
+    def com(self):
+        """[n, 4] = (forward, up) position and velocity of the torso subtree's centre of mass of every env
+        (MujocoEnv.get_body_com / get_body_comvel, mujoco_env.py:232-238): rl_vecenv_com."""
+        out = torch.empty((4, self.n), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib.rl_vecenv_com(self.kind, self.n, _lib.ptr(self.state), _lib.ptr(out), _lib.stream_ptr()),
+                   "rl_vecenv_com")
+        return out.t()
 
     def get_state(self):
         """[n, S] host copy of the persisted state (layout per env kind: csrc/dyn_*.h)."""
@@ -127,11 +183,15 @@ class HipVecEnv(object):
         self.ts.zero_()
 
     # -- fused rollout ---------------------------------------------------------
-    def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None):
+    def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
+                obs_noise_z=None):
         """``horizon`` lock-step iterations of get_actions -> step -> record ->
         auto-reset in ONE launch (rl_rollout_gaussian_mlp).  Returns
-        ``Trajectories``.  ``eps`` [Da, T, n] / ``reset_draws`` [T+1, R, n]
-        inject pre-generated noise (parity runs)."""
+        ``Trajectories``.  ``eps`` [Da, T, n] / ``reset_draws`` [T+1, R, n] / ``action_noise_z`` [T, Da, n] /
+        ``obs_noise_z`` [T+1, Do, n] inject pre-generated noise (parity runs)."""
+        if self.position_ids is not None:
+            raise NotImplementedError("position_only observations: the fused rollout feeds the policy the full "
+                                      "observation; sample through the per-transition path")
         T, n = int(horizon), self.n
         do, da = self.q["obs_dim"], self.q["act_dim"]
         hs = tuple(policy.hidden_sizes)
@@ -152,7 +212,10 @@ class HipVecEnv(object):
         if reset_draws is not None:
             reset_draws = torch.as_tensor(reset_draws, **f32).contiguous()
             assert reset_draws.shape == (T + 1, self.q["reset_draws"], n)
+        az = self._plane(action_noise_z, (T, da, n))
+        oz = self._plane(obs_noise_z, (T + 1, do, n))
         log_min_std = math.log(policy.min_std) if policy.min_std is not None else -1e30
+        self._cfg_with(az, oz)
         args = _lib.RolloutArgs(
             kind=self.kind, n_envs=n, horizon=T, max_path_length=self.max_path_length,
             normalize=int(self.normalize), reset_at_start=int(reset_at_start),
@@ -163,7 +226,8 @@ class HipVecEnv(object):
             eps=eps.data_ptr() if eps is not None else None,
             reset_draws=reset_draws.data_ptr() if reset_draws is not None else None,
             obs=obs.data_ptr(), actions=act.data_ptr(), means=mean.data_ptr(),
-            rewards=rew.data_ptr(), dones=done.data_ptr(), last_obs=self._obs.data_ptr())
+            rewards=rew.data_ptr(), dones=done.data_ptr(), last_obs=self._obs.data_ptr(),
+            cfg=ctypes.pointer(self.cfg))
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1
@@ -175,12 +239,17 @@ class HipEnv(Env, Serializable):
     """Base of the HIP-native envs; subclasses set ``KIND``."""
     KIND = None
 
-    def __init__(self):
+    def __init__(self, cfg=None, position_ids=None):
+        """``cfg``: env options for the kernels (dict of rl_env_cfg fields; validated by the library on first use);
+        ``position_ids``: observation rows kept by Box2DEnv(position_only=True)."""
         q = _lib.env_query(self.KIND)
         self._q = q
+        self._cfg = dict(cfg or {})
+        _lib.env_default_cfg(self.KIND, **self._cfg)      # unknown option names fail here, at construction
+        self._position_ids = None if position_ids is None else list(position_ids)
         lb, ub = _lib.env_action_bounds(self.KIND)
         self._action_space = spaces.Box(lb, ub)
-        ob = BIG * np.ones(q["obs_dim"])
+        ob = BIG * np.ones(q["obs_dim"] if self._position_ids is None else len(self._position_ids))
         self._observation_space = spaces.Box(-ob, ob)
         self._single = None
 
@@ -205,7 +274,7 @@ class HipEnv(Env, Serializable):
         return HipVecEnv(self.KIND, n_envs, max_path_length, normalize=normalize,
                          scale_reward=scale_reward, seed=seed, env_offset=env_offset,
                          action_space=self.action_space, observation_space=self.observation_space,
-                         auto_reset=auto_reset)
+                         auto_reset=auto_reset, cfg=self._cfg, position_ids=self._position_ids)
 
     # -- single-env face (rllab/envs/base.py) on a 1-env executor --------------
     def _one(self):

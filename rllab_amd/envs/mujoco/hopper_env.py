@@ -11,13 +11,11 @@ class HopperEnv(MujocoEnv, Serializable):
     KIND = _lib.ENV_HOPPER
 
     def __init__(self, alive_coeff=1, ctrl_cost_coeff=0.01, *args, **kwargs):
-        if alive_coeff != 1 or ctrl_cost_coeff != 0.01:
-            raise NotImplementedError(
-                "HopperEnv: alive_coeff / ctrl_cost_coeff are compiled into the HIP kernel (1, 0.01)")
         self.alive_coeff = alive_coeff
         self.ctrl_cost_coeff = ctrl_cost_coeff
-        super(HopperEnv, self).__init__(*args, **kwargs)
         Serializable.quick_init(self, locals())
+        super(HopperEnv, self).__init__(*args, alive_coeff=float(alive_coeff), ctrl_cost_coeff=float(ctrl_cost_coeff),
+                                        **kwargs)
 
     def log_diagnostics(self, paths):
         self._log_forward_progress(paths)

@@ -12,9 +12,8 @@ class InvertedDoublePendulumEnv(MujocoEnv, Serializable):
     progress_obs_index = None      # no forward-progress diagnostic (the reference class logs none)
 
     def __init__(self, *args, **kwargs):
-        self.random_start = kwargs.pop("random_start", True)
-        if not self.random_start:
-            raise NotImplementedError(
-                "InvertedDoublePendulumEnv: random_start=False is not compiled into the HIP kernel")
-        super(InvertedDoublePendulumEnv, self).__init__(*args, **kwargs)
         Serializable.quick_init(self, locals())
+        kwargs = dict(kwargs)
+        self.random_start = kwargs.pop("random_start", True)
+        super(InvertedDoublePendulumEnv, self).__init__(*args, flags=0 if self.random_start else _lib.CFG_FIXED_START,
+                                                        **kwargs)

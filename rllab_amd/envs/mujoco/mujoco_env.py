@@ -2,8 +2,9 @@
 
 The reference loads an MJCF into the proprietary MuJoCo 1.31 binary through ctypes
 (rllab/mujoco_py); importing this module needs no MuJoCo: each task's model is
-compiled into a HIP kernel (csrc/dyn_planar.h + dyn_<task>.h).  Options that change
-the simulated world are rejected loudly.
+compiled into a HIP kernel (csrc/dyn_planar.h + dyn_<task>.h).  ``action_noise`` and the
+tasks' reward coefficients are run-time options of the kernels (``rl_env_cfg``); options
+that name a different model are rejected loudly.
 """
 import numpy as np
 
@@ -16,18 +17,18 @@ class MujocoEnv(HipEnv):
     # (obs[-3] = x of the subtree COM: swimmer_env.py:48-62, half_cheetah_env.py:48-56)
     progress_obs_index = -3
 
-    def __init__(self, action_noise=0.0, file_path=None, template_args=None):
-        unsupported = []
-        if action_noise != 0.0:
-            unsupported.append("action_noise")
+    def __init__(self, action_noise=0.0, file_path=None, template_args=None, **engine_cfg):
+        """``action_noise``: ctrl = action + 0.5 (ub - lb) * action_noise * N(0,1) (mujoco_env.py:175-187), drawn by
+        the kernels (Philox stream; ``np.random`` in the reference).  ``file_path`` / ``template_args`` would name a
+        different MJCF: only the task's own model is compiled into a kernel."""
         if file_path is not None or template_args is not None:
-            unsupported.append("file_path/template_args")
-        if unsupported:
             raise NotImplementedError(
-                "%s: options %s are not compiled into the HIP kernel of this env" %
-                (type(self).__name__, ", ".join(unsupported)))
-        self.action_noise = action_noise
-        HipEnv.__init__(self)
+                "%s: file_path / template_args describe a different model; only the task's own MJCF constants are "
+                "compiled into the HIP kernel of this env" % type(self).__name__)
+        if action_noise < 0:
+            raise ValueError("action_noise must be >= 0")
+        self.action_noise = float(action_noise)
+        HipEnv.__init__(self, cfg=dict(engine_cfg, action_noise=self.action_noise))
 
     # -- state-level API of the reference base class (mujoco_env.py:109-238) --------------------------------------
     @property
@@ -54,20 +55,29 @@ class MujocoEnv(HipEnv):
         lb, ub = self.action_bounds
         return action + 0.5 * (ub - lb) * noise
 
-    def get_body_com(self, body_name):
-        """Subtree centre of mass; the compiled envs expose the one their observation carries -- the torso's
-        (``com_subtree[0]``, the last three observation entries, swimmer_env.py:25-30)."""
+    def _torso_com(self, body_name):
         if body_name != "torso":
-            raise NotImplementedError("%s: only the torso subtree COM is produced by the HIP kernel"
+            raise NotImplementedError("%s: the kernels export the torso subtree (= whole model) only"
                                       % type(self).__name__)
-        if not getattr(self, "OBS_ENDS_WITH_TORSO_COM", False):
-            raise NotImplementedError("%s: the observation does not carry the torso COM" % type(self).__name__)
-        return self.get_current_obs()[-3:]
+        return self._one().com()[0].cpu().numpy().astype(np.float64)   # forward, up, d/dt forward, d/dt up
+
+    def get_body_com(self, body_name):
+        """Subtree centre of mass of the torso, ``model.data.com_subtree[idx]`` (mujoco_env.py:232-234): (x, y, z)
+        with the planar model's forward / up coordinates in the slots its observation uses."""
+        c = self._torso_com(body_name)
+        return self._planar_to_xyz(c[0], c[1])
 
     def get_body_comvel(self, body_name):
-        raise NotImplementedError(
-            "%s: subtree COM velocities live inside the step kernel (they enter the reward) and are not exported"
-            % type(self).__name__)
+        """Subtree linear momentum / subtree mass (mujoco_env.py:236-238, mjcore.py:58-81) -- the quantity whose
+        forward component is the reward's ``comvel_x``."""
+        c = self._torso_com(body_name)
+        return self._planar_to_xyz(c[2], c[3])
+
+    # the swimmer moves in the x-y plane (z = 0); the legged models in x-z (y = 0)
+    PLANE = "xz"
+
+    def _planar_to_xyz(self, forward, up):
+        return np.array([forward, up, 0.0]) if self.PLANE == "xy" else np.array([forward, 0.0, up])
 
     def _log_forward_progress(self, paths):
         """Average/Max/Min/StdForwardProgress = obs[-1][-3] - obs[0][-3] per path

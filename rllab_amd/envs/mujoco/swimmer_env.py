@@ -12,12 +12,12 @@ class SwimmerEnv(MujocoEnv, Serializable):
     KIND = _lib.ENV_SWIMMER
     OBS_ENDS_WITH_TORSO_COM = True     # obs = [..., com_subtree(torso)] (get_body_com)
 
+    PLANE = "xy"
+
     def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
-        if ctrl_cost_coeff != 1e-2:
-            raise NotImplementedError("SwimmerEnv: ctrl_cost_coeff is compiled into the HIP kernel (1e-2)")
         self.ctrl_cost_coeff = ctrl_cost_coeff
-        super(SwimmerEnv, self).__init__(*args, **kwargs)
         Serializable.quick_init(self, locals())
+        super(SwimmerEnv, self).__init__(*args, ctrl_cost_coeff=float(ctrl_cost_coeff), **kwargs)
 
     def get_ori(self):
         """Heading of the first link: qpos[ORI_IND] (swimmer_env.py:32-33)."""

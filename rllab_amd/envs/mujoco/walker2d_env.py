@@ -12,11 +12,9 @@ class Walker2DEnv(MujocoEnv, Serializable):
     OBS_ENDS_WITH_TORSO_COM = True     # obs = [..., com_subtree(torso)] (get_body_com)
 
     def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
-        if ctrl_cost_coeff != 1e-2:
-            raise NotImplementedError("Walker2DEnv: ctrl_cost_coeff is compiled into the HIP kernel (1e-2)")
         self.ctrl_cost_coeff = ctrl_cost_coeff
-        super(Walker2DEnv, self).__init__(*args, **kwargs)
         Serializable.quick_init(self, locals())
+        super(Walker2DEnv, self).__init__(*args, ctrl_cost_coeff=float(ctrl_cost_coeff), **kwargs)
 
     def log_diagnostics(self, paths):
         self._log_forward_progress(paths)

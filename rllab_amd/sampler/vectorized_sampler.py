@@ -67,7 +67,7 @@ class VectorizedSampler(BaseSampler):
         T = algo.max_path_length
         t_start = time.time()
         if getattr(policy, "fusable", False) and len(getattr(policy, "hidden_sizes", ())) == 2 \
-                and tuple(policy.hidden_sizes) in ((32, 32), (64, 64)):
+                and tuple(policy.hidden_sizes) in ((32, 32), (64, 64)) and self.vec_env.position_ids is None:
             traj = self.vec_env.rollout(policy, T, reset_at_start=True)
         elif self.use_graph and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "recorded_log_std"):
             try:
@@ -99,7 +99,7 @@ class VectorizedSampler(BaseSampler):
         g = getattr(self, "_step_graph", None)
         if g is not None and g["key"] == key:
             return g
-        n, do, da = v.n, v.q["obs_dim"], v.q["act_dim"]
+        n, do, da = v.n, v.obs_rows, v.q["act_dim"]
         dev = v.device
         f32 = dict(dtype=torch.float32, device=dev)
         st = dict(key=key,
@@ -111,8 +111,8 @@ class VectorizedSampler(BaseSampler):
                   counter=torch.zeros(1, dtype=torch.int64, device=dev))
 
         def one_transition():
-            obs = v._obs.t()                                           # [n, Do] view of the executor's buffer
-            st["obs_p"].index_copy_(1, st["t_idx"], v._obs.unsqueeze(1))
+            obs = v._filtered(v._obs)                                  # [n, Do] view of the executor's buffer
+            st["obs_p"].index_copy_(1, st["t_idx"], obs.t().unsqueeze(1))
             actions, info = policy.get_actions(obs)
             st["a_planes"].copy_(actions.t())
             st["act_p"].index_copy_(1, st["t_idx"], st["a_planes"].unsqueeze(1))
@@ -120,8 +120,8 @@ class VectorizedSampler(BaseSampler):
             _lib.check(_lib.lib.rl_vecenv_step_graph(
                 v.kind, n, int(v.normalize), v.scale_reward, v.max_path_length, int(v.auto_reset),
                 _lib.ptr(v.state), _lib.ptr(v.ts), _lib.ptr(st["a_planes"]), v.seed, _lib.ptr(st["counter"]),
-                v.env_offset, _lib.ptr(v._obs), _lib.ptr(v._reward), _lib.ptr(v._done), _lib.stream_ptr()),
-                "rl_vecenv_step_graph")
+                v.env_offset, v._cfg_with(), _lib.ptr(v._obs), _lib.ptr(v._reward), _lib.ptr(v._done),
+                _lib.stream_ptr()), "rl_vecenv_step_graph")
             st["rew_p"].index_copy_(0, st["t_idx"], v._reward.unsqueeze(0))
             st["done_p"].index_copy_(0, st["t_idx"], v._done.unsqueeze(0))
             st["t_idx"].add_(1)
@@ -163,7 +163,7 @@ class VectorizedSampler(BaseSampler):
     def _stepwise_rollout(self, policy, T):
         """Generic vectorised path: one policy.get_actions + one rl_vecenv_step launch per step."""
         v = self.vec_env
-        n, do, da = v.n, v.q["obs_dim"], v.q["act_dim"]
+        n, do, da = v.n, v.obs_rows, v.q["act_dim"]
         dev = v.device
         obs_p = torch.empty((do, T, n), dtype=torch.float32, device=dev)
         act_p = torch.empty((da, T, n), dtype=torch.float32, device=dev)

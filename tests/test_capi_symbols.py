@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.rl_abi_version() == 5
+    assert _lib.lib.rl_abi_version() == 6
 
 
 def test_env_query_and_errors():
@@ -44,18 +44,38 @@ def test_env_query_and_errors():
     assert list(lb) == [-50, -50] and list(ub) == [50, 50]
     assert _lib.lib.rl_env_query(99, None, None, None, None, None) == -1
     assert b"env kind 99" in _lib.lib.rl_last_error()
-    assert _lib.lib.rl_vecenv_reset(0, 0, None, None, None, None, 0, 0, 0, None, None) == -1
+    assert _lib.lib.rl_vecenv_reset(0, 0, None, None, None, None, 0, 0, 0, None, None, None) == -1
     assert _lib.lib.rl_gae(0, 0, None, None, None, 0.99, 1.0, None, None, None, None) == -1
     assert _lib.lib.rl_rollout_gaussian_mlp(None, None) == -1
     assert _lib.lib.rl_policy_fvp(None, None, None, 0, None, None) == -1
     assert _lib.lib.rl_policy_workspace_bytes(13, 2, 32, 32) > 0
 
 
+def test_env_default_cfg():
+    """rl_env_default_cfg: the reward coefficients / frame skips the reference's env constructors default to."""
+    from rllab_amd import _lib
+    want = {_lib.ENV_CARTPOLE: (0.0, 0.0, 1), _lib.ENV_DOUBLE_PENDULUM: (0.0, 0.0, 2),
+            _lib.ENV_SWIMMER: (1e-2, 0.0, 1), _lib.ENV_WALKER2D: (1e-2, 0.0, 1), _lib.ENV_HOPPER: (0.01, 1.0, 1)}
+    for kind, (cc, alive, fs) in want.items():
+        c = _lib.env_default_cfg(kind)
+        assert abs(c.ctrl_cost_coeff - cc) < 1e-9 and c.alive_coeff == alive and c.frame_skip == fs
+        assert c.action_noise == 0.0 and c.obs_noise == 0.0 and c.flags == 0
+        assert not c.action_noise_z and not c.obs_noise_z
+    c = _lib.env_default_cfg(_lib.ENV_SWIMMER, ctrl_cost_coeff=0.5, action_noise=0.1)
+    assert c.ctrl_cost_coeff == 0.5 and abs(c.action_noise - 0.1) < 1e-8
+    import pytest
+    with pytest.raises(TypeError):
+        _lib.env_default_cfg(_lib.ENV_SWIMMER, gravity=3.0)
+    assert _lib.lib.rl_env_default_cfg(99, ctypes.byref(_lib.EnvCfg())) == -1
+    assert _lib.lib.rl_vecenv_com(_lib.ENV_SWIMMER, 0, None, None, None) == -1
+
+
 def test_structs_match_header_layout():
     """ctypes mirrors have the field order / count of the C structs."""
     from rllab_amd import _lib
     text = open(os.path.join(ROOT, "include", "rllab_amd.h")).read()
-    for cname, cls in (("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch)):
+    for cname, cls in (("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch),
+                       ("rl_env_cfg", _lib.EnvCfg)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

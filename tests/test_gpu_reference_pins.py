@@ -108,7 +108,7 @@ def test_trpo_cartpole_iteration0_against_the_documented_log(quiet_logger):
     tabs = [_iteration0(seed, 4000) for seed in range(1, 9)]
     for t in tabs:
         assert abs(t["Entropy"] - 1.41894) < 1e-4 and abs(t["Perplexity"] - 4.13273) < 1e-3
-        assert abs(t["AveragePolicyStd"] - 1.0) < 1e-6 and t["ExplainedVariance"] == 0.0
+        assert abs(t["AveragePolicyStd"] - 1.0) < 1e-6 and abs(t["ExplainedVariance"]) < 1e-9
         assert 5e-4 < t["MeanKL"] <= 0.0101 and t["LossAfter"] < t["LossBefore"]
         assert 0 <= t["BacktrackItr"] <= 15
     avg = np.array([t["AverageReturn"] for t in tabs])

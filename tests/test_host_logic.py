@@ -284,10 +284,22 @@ def test_unsupported_options_fail_loudly():
     from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv
     from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
     from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    # options that name a different world / model have no kernel; the ones the kernels honour are accepted
     with pytest.raises(NotImplementedError):
-        CartpoleEnv(obs_noise=0.1)
+        CartpoleEnv(template_args=dict(noise=True))
     with pytest.raises(NotImplementedError):
-        SwimmerEnv(action_noise=0.1)
+        SwimmerEnv(file_path="/tmp/other.xml")
+    with pytest.raises(ValueError):
+        CartpoleEnv(obs_noise=-0.1)
+    env = CartpoleEnv(obs_noise=0.1, action_noise=0.05, frame_skip=2, position_only=True)
+    assert env.observation_space.flat_dim == 2 and env.frame_skip == 2 and env.obs_noise == 0.1
+    sw = SwimmerEnv(ctrl_cost_coeff=0.5, action_noise=0.1)
+    assert sw.ctrl_cost_coeff == 0.5 and sw._cfg["ctrl_cost_coeff"] == 0.5 and sw._cfg["action_noise"] == 0.1
+    import pickle
+    sw2 = pickle.loads(pickle.dumps(sw))                  # options survive the ctor-args pickle
+    assert sw2.ctrl_cost_coeff == 0.5 and sw2.action_noise == 0.1
+    cp = pickle.loads(pickle.dumps(CartpoleEnv(reset_pole_follows_cart=True, obs_noise=0.2)))
+    assert cp.reset_pole_follows_cart and cp._cfg["flags"] == 1 and cp.obs_noise == 0.2
     with pytest.raises(NotImplementedError):
         GaussianMLPPolicy(_spec(4, 1), adaptive_std=True)
     # NPO's default optimizer is the reference's PenaltyLbfgsOptimizer (npo.py:27-30)

@@ -42,7 +42,7 @@ def main():
         def launch():
             _lib.check(_lib.lib.rl_vecenv_step(
                 kind, n, 1, 1.0, 0, 1, _lib.ptr(v.state), _lib.ptr(v.ts), _lib.ptr(act), None, v.seed,
-                v.step_counter, 0, _lib.ptr(v._obs), _lib.ptr(v._reward), _lib.ptr(v._done), _lib.stream_ptr()),
+                v.step_counter, 0, None, _lib.ptr(v._obs), _lib.ptr(v._reward), _lib.ptr(v._done), _lib.stream_ptr()),
                 "rl_vecenv_step")
             v.step_counter += 1
         for _ in range(args.warmup):
