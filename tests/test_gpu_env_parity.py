@@ -245,10 +245,14 @@ def test_single_env_state_api():
     np.random.seed(9)
     sw.inject_action_noise(np.zeros(2))
     assert np.random.rand() == nxt                      # ... but the draw was made
+    # subtree COM / COM velocity of the torso come from rl_vecenv_com; other bodies are not exported
+    assert sw.get_body_comvel("torso").shape == (3,) and sw.get_body_comvel("torso")[2] == 0.0
+    hp = HopperEnv()
+    hp.reset()
+    com = hp.get_body_com("torso")
+    assert com.shape == (3,) and com[1] == 0.0 and 0.5 < com[2] < 1.5          # (x, 0, z): the hopper stands ~1 m tall
     with pytest.raises(NotImplementedError):
-        sw.get_body_comvel("torso")
-    with pytest.raises(NotImplementedError):
-        HopperEnv().get_body_com("torso")
+        sw.get_body_com("mid")
 
 
 def test_stepwise_rollout_through_a_hip_graph(quiet_logger):
