@@ -194,9 +194,11 @@ class HipVecEnv(object):
                                       "observation; sample through the per-transition path")
         T, n = int(horizon), self.n
         do, da = self.q["obs_dim"], self.q["act_dim"]
-        hs = tuple(policy.hidden_sizes)
-        if len(hs) != 2 or not policy.fusable:
-            raise NotImplementedError("fused rollout needs a 2-hidden-layer tanh GaussianMLPPolicy")
+        layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
+        if layout is None:
+            raise NotImplementedError("fused rollout needs a GaussianMLPPolicy with two tanh hidden layers of at "
+                                      "most 64 units (policies/kernel_layout.py)")
+        hs = (layout.H, layout.H)
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         obs = torch.empty((do, T, n), **f32)
@@ -204,7 +206,7 @@ class HipVecEnv(object):
         mean = torch.empty((da, T, n), **f32)
         rew = torch.empty((T, n), **f32)
         done = torch.empty((T, n), dtype=torch.uint8, device=dev)
-        theta = policy.flat_params.detach()
+        theta = layout.theta()              # the parameters in the kernels' layout (zero-padded hidden units)
         assert theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous()
         if eps is not None:
             eps = torch.as_tensor(eps, **f32).contiguous()

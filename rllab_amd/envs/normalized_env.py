@@ -4,10 +4,14 @@ For a HIP-native wrapped env the action map ``lb + (a+1)/2*(ub-lb)`` + clip and
 ``scale_reward`` are fused into the step kernel (``normalize`` / ``scale_reward``
 arguments of the C ABI); the numpy implementation below serves arbitrary Python
 envs exactly like the reference.  Running obs/reward normalisation
-(``normalize_obs`` / ``normalize_reward``, off by default) is a sequential EMA
-over a single env's stream and is only available on the numpy path.
+(``normalize_obs`` / ``normalize_reward``, off by default) is an exponential moving
+estimate over each env copy's own stream (the reference's VecEnvExecutor holds n
+pickled copies of the env, each with its own estimates,
+sandbox/rocky/tf/envs/vec_env_executor.py:8-14): on the vectorised path
+``NormalizingVecEnv`` keeps those estimates as [., n] device planes around the HIP executor.
 """
 import numpy as np
+import torch
 
 from rllab_amd import spaces
 from rllab_amd.core.serializable import Serializable
@@ -100,16 +104,86 @@ class NormalizedEnv(ProxyEnv, Serializable):
     # -- vectorised boundary: the affine action map and scale_reward are fused into the step kernels -------
     @property
     def vectorized(self):
-        return bool(getattr(self._wrapped_env, "vectorized", False)) and \
-            not (self._normalize_obs or self._normalize_reward)
+        return bool(getattr(self._wrapped_env, "vectorized", False))
 
     def vec_env_executor(self, n_envs, max_path_length, **kwargs):
         if not self.vectorized:
-            raise NotImplementedError("NormalizedEnv: wrapped env is not vectorized (or running "
-                                      "obs/reward normalisation is on)")
-        return self._wrapped_env.vec_env_executor(
-            n_envs=n_envs, max_path_length=max_path_length, normalize=True,
-            scale_reward=float(self._scale_reward), **kwargs)
+            raise NotImplementedError("NormalizedEnv: wrapped env is not vectorized")
+        if not (self._normalize_obs or self._normalize_reward):
+            return self._wrapped_env.vec_env_executor(
+                n_envs=n_envs, max_path_length=max_path_length, normalize=True,
+                scale_reward=float(self._scale_reward), **kwargs)
+        # running normalisation sits between the env's reward and scale_reward (:85-92): the kernel leaves the
+        # reward unscaled and the wrapper applies normalisation, then the scale
+        inner = self._wrapped_env.vec_env_executor(n_envs=n_envs, max_path_length=max_path_length, normalize=True,
+                                                   scale_reward=1.0, **kwargs)
+        return NormalizingVecEnv(inner, float(self._scale_reward), self._normalize_obs, self._normalize_reward,
+                                 self._obs_stats.alpha, self._reward_stats.alpha)
+
+
+class NormalizingVecEnv(object):
+    """The VecEnvExecutor surface over a HIP executor with NormalizedEnv's running estimates per env copy:
+        mean <- (1 - a) mean + a x;  var <- (1 - a) var + a (x - mean)^2     (normalized_env.py:33-49, float64)
+        obs -> (obs - mean) / (sqrt(var) + 1e-8);   reward -> reward / (sqrt(var_r) + 1e-8), then * scale_reward.
+    One update per returned observation: an env that finished inside ``step`` hands back its reset observation (the
+    executor contract), which is the one that is whitened -- the reference additionally feeds the discarded terminal
+    observation to the estimate.  Sampled through the per-transition loop (the fused rollout feeds the policy raw
+    observations)."""
+    graphable = False          # the sampler's hipGraph loop talks to the raw executor's buffers
+
+    def __init__(self, inner, scale_reward, normalize_obs, normalize_reward, obs_alpha, reward_alpha):
+        self.inner = inner
+        self.scale_reward_outer = float(scale_reward)
+        self.normalize_obs, self.normalize_reward = bool(normalize_obs), bool(normalize_reward)
+        self.obs_alpha, self.reward_alpha = float(obs_alpha), float(reward_alpha)
+        f64 = dict(dtype=torch.float64, device=inner.device)
+        self.obs_mean = torch.zeros((inner.obs_rows, inner.n), **f64)
+        self.obs_var = torch.ones((inner.obs_rows, inner.n), **f64)
+        self.reward_mean = torch.zeros(inner.n, **f64)
+        self.reward_var = torch.ones(inner.n, **f64)
+
+    def __getattr__(self, name):                      # n, q, device, obs_rows, max_path_length, position_ids, ...
+        if name == "inner":
+            raise AttributeError(name)
+        return getattr(self.inner, name)
+
+    @property
+    def num_envs(self):
+        return self.inner.n
+
+    def rollout(self, *args, **kwargs):
+        raise NotImplementedError("running obs / reward normalisation: sample through reset() / step()")
+
+    def _whiten(self, obs_n):
+        if not self.normalize_obs:
+            return obs_n
+        x = obs_n.t().to(torch.float64)
+        a = self.obs_alpha
+        self.obs_mean.mul_(1 - a).add_(x, alpha=a)
+        self.obs_var.mul_(1 - a).add_((x - self.obs_mean) ** 2, alpha=a)
+        return ((x - self.obs_mean) / (torch.sqrt(self.obs_var) + 1e-8)).t().to(torch.float32)
+
+    def reset(self, *args, **kwargs):
+        return self._whiten(self.inner.reset(*args, **kwargs))
+
+    def step(self, action_n, **kwargs):
+        is_np = not torch.is_tensor(action_n)
+        a = torch.as_tensor(np.asarray(action_n), device=self.inner.device) if is_np else action_n
+        obs, rew, done, info = self.inner.step(a, **kwargs)
+        obs = self._whiten(obs)
+        r = rew.to(torch.float64)
+        if self.normalize_reward:
+            al = self.reward_alpha
+            self.reward_mean.mul_(1 - al).add_(r, alpha=al)
+            self.reward_var.mul_(1 - al).add_((r - self.reward_mean) ** 2, alpha=al)
+            r = r / (torch.sqrt(self.reward_var) + 1e-8)
+        r = (r * self.scale_reward_outer).to(torch.float32)
+        if is_np:
+            return (obs.cpu().numpy().astype(np.float64), r.cpu().numpy().astype(np.float64), done.cpu().numpy(), info)
+        return obs, r, done, info
+
+    def terminate(self):
+        self.inner.terminate()
 
 
 normalize = NormalizedEnv

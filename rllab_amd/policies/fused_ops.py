@@ -18,21 +18,33 @@ from rllab_amd.sampler import dist as D
 class FusedGaussianMLPOps(object):
     def __init__(self, policy):
         self.policy = policy
-        hs = tuple(policy.hidden_sizes)
-        assert len(hs) == 2 and policy.fusable
-        self.dims = (policy.obs_dim, policy.action_dim, hs[0], hs[1])
+        self.layout = policy.kernel_layout()
+        assert self.layout is not None
+        # what the kernels are told: the padded hidden width (policies/kernel_layout.py); P_pad parameters
+        self.dims = (policy.obs_dim, policy.action_dim, self.layout.H, self.layout.H)
+        self.n_kernel = self.layout.P_pad
         self._ws = None
         self._loss_cache = None
         self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
         self._acts = None    # hidden-activation cache the gradient pass fills for the FVP passes
         self._acts_tag = None
-        self._epoch = 0      # parameter updates written by our own kernels (see _eval_point)
+
+    # parameter updates written by our own kernels straight into the parameter vector (see _eval_point): kept on the
+    # policy, because the rollout's padded parameter copy must notice them too
+    @property
+    def _epoch(self):
+        return getattr(self.policy, "_raw_writes", 0)
+
+    @_epoch.setter
+    def _epoch(self, value):
+        self.policy._raw_writes = value
 
     @staticmethod
     def supported(policy):
-        hs = tuple(getattr(policy, "hidden_sizes", ()))
-        return (getattr(policy, "fusable", False) and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (32, 64)
-                and policy.flat_params.is_cuda and policy.learn_std
+        """Two tanh hidden layers of at most 64 units each (zero-padded to the kernels' tiles), learned
+        state-independent std, one of the (obs_dim, action_dim) pairs the kernels are instantiated for -- the
+        HIP-native envs' -- and parameters on the device."""
+        return (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None and policy.learn_std
                 and (policy.obs_dim, policy.action_dim) in ((4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6)))
 
     def accepts(self, inputs):
@@ -49,15 +61,16 @@ class FusedGaussianMLPOps(object):
         """The C-ABI batch descriptor of an input tuple.  Built once per tuple (one update uses
         the same tuple for ~30 passes): contiguity fix-ups, pointer extraction and the one
         host read of 1/W happen here, not per pass."""
+        self.layout.theta()                 # bring the kernels' copy of the parameters up to date (no-op if current)
         key = tuple(id(t) for t in inputs)
         hit = self._bound.get(key)
         if hit is not None:
             return hit
         obs, act, adv, old_mean, old_log_std, w, inv_count = inputs
-        theta = self.policy.flat_params.detach()
+        theta = self.layout.theta()          # kernel layout; a persistent buffer, refreshed in place (_refresh)
         keep = [t.contiguous() for t in (obs, act, adv, old_mean, old_log_std.reshape(-1).float(), w, theta)]
         obs, act, adv, old_mean, old_ls, w, theta = keep
-        assert theta.data_ptr() == self.policy.flat_params.data_ptr()   # updates are in place
+        assert theta.data_ptr() == self.layout.theta().data_ptr()       # updates are in place
         pol = self.policy
         inv = float(inv_count)
         b = _lib.PolicyBatch(
@@ -155,7 +168,7 @@ class FusedGaussianMLPOps(object):
         that belongs to this point costs no pass of its own."""
         b, keep, inv = self._batch(inputs)
         ws = self._workspace(keep[0].device)
-        out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
+        out = torch.empty(self.n_kernel, dtype=torch.float64, device=keep[0].device)
         self._acts_tag = None
         b.activations = None
         if keep_activations and not vpg:
@@ -179,7 +192,7 @@ class FusedGaussianMLPOps(object):
                 self._acts_tag = tag
         finally:
             b.activations = None
-        return D.all_reduce_sum_(out)
+        return D.all_reduce_sum_(self.layout.unpack(out))
 
     def _fvp_into(self, b, ws, vec32, out, inputs=None):
         cached = inputs is not None and self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
@@ -194,21 +207,22 @@ class FusedGaussianMLPOps(object):
     def fvp(self, inputs, vec):
         b, keep, _ = self._batch(inputs)
         ws = self._workspace(keep[0].device)
-        v = vec.to(torch.float32).contiguous()
-        out = torch.empty(self.policy.flat_params.numel(), dtype=torch.float64, device=keep[0].device)
-        return self._fvp_into(b, ws, v, out, inputs)
+        v = self.layout.pack(vec.to(torch.float32)).contiguous()
+        out = torch.empty(self.n_kernel, dtype=torch.float64, device=keep[0].device)
+        return self.layout.unpack(self._fvp_into(b, ws, v, out, inputs))
 
     def cg(self, inputs, g, cg_iters, reg_coeff, residual_tol=1e-10):
         """krylov.cg (rllab/misc/krylov.py:7-39) on Hx = F x + reg_coeff x with the vector algebra of
         each iteration in ONE launch (rl_cg_step) between the Fisher-vector-product passes: two
         kernels + one all-reduce per iteration, no host synchronisation.
-        Returns (x, x^T H x) as float64 device tensors."""
+        Returns (x, x^T H x) as float64 device tensors.  Runs in the kernels' (zero-padded) parameter space:
+        padded entries of g are 0 and stay 0 in every iterate."""
         b, keep, _ = self._batch(inputs)
         dev = keep[0].device
         ws = self._workspace(dev)
-        n = self.policy.flat_params.numel()
+        n = self.n_kernel
         f64 = dict(dtype=torch.float64, device=dev)
-        g = g.to(torch.float64).contiguous()
+        g = self.layout.pack(g.to(torch.float64)).contiguous()
         x, r, p, z = (torch.empty(n, **f64) for _ in range(4))
         p32 = torch.empty(n, dtype=torch.float32, device=dev)
         scal = torch.empty(4, **f64)
@@ -224,7 +238,7 @@ class FusedGaussianMLPOps(object):
         x32 = x.to(torch.float32)
         self._fvp_into(b, ws, x32, z, inputs)
         xHx = x.dot(z + float(reg_coeff) * x)
-        return x, xHx
+        return self.layout.unpack(x), xHx
 
     def cg_step_vector(self, inputs, g, cg_iters, reg_coeff, max_constraint, residual_tol=1e-10,
                        reuse_cg_residual=True):
@@ -236,9 +250,9 @@ class FusedGaussianMLPOps(object):
         b, keep, _ = self._batch(inputs)
         dev = keep[0].device
         ws = self._workspace(dev)
-        n = self.policy.flat_params.numel()
+        n = self.n_kernel
         f64 = dict(dtype=torch.float64, device=dev)
-        g = g.to(torch.float64).contiguous()
+        g = self.layout.pack(g.to(torch.float64)).contiguous()
         x, r, p, z, step = (torch.empty(n, **f64) for _ in range(5))
         p32 = torch.empty(n, dtype=torch.float32, device=dev)
         scal = torch.empty(4, **f64)
@@ -260,7 +274,7 @@ class FusedGaussianMLPOps(object):
             _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(z), None, float(reg_coeff),
                                              float(max_constraint), _lib.ptr(step), _lib.ptr(stats), st),
                        "rl_trpo_step")
-        return step, stats
+        return self.layout.unpack(step), stats
 
     def line_search_point(self, prev32, step, ratio):
         """theta <- (float)(prev - ratio * step), written in place into the policy's parameter vector."""

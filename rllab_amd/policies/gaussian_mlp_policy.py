@@ -12,6 +12,7 @@ read.  Initialisation follows the reference: Glorot-uniform W
 import numpy as np
 import torch
 
+from rllab_amd.core.network import MLP
 from rllab_amd.core.parameterized import Param
 from rllab_amd.core.serializable import Serializable
 from rllab_amd.distributions.diagonal_gaussian import DiagonalGaussian
@@ -35,45 +36,60 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
                  dist_cls=DiagonalGaussian):
         Serializable.quick_init(self, locals())
         assert isinstance(env_spec.action_space, Box)
-        if adaptive_std or std_network is not None or mean_network is not None:
-            raise NotImplementedError("GaussianMLPPolicy: adaptive_std / custom networks are outside "
-                                      "the hot path built here (SURVEY.md section 8)")
         StochasticPolicy.__init__(self, env_spec)
         obs_dim = env_spec.observation_space.flat_dim
         action_dim = env_spec.action_space.flat_dim
         self.obs_dim, self.action_dim = obs_dim, action_dim
-        self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
-        self.hidden_nonlinearity = hidden_nonlinearity
-        self.output_nonlinearity = output_nonlinearity
         self.learn_std = learn_std
         self.min_std = min_std
         self._dist = dist_cls(action_dim)
 
-        sizes = (obs_dim,) + self.hidden_sizes + (action_dim,)
-        params, off = [], 0
-        n_layers = len(sizes) - 1
-        for li in range(n_layers):
-            lname = "output" if li == n_layers - 1 else "hidden_%d" % li
-            w = Param("%s.W" % lname, (sizes[li], sizes[li + 1]), off)
-            off += w.size
-            b = Param("%s.b" % lname, (sizes[li + 1],), off, regularizable=False)
-            off += b.size
-            params += [w, b]
-        ls = Param("output_log_std.param", (action_dim,), off, trainable=learn_std, regularizable=False)
-        off += ls.size
-        params.append(ls)
+        # mean network (reference :60-69); a custom ``mean_network`` is an MLP description (core/network.py) whose
+        # layer sizes / nonlinearities are taken over -- its parameters are re-created in this policy's flat vector
+        if mean_network is not None:
+            assert mean_network.input_dim == obs_dim and mean_network.output_dim == action_dim
+            hidden_sizes, hidden_nonlinearity = mean_network.hidden_sizes, mean_network.hidden_nonlinearity
+            output_nonlinearity = mean_network.output_nonlinearity
+        self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
+        self.hidden_nonlinearity = hidden_nonlinearity
+        self.output_nonlinearity = output_nonlinearity
+        self._mean_network = MLP((obs_dim,), action_dim, self.hidden_sizes, hidden_nonlinearity, output_nonlinearity,
+                                 offset=0)
+        params = list(self._mean_network.params)
+        off = self._mean_network.end_offset
+        # log-std head (:73-92): a network of its own on the same input (adaptive_std / std_network), or one free
+        # row.  ``std_share_network`` is accepted and, as in the reference's constructor body, has no effect.
+        self._std_network = None
+        self._log_std_param = None
+        if std_network is not None or adaptive_std:
+            if std_network is not None:
+                assert std_network.input_dim == obs_dim and std_network.output_dim == action_dim
+                std_hidden_sizes, std_hidden_nonlinearity = std_network.hidden_sizes, std_network.hidden_nonlinearity
+                std_out = std_network.output_nonlinearity
+            else:
+                std_out = None
+            self._std_network = MLP((obs_dim,), action_dim, tuple(std_hidden_sizes), std_hidden_nonlinearity, std_out,
+                                    name="std", offset=off)
+            params += self._std_network.params
+            off = self._std_network.end_offset
+        else:
+            ls = Param("output_log_std.param", (action_dim,), off, trainable=learn_std, regularizable=False)
+            off += ls.size
+            params.append(ls)
+            self._log_std_param = ls
         self._params = params
-        self._log_std_param = ls
         for p in params:
             p._owner = self
 
-        # host-side init with np.random (so CPU oracle and GPU share theta under a seed)
+        # host-side init with np.random (so CPU oracle and GPU share theta under a seed): Glorot-uniform weights,
+        # zero biases (network.py:38-39), log_std row = log(init_std) (:88-94)
         flat = np.zeros(off, dtype=np.float32)
-        for li in range(n_layers):
-            w = params[2 * li]
-            bound = np.sqrt(6.0 / (w.shape[0] + w.shape[1]))
-            flat[w.offset:w.offset + w.size] = np.random.uniform(-bound, bound, size=w.shape).reshape(-1)
-        flat[ls.offset:ls.offset + ls.size] = np.log(init_std)
+        self._mean_network.init_values(flat)
+        if self._std_network is not None:
+            self._std_network.init_values(flat)
+        else:
+            ls = self._log_std_param
+            flat[ls.offset:ls.offset + ls.size] = np.log(init_std)
         self.flat_params = torch.tensor(flat, dtype=torch.float32, device=_default_device())
 
     # -- Parameterized ----------------------------------------------------------
@@ -82,15 +98,44 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
 
     # -- forward ------------------------------------------------------------------
     @property
+    def state_dependent_std(self):
+        """True with a log-std network (adaptive_std / std_network): agent_info["log_std"] then varies per sample."""
+        return self._std_network is not None
+
+    @property
     def fusable(self):
-        """True when the in-kernel MLP (tanh hidden, linear output) matches this policy."""
-        return self.hidden_nonlinearity is tanh and self.output_nonlinearity is None
+        """True when the in-kernel policy (tanh hidden layers, linear output, one free log_std row) is this policy."""
+        return (self.hidden_nonlinearity is tanh and self.output_nonlinearity is None
+                and not self.state_dependent_std)
 
     @property
     def vectorized(self):
         return True
 
+    # -- what the HIP kernels read ---------------------------------------------------------------------------------
+    def param_version(self):
+        """Changes whenever the parameters do: torch's in-place version counter plus the writes our own kernels
+        make through raw pointers (rl_line_search_point, rl_adam_step), which torch cannot see."""
+        return (self.flat_params._version, getattr(self, "_raw_writes", 0))
+
+    def note_raw_write(self):
+        self._raw_writes = getattr(self, "_raw_writes", 0) + 1
+
+    def kernel_layout(self):
+        """``KernelLayout`` (policies/kernel_layout.py) when the fused kernels can run this policy -- two tanh
+        hidden layers of at most 64 units (zero-padded to the kernels' 32 / 64 tiles), linear output, learned
+        state-independent std, float32 parameters on the device -- else None."""
+        if not hasattr(self, "_kernel_layout"):
+            from rllab_amd.policies.kernel_layout import KernelLayout, tile_for
+            ok = (self.fusable and tile_for(self.hidden_sizes) is not None and self.flat_params.is_cuda
+                  and self.flat_params.dtype == torch.float32)
+            self._kernel_layout = KernelLayout(self) if ok else None
+        return self._kernel_layout
+
     def effective_log_std(self, flat=None):
+        if self._log_std_param is None:
+            raise AttributeError("this policy's log_std depends on the observation (adaptive_std): use "
+                                 "log_std_planes(obs) / dist_info_planes(obs)")
         flat = self.flat_params if flat is None else flat
         ls = self._log_std_param.view(flat)
         if self.min_std is not None:
@@ -101,31 +146,35 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
         """The log_std row a rollout records as agent_info (the "old" distribution of the update): always a
         COPY -- with ``min_std=None`` ``effective_log_std`` is a view into ``flat_params``, and the line search /
         Adam step rewrite that vector in place, which would make old and new log_std the same tensor."""
+        if self.state_dependent_std:
+            return None                      # per-sample log_std planes are recorded instead (sampler)
         return self.effective_log_std().detach().clone()
 
     def mean_planes(self, obs_planes, flat=None):
         """obs [Do, B] -> mean [Da, B] ("planes": feature axis first, the engine's layout)."""
         flat = self.flat_params if flat is None else flat
-        h = obs_planes
-        n_layers = len(self._params) // 2
-        for li in range(n_layers):
-            W = self._params[2 * li].view(flat)
-            b = self._params[2 * li + 1].view(flat)
-            h = W.t() @ h + b[:, None]
-            if li < n_layers - 1:
-                h = self.hidden_nonlinearity(h)
-            elif self.output_nonlinearity is not None:
-                h = self.output_nonlinearity(h)
-        return h
+        return self._mean_network.forward_planes(obs_planes, flat)
+
+    def log_std_planes(self, obs_planes, flat=None):
+        """obs [Do, B] -> log_std [Da, B] (a broadcastable [Da, 1] column when the std is state independent),
+        floored at log(min_std) (reference :100-101,120-121)."""
+        flat = self.flat_params if flat is None else flat
+        if self._std_network is None:
+            return self.effective_log_std(flat)[:, None]
+        ls = self._std_network.forward_planes(obs_planes, flat)
+        if self.min_std is not None:
+            ls = ls.clamp_min(float(np.log(self.min_std)))
+        return ls
 
     def dist_info_planes(self, obs_planes, flat=None):
-        return dict(mean=self.mean_planes(obs_planes, flat), log_std=self.effective_log_std(flat)[:, None])
+        return dict(mean=self.mean_planes(obs_planes, flat), log_std=self.log_std_planes(obs_planes, flat))
 
     def dist_info_sym(self, obs_var, state_info_vars=None):
         """[B, Do] tensor -> dict(mean [B, Da], log_std [B, Da]) (reference :118-122)."""
         obs_var = torch.as_tensor(obs_var, dtype=self.flat_params.dtype, device=self.flat_params.device)
-        mean = self.mean_planes(obs_var.t()).t()
-        log_std = self.effective_log_std().unsqueeze(0).expand_as(mean)
+        planes = obs_var.t()
+        mean = self.mean_planes(planes).t()
+        log_std = self.log_std_planes(planes).t().expand_as(mean)
         return dict(mean=mean, log_std=log_std)
 
     def dist_info(self, obs, state_infos=None):
@@ -171,6 +220,16 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
         if traj is not None and getattr(traj, "log_std_host", None) is not None:
             # the row the rollout recorded, already on the host (read with the batch statistics)
             logger.record_tabular('AveragePolicyStd', float(np.mean(np.exp(traj.log_std_host))))
+            return
+        if traj is not None and getattr(traj, "log_std_planes", None) is not None:
+            w = traj.valid.to(torch.float64) if getattr(traj, "valid", None) is not None else None
+            e = torch.exp(traj.log_std_planes.double())
+            val = float(e.mean()) if w is None else float((e * w).sum() / (w.sum() * e.shape[0]).clamp_min(1.0))
+            logger.record_tabular('AveragePolicyStd', val)
+            return
+        if self.state_dependent_std:
+            log_stds = np.vstack([path["agent_infos"]["log_std"] for path in paths])
+            logger.record_tabular('AveragePolicyStd', float(np.mean(np.exp(log_stds))))
             return
         ls = self.effective_log_std().detach()
         logger.record_tabular('AveragePolicyStd', float(torch.exp(ls.double()).mean()))

@@ -66,10 +66,12 @@ class VectorizedSampler(BaseSampler):
         policy = algo.policy
         T = algo.max_path_length
         t_start = time.time()
-        if getattr(policy, "fusable", False) and len(getattr(policy, "hidden_sizes", ())) == 2 \
-                and tuple(policy.hidden_sizes) in ((32, 32), (64, 64)) and self.vec_env.position_ids is None:
+        graphable = getattr(self.vec_env, "graphable", True)
+        if hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None \
+                and self.vec_env.position_ids is None and graphable:
             traj = self.vec_env.rollout(policy, T, reset_at_start=True)
-        elif self.use_graph and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "recorded_log_std"):
+        elif self.use_graph and graphable and not os.environ.get("RLLAB_NO_GRAPH") \
+                and hasattr(policy, "recorded_log_std"):
             try:
                 traj = self._stepwise_rollout_graph(policy, T)
             except RuntimeError as err:
@@ -107,6 +109,8 @@ class VectorizedSampler(BaseSampler):
                   mean_p=torch.empty((da, T, n), **f32), rew_p=torch.empty((T, n), **f32),
                   done_p=torch.empty((T, n), dtype=torch.uint8, device=dev),
                   a_planes=torch.zeros((da, n), **f32),
+                  # agent_info["log_std"] per sample: only a policy with a log-std network needs the planes
+                  ls_p=torch.empty((da, T, n), **f32) if getattr(policy, "state_dependent_std", False) else None,
                   t_idx=torch.zeros(1, dtype=torch.int64, device=dev),
                   counter=torch.zeros(1, dtype=torch.int64, device=dev))
 
@@ -117,6 +121,8 @@ class VectorizedSampler(BaseSampler):
             st["a_planes"].copy_(actions.t())
             st["act_p"].index_copy_(1, st["t_idx"], st["a_planes"].unsqueeze(1))
             st["mean_p"].index_copy_(1, st["t_idx"], info["mean"].t().unsqueeze(1))
+            if st["ls_p"] is not None:
+                st["ls_p"].index_copy_(1, st["t_idx"], info["log_std"].t().unsqueeze(1))
             _lib.check(_lib.lib.rl_vecenv_step_graph(
                 v.kind, n, int(v.normalize), v.scale_reward, v.max_path_length, int(v.auto_reset),
                 _lib.ptr(v.state), _lib.ptr(v.ts), _lib.ptr(st["a_planes"]), v.seed, _lib.ptr(st["counter"]),
@@ -158,7 +164,7 @@ class VectorizedSampler(BaseSampler):
         # the planes belong to the graph: hand out copies, as the eager path hands out fresh tensors
         return Trajectories(st["obs_p"].clone(), st["act_p"].clone(), st["mean_p"].clone(),
                             policy.recorded_log_std(), st["rew_p"].clone(), st["done_p"].clone(),
-                            v.max_path_length)
+                            v.max_path_length, log_std_planes=None if st["ls_p"] is None else st["ls_p"].clone())
 
     def _stepwise_rollout(self, policy, T):
         """Generic vectorised path: one policy.get_actions + one rl_vecenv_step launch per step."""
@@ -170,14 +176,18 @@ class VectorizedSampler(BaseSampler):
         mean_p = torch.empty((da, T, n), dtype=torch.float32, device=dev)
         rew_p = torch.empty((T, n), dtype=torch.float32, device=dev)
         done_p = torch.empty((T, n), dtype=torch.uint8, device=dev)
+        ls_p = torch.empty((da, T, n), dtype=torch.float32, device=dev) \
+            if getattr(policy, "state_dependent_std", False) else None
         obs = v.reset()
         for t in range(T):
             obs_p[:, t, :] = obs.t()
             actions, info = policy.get_actions(obs)
             act_p[:, t, :] = actions.t()
             mean_p[:, t, :] = info["mean"].t()
+            if ls_p is not None:
+                ls_p[:, t, :] = info["log_std"].t()
             obs, rew, done, _ = v.step(actions)
             rew_p[t] = rew
             done_p[t] = done.to(torch.uint8)
         return Trajectories(obs_p, act_p, mean_p, policy.recorded_log_std(), rew_p, done_p,
-                            v.max_path_length)
+                            v.max_path_length, log_std_planes=ls_p)

@@ -138,3 +138,85 @@ def test_collective_accounting_is_a_noop_without_a_process_group():
     D.broadcast_(t)
     assert D.all_gather_rows(t).shape == (1, 3)
     assert D.accounting()["count"] == 0 and D.world_size() == 1 and D.backend() is None
+
+
+def test_kernel_layout_zero_padding_is_exact():
+    """policies/kernel_layout.py: a (h0, h1) policy presented to the H-wide kernels by zero padding computes the same
+    mean (padded units are tanh(0) = 0 and feed nothing), pack / unpack are inverse on the real entries."""
+    from rllab_amd.policies.kernel_layout import KernelLayout, tile_for
+    assert tile_for((32, 32)) == 32 and tile_for((16, 8)) == 32 and tile_for((50, 25)) == 64
+    assert tile_for((64, 64)) == 64 and tile_for((65, 8)) is None and tile_for((32,)) is None
+    for hs in [(16, 16), (50, 25), (7, 64), (32, 32)]:
+        pol = _cpu_policy(do=5, da=2, h=8)
+        from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+        np.random.seed(1)
+        pol = GaussianMLPPolicy(pol.env_spec if hasattr(pol, "env_spec") else pol._env_spec, hidden_sizes=hs)
+        lay = KernelLayout(pol)
+        H = lay.H
+        theta = lay.theta()
+        assert theta.numel() == 5 * H + H + H * H + H + H * 2 + 4
+        if lay.exact:
+            assert theta.data_ptr() == pol.flat_params.data_ptr()
+            continue
+        # forward pass of the padded net with plain torch == the policy's own
+        o = 0
+        W0 = theta[o:o + 5 * H].view(5, H); o += 5 * H
+        b0 = theta[o:o + H]; o += H
+        W1 = theta[o:o + H * H].view(H, H); o += H * H
+        b1 = theta[o:o + H]; o += H
+        W2 = theta[o:o + H * 2].view(H, 2); o += H * 2
+        b2 = theta[o:o + 2]; o += 2
+        ls = theta[o:o + 2]
+        x = torch.randn(5, 11)
+        h = torch.tanh(W1.t() @ torch.tanh(W0.t() @ x + b0[:, None]) + b1[:, None])
+        assert torch.allclose(W2.t() @ h + b2[:, None], pol.mean_planes(x), atol=1e-6)
+        assert torch.equal(ls, pol.effective_log_std())
+        assert int((theta != 0).sum()) <= pol.flat_params.numel()
+        v = torch.randn(pol.flat_params.numel(), dtype=torch.float64)
+        assert torch.equal(lay.unpack(lay.pack(v)), v) and lay.pack(v).numel() == lay.P_pad
+        # the padded copy follows in-place parameter updates
+        with torch.no_grad():
+            pol.flat_params.mul_(2.0)
+        assert torch.equal(lay.unpack(lay.theta()), pol.flat_params)
+        pol.note_raw_write()
+        assert lay.theta() is lay._theta
+
+
+def test_adaptive_std_policy_forward_layout_and_pickle():
+    """GaussianMLPPolicy(adaptive_std=True): log_std = a second MLP on the observation, floored at log(min_std)
+    (gaussian_mlp_policy.py:73-101); parameters = mean network then std network in Lasagne order; the reference's
+    regression test constructs exactly this (tests/regression_tests/test_issue_3.py:12-29)."""
+    import pickle
+    from rllab_amd.core.network import MLP, rectify
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    np.random.seed(3)
+    spec = EnvSpec(Box(-np.ones(4), np.ones(4)), Box(-np.ones(2), np.ones(2)))
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(8, 6), adaptive_std=True, std_hidden_sizes=(5,), min_std=0.5,
+                            std_share_network=True)
+    assert pol.state_dependent_std and not pol.fusable and pol.kernel_layout() is None
+    shapes = pol.get_param_shapes()
+    assert shapes == [(4, 8), (8,), (8, 6), (6,), (6, 2), (2,), (4, 5), (5,), (5, 2), (2,)]
+    theta = pol.get_param_values()
+    parts = pol.flat_to_params(theta)
+    obs = np.random.randn(7, 4)
+    h = np.tanh(np.tanh(obs @ parts[0] + parts[1]) @ parts[2] + parts[3])
+    mean = h @ parts[4] + parts[5]
+    ls = np.maximum(np.tanh(obs @ parts[6] + parts[7]) @ parts[8] + parts[9], np.log(0.5))
+    d = pol.dist_info(obs)
+    np.testing.assert_allclose(d["mean"], mean, atol=1e-5)
+    np.testing.assert_allclose(d["log_std"], ls, atol=1e-5)
+    assert (d["log_std"] >= np.log(0.5) - 1e-7).all()
+    a, info = pol.get_action(obs[0])
+    assert a.shape == (2,) and info["log_std"].shape == (2,)
+    acts, infos = pol.get_actions(obs)
+    assert acts.shape == (7, 2) and infos["log_std"].shape == (7, 2)
+    with pytest.raises(AttributeError):
+        pol.effective_log_std()
+    pol2 = pickle.loads(pickle.dumps(pol))
+    assert np.array_equal(pol2.get_param_values(), theta) and pol2.state_dependent_std
+    # custom networks: MLP descriptions whose layer sizes / nonlinearities are taken over
+    pol3 = GaussianMLPPolicy(spec, mean_network=MLP((4,), 2, (9,), rectify), std_network=MLP((4,), 2, (3, 3), torch.tanh))
+    assert pol3.hidden_sizes == (9,) and pol3.get_param_shapes()[-4:] == [(3, 3), (3,), (3, 2), (2,)]
+    assert not pol3.fusable
