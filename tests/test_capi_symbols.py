@@ -100,3 +100,24 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or '#include "../../oracle' in src:
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_integration_md_bindings_match_the_library():
+    """Every ``lib.rl_*.argtypes = [...]`` a maintainer would copy out of INTEGRATION.md has the argument count and
+    types ``rllab_amd/_lib.py`` binds (which test_structs / the GPU tests exercise against the real library)."""
+    from rllab_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    short = {"vp": ctypes.c_void_p, "i32": ctypes.c_int, "u64": ctypes.c_uint64, "f32": ctypes.c_float,
+             "f64": ctypes.c_double, "sz": ctypes.c_size_t, "u32": ctypes.c_uint32,
+             "cfgp": ctypes.POINTER(_lib.EnvCfg), "pb": ctypes.POINTER(_lib.PolicyBatch),
+             "ctypes.POINTER(RolloutArgs)": ctypes.POINTER(_lib.RolloutArgs),
+             "ip": ctypes.POINTER(ctypes.c_int), "fp": ctypes.POINTER(ctypes.c_float)}
+    found = re.findall(r"^\s*lib\.(rl_\w+)\.argtypes\s*= \[([^\]]*)\]", text, flags=re.M)
+    assert len(found) >= 15
+    for fn, args in found:
+        toks = [a.strip() for a in args.split(",") if a.strip()]
+        want = list(getattr(_lib.lib, fn).argtypes)
+        assert len(toks) == len(want), "%s: INTEGRATION.md lists %d arguments, the ABI has %d" % (fn, len(toks), len(want))
+        for k, (t, w) in enumerate(zip(toks, want)):
+            assert short[t] is w, "%s argument %d: INTEGRATION.md says %s, the binding is %s" % (fn, k, t, w)
+    assert "rl_abi_version() == %d" % _lib.lib.rl_abi_version() in text

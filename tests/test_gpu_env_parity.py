@@ -256,7 +256,7 @@ def test_single_env_state_api():
 
 
 def test_stepwise_rollout_through_a_hip_graph(quiet_logger):
-    """A policy without a fused rollout (hidden sizes the kernels are not built for) is sampled one transition at
+    """A policy without a fused rollout (an architecture the kernels are not built for) is sampled one transition at
     a time; that loop is captured into a hipGraph and replayed.  The recorded batch must be a valid rollout: env
     dynamics replay bit-exactly on the host, recorded means are the policy's, the noise is fresh in every step and
     every call, episodes reset with fresh draws, and it agrees in distribution with the eager loop."""
@@ -271,7 +271,8 @@ def test_stepwise_rollout_through_a_hip_graph(quiet_logger):
     ext.set_seed(3)
     torch.manual_seed(3)
     env = normalize(CartpoleEnv())
-    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(16, 16))        # no fused kernel for (16, 16)
+    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(16, 16, 16))    # three layers: no fused kernel
+    assert pol.kernel_layout() is None
     n, T = 512, 60
     algo = TRPO(env=env, policy=pol, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=n * T,
                 max_path_length=T, n_itr=1, sampler_args=dict(n_envs=n, seed=3))

@@ -26,7 +26,10 @@ def _free_port():
     return port
 
 
-def _run(n_envs, n_itr=2, env_name="swimmer"):
+def _run(n_envs, n_itr=2, env_name="swimmer", pinned=False):
+    """``pinned``: one CG iteration and a single line-search candidate (max_backtracks=1, accept_violation) -- the
+    update then is a smooth function of the all-reduced sums (no ill-conditioned 10-step Krylov recursion, no
+    discrete 0.8x choice), so the sharded run must reproduce the single-process PARAMETERS to summation order."""
     from rllab_amd.algos.trpo import TRPO
     from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
     from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv
@@ -42,8 +45,9 @@ def _run(n_envs, n_itr=2, env_name="swimmer"):
     D.broadcast_(policy.flat_params)
     baseline = LinearFeatureBaseline(env_spec=env.spec)
     T = 40
+    opt_args = dict(cg_iters=1, max_backtracks=1, accept_violation=True) if pinned else None
     algo = TRPO(env=env, policy=policy, baseline=baseline, batch_size=n_envs * T, max_path_length=T, n_itr=n_itr,
-                discount=0.99, step_size=0.01, sampler_args=dict(n_envs=n_envs, seed=17))
+                discount=0.99, step_size=0.01, sampler_args=dict(n_envs=n_envs, seed=17), optimizer_args=opt_args)
     algo.start_worker()
     algo.init_opt()
     stats = []
@@ -71,6 +75,9 @@ def _run(n_envs, n_itr=2, env_name="swimmer"):
 def _worker(rank, world, port, outdir, env_name):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    theta_p, stats_p, _, _ = _run(64, n_itr=3, env_name=env_name, pinned=True)
+    np.save(os.path.join(outdir, "theta_pinned_%d.npy" % rank), theta_p)
+    np.save(os.path.join(outdir, "stats_pinned_%d.npy" % rank), stats_p)
     theta, stats, coef, probes = _run(64, env_name=env_name)
     np.save(os.path.join(outdir, "probes_%d.npy" % rank), probes)
     np.save(os.path.join(outdir, "theta_%d.npy" % rank), theta)
@@ -114,6 +121,16 @@ def test_two_ranks_on_the_kernels_equal_one_process(tmp_path, env_name):
     theta_init = _initial_theta(env_name)
     step = np.abs(want_theta - theta_init).max()
     assert step > 0 and np.abs(t0 - want_theta).max() <= 0.75 * step
+    # pinned control flow (cg_iters=1, one line-search candidate): THREE iterations of the sharded run reproduce the
+    # single-process parameters and every logged number to the f32 summation order of the batch partition
+    want_tp, want_sp, _, _ = _run(128, n_itr=3, env_name=env_name, pinned=True)
+    tp0, tp1 = (np.load(str(tmp_path / ("theta_pinned_%d.npy" % r))) for r in range(2))
+    sp0 = np.load(str(tmp_path / "stats_pinned_0.npy"))
+    assert np.array_equal(tp0, tp1)
+    moved = np.abs(want_tp - theta_init).max()
+    assert moved > 0 and np.abs(tp0 - want_tp).max() <= 2e-3 * moved, (np.abs(tp0 - want_tp).max(), moved)
+    assert np.allclose(sp0[0], want_sp[0], rtol=2e-4, atol=1e-7), (sp0[0], want_sp[0])
+    assert np.allclose(sp0[:, :n_samp], want_sp[:, :n_samp], rtol=5e-3, atol=1e-4), (sp0, want_sp)
 
 
 def _initial_theta(env_name):
