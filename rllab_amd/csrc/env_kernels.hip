@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
         ts = 0;
     }
     float o[Env::OBS];
+    float zq[Env::ACT] = {};      // policy noise of four steps, one step per replica group (lane-group shapes)
     Env::template observe<float>(s, o);
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
@@ -493,6 +494,16 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
+        } else if constexpr (EPW == 16) {
+            // the four replicas of an env draw the noise of FOUR consecutive steps at once -- replica g that of step
+            // t + g, the same Philox block (seed; env, step, POLICY) the one-draw-per-step form evaluates -- and
+            // every step fetches its row from the replica that holds it: a quarter of the integer multiplies and
+            // transcendentals of the draw per env-step
+            if ((t & 3) == 0)
+                philox_draws<Env::ACT, true>(zq, a.seed, env_global, a.step_counter + (uint64_t)(t + (lane >> 4)),
+                                             RNG_POLICY);
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) z[k] = __shfl(zq[k], (lane & 15) + 16 * (t & 3), 64);
         } else {
             philox_draws<Env::ACT, true>(z, a.seed, env_global, a.step_counter + (uint64_t)t, RNG_POLICY);
         }
@@ -586,6 +597,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
         ts = 0;
     }
     float o[Env::OBS];
+    float zq[Env::ACT] = {};      // policy noise of four steps, one step per replica group (lane-group shapes)
     Env::template observe<float>(s, o);
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
@@ -602,7 +614,12 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
         } else {
-            philox_draws<Env::ACT, true>(z, a.seed, env_global, a.step_counter + (uint64_t)t, RNG_POLICY);
+            // four steps' noise at once, one step per replica group (see rollout_kernel)
+            if ((t & 3) == 0)
+                philox_draws<Env::ACT, true>(zq, a.seed, env_global, a.step_counter + (uint64_t)(t + (lane >> 4)),
+                                             RNG_POLICY);
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) z[k] = __shfl(zq[k], el + 16 * (t & 3), 64);
         }
 #pragma unroll
         for (int k = 0; k < Env::ACT; ++k) {
@@ -783,7 +800,7 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     a.obs_noise_z = g->cfg ? g->cfg->obs_noise_z : nullptr;
     if constexpr (std::is_same<Env, Swimmer>::value) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
-        static const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;
+        const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;   // per launch: tests switch shapes
         if (!lane_kernel && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
             dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);

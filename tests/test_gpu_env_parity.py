@@ -305,3 +305,30 @@ def test_stepwise_rollout_through_a_hip_graph(quiet_logger):
     t0 = time.time(); s.obtain_samples(4); torch.cuda.synchronize(); t_eager = time.time() - t0
     print("stepwise rollout %d envs x %d steps: hipGraph %.2f ms, eager %.2f ms" % (n, T, t_graph * 1e3, t_eager * 1e3))
     assert t_graph < t_eager
+
+
+@pytest.mark.parametrize("kind", [0, 2, 3])
+def test_policy_noise_stream_is_the_same_in_every_launch_shape(kind, monkeypatch):
+    """In-kernel policy noise is a function of (seed, global env index, step) only: the lane-group shapes draw four
+    steps at once on the four replicas of an env, the env-per-lane shape one step per launch iteration -- the
+    standardised noise (action - mean) / std must agree (to the rounding of the two policy forward passes)."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    policy = _make_policy(kind, (32, 32))
+    n, T = 100, 23                    # T not a multiple of four: the last group of draws is partly unused
+
+    def run():
+        v = HipVecEnv(kind, n, 9, normalize=True, seed=21)
+        tr = v.rollout(policy, T, reset_at_start=True)
+        std = torch.exp(policy.effective_log_std())[:, None, None]
+        return ((tr.actions - tr.means) / std).cpu().numpy(), tr.obs.cpu().numpy()
+    monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
+    monkeypatch.delenv("RLLAB_SWIMMER_LANE_KERNEL", raising=False)
+    z16, o16 = run()
+    monkeypatch.setenv("RLLAB_ROLLOUT_EPW", "64")
+    monkeypatch.setenv("RLLAB_SWIMMER_LANE_KERNEL", "1")
+    z64, o64 = run()
+    assert np.array_equal(o16[:, 0], o64[:, 0])                       # same reset draws
+    assert np.abs(z16[:, 0] - z64[:, 0]).max() < 1e-5                 # step 0: same observation, same noise
+    # later steps: trajectories drift apart by rounding, the noise does not depend on them
+    assert np.abs(z16 - z64).max() < 2e-3 and abs(z16.std() - 1.0) < 0.05
+    assert np.abs(z16[:, 1:] - z16[:, :-1]).max() > 0.1               # fresh per step
