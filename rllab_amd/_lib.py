@@ -69,7 +69,11 @@ class PolicyBatch(ctypes.Structure):
         ("log_min_std", ctypes.c_float), ("theta", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
         ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
+        ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32),
     ]
+
+
+ACT_TANH, ACT_RECTIFY = 0, 1
 
 
 def _load():

@@ -82,13 +82,22 @@ struct PolicyBatch {
     const float* weight;       // [B] 0/1
     float inv_count;
     float log_min_std;
+    float kl_penalty;          // MODE_VPG: gradient of  -sum w logp adv + kl_penalty * sum w KL(old || new)  (regressors)
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
 };
 
-template <class N, int MODE, bool CACHE>
+// hidden nonlinearity: tanh (GaussianMLPPolicy, network.py:38-39 default) or rectify (GaussianMLPRegressor /
+// GaussianMLPBaseline, gaussian_mlp_regressor.py:31); the derivative is expressed through the activation itself
+template <bool RELU> __device__ __forceinline__ float act_fn(float z) { return RELU ? fmaxf(z, 0.0f) : ftanh(z); }
+template <bool RELU> __device__ __forceinline__ float act_dz(float h) {
+    return RELU ? (h > 0.0f ? 1.0f : 0.0f) : (1.0f - h * h);
+}
+
+template <class N, int MODE, bool CACHE, bool RELU = false>
 __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
     static_assert(!CACHE || MODE == MODE_GRAD || MODE == MODE_FVP, "activation cache: grad writes, FVP reads");
+    static_assert(!RELU || MODE == MODE_LOSS || MODE == MODE_VPG, "rectify nets: loss and log-likelihood gradient");
     using S = Smem<N, MODE, CACHE>;
     constexpr int DO = N::DO, DA = N::DA, H = N::H, HT = N::HT, KS0 = N::KS0, KS1 = N::KS1, P = N::P;
     constexpr bool GRADLIKE = S::GRADLIKE, FVP = S::FVP;
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                 for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = ftanh(acc[r]);
+                for (int r = 0; r < 16; ++r) h0[t][r] = act_fn<RELU>(acc[r]);
             }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -272,7 +281,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                 for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h1[t][r] = ftanh(acc[r]);
+                for (int r = 0; r < 16; ++r) h1[t][r] = act_fn<RELU>(acc[r]);
             }
             if constexpr (STORE_ACTS) {
                 f32x4* dst = reinterpret_cast<f32x4*>(a.acts) + (size_t)tile * ACT_ROWS * WV + lane;
@@ -307,7 +316,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
             }
             const float advb = a.adv[bi];
             float zz_new = 0.0f, zz_old = 0.0f, sls_new = 0.0f, sls_old = 0.0f, kl = 0.0f;
-            float znew[DA];
+            float znew[DA], dmv[DA], numv[DA];          // the last two: pieces of the KL the penalty gradient reuses
 #pragma unroll
             for (int k = 0; k < DA; ++k) {
                 const float ak = a.act[(size_t)k * B + bi];
@@ -322,7 +331,10 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                 sls_old += lo;
                 const float dm = mo - mean[k];
                 const float num = dm * dm + so * so - var_[k];
-                kl += num / (2.0f * var_[k] + 1e-8f) + lstd[k] - lo;
+                const float den = 2.0f * var_[k] + 1e-8f;
+                kl += num / den + lstd[k] - lo;
+                dmv[k] = dm;
+                numv[k] = num;
             }
             // logli_new - logli_old (diagonal_gaussian.py:56-69); the 0.5*Da*log(2 pi) terms cancel
             const float logp_new = -sls_new - 0.5f * zz_new;
@@ -344,6 +356,19 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                 for (int k = 0; k < DA; ++k) {
                     gmu[k] = c * znew[k] * inv_std[k];
                     if (!floored[k]) gls[k] += c1 * (znew[k] * znew[k] - 1.0f);
+                }
+                if (MODE == MODE_VPG && a.kl_penalty != 0.0f) {     // wave-uniform: + kl_penalty * d(sum w KL / W)
+                    const float p = a.kl_penalty * wgt * a.inv_count;
+                    const float p1 = (lh == 0) ? p : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < DA; ++k) {
+                        // KL_k = num / den + ls_new - ls_old, num = (mu_o - mu)^2 + s_o^2 - v, den = 2 v + 1e-8, v = e^{2 ls_new}
+                        const float den = 2.0f * var_[k] + 1e-8f;
+                        const float dkl_mu = -2.0f * dmv[k] / den;
+                        const float dkl_ls = 1.0f - (2.0f * var_[k] * den + 4.0f * var_[k] * numv[k]) / (den * den);
+                        gmu[k] = __builtin_fmaf(p, dkl_mu, gmu[k]);
+                        if (!floored[k]) gls[k] += p1 * dkl_ls;
+                    }
                 }
             }
         } else {
@@ -401,7 +426,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                     for (int k = 0; k < DA; ++k)
                         g = __builtin_fmaf(tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], gmu[k], g);
-                    gz1[t][r] = g * (1.0f - h1[t][r] * h1[t][r]);
+                    gz1[t][r] = g * act_dz<RELU>(h1[t][r]);
                 }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -411,7 +436,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
 #pragma unroll
                 for (int m = 0; m < KS1; ++m) acc = mfma(fa1t[(t * KS1 + m) * WV + lane], gz1[m / 16][m % 16], acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gz0[t][r] = acc[r] * (1.0f - h0[t][r] * h0[t][r]);
+                for (int r = 0; r < 16; ++r) gz0[t][r] = acc[r] * act_dz<RELU>(h0[t][r]);
             }
 
             // ---- gb2, gmu / x rows for the broadcast (VALU) products -------------------------------------
@@ -670,12 +695,13 @@ __global__ void __launch_bounds__(LOSS_COLS * WV) reduce_loss_kernel(const doubl
 
 constexpr int MAX_GRID = 256 * 3;   // workgroups of a pass: <= 3 per CU
 
-template <class N, int MODE, bool CACHE = false>
+template <class N, int MODE, bool CACHE = false, bool RELU = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
                        double* out, hipStream_t st, double* loss_out = nullptr) {
     using S = Smem<N, MODE, CACHE>;
     PolicyBatch a;
     a.acts = g->activations;
+    a.kl_penalty = g->kl_penalty;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
@@ -698,7 +724,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     a.partial = (float*)workspace;
     a.partial_loss = (MODE == MODE_LOSS) ? (double*)workspace
                                          : (with_loss ? (double*)((char*)workspace + row_bytes) : nullptr);
-    auto kern = policy_pass_kernel<N, MODE, CACHE>;
+    auto kern = policy_pass_kernel<N, MODE, CACHE, RELU>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -738,9 +764,30 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
 }
 
+// rectify nets (regressors): loss / log-likelihood gradient only, one output, 32 hidden units
+template <class N>
+static int dispatch_relu(int mode, const rl_policy_batch* g, void* ws, size_t ws_bytes, double* out, hipStream_t st,
+                         double* loss_out) {
+    switch (mode) {
+        case MODE_LOSS: return launch_pass<N, MODE_LOSS, false, true>(g, nullptr, ws, ws_bytes, out, st);
+        case MODE_VPG: return launch_pass<N, MODE_VPG, false, true>(g, nullptr, ws, ws_bytes, out, st, loss_out);
+    }
+    return set_error(RL_ERR_UNSUPPORTED, "rectify networks: only the loss and the log-likelihood gradient are built");
+}
+
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
                         double* out, hipStream_t st, double* loss_out = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
+    if (g->activation == RL_ACT_RECTIFY) {
+#define RELUCASE(DO) \
+        if (d == DO && k == 1 && h0 == 32 && h1 == 32) return dispatch_relu<Net<DO, 1, 32>>(mode, g, ws, ws_bytes, out, st, loss_out);
+        RELUCASE(4) RELUCASE(6) RELUCASE(11) RELUCASE(13) RELUCASE(20) RELUCASE(21)
+#undef RELUCASE
+        return set_error(RL_ERR_UNSUPPORTED, "no rectify kernel for obs_dim=%d act_dim=%d hidden=(%d,%d)", d, k, h0, h1);
+    }
+    if (g->activation != RL_ACT_TANH) return set_error(RL_ERR_ARG, "unknown activation %d", g->activation);
+    if (g->kl_penalty != 0.0f && mode != MODE_VPG)
+        return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the log-likelihood gradient (vpg != 0) only");
 #define NETCASE(DO, DA, H) \
     if (d == DO && k == DA && h0 == H && h1 == H) \
         return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out);
@@ -758,6 +805,9 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     NETCASE(20, 3, 64)
     NETCASE(20, 6, 64)
     NETCASE(21, 6, 64)
+    NETCASE(13, 1, 32)   // one-output nets: value-function regressors on the Swimmer / HalfCheetah / Walker2D observations
+    NETCASE(20, 1, 32)
+    NETCASE(21, 1, 32)
 #undef NETCASE
     return set_error(RL_ERR_UNSUPPORTED,
                      "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d); the torch autograd "

@@ -43,11 +43,21 @@ class LbfgsOptimizer(Serializable):
         self._callback = callback
 
     def update_opt(self, loss, target, inputs=None, extra_inputs=None, gradients=None, *args, **kwargs):
+        """``fused`` (keyword): an object with ``accepts(inputs)``, ``loss_and_kl(inputs)`` and
+        ``value_and_grad(inputs, penalty)`` evaluating the same loss with HIP kernels
+        (regressors/fused_regressor_ops.py); the closure stays the definition and the fallback."""
         self._target = target
         self._loss = loss
+        self._fused = kwargs.get("fused")
+
+    def _fused_for(self, inputs):
+        f = getattr(self, "_fused", None)
+        return f if (f is not None and f.accepts(inputs)) else None
 
     def loss(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if self._fused_for(inputs) is not None:
+            return self._fused.loss_and_kl(inputs)[0]
         with torch.no_grad():
             v = self._loss(self._target.flat_params, *inputs).to(torch.float64)
         return float(D.all_reduce_sum_(v))
@@ -55,8 +65,12 @@ class LbfgsOptimizer(Serializable):
     def optimize(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
 
+        fused = self._fused_for(inputs)
+
         def f_opt_wrapper(flat_params):
             self._target.set_param_values(flat_params, trainable=True)
+            if fused is not None:
+                return fused.value_and_grad(inputs)
             return value_and_grad(self._loss, self._target, inputs)
 
         itr = [0]

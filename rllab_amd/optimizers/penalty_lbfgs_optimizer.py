@@ -81,6 +81,13 @@ class PenaltyLbfgsOptimizer(Serializable):
         self._loss, self._target = loss, target
         self._constraint, self._max_constraint_val = leq_constraint
         self._constraint_name = constraint_name
+        # HIP-kernel evaluation of loss / constraint / penalised gradient (regressors/fused_regressor_ops.py); the
+        # closures stay the definition and the fallback
+        self._fused = kwargs.get("fused")
+
+    def _fused_for(self, inputs):
+        f = getattr(self, "_fused", None)
+        return f if (f is not None and f.accepts(inputs)) else None
 
     # -- evaluations at the target's current parameters ---------------------------------------------------------
     def _value(self, fn, inputs):
@@ -89,18 +96,28 @@ class PenaltyLbfgsOptimizer(Serializable):
         return float(D.all_reduce_sum_(v))
 
     def loss(self, inputs, extra_inputs=None):
-        return self._value(self._loss, tuple(inputs) + tuple(extra_inputs or ()))
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if self._fused_for(inputs) is not None:
+            return self._fused.loss_and_kl(inputs)[0]
+        return self._value(self._loss, inputs)
 
     def constraint_val(self, inputs, extra_inputs=None):
-        return self._value(self._constraint, tuple(inputs) + tuple(extra_inputs or ()))
+        inputs = tuple(inputs) + tuple(extra_inputs or ())
+        if self._fused_for(inputs) is not None:
+            return self._fused.loss_and_kl(inputs)[1]
+        return self._value(self._constraint, inputs)
 
     def _lbfgs(self, penalty, x0, inputs):
         """L-BFGS on the penalised objective from ``x0``; leaves the target at the last point scipy evaluated."""
         def penalised(flat, *a):
             return self._loss(flat, *a) + penalty * self._constraint(flat, *a)
 
+        fused = self._fused_for(inputs)
+
         def objective(flat_params):
             self._target.set_param_values(flat_params, trainable=True)
+            if fused is not None:
+                return fused.value_and_grad(inputs, penalty)     # one launch: value, KL and the penalised gradient
             return value_and_grad(penalised, self._target, inputs)
         return scipy.optimize.fmin_l_bfgs_b(func=objective, x0=x0, maxiter=self._max_opt_itr)[0]
 
@@ -113,7 +130,10 @@ class PenaltyLbfgsOptimizer(Serializable):
             logger.log('trying penalty=%.3f...' % penalty)
             solution = self._lbfgs(penalty, start, inputs)
             # judged where scipy's last function call left the parameters, like the reference (:112)
-            trial_loss, trial_constraint = self._value(self._loss, inputs), self._value(self._constraint, inputs)
+            if self._fused_for(inputs) is not None:
+                trial_loss, trial_constraint = self._fused.loss_and_kl(inputs)
+            else:
+                trial_loss, trial_constraint = self._value(self._loss, inputs), self._value(self._constraint, inputs)
             logger.log('penalty %f => loss %f, %s %f' % (penalty, trial_loss, self._constraint_name, trial_constraint))
             if search.record(solution, trial_constraint, trial):
                 break
