@@ -280,11 +280,12 @@ typedef struct rl_policy_batch {
                                 * which passes the buffer uses the same obs / theta as the gradient call that filled
                                 * it -- in ConjugateGradientOptimizer.optimize (conjugate_gradient_optimizer.py:
                                 * 229-296) the 11 f_Hx_plain evaluations follow f_grad at the same parameters. */
-    float kl_penalty;          /* rl_policy_grad / rl_policy_grad_loss with vpg != 0: the gradient becomes that of
-                                *   (-sum_b w logp adv + kl_penalty * sum_b w KL(old_b || new_b)) * inv_count,
+    float kl_penalty;          /* rl_policy_grad / rl_policy_grad_loss: the gradient becomes that of
+                                *   (-sum_b w {lr | logp} adv + kl_penalty * sum_b w KL(old_b || new_b)) * inv_count,
                                 * the penalised objective PenaltyLbfgsOptimizer hands to L-BFGS
-                                * (rllab/optimizers/penalty_lbfgs_optimizer.py:66-79) when GaussianMLPRegressor fits
-                                * under its mean-KL trust region (gaussian_mlp_regressor.py:126-143).  0 = none. */
+                                * (rllab/optimizers/penalty_lbfgs_optimizer.py:66-79): PPO on NPO's surrogate
+                                * (vpg == 0, rllab/algos/ppo.py:8-22), GaussianMLPRegressor on the log-likelihood under
+                                * its mean-KL trust region (vpg != 0, gaussian_mlp_regressor.py:126-143).  0 = none. */
     int32_t activation;        /* RL_ACT_TANH (policies) or RL_ACT_RECTIFY (GaussianMLPRegressor's default hidden
                                 * nonlinearity, gaussian_mlp_regressor.py:31; loss and vpg gradient only, act_dim 1,
                                 * hidden 32x32) */

@@ -82,7 +82,8 @@ struct PolicyBatch {
     const float* weight;       // [B] 0/1
     float inv_count;
     float log_min_std;
-    float kl_penalty;          // MODE_VPG: gradient of  -sum w logp adv + kl_penalty * sum w KL(old || new)  (regressors)
+    float kl_penalty;          // MODE_GRAD / MODE_VPG: the gradient gains  + kl_penalty * d(sum w KL(old || new)) / dtheta
+                               // (PenaltyLbfgsOptimizer's objective: PPO on the surrogate, regressors on the log-likelihood)
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
 };
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                     gmu[k] = c * znew[k] * inv_std[k];
                     if (!floored[k]) gls[k] += c1 * (znew[k] * znew[k] - 1.0f);
                 }
-                if (MODE == MODE_VPG && a.kl_penalty != 0.0f) {     // wave-uniform: + kl_penalty * d(sum w KL / W)
+                if (a.kl_penalty != 0.0f) {     // wave-uniform: + kl_penalty * d(sum w KL(old || new) / W) / dtheta
                     const float p = a.kl_penalty * wgt * a.inv_count;
                     const float p1 = (lh == 0) ? p : 0.0f;
 #pragma unroll
@@ -786,8 +787,8 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
         return set_error(RL_ERR_UNSUPPORTED, "no rectify kernel for obs_dim=%d act_dim=%d hidden=(%d,%d)", d, k, h0, h1);
     }
     if (g->activation != RL_ACT_TANH) return set_error(RL_ERR_ARG, "unknown activation %d", g->activation);
-    if (g->kl_penalty != 0.0f && mode != MODE_VPG)
-        return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the log-likelihood gradient (vpg != 0) only");
+    if (g->kl_penalty != 0.0f && mode != MODE_VPG && mode != MODE_GRAD)
+        return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the gradient passes only");
 #define NETCASE(DO, DA, H) \
     if (d == DO && k == DA && h0 == H && h1 == H) \
         return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out);

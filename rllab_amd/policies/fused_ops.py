@@ -194,6 +194,30 @@ class FusedGaussianMLPOps(object):
             b.activations = None
         return D.all_reduce_sum_(self.layout.unpack(out))
 
+    def value_and_grad(self, inputs, penalty=0.0):
+        """float64 (value, flat gradient over the trainable parameters) of  surrogate loss + penalty * mean KL  in ONE
+        pass (rl_policy_grad_loss with rl_policy_batch.kl_penalty): PenaltyLbfgsOptimizer's objective when PPO / NPO
+        run it on a GaussianMLPPolicy (rllab/algos/ppo.py:8-22, penalty_lbfgs_optimizer.py:66-79)."""
+        b, keep, inv = self._batch(inputs)
+        dev = keep[0].device
+        ws = self._workspace(dev)
+        grad = torch.empty(self.n_kernel, dtype=torch.float64, device=dev)
+        out4 = torch.empty(4, dtype=torch.float64, device=dev)
+        self._acts_tag = None
+        b.activations = None
+        b.kl_penalty = float(penalty)
+        try:
+            _lib.check(_lib.lib.rl_policy_grad_loss(ctypes.byref(b), 0, _lib.ptr(ws), ws.numel(), _lib.ptr(grad),
+                                                    _lib.ptr(out4), _lib.stream_ptr()), "rl_policy_grad_loss")
+        finally:
+            b.kl_penalty = 0.0
+        packed = torch.cat([out4[:3], self.layout.unpack(grad)])
+        D.all_reduce_sum_(packed)
+        idx = self.policy._flat_index(trainable=True)
+        host = packed.cpu().numpy()
+        g = host[3:] if idx is None else host[3:][idx.cpu().numpy()]
+        return float((-host[0] + penalty * host[1]) * inv), g.copy()
+
     def _fvp_into(self, b, ws, vec32, out, inputs=None):
         cached = inputs is not None and self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
         b.activations = self._acts.data_ptr() if cached else None

@@ -203,3 +203,49 @@ def test_running_obs_and_reward_normalisation_on_the_vectorised_path(quiet_logge
                n_itr=2, sampler_args=dict(n_envs=32))
     algo.train()
     assert np.isfinite(policy.get_param_values()).all()
+
+
+@pytest.mark.parametrize("do,da,h", [(4, 1, 32), (13, 2, 32), (20, 6, 64)])
+@pytest.mark.parametrize("penalty", [0.0, 2.5])
+def test_penalised_surrogate_value_and_gradient(do, da, h, penalty):
+    """PenaltyLbfgsOptimizer's objective on a policy (PPO, rllab/algos/ppo.py:8-22): surrogate loss + penalty * mean KL
+    and its gradient from ONE kernel pass (rl_policy_grad_loss with kl_penalty) against float64 autograd."""
+    from tests import test_gpu_update_parity as U
+    pol = U._policy(do, da, h)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, 5003)
+    surr, kl, _ = U._closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    obj = surr(flat64, *inp) + penalty * kl(flat64, *inp)
+    g64 = torch.autograd.grad(obj, flat64)[0].cpu().numpy()
+    val, g = ops.value_and_grad(inp, penalty)
+    assert abs(val - float(obj.detach())) <= 2e-5 * max(1.0, abs(float(obj.detach())))
+    assert np.abs(g - g64).max() <= 3e-5 * max(1e-3, np.abs(g64).max())
+
+
+def test_ppo_runs_on_the_kernels_and_learns(quiet_logger):
+    from rllab.algos.ppo import PPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(5)
+    env = normalize(CartpoleEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    algo = PPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=256 * 100,
+               max_path_length=100, n_itr=10, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    assert algo.optimizer._fused is not None and hasattr(algo.optimizer._fused, "value_and_grad")
+    rets = []
+    for itr in range(10):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.log_diagnostics(paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        rets.append(float(tab["AverageReturn"]))
+        assert float(tab["MeanKL"]) <= 0.0101 and float(tab["LossAfter"]) <= float(tab["LossBefore"]) + 1e-7
+        logger.dump_tabular()
+    assert np.mean(rets[-2:]) > 1.5 * np.mean(rets[:2]), rets

@@ -300,8 +300,8 @@ def test_unsupported_options_fail_loudly():
     assert sw2.ctrl_cost_coeff == 0.5 and sw2.action_noise == 0.1
     cp = pickle.loads(pickle.dumps(CartpoleEnv(reset_pole_follows_cart=True, obs_noise=0.2)))
     assert cp.reset_pole_follows_cart and cp._cfg["flags"] == 1 and cp.obs_noise == 0.2
-    with pytest.raises(NotImplementedError):
-        GaussianMLPPolicy(_spec(4, 1), adaptive_std=True)
+    ad = GaussianMLPPolicy(_spec(4, 1), adaptive_std=True)     # the reference's tests/regression_tests/test_issue_3.py
+    assert ad.state_dependent_std and ad.kernel_layout() is None
     # NPO's default optimizer is the reference's PenaltyLbfgsOptimizer (npo.py:27-30)
     from rllab_amd.optimizers.penalty_lbfgs_optimizer import PenaltyLbfgsOptimizer
     assert isinstance(NPO(env=None, policy=None, baseline=None).optimizer, PenaltyLbfgsOptimizer)
