@@ -341,6 +341,15 @@ int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p
 int rl_cg_step(int n, const double* fvp, double reg_coeff, double residual_tol, double* x, double* r,
                double* p, float* p32, double* scal, void* stream);
 
+/* rl_policy_fvp (vec = p32) and rl_cg_step in two launches instead of three, for a single rank (no all-reduce sits
+ * between the product and the CG algebra): the workgroup that finishes the row reduction of F p last runs the CG
+ * iteration.  Same arithmetic in the same order as rl_policy_fvp followed by rl_cg_step.
+ *   fvp_scratch  double[P]: receives F p
+ *   ticket       one uint32, zero before the first call; every call leaves it zero */
+int rl_policy_fvp_cg_step(const rl_policy_batch* batch, void* workspace, size_t workspace_bytes, double reg_coeff,
+                          double residual_tol, double* x, double* r, double* p, float* p32, double* scal,
+                          double* fvp_scratch, unsigned int* ticket, void* stream);
+
 /* The step ConjugateGradientOptimizer.optimize forms after CG
  * (rllab/optimizers/conjugate_gradient_optimizer.py:257-262), float64, one launch:
  *   xHx = x . (a - b + reg_coeff x);  beta = sqrt(2 max_constraint * (1 / (xHx + 1e-8)))  (NaN -> 1);

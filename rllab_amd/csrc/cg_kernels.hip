@@ -14,25 +14,9 @@
 #include <hip/hip_runtime.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
+#include "cg_device.h"
 
 namespace rl {
-
-constexpr int CG_THREADS = 1024;
-constexpr int CG_MAX_PER_THREAD = 16;   // n <= 16384 parameters
-
-__device__ __forceinline__ double block_sum(double v, double* scratch) {
-    // wavefront butterfly, then the 16 wave sums in order
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < CG_THREADS / 64; ++w) s += scratch[w];
-    return s;
-}
 
 // scal[0] = rdotr, scal[1] = active (1 / 0), scal[2] = p.Ap of the last step, scal[3] = steps taken
 __global__ void __launch_bounds__(CG_THREADS) cg_init_kernel(int n, const double* __restrict__ b,
@@ -55,51 +39,7 @@ __global__ void __launch_bounds__(CG_THREADS) cg_step_kernel(int n, const double
                                                              double* __restrict__ r, double* __restrict__ p,
                                                              float* __restrict__ p32, double* __restrict__ scal) {
     __shared__ double scratch[CG_THREADS / 64];
-    const double rdotr = scal[0];
-    const bool active = scal[1] != 0.0;
-    double z[CG_MAX_PER_THREAD], pv[CG_MAX_PER_THREAD];
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
-        const int i = threadIdx.x + k * CG_THREADS;
-        if (i < n) {
-            pv[k] = p[i];
-            z[k] = fp[i] + reg * pv[k];      // Hx = F p + reg_coeff * p
-            acc += pv[k] * z[k];
-        }
-    }
-    const double pz = block_sum(acc, scratch);
-    if (!active) return;                     // wave-uniform: scal[1] is one value for the whole grid
-    const double v = rdotr / pz;
-    double rn[CG_MAX_PER_THREAD];
-    acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
-        const int i = threadIdx.x + k * CG_THREADS;
-        if (i < n) {
-            x[i] += v * pv[k];
-            rn[k] = r[i] - v * z[k];
-            r[i] = rn[k];
-            acc += rn[k] * rn[k];
-        }
-    }
-    const double newrdotr = block_sum(acc, scratch);
-    const double mu = newrdotr / rdotr;
-#pragma unroll
-    for (int k = 0; k < CG_MAX_PER_THREAD; ++k) {
-        const int i = threadIdx.x + k * CG_THREADS;
-        if (i < n) {
-            const double pn = rn[k] + mu * pv[k];
-            p[i] = pn;
-            p32[i] = (float)pn;
-        }
-    }
-    if (threadIdx.x == 0) {
-        scal[0] = newrdotr;
-        scal[1] = (newrdotr >= tol) ? 1.0 : 0.0;
-        scal[2] = pz;
-        scal[3] += 1.0;
-    }
+    cg_step_body(n, fp, reg, tol, x, r, p, p32, scal, scratch);
 }
 
 // After CG (conjugate_gradient_optimizer.py:257-262):  xHx = x . (a - b + reg x),

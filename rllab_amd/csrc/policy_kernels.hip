@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
+#include "cg_device.h"
 #include "policy_mfma.h"
 
 namespace rl {
@@ -677,6 +678,59 @@ __global__ void __launch_bounds__(RR_WAVES * WV) reduce_rows_kernel(const float*
     }
 }
 
+// rl_policy_fvp_cg_step: the row reduction of a Fisher-vector product and the CG iteration that consumes it in ONE
+// launch.  Every workgroup reduces its 64 columns exactly like reduce_rows_kernel and publishes them; the workgroup
+// that takes the LAST ticket (all columns are then in memory: release fence before the ticket, acquire after) runs
+// cg_step_body over the whole vector and rewinds the ticket counter for the next launch.  Same arithmetic, same
+// order, as reduce_rows_kernel followed by cg_step_kernel.
+struct CgArgs {
+    double reg, tol;
+    double* x;
+    double* r;
+    double* p;
+    float* p32;
+    double* scal;
+    double* fp;              // [n] scratch: F p
+    unsigned int* ticket;    // zero before the first launch; left zero by every launch
+};
+static_assert(RR_WAVES * WV == CG_THREADS, "the reducing workgroup doubles as the CG workgroup");
+__global__ void __launch_bounds__(RR_WAVES * WV) reduce_rows_cg_kernel(const float* __restrict__ partial, int rows,
+                                                                        int cols, CgArgs c) {
+    __shared__ double part[RR_WAVES][WV];
+    __shared__ double scratch[CG_THREADS / 64];
+    __shared__ unsigned int my_ticket;
+    const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
+    const int col = blockIdx.x * WV + lane;
+    double s = 0.0;
+    if (col < cols) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = wave;
+        for (; r + 3 * RR_WAVES < rows; r += 4 * RR_WAVES) {
+            s0 += (double)partial[(size_t)r * cols + col];
+            s1 += (double)partial[(size_t)(r + RR_WAVES) * cols + col];
+            s2 += (double)partial[(size_t)(r + 2 * RR_WAVES) * cols + col];
+            s3 += (double)partial[(size_t)(r + 3 * RR_WAVES) * cols + col];
+        }
+        for (; r < rows; r += RR_WAVES) s0 += (double)partial[(size_t)r * cols + col];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        double t = part[0][lane];
+        for (int w = 1; w < RR_WAVES; ++w) t += part[w][lane];
+        c.fp[col] = t;
+    }
+    __threadfence();                       // this workgroup's columns are visible device-wide before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) my_ticket = atomicAdd(c.ticket, 1u);
+    __syncthreads();
+    if (my_ticket != gridDim.x - 1) return;
+    __threadfence();                       // acquire: every other workgroup's columns
+    cg_step_body(cols, c.fp, c.reg, c.tol, c.x, c.r, c.p, c.p32, c.scal, scratch);
+    if (threadIdx.x == 0) *c.ticket = 0u;
+}
+
 // loss partials: columns 0..2 summed, column 3 maxed; one wavefront per column
 __global__ void __launch_bounds__(LOSS_COLS * WV) reduce_loss_kernel(const double* __restrict__ partial, int rows,
                                                                      double* __restrict__ out) {
@@ -698,7 +752,7 @@ constexpr int MAX_GRID = 256 * 3;   // workgroups of a pass: <= 3 per CU
 
 template <class N, int MODE, bool CACHE = false, bool RELU = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
-                       double* out, hipStream_t st, double* loss_out = nullptr) {
+                       double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr) {
     using S = Smem<N, MODE, CACHE>;
     PolicyBatch a;
     a.acts = g->activations;
@@ -738,6 +792,9 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     if (rc) return rc;
     if (MODE == MODE_LOSS) {
         hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(LOSS_COLS * WV), 0, st, a.partial_loss, grid, out);
+    } else if (cg != nullptr) {
+        hipLaunchKernelGGL(reduce_rows_cg_kernel, dim3((N::P + WV - 1) / WV), dim3(RR_WAVES * WV), 0, st, a.partial,
+                           grid, N::P, *cg);
     } else {
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((N::P + WV - 1) / WV), dim3(RR_WAVES * WV), 0, st, a.partial,
                            grid, N::P, out);
@@ -749,7 +806,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
 
 template <class N>
 static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
-                         double* out, hipStream_t st, double* loss_out) {
+                         double* out, hipStream_t st, double* loss_out, const CgArgs* cg = nullptr) {
     switch (mode) {
         case MODE_LOSS: return launch_pass<N, MODE_LOSS>(g, vec, ws, ws_bytes, out, st);
         case MODE_GRAD:
@@ -758,8 +815,8 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
             return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st, loss_out);
         case MODE_FVP:
             if constexpr (N::ACT_CACHE)
-                if (g->activations) return launch_pass<N, MODE_FVP, true>(g, vec, ws, ws_bytes, out, st);
-            return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st);
+                if (g->activations) return launch_pass<N, MODE_FVP, true>(g, vec, ws, ws_bytes, out, st, nullptr, cg);
+            return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st, nullptr, cg);
         case MODE_VPG: return launch_pass<N, MODE_VPG>(g, vec, ws, ws_bytes, out, st, loss_out);
     }
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
@@ -777,7 +834,7 @@ static int dispatch_relu(int mode, const rl_policy_batch* g, void* ws, size_t ws
 }
 
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
-                        double* out, hipStream_t st, double* loss_out = nullptr) {
+                        double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
     if (g->activation == RL_ACT_RECTIFY) {
 #define RELUCASE(DO) \
@@ -791,7 +848,7 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
         return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the gradient passes only");
 #define NETCASE(DO, DA, H) \
     if (d == DO && k == DA && h0 == H && h1 == H) \
-        return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out);
+        return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out, cg);
     NETCASE(4, 1, 32)    // Cartpole
     NETCASE(6, 1, 32)    // DoublePendulum
     NETCASE(11, 1, 32)   // InvertedDoublePendulum
@@ -869,6 +926,19 @@ extern "C" int rl_policy_grad_loss(const rl_policy_batch* g, int vpg, void* work
         return set_error(RL_ERR_ARG, "rl_policy_grad_loss: bad argument");
     return dispatch_net(vpg ? MODE_VPG : MODE_GRAD, g, nullptr, workspace, workspace_bytes, grad_out,
                         (hipStream_t)stream, out4);
+}
+
+extern "C" int rl_policy_fvp_cg_step(const rl_policy_batch* g, void* workspace, size_t workspace_bytes, double reg_coeff,
+                                     double residual_tol, double* x, double* r, double* p, float* p32, double* scal,
+                                     double* fvp_scratch, unsigned int* ticket, void* stream) {
+    int rc = check_batch(g, "rl_policy_fvp_cg_step");
+    if (rc) return rc;
+    if (!x || !r || !p || !p32 || !scal || !fvp_scratch || !ticket)
+        return set_error(RL_ERR_ARG, "rl_policy_fvp_cg_step: bad argument");
+    CgArgs c;
+    c.reg = reg_coeff; c.tol = residual_tol; c.x = x; c.r = r; c.p = p; c.p32 = p32; c.scal = scal;
+    c.fp = fvp_scratch; c.ticket = ticket;
+    return dispatch_net(MODE_FVP, g, p32, workspace, workspace_bytes, fvp_scratch, (hipStream_t)stream, nullptr, &c);
 }
 
 extern "C" int rl_policy_fvp(const rl_policy_batch* g, const float* vec, void* workspace,

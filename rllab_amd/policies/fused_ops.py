@@ -235,6 +235,31 @@ class FusedGaussianMLPOps(object):
         out = torch.empty(self.n_kernel, dtype=torch.float64, device=keep[0].device)
         return self.layout.unpack(self._fvp_into(b, ws, v, out, inputs))
 
+    def _cg_loop(self, b, ws, inputs, cg_iters, reg_coeff, residual_tol, x, r, p, p32, z, scal, st):
+        """cg_iters x (Fisher-vector product of the direction p32, one krylov.cg iteration).  One rank: two launches
+        per iteration (rl_policy_fvp_cg_step -- the row reduction's last workgroup runs the CG algebra); sharded:
+        product, all-reduce, rl_cg_step."""
+        n = self.n_kernel
+        if D.is_distributed() or not getattr(self, "fuse_cg", True):
+            for _ in range(cg_iters):
+                self._fvp_into(b, ws, p32, z, inputs)
+                _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
+                                               _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
+                           "rl_cg_step")
+            return
+        if getattr(self, "_ticket", None) is None or self._ticket.device != x.device:
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=x.device)
+        cached = self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
+        b.activations = self._acts.data_ptr() if cached else None
+        try:
+            for _ in range(cg_iters):
+                _lib.check(_lib.lib.rl_policy_fvp_cg_step(
+                    ctypes.byref(b), _lib.ptr(ws), ws.numel(), float(reg_coeff), float(residual_tol), _lib.ptr(x),
+                    _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), _lib.ptr(z), _lib.ptr(self._ticket), st),
+                    "rl_policy_fvp_cg_step")
+        finally:
+            b.activations = None
+
     def cg(self, inputs, g, cg_iters, reg_coeff, residual_tol=1e-10):
         """krylov.cg (rllab/misc/krylov.py:7-39) on Hx = F x + reg_coeff x with the vector algebra of
         each iteration in ONE launch (rl_cg_step) between the Fisher-vector-product passes: two
@@ -253,11 +278,7 @@ class FusedGaussianMLPOps(object):
         st = _lib.stream_ptr()
         _lib.check(_lib.lib.rl_cg_init(n, _lib.ptr(g), _lib.ptr(x), _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32),
                                        _lib.ptr(scal), st), "rl_cg_init")
-        for _ in range(cg_iters):
-            self._fvp_into(b, ws, p32, z, inputs)
-            _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
-                                           _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
-                       "rl_cg_step")
+        self._cg_loop(b, ws, inputs, cg_iters, reg_coeff, residual_tol, x, r, p, p32, z, scal, st)
         # F x for the initial step size (conjugate_gradient_optimizer.py:258-260)
         x32 = x.to(torch.float32)
         self._fvp_into(b, ws, x32, z, inputs)
@@ -284,11 +305,7 @@ class FusedGaussianMLPOps(object):
         st = _lib.stream_ptr()
         _lib.check(_lib.lib.rl_cg_init(n, _lib.ptr(g), _lib.ptr(x), _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32),
                                        _lib.ptr(scal), st), "rl_cg_init")
-        for _ in range(cg_iters):
-            self._fvp_into(b, ws, p32, z, inputs)
-            _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
-                                           _lib.ptr(r), _lib.ptr(p), _lib.ptr(p32), _lib.ptr(scal), st),
-                       "rl_cg_step")
+        self._cg_loop(b, ws, inputs, cg_iters, reg_coeff, residual_tol, x, r, p, p32, z, scal, st)
         if reuse_cg_residual:
             _lib.check(_lib.lib.rl_trpo_step(n, _lib.ptr(x), _lib.ptr(g), _lib.ptr(r), 0.0, float(max_constraint),
                                              _lib.ptr(step), _lib.ptr(stats), st), "rl_trpo_step")

@@ -383,3 +383,27 @@ def test_adam_step_kernel_matches_the_tensor_form():
         assert torch.allclose(a.m, b.m, rtol=1e-13, atol=1e-300) and torch.allclose(a.v, b.v, rtol=1e-13, atol=1e-300)
         assert float((ta - tb).abs().max()) <= 2.4e-7 * float(ta.abs().max()), k
         ta = tb.clone()
+
+
+@pytest.mark.parametrize("do,da,h", [(13, 2, 32), (20, 6, 64), (4, 1, 32)])
+def test_fused_fvp_cg_step_is_the_three_launch_sequence(do, da, h):
+    """rl_policy_fvp_cg_step (row reduction's last workgroup runs the CG iteration) == rl_policy_fvp + rl_cg_step,
+    bit for bit: same partial rows, same fixed reduction order, same float64 algebra -- over a whole CG run
+    including the early exit, with and without the activation cache."""
+    pol = _policy(do, da, h)
+    inp = _inputs(pol, 20011, old_equals_new=True)
+    g = torch.as_tensor(np.random.RandomState(5).randn(pol.flat_params.numel()), device="cuda")
+    for cached in (False, True):
+        for iters in (3, 10, 40):                 # 40: the residual test fires and freezes the iterates
+            res = []
+            for fuse in (True, False):
+                ops = pol.fused_ops()
+                ops.fuse_cg = fuse
+                if cached:
+                    ops.loss_grad(inp, keep_activations=True)
+                x, xHx = ops.cg(inp, g, iters, 1e-5)
+                step, stats = ops.cg_step_vector(inp, g, iters, 1e-5, 0.01)
+                res.append((x.clone(), xHx.clone(), step.clone(), stats.clone()))
+                ops.release()
+            for a, b in zip(*res):
+                assert torch.equal(a, b), (cached, iters)
