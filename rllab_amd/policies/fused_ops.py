@@ -6,6 +6,7 @@ global values.  Inputs are the tuples built by ``rllab_amd.algos.npo.npo_inputs`
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -236,11 +237,15 @@ class FusedGaussianMLPOps(object):
         return self.layout.unpack(self._fvp_into(b, ws, v, out, inputs))
 
     def _cg_loop(self, b, ws, inputs, cg_iters, reg_coeff, residual_tol, x, r, p, p32, z, scal, st):
-        """cg_iters x (Fisher-vector product of the direction p32, one krylov.cg iteration).  One rank: two launches
-        per iteration (rl_policy_fvp_cg_step -- the row reduction's last workgroup runs the CG algebra); sharded:
-        product, all-reduce, rl_cg_step."""
+        """cg_iters x (Fisher-vector product of the direction p32, one krylov.cg iteration): product (+ row
+        reduction), all-reduce when sharded, rl_cg_step -- three launches per iteration.
+        ``fuse_cg`` (or RLLAB_FUSE_CG=1) selects rl_policy_fvp_cg_step instead, where the row reduction's last
+        workgroup runs the CG algebra (two launches, bit-identical results).  MEASURED SLOWER on MI355X (update
+        3.43 -> 3.52 ms at the bench size, profiles/r02_notes.md): the hand-over inside one launch needs a device-scope
+        release / acquire, which on an 8-XCD part writes back and invalidates the per-XCD L2s -- more than the
+        launch boundary it saves.  Kept as a tested alternative, off by default."""
         n = self.n_kernel
-        if D.is_distributed() or not getattr(self, "fuse_cg", True):
+        if D.is_distributed() or not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
             for _ in range(cg_iters):
                 self._fvp_into(b, ws, p32, z, inputs)
                 _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),
