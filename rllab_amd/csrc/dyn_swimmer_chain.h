@@ -57,9 +57,9 @@ struct SwimChain {
     template <typename R>
     RL_HD static R joint_torque(R th, R thd, R act, R lim_k, R lim_b) {
         const R viol = th - rl_clamp_finite(th, (R)Mdl::lo(1), (R)Mdl::hi(1));
-        const R damp = (viol != (R)0) ? lim_b * thd : (R)0;
-        const R t = -(lim_k * viol) - damp;
-        return t + act;
+        const R b_on = (viol != (R)0) ? lim_b : (R)0;         // the damper acts only beyond the range
+        const R t = act - lim_k * viol;                       // one fused multiply-add
+        return t - b_on * thd;                                // and another
     }
     // coupling of body b (cb, sb) to a partner x (cx, sx):  S = Sc_bx cos(phi_x - phi_b)  (bitwise symmetric in b <-> x:
     // the product and the fused product commute),  t = Ac_bx sin(phi_x - phi_b)  (rhs_b += w_x^2 t)
@@ -123,23 +123,26 @@ struct SwimChain {
         Q[1] = (((R)cxb(1) * ft[1] + tz[1]) + (R)jxo(1) * (cs[1] * Fsy[2] - sn[1] * Fsx[2])) + (tau[1] - tau[2]);
         Q[2] = ((R)cxb(2) * ft[2] + tz[2]) + tau[2];
         // translation coupling and centripetal terms
-        R Gx[3], Gy[3], w2[3], wgx[3], wgy[3];
+        R Gx[3], Gy[3], w2[3], fwx[3], fwy[3];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) {
             const R DB = (R)db(b);
             Gx[b] = cs[b] * DB;
             Gy[b] = sn[b] * DB;
             w2[b] = om[b] * om[b];
-            wgx[b] = w2[b] * Gx[b];
-            wgy[b] = w2[b] * Gy[b];
+            fwx[b] = Fx[b] + w2[b] * Gx[b];       // force + centripetal term of body b, one fused multiply-add
+            fwy[b] = Fy[b] + w2[b] * Gy[b];
         }
-        // total force + centripetal term, summed per body first (the lane-group program folds this sum with one
-        // butterfly; its fourth lane adds an exact zero)
-        const R grx = (((Fx[0] + wgx[0]) + (Fx[1] + wgx[1])) + (Fx[2] + wgx[2])) * (R)INV_M;
-        const R gry = (((Fy[0] + wgy[0]) + (Fy[1] + wgy[1])) + (Fy[2] + wgy[2])) * (R)INV_M;
+        // their sum over the bodies, UNSCALED: the 1 / M of the translation block is applied where the sum is used
+        // (the lane-group program folds this sum with one butterfly; its fourth lane adds an exact zero)
+        const R sfx = (fwx[0] + fwx[1]) + fwx[2];
+        const R sfy = (fwy[0] + fwy[1]) + fwy[2];
         R bq[3];
         RL_UNROLL
-        for (int b = 0; b < 3; ++b) bq[b] = Q[b] - (Gx[b] * gry - Gy[b] * grx);
+        for (int b = 0; b < 3; ++b) {
+            const R cross = Gx[b] * sfy - Gy[b] * sfx;
+            bq[b] = Q[b] - (R)INV_M * cross;
+        }
         // coupling to the cyclic partners and the rows of the 3x3 solve
         // one coupling per pair: body b evaluates (b, p); its coupling to q is pair (q, b) seen from the other side --
         // S is symmetric bit for bit, the sine term changes sign
@@ -170,10 +173,12 @@ struct SwimChain {
         }
         const R sx = (cxp[0] + cxp[1]) + cxp[2];
         const R sy = (cyp[0] + cyp[1]) + cyp[2];
-        const R ax = grx - sx * (R)INV_M;
-        const R ay = gry - sy * (R)INV_M;
-        r[2] = r[2] + h * ax;
-        r[3] = r[3] + h * ay;
+        // root acceleration (sf - s) / M, integrated with the loop-invariant h / M
+        const R hm = h * (R)INV_M;
+        const R dx_ = sfx - sx;
+        const R dy_ = sfy - sy;
+        r[2] = r[2] + hm * dx_;
+        r[3] = r[3] + hm * dy_;
         r[0] = r[0] + h * r[2];
         r[1] = r[1] + h * r[3];
         RL_UNROLL
@@ -261,11 +266,12 @@ struct SwimChain {
         const R Gx = s.cs * c.db;
         const R Gy = s.sn * c.db;
         const R w2 = s.om * s.om;
-        const R wgx = w2 * Gx;
-        const R wgy = w2 * Gy;
-        const R grx = quad_sum(x, Fx + wgx) * (R)INV_M;
-        const R gry = quad_sum(x, Fy + wgy) * (R)INV_M;
-        const R bq = Q - (Gx * gry - Gy * grx);
+        const R fwx = Fx + w2 * Gx;
+        const R fwy = Fy + w2 * Gy;
+        const R sfx = quad_sum(x, fwx);
+        const R sfy = quad_sum(x, fwy);
+        const R cross = Gx * sfy - Gy * sfx;
+        const R bq = Q - (R)INV_M * cross;
         // coupling to the cyclic partner p; the pair (b, q) is partner q's own pair seen from the other side
         const R cp_ = x.template qp<NX1>(s.cs), sp_ = x.template qp<NX1>(s.sn), w2p = x.template qp<NX1>(w2);
         const R w2q = x.template qp<NX2>(w2);
@@ -280,10 +286,11 @@ struct SwimChain {
         const R cyp = Gx * thb;
         const R sx = quad_sum(x, cxp);
         const R sy = quad_sum(x, cyp);
-        const R ax = grx - sx * (R)INV_M;
-        const R ay = gry - sy * (R)INV_M;
-        s.vx = s.vx + h * ax;
-        s.vy = s.vy + h * ay;
+        const R hm = h * (R)INV_M;
+        const R dx_ = sfx - sx;
+        const R dy_ = sfy - sy;
+        s.vx = s.vx + hm * dx_;
+        s.vy = s.vy + hm * dy_;
         s.rx = s.rx + h * s.vx;
         s.ry = s.ry + h * s.vy;
         s.om = s.om + h * thb;

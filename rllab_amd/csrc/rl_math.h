@@ -117,15 +117,16 @@ RL_HD void rl_rotate_small(R& sn, R& cs, R d) {
     cs = c;
 }
 
-// Same rotation for |d| << 1 (one 1 ms sub-step of a swimmer link: |d| < 0.05): in single precision the series are cut
-// one term earlier (sin: d^5/120 < 3e-9, cos: d^6/720 < 3e-11 -- below half an ulp of the results).
+// Same rotation for |d| << 1 (one 1 ms sub-step of a swimmer link: |d| = 1e-3 |omega| < 0.02): in single precision the
+// series are cut where the next term is below half an ulp of the result (sin: d^5/120 < 3e-11, cos: d^4/24 < 7e-9; the
+// carried pair is re-seeded with exact values every env step, so nothing accumulates beyond 50 sub-steps).
 template <typename R>
 RL_HD void rl_rotate_tiny(R& sn, R& cs, R d) {
     if constexpr (sizeof(R) == 4) {
         const R d2 = d * d;
         const R t = d2 * (R)(-1.0 / 6);
         const R sd = d + d * t;
-        const R cd = (R)1 + d2 * ((R)-0.5 + d2 * (R)(1.0 / 24));
+        const R cd = (R)1 + d2 * (R)-0.5;
         const R s = sn * cd + cs * sd;
         const R c = cs * cd - sn * sd;
         sn = s;
