@@ -201,16 +201,25 @@ def main():
     timed_events = []
     host_stamps = []   # host clock at the phase boundaries (enqueue side), for RLLAB_BENCH_HOSTTIMES=1
 
-    def iteration(itr, timed):
+    pending = {}
+
+    def launch_rollout(itr):
+        e0, e1 = ev(), ev()
+        e0.record()
+        paths = algo.sampler.obtain_samples(itr)        # one asynchronous launch
+        e1.record()
+        return e0, e1, paths
+
+    def iteration(itr, timed, prefetch_next):
         # events only: per-phase times are read after the timed region, so the loop carries no
-        # measurement synchronisation of its own
+        # measurement synchronisation of its own.  As in BatchPolopt.train_iteration, the NEXT iteration's rollout
+        # is enqueued right after the update, before the host writes this iteration's log -- except across the
+        # boundaries of the timed region, which therefore contains exactly K rollouts, K process_samples, K updates.
         h = [time.perf_counter()]
-        e = [ev() for _ in range(4)]
-        e[0].record()
+        e = [None, None, ev(), ev()]
         h.append(time.perf_counter())
-        paths = algo.sampler.obtain_samples(itr)
+        e[0], e[1], paths = pending.pop(itr) if itr in pending else launch_rollout(itr)
         h.append(time.perf_counter())
-        e[1].record()
         samples = algo.sampler.process_samples(itr, paths)
         algo.log_diagnostics(paths)
         h.append(time.perf_counter())
@@ -218,6 +227,8 @@ def main():
         algo.optimize_policy(itr, samples)
         h.append(time.perf_counter())
         e[3].record()
+        if prefetch_next:
+            pending[itr + 1] = launch_rollout(itr + 1)
         last["samples"] = samples
         logger.dump_tabular()
         h.append(time.perf_counter())
@@ -226,7 +237,7 @@ def main():
             host_stamps.append(h)
 
     for w in range(args.warmup):
-        iteration(w, False)
+        iteration(w, False, w + 1 < args.warmup)
     # a generation-2 pass of Python's cyclic GC walks every object torch has created (~35 ms here)
     # and would land inside one timed iteration: collect now and freeze the survivors
     import gc
@@ -239,7 +250,7 @@ def main():
     D.reset_accounting(timing=False)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        iteration(args.warmup + k, True)
+        iteration(args.warmup + k, True, k + 1 < args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -255,7 +266,7 @@ def main():
         D.reset_accounting(timing=True)
         extra = 3
         for k in range(extra):
-            iteration(args.warmup + args.steps + k, False)
+            iteration(args.warmup + args.steps + k, False, False)
         torch.cuda.synchronize()
         collective_ms_per_iter = D.accounting()["seconds"] * 1e3 / extra
         D.reset_accounting(timing=False)

@@ -126,6 +126,9 @@ class BatchPolopt(RLAlgorithm):
             samples_data = self.sampler.process_samples(itr, paths)
             self.log_diagnostics(paths)
             self.optimize_policy(itr, samples_data)
+            # the next rollout depends on nothing below: start it before the host turns to snapshot and log
+            if itr + 1 < self.n_itr and hasattr(self.sampler, "prefetch") and not self.store_paths:
+                self.sampler.prefetch(itr + 1)
             logger.log("saving snapshot...")
             params = self.get_itr_snapshot(itr, samples_data)
             self.current_itr = itr + 1

@@ -38,12 +38,6 @@ class VectorizedSampler(BaseSampler):
         self.last_sample_time = None
         self.last_num_samples = None
 
-    def __getstate__(self):
-        d = dict(self.__dict__)
-        d["vec_env"] = None
-        d.pop("_step_graph", None)
-        return d
-
     def start_worker(self):
         algo = self.algo
         n_envs = self.n_envs
@@ -61,9 +55,33 @@ class VectorizedSampler(BaseSampler):
         if self.vec_env is not None:
             self.vec_env.terminate()
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["vec_env"] = None
+        d.pop("_step_graph", None)
+        d.pop("_prefetched", None)
+        return d
+
+    def prefetch(self, itr):
+        """Enqueue iteration ``itr``'s rollout NOW (it is one asynchronous launch) and keep the lazy batch for
+        ``obtain_samples(itr)``: BatchPolopt calls this right after the parameter update, so the device starts the
+        next rollout while the host still writes the previous iteration's log lines and snapshot.  The batch is
+        only handed out if the parameters have not changed in between."""
+        if getattr(self, "_prefetched", None) is not None and self._prefetched[0] == itr:
+            return
+        self._prefetched = None
+        paths = self.obtain_samples(itr)
+        self._prefetched = (itr, self.algo.policy.param_version() if hasattr(self.algo.policy, "param_version")
+                            else None, paths)
+
     def obtain_samples(self, itr):
         algo = self.algo
         policy = algo.policy
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None:
+            self._prefetched = None
+            if pre[0] == itr and pre[1] is not None and pre[1] == policy.param_version():
+                return pre[2]
         T = algo.max_path_length
         t_start = time.time()
         graphable = getattr(self.vec_env, "graphable", True)

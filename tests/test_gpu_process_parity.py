@@ -400,3 +400,43 @@ def test_forward_progress_from_stats_kernel_matches_path_index(quiet_logger):
     tab = logger.get_tabular()
     assert np.isclose(float(tab["AverageForwardProgress"]), want[0]) and np.isclose(float(tab["StdForwardProgress"]), want[3])
     logger.dump_tabular()
+
+
+def test_prefetched_rollout_changes_nothing(quiet_logger, monkeypatch):
+    """BatchPolopt.train enqueues iteration k + 1's rollout right after update k (sampler.prefetch), before the host
+    writes log and snapshot: same launches in the same order -- parameters and every logged number are identical to
+    the run that launches the rollout at the top of the next iteration."""
+    from rllab_amd.algos.trpo import TRPO
+    from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.misc import ext, logger
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.sampler.vectorized_sampler import VectorizedSampler
+
+    def run(prefetch):
+        ext.set_seed(4)
+        env = normalize(SwimmerEnv())
+        pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+        algo = TRPO(env=env, policy=pol, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=64 * 50,
+                    max_path_length=50, n_itr=4, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=64, seed=9))
+        calls = []
+        orig = VectorizedSampler.prefetch
+        if prefetch:
+            monkeypatch.setattr(VectorizedSampler, "prefetch", lambda self, itr: (calls.append(itr), orig(self, itr))[1])
+        else:
+            monkeypatch.setattr(VectorizedSampler, "prefetch", lambda self, itr: calls.append(("skipped", itr)))
+        rows = []
+        orig_dump = logger.dump_tabular
+        monkeypatch.setattr(logger, "dump_tabular", lambda *a, **k: (rows.append(logger.get_tabular()), orig_dump(*a, **k))[1])
+        algo.train()
+        monkeypatch.setattr(logger, "dump_tabular", orig_dump)
+        monkeypatch.setattr(VectorizedSampler, "prefetch", orig)
+        return pol.get_param_values(), rows, calls
+    th_a, rows_a, calls_a = run(True)
+    th_b, rows_b, calls_b = run(False)
+    assert calls_a == [1, 2, 3] and calls_b == [("skipped", 1), ("skipped", 2), ("skipped", 3)]
+    assert np.array_equal(th_a, th_b)
+    for ra, rb in zip(rows_a, rows_b):
+        for k in ("AverageReturn", "LossBefore", "LossAfter", "MeanKL", "Entropy"):
+            assert ra[k] == rb[k], (k, ra[k], rb[k])
