@@ -143,7 +143,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if args.gpus > torch.cuda.device_count():
+        # (RLLAB_DIST_BACKEND=gloo is the test mode in which ranks may share a device)
+        if args.gpus > torch.cuda.device_count() and os.environ.get("RLLAB_DIST_BACKEND", "nccl") == "nccl":
             sys.exit("bench.py --gpus %d: this node has %d GPUs" % (args.gpus, torch.cuda.device_count()))
         cmd = self_launch_argv(args.gpus, sys.argv[1:])
         sys.stderr.write("[bench] launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))

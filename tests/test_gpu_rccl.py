@@ -40,3 +40,24 @@ def test_bench_iteration_over_rccl_single_rank():
     assert forced["collective_bytes_per_iter"] < 1 << 20
     assert forced["collective_ms_per_iter"] is not None and 0 < forced["collective_ms_per_iter"] < 50
     assert forced["value"] > 0 and forced["config"]["n_envs_per_gpu"] == 512
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run
+    (two ranks, rendezvous on 127.0.0.1), the ranks shard the envs and rank 0 prints ONE JSON line that reports what
+    torch.distributed saw.  The GPU box has one device, so the ranks share it over gloo (the test backend); on an
+    8-GPU node the same command runs one rank per GPU over RCCL."""
+    env = dict(os.environ, RLLAB_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--n-envs", "256"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT,
+                       universal_newlines=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["config"]["samples_per_iteration"] == 2 * 256 * 500 and d["config"]["parallelism"] == "env-sharded dp2"
+    assert 12 <= d["collectives_per_iter"] <= 40 and d["collective_ms_per_iter"] > 0
+    assert d["value"] > 0 and "cpu_baseline" not in d
