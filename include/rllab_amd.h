@@ -72,6 +72,9 @@ int rl_env_action_bounds(int kind, float* lb_host, float* ub_host);
  *   obs_noise        Box2DEnv(obs_noise=..): observation + obs_noise * N(0,1) entry-wise (box2d_env.py:194-218)
  *   frame_skip       Box2DEnv(frame_skip=..): world steps per env step; 0 = the env's default
  *   flags            RL_CFG_* below
+ *   link_len         DoublePendulumEnv: length of both links; the reference draws it once per env object when
+ *                    template_args = {noise: True} (double_pendulum_env.py:17-21), else 1.  0 = the model's.
+ *   reserved         0
  *   action_noise_z   DEVICE pointer or NULL: injected N(0,1) draws of the action noise (parity runs);
  *                    rl_vecenv_step: float[act_dim][n], rl_rollout_gaussian_mlp: float[T][act_dim][n].
  *                    NULL = Philox4x32-10 keyed (seed; env, step, ACT_NOISE)
@@ -84,6 +87,8 @@ typedef struct rl_env_cfg {
     float obs_noise;
     int32_t frame_skip;
     int32_t flags;
+    float link_len;
+    float reserved;
     const float* action_noise_z;
     const float* obs_noise_z;
 } rl_env_cfg;

@@ -43,6 +43,7 @@ int step_t(R* s, const R* a, int normalize, R* obs, R* reward, int* done) {
 struct OracleCfg {
     double ctrl_cost_coeff, alive_coeff, action_noise, obs_noise;
     int frame_skip, flags;
+    double link_len;
 };
 
 template <class E, typename R>
@@ -53,6 +54,7 @@ rl::EnvCfgT<R> cfg_of(const OracleCfg* c) {
         o.action_noise = (R)c->action_noise; o.obs_noise = (R)c->obs_noise;
         if (c->frame_skip > 0) o.frame_skip = c->frame_skip;
         o.flags = c->flags;
+        if (c->link_len > 0.0) o.link_len = (R)c->link_len;
     }
     return o;
 }
@@ -61,12 +63,16 @@ template <class E>
 int default_cfg_t(OracleCfg* c) {
     const rl::EnvCfgT<double> d = rl::default_cfg<E, double>();
     c->ctrl_cost_coeff = d.ctrl_cost_coeff; c->alive_coeff = d.alive_coeff; c->action_noise = 0.0; c->obs_noise = 0.0;
-    c->frame_skip = d.frame_skip; c->flags = 0;
+    c->frame_skip = d.frame_skip; c->flags = 0; c->link_len = d.link_len;
     return 0;
 }
 
 template <class E, typename R>
-int reset_cfg_t(R* s, const R* draws, const OracleCfg* c) { E::template reset<R>(s, draws, c ? c->flags : 0); return 0; }
+int reset_cfg_t(R* s, const R* draws, const OracleCfg* c) {
+    const rl::EnvCfgT<R> k = cfg_of<E, R>(c);
+    E::template reset<R>(s, draws, k.flags, k.link_len);
+    return 0;
+}
 
 // Env.step under options: zact = the N(0,1) draws of the action noise (read only when action_noise != 0)
 template <class E, typename R>
@@ -122,7 +128,7 @@ int vec_step_t(int n, int normalize, float scale_reward, int max_path_length, in
         if (max_path_length > 0 && t >= max_path_length) dn = true;
         if (dn && auto_reset) {
             for (int k = 0; k < E::RESET_DRAWS; ++k) d[k] = reset_draws[(size_t)k * n + i];
-            E::template reset<float>(s, d, cfg.flags);
+            E::template reset<float>(s, d, cfg.flags, cfg.link_len);
             E::template observe<float>(s, o);
             t = 0;
         }
@@ -148,7 +154,7 @@ int vec_reset_t(int n, float* state, int32_t* ts, const uint8_t* mask, const flo
         float s[E::STATE], o[E::OBS], d[E::RESET_DRAWS], zo[E::OBS];
         for (int k = 0; k < E::STATE; ++k) s[k] = state[(size_t)k * n + i];
         for (int k = 0; k < E::RESET_DRAWS; ++k) d[k] = draws[(size_t)k * n + i];
-        E::template reset<float>(s, d, cfg.flags);
+        E::template reset<float>(s, d, cfg.flags, cfg.link_len);
         E::template observe<float>(s, o);
         if (cfg.obs_noise != 0.0f) {
             for (int k = 0; k < E::OBS; ++k) zo[k] = obs_z[(size_t)k * n + i];

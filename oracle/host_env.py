@@ -49,7 +49,7 @@ class OracleCfg(ctypes.Structure):
     """Env options (struct OracleCfg of env_host.cpp; the C ABI's rl_env_cfg without the injected-draw pointers)."""
     _fields_ = [("ctrl_cost_coeff", ctypes.c_double), ("alive_coeff", ctypes.c_double),
                 ("action_noise", ctypes.c_double), ("obs_noise", ctypes.c_double),
-                ("frame_skip", ctypes.c_int), ("flags", ctypes.c_int)]
+                ("frame_skip", ctypes.c_int), ("flags", ctypes.c_int), ("link_len", ctypes.c_double)]
 
 
 CFG_POLE_FOLLOWS_CART, CFG_FIXED_START = 1, 2

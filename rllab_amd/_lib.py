@@ -39,7 +39,7 @@ class EnvCfg(ctypes.Structure):
     _fields_ = [
         ("ctrl_cost_coeff", ctypes.c_float), ("alive_coeff", ctypes.c_float), ("action_noise", ctypes.c_float),
         ("obs_noise", ctypes.c_float), ("frame_skip", ctypes.c_int32), ("flags", ctypes.c_int32),
-        ("action_noise_z", ctypes.c_void_p), ("obs_noise_z", ctypes.c_void_p),
+        ("link_len", ctypes.c_float), ("reserved", ctypes.c_float), ("action_noise_z", ctypes.c_void_p), ("obs_noise_z", ctypes.c_void_p),
     ]
 
 

@@ -78,7 +78,7 @@ struct Cartpole {
     // joint starts violated by |x| and is pulled together by the position solver.
     template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, 1); }
 
-    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0, R /*link_len*/ = (R)1) {
         const R b0 = (R)2.4, b1 = (R)4.0, b2 = (R)0.2, b3 = (R)4.0, rr = (R)0.05;
         R lo0 = -rr * b0, lo1 = -rr * b1, lo2 = -rr * b2, lo3 = -rr * b3;
         R xpos = lo0 + u[0] * (rr * b0 - lo0);
@@ -268,7 +268,7 @@ struct Cartpole {
 struct CartpoleSwingup : Cartpole {
     static constexpr int KIND = 4;
 
-    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0, R /*link_len*/ = (R)1) {
         const R PI_ = (R)3.14159265358979323846;
         const R lo0 = (R)-1, lo1 = (R)-2, lo2 = PI_ - (R)1, lo3 = (R)-3;
         const R hi0 = (R)1, hi1 = (R)2, hi2 = PI_ + (R)1, hi3 = (R)3;

@@ -101,7 +101,7 @@ struct HalfCheetah {
     // qpos = init + 0.01 N(0,1), qvel = 0.1 N(0,1) in MuJoCo order [x, z, rooty, joints]
     template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, 1); }
 
-    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0, R /*link_len*/ = (R)1) {
         s[0] = (R)0.7 + z[1] * (R)0.01;   // absolute torso height
         s[1] = z[0] * (R)0.01;            // x
         s[9] = z[10] * (R)0.1;            // zdot

@@ -56,6 +56,24 @@ struct DoublePendulum {
         ub[0] = C<R>::act_ub;
     }
 
+    // Link geometry.  Both links are boxes 0.1 x link_len of density 5 hinged at one end (double_pendulum.xml.mako:9-29);
+    // link_len is 1 unless DoublePendulumEnv(template_args=dict(noise=True)) drew another (double_pendulum_env.py:17-21).
+    // len == 1 takes the compile-time constants, so the default keeps its bits.
+    template <typename R> struct Geo { R len, half, inv_m, inv_i; };
+    template <typename R> RL_HD static Geo<R> geo(R len) {
+        Geo<R> g;
+        if (len == (R)1) {
+            g.len = (R)1; g.half = C<R>::half; g.inv_m = C<R>::inv_m; g.inv_i = C<R>::inv_i;
+        } else {
+            const R mass = (R)5 * (R)0.1 * len;                         // density * width * length
+            g.len = len;
+            g.half = (R)0.5 * len;
+            g.inv_m = (R)1 / mass;
+            g.inv_i = (R)12 / (mass * ((R)0.01 + len * len));           // box about its centre: m (w^2 + l^2) / 12
+        }
+        return g;
+    }
+
     template <typename R> RL_HD static void solve22(R k11, R k12, R k22, R bx, R by, R& x, R& y) {
         R det = k11 * k22 - k12 * k12;
         if (det != (R)0) det = (R)1 / det;
@@ -68,15 +86,16 @@ struct DoublePendulum {
     // (0,0) and (0,-1): joint 2 starts violated and is pulled together by the position solver.
     template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, FRAME_SKIP); }
 
-    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0, R link_len = (R)1) {
+        const Geo<R> g = geo<R>(link_len);
         const R a1 = z[0] * (R)0.1, a2 = z[1] * (R)0.1, w1 = z[2] * (R)0.01, w2 = z[3] * (R)0.01;
         R s1, c1, s2, c2;
         rl_sincos(a1, s1, c1);
         rl_sincos(a2, s2, c2);
-        // centre = origin + R(a) * (0, -0.5)
-        s[0] = s1 * C<R>::half;            s[1] = -c1 * C<R>::half;
+        // centre = origin + R(a) * (0, -len / 2); link2's origin sits at (0, -len)
+        s[0] = s1 * g.half;            s[1] = -c1 * g.half;
         s[2] = a1; s[3] = (R)0; s[4] = (R)0; s[5] = w1;
-        s[6] = s2 * C<R>::half;            s[7] = (R)-1 - c2 * C<R>::half;
+        s[6] = s2 * g.half;            s[7] = -g.len - c2 * g.half;
         s[8] = a2; s[9] = (R)0; s[10] = (R)0; s[11] = w2;
     }
 
@@ -105,9 +124,9 @@ struct DoublePendulum {
     }
 
     // one b2World::Step(0.01, 20, 20) with the joint-2 motor set from `torque`
-    template <typename R> RL_HD static void world_step(R* s, R torque) {
+    template <typename R> RL_HD static void world_step(R* s, R torque, const Geo<R>& g = geo<R>((R)1)) {
         using K = C<R>;
-        const R h = K::dt, m = K::inv_m, ii = K::inv_i;
+        const R h = K::dt, m = g.inv_m, ii = g.inv_i;
         R x1 = s[0], y1 = s[1], a1 = s[2], vx1 = s[3], vy1 = s[4], w1 = s[5];
         R x2 = s[6], y2 = s[7], a2 = s[8], vx2 = s[9], vy2 = s[10], w2 = s[11];
         R j2x = s[12], j2y = s[13], jm = s[14], j1x = s[15], j1y = s[16];
@@ -122,8 +141,8 @@ struct DoublePendulum {
         rl_sincos(a1, s1, c1);
         rl_sincos(a2, s2, c2);
         // joint 2 (A = link1, B = link2): rA = q1*(0,-0.5), rB = q2*(0,0.5)
-        R rAx = s1 * K::half, rAy = -c1 * K::half;
-        R rBx = -s2 * K::half, rBy = c2 * K::half;
+        R rAx = s1 * g.half, rAy = -c1 * g.half;
+        R rBx = -s2 * g.half, rBy = c2 * g.half;
         R k11 = m + m + rAy * rAy * ii + rBy * rBy * ii;
         R k12 = -rAy * rAx * ii - rBy * rBx * ii;
         R k22 = m + m + rAx * rAx * ii + rBx * rBx * ii;
@@ -134,7 +153,7 @@ struct DoublePendulum {
         vx2 = vx2 + m * j2x; vy2 = vy2 + m * j2y;
         w2 = w2 + ii * ((rBx * j2y - rBy * j2x) + jm);
         // joint 1 (A = static track, B = link1): rB = q1*(0,0.5)
-        R tBx = -s1 * K::half, tBy = c1 * K::half;
+        R tBx = -s1 * g.half, tBy = c1 * g.half;
         R t11 = m + tBy * tBy * ii;
         R t12 = -tBy * tBx * ii;
         R t22 = m + tBx * tBx * ii;
@@ -187,8 +206,8 @@ struct DoublePendulum {
             rl_sincos(a2, s2, c2);
             bool ok2, ok1;
             {   // joint 2
-                R ax = s1 * K::half, ay = -c1 * K::half;
-                R bx = -s2 * K::half, by = c2 * K::half;
+                R ax = s1 * g.half, ay = -c1 * g.half;
+                R bx = -s2 * g.half, by = c2 * g.half;
                 R Cx = x2 + bx - x1 - ax, Cy = y2 + by - y1 - ay;
                 R err = rl_sqrt(Cx * Cx + Cy * Cy);
                 R p11 = m + m + ii * ay * ay + ii * by * by;
@@ -207,7 +226,7 @@ struct DoublePendulum {
                 // as updated by joint 2 in this iteration
                 R sn, cs;
                 rl_sincos(a1, sn, cs);
-                R bx = -sn * K::half, by = cs * K::half;
+                R bx = -sn * g.half, by = cs * g.half;
                 R Cx = x1 + bx, Cy = y1 + by;
                 R err = rl_sqrt(Cx * Cx + Cy * Cy);
                 R p11 = m + ii * by * by;
@@ -240,14 +259,17 @@ struct DoublePendulum {
         R applied = act;
         if (o.dact) applied = act + o.dact[0];                      // _inject_action_noise (box2d_env.py:219-226)
         const R torque = rl_clamp(applied, K::act_lb, K::act_ub);   // forward_dynamics clips (box2d_env.py:123-124)
-        for (int f = 0; f < o.frame_skip; ++f) world_step(s, torque);
-        // reward = -|tip - (0, 2)|, tip = link2.position - link_len*(sin a2, cos a2)
-        // (double_pendulum_env.py:43-58); link2.position = centre - R(a2)*(0,-0.5)
+        const Geo<R> g = geo<R>(o.link_len);
+        for (int f = 0; f < o.frame_skip; ++f) world_step(s, torque, g);
+        // reward = -|tip - (0, 2 link_len)|, tip = link2.position - link_len*(sin a2, cos a2)
+        // (double_pendulum_env.py:43-58); link2.position = centre - R(a2)*(0,-link_len/2)
         R s2, c2;
         rl_sincos(s[8], s2, c2);
-        const R ox = s[6] - s2 * K::half, oy = s[7] + c2 * K::half;
-        const R tx = ox - s2, ty = oy - c2;
-        const R dx = tx, dy = ty - (R)2;
+        const R ox = s[6] - s2 * g.half, oy = s[7] + c2 * g.half;
+        R tx, ty, goal;
+        if (g.len == (R)1) { tx = ox - s2; ty = oy - c2; goal = (R)2; }
+        else { tx = ox - g.len * s2; ty = oy - g.len * c2; goal = g.len * (R)2; }
+        const R dx = tx, dy = ty - goal;
         reward = -rl_sqrt(dx * dx + dy * dy);
         done = false;
         observe(s, obs);

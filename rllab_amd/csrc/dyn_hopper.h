@@ -46,7 +46,7 @@ struct Hopper {
     // [rootz, rootx, rooty, joints] and MuJoCo sign convention for the joints
     template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.01, 1.0, 1); }
 
-    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0, R /*link_len*/ = (R)1) {
         s[0] = (R)1.25 + z[0] * (R)0.01;
         s[1] = z[1] * (R)0.01;
         s[2] = z[2] * (R)0.01;

@@ -62,7 +62,7 @@ struct InvertedDoublePendulum {
     // random_start: qpos[1] = (U[0,1) - 0.5) * 40 / 180 * pi, everything else 0   (:47-58)
     template <typename R> RL_HD static StepOpts<R> default_opts() { return make_opts<R>(0.0, 0.0, 1); }
 
-    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* u, int flags = 0, R /*link_len*/ = (R)1) {
         RL_UNROLL
         for (int i = 0; i < STATE; ++i) s[i] = (R)0;
         // random_start=False keeps the model's initial pose (inverted_double_pendulum_env.py:20,47-58)

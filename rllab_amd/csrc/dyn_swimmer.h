@@ -120,7 +120,7 @@ struct Swimmer {
 
     // MujocoEnv.reset_mujoco: qpos = init_qpos + 0.01*N(0,1), qvel = init_qvel + 0.1*N(0,1),
     // init_qpos = init_qvel = 0 (mujoco_env.py:109-116)
-    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0) {
+    template <typename R> RL_HD static void reset(R* s, const R* z, int /*flags*/ = 0, R /*link_len*/ = (R)1) {
         RL_UNROLL
         for (int i = 0; i < 5; ++i) {
             s[i] = z[i] * (R)0.01;

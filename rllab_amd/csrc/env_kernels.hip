@@ -32,7 +32,7 @@ __device__ __forceinline__ void store_state(float* __restrict__ state, int n, in
 
 template <class Env>
 __device__ __forceinline__ void reset_one(float* s, const float* __restrict__ draws, int n, int i,
-                                          uint64_t seed, uint32_t env_global, uint64_t step, int flags) {
+                                          uint64_t seed, uint32_t env_global, uint64_t step, const EnvCfg& cfg) {
     float d[Env::RESET_DRAWS];
     if (draws) {
 #pragma unroll
@@ -40,7 +40,7 @@ __device__ __forceinline__ void reset_one(float* s, const float* __restrict__ dr
     } else {
         philox_draws<Env::RESET_DRAWS, Env::RESET_NORMAL>(d, seed, env_global, step, RNG_RESET);
     }
-    Env::template reset<float>(s, d, flags);
+    Env::template reset<float>(s, d, cfg.flags, cfg.link_len);
 }
 
 // N(0,1) draws of one env for one transition: slice `z` (a [COUNT][n] plane set injected by the caller -- parity
@@ -90,7 +90,7 @@ vecenv_reset_kernel(int n, float* __restrict__ state, int32_t* __restrict__ ts,
     if (mask && !mask[i]) return;
     float s[Env::STATE];
     load_state<Env>(state, n, i, s);  // persisted solver state survives reset
-    reset_one<Env>(s, draws, n, i, seed, (uint32_t)(env_offset + i), step, cfg.flags);
+    reset_one<Env>(s, draws, n, i, seed, (uint32_t)(env_offset + i), step, cfg);
     store_state<Env>(state, n, i, s);
     ts[i] = 0;
     float o[Env::OBS];
@@ -159,7 +159,7 @@ vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length
     int t = ts[i] + 1;
     if (max_path_length > 0 && t >= max_path_length) d = true;
     if (d && auto_reset) {
-        reset_one<Env>(s, reset_draws, n, i, seed, env_global, step, cfg.flags);
+        reset_one<Env>(s, reset_draws, n, i, seed, env_global, step, cfg);
         Env::template observe<float>(s, o);
         t = 0;
     }
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
     int ts = a.ts[i];
     const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
     if (a.reset_at_start) {
-        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg.flags);
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg);
         ts = 0;
     }
     float o[Env::OBS];
@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
-            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg.flags);
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg);
             Env::template observe<float>(s, o);
             ts = 0;
         }
@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     int ts = a.ts[i];
     const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
     if (a.reset_at_start) {
-        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg.flags);
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg);
         ts = 0;
     }
     float o[Env::OBS];
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
-            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg.flags);
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg);
             Env::template observe<float>(s, o);
             ts = 0;
         }
@@ -728,6 +728,9 @@ static int device_cfg(const rl_env_cfg* cfg, EnvCfg& c) {
     c.action_noise = cfg->action_noise; c.obs_noise = cfg->obs_noise;
     if (cfg->frame_skip > 0) c.frame_skip = cfg->frame_skip;
     c.flags = cfg->flags;
+    if (cfg->link_len < 0.0f || cfg->link_len > 8.0f)
+        return set_error(RL_ERR_ARG, "rl_env_cfg.link_len = %g (0 = the model's, else (0, 8])", (double)cfg->link_len);
+    if (cfg->link_len > 0.0f) c.link_len = cfg->link_len;
     return 0;
 }
 
@@ -840,6 +843,7 @@ static void fill_default_cfg(rl_env_cfg* cfg) {
     const EnvCfg c = default_cfg<Env, float>();
     cfg->ctrl_cost_coeff = c.ctrl_cost_coeff; cfg->alive_coeff = c.alive_coeff;
     cfg->action_noise = 0.0f; cfg->obs_noise = 0.0f; cfg->frame_skip = c.frame_skip; cfg->flags = 0;
+    cfg->link_len = c.link_len; cfg->reserved = 0.0f;
     cfg->action_noise_z = nullptr; cfg->obs_noise_z = nullptr;
 }
 

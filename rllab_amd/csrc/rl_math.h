@@ -201,6 +201,7 @@ template <typename R>
 struct EnvCfgT {
     R ctrl_cost_coeff, alive_coeff, action_noise, obs_noise;
     int frame_skip, flags;
+    R link_len;                  // DoublePendulumEnv: length of both links (1 unless template_args noise drew another)
 };
 using EnvCfg = EnvCfgT<float>;
 enum EnvCfgFlags : int {
@@ -212,11 +213,13 @@ struct StepOpts {
     R ctrl_cost_coeff, alive_coeff;
     int frame_skip;
     const R* dact;               // per-dimension additive perturbation of the applied action, or null
+    R link_len;
 };
 template <typename R>
 RL_HD StepOpts<R> make_opts(double ctrl_cost_coeff, double alive_coeff, int frame_skip) {
     StepOpts<R> o;
     o.ctrl_cost_coeff = (R)ctrl_cost_coeff; o.alive_coeff = (R)alive_coeff; o.frame_skip = frame_skip; o.dact = nullptr;
+    o.link_len = (R)1;
     return o;
 }
 // the options an env runs with when the caller gives none
@@ -225,13 +228,14 @@ RL_HD EnvCfgT<R> default_cfg() {
     const StepOpts<R> o = Env::template default_opts<R>();
     EnvCfgT<R> c;
     c.ctrl_cost_coeff = o.ctrl_cost_coeff; c.alive_coeff = o.alive_coeff; c.action_noise = (R)0; c.obs_noise = (R)0;
-    c.frame_skip = o.frame_skip; c.flags = 0;
+    c.frame_skip = o.frame_skip; c.flags = 0; c.link_len = (R)1;
     return c;
 }
 template <typename R>
 RL_HD StepOpts<R> opts_from_cfg(const EnvCfgT<R>& c) {
     StepOpts<R> o;
     o.ctrl_cost_coeff = c.ctrl_cost_coeff; o.alive_coeff = c.alive_coeff; o.frame_skip = c.frame_skip; o.dact = nullptr;
+    o.link_len = c.link_len;
     return o;
 }
 // Box2DEnv._inject_action_noise / MujocoEnv.inject_action_noise (box2d_env.py:219-226, mujoco_env.py:175-182):

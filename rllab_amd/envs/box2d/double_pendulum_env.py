@@ -1,5 +1,7 @@
 """DoublePendulumEnv (API of rllab/envs/box2d/double_pendulum_env.py:11-61); dynamics in
 csrc/dyn_double_pendulum.h (``rl::DoublePendulum``)."""
+import numpy as np
+
 from rllab_amd import _lib
 from rllab_amd.core.serializable import Serializable
 from rllab_amd.envs.box2d.box2d_env import Box2DEnv
@@ -14,9 +16,15 @@ class DoublePendulumEnv(Box2DEnv, Serializable):
         Serializable.quick_init(self, locals())
         kwargs = dict(kwargs)
         kwargs["frame_skip"] = kwargs.get("frame_skip", 2)
-        if kwargs.get("template_args", {}) and kwargs["template_args"].get("noise", False):
-            raise NotImplementedError("DoublePendulumEnv: a randomised link length (template_args noise) changes the "
-                                      "world's masses and anchors; only link_len = 1 is compiled into the kernel")
-        kwargs.pop("template_args", None)
-        self.link_len = 1
+        # template_args = {noise: True}: one random link length per env object, drawn from np.random at construction
+        # (double_pendulum_env.py:17-21); masses, inertias and anchors follow it inside the kernel (rl_env_cfg.link_len)
+        targs = dict(kwargs.pop("template_args", None) or {})
+        noise = bool(targs.pop("noise", False))
+        link_len = targs.pop("link_len", None)              # engine extension: name the length instead of drawing it
+        if targs:
+            raise NotImplementedError("DoublePendulumEnv: template_args %r have no kernel" % (sorted(targs),))
+        if link_len is None:
+            link_len = (np.random.rand() - 0.5) + 1 if noise else 1
+        self.link_len = link_len
+        kwargs["link_len"] = float(link_len)
         super(DoublePendulumEnv, self).__init__(None, *args, **kwargs)

@@ -15,6 +15,7 @@ CASES = [
     (0, dict(action_noise=0.3)), (0, dict(obs_noise=0.05)), (0, dict(frame_skip=3)), (0, dict(flags=1)),
     (0, dict(action_noise=0.2, obs_noise=0.1, frame_skip=2, flags=1)),
     (1, dict(action_noise=0.1, obs_noise=0.02)), (1, dict(frame_skip=1)), (1, dict(frame_skip=4)),
+    (1, dict(link_len=1.37)), (1, dict(link_len=0.6, action_noise=0.1, frame_skip=3)),
     (4, dict(action_noise=0.5, obs_noise=0.3, flags=1)),
     (2, dict(ctrl_cost_coeff=0.7)), (2, dict(action_noise=0.25)), (2, dict(ctrl_cost_coeff=0.0, action_noise=0.1)),
     (3, dict(action_noise=0.4)),
@@ -65,6 +66,7 @@ def test_vecenv_step_with_options_bit_exact(kind, cfg):
 @pytest.mark.parametrize("kind,cfg,hidden", [
     (0, dict(action_noise=0.2, obs_noise=0.05, frame_skip=2, flags=1), (32, 32)),
     (1, dict(action_noise=0.1, obs_noise=0.02), (32, 32)),
+    (1, dict(link_len=0.75, action_noise=0.05), (32, 32)),
     (2, dict(ctrl_cost_coeff=0.4, action_noise=0.15), (32, 32)),      # the lane-group (quad) kernel
     (2, dict(ctrl_cost_coeff=0.4, action_noise=0.15), (64, 64)),
     (3, dict(action_noise=0.3), (64, 64)),

@@ -300,6 +300,16 @@ def test_unsupported_options_fail_loudly():
     assert sw2.ctrl_cost_coeff == 0.5 and sw2.action_noise == 0.1
     cp = pickle.loads(pickle.dumps(CartpoleEnv(reset_pole_follows_cart=True, obs_noise=0.2)))
     assert cp.reset_pole_follows_cart and cp._cfg["flags"] == 1 and cp.obs_noise == 0.2
+    from rllab_amd.envs.box2d.double_pendulum_env import DoublePendulumEnv
+    np.random.seed(11)
+    want = (np.random.rand() - 0.5) + 1
+    np.random.seed(11)
+    dp = DoublePendulumEnv(template_args=dict(noise=True))          # one random link length per env object (:17-21)
+    assert dp.link_len == want and 0.5 <= dp.link_len < 1.5 and abs(dp._cfg["link_len"] - want) < 1e-12
+    assert pickle.loads(pickle.dumps(DoublePendulumEnv(template_args=dict(link_len=1.25)))).link_len == 1.25
+    assert DoublePendulumEnv().link_len == 1 and DoublePendulumEnv().frame_skip == 2
+    with pytest.raises(NotImplementedError):
+        DoublePendulumEnv(template_args=dict(gravity=3))
     ad = GaussianMLPPolicy(_spec(4, 1), adaptive_std=True)     # the reference's tests/regression_tests/test_issue_3.py
     assert ad.state_dependent_std and ad.kernel_layout() is None
     # NPO's default optimizer is the reference's PenaltyLbfgsOptimizer (npo.py:27-30)

@@ -138,17 +138,21 @@ def test_cartpole_reward_done_and_reset_contract():
     assert np.array_equal(oa, ob) and ra == rb
 
 
-def test_double_pendulum_island_solver_tracks_lagrangian():
+@pytest.mark.parametrize("L", [1.0, 0.62, 1.45])
+def test_double_pendulum_island_solver_tracks_lagrangian(L):
     """Two hanging links + motor torque on the second joint: the Box2D-style step must follow
-    semi-implicit Euler on the Lagrange equations (autodiff, float64) to O(dt * w^2)."""
+    semi-implicit Euler on the Lagrange equations (autodiff, float64) to O(dt * w^2).  L = the link length
+    (1 in the XML; DoublePendulumEnv(template_args=dict(noise=True)) draws it from [0.5, 1.5),
+    double_pendulum_env.py:17-21): boxes 0.1 x L of density 5, hinged at their ends."""
     import torch
-    m, I, g, h = 0.5, 0.5 * 1.01 / 12, 10.0, 0.01
+    m, g, h = 5.0 * 0.1 * L, 10.0, 0.01
+    I = m * (0.1 ** 2 + L ** 2) / 12
 
     def energy_terms(q, qd):
         a1, a2 = q
-        p1 = torch.stack([0.5 * torch.sin(a1), -0.5 * torch.cos(a1)])
-        o2 = torch.stack([torch.sin(a1), -torch.cos(a1)])
-        p2 = o2 + torch.stack([0.5 * torch.sin(a2), -0.5 * torch.cos(a2)])
+        p1 = torch.stack([0.5 * L * torch.sin(a1), -0.5 * L * torch.cos(a1)])
+        o2 = torch.stack([L * torch.sin(a1), -L * torch.cos(a1)])
+        p2 = o2 + torch.stack([0.5 * L * torch.sin(a2), -0.5 * L * torch.cos(a2)])
         return p1, p2
 
     def acc(q, qd, tau):
@@ -168,8 +172,9 @@ def test_double_pendulum_island_solver_tracks_lagrangian():
         c = torch.autograd.functional.jacobian(mom, q) @ qd - torch.autograd.functional.jacobian(lambda z: T(z, qd), q)
         Q = -torch.autograd.functional.jacobian(V, q) + torch.tensor([-tau, tau], dtype=torch.float64)
         return torch.linalg.solve(M, Q - c).numpy()
-    e = H.HostEnv(1, np.float64)
+    e = H.HostEnv(1, np.float64, cfg=dict(link_len=L))
     e.reset(np.zeros(4))
+    assert np.allclose(e.state[[0, 1, 6, 7]], [0.0, -0.5 * L, 0.0, -1.5 * L], atol=1e-15)
     q, qd = np.zeros(2), np.zeros(2)
     for t in range(6):
         o, r, d = e.step([1.0])             # 2 world steps of 0.01 s each
@@ -179,13 +184,14 @@ def test_double_pendulum_island_solver_tracks_lagrangian():
             q = q + h * qd
         got = np.array([e.state[2], e.state[8], e.state[5], e.state[11]])
         want = np.array([q[0], q[1], qd[0], qd[1]])
-        assert np.abs(got - want).max() < (2e-5 if t == 0 else 1e-3), (t, got, want)
+        # the error is O(dt * w^2): shorter links are lighter and spin up faster under the same 50 N m
+        assert np.abs(got - want).max() < (2e-5 if t == 0 else 1e-3) * max(1.0, L ** -2), (t, got, want)
         assert not d
     assert abs(q[1]) > 0.005                 # the torque moved the second link
-    # reward = -|tip - (0,2)| with the reference's tip formula (double_pendulum_env.py:43-58)
+    # reward = -|tip - (0, 2 L)| with the reference's tip formula (double_pendulum_env.py:43-58)
     s = e.state
-    ox, oy = s[6] - np.sin(s[8]) * 0.5, s[7] + np.cos(s[8]) * 0.5
-    assert np.isclose(r, -np.hypot(ox - np.sin(s[8]), oy - np.cos(s[8]) - 2.0), atol=1e-12)
+    ox, oy = s[6] - np.sin(s[8]) * 0.5 * L, s[7] + np.cos(s[8]) * 0.5 * L
+    assert np.isclose(r, -np.hypot(ox - L * np.sin(s[8]), oy - L * np.cos(s[8]) - 2.0 * L), atol=1e-12)
 
 
 def test_cheetah_constants_header_is_generated_from_the_mjcf_numbers():
