@@ -177,15 +177,15 @@ def test_double_pendulum_island_solver_tracks_lagrangian(L):
     assert np.allclose(e.state[[0, 1, 6, 7]], [0.0, -0.5 * L, 0.0, -1.5 * L], atol=1e-15)
     q, qd = np.zeros(2), np.zeros(2)
     for t in range(6):
-        o, r, d = e.step([1.0])             # 2 world steps of 0.01 s each
+        tau = 1.0 * L ** 3                  # same angular accelerations at every length (inertia ~ L^3)
+        o, r, d = e.step([tau])             # 2 world steps of 0.01 s each
         for _ in range(2):
-            a = acc(q, qd, 1.0)
+            a = acc(q, qd, tau)
             qd = qd + h * a
             q = q + h * qd
         got = np.array([e.state[2], e.state[8], e.state[5], e.state[11]])
         want = np.array([q[0], q[1], qd[0], qd[1]])
-        # the error is O(dt * w^2): shorter links are lighter and spin up faster under the same 50 N m
-        assert np.abs(got - want).max() < (2e-5 if t == 0 else 1e-3) * max(1.0, L ** -2), (t, got, want)
+        assert np.abs(got - want).max() < (2e-5 if t == 0 else 1e-3) * max(1.0, 1.0 / L), (t, got, want)
         assert not d
     assert abs(q[1]) > 0.005                 # the torque moved the second link
     # reward = -|tip - (0, 2 L)| with the reference's tip formula (double_pendulum_env.py:43-58)
