@@ -11,8 +11,9 @@ imported from /root/reference behind oracle/ref_shim.py and every module the imp
 pulled in from that tree is copied byte for byte to the same relative path
 (``rllab/sampler/stateful_pool.py`` -> ``oracle/_ref/rllab/sampler/stateful_pool.py``).
 Plus the two acceptance scripts ``examples/trpo_{cartpole,swimmer}.py``
-(tests/test_examples_dropin.py runs them verbatim through the product's ``rllab``
-alias) and a MANIFEST.json with the sha256 of every staged file.
+(tests/test_gpu_reference_pins.py runs them verbatim through the product's ``rllab``
+alias), the reference's own test files of this path (tests/test_reference_tests_verbatim.py
+runs them verbatim against the engine) and a MANIFEST.json with the sha256 of every staged file.
 
 Used by
   * oracle/ref_sampler.py -- the ``cpu_baseline`` of bench.py, ``kind: "reference"``:
@@ -41,7 +42,11 @@ ROOTS = [
     "rllab.misc.logger", "rllab.misc.krylov", "rllab.algos.util", "rllab.baselines.linear_feature_baseline",
     "rllab.baselines.zero_baseline", "rllab.distributions.diagonal_gaussian",
 ]
-EXTRA_FILES = ["examples/trpo_cartpole.py", "examples/trpo_swimmer.py"]
+EXTRA_FILES = ["examples/trpo_cartpole.py", "examples/trpo_swimmer.py",
+               # the reference's own tests of this path, run verbatim against the engine
+               # (tests/test_reference_tests_verbatim.py)
+               "tests/test_sampler.py", "tests/test_stateful_pool.py", "tests/test_baselines.py",
+               "tests/regression_tests/test_issue_3.py"]
 
 
 def stage(verbose=True):
