@@ -318,10 +318,12 @@ void swim_compare(const R* state, const R* ctrl2, int nsub, R* out_scalar, R* ou
         Chain::LaneConst<R> consts[4];
         for (int b = 0; b < 4; ++b) {
             consts[b] = Chain::template lane_const<R>(b);
-            lanes[b].cs = b < 3 ? cs[b] : (R)1; lanes[b].sn = b < 3 ? sn[b] : (R)0;
+            lanes[b].set_direction(b < 3 ? cs[b] : (R)1, b < 3 ? sn[b] : (R)0);
             lanes[b].om = b < 3 ? om[b] : (R)0; lanes[b].th = b < 3 ? th[b] : (R)0;
-            lanes[b].rx = r4[0]; lanes[b].ry = r4[1]; lanes[b].vx = r4[2]; lanes[b].vy = r4[3];
+            lanes[b].r = rl::V2<R>{r4[0], r4[1]}; lanes[b].v = rl::V2<R>{r4[2], r4[3]};
         }
+        // the carried joint rate: own absolute rate - parent's (quad_perm PAR1: lane 0 reads the zero lane 3)
+        for (int b = 0; b < 4; ++b) lanes[b].qd = lanes[b].om - lanes[(b + 3) & 3].om;
         for (int it = 0; it < nsub; ++it) {
             std::vector<std::array<R, 4>> log;
             int n_points = -1;
@@ -338,16 +340,14 @@ void swim_compare(const R* state, const R* ctrl2, int nsub, R* out_scalar, R* ou
             for (int b = 0; b < 4; ++b) lanes[b] = result[b];
         }
         // back to (qpos, qvel) exactly as the rollout kernel does it
-        out_quad[0] = lanes[0].rx; out_quad[1] = lanes[0].ry; out_quad[5] = lanes[0].vx; out_quad[6] = lanes[0].vy;
+        out_quad[0] = lanes[0].r.x; out_quad[1] = lanes[0].r.y; out_quad[5] = lanes[0].v.x; out_quad[6] = lanes[0].v.y;
         for (int b = 0; b < 3; ++b) out_quad[2 + b] = lanes[b].th;
-        out_quad[7] = lanes[0].om;
-        out_quad[8] = lanes[1].om - lanes[0].om;
-        out_quad[9] = lanes[2].om - lanes[1].om;
-        for (int b = 0; b < 3; ++b) { out_quad[10 + b] = lanes[b].sn; out_quad[13 + b] = lanes[b].cs; }
+        for (int b = 0; b < 3; ++b) out_quad[7 + b] = lanes[b].qd;
+        for (int b = 0; b < 3; ++b) { out_quad[10 + b] = lanes[b].A.y; out_quad[13 + b] = lanes[b].A.x; }
         // the replicated root translation must agree on every lane of the quad
         for (int b = 1; b < 4; ++b)
-            if (!(lanes[b].rx == lanes[0].rx && lanes[b].ry == lanes[0].ry && lanes[b].vx == lanes[0].vx &&
-                  lanes[b].vy == lanes[0].vy)) out_quad[0] = out_quad[0] * (R)0 + (R)1e30;   // poison: caught by the test
+            if (!(lanes[b].r.x == lanes[0].r.x && lanes[b].r.y == lanes[0].r.y && lanes[b].v.x == lanes[0].v.x &&
+                  lanes[b].v.y == lanes[0].v.y)) out_quad[0] = out_quad[0] * (R)0 + (R)1e30;   // poison: caught by the test
         // role 3 is the zero lane the bodies read "no parent" / "no child" from
         if (!(lanes[3].om == (R)0)) out_quad[0] = out_quad[0] * (R)0 + (R)1e30;
     }

@@ -4,7 +4,7 @@
 //                         Used by the host oracle build, by the per-step VecEnv kernels and as the definition of the
 //                         env's arithmetic.
 //   swim_substep_quad   : four lanes per env (lane role b = body 0, 1, 2; lane 3 idles with zero constants).  Every
-//                         lane runs the same ~180-instruction stream on its own body, values cross lanes by
+//                         lane runs the same instruction stream on its own body, values cross lanes by
 //                         quad-permute moves, the 3x3 solve is replicated.  Used by the fused rollout, where a lone
 //                         wavefront per SIMD is bound by instruction issue: the per-env instruction stream shrinks
 //                         from ~260 to ~180 per sub-step and four times as many wavefronts share the work.
@@ -45,7 +45,7 @@ struct SwimChain {
     RL_HD static void fluid(R cs, R sn, R vpx, R vpy, R om, R visc_lin, R drag_ax, R drag_perp, R visc_ang, R drag_ang,
                             R& Fx, R& Fy, R& tz, R& ft_out) {
         const R vl = cs * vpx + sn * vpy;
-        const R vt = cs * vpy - sn * vpx;
+        const R vt = -sn * vpx + cs * vpy;              // (the lane-group program rotates with the pair (-sn, cs))
         const R fl = -(vl * (visc_lin + drag_ax * rl_abs(vl)));
         const R ft = -(vt * (visc_lin + drag_perp * rl_abs(vt)));
         Fx = cs * fl - sn * ft;
@@ -66,7 +66,7 @@ struct SwimChain {
     template <typename R>
     RL_HD static void couple(R cb, R sb, R cx, R sx, R sc, R ac, R& S, R& t) {
         const R cd = cb * cx + sb * sx;
-        const R sd = sx * cb - cx * sb;
+        const R sd = -sb * cx + cb * sx;
         S = sc * cd;
         t = ac * sd;
     }
@@ -191,13 +191,21 @@ struct SwimChain {
     }
 
     // ---- quad program ------------------------------------------------------------------------------------------------
+    // The x / y pairs of the planar dynamics travel as two-component vectors (rl_math.h V2): one v_pk_{mul,fma,add}_f32
+    // per pair on gfx950 (5 cycles for a lone wavefront against 2 x 4 for the scalar forms), operand swizzles and
+    // broadcasts ride in op_sel.  Rotations use the body direction A = (cs, sn) and its perpendicular Ap = (-sn, cs), so
+    // that no component needs a separate sign flip:  R(a, b) = A a + Ap b,  R^-1(a, b) = Ap.yx a + A.yx b.
     // per-lane constants, selected by the lane's role b = lane & 3 (role 3: all zero)
     template <typename R>
     struct LaneConst {
-        R jxo, cxb, db, visc_lin, drag_ax, drag_perp, visc_ang, drag_ang;
-        R lim_k, lim_b;      // joint-limit penalty of the hinge that carries body b (roles 0 and 3: none)
-        R scp, acp;                  // coupling constants to the partner p = b + 1 (mod 3)
-        R d_b, d_pq, d_p, d_q;       // diagonal of the 3x3 system in the cyclic order (role 3: identity)
+        V2<R> kj;                    // (-jxo, jxo): child joint offset, signed for (wlx, wly)
+        V2<R> kc;                    // (-cxb, cxb): centre offset, signed for (vpx, vpy)
+        V2<R> ksa;                   // (Sc, Ac) coupling constants to the partner p = b + 1 (mod 3)
+        V2<R> kdqp;                  // (d_q, d_p)
+        V2<R> kdrag;                 // (drag_ax, drag_perp)
+        R jxo, cxb, db, visc_lin, visc_ang, drag_ang;
+        R lim_k, lim_b;              // joint-limit penalty of the hinge that carries body b (roles 0 and 3: none)
+        R d_b, d_pq;                 // diagonal of the 3x3 system in the cyclic order (role 3: identity)
         int b;
     };
     template <typename R>
@@ -207,27 +215,31 @@ struct SwimChain {
         c.jxo = (R)(b == 0 ? jxo(0) : b == 1 ? jxo(1) : 0.0);
         c.cxb = (R)(b == 0 ? cxb(0) : b == 1 ? cxb(1) : b == 2 ? cxb(2) : 0.0);
         c.db = (R)(b == 0 ? db(0) : b == 1 ? db(1) : b == 2 ? db(2) : 0.0);
+        c.kj = V2<R>{-c.jxo, c.jxo};
+        c.kc = V2<R>{-c.cxb, c.cxb};
         const bool body = b < 3;
         c.visc_lin = body ? (R)Mdl::VISC_LIN : (R)0;
-        c.drag_ax = body ? (R)Mdl::DRAG_AX : (R)0;
-        c.drag_perp = body ? (R)Mdl::DRAG_PERP : (R)0;
+        c.kdrag = V2<R>{body ? (R)Mdl::DRAG_AX : (R)0, body ? (R)Mdl::DRAG_PERP : (R)0};
         c.visc_ang = body ? (R)Mdl::VISC_ANG : (R)0;
         c.drag_ang = body ? (R)Mdl::DRAG_ANG : (R)0;
         const bool hinge = (b == 1 || b == 2);
         c.lim_k = hinge ? (R)Mdl::limit_k() : (R)0;
         c.lim_b = hinge ? (R)Mdl::limit_b() : (R)0;
-        c.scp = (R)(b == 0 ? scc(0, 1) : b == 1 ? scc(1, 2) : b == 2 ? scc(2, 0) : 0.0);
-        c.acp = (R)(b == 0 ? acc(0, 1) : b == 1 ? acc(1, 2) : b == 2 ? acc(2, 0) : 0.0);
+        c.ksa = V2<R>{(R)(b == 0 ? scc(0, 1) : b == 1 ? scc(1, 2) : b == 2 ? scc(2, 0) : 0.0),
+                      (R)(b == 0 ? acc(0, 1) : b == 1 ? acc(1, 2) : b == 2 ? acc(2, 0) : 0.0)};
         c.d_b = (R)(b == 0 ? sdiag(0) : b == 1 ? sdiag(1) : b == 2 ? sdiag(2) : 1.0);
         c.d_pq = (R)(b == 0 ? dpq(0) : b == 1 ? dpq(1) : b == 2 ? dpq(2) : 1.0);
-        c.d_p = (R)(b == 0 ? sdiag(1) : b == 1 ? sdiag(2) : b == 2 ? sdiag(0) : 0.0);
-        c.d_q = (R)(b == 0 ? sdiag(2) : b == 1 ? sdiag(0) : b == 2 ? sdiag(1) : 0.0);
+        c.kdqp = V2<R>{(R)(b == 0 ? sdiag(2) : b == 1 ? sdiag(0) : b == 2 ? sdiag(1) : 0.0),
+                       (R)(b == 0 ? sdiag(1) : b == 1 ? sdiag(2) : b == 2 ? sdiag(0) : 0.0)};
         return c;
     }
     template <typename R>
     struct Lane {
-        R cs, sn, om, th;    // own body (role 3: cs = 1, om = 0 and stays 0 -- the other lanes read it as their zero)
-        R rx, ry, vx, vy;    // root translation, replicated on the four lanes
+        V2<R> A, Ap;         // own body: (cs, sn) and (-sn, cs)   (role 3: A = (1, 0))
+        V2<R> v, r;          // root velocity / position, replicated on the four lanes
+        R om, th;            // absolute rate (role 3: 0, and stays 0 -- the other lanes read it as their zero), joint angle
+        R qd;                // om - parent's om: the joint rate, carried from the end of the previous sub-step
+        RL_HD void set_direction(R cs, R sn) { A = V2<R>{cs, sn}; Ap = V2<R>{-sn, cs}; }
     };
 
     // quad_perm controls: lane i of the quad reads lane P[i]
@@ -243,59 +255,75 @@ struct SwimChain {
         const R v1 = v + x.template qp<SW1>(v);
         return v1 + x.template qp<SW2>(v1);
     }
+    template <int CTRL, typename R, class X>
+    RL_HD static V2<R> qp2(X& x, V2<R> v) {
+        return V2<R>{x.template qp<CTRL>(v.x), x.template qp<CTRL>(v.y)};
+    }
+
+    // the joint rate a lane carries: own absolute rate - parent's
+    template <typename R, class X>
+    RL_HD static R joint_rate(X& x, R om) { return om - x.template qp<PAR1>(om); }
 
     // X: exchange context, x.template qp<CTRL>(v) = value of v in the lane selected by CTRL
     template <typename R, class X>
     RL_HD static void substep_quad(X& x, const LaneConst<R>& c, Lane<R>& s, R act, R h) {
-        const R osn = s.om * s.sn;
-        const R ocs = s.om * s.cs;
-        const R wlx = -(osn * c.jxo);
-        const R wly = ocs * c.jxo;
-        const R vax = (s.vx + x.template qp<PAR1>(wlx)) + x.template qp<PAR2>(wlx);
-        const R vay = (s.vy + x.template qp<PAR1>(wly)) + x.template qp<PAR2>(wly);
-        const R vpx = vax - osn * c.cxb;
-        const R vpy = vay + ocs * c.cxb;
-        R Fx, Fy, tz, ft;
-        fluid(s.cs, s.sn, vpx, vpy, s.om, c.visc_lin, c.drag_ax, c.drag_perp, c.visc_ang, c.drag_ang, Fx, Fy, tz, ft);
-        const R tau = joint_torque(s.th, s.om - x.template qp<PAR1>(s.om), act, c.lim_k, c.lim_b);
+        using P = V2<R>;
+        const P A = s.A, Ap = s.Ap;
+        const P oc = s.om * A;                                   // (ocs, osn)
+        const P wl = oc.yx * c.kj;                               // (wlx, wly) = (-(osn jxo), ocs jxo)
+        // cross-lane sums stay per component: each is one v_add_f32 with the quad-permute fused in
+        const P va = P{(s.v.x + x.template qp<PAR1>(wl.x)) + x.template qp<PAR2>(wl.x),
+                       (s.v.y + x.template qp<PAR1>(wl.y)) + x.template qp<PAR2>(wl.y)};
+        const P vp = va + oc.yx * c.kc;                          // (vax - osn cxb, vay + ocs cxb)
+        // body-frame velocity (vl, vt) = R^-1 vp, fluid force (fl, ft) along / across the body, world force F = R f
+        const P lt = Ap.yx * vp.xx + A.yx * vp.yy;
+        const P m = P{c.visc_lin + c.kdrag.x * rl_abs(lt.x), c.visc_lin + c.kdrag.y * rl_abs(lt.y)};
+        const P f = -(lt * m);
+        const P F = A * f.xx + Ap * f.yy;
+        const R tz = -(s.om * (c.visc_ang + c.drag_ang * rl_abs(s.om)));
+        const R tau = joint_torque(s.th, s.qd, act, c.lim_k, c.lim_b);
         const R taun = x.template qp<SHL1>(tau);
         // force on the subtree hanging off this body's child joint = child's + grandchild's (the zero lane beyond)
-        const R fnx = x.template qp<SHL1>(Fx) + x.template qp<SHL2>(Fx);
-        const R fny = x.template qp<SHL1>(Fy) + x.template qp<SHL2>(Fy);
-        const R Q = ((c.cxb * ft + tz) + c.jxo * (s.cs * fny - s.sn * fnx)) + (tau - taun);
-        const R Gx = s.cs * c.db;
-        const R Gy = s.sn * c.db;
+        const P fn = P{x.template qp<SHL1>(F.x) + x.template qp<SHL2>(F.x),
+                       x.template qp<SHL1>(F.y) + x.template qp<SHL2>(F.y)};
+        const R Q = ((c.cxb * f.y + tz) + c.jxo * (A.x * fn.y - A.y * fn.x)) + (tau - taun);
+        const P G = A * c.db;                                    // (Gx, Gy)
+        const P Gp = Ap * c.db;                                  // (-Gy, Gx)
         const R w2 = s.om * s.om;
-        const R fwx = Fx + w2 * Gx;
-        const R fwy = Fy + w2 * Gy;
-        const R sfx = quad_sum(x, fwx);
-        const R sfy = quad_sum(x, fwy);
-        const R cross = Gx * sfy - Gy * sfx;
+        const P fw = F + w2 * G;
+        const P sf = P{quad_sum(x, fw.x), quad_sum(x, fw.y)};
+        const R cross = G.x * sf.y - G.y * sf.x;
         const R bq = Q - (R)INV_M * cross;
         // coupling to the cyclic partner p; the pair (b, q) is partner q's own pair seen from the other side
-        const R cp_ = x.template qp<NX1>(s.cs), sp_ = x.template qp<NX1>(s.sn), w2p = x.template qp<NX1>(w2);
-        const R w2q = x.template qp<NX2>(w2);
-        R Sbp, tp;
-        couple(s.cs, s.sn, cp_, sp_, c.scp, c.acp, Sbp, tp);
-        const R Sbq = x.template qp<NX2>(Sbp), tqn = x.template qp<NX2>(tp);
+        const P Pn = qp2<NX1>(x, A);
+        const R w2p = x.template qp<NX1>(w2), w2q = x.template qp<NX2>(w2);
+        const P cds = Ap.yx * Pn.xx + A.yx * Pn.yy;              // (cos, sin)(phi_p - phi_b)
+        const R Sbp = c.ksa.x * cds.x, tp = c.ksa.y * cds.y;     // (S_bp, t_bp)
+        const P SS = P{Sbp, x.template qp<NX2>(Sbp)};            // (S_bp, S_bq)
+        const R tqn = x.template qp<NX2>(tp);                    // t_qb
         const R rb = (bq + w2p * tp) - w2q * tqn;
         const R Spq = x.template qp<NX1>(Sbp);
         const R rp = x.template qp<NX1>(rb), rq = x.template qp<NX2>(rb);
-        const R thb = solve_row(c.d_b, c.d_pq, c.d_p, c.d_q, Sbp, Sbq, Spq, rb, rp, rq);
-        const R cxp = -(Gy * thb);
-        const R cyp = Gx * thb;
-        const R sx = quad_sum(x, cxp);
-        const R sy = quad_sum(x, cyp);
+        // row b of the 3x3 solve (solve_row): the two cofactors and (det, num) evaluated side by side
+        const R c0 = c.d_pq - Spq * Spq;
+        const P c12 = Spq * SS.yx - SS * c.kdqp;                 // (c1, c2)
+        const P dn = c0 * P{c.d_b, rb} + P{SS.x * c12.x + SS.y * c12.y, c12.x * rp + c12.y * rq};   // (det, num)
+        const R thb = rl_div_normal(dn.y, dn.x);
+        const P cp = Gp * thb;                                   // (cxp, cyp)
+        const P s2 = P{quad_sum(x, cp.x), quad_sum(x, cp.y)};
         const R hm = h * (R)INV_M;
-        const R dx_ = sfx - sx;
-        const R dy_ = sfy - sy;
-        s.vx = s.vx + hm * dx_;
-        s.vy = s.vy + hm * dy_;
-        s.rx = s.rx + h * s.vx;
-        s.ry = s.ry + h * s.vy;
+        const P d = sf - s2;
+        s.v = s.v + hm * d;
+        s.r = s.r + h * s.v;
         s.om = s.om + h * thb;
-        s.th = s.th + h * (s.om - x.template qp<PAR1>(s.om));
-        rl_rotate_tiny(s.sn, s.cs, h * s.om);
+        s.qd = joint_rate(x, s.om);
+        s.th = s.th + h * s.qd;
+        // rl_rotate_tiny on the pair
+        const R dth = h * s.om;
+        R sd, cd;
+        rl_tiny_sincos(dth, sd, cd);
+        s.A = A * cd + Ap * sd;
+        s.Ap = P{-s.A.y, s.A.x};
     }
 };
 

@@ -650,24 +650,29 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
             g[10] = __shfl(ctrl[1], q_src, 64);
             g[11] = __shfl(ctrl[2], q_src, 64);
             Chain::Lane<float> ls;
-            ls.rx = g[0]; ls.ry = g[1]; ls.vx = g[5]; ls.vy = g[6];
+            ls.r = V2<float>{g[0], g[1]};
+            ls.v = V2<float>{g[5], g[6]};
             const float phi1 = g[2] + g[3], om1 = g[7] + g[8];
             const float phi2 = phi1 + g[4], om2 = om1 + g[9];
             const float phi = (b == 0) ? g[2] : (b == 1) ? phi1 : (b == 2) ? phi2 : 0.0f;
             ls.om = (b == 0) ? g[7] : (b == 1) ? om1 : (b == 2) ? om2 : 0.0f;
             ls.th = (b == 0) ? g[2] : (b == 1) ? g[3] : (b == 2) ? g[4] : 0.0f;
-            rl_sincos(phi, ls.sn, ls.cs);
+            float sn_b, cs_b;
+            rl_sincos(phi, sn_b, cs_b);
+            ls.set_direction(cs_b, sn_b);
+            ls.qd = Chain::joint_rate(dpp, ls.om);
             const float lact = (b == 1) ? g[10] : (b == 2) ? g[11] : 0.0f;
 #pragma unroll 5
             for (int it = 0; it < Env::FRAME_SKIP; ++it)
                 Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
-            // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's)
-            const float qdj = ls.om - dpp.template qp<Chain::PAR1>(ls.om);   // role 3 keeps om = 0
+            // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's,
+            // carried by the lane program; role 3 keeps om = 0)
+            const float qdj = ls.qd;
             const int base = 4 * el;
-            s[0] = __shfl(ls.rx, base, 64);
-            s[1] = __shfl(ls.ry, base, 64);
-            s[5] = __shfl(ls.vx, base, 64);
-            s[6] = __shfl(ls.vy, base, 64);
+            s[0] = __shfl(ls.r.x, base, 64);
+            s[1] = __shfl(ls.r.y, base, 64);
+            s[5] = __shfl(ls.v.x, base, 64);
+            s[6] = __shfl(ls.v.y, base, 64);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 s[2 + j] = __shfl(ls.th, base + j, 64);

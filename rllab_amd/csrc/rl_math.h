@@ -121,20 +121,33 @@ RL_HD void rl_rotate_small(R& sn, R& cs, R d) {
 // series are cut where the next term is below half an ulp of the result (sin: d^5/120 < 3e-11, cos: d^4/24 < 7e-9; the
 // carried pair is re-seeded with exact values every env step, so nothing accumulates beyond 50 sub-steps).
 template <typename R>
-RL_HD void rl_rotate_tiny(R& sn, R& cs, R d) {
+RL_HD void rl_tiny_sincos(R d, R& sd, R& cd) {
+    const R d2 = d * d;
     if constexpr (sizeof(R) == 4) {
-        const R d2 = d * d;
         const R t = d2 * (R)(-1.0 / 6);
-        const R sd = d + d * t;
-        const R cd = (R)1 + d2 * (R)-0.5;
-        const R s = sn * cd + cs * sd;
-        const R c = cs * cd - sn * sd;
-        sn = s;
-        cs = c;
+        sd = d + d * t;
+        cd = (R)1 + d2 * (R)-0.5;
     } else {
-        rl_rotate_small(sn, cs, d);
+        sd = d * ((R)1 + d2 * ((R)(-1.0 / 6) + d2 * ((R)(1.0 / 120) + d2 * ((R)(-1.0 / 5040) +
+             d2 * ((R)(1.0 / 362880) + d2 * (R)(-1.0 / 39916800))))));
+        cd = (R)1 + d2 * ((R)-0.5 + d2 * ((R)(1.0 / 24) + d2 * ((R)(-1.0 / 720) + d2 * ((R)(1.0 / 40320) +
+             d2 * ((R)(-1.0 / 3628800) + d2 * (R)(1.0 / 479001600))))));
     }
 }
+template <typename R>
+RL_HD void rl_rotate_tiny(R& sn, R& cs, R d) {
+    R sd, cd;
+    rl_tiny_sincos(d, sd, cd);
+    const R s = sn * cd + cs * sd;
+    const R c = cs * cd - sn * sd;
+    sn = s;
+    cs = c;
+}
+
+// Two-component vector for the x / y pairs of the planar dynamics: elementwise +, -, *, scalar broadcast and
+// .xy swizzles (clang ext_vector_type, the same front-end for both builds; -ffp-contract=on fuses a * b + c per
+// component exactly as for scalars).  On gfx950 one v_pk_{mul,add,fma}_f32 per operation, swizzles in op_sel.
+template <typename R> using V2 = R __attribute__((ext_vector_type(2)));
 
 // The double instantiation is host-only (independent physics checks at 1e-10);
 // it may use libm.
