@@ -71,8 +71,8 @@ struct SwimChain {
         t = ac * sd;
     }
     // row b of the symmetric 3x3 solve in the cyclic order (b, p, q): cofactors of row b are the cross product of rows
-    // p and q, every body divides by its own expansion of the determinant (equal up to rounding), so the four-lane
-    // program needs no replicated adjugate:  x_b = cof . (r_b, r_p, r_q) / (row_b . cof)
+    // p and q, every body uses its own expansion of the determinant (equal up to rounding), so the four-lane
+    // program needs no replicated adjugate:  x_b = cof . (r_b, r_p, r_q) * (1 / (row_b . cof))
     template <typename R>
     RL_HD static R solve_row(R d_b, R d_pq, R d_p, R d_q, R Sbp, R Sbq, R Spq, R rb, R rp, R rq) {
         const R c0 = d_pq - Spq * Spq;
@@ -80,7 +80,7 @@ struct SwimChain {
         const R c2 = Sbp * Spq - d_p * Sbq;
         const R det = d_b * c0 + (Sbp * c1 + Sbq * c2);
         const R num = c0 * rb + (c1 * rp + c2 * rq);
-        return rl_div_normal(num, det);
+        return num * rl_recip_normal(det);
     }
 
     // ---- scalar program ---------------------------------------------------------------------------------------------
@@ -152,10 +152,14 @@ struct SwimChain {
             const int p = nxt(b);
             couple(cs[b], sn[b], cs[p], sn[p], (R)scc(b, p), (R)acc(b, p), Sbp[b], tp[b]);
         }
+        // the centripetal term of pair (q, b) is formed by its owner q (own rate^2 x own pair: one product, one rounding)
+        R zc[3];
+        RL_UNROLL
+        for (int b = 0; b < 3; ++b) zc[b] = w2[b] * tp[b];
         RL_UNROLL
         for (int b = 0; b < 3; ++b) {
             const int p = nxt(b), q = nx2(b);
-            rb[b] = (bq[b] + w2[p] * tp[b]) - w2[q] * tp[q];
+            rb[b] = (bq[b] + w2[p] * tp[b]) - zc[q];
         }
         R thb[3];
         RL_UNROLL
@@ -296,19 +300,21 @@ struct SwimChain {
         const R bq = Q - (R)INV_M * cross;
         // coupling to the cyclic partner p; the pair (b, q) is partner q's own pair seen from the other side
         const P Pn = qp2<NX1>(x, A);
-        const R w2p = x.template qp<NX1>(w2), w2q = x.template qp<NX2>(w2);
+        const R w2p = x.template qp<NX1>(w2);
         const P cds = Ap.yx * Pn.xx + A.yx * Pn.yy;              // (cos, sin)(phi_p - phi_b)
         const R Sbp = c.ksa.x * cds.x, tp = c.ksa.y * cds.y;     // (S_bp, t_bp)
         const P SS = P{Sbp, x.template qp<NX2>(Sbp)};            // (S_bp, S_bq)
-        const R tqn = x.template qp<NX2>(tp);                    // t_qb
-        const R rb = (bq + w2p * tp) - w2q * tqn;
+        const R zc = w2 * tp;                                    // own rate^2 x own pair, fetched by the pair's other end
+        const R rb = (bq + w2p * tp) - x.template qp<NX2>(zc);
         const R Spq = x.template qp<NX1>(Sbp);
         const R rp = x.template qp<NX1>(rb), rq = x.template qp<NX2>(rb);
         // row b of the 3x3 solve (solve_row): the two cofactors and (det, num) evaluated side by side
         const R c0 = c.d_pq - Spq * Spq;
         const P c12 = Spq * SS.yx - SS * c.kdqp;                 // (c1, c2)
-        const P dn = c0 * P{c.d_b, rb} + P{SS.x * c12.x + SS.y * c12.y, c12.x * rp + c12.y * rq};   // (det, num)
-        const R thb = rl_div_normal(dn.y, dn.x);
+        // the determinant and its reciprocal do not wait for the right-hand sides: they fill the exchange gaps of rb
+        const R det = c.d_b * c0 + (SS.x * c12.x + SS.y * c12.y);
+        const R num = c0 * rb + (c12.x * rp + c12.y * rq);
+        const R thb = num * rl_recip_normal(det);
         const P cp = Gp * thb;                                   // (cxp, cyp)
         const P s2 = P{quad_sum(x, cp.x), quad_sum(x, cp.y)};
         const R hm = h * (R)INV_M;

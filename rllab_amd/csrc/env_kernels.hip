@@ -581,7 +581,9 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     const size_t plane = (size_t)T * n;
     // lane-group phase: quad q_env = lane / 4 works on the env held by lane q_env, role b = lane % 4
     const int q_src = lane >> 2, b = lane & 3;
-    const Chain::LaneConst<float> kc = Chain::lane_const<float>(b);
+    Chain::LaneConst<float> kc = Chain::lane_const<float>(b);
+    // the role-dependent constants are values in registers, not selects the optimiser may re-derive inside the sub-step
+    asm volatile("" : "+v"(kc.lim_k), "+v"(kc.lim_b));
     const DppQuad dpp;
 
     float std_[Env::ACT];
@@ -609,7 +611,11 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
             for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
         }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
+#ifdef RL_EXP_NOPOLICY
+        mean[0] = o[0]; mean[1] = o[1];
+#else
         pol.forward16(o, mean);
+#endif
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
@@ -662,8 +668,13 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
             ls.set_direction(cs_b, sn_b);
             ls.qd = Chain::joint_rate(dpp, ls.om);
             const float lact = (b == 1) ? g[10] : (b == 2) ? g[11] : 0.0f;
+#ifdef RL_EXP_SUBSTEPS
+#pragma unroll 5
+            for (int it = 0; it < RL_EXP_SUBSTEPS; ++it)
+#else
 #pragma unroll 5
             for (int it = 0; it < Env::FRAME_SKIP; ++it)
+#endif
                 Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
             // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's,
             // carried by the lane program; role 3 keeps om = 0)

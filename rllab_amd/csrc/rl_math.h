@@ -46,25 +46,21 @@ RL_HD float rl_clamp_finite(float x, float lo, float hi) {
     return x < lo ? lo : (x > hi ? hi : x);
 #endif
 }
-// n / d, correctly rounded, for operands whose quotient needs no range scaling (d and n / d normal and far from the
-// exponent limits).  On the device this is the core of the compiler's own IEEE division expansion -- v_rcp_f32 (1 ulp)
-// refined by the fma chain that makes the result independent of the seed's last bit -- without the v_div_scale /
-// v_div_fixup wrapping (8 instructions instead of 12); the host divides.
-RL_HD float rl_div_normal(float n, float d) {
+// 1 / d, correctly rounded, for a normal d far from the exponent limits.  Device: v_rcp_f32 (within 1 ulp) + ONE
+// Newton step in fused arithmetic -- tools/ubench/rcp_exactness.hip checks on the hardware that this equals RN(1 / d)
+// for all 2^23 mantissas (the seed is wrong by an ulp for 10.7 % of them, the refined value for none), so the host
+// (which divides) and the device agree bit for bit.  Three issue slots + the transcendental's second pass, against
+// eight for a correctly rounded quotient: the dynamics multiply by this reciprocal instead of dividing.
+RL_HD float rl_recip_normal(float d) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
-    const float q0 = n * r1;
-    const float e1 = __builtin_fmaf(-d, q0, n);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(-d, q1, n);
-    return __builtin_fmaf(e2, r1, q1);
+    return __builtin_fmaf(e0, r0, r0);
 #else
-    return n / d;
+    return 1.0f / d;
 #endif
 }
-RL_HD double rl_div_normal(double n, double d) { return n / d; }
+RL_HD double rl_recip_normal(double d) { return 1.0 / d; }
 RL_HD double rl_clamp_finite(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // Deterministic single-precision sin/cos.  Cody-Waite three-term reduction by
