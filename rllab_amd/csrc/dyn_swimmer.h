@@ -162,16 +162,25 @@ struct Swimmer {
     template <typename R>
     RL_HD static void step_end(const R* s, const R* act, R* obs, R& reward, bool& done,
                                R ctrl_cost_coeff = (R)1e-2) {
-        const R lb = (R)-50, ub = (R)50;
+        PlanarKin<R, Tree::NB> k;
+        Tree::template angles<R>(s, k.sn, k.cs);
+        step_end_sc(s, act, k, obs, reward, done, ctrl_cost_coeff);
+    }
+    // the same with the sines / cosines of the absolute body angles already in k.sn / k.cs (rl_sincos of the same
+    // angles, evaluated one body per lane by the fused rollout)
+    template <typename R>
+    RL_HD static void step_end_sc(const R* s, const R* act, PlanarKin<R, Tree::NB>& k, R* obs, R& reward, bool& done,
+                                  R ctrl_cost_coeff = (R)1e-2) {
         R cx, cy, vx, vy;
-        Tree::template com<R>(s, s + 5, cx, cy, vx, vy);
+        Tree::template com_sc<R>(s, s + 5, k, cx, cy, vx, vy);
         RL_UNROLL
         for (int i = 0; i < 10; ++i) obs[i] = s[i];
         obs[10] = cx; obs[11] = cy; obs[12] = (R)0;
-        // reward = comvel_x - 0.5 * ctrl_cost_coeff * sum((action / scaling)^2), scaling = (ub - lb)/2; coefficient 1e-2
-        // unless SwimmerEnv(ctrl_cost_coeff=..) says otherwise (0.5 * c is exact, so the default keeps its bits)
-        const R scaling = (ub - lb) * (R)0.5;
-        const R a0 = act[0] / scaling, a1 = act[1] / scaling;
+        // reward = comvel_x - 0.5 * ctrl_cost_coeff * sum((action / scaling)^2), scaling = (ub - lb)/2 = 50 (as a
+        // multiplication by 1/50); coefficient 1e-2 unless SwimmerEnv(ctrl_cost_coeff=..) says otherwise (0.5 * c is
+        // exact, so the default keeps its bits)
+        const R inv_scaling = (R)(1.0 / 50.0);
+        const R a0 = act[0] * inv_scaling, a1 = act[1] * inv_scaling;
         const R ctrl_cost = (R)0.5 * ctrl_cost_coeff * (a0 * a0 + a1 * a1);
         reward = vx - ctrl_cost;
         done = false;

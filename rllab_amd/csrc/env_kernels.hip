@@ -560,6 +560,14 @@ struct DppQuad {
     }
 };
 
+// prefix sums along the chain, one body per lane (role b): v_0, v_0 + v_1, (v_0 + v_1) + v_2; role 3: 0
+__device__ __forceinline__ float prefix3(const DppQuad& x, float v, int b) {
+    constexpr int PAR1 = 0x93;      // quad_perm [3,0,1,2]: every lane reads its parent
+    const float p1 = x.qp<PAR1>(v) + v;
+    const float p2 = x.qp<PAR1>(p1) + v;
+    return (b == 0) ? v : (b == 1) ? p1 : (b == 2) ? p2 : 0.0f;
+}
+
 constexpr int QUAD_ENVS = 16;   // envs per wavefront
 
 template <int H>
@@ -604,6 +612,12 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
 
+    // lane-group state of the env, resident across env-steps (valid until a reset touches the wavefront)
+    Chain::Lane<float> ls;
+    PlanarKin<float, 3> kin;
+    float sn_b = 0.0f, cs_b = 1.0f;
+    bool chain_valid = false;
+
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
         if (live) {
@@ -611,11 +625,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
             for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
         }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
-#ifdef RL_EXP_NOPOLICY
-        mean[0] = o[0]; mean[1] = o[1];
-#else
         pol.forward16(o, mean);
-#endif
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
@@ -648,37 +658,41 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
             Env::template step_begin<float>(act, a.normalize, eact, ctrl);
         }
         {
-            // hand the env of lane q_src to its quad: each lane derives the variables of ITS body with the same
-            // expressions as Swimmer::to_chain
-            float g[12];
+            const float c1 = __shfl(ctrl[1], q_src, 64), c2 = __shfl(ctrl[2], q_src, 64);
+            const float lact = (b == 1) ? c1 : (b == 2) ? c2 : 0.0f;
+            if (!chain_valid) {
+                // hand the env of lane q_src to its quad: each lane derives the variables of ITS body with the same
+                // expressions as Swimmer::to_chain (first step, and after a reset anywhere in the wavefront)
+                float g[10];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) g[k] = __shfl(s[k], q_src, 64);
-            g[10] = __shfl(ctrl[1], q_src, 64);
-            g[11] = __shfl(ctrl[2], q_src, 64);
-            Chain::Lane<float> ls;
-            ls.r = V2<float>{g[0], g[1]};
-            ls.v = V2<float>{g[5], g[6]};
-            const float phi1 = g[2] + g[3], om1 = g[7] + g[8];
-            const float phi2 = phi1 + g[4], om2 = om1 + g[9];
-            const float phi = (b == 0) ? g[2] : (b == 1) ? phi1 : (b == 2) ? phi2 : 0.0f;
-            ls.om = (b == 0) ? g[7] : (b == 1) ? om1 : (b == 2) ? om2 : 0.0f;
-            ls.th = (b == 0) ? g[2] : (b == 1) ? g[3] : (b == 2) ? g[4] : 0.0f;
-            float sn_b, cs_b;
-            rl_sincos(phi, sn_b, cs_b);
+                for (int k = 0; k < 10; ++k) g[k] = __shfl(s[k], q_src, 64);
+                ls.r = V2<float>{g[0], g[1]};
+                ls.v = V2<float>{g[5], g[6]};
+                const float phi1 = g[2] + g[3], om1 = g[7] + g[8];
+                const float phi2 = phi1 + g[4], om2 = om1 + g[9];
+                const float phi = (b == 0) ? g[2] : (b == 1) ? phi1 : (b == 2) ? phi2 : 0.0f;
+                ls.om = (b == 0) ? g[7] : (b == 1) ? om1 : (b == 2) ? om2 : 0.0f;
+                ls.th = (b == 0) ? g[2] : (b == 1) ? g[3] : (b == 2) ? g[4] : 0.0f;
+                rl_sincos(phi, sn_b, cs_b);
+            } else {
+                // the quad still holds the env from the previous step: root translation and joint angles as they are,
+                // absolute rates re-derived from the joint rates exactly as to_chain(from_chain(.)) does
+                // (om_1 = qd_0 + qd_1, om_2 = om_1 + qd_2), (sin, cos) = the pair evaluated after the last sub-step
+                ls.om = prefix3(dpp, ls.qd, b);
+                ls.th = (b < 3) ? ls.th : 0.0f;
+            }
             ls.set_direction(cs_b, sn_b);
             ls.qd = Chain::joint_rate(dpp, ls.om);
-            const float lact = (b == 1) ? g[10] : (b == 2) ? g[11] : 0.0f;
-#ifdef RL_EXP_SUBSTEPS
-#pragma unroll 5
-            for (int it = 0; it < RL_EXP_SUBSTEPS; ++it)
-#else
 #pragma unroll 5
             for (int it = 0; it < Env::FRAME_SKIP; ++it)
-#endif
                 Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
+            // exact sines of the new absolute angles, one body per lane: Swimmer::step_end's centre of mass needs
+            // them now (PlanarTree::angles: phi_1 = th_0 + th_1, phi_2 = phi_1 + th_2), the next step's sub-steps
+            // start from them
+            rl_sincos(prefix3(dpp, ls.th, b), sn_b, cs_b);
+            chain_valid = true;
             // back: qpos / qvel as Swimmer::from_chain forms them (joint rate = own absolute rate - parent's,
             // carried by the lane program; role 3 keeps om = 0)
-            const float qdj = ls.qd;
             const int base = 4 * el;
             s[0] = __shfl(ls.r.x, base, 64);
             s[1] = __shfl(ls.r.y, base, 64);
@@ -687,12 +701,14 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 s[2 + j] = __shfl(ls.th, base + j, 64);
-                s[7 + j] = __shfl(qdj, base + j, 64);
+                s[7 + j] = __shfl(ls.qd, base + j, 64);
+                kin.sn[j] = __shfl(sn_b, base + j, 64);
+                kin.cs[j] = __shfl(cs_b, base + j, 64);
             }
         }
         float r;
         bool d;
-        Env::template step_end<float>(s, eact, o, r, d, a.cfg.ctrl_cost_coeff);
+        Env::template step_end_sc<float>(s, eact, kin, o, r, d, a.cfg.ctrl_cost_coeff);
 
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
@@ -706,6 +722,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
             Env::template observe<float>(s, o);
             ts = 0;
         }
+        if (__builtin_amdgcn_ballot_w64(d) != 0) chain_valid = false;     // some env of this wavefront starts afresh
         observed<Env>(o, a.cfg, a.obs_noise_z ? a.obs_noise_z + (size_t)(t + 1) * obs_z_slice : nullptr, n, i, a.seed,
                       env_global, a.step_counter + (uint64_t)t + 1);
     }
