@@ -174,7 +174,7 @@ struct PlanarTree {
             const R A = d * f - e * e, B = c * e - bb * f, C = bb * e - c * d;
             const R D = a * f - c * c, E = bb * c - a * e, F = a * d - bb * bb;
             const R det = a * A + (bb * B + c * C);
-            const R inv = (R)1 / det;
+            const R inv = rl_recip_normal(det);
             x[0] = (A * b[0] + (B * b[1] + C * b[2])) * inv;
             x[1] = (B * b[0] + (D * b[1] + E * b[2])) * inv;
             x[2] = (C * b[0] + (E * b[1] + F * b[2])) * inv;
@@ -188,7 +188,7 @@ struct PlanarTree {
                     d = d - S[c][t] * S[c][t] * Dg[t];
                 });
                 Dg[c] = d;
-                const R inv = (R)1 / d;
+                const R inv = rl_recip_normal(d);
                 Di[c] = inv;
                 static_for<c + 1, N>([&](auto Rr) {
                     constexpr int r = decltype(Rr)::value;
@@ -534,7 +534,7 @@ struct PlanarTree {
         const R A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
         const R D = a * f - c * c, E = b * c - a * e, F = a * d - b * b;
         const R det = a * A + (b * B + c * C);
-        const R inv = (R)1 / det;
+        const R inv = rl_recip_normal(det);
         adj[0] = A * inv; adj[1] = B * inv; adj[2] = C * inv; adj[3] = D * inv; adj[4] = E * inv; adj[5] = F * inv;
     }
     template <typename R>
