@@ -357,10 +357,11 @@ def main():
                      "valu_peak_tflops": 157.3, "wavefronts": n_waves, "simds": 1024,
                      "envs_per_wavefront": envs_per_wave,
                      "note": "issue-bound, not HBM-bound: %d envs per wavefront => %d wavefronts on 1024 SIMDs, each "
-                             "a single dependent instruction stream (physics sub-steps fused in registers); a lone "
-                             "wavefront issues 1 VALU op per 4 cycles nine tenths of the time (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = "
-                             "0.90), so launch time ~ instructions per wavefront x 4.5 cycles x T and the HBM fraction "
-                             "is small by construction (SURVEY.md 8d, DESIGN.md 3.1)" % (envs_per_wave, n_waves)},
+                             "a single instruction stream (physics sub-steps fused in registers); a lone wavefront "
+                             "pays 4 cycles per issue slot whatever it issues (vector, scalar, each s_nop wait "
+                             "state; packed f32 5, transcendental 8 -- tools/ubench/valu_latency.hip), so launch "
+                             "time = issue slots per wavefront x 4 cycles x T and the HBM fraction is small by "
+                             "construction (SURVEY.md 8d, DESIGN.md 3.1)" % (envs_per_wave, n_waves)},
     }
     if fvp_ms is not None:
         tiles = (n_envs * T + 31) // 32
