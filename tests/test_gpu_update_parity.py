@@ -179,12 +179,16 @@ def test_log_std_floor_blocks_its_gradient():
     assert torch.isfinite(hv).all() and float(hv[-1]) == 0.0
 
 
-def test_trpo_step_fused_matches_oracle_control_flow(quiet_logger):
+@pytest.mark.parametrize("algo", ["trpo", "tnpg"])
+def test_trpo_step_fused_matches_oracle_control_flow(quiet_logger, algo):
     """One ConjugateGradientOptimizer.optimize with the fused kernels vs the numpy restatement
     of the reference control flow (oracle/np_reference.cg_optimize) driven by float64 torch
-    closures: same accepted step (parameters within 1e-4 relative of the step norm)."""
+    closures: same accepted step (parameters within 1e-4 relative of the step norm).  "tnpg": the optimizer as
+    rllab/algos/tnpg.py:16-21 configures it (max_backtracks = 1: the full natural-gradient step, taken once)."""
     from oracle import np_reference as R
     from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+    from rllab_amd.algos.tnpg import TNPG
+    from rllab_amd.algos.npo import pick_optimizer
     pol = _policy(13, 2, 32)
     inp = _inputs(pol, 20000, old_equals_new=True, ragged=True)
     surr, kl, _ = _closures(pol)
@@ -204,15 +208,23 @@ def test_trpo_step_fused_matches_oracle_control_flow(quiet_logger):
         t = as_t(th).requires_grad_(True)
         g = torch.autograd.grad(kl(t, *inp), t, create_graph=True)[0]
         return torch.autograd.grad((g * as_t(x)).sum(), t)[0].cpu().numpy()
-    want, info = R.cg_optimize(theta0.copy(), f_loss, f_grad, f_kl, f_hx, 0.01)
-
-    opt = ConjugateGradientOptimizer()
+    if algo == "tnpg":
+        want, info = R.cg_optimize(theta0.copy(), f_loss, f_grad, f_kl, f_hx, 0.01, max_backtracks=1)
+        opt = pick_optimizer(None, None, ConjugateGradientOptimizer, max_backtracks=1)    # what TNPG.__init__ builds
+        assert opt._max_backtracks == 1
+    else:
+        want, info = R.cg_optimize(theta0.copy(), f_loss, f_grad, f_kl, f_hx, 0.01)
+        opt = ConjugateGradientOptimizer()
     opt.update_opt(loss=surr, target=pol, leq_constraint=(kl, 0.01), fused=pol.fused_ops())
     opt.optimize(inp)
     got = pol.get_param_values()
     step = np.abs(want - theta0).max()
-    assert step > 0 and not info["rejected"]
-    assert np.abs(got - want).max() <= 2e-3 * step
+    if algo == "trpo":
+        assert step > 0 and not info["rejected"]
+    if info["rejected"]:                       # the single full step broke the constraint: both sides restore theta
+        assert np.array_equal(got, theta0)
+    else:
+        assert np.abs(got - want).max() <= 2e-3 * step
     assert opt.last_backtrack_iters == info["backtrack_iters"]
 
 
