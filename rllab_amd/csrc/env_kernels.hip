@@ -612,6 +612,31 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
 
+    // Output addressing: one uniform base per array, advanced by a row (n floats) per env-step, + a loop-invariant
+    // 32-bit byte offset per lane and plane in a VGPR (the dispatcher guarantees OBS * T * n * 4 < 2^32) -- a store is
+    // one instruction; the plane bases as 64-bit scalars would not fit the scalar register file next to the argument
+    // block and came back as ~45 v_readlane + 13 address adds per env-step.
+    uint32_t vo_obs[Env::OBS], vo_act[Env::ACT];
+#pragma unroll
+    for (int k = 0; k < Env::OBS; ++k) {
+        vo_obs[k] = (uint32_t)(((size_t)k * plane + (size_t)i) * 4);
+        asm volatile("" : "+v"(vo_obs[k]));          // a value in a register, not an expression to re-derive per store
+    }
+#pragma unroll
+    for (int k = 0; k < Env::ACT; ++k) {
+        vo_act[k] = (uint32_t)(((size_t)k * plane + (size_t)i) * 4);
+        asm volatile("" : "+v"(vo_act[k]));
+    }
+    uint32_t vo_row = (uint32_t)i * 4, vo_done = (uint32_t)i;
+    asm volatile("" : "+v"(vo_row), "+v"(vo_done));
+    // (the in-place asm keeps the zero-extension of the offset next to the add, which is what the back-end needs to
+    //  select the scalar-base + 32-bit-offset form of global_store; it emits no instruction)
+    auto at = [](auto* base, size_t row_elems, uint32_t& byte_off) {
+        using P = decltype(base);
+        asm volatile("" : "+v"(byte_off));
+        return reinterpret_cast<P>(reinterpret_cast<char*>(base + row_elems) + byte_off);
+    };
+
     // lane-group state of the env, resident across env-steps (valid until a reset touches the wavefront)
     Chain::Lane<float> ls;
     PlanarKin<float, 3> kin;
@@ -620,9 +645,10 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
 
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
+        const size_t row = (size_t)t * n;            // uniform
         if (live) {
 #pragma unroll
-            for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
+            for (int k = 0; k < Env::OBS; ++k) *at(a.obs, row, vo_obs[k]) = o[k];
         }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
         pol.forward16(o, mean);
@@ -641,8 +667,8 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
         for (int k = 0; k < Env::ACT; ++k) {
             act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
             if (live) {
-                a.actions[k * plane + off] = act[k];
-                a.means[k * plane + off] = mean[k];
+                *at(a.actions, row, vo_act[k]) = act[k];
+                *at(a.means, row, vo_act[k]) = mean[k];
             }
         }
 
@@ -713,8 +739,8 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
         if (live) {
-            a.rewards[off] = r * a.scale_reward;
-            a.dones[off] = d ? 1 : 0;
+            *at(a.rewards, row, vo_row) = r * a.scale_reward;
+            *at(a.dones, row, vo_done) = d ? 1 : 0;
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
@@ -837,7 +863,8 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     if constexpr (std::is_same<Env, Swimmer>::value) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
         const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;   // per launch: tests switch shapes
-        if (!lane_kernel && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
+        const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
+        if (!lane_kernel && small_offsets && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
             dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
             if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, qblock, 0, st, a);
