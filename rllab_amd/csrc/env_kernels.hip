@@ -440,6 +440,24 @@ struct RolloutDev {
 // several (16 384 Swimmer envs = 1024 wavefronts took 1.9x the time of 256).
 constexpr int LANE_TPB = 256;
 
+// v[0..NP) -> NP planes of a [NP][T][n] array at (t, i): the scalar row pointer walks the planes (one s_add_u32 /
+// s_addc_u32 pair per plane), every store is the scalar-base + 32-bit lane offset form of global_store.  The asm
+// statements emit nothing: they keep the walk a walk (NP hoisted 64-bit plane bases do not fit the scalar register
+// file next to the argument block and come back as v_readlane reloads + vector address adds) and the zero-extension
+// of the lane offset next to its add, which is what the back-end's scalar-base addressing pattern needs.
+template <int NP, typename V>
+__device__ __forceinline__ void store_planes(V* row_ptr, size_t plane, uint32_t& lane_bytes, const V* v) {
+    typedef __attribute__((address_space(1))) V* global_ptr;
+    uintptr_t walk = reinterpret_cast<uintptr_t>(row_ptr);          // address of plane k's row, a scalar
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        asm volatile("" : "+s"(walk));
+        asm volatile("" : "+v"(lane_bytes));
+        *reinterpret_cast<global_ptr>(walk + lane_bytes) = v[k];
+        walk += plane * sizeof(V);
+    }
+}
+
 template <class Env, int H0, int H1, int EPW>
 __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(RolloutDev a) {
     static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
@@ -482,12 +500,11 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
 
+    uint32_t lane_f32 = (uint32_t)i * 4, lane_u8 = (uint32_t)i;      // byte offset of env i inside a row
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < Env::OBS; ++k) a.obs[k * plane + off] = o[k];
-        }
+        const size_t row = (size_t)t * n;
+        if (live) store_planes<Env::OBS>(a.obs + row, plane, lane_f32, o);
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
         if constexpr (EPW == 16) pol.forward16(o, mean);
         else pol.forward(o, mean);
@@ -508,12 +525,10 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
             philox_draws<Env::ACT, true>(z, a.seed, env_global, a.step_counter + (uint64_t)t, RNG_POLICY);
         }
 #pragma unroll
-        for (int k = 0; k < Env::ACT; ++k) {
-            act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
-            if (live) {
-                a.actions[k * plane + off] = act[k];
-                a.means[k * plane + off] = mean[k];
-            }
+        for (int k = 0; k < Env::ACT; ++k) act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
+        if (live) {
+            store_planes<Env::ACT>(a.actions + row, plane, lane_f32, act);
+            store_planes<Env::ACT>(a.means + row, plane, lane_f32, mean);
         }
 
         float r;
@@ -524,8 +539,10 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
         if (live) {
-            a.rewards[off] = r * a.scale_reward;
-            a.dones[off] = d ? 1 : 0;
+            const float rs = r * a.scale_reward;
+            const uint8_t db = d ? 1 : 0;
+            store_planes<1>(a.rewards + row, plane, lane_f32, &rs);
+            store_planes<1>(a.dones + row, plane, lane_u8, &db);
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
