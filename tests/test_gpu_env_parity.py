@@ -127,6 +127,27 @@ def test_fused_rollout_injected_noise(kind, hidden, rollout_shape):
         assert np.array_equal(o0[:, i].view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind,scale", [(2, 30.0), (2, 100.0), (3, 30.0), (5, 30.0), (6, 30.0)])
+def test_fused_rollout_from_wild_states(kind, scale, rollout_shape):
+    """The same bit-exact replay from far outside the reset distribution (injected reset draws scaled by 30 / 100:
+    hinges beyond their limits, body rates of tens of rad/s, strong policy noise): the penalty branches, the packed
+    pair arithmetic, the reciprocal of the solve and the carried sines of the Swimmer's lane-group program see large
+    arguments, and every recorded transition must still be the host build's, bit for bit."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from oracle.replay import replay_check
+    rng = np.random.RandomState(7)
+    n, T, mpl = 96, 60, 25
+    policy = _make_policy(kind, seed=3)
+    v = HipVecEnv(kind, n, mpl, normalize=True, seed=2)
+    q = v.q
+    eps = (3.0 * rng.randn(q["act_dim"], T, n)).astype(np.float32)
+    draws = (scale * (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n)).astype(np.float32)
+    traj = v.rollout(policy, T, reset_at_start=True, eps=eps, reset_draws=draws)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(traj.obs).all()) and bool(torch.isfinite(traj.rewards).all())
+    assert replay_check(v, traj, max_envs=n, reset_draws=draws) == n * T
+
+
 @pytest.mark.parametrize("kind", OBS_INVERTIBLE)
 def test_fused_rollout_production_rng(kind, rollout_shape):
     """Production mode (in-kernel Philox): dynamics still replay bit-exactly, the
