@@ -1,4 +1,6 @@
-// dyn_swimmer_chain.h -- the sub-step of the 3-link swimmer chain, written twice with IDENTICAL expression trees:
+// dyn_swimmer_chain.h -- the sub-step of the 3-link swimmer chain, written twice with IDENTICAL arithmetic (the same
+// products, sums and fused multiply-adds in the same association; the lane-group program evaluates x / y pairs as
+// two-component vectors):
 //
 //   swim_substep_scalar : one env per lane / host thread; the three bodies are unrolled in one instruction stream.
 //                         Used by the host oracle build, by the per-step VecEnv kernels and as the definition of the
@@ -6,8 +8,8 @@
 //   swim_substep_quad   : four lanes per env (lane role b = body 0, 1, 2; lane 3 idles with zero constants).  Every
 //                         lane runs the same instruction stream on its own body, values cross lanes by
 //                         quad-permute moves, the 3x3 solve is replicated.  Used by the fused rollout, where a lone
-//                         wavefront per SIMD is bound by instruction issue: the per-env instruction stream shrinks
-//                         from ~260 to ~180 per sub-step and four times as many wavefronts share the work.
+//                         wavefront per SIMD pays 4 cycles per issued instruction: the per-env instruction stream
+//                         shrinks from ~260 to 89 per sub-step and four times as many wavefronts share the work.
 //
 // Bit-exactness contract: every value the quad program computes is computed by the scalar program with the same
 // expression (same operands, same association, same statement boundaries -- the front-end contracts a*b+c only inside

@@ -568,8 +568,9 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
 // cores, noise, action map, observation, reward, record, reset) runs env-per-lane exactly as in rollout_kernel
 // -- replicated on the four lanes l, l+16, l+32, l+48, which costs nothing: a lone wavefront is bound by its
 // instruction stream, not by lanes -- and only the 50 physics sub-steps switch to FOUR LANES PER ENV
-// (dyn_swimmer_chain.h: one body per lane, quad-permute DPP exchange, replicated 3x3 solve): ~180 instead of
-// ~280 instructions per sub-step, on four times as many wavefronts.
+// (dyn_swimmer_chain.h: one body per lane, quad-permute DPP exchange, x / y pairs on packed f32, replicated 3x3
+// solve): 89 instead of ~260 instructions per sub-step, on four times as many wavefronts.  The lane-group state stays
+// resident across env-steps; only the motor torques go in and the observation / reward inputs come back.
 // ---------------------------------------------------------------------------
 struct DppQuad {
     template <int CTRL> __device__ __forceinline__ float qp(float v) const {
