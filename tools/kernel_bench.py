@@ -55,7 +55,7 @@ def main():
         inp = (obs, act, adv, mean, ls.reshape(-1, 1), w, 1.0 / B)
         v = torch.randn(pol.flat_params.numel(), device=dev, dtype=torch.float64, generator=g)
         fwd_flops = 2 * (do * h + h * h + h * da)
-        for name, fn, mult in (("loss_kl", lambda: ops.loss_stats(inp), 1.0),
+        for name, fn, mult in (("loss_kl", lambda: (pol.note_raw_write(), ops.loss_stats(inp)), 1.0),
                                ("grad", lambda: ops.loss_grad(inp), 3.0),
                                ("fvp", lambda: ops.fvp(inp, v), 6.0)):
             ms = timeit(fn)
