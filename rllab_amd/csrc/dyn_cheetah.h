@@ -22,7 +22,7 @@
 // bfoot, fthigh, fshin, ffoot], qd[9].  MuJoCo's qpos = [x, z - 0.7, rooty, ...].
 #pragma once
 #include "cheetah_constants.h"
-#include "dyn_planar.h"
+#include "dyn_two_legs.h"
 
 namespace rl {
 
@@ -45,6 +45,14 @@ struct CheetahModel {
     RL_HD static constexpr double limit_b() { return 15.0; }
     RL_HD static constexpr double gx() { return -9.81; }  // gravity along -z = -P1
     RL_HD static constexpr double gy() { return 0.0; }
+
+    // contact table (dyn_two_legs.h): torso spheres first, then two per leg body
+    static constexpr int NC = cheetah::NC;
+    RL_HD static constexpr int cbody(int c) { return cheetah::CBODY[c]; }
+    RL_HD static constexpr double cpx(int c) { return cheetah::CPX[c]; }
+    RL_HD static constexpr double cpy(int c) { return cheetah::CPY[c]; }
+    RL_HD static constexpr double crad(int) { return cheetah::CRAD; }
+    RL_HD static constexpr double cmu(int) { return MU; }
 
     static constexpr double CONTACT_K = 2.0e4;   // N/m per end sphere
     static constexpr double CONTACT_B = 3.0e2;   // N s/m while penetrating
@@ -92,6 +100,7 @@ struct HalfCheetah {
     static constexpr int KIND = 3;
     static constexpr int SUBSTEPS = 4;      // 4 x 0.0025 s = one 0.01 s MuJoCo step, frame_skip 1
     using Tree = PlanarTree<CheetahModel>;
+    using Legs = TwoLegs<CheetahModel>;
 
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
         RL_UNROLL
@@ -148,9 +157,8 @@ struct HalfCheetah {
         R q[9], qd[9];
         RL_UNROLL
         for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
-        R sn[CheetahModel::NB], cs[CheetahModel::NB];
-        Tree::template angles<R>(q, sn, cs);
-        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025, sn, cs);
+        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+        Legs::template advance<R>(q, qd, tau, (R)0.0025, SUBSTEPS);
         RL_UNROLL
         for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
         R cz, cx, vz, vx;

@@ -58,6 +58,14 @@ struct LeggedModel {
     static constexpr double CONTACT_B = 3.0e2;   // N s/m while penetrating
     static constexpr double FRICTION_C = 3.0e2;  // N s/m tangential, clamped to mu * f_n
 
+    // contact table (dyn_two_legs.h)
+    static constexpr int NC = K::NC;
+    RL_HD static constexpr int cbody(int c) { return K::cbody(c); }
+    RL_HD static constexpr double cpx(int c) { return K::cpx(c); }
+    RL_HD static constexpr double cpy(int c) { return K::cpy(c); }
+    RL_HD static constexpr double crad(int c) { return K::crad(c); }
+    RL_HD static constexpr double cmu(int c) { return K::cmu(c); }
+
     // capsule end spheres against the floor z = 0
     template <typename R>
     RL_HD static void external(const R* q, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {

@@ -20,6 +20,7 @@
 // rooty, thigh, leg, foot, thigh_left, leg_left, foot_left], qd[9].
 #pragma once
 #include "dyn_legged.h"
+#include "dyn_two_legs.h"
 #include "walker_constants.h"
 
 namespace rl {
@@ -36,6 +37,7 @@ struct Walker2D {
     static constexpr int KIND = 5;
     static constexpr int SUBSTEPS = 2;      // 2 x 0.0025 s = one 0.005 s MuJoCo step, frame_skip 1
     using Tree = PlanarTree<WalkerModel>;
+    using Legs = TwoLegs<WalkerModel>;
 
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
         RL_UNROLL
@@ -99,9 +101,8 @@ struct Walker2D {
         R q[9], qd[9];
         RL_UNROLL
         for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
-        R sn[WalkerModel::NB], cs[WalkerModel::NB];
-        Tree::template angles<R>(q, sn, cs);
-        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025, sn, cs);
+        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+        Legs::template advance<R>(q, qd, tau, (R)0.0025, SUBSTEPS);
         RL_UNROLL
         for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
         R cz, cx, vz, vx;
