@@ -95,6 +95,7 @@ struct HalfCheetah {
     static constexpr int OBS = 20;
     static constexpr int ACT = 6;
     static constexpr int STATE = 18;
+    static constexpr int ACT_BUF = ACT;   // step_begin's hand-over to step_end
     static constexpr int RESET_DRAWS = 18;  // N(0,1): 9 for qpos, 9 for qvel (MuJoCo order)
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 3;
@@ -140,10 +141,12 @@ struct HalfCheetah {
         o[17] = cx; o[18] = (R)0; o[19] = cz;
     }
 
+    // Env.step in three parts (the lane-group rollout runs the sub-steps one leg per lane):
+    //   step_begin : NormalizedEnv action map, ctrl clamp, geared motor torques        (normalized_env.py:78-92)
+    //   sub-steps  : SUBSTEPS x TwoLegs::substep
+    //   step_end   : observation, reward, done                                         (half_cheetah_env.py:22-46)
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
-                           const StepOpts<R>& o = default_opts<R>()) {
-        R act[ACT], tau[CheetahModel::NB];
+    RL_HD static void step_begin(const R* a, int normalize, const StepOpts<R>& o, R* act, R* tau) {
         tau[0] = (R)0;
         RL_UNROLL
         for (int k = 0; k < ACT; ++k) {
@@ -154,25 +157,34 @@ struct HalfCheetah {
             if (o.dact) applied = v + o.dact[k];       // ctrl = inject_action_noise(action) (mujoco_env.py:175-187)
             tau[1 + k] = (R)cheetah::GEAR[1 + k] * rl_clamp(applied, (R)-1, (R)1);  // ctrllimited motor
         }
-        R q[9], qd[9];
-        RL_UNROLL
-        for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
-        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
-        Legs::template advance<R>(q, qd, tau, (R)0.0025, SUBSTEPS);
-        RL_UNROLL
-        for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
+    }
+    // k.sn / k.cs: sines of the absolute body angles of the state s (PlanarTree::angles)
+    template <typename R>
+    RL_HD static void step_end_sc(const R* s, const R* act, PlanarKin<R, CheetahModel::NB>& k, R* obs, R& reward,
+                                  bool& done, const StepOpts<R>& /*o*/) {
         R cz, cx, vz, vx;
-        Tree::template com<R>(q, qd, cz, cx, vz, vx);
+        Tree::template com_sc<R>(s, s + 9, k, cz, cx, vz, vx);
         write_obs(s, cx, cz, obs);
         // reward = comvel_x - 0.1 * 0.5 * sum(clip(action)^2)   (half_cheetah_env.py:37-46)
         R ctrl = (R)0;
         RL_UNROLL
-        for (int k = 0; k < ACT; ++k) {
-            const R c = rl_clamp(act[k], (R)-1, (R)1);
+        for (int kk = 0; kk < ACT; ++kk) {
+            const R c = rl_clamp(act[kk], (R)-1, (R)1);
             ctrl = ctrl + c * c;
         }
         reward = vx - (R)0.1 * (R)0.5 * ctrl;
         done = false;
+    }
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
+        R act[ACT], tau[CheetahModel::NB];
+        step_begin(a, normalize, o, act, tau);
+        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+        Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
+        PlanarKin<R, CheetahModel::NB> k;
+        Tree::template angles<R>(s, k.sn, k.cs);
+        step_end_sc(s, act, k, obs, reward, done, o);
     }
 
     // (x, z) of the torso subtree COM and its velocity, in the order get_body_com / get_body_comvel report them

@@ -32,6 +32,7 @@ struct Walker2D {
     static constexpr int OBS = 21;
     static constexpr int ACT = 6;
     static constexpr int STATE = 18;
+    static constexpr int ACT_BUF = ACT + 1;   // step_begin's hand-over to step_end
     static constexpr int RESET_DRAWS = 18;  // N(0,1): 9 for qpos, 9 for qvel (MuJoCo order)
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 5;
@@ -80,10 +81,10 @@ struct Walker2D {
         o[18] = cx; o[19] = (R)0; o[20] = cz;
     }
 
+    // Env.step in three parts (the lane-group rollout runs the sub-steps one leg per lane); act[ACT] carries the
+    // clipped action, act[ACT] the control cost accumulated in step_begin
     template <typename R>
-    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
-                           const StepOpts<R>& o = default_opts<R>()) {
-        R act[ACT], tau[WalkerModel::NB];
+    RL_HD static void step_begin(const R* a, int normalize, const StepOpts<R>& o, R* act, R* tau) {
         tau[0] = (R)0;
         R ctrl_cost = (R)0;
         RL_UNROLL
@@ -98,20 +99,29 @@ struct Walker2D {
             const R sc = act[k] / ((ub - lb) * (R)0.5);
             ctrl_cost = ctrl_cost + sc * sc;
         }
-        R q[9], qd[9];
-        RL_UNROLL
-        for (int i = 0; i < 9; ++i) { q[i] = s[i]; qd[i] = s[9 + i]; }
-        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
-        Legs::template advance<R>(q, qd, tau, (R)0.0025, SUBSTEPS);
-        RL_UNROLL
-        for (int i = 0; i < 9; ++i) { s[i] = q[i]; s[9 + i] = qd[i]; }
+        act[ACT] = ctrl_cost;
+    }
+    template <typename R>
+    RL_HD static void step_end_sc(const R* s, const R* act, PlanarKin<R, WalkerModel::NB>& k, R* obs, R& reward,
+                                  bool& done, const StepOpts<R>& o) {
         R cz, cx, vz, vx;
-        Tree::template com<R>(q, qd, cz, cx, vz, vx);
+        Tree::template com_sc<R>(s, s + 9, k, cz, cx, vz, vx);
         write_obs(s, cx, cz, obs);
         // reward = comvel_x - 0.5 * 1e-2 * sum((action / scaling)^2)      (walker2d_env.py:35-44)
-        reward = vx - (R)0.5 * o.ctrl_cost_coeff * ctrl_cost;
+        reward = vx - (R)0.5 * o.ctrl_cost_coeff * act[ACT];
         // done = not (0.8 < qpos[0] < 2.0 and -1 < qpos[2] < 1)            (:46-48)
         done = !(s[0] > (R)0.8 && s[0] < (R)2.0 && s[2] > (R)-1.0 && s[2] < (R)1.0);
+    }
+    template <typename R>
+    RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
+                           const StepOpts<R>& o = default_opts<R>()) {
+        R act[ACT + 1], tau[WalkerModel::NB];
+        step_begin(a, normalize, o, act, tau);
+        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+        Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
+        PlanarKin<R, WalkerModel::NB> k;
+        Tree::template angles<R>(s, k.sn, k.cs);
+        step_end_sc(s, act, k, obs, reward, done, o);
     }
 
     template <typename R> RL_HD static void com(const R* s, R* c4) {

@@ -780,6 +780,201 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     }
 }
 
+// ---------------------------------------------------------------------------
+// Lane-group rollout of the two-legged envs (HalfCheetah, Walker2D): 16 envs per wavefront, everything per
+// env-step env-per-lane on four replicas exactly as in rollout_kernel, and the physics sub-steps ONE LEG PER LANE
+// (dyn_two_legs.h, V = float): lane 4e + b of env e's quad walks the chain torso -> leg (b & 1), the other leg's
+// contributions to the torso arrive by quad-permute DPP (15 values per sub-step); lanes 2, 3 shadow lanes 0, 1.
+// The legs' state stays in the lanes across env-steps; each step hands the six motor torques in and the new state
+// and the sines of its seven absolute angles (one rl_sincos per lane and body of its chain) back out.
+// ---------------------------------------------------------------------------
+struct DppPair {
+    __device__ __forceinline__ float other(float v) const {      // quad_perm [1,0,3,2]
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    }
+};
+
+template <class Env, int H>
+__global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutDev a) {
+    using Legs = typename Env::Legs;
+    using Tree = typename Env::Tree;
+    using Pol = RolloutPolicy16<Env, H>;
+    Pol pol;
+    pol.init(a.theta);
+
+    const int n = a.n, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int el = lane & (QUAD_ENVS - 1);            // env slot of this lane in the env-per-lane phases
+    const int i_raw = wave_global * QUAD_ENVS + el;
+    const bool live = (i_raw < n) && (lane < QUAD_ENVS);   // one of the four copies stores
+    const int i = (i_raw < n) ? i_raw : n - 1;
+    const uint32_t env_global = (uint32_t)(a.env_offset + i);
+    const size_t plane = (size_t)T * n;
+    // lane-group phase: quad lane / 4 works on the env held by lane q_src, this lane on leg (lane & 1)
+    const int q_src = lane >> 2, leg = lane & 1;
+    const typename Legs::template LegK<float> kc = Legs::template leg_constants<float>(leg);
+    const DppPair dpp;
+
+    float std_[Env::ACT];
+#pragma unroll
+    for (int k = 0; k < Env::ACT; ++k) std_[k] = __expf(fmaxf(pol.log_std(k), a.log_min_std));
+
+    float s[Env::STATE];
+    load_state<Env>(a.state, n, i, s);
+    int ts = a.ts[i];
+    const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
+    if (a.reset_at_start) {
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg);
+        ts = 0;
+    }
+    float o[Env::OBS];
+    float zq[Env::ACT] = {};      // policy noise of four steps, one step per replica group (lane-group shapes)
+    Env::template observe<float>(s, o);
+    const size_t obs_z_slice = (size_t)Env::OBS * n;
+    observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
+    uint32_t lane_f32 = (uint32_t)i * 4, lane_u8 = (uint32_t)i;      // byte offset of env i inside a row
+
+    typename Legs::template State<float> ls;        // resident across env-steps (valid until a reset touches the wavefront)
+    bool chain_valid = false;
+    const StepOpts<float> base_opts = opts_from_cfg<float>(a.cfg);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t off = (size_t)t * n + i;
+        const size_t row = (size_t)t * n;
+        if (live) store_planes<Env::OBS>(a.obs + row, plane, lane_f32, o);
+        float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
+        pol.forward16(o, mean);
+        if (a.eps) {
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
+        } else {
+            // four steps' noise at once, one step per replica group (see rollout_kernel)
+            if ((t & 3) == 0)
+                philox_draws<Env::ACT, true>(zq, a.seed, env_global, a.step_counter + (uint64_t)(t + (lane >> 4)),
+                                             RNG_POLICY);
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) z[k] = __shfl(zq[k], el + 16 * (t & 3), 64);
+        }
+#pragma unroll
+        for (int k = 0; k < Env::ACT; ++k) act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
+        if (live) {
+            store_planes<Env::ACT>(a.actions + row, plane, lane_f32, act);
+            store_planes<Env::ACT>(a.means + row, plane, lane_f32, mean);
+        }
+
+        // ---- Env.step: begin (env per lane) -> sub-steps (one leg per lane) -> end (env per lane) ----
+        float eact[Env::ACT_BUF], tau[7];
+        StepOpts<float> opts = base_opts;
+        float dact[Env::ACT];
+        if (a.cfg.action_noise != 0.0f) {      // wave-uniform: MujocoEnv(action_noise=..) (mujoco_env.py:175-187)
+            float zn[Env::ACT];
+            noise_draws<Env::ACT>(zn, a.act_noise_z ? a.act_noise_z + (size_t)t * Env::ACT * n : nullptr, n, i, a.seed,
+                                  env_global, a.step_counter + (uint64_t)t, RNG_ACT_NOISE);
+            action_perturbation<Env, float>(a.cfg, zn, dact);
+            opts.dact = dact;
+        }
+        Env::template step_begin<float>(act, a.normalize, opts, eact, tau);
+        PlanarKin<float, 7> kin;
+        {
+            float lact[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float tb = __shfl(tau[1 + j], q_src, 64), tf = __shfl(tau[4 + j], q_src, 64);
+                lact[j] = leg ? tf : tb;
+            }
+            if (!chain_valid) {
+                // hand the env of lane q_src to its quad (first step, and after a reset anywhere in the wavefront)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    ls.qr[r] = __shfl(s[r], q_src, 64);
+                    ls.qdr[r] = __shfl(s[9 + r], q_src, 64);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float qb = __shfl(s[3 + j], q_src, 64), qf = __shfl(s[6 + j], q_src, 64);
+                    const float vb = __shfl(s[12 + j], q_src, 64), vf = __shfl(s[15 + j], q_src, 64);
+                    ls.q[j] = leg ? qf : qb;
+                    ls.qd[j] = leg ? vf : vb;
+                }
+            }
+            // exact sines of the chain's absolute angles (PlanarTree::angles: phi_child = phi_parent + hinge) -- unless
+            // they are the ones evaluated after the previous step's sub-steps
+            if (!chain_valid) {
+                float phi = ls.qr[2];
+                rl_sincos(phi, ls.sn[0], ls.cs[0]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    phi = phi + ls.q[j];
+                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
+                }
+            }
+            for (int it = 0; it < Env::SUBSTEPS; ++it)
+                Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
+            // the sines of the new angles: step_end's centre of mass needs all seven now, the next step starts from them
+            {
+                float phi = ls.qr[2];
+                rl_sincos(phi, ls.sn[0], ls.cs[0]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    phi = phi + ls.q[j];
+                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
+                }
+            }
+            chain_valid = true;
+            // back to the env-per-lane copies: lane 4 el holds the back leg, 4 el + 1 the front leg
+            const int base = 4 * el;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                s[r] = __shfl(ls.qr[r], base, 64);
+                s[9 + r] = __shfl(ls.qdr[r], base, 64);
+            }
+            kin.sn[0] = __shfl(ls.sn[0], base, 64);
+            kin.cs[0] = __shfl(ls.cs[0], base, 64);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                s[3 + j] = __shfl(ls.q[j], base, 64);
+                s[6 + j] = __shfl(ls.q[j], base + 1, 64);
+                s[12 + j] = __shfl(ls.qd[j], base, 64);
+                s[15 + j] = __shfl(ls.qd[j], base + 1, 64);
+                kin.sn[1 + j] = __shfl(ls.sn[1 + j], base, 64);
+                kin.sn[4 + j] = __shfl(ls.sn[1 + j], base + 1, 64);
+                kin.cs[1 + j] = __shfl(ls.cs[1 + j], base, 64);
+                kin.cs[4 + j] = __shfl(ls.cs[1 + j], base + 1, 64);
+            }
+        }
+        float r;
+        bool d;
+        Env::template step_end_sc<float>(s, eact, kin, o, r, d, opts);
+
+        ts += 1;
+        if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
+        if (live) {
+            const float rs = r * a.scale_reward;
+            const uint8_t db = d ? 1 : 0;
+            store_planes<1>(a.rewards + row, plane, lane_f32, &rs);
+            store_planes<1>(a.dones + row, plane, lane_u8, &db);
+        }
+        if (d) {
+            const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg);
+            Env::template observe<float>(s, o);
+            ts = 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(d) != 0) chain_valid = false;     // some env of this wavefront starts afresh
+        observed<Env>(o, a.cfg, a.obs_noise_z ? a.obs_noise_z + (size_t)(t + 1) * obs_z_slice : nullptr, n, i, a.seed,
+                      env_global, a.step_counter + (uint64_t)t + 1);
+    }
+    if (live) {
+        store_state<Env>(a.state, n, i, s);
+        a.ts[i] = ts;
+        if (a.last_obs) {
+#pragma unroll
+            for (int k = 0; k < Env::OBS; ++k) a.last_obs[(size_t)k * n + i] = o[k];
+        }
+    }
+}
+
 __global__ void philox_debug_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                     uint32_t k1, int count, uint32_t* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -888,6 +1083,19 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, qblock, 0, st, a);
             else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), qgrid, qblock, 0, st, a);
             return check_launch("rollout_swimmer_quad_kernel");
+        }
+    }
+    if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
+        // one leg per lane while every lane-group wavefront still gets a SIMD of its own (RLLAB_TWO_LEG_LANE_KERNEL=0:
+        // the generic kernel, for A/B timing and for the tests that run every shape)
+        const char* tl = getenv("RLLAB_TWO_LEG_LANE_KERNEL");
+        const bool lanes_on = !(tl && tl[0] == '0') && getenv("RLLAB_ROLLOUT_EPW") == nullptr;
+        if (lanes_on && a.n <= 16 * 1024 && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
+            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
+            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
+            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32>), qgrid, qblock, 0, st, a);
+            else hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64>), qgrid, qblock, 0, st, a);
+            return check_launch("rollout_two_leg_quad_kernel");
         }
     }
     // 16 envs per wavefront while that still leaves every wavefront a SIMD of its own (1024 SIMDs); beyond, the
