@@ -126,7 +126,7 @@ struct HalfCheetah {
     // obs = [qpos[1:], qvel, com_subtree(torso)] (half_cheetah_env.py:22-27)
     template <typename R> RL_HD static void observe(const R* s, R* o) {
         R cz, cx, vz, vx;
-        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
         write_obs(s, cx, cz, o);
     }
 
@@ -158,12 +158,10 @@ struct HalfCheetah {
             tau[1 + k] = (R)cheetah::GEAR[1 + k] * rl_clamp(applied, (R)-1, (R)1);  // ctrllimited motor
         }
     }
-    // k.sn / k.cs: sines of the absolute body angles of the state s (PlanarTree::angles)
+    // (cz, cx, vz, vx): centre of mass of the state s and its velocity (TwoLegs::com)
     template <typename R>
-    RL_HD static void step_end_sc(const R* s, const R* act, PlanarKin<R, CheetahModel::NB>& k, R* obs, R& reward,
-                                  bool& done, const StepOpts<R>& /*o*/) {
-        R cz, cx, vz, vx;
-        Tree::template com_sc<R>(s, s + 9, k, cz, cx, vz, vx);
+    RL_HD static void step_end_com(const R* s, const R* act, R cz, R cx, R /*vz*/, R vx, R* obs, R& reward, bool& done,
+                                   const StepOpts<R>& /*o*/) {
         write_obs(s, cx, cz, obs);
         // reward = comvel_x - 0.1 * 0.5 * sum(clip(action)^2)   (half_cheetah_env.py:37-46)
         R ctrl = (R)0;
@@ -182,15 +180,15 @@ struct HalfCheetah {
         step_begin(a, normalize, o, act, tau);
         // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
         Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
-        PlanarKin<R, CheetahModel::NB> k;
-        Tree::template angles<R>(s, k.sn, k.cs);
-        step_end_sc(s, act, k, obs, reward, done, o);
+        R cz, cx, vz, vx;
+        Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
+        step_end_com(s, act, cz, cx, vz, vx, obs, reward, done, o);
     }
 
     // (x, z) of the torso subtree COM and its velocity, in the order get_body_com / get_body_comvel report them
     template <typename R> RL_HD static void com(const R* s, R* c4) {
         R cz, cx, vz, vx;
-        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
         c4[0] = cx; c4[1] = cz; c4[2] = vx; c4[3] = vz;
     }
     static constexpr bool HAS_COM = true;

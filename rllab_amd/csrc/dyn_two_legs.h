@@ -213,40 +213,77 @@ struct TwoLegs {
         tz = tz + rl_if_pos(depth, mom, zero);
     }
 
+    // positions / velocities along the chain torso -> leg, relative to the root origin (dyn_planar.h kinematics_sc)
+    template <typename V>
+    struct Kin {
+        V om[4], ax[4], ay[4], lx[4], ly[4], ex[4], ey[4], px[4], py[4], vax[4], vay[4], vpx[4], vpy[4];
+    };
+    template <typename R, typename V>
+    RL_HD static void kinematics(const LegK<V>& c, const State<V>& s, Kin<V>& k) {
+        const V zero = Lanes<V>::splat((R)0);
+        k.om[0] = s.qdr[2];
+        RL_UNROLL
+        for (int i = 1; i < 4; ++i) k.om[i] = k.om[i - 1] + s.qd[i - 1];
+        k.vax[0] = s.qdr[0]; k.vay[0] = s.qdr[1];
+        k.ex[0] = s.cs[0] * (R)Mdl::cx(0) - s.sn[0] * (R)Mdl::cy(0);
+        k.ey[0] = s.sn[0] * (R)Mdl::cx(0) + s.cs[0] * (R)Mdl::cy(0);
+        k.px[0] = k.ex[0]; k.py[0] = k.ey[0];
+        k.ax[0] = zero; k.ay[0] = zero; k.lx[0] = zero; k.ly[0] = zero;      // the root anchor is the origin
+        RL_UNROLL
+        for (int i = 1; i < 4; ++i) {
+            const int p = i - 1, j = i - 1;
+            k.lx[i] = s.cs[p] * c.jx[j] - s.sn[p] * c.jy[j];                 // R(phi_parent) * joint offset
+            k.ly[i] = s.sn[p] * c.jx[j] + s.cs[p] * c.jy[j];
+            if (i == 1) { k.ax[i] = k.lx[i]; k.ay[i] = k.ly[i]; }
+            else { k.ax[i] = k.ax[p] + k.lx[i]; k.ay[i] = k.ay[p] + k.ly[i]; }
+            k.vax[i] = k.vax[p] - k.om[p] * k.ly[i];                         // + Omega_p x d
+            k.vay[i] = k.vay[p] + k.om[p] * k.lx[i];
+            k.ex[i] = s.cs[i] * c.cx[j] - s.sn[i] * c.cy[j];                 // R(phi_i) * com offset
+            k.ey[i] = s.sn[i] * c.cx[j] + s.cs[i] * c.cy[j];
+            k.px[i] = k.ax[i] + k.ex[i];
+            k.py[i] = k.ay[i] + k.ey[i];
+        }
+        RL_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            k.vpx[i] = k.vax[i] - k.om[i] * k.ey[i];
+            k.vpy[i] = k.vay[i] + k.om[i] * k.ex[i];
+        }
+    }
+    // centre of mass of the whole tree (world) and its velocity: torso + (own leg + other leg), scaled by 1 / total mass
+    template <typename R, typename V, class X>
+    RL_HD static void com(const X& x, const LegK<V>& c, const State<V>& s, V& cx, V& cy, V& vx, V& vy) {
+        Kin<V> k;
+        kinematics<R, V>(c, s, k);
+        V lsx = c.mass[0] * k.px[1], lsy = c.mass[0] * k.py[1];
+        V lvx = c.mass[0] * k.vpx[1], lvy = c.mass[0] * k.vpy[1];
+        RL_UNROLL
+        for (int i = 2; i < 4; ++i) {
+            lsx = lsx + c.mass[i - 1] * k.px[i];
+            lsy = lsy + c.mass[i - 1] * k.py[i];
+            lvx = lvx + c.mass[i - 1] * k.vpx[i];
+            lvy = lvy + c.mass[i - 1] * k.vpy[i];
+        }
+        const R m0 = (R)Mdl::mass(0), im = (R)(1.0 / total_mass());
+        const V sx = m0 * k.px[0] + (lsx + x.other(lsx));
+        const V sy = m0 * k.py[0] + (lsy + x.other(lsy));
+        const V mvx = m0 * k.vpx[0] + (lvx + x.other(lvx));
+        const V mvy = m0 * k.vpy[0] + (lvy + x.other(lvy));
+        cx = s.qr[0] + sx * im;
+        cy = s.qr[1] + sy * im;
+        vx = mvx * im;
+        vy = mvy * im;
+    }
+
     // One sub-step of length h.  act[j]: motor torque on the leg's j-th hinge.  X: x.other(v) = the other leg's v.
     template <typename R, typename V, class X>
     RL_HD static void substep(const X& x, const LegK<V>& c, State<V>& s, const V* act, R h) {
         constexpr double GX = Mdl::gx(), GY = Mdl::gy();
-        // ---- kinematics of the chain torso -> leg ----------------------------------------------------------------------
-        V om[4], ax[4], ay[4], lx[4], ly[4], ex[4], ey[4], px[4], py[4], vax[4], vay[4], vpx[4], vpy[4];
-        om[0] = s.qdr[2];
-        RL_UNROLL
-        for (int i = 1; i < 4; ++i) om[i] = om[i - 1] + s.qd[i - 1];
-        vax[0] = s.qdr[0]; vay[0] = s.qdr[1];
-        ex[0] = s.cs[0] * (R)Mdl::cx(0) - s.sn[0] * (R)Mdl::cy(0);
-        ey[0] = s.sn[0] * (R)Mdl::cx(0) + s.cs[0] * (R)Mdl::cy(0);
-        px[0] = ex[0]; py[0] = ey[0];
         const V zero = Lanes<V>::splat((R)0);
-        ax[0] = zero; ay[0] = zero; lx[0] = zero; ly[0] = zero;                  // the root anchor is the origin
-        RL_UNROLL
-        for (int i = 1; i < 4; ++i) {
-            const int p = i - 1, j = i - 1;
-            lx[i] = s.cs[p] * c.jx[j] - s.sn[p] * c.jy[j];                   // R(phi_parent) * joint offset
-            ly[i] = s.sn[p] * c.jx[j] + s.cs[p] * c.jy[j];
-            if (i == 1) { ax[i] = lx[i]; ay[i] = ly[i]; }
-            else { ax[i] = ax[p] + lx[i]; ay[i] = ay[p] + ly[i]; }
-            vax[i] = vax[p] - om[p] * ly[i];                                 // + Omega_p x d
-            vay[i] = vay[p] + om[p] * lx[i];
-            ex[i] = s.cs[i] * c.cx[j] - s.sn[i] * c.cy[j];                   // R(phi_i) * com offset
-            ey[i] = s.sn[i] * c.cx[j] + s.cs[i] * c.cy[j];
-            px[i] = ax[i] + ex[i];
-            py[i] = ay[i] + ey[i];
-        }
-        RL_UNROLL
-        for (int i = 0; i < 4; ++i) {
-            vpx[i] = vax[i] - om[i] * ey[i];
-            vpy[i] = vay[i] + om[i] * ex[i];
-        }
+        Kin<V> kn;
+        kinematics<R, V>(c, s, kn);
+        V (&om)[4] = kn.om; V (&ax)[4] = kn.ax; V (&ay)[4] = kn.ay; V (&lx)[4] = kn.lx; V (&ly)[4] = kn.ly;
+        V (&ex)[4] = kn.ex; V (&ey)[4] = kn.ey; V (&px)[4] = kn.px; V (&py)[4] = kn.py;
+        V (&vax)[4] = kn.vax; V (&vay)[4] = kn.vay;
         // ---- hinge torques: spring (ref 0), damper, soft range limits, motor ---------------------------------------------
         V tau[4];
         RL_UNROLL
@@ -419,6 +456,18 @@ struct TwoLegs {
             q[3 + j] = s.q[j].x; q[6 + j] = s.q[j].y;
             qd[3 + j] = s.qd[j].x; qd[6 + j] = s.qd[j].y;
         }
+    }
+    // centre of mass of (q, qd) and its velocity, env-per-lane form (exact sines of the seven absolute angles)
+    template <typename R>
+    RL_HD static void com_of(const R* q, const R* qd, R& cx, R& cy, R& vx, R& vy) {
+        R sn[NB], cs[NB];
+        PlanarTree<Mdl>::template angles<R>(q, sn, cs);
+        State<V2<R>> s;
+        load(q, qd, sn, cs, s);
+        const LegK<V2<R>> k = both_leg_constants<R>();
+        V2<R> c0, c1, v0, v1;
+        com<R, V2<R>, BothLegs>(BothLegs(), k, s, c0, c1, v0, v1);
+        cx = c0.x; cy = c1.x; vx = v0.x; vy = v1.x;
     }
     // n sub-steps from (q, qd) with hinge torques tau[1..6] (tau[0] unused), exact sines at the start
     template <typename R>

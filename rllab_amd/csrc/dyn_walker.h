@@ -66,7 +66,7 @@ struct Walker2D {
     // obs = [qpos, qvel, com_subtree(torso)] in MuJoCo's convention (walker2d_env.py:28-33)
     template <typename R> RL_HD static void observe(const R* s, R* o) {
         R cz, cx, vz, vx;
-        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
         write_obs(s, cx, cz, o);
     }
 
@@ -102,10 +102,8 @@ struct Walker2D {
         act[ACT] = ctrl_cost;
     }
     template <typename R>
-    RL_HD static void step_end_sc(const R* s, const R* act, PlanarKin<R, WalkerModel::NB>& k, R* obs, R& reward,
-                                  bool& done, const StepOpts<R>& o) {
-        R cz, cx, vz, vx;
-        Tree::template com_sc<R>(s, s + 9, k, cz, cx, vz, vx);
+    RL_HD static void step_end_com(const R* s, const R* act, R cz, R cx, R /*vz*/, R vx, R* obs, R& reward, bool& done,
+                                   const StepOpts<R>& o) {
         write_obs(s, cx, cz, obs);
         // reward = comvel_x - 0.5 * 1e-2 * sum((action / scaling)^2)      (walker2d_env.py:35-44)
         reward = vx - (R)0.5 * o.ctrl_cost_coeff * act[ACT];
@@ -119,14 +117,14 @@ struct Walker2D {
         step_begin(a, normalize, o, act, tau);
         // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
         Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
-        PlanarKin<R, WalkerModel::NB> k;
-        Tree::template angles<R>(s, k.sn, k.cs);
-        step_end_sc(s, act, k, obs, reward, done, o);
+        R cz, cx, vz, vx;
+        Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
+        step_end_com(s, act, cz, cx, vz, vx, obs, reward, done, o);
     }
 
     template <typename R> RL_HD static void com(const R* s, R* c4) {
         R cz, cx, vz, vx;
-        Tree::template com<R>(s, s + 9, cz, cx, vz, vx);
+        Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
         c4[0] = cx; c4[1] = cz; c4[2] = vx; c4[3] = vz;
     }
     static constexpr bool HAS_COM = true;

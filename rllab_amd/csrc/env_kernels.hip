@@ -833,7 +833,25 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
     Env::template observe<float>(s, o);
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
-    uint32_t lane_f32 = (uint32_t)i * 4, lane_u8 = (uint32_t)i;      // byte offset of env i inside a row
+    // output addressing as in rollout_swimmer_quad_kernel: uniform base per array + 32-bit byte offset per lane and plane
+    uint32_t vo_obs[Env::OBS], vo_act[Env::ACT];
+#pragma unroll
+    for (int k = 0; k < Env::OBS; ++k) {
+        vo_obs[k] = (uint32_t)(((size_t)k * plane + (size_t)i) * 4);
+        asm volatile("" : "+v"(vo_obs[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < Env::ACT; ++k) {
+        vo_act[k] = (uint32_t)(((size_t)k * plane + (size_t)i) * 4);
+        asm volatile("" : "+v"(vo_act[k]));
+    }
+    uint32_t vo_row = (uint32_t)i * 4, vo_done = (uint32_t)i;
+    asm volatile("" : "+v"(vo_row), "+v"(vo_done));
+    auto at = [](auto* base, size_t row_elems, uint32_t& byte_off) {
+        using P = decltype(base);
+        asm volatile("" : "+v"(byte_off));
+        return reinterpret_cast<P>(reinterpret_cast<char*>(base + row_elems) + byte_off);
+    };
 
     typename Legs::template State<float> ls;        // resident across env-steps (valid until a reset touches the wavefront)
     bool chain_valid = false;
@@ -842,7 +860,10 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
     for (int t = 0; t < T; ++t) {
         const size_t off = (size_t)t * n + i;
         const size_t row = (size_t)t * n;
-        if (live) store_planes<Env::OBS>(a.obs + row, plane, lane_f32, o);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < Env::OBS; ++k) *at(a.obs, row, vo_obs[k]) = o[k];
+        }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
         pol.forward16(o, mean);
         if (a.eps) {
@@ -859,8 +880,11 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
 #pragma unroll
         for (int k = 0; k < Env::ACT; ++k) act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
         if (live) {
-            store_planes<Env::ACT>(a.actions + row, plane, lane_f32, act);
-            store_planes<Env::ACT>(a.means + row, plane, lane_f32, mean);
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) {
+                *at(a.actions, row, vo_act[k]) = act[k];
+                *at(a.means, row, vo_act[k]) = mean[k];
+            }
         }
 
         // ---- Env.step: begin (env per lane) -> sub-steps (one leg per lane) -> end (env per lane) ----
@@ -875,7 +899,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
             opts.dact = dact;
         }
         Env::template step_begin<float>(act, a.normalize, opts, eact, tau);
-        PlanarKin<float, 7> kin;
+        float com4[4];
         {
             float lact[3];
 #pragma unroll
@@ -911,7 +935,8 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
             }
             for (int it = 0; it < Env::SUBSTEPS; ++it)
                 Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
-            // the sines of the new angles: step_end's centre of mass needs all seven now, the next step starts from them
+            // the sines of the new angles: the centre of mass of step_end needs them now (each lane its chain's part,
+            // TwoLegs::com), the next step's sub-steps start from them
             {
                 float phi = ls.qr[2];
                 rl_sincos(phi, ls.sn[0], ls.cs[0]);
@@ -922,6 +947,8 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
                 }
             }
             chain_valid = true;
+            float lc[4];
+            Legs::template com<float, float, DppPair>(dpp, kc, ls, lc[0], lc[1], lc[2], lc[3]);
             // back to the env-per-lane copies: lane 4 el holds the back leg, 4 el + 1 the front leg
             const int base = 4 * el;
 #pragma unroll
@@ -929,31 +956,25 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
                 s[r] = __shfl(ls.qr[r], base, 64);
                 s[9 + r] = __shfl(ls.qdr[r], base, 64);
             }
-            kin.sn[0] = __shfl(ls.sn[0], base, 64);
-            kin.cs[0] = __shfl(ls.cs[0], base, 64);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 s[3 + j] = __shfl(ls.q[j], base, 64);
                 s[6 + j] = __shfl(ls.q[j], base + 1, 64);
                 s[12 + j] = __shfl(ls.qd[j], base, 64);
                 s[15 + j] = __shfl(ls.qd[j], base + 1, 64);
-                kin.sn[1 + j] = __shfl(ls.sn[1 + j], base, 64);
-                kin.sn[4 + j] = __shfl(ls.sn[1 + j], base + 1, 64);
-                kin.cs[1 + j] = __shfl(ls.cs[1 + j], base, 64);
-                kin.cs[4 + j] = __shfl(ls.cs[1 + j], base + 1, 64);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) com4[k] = __shfl(lc[k], base, 64);
         }
         float r;
         bool d;
-        Env::template step_end_sc<float>(s, eact, kin, o, r, d, opts);
+        Env::template step_end_com<float>(s, eact, com4[0], com4[1], com4[2], com4[3], o, r, d, opts);
 
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
         if (live) {
-            const float rs = r * a.scale_reward;
-            const uint8_t db = d ? 1 : 0;
-            store_planes<1>(a.rewards + row, plane, lane_f32, &rs);
-            store_planes<1>(a.dones + row, plane, lane_u8, &db);
+            *at(a.rewards, row, vo_row) = r * a.scale_reward;
+            *at(a.dones, row, vo_done) = d ? 1 : 0;
         }
         if (d) {
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
@@ -1090,7 +1111,9 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         // the generic kernel, for A/B timing and for the tests that run every shape)
         const char* tl = getenv("RLLAB_TWO_LEG_LANE_KERNEL");
         const bool lanes_on = !(tl && tl[0] == '0') && getenv("RLLAB_ROLLOUT_EPW") == nullptr;
-        if (lanes_on && a.n <= 16 * 1024 && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
+        const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
+        if (lanes_on && small_offsets && a.n <= 16 * 1024 && (g->hidden0 == g->hidden1) &&
+            (g->hidden0 == 32 || g->hidden0 == 64)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
             dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
             if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32>), qgrid, qblock, 0, st, a);
