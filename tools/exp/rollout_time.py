@@ -11,13 +11,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CHILD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
-from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
-from rllab_amd.envs.mujoco.half_cheetah_env import HalfCheetahEnv
+import importlib
+ENVS = dict(swimmer=("rllab_amd.envs.mujoco.swimmer_env", "SwimmerEnv"), half_cheetah=("rllab_amd.envs.mujoco.half_cheetah_env", "HalfCheetahEnv"),
+            walker2d=("rllab_amd.envs.mujoco.walker2d_env", "Walker2DEnv"), hopper=("rllab_amd.envs.mujoco.hopper_env", "HopperEnv"),
+            cartpole=("rllab_amd.envs.box2d.cartpole_env", "CartpoleEnv"), double_pendulum=("rllab_amd.envs.box2d.double_pendulum_env", "DoublePendulumEnv"))
 from rllab_amd.envs.normalized_env import normalize
 from rllab_amd.envs.hip_env import HipVecEnv
 from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
 kind, n, T, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-env = normalize(SwimmerEnv() if kind == "swimmer" else HalfCheetahEnv())
+mod, cls = ENVS[kind]
+env = normalize(getattr(importlib.import_module(mod), cls)())
 np.random.seed(0)
 pol = GaussianMLPPolicy(env.spec, hidden_sizes=(h, h))
 vec = env.vec_env_executor(n_envs=n, max_path_length=T)
