@@ -354,7 +354,117 @@ void swim_compare(const R* state, const R* ctrl2, int nsub, R* out_scalar, R* ou
 }
 }  // namespace
 
+// ---- lock-step emulation of the one-leg-per-lane form of the two-legged sub-step (rllab_amd/csrc/dyn_two_legs.h) ------
+// The same replay idea: the lane program's only cross-lane operation is x.other(v); pass k answers the first k
+// exchange points from the log and records point k.  Returns, for `nsub` sub-steps from the same (q, qd, tau), the
+// state of the packed form (both legs in two-component values: what HostEnv / the per-step kernels run) and of the
+// two emulated lanes (what rollout_two_leg_quad_kernel runs): they must be bit-identical, and the torso's replicated
+// coordinates must agree between the lanes.
+namespace {
+template <typename R>
+struct PairReplayCtx {
+    int lane, filled;
+    mutable int counter;
+    std::vector<std::array<R, 2>>* log;
+    R other(R v) const {
+        const int k = counter++;
+        if (k < filled) return (*log)[k][lane ^ 1];
+        if ((int)log->size() <= k) log->resize(k + 1);
+        if (k == filled) (*log)[k][lane] = v;
+        return v;   // beyond the recorded prefix: placeholder, this pass's result is discarded
+    }
+};
+
+template <class Env, typename R>
+void two_leg_compare(const R* state, const R* tau, int nsub, R* out_packed, R* out_lanes) {
+    using Legs = typename Env::Legs;
+    using Tree = typename Env::Tree;
+    const R h = (R)0.0025;
+    // packed: exactly what Env::step runs between step_begin and step_end
+    {
+        R q[9], qd[9];
+        for (int i = 0; i < 9; ++i) { q[i] = state[i]; qd[i] = state[9 + i]; }
+        Legs::template advance<R>(q, qd, tau, h, nsub);
+        for (int i = 0; i < 9; ++i) { out_packed[i] = q[i]; out_packed[9 + i] = qd[i]; }
+        R c[4];
+        Legs::template com_of<R>(q, qd, c[0], c[1], c[2], c[3]);
+        for (int k = 0; k < 4; ++k) out_packed[18 + k] = c[k];
+    }
+    // two lanes
+    {
+        R sn[7], cs[7];
+        Tree::template angles<R>(state, sn, cs);
+        typename Legs::template State<R> lanes[2];
+        typename Legs::template LegK<R> kc[2];
+        R act[2][3];
+        for (int l = 0; l < 2; ++l) {
+            kc[l] = Legs::template leg_constants<R>(l);
+            for (int r = 0; r < 3; ++r) { lanes[l].qr[r] = state[r]; lanes[l].qdr[r] = state[9 + r]; }
+            lanes[l].sn[0] = sn[0]; lanes[l].cs[0] = cs[0];
+            for (int j = 0; j < 3; ++j) {
+                lanes[l].q[j] = state[3 + 3 * l + j]; lanes[l].qd[j] = state[12 + 3 * l + j];
+                lanes[l].sn[1 + j] = sn[1 + 3 * l + j]; lanes[l].cs[1 + j] = cs[1 + 3 * l + j];
+                act[l][j] = tau[1 + 3 * l + j];
+            }
+        }
+        for (int it = 0; it < nsub; ++it) {
+            std::vector<std::array<R, 2>> log;
+            int n_points = -1;
+            typename Legs::template State<R> result[2];
+            for (int pass = 0; n_points < 0 || pass <= n_points; ++pass)
+                for (int l = 0; l < 2; ++l) {
+                    PairReplayCtx<R> x{l, pass, 0, &log};
+                    typename Legs::template State<R> s = lanes[l];
+                    Legs::template substep<R, R, PairReplayCtx<R>>(x, kc[l], s, act[l], h);
+                    n_points = x.counter;
+                    result[l] = s;
+                }
+            lanes[0] = result[0]; lanes[1] = result[1];
+        }
+        for (int r = 0; r < 3; ++r) { out_lanes[r] = lanes[0].qr[r]; out_lanes[9 + r] = lanes[0].qdr[r]; }
+        for (int l = 0; l < 2; ++l)
+            for (int j = 0; j < 3; ++j) { out_lanes[3 + 3 * l + j] = lanes[l].q[j]; out_lanes[12 + 3 * l + j] = lanes[l].qd[j]; }
+        // centre of mass as the kernel forms it: exact sines of the new angles, one chain per lane + one exchange
+        R c[2][4];
+        {
+            for (int l = 0; l < 2; ++l) {
+                R phi = lanes[l].qr[2];
+                rl::rl_sincos(phi, lanes[l].sn[0], lanes[l].cs[0]);
+                for (int j = 0; j < 3; ++j) { phi = phi + lanes[l].q[j]; rl::rl_sincos(phi, lanes[l].sn[1 + j], lanes[l].cs[1 + j]); }
+            }
+            std::vector<std::array<R, 2>> log;
+            int n_points = -1;
+            for (int pass = 0; n_points < 0 || pass <= n_points; ++pass)
+                for (int l = 0; l < 2; ++l) {
+                    PairReplayCtx<R> x{l, pass, 0, &log};
+                    Legs::template com<R, R, PairReplayCtx<R>>(x, kc[l], lanes[l], c[l][0], c[l][1], c[l][2], c[l][3]);
+                    n_points = x.counter;
+                }
+        }
+        for (int k = 0; k < 4; ++k) out_lanes[18 + k] = c[0][k];
+        // the replicated torso coordinates and the centre of mass must agree between the lanes
+        bool same = true;
+        for (int r = 0; r < 3; ++r) same = same && lanes[0].qr[r] == lanes[1].qr[r] && lanes[0].qdr[r] == lanes[1].qdr[r];
+        for (int k = 0; k < 4; ++k) same = same && c[0][k] == c[1][k];
+        if (!same) out_lanes[0] = out_lanes[0] * (R)0 + (R)1e30;   // poison: caught by the test
+    }
+}
+}  // namespace
+
 extern "C" {
+// kind: 3 = HalfCheetah, 5 = Walker2D.  state[18] = (q, qd), tau[7] (tau[0] unused).  out_*[22] = q, qd, centre of mass (4)
+int oracle_two_leg_compare_f32(int kind, const float* state, const float* tau, int nsub, float* out_packed, float* out_lanes) {
+    if (kind == 3) two_leg_compare<rl::HalfCheetah, float>(state, tau, nsub, out_packed, out_lanes);
+    else if (kind == 5) two_leg_compare<rl::Walker2D, float>(state, tau, nsub, out_packed, out_lanes);
+    else return -1;
+    return 0;
+}
+int oracle_two_leg_compare_f64(int kind, const double* state, const double* tau, int nsub, double* out_packed, double* out_lanes) {
+    if (kind == 3) two_leg_compare<rl::HalfCheetah, double>(state, tau, nsub, out_packed, out_lanes);
+    else if (kind == 5) two_leg_compare<rl::Walker2D, double>(state, tau, nsub, out_packed, out_lanes);
+    else return -1;
+    return 0;
+}
 int oracle_swim_quad_compare_f32(const float* state, const float* ctrl2, int nsub, float* out_scalar, float* out_quad) {
     swim_compare<float>(state, ctrl2, nsub, out_scalar, out_quad);
     return 0;

@@ -226,3 +226,18 @@ def swim_quad_compare(state, ctrl, nsub, dtype=np.float32):
     a, b = np.zeros(16, dtype), np.zeros(16, dtype)
     fn(np.ascontiguousarray(state, dtype), np.ascontiguousarray(ctrl, dtype), int(nsub), a, b)
     return a, b
+
+
+lib.oracle_two_leg_compare_f32.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int, _f32p, _f32p]
+lib.oracle_two_leg_compare_f64.argtypes = [ctypes.c_int, _f64p, _f64p, ctypes.c_int, _f64p, _f64p]
+
+
+def two_leg_compare(kind, state, tau, nsub, dtype=np.float32):
+    """(packed, emulated one-leg-per-lane) results of ``nsub`` sub-steps of a two-legged env (kind 3 / 5) from one
+    state (q[9], qd[9]) under hinge torques tau[7]: 22 values each (q, qd, centre of mass and its velocity)."""
+    dtype = np.dtype(dtype)
+    fn = lib.oracle_two_leg_compare_f32 if dtype == np.float32 else lib.oracle_two_leg_compare_f64
+    a, b = np.zeros(22, dtype), np.zeros(22, dtype)
+    rc = fn(int(kind), np.ascontiguousarray(state, dtype), np.ascontiguousarray(tau, dtype), int(nsub), a, b)
+    assert rc == 0
+    return a, b

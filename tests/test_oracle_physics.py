@@ -364,6 +364,29 @@ def test_swimmer_lane_group_program_is_bitwise_the_scalar_program(dtype, nsub):
         assert a.tobytes() == b.tobytes(), (trial, a, b)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", [3, 5])
+def test_two_leg_lane_program_is_bitwise_the_packed_program(kind, dtype):
+    """dyn_two_legs.h instantiated one leg per lane (what rollout_two_leg_quad_kernel runs; emulated on the host with a
+    replayed exchange) must reproduce the packed instantiation (both legs in two-component values: the host build and
+    the per-step kernels) bit for bit -- state, and the centre of mass the observation carries -- with feet in the
+    floor, hinges beyond their limits and large rates."""
+    rng = np.random.default_rng(5)
+    z0 = 0.7 if kind == 3 else 1.25
+    touched = 0
+    for trial in range(40):
+        q = np.concatenate([[z0 + rng.uniform(-0.35, 0.1)], rng.normal(0, 1.0, 1), rng.uniform(-0.5, 0.5, 1),
+                            rng.uniform(-1.4, 1.4, 6)])
+        qd = rng.normal(0, 4.0, 9)
+        tau = np.concatenate([[0.0], rng.uniform(-1, 1, 6) * (120 if kind == 3 else 100)])
+        for nsub in (1, 4):
+            a, b = H.two_leg_compare(kind, np.concatenate([q, qd]), tau, nsub, dtype)
+            assert np.all(np.isfinite(a))
+            assert a.tobytes() == b.tobytes(), (trial, nsub, a, b)
+        touched += int(q[0] < z0 - 0.15)
+    assert touched > 5
+
+
 def test_hopper_dynamics_vs_independent_lagrangian():
     """Hopper-style env (kind 6): one env step (8 sub-steps) of the product's dynamics source, float64 host build,
     equals the model-driven autodiff-Lagrangian oracle typed in from hopper.xml in MuJoCo's coordinates -- foot on
