@@ -58,37 +58,6 @@ struct CheetahModel {
     static constexpr double CONTACT_B = 3.0e2;   // N s/m while penetrating
     static constexpr double FRICTION_C = 3.0e2;  // N s/m tangential, clamped to mu * f_n
     static constexpr double MU = 0.4;
-
-    // capsule end spheres against the floor z = 0
-    template <typename R>
-    RL_HD static void external(const R* q, const PlanarKin<R, NB>& k, R* fx, R* fy, R* tz) {
-        RL_UNROLL
-        for (int i = 0; i < NB; ++i) { fx[i] = (R)0; fy[i] = (R)0; tz[i] = (R)0; }
-        RL_UNROLL
-        for (int c = 0; c < cheetah::NC; ++c) {
-            const int b = cheetah::CBODY[c];
-            const R lx = (R)cheetah::CPX[c], ly = (R)cheetah::CPY[c];
-            // sphere centre relative to the body anchor / root origin
-            const R rx = k.cs[b] * lx - k.sn[b] * ly;
-            const R ry = k.sn[b] * lx + k.cs[b] * ly;
-            const R height = q[0] + k.ax[b] + rx;                 // P1 = z of the sphere centre
-            const R depth = (R)cheetah::CRAD - height;
-            if (depth > (R)0) {
-                // velocity of the sphere centre
-                const R vn = k.vax[b] - k.om[b] * ry;
-                const R vt = k.vay[b] + k.om[b] * rx;
-                R fn = (R)CONTACT_K * depth - (R)CONTACT_B * vn;
-                fn = rl_max(fn, (R)0);
-                const R ft = -rl_clamp((R)FRICTION_C * vt, -(R)MU * fn, (R)MU * fn);
-                // applied at the lowest point of the sphere; lever arm from the body COM
-                const R ax_ = (k.ax[b] + rx - (R)cheetah::CRAD) - k.px[b];
-                const R ay_ = (k.ay[b] + ry) - k.py[b];
-                fx[b] = fx[b] + fn;
-                fy[b] = fy[b] + ft;
-                tz[b] = tz[b] + (ax_ * ft - ay_ * fn);
-            }
-        }
-    }
 };
 
 struct HalfCheetah {

@@ -381,238 +381,13 @@ struct PlanarTree {
         });
     }
 
-    // The same accelerations by composite rigid bodies (joint-space inertia assembled from subtree
-    // mass / first moment / inertia about the root origin, bias forces by a recursive pass, translation
-    // block eliminated by a Schur complement): O(NB * depth) work where the pairwise form above is
-    // O(NB^2), so it wins for the larger trees (7-body cheetah: ~1100 vs ~1400 instructions).
-    template <typename R>
-    RL_HD static void forward_dynamics_crb(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
-                                       const R* fy, const R* tz, R* qacc) {
-        // --- velocity-product (bias) accelerations with qacc = 0 ---------------------
-        R aax[NB], aay[NB];  // anchor acceleration (the root anchor does not accelerate)
-        R Fx[NB], Fy[NB], Nz[NB];
-        static_for<0, NB>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            const R w2 = k.om[i] * k.om[i];
-            R ex, ey;                                         // COM relative to the body's own anchor
-            if constexpr (i == 0) { ex = k.px[0]; ey = k.py[0]; }
-            else { ex = k.px[i] - k.ax[i]; ey = k.py[i] - k.ay[i]; }
-            R acx, acy;
-            if constexpr (i == 0) {
-                acx = -(w2 * ex);
-                acy = -(w2 * ey);
-            } else {
-                constexpr int p = Mdl::parent(i);
-                const R wp2 = k.om[p] * k.om[p];
-                if constexpr (p == 0) {
-                    aax[i] = -(wp2 * k.ax[i]);
-                    aay[i] = -(wp2 * k.ay[i]);
-                } else {
-                    aax[i] = aax[p] - wp2 * (k.ax[i] - k.ax[p]);
-                    aay[i] = aay[p] - wp2 * (k.ay[i] - k.ay[p]);
-                }
-                acx = aax[i] - w2 * ex;
-                acy = aay[i] - w2 * ey;
-            }
-            constexpr double M_I = Mdl::mass(i);
-            // net force on body i after moving m*a_bias to the right-hand side
-            if constexpr (HAS_GRAVITY) {
-                Fx[i] = fx[i] + (R)M_I * ((R)Mdl::gx() - acx);
-                Fy[i] = fy[i] + (R)M_I * ((R)Mdl::gy() - acy);
-            } else {
-                Fx[i] = fx[i] - (R)M_I * acx;
-                Fy[i] = fy[i] - (R)M_I * acy;
-            }
-            // moment of that force about the body's own anchor, plus pure torque
-            Nz[i] = (ex * Fy[i] - ey * Fx[i]) + tz[i];
-        });
-        // --- accumulate subtree wrenches (leaves -> root) ----------------------------
-        static_for_down<NB, 1>([&](auto I) {
-            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
-            R dx, dy;
-            if constexpr (p == 0) { dx = k.ax[i]; dy = k.ay[i]; }
-            else { dx = k.ax[i] - k.ax[p]; dy = k.ay[i] - k.ay[p]; }
-            Nz[p] = Nz[p] + Nz[i] + (dx * Fy[i] - dy * Fx[i]);
-            Fx[p] = Fx[p] + Fx[i];
-            Fy[p] = Fy[p] + Fy[i];
-        });
-        // --- composite bodies: mass (compile-time), first moment, inertia about the ROOT origin ----
-        R hx[NB], hy[NB], J[NB];
-        static_for<0, NB>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr double M_I = Mdl::mass(i);
-            hx[i] = (R)M_I * k.px[i];
-            hy[i] = (R)M_I * k.py[i];
-            J[i] = (R)Mdl::inertia(i) + (R)M_I * (k.px[i] * k.px[i] + k.py[i] * k.py[i]);
-        });
-        static_for_down<NB, 1>([&](auto I) {
-            constexpr int i = decltype(I)::value, p = Mdl::parent(i);
-            hx[p] = hx[p] + hx[i];
-            hy[p] = hy[p] + hy[i];
-            J[p] = J[p] + J[i];
-        });
-        // --- joint-space inertia.  Translation rows: M_tt = m_total I_2 (constant); coupling
-        // Bx[k], By[k] = e_x / e_y . perp(h_k - mc_k a_k); rotational block C (lower triangle,
-        // entries of unrelated hinge pairs are 0).
-        R Bx[NB], By[NB];
-        R C[NB][NB];
-        static_for<0, NB>([&](auto Kk) {
-            constexpr int kk = decltype(Kk)::value;
-            constexpr double MC = subtree_mass(kk);
-            if constexpr (kk == 0) {
-                Bx[0] = -hy[0];
-                By[0] = hx[0];
-            } else {
-                Bx[kk] = -(hy[kk] - (R)MC * k.ay[kk]);
-                By[kk] = (hx[kk] - (R)MC * k.ax[kk]);
-            }
-            static_for<0, kk + 1>([&](auto Jj) {
-                constexpr int j = decltype(Jj)::value;
-                if constexpr (!is_ancestor(j, kk)) {
-                    C[kk][j] = (R)0;
-                } else if constexpr (kk == 0) {
-                    C[0][0] = J[0];
-                } else if constexpr (j == 0) {
-                    C[kk][0] = J[kk] - (k.ax[kk] * hx[kk] + k.ay[kk] * hy[kk]);
-                } else {
-                    R v = J[kk] - ((k.ax[j] + k.ax[kk]) * hx[kk] + (k.ay[j] + k.ay[kk]) * hy[kk]) +
-                          (R)MC * (k.ax[j] * k.ax[kk] + k.ay[j] * k.ay[kk]);
-                    if constexpr (j == kk && Mdl::armature(kk) != 0.0) v = v + (R)Mdl::armature(kk);
-                    C[kk][j] = v;
-                }
-            });
-        });
-        if constexpr (two_legs()) {
-            solve_two_legs<R>(Bx, By, C, Nz, tau_j, Fx[0], Fy[0], qacc);
-            return;
-        }
-        // --- eliminate the translations: S = C - B^T B / m,  b = rhs_rot - B^T rhs_xy / m -------------
-        constexpr double INV_M = 1.0 / total_mass();
-        const R gx_ = Fx[0] * (R)INV_M, gy_ = Fy[0] * (R)INV_M;   // rhs_xy / m
-        R S[NB][NB], b[NB], th[NB];
-        static_for<0, NB>([&](auto Rr) {
-            constexpr int r = decltype(Rr)::value;
-            R rhs = Nz[r];
-            if constexpr (r > 0) rhs = rhs + tau_j[r];
-            b[r] = rhs - (Bx[r] * gx_ + By[r] * gy_);
-            const R bxm = Bx[r] * (R)INV_M, bym = By[r] * (R)INV_M;
-            static_for<0, r + 1>([&](auto Cc) {
-                constexpr int c = decltype(Cc)::value;
-                if constexpr (is_ancestor(c, r)) S[r][c] = C[r][c] - (bxm * Bx[c] + bym * By[c]);
-                else S[r][c] = -(bxm * Bx[c] + bym * By[c]);
-            });
-        });
-        solve_spd<R, NB>(S, b, th);
-        // translations: xdd = (rhs_xy - B th) / m
-        R sx = (R)0, sy = (R)0;
-        static_for<0, NB>([&](auto Rr) {
-            constexpr int r = decltype(Rr)::value;
-            if constexpr (r == 0) { sx = Bx[0] * th[0]; sy = By[0] * th[0]; }
-            else { sx = sx + Bx[r] * th[r]; sy = sy + By[r] * th[r]; }
-        });
-        qacc[0] = gx_ - sx * (R)INV_M;
-        qacc[1] = gy_ - sy * (R)INV_M;
-        static_for<0, NB>([&](auto Rr) {
-            constexpr int r = decltype(Rr)::value;
-            qacc[2 + r] = th[r];
-        });
-    }
-
-    // A torso carrying two three-link legs (HalfCheetah, Walker2D): bodies 1-2-3 and 4-5-6 are chains off body 0.
-    static constexpr bool two_legs() {
-        if (NB != 7) return false;
-        constexpr int want[7] = {-1, 0, 1, 2, 0, 4, 5};
-        for (int i = 1; i < 7; ++i)
-            if (Mdl::parent(i) != want[i]) return false;
-        return true;
-    }
-
-    // x = K^-1 r for a symmetric positive definite 3x3 K given by (a, b, c, d, e, f) = (K00, K10, K20, K11, K21, K22):
-    // adjugate form, `adj` = the six cofactors times 1 / det, so several right-hand sides share ONE division
-    template <typename R>
-    RL_HD static void spd3_inverse(R a, R b, R c, R d, R e, R f, R* adj) {
-        const R A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
-        const R D = a * f - c * c, E = b * c - a * e, F = a * d - b * b;
-        const R det = a * A + (b * B + c * C);
-        const R inv = rl_recip_normal(det);
-        adj[0] = A * inv; adj[1] = B * inv; adj[2] = C * inv; adj[3] = D * inv; adj[4] = E * inv; adj[5] = F * inv;
-    }
-    template <typename R>
-    RL_HD static void spd3_apply(const R* adj, R r0, R r1, R r2, R& x0, R& x1, R& x2) {
-        x0 = adj[0] * r0 + (adj[1] * r1 + adj[2] * r2);
-        x1 = adj[1] * r0 + (adj[3] * r1 + adj[4] * r2);
-        x2 = adj[2] * r0 + (adj[4] * r1 + adj[5] * r2);
-    }
-
-    // The joint-space system of a two-legged tree,
-    //     [ m I_2   B   ] [ a  ]   [ F   ]        B_r = (Bx[r], By[r]),  C tree-sparse: legs couple only through body 0,
-    //     [ B^T     C   ] [ th ] = [ rhs ]
-    // solved leaves first: each leg's 3x3 block K_L (closed form, one division, the two legs independent of each other)
-    // is eliminated onto the root block u = (a_x, a_y, th_0), whose 3x3 Schur complement is solved in closed form, then
-    // the legs are back-substituted: th_L = K_L^-1 rhs_L - (K_L^-1 G_L) u, G_L = rows (Bx, By, C[.][0]) of the leg.
-    // Eliminating the translations first (the generic path below) fills the 7x7 rotational block completely and then
-    // needs seven sequential pivots; this order keeps the tree's sparsity: three divisions, two of them in parallel.
-    template <typename R>
-    RL_HD static void solve_two_legs(const R* Bx, const R* By, const R (&C)[NB][NB], const R* Nz, const R* tau_j,
-                                     R Fx0, R Fy0, R* qacc) {
-        R Y[2][3][3];      // K_L^-1 G_L : [leg][row in leg][x, y, th0]
-        R y[2][3];         // K_L^-1 rhs_L
-        R Rm[6];           // root block, lower triangle (xx, yx, yy, tx, ty, tt), starts as [[m, 0, Bx0], [0, m, By0], [., ., C00]]
-        R ru[3];           // root right-hand side
-        Rm[0] = (R)total_mass(); Rm[1] = (R)0; Rm[2] = (R)total_mass();
-        Rm[3] = Bx[0]; Rm[4] = By[0]; Rm[5] = C[0][0];
-        ru[0] = Fx0; ru[1] = Fy0; ru[2] = Nz[0];
-        static_for<0, 2>([&](auto Ll) {
-            constexpr int L = decltype(Ll)::value, i1 = 1 + 3 * L, i2 = i1 + 1, i3 = i1 + 2;
-            R adj[6];
-            spd3_inverse<R>(C[i1][i1], C[i2][i1], C[i3][i1], C[i2][i2], C[i3][i2], C[i3][i3], adj);
-            const R r1 = Nz[i1] + tau_j[i1], r2 = Nz[i2] + tau_j[i2], r3 = Nz[i3] + tau_j[i3];
-            spd3_apply<R>(adj, r1, r2, r3, y[L][0], y[L][1], y[L][2]);
-            const R gx[3] = {Bx[i1], Bx[i2], Bx[i3]}, gy[3] = {By[i1], By[i2], By[i3]};
-            const R gt[3] = {C[i1][0], C[i2][0], C[i3][0]};
-            spd3_apply<R>(adj, gx[0], gx[1], gx[2], Y[L][0][0], Y[L][1][0], Y[L][2][0]);
-            spd3_apply<R>(adj, gy[0], gy[1], gy[2], Y[L][0][1], Y[L][1][1], Y[L][2][1]);
-            spd3_apply<R>(adj, gt[0], gt[1], gt[2], Y[L][0][2], Y[L][1][2], Y[L][2][2]);
-            // Schur complement of the leg on the root block (symmetric: lower triangle) and on its right-hand side
-            Rm[0] = Rm[0] - (gx[0] * Y[L][0][0] + (gx[1] * Y[L][1][0] + gx[2] * Y[L][2][0]));
-            Rm[1] = Rm[1] - (gy[0] * Y[L][0][0] + (gy[1] * Y[L][1][0] + gy[2] * Y[L][2][0]));
-            Rm[2] = Rm[2] - (gy[0] * Y[L][0][1] + (gy[1] * Y[L][1][1] + gy[2] * Y[L][2][1]));
-            Rm[3] = Rm[3] - (gt[0] * Y[L][0][0] + (gt[1] * Y[L][1][0] + gt[2] * Y[L][2][0]));
-            Rm[4] = Rm[4] - (gt[0] * Y[L][0][1] + (gt[1] * Y[L][1][1] + gt[2] * Y[L][2][1]));
-            Rm[5] = Rm[5] - (gt[0] * Y[L][0][2] + (gt[1] * Y[L][1][2] + gt[2] * Y[L][2][2]));
-            ru[0] = ru[0] - (gx[0] * y[L][0] + (gx[1] * y[L][1] + gx[2] * y[L][2]));
-            ru[1] = ru[1] - (gy[0] * y[L][0] + (gy[1] * y[L][1] + gy[2] * y[L][2]));
-            ru[2] = ru[2] - (gt[0] * y[L][0] + (gt[1] * y[L][1] + gt[2] * y[L][2]));
-        });
-        R adj[6], u0, u1, u2;
-        spd3_inverse<R>(Rm[0], Rm[1], Rm[3], Rm[2], Rm[4], Rm[5], adj);
-        spd3_apply<R>(adj, ru[0], ru[1], ru[2], u0, u1, u2);
-        qacc[0] = u0;
-        qacc[1] = u1;
-        qacc[2] = u2;
-        static_for<0, 2>([&](auto Ll) {
-            constexpr int L = decltype(Ll)::value, i1 = 1 + 3 * L;
-            static_for<0, 3>([&](auto Jj) {
-                constexpr int j = decltype(Jj)::value;
-                qacc[2 + i1 + j] = y[L][j] - (Y[L][j][0] * u0 + (Y[L][j][1] * u1 + Y[L][j][2] * u2));
-            });
-        });
-    }
-
-    static constexpr double subtree_mass(int kk) {
-        double m = 0.0;
-        for (int i = kk; i < NB; ++i)
-            if (is_ancestor(kk, i)) m += Mdl::mass(i);
-        return m;
-    }
-
-    // pairwise absolute-angle form for small trees, composite rigid bodies for large ones
-    static constexpr bool USE_PAIRWISE = (NB <= 4);
+    // The pairwise absolute-angle form serves the small trees (Swimmer's scalar program, Hopper, the pendula); the
+    // two-legged seven-body trees (HalfCheetah, Walker2D) have their own sub-step, dyn_two_legs.h.
     template <typename R>
     RL_HD static void forward_dynamics(const PlanarKin<R, NB>& k, const R* tau_j, const R* fx,
                                        const R* fy, const R* tz, R* qacc) {
-        if constexpr (USE_PAIRWISE) forward_dynamics_abs(k, tau_j, fx, fy, tz, qacc);
-        else forward_dynamics_crb(k, tau_j, fx, fy, tz, qacc);
+        static_assert(NB <= 4, "trees beyond four bodies: dyn_two_legs.h");
+        forward_dynamics_abs(k, tau_j, fx, fy, tz, qacc);
     }
 
     // passive joint torques: spring (ref 0), damper, soft range limits
