@@ -450,10 +450,20 @@ def main():
                         "control flow, float64 torch-CPU closures in place of the compiled Theano functions) on a "
                         "prefix of the sampled paths; the estimate scales both linearly to the bench batch and adds "
                         "the sampling time at the reference sampler's measured rate"}
+    dist_on = dist.is_initialized()
+    if dist_on:
+        dist.destroy_process_group()
+        # RCCL leaves a banner (its version, the HIP version, hostname, library path) in the C stdio buffer of every
+        # rank; flushed at exit it would follow the JSON line.  Push it out now, print the line LAST, and leave without
+        # the exit-time flushes so that the one JSON line is also the last line of the job's stdout.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if dist_on:
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
