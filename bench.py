@@ -452,12 +452,17 @@ def main():
                         "the sampling time at the reference sampler's measured rate"}
     dist_on = dist.is_initialized()
     if dist_on:
-        dist.destroy_process_group()
         # RCCL leaves a banner (its version, the HIP version, hostname, library path) in the C stdio buffer of every
-        # rank; flushed at exit it would follow the JSON line.  Push it out now, print the line LAST, and leave without
-        # the exit-time flushes so that the one JSON line is also the last line of the job's stdout.
+        # rank; flushed at exit it would follow the JSON line.  Every rank pushes it out BEFORE the last barrier, rank 0
+        # prints the line after it, and all leave without the exit-time flushes: the one JSON line is the last line
+        # of the job's stdout.
         import ctypes
-        ctypes.CDLL(None).fflush(None)
+        libc = ctypes.CDLL(None)
+        libc.fflush(None)
+        sys.stdout.flush()
+        dist.barrier()
+        dist.destroy_process_group()
+        libc.fflush(None)
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
