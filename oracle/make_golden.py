@@ -241,6 +241,19 @@ def main():
     flat = tensor_utils.flatten_tensors(tensors)
     np.savez(os.path.join(OUT, "flat_params.npz"), flat=flat, W0=tensors[0], b0=tensors[1], W1=tensors[2],
              b1=tensors[3], W2=tensors[4], b2=tensors[5], log_std=tensors[6])
+    # ---- ext.sliced_fun (rllab/misc/ext.py:341-370) ------------------------------------------
+    from rllab.misc import ext as ref_ext
+    sx, sy = rng.randn(23, 3), rng.randn(23)
+    sw = rng.randn(3)
+
+    def sliced_target(xs, ys, w):
+        return (xs.dot(w) * ys).mean(), np.array([xs.mean(axis=0).sum(), (ys ** 2).mean()])
+    sl = {}
+    for k in (1, 2, 4, 5, 23, 40):
+        a, b = ref_ext.sliced_fun(sliced_target, k)([sx, sy], [sw])
+        sl["k%d_0" % k], sl["k%d_1" % k] = a, b
+    bare = ref_ext.sliced_fun(lambda xs: xs.mean(), 4)([sy])
+    np.savez(os.path.join(OUT, "sliced_fun.npz"), x=sx, y=sy, w=sw, bare=bare, **sl)
     print("golden fixtures written to", OUT, sorted(os.listdir(OUT)))
 
 

@@ -43,7 +43,7 @@ class BatchPolopt(RLAlgorithm):
     def __init__(self, env, policy, baseline, scope=None, n_itr=500, start_itr=0, batch_size=5000,
                  max_path_length=500, discount=0.99, gae_lambda=1, plot=False, pause_for_plot=False,
                  center_adv=True, positive_adv=False, store_paths=False, whole_paths=True,
-                 sampler_cls=None, sampler_args=None, **kwargs):
+                 sampler_cls=None, sampler_args=None, prefetch_rollout=True, **kwargs):
         self.env = env
         self.policy = policy
         self.baseline = baseline
@@ -60,6 +60,8 @@ class BatchPolopt(RLAlgorithm):
         self.positive_adv = positive_adv
         self.store_paths = store_paths
         self.whole_paths = whole_paths
+        # engine option: enqueue the next iteration's rollout right after the update (VectorizedSampler.prefetch)
+        self.prefetch_rollout = prefetch_rollout
         if plot:
             raise NotImplementedError("plotting is out of scope (SURVEY.md section 2, row 27)")
         if sampler_cls is None:
@@ -127,7 +129,8 @@ class BatchPolopt(RLAlgorithm):
             self.log_diagnostics(paths)
             self.optimize_policy(itr, samples_data)
             # the next rollout depends on nothing below: start it before the host turns to snapshot and log
-            if itr + 1 < self.n_itr and hasattr(self.sampler, "prefetch") and not self.store_paths:
+            if itr + 1 < self.n_itr and hasattr(self.sampler, "prefetch") and not self.store_paths \
+                    and getattr(self, "prefetch_rollout", True):
                 self.sampler.prefetch(itr + 1)
             logger.log("saving snapshot...")
             params = self.get_itr_snapshot(itr, samples_data)
@@ -137,7 +140,7 @@ class BatchPolopt(RLAlgorithm):
                 params["paths"] = samples_data["paths"]
             logger.save_itr_params(itr, params)
             logger.log("saved")
-            self.itr_times.append(time.time() - itr_start)
+            self.itr_times.append(time.time() - itr_start)   # includes the ENQUEUE of the prefetched rollout only
             logger.record_tabular('ItrTime', self.itr_times[-1])
             logger.dump_tabular(with_prefix=False)
         return samples_data

@@ -51,7 +51,7 @@ class VPG(BatchPolopt, Serializable):
             def f_kl(inputs):  # noqa: F811  (HIP kernel version of the same statistic)
                 s = fused.loss_stats_host(inputs)      # the evaluation's one host read (shared with loss())
                 return s[1], s[3]
-        self.optimizer.update_opt(surr_obj, target=policy, inputs=None, fused=fused)
+        self.optimizer.update_opt(surr_obj, target=policy, inputs=None, fused=fused, weighted_mean_inputs=True)
         self.opt_info = dict(f_kl=f_kl)
 
     def optimize_policy(self, itr, samples_data):

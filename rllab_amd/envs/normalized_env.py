@@ -63,7 +63,17 @@ class NormalizedEnv(ProxyEnv, Serializable):
         self._reward_stats.update(reward)
         return reward / self._reward_stats.std
 
+    def _pull_live_estimates(self):
+        """A live vectorised executor owns the running estimates (one per env copy, on the device): before this env
+        is pickled -- every snapshot pickles ``algo.env`` -- take env copy 0's, so a policy trained on whitened
+        observations is replayed against the estimator it was trained with, not one restarting at mean 0 / var 1."""
+        ref = getattr(self, "_live_vec", None)
+        vec = ref() if ref is not None else None
+        if vec is not None:
+            vec.write_back(self)
+
     def __getstate__(self):
+        self._pull_live_estimates()
         d = Serializable.__getstate__(self)
         d["_obs_mean"], d["_obs_var"] = self._obs_stats.mean, self._obs_stats.var
         return d
@@ -114,24 +124,32 @@ class NormalizedEnv(ProxyEnv, Serializable):
                 n_envs=n_envs, max_path_length=max_path_length, normalize=True,
                 scale_reward=float(self._scale_reward), **kwargs)
         # running normalisation sits between the env's reward and scale_reward (:85-92): the kernel leaves the
-        # reward unscaled and the wrapper applies normalisation, then the scale
+        # reward unscaled and the wrapper applies normalisation, then the scale.  The inner executor does NOT
+        # auto-reset: the wrapper has to see the terminal observation before the reset one (below).
+        import weakref
         inner = self._wrapped_env.vec_env_executor(n_envs=n_envs, max_path_length=max_path_length, normalize=True,
-                                                   scale_reward=1.0, **kwargs)
-        return NormalizingVecEnv(inner, float(self._scale_reward), self._normalize_obs, self._normalize_reward,
-                                 self._obs_stats.alpha, self._reward_stats.alpha)
+                                                   scale_reward=1.0, auto_reset=False, **kwargs)
+        vec = NormalizingVecEnv(inner, float(self._scale_reward), self._normalize_obs, self._normalize_reward,
+                                self._obs_stats.alpha, self._reward_stats.alpha, owner=self)
+        self._live_vec = weakref.ref(vec)
+        return vec
 
 
 class NormalizingVecEnv(object):
     """The VecEnvExecutor surface over a HIP executor with NormalizedEnv's running estimates per env copy:
         mean <- (1 - a) mean + a x;  var <- (1 - a) var + a (x - mean)^2     (normalized_env.py:33-49, float64)
         obs -> (obs - mean) / (sqrt(var) + 1e-8);   reward -> reward / (sqrt(var_r) + 1e-8), then * scale_reward.
-    One update per returned observation: an env that finished inside ``step`` hands back its reset observation (the
-    executor contract), which is the one that is whitened -- the reference additionally feeds the discarded terminal
-    observation to the estimate.  Sampled through the per-transition loop (the fused rollout feeds the policy raw
-    observations)."""
+    Update order of the reference's VecEnvExecutor over n NormalizedEnv copies (vec_env_executor.py:16-28): every
+    copy's ``step`` feeds its estimate the observation it produced -- the TERMINAL one included -- and a copy that is
+    done is then ``reset``, which feeds the estimate once more with the reset observation and returns that one
+    whitened.  So the inner executor steps without auto-reset, the estimates see the step's observations of all
+    copies, then the finished copies are reset under a mask and only their estimates see the reset observations.
+    Estimates start from the owning NormalizedEnv's (a snapshot's) and env copy 0's are written back to it when it
+    is pickled or the executor terminates.  Sampled through the per-transition loop (the fused rollout feeds the
+    policy raw observations)."""
     graphable = False          # the sampler's hipGraph loop talks to the raw executor's buffers
 
-    def __init__(self, inner, scale_reward, normalize_obs, normalize_reward, obs_alpha, reward_alpha):
+    def __init__(self, inner, scale_reward, normalize_obs, normalize_reward, obs_alpha, reward_alpha, owner=None):
         self.inner = inner
         self.scale_reward_outer = float(scale_reward)
         self.normalize_obs, self.normalize_reward = bool(normalize_obs), bool(normalize_reward)
@@ -141,6 +159,12 @@ class NormalizingVecEnv(object):
         self.obs_var = torch.ones((inner.obs_rows, inner.n), **f64)
         self.reward_mean = torch.zeros(inner.n, **f64)
         self.reward_var = torch.ones(inner.n, **f64)
+        self._owner = owner
+        if owner is not None:                         # resume from the owner's (snapshotted) estimates
+            self.obs_mean += torch.as_tensor(np.asarray(owner._obs_stats.mean, dtype=np.float64), **f64).reshape(-1, 1)
+            self.obs_var *= torch.as_tensor(np.asarray(owner._obs_stats.var, dtype=np.float64), **f64).reshape(-1, 1)
+            self.reward_mean += float(owner._reward_stats.mean)
+            self.reward_var *= float(owner._reward_stats.var)
 
     def __getattr__(self, name):                      # n, q, device, obs_rows, max_path_length, position_ids, ...
         if name == "inner":
@@ -154,14 +178,26 @@ class NormalizingVecEnv(object):
     def rollout(self, *args, **kwargs):
         raise NotImplementedError("running obs / reward normalisation: sample through reset() / step()")
 
-    def _whiten(self, obs_n):
+    def write_back(self, env):
+        """Env copy 0's estimates -> the NormalizedEnv that gets pickled (its ``_obs_mean`` / ``_obs_var`` state)."""
+        env._obs_stats.mean = self.obs_mean[:, 0].cpu().numpy().copy()
+        env._obs_stats.var = self.obs_var[:, 0].cpu().numpy().copy()
+        env._reward_stats.mean = float(self.reward_mean[0])
+        env._reward_stats.var = float(self.reward_var[0])
+
+    def _whiten(self, obs_n, only=None):
+        """Feed the estimates ``obs_n`` [n, Do] and whiten it; ``only`` [n] bool: just those env copies move."""
         if not self.normalize_obs:
             return obs_n
         x = obs_n.t().to(torch.float64)
         a = self.obs_alpha
-        self.obs_mean.mul_(1 - a).add_(x, alpha=a)
-        self.obs_var.mul_(1 - a).add_((x - self.obs_mean) ** 2, alpha=a)
-        return ((x - self.obs_mean) / (torch.sqrt(self.obs_var) + 1e-8)).t().to(torch.float32)
+        mean = self.obs_mean * (1 - a) + a * x
+        var = self.obs_var * (1 - a) + a * (x - mean) ** 2
+        if only is not None:
+            mean = torch.where(only, mean, self.obs_mean)
+            var = torch.where(only, var, self.obs_var)
+        self.obs_mean, self.obs_var = mean, var
+        return ((x - mean) / (torch.sqrt(var) + 1e-8)).t().to(torch.float32)
 
     def reset(self, *args, **kwargs):
         return self._whiten(self.inner.reset(*args, **kwargs))
@@ -169,13 +205,16 @@ class NormalizingVecEnv(object):
     def step(self, action_n, **kwargs):
         is_np = not torch.is_tensor(action_n)
         a = torch.as_tensor(np.asarray(action_n), device=self.inner.device) if is_np else action_n
-        obs, rew, done, info = self.inner.step(a, **kwargs)
+        obs, rew, done, info = self.inner.step(a, **kwargs)      # no auto-reset: terminal observations
         obs = self._whiten(obs)
+        done = done.clone()
+        fresh = self._whiten(self.inner.reset(mask=done), only=done)   # done copies only; a launch over a mask of
+        obs = torch.where(done.unsqueeze(1), fresh, obs)                # zeros when nobody finished (no host sync)
         r = rew.to(torch.float64)
         if self.normalize_reward:
             al = self.reward_alpha
-            self.reward_mean.mul_(1 - al).add_(r, alpha=al)
-            self.reward_var.mul_(1 - al).add_((r - self.reward_mean) ** 2, alpha=al)
+            self.reward_mean = self.reward_mean * (1 - al) + al * r
+            self.reward_var = self.reward_var * (1 - al) + al * (r - self.reward_mean) ** 2
             r = r / (torch.sqrt(self.reward_var) + 1e-8)
         r = (r * self.scale_reward_outer).to(torch.float32)
         if is_np:
@@ -183,6 +222,8 @@ class NormalizingVecEnv(object):
         return obs, r, done, info
 
     def terminate(self):
+        if self._owner is not None:
+            self.write_back(self._owner)
         self.inner.terminate()
 
 

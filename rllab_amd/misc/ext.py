@@ -1,5 +1,6 @@
-"""The few helpers of rllab/misc/ext.py the hot path uses: ``extract`` (:14-20),
-``set_seed`` (:188-206), ``sliced_fun`` (:341-370), ``lazydict``."""
+"""The helpers of rllab/misc/ext.py the hot path uses, and nothing else of that module: ``extract`` (:14-20),
+``set_seed`` (:188-206), ``is_iterable`` (:209-210), ``flatten_tensor_variables`` (:297-299), ``sliced_fun``
+(:341-370).  The reference file is the contract (what goes in, what comes out), not the text."""
 import random
 
 import numpy as np
@@ -8,11 +9,12 @@ seed_ = None
 
 
 def extract(x, *keys):
+    """``extract(d, 'a', 'b') -> (d['a'], d['b'])``; for a list of dicts each entry is the list over the dicts."""
     if isinstance(x, dict):
         return tuple(x[k] for k in keys)
-    elif isinstance(x, list):
-        return tuple([xi[k] for xi in x] for k in keys)
-    raise NotImplementedError
+    if isinstance(x, list):
+        return tuple([item[k] for item in x] for k in keys)
+    raise NotImplementedError("extract() takes a dict or a list of dicts, not %s" % type(x).__name__)
 
 
 def set_seed(seed):
@@ -31,44 +33,44 @@ def get_seed():
     return seed_
 
 
-class lazydict(object):
-    def __init__(self, **kwargs):
-        self._lazy_dict = kwargs
-        self._dict = {}
+class _SampleWeightedMean(object):
+    """Accumulator behind ``sliced_fun``: sum_k n_k * out_k / sum_k n_k, per output position."""
 
-    def __getitem__(self, key):
-        if key not in self._dict:
-            self._dict[key] = self._lazy_dict[key]()
-        return self._dict[key]
+    def __init__(self):
+        self.weight = 0
+        self.sums = None
+        self.shape = None          # None: bare value; tuple / list: the container type f returned
 
-    def set(self, key, value):
-        self._lazy_dict[key] = value
+    def add(self, out, n):
+        if isinstance(out, (tuple, list)):
+            self.shape, values = type(out), list(out)
+        else:
+            self.shape, values = None, [out]
+        terms = [np.asarray(v) * n for v in values]
+        self.sums = terms if self.sums is None else [s + t for s, t in zip(self.sums, terms)]
+        self.weight += n
+
+    def result(self):
+        means = [s / self.weight for s in self.sums]
+        return means[0] if self.shape is None else self.shape(means)
 
 
 def sliced_fun(f, n_slices):
-    """Evaluate ``f`` on ``n_slices`` slices of the sample axis and return the
-    sample-weighted mean (reference :341-370).  With ``n_slices == 1`` it is a
-    plain call."""
+    """``sliced_fun(f, k)(sliced_inputs, non_sliced_inputs=None)``: cut every array of ``sliced_inputs`` into
+    chunks of ``max(1, n // k)`` samples along the first axis, call ``f(*chunk, *non_sliced_inputs)`` per chunk and
+    return the sample-weighted mean of what it returned -- a bare value, or a tuple / list of the same kind
+    (contract: rllab/misc/ext.py:341-370).  A ragged tail is one more, shorter chunk, weighted by its own length.
+    On a 288 GB part no batch of this path needs slicing, so the optimizers keep ``num_slices`` for signature
+    compatibility and evaluate whole batches; this function serves callers that slice host-side closures."""
     def sliced_f(sliced_inputs, non_sliced_inputs=None):
-        if non_sliced_inputs is None:
-            non_sliced_inputs = []
-        non_sliced_inputs = list(non_sliced_inputs)
-        n_paths = len(sliced_inputs[0])
-        slice_size = max(1, n_paths // n_slices)
-        ret_vals = None
-        was_tuple = was_seq = False
-        for start in range(0, n_paths, slice_size):
-            inputs_slice = [v[start:start + slice_size] for v in sliced_inputs]
-            out = f(*(inputs_slice + non_sliced_inputs))
-            was_seq = isinstance(out, (tuple, list))
-            was_tuple = isinstance(out, tuple)
-            outs = list(out) if was_seq else [out]
-            scaled = [np.asarray(v) * len(inputs_slice[0]) for v in outs]
-            ret_vals = scaled if ret_vals is None else [x + y for x, y in zip(ret_vals, scaled)]
-        ret_vals = [v / n_paths for v in ret_vals]
-        if not was_seq:
-            return ret_vals[0]
-        return tuple(ret_vals) if was_tuple else ret_vals
+        rest = list(non_sliced_inputs) if non_sliced_inputs is not None else []
+        n = len(sliced_inputs[0])
+        chunk = max(1, n // n_slices)
+        acc = _SampleWeightedMean()
+        for lo in range(0, n, chunk):
+            part = [v[lo:lo + chunk] for v in sliced_inputs]
+            acc.add(f(*(part + rest)), len(part[0]))
+        return acc.result()
     return sliced_f
 
 
@@ -82,96 +84,3 @@ def flatten_tensor_variables(ts):
     variables; here torch tensors, order preserved, graph kept)."""
     import torch
     return torch.cat([torch.reshape(t, (-1,)) for t in ts])
-
-
-# -- small generic helpers scripts written against rllab/misc/ext.py use -----------------------------------------
-class AttrDict(dict):
-    """dict whose items are also attributes (ext.py:42-46)."""
-
-    def __init__(self, *args, **kwargs):
-        super(AttrDict, self).__init__(*args, **kwargs)
-        self.__dict__ = self
-
-
-def extract_dict(x, *keys):
-    return {k: x[k] for k in keys if k in x}
-
-
-def compact(x):
-    """Drop the None entries of a dict / list (ext.py:32-39)."""
-    if isinstance(x, dict):
-        return {k: v for k, v in x.items() if v is not None}
-    if isinstance(x, list):
-        return [v for v in x if v is not None]
-    return x
-
-
-def flatten(xs):
-    """One level of nesting removed."""
-    return [x for group in xs for x in group]
-
-
-def shuffled(sequence):
-    """Generator over a random permutation of the sequence (np.random)."""
-    import numpy as np
-    for i in np.random.permutation(len(sequence)):
-        yield sequence[i]
-
-
-def path_len(p):
-    return len(p["states"]) if "states" in p else len(p["rewards"])
-
-
-def concat_paths(p1, p2):
-    import numpy as np
-    return {k: np.concatenate([p1[k], p2[k]]) for k in p1.keys() if k in p2}
-
-
-def truncate_path(p, t):
-    return {k: v[:t] for k, v in p.items()}
-
-
-def iterate_minibatches_generic(input_lst=None, batchsize=None, shuffle=False):
-    """Aligned mini-batches of several arrays (ext.py:158-176); batchsize None = one batch of everything."""
-    import numpy as np
-    n = len(input_lst[0])
-    if batchsize is None:
-        batchsize = n
-    assert all(len(x) == n for x in input_lst)
-    order = np.random.permutation(n) if shuffle else np.arange(n)
-    for start in range(0, n, batchsize):
-        sel = order[start:start + batchsize]
-        yield [x[sel] for x in input_lst]
-
-
-def stdize(data, eps=1e-6):
-    import numpy as np
-    return (data - np.mean(data, axis=0)) / (np.std(data, axis=0) + eps)
-
-
-def scanl(f, xs, init):
-    """Running left fold: [init, f(init, x0), f(f(init, x0), x1), ...]."""
-    out = [init]
-    for x in xs:
-        out.append(f(out[-1], x))
-    return out
-
-
-def scanr(f, xs, init):
-    """Running right fold, aligned like the reference: result[i] folds xs[i:]; result[-1] = init."""
-    out = [init]
-    for x in reversed(list(xs)):
-        out.append(f(x, out[-1]))
-    return out[::-1]
-
-
-def unflatten_tensor_variables(flatarr, shapes, symb_arrs=None):
-    """Inverse of flatten_tensor_variables for torch tensors (ext.py:302-311)."""
-    out, n = [], 0
-    for shape in shapes:
-        size = 1
-        for s in shape:
-            size *= int(s)
-        out.append(flatarr[n:n + size].reshape(tuple(shape)))
-        n += size
-    return out

@@ -25,25 +25,36 @@ from contextlib import contextmanager
 
 
 class TextSink(object):
+    """Append-mode log file, opened by the first line actually written (a non-primary rank that registers the sink
+    before ``init_process_group`` therefore never touches the file)."""
+
     def __init__(self, path):
-        _ensure_parent(path)
-        self.fh = open(path, "a")
+        self.path, self.fh = path, None
 
     def write_line(self, line):
+        if self.fh is None:
+            _ensure_parent(self.path)
+            self.fh = open(self.path, "a")
         self.fh.write(line + "\n")
         self.fh.flush()
 
     def close(self):
-        self.fh.close()
+        if self.fh is not None:
+            self.fh.close()
+            self.fh = None
 
 
 class CsvSink(object):
+    """One CSV per experiment; created (mode 'w') and given its header by the first row actually written."""
+
     def __init__(self, path):
-        _ensure_parent(path)
-        self.fh = open(path, "w")
+        self.path, self.fh = path, None
         self.columns = None
 
     def write_row(self, row):
+        if self.fh is None:
+            _ensure_parent(self.path)
+            self.fh = open(self.path, "w")
         if self.columns is None:
             self.columns = list(row)
             csv.writer(self.fh).writerow(self.columns)
@@ -52,7 +63,9 @@ class CsvSink(object):
         self.fh.flush()
 
     def close(self):
-        self.fh.close()
+        if self.fh is not None:
+            self.fh.close()
+            self.fh = None
 
 
 def _ensure_parent(path):
@@ -82,7 +95,12 @@ class Logger(object):
                 return dist.get_rank() == 0
         except ImportError:
             pass
-        return True
+        # before the process group exists (run_experiment_lite opens the sinks before a user script calls
+        # init_process_group): the launcher's environment already says which rank this process will be
+        try:
+            return int(os.environ.get("RANK", "0")) == 0
+        except ValueError:
+            return True
 
     def set_primary(self, flag):
         self.primary = flag
@@ -92,7 +110,8 @@ class Logger(object):
 
     # -- sinks ------------------------------------------------------------------------------------------------
     def add_text_output(self, file_name):
-        if file_name not in self.text_sinks and self.is_primary():
+        # registered on every rank, opened lazily by the first PRIMARY write (is_primary is re-checked per write)
+        if file_name not in self.text_sinks:
             self.text_sinks[file_name] = TextSink(file_name)
 
     def remove_text_output(self, file_name):
@@ -101,7 +120,7 @@ class Logger(object):
             sink.close()
 
     def add_tabular_output(self, file_name):
-        if file_name not in self.csv_sinks and self.is_primary():
+        if file_name not in self.csv_sinks:
             self.csv_sinks[file_name] = CsvSink(file_name)
 
     def remove_tabular_output(self, file_name):

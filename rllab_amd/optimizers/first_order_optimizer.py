@@ -90,6 +90,10 @@ class FirstOrderOptimizer(Serializable):
         self._loss = loss
         self._updater = self._update_factory()
         self._fused = kwargs.get("fused")
+        # opt-in of the caller (algos/vpg.py passes weighted_mean_inputs=True): the inputs END with
+        # [..., weights, 1 / W] and a mini-batch's mean must be renormalised by its own weight sum.  Never inferred
+        # from the inputs' types: (xs, ys) inputs or appended extra_inputs keep their last entry.
+        self._weighted_mean_inputs = bool(kwargs.get("weighted_mean_inputs", False))
 
     def loss(self, inputs, extra_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
@@ -144,18 +148,20 @@ class FirstOrderOptimizer(Serializable):
         if last_loss is not None:
             self.last_before = (last_loss, None, None)
         start_time = time.time()
+        n_main = len(inputs) - len(tuple(extra_inputs or ()))             # extra_inputs ride behind, untouched
         dataset = BatchDataset(inputs, self._batch_size, sample_axis=-1)   # planes: the sample axis is last
         itr = 0
         for epoch in range(self._max_epochs):
             for batch in dataset.iterate(update=True):
                 before = None
-                if self._batch_size is not None and len(batch) >= 2 and torch.is_tensor(batch[-2]):
-                    # input convention (algos/npo.py, algos/vpg.py): [..., weights, 1 / W].  A mini-batch is
-                    # normalised by ITS OWN (global, all-reduced) weight sum -- the reference's compiled loss is
+                if self._batch_size is not None and getattr(self, "_weighted_mean_inputs", False) and n_main >= 2:
+                    # declared input convention (algos/npo.py, algos/vpg.py): [..., weights, 1 / W].  A mini-batch
+                    # is normalised by ITS OWN (global, all-reduced) weight sum -- the reference's compiled loss is
                     # the mean over whatever slice it is given (first_order_optimizer.py:112-114)
-                    cnt = D.all_reduce_sum_(batch[-2].to(torch.float64).sum())
-                    batch[-1] = (1.0 / cnt.clamp_min(1.0)).to(batch[-1].dtype if torch.is_tensor(batch[-1])
-                                                               else torch.float64)
+                    w_at, inv_at = n_main - 2, n_main - 1
+                    cnt = D.all_reduce_sum_(batch[w_at].to(torch.float64).sum())
+                    batch[inv_at] = (1.0 / cnt.clamp_min(1.0)).to(
+                        batch[inv_at].dtype if torch.is_tensor(batch[inv_at]) else torch.float64)
                 if fused_full and last_loss is None:
                     self._step(tuple(batch), with_loss=True)       # records the loss / KL sums of the old parameters
                 else:

@@ -62,17 +62,30 @@ class VectorizedSampler(BaseSampler):
         d.pop("_prefetched", None)
         return d
 
+    def _takes_fused_rollout(self, policy):
+        """True when ``obtain_samples`` is ONE asynchronous launch for this policy (the fused rollout kernels)."""
+        return (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None
+                and self.vec_env is not None and self.vec_env.position_ids is None
+                and getattr(self.vec_env, "graphable", True))
+
     def prefetch(self, itr):
-        """Enqueue iteration ``itr``'s rollout NOW (it is one asynchronous launch) and keep the lazy batch for
-        ``obtain_samples(itr)``: BatchPolopt calls this right after the parameter update, so the device starts the
-        next rollout while the host still writes the previous iteration's log lines and snapshot.  The batch is
-        only handed out if the parameters have not changed in between."""
+        """Enqueue iteration ``itr``'s rollout NOW and keep the lazy batch for ``obtain_samples(itr)``: BatchPolopt
+        calls this right after the parameter update, so the device starts the next rollout while the host still
+        writes the previous iteration's log lines and snapshot.  The batch is only handed out if the parameters
+        have not changed in between -- which needs ``policy.param_version()`` -- and only the fused rollout is one
+        asynchronous launch: for any other policy (no version to check, or the host-bound per-transition loop,
+        where nothing overlaps) this is a no-op, never a rollout that would be thrown away.
+        ``BatchPolopt(prefetch_rollout=False)`` turns it off altogether."""
         if getattr(self, "_prefetched", None) is not None and self._prefetched[0] == itr:
             return
         self._prefetched = None
+        policy = self.algo.policy
+        if not hasattr(policy, "param_version") or not self._takes_fused_rollout(policy):
+            return
+        t_keep = self.last_sample_time          # the enqueue of the NEXT batch is not this iteration's sample time
         paths = self.obtain_samples(itr)
-        self._prefetched = (itr, self.algo.policy.param_version() if hasattr(self.algo.policy, "param_version")
-                            else None, paths)
+        self.last_sample_time = t_keep
+        self._prefetched = (itr, policy.param_version(), paths)
 
     def obtain_samples(self, itr):
         algo = self.algo
@@ -85,8 +98,7 @@ class VectorizedSampler(BaseSampler):
         T = algo.max_path_length
         t_start = time.time()
         graphable = getattr(self.vec_env, "graphable", True)
-        if hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None \
-                and self.vec_env.position_ids is None and graphable:
+        if self._takes_fused_rollout(policy):
             traj = self.vec_env.rollout(policy, T, reset_at_start=True)
         elif self.use_graph and graphable and not os.environ.get("RLLAB_NO_GRAPH") \
                 and hasattr(policy, "recorded_log_std"):

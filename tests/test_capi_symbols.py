@@ -121,3 +121,96 @@ def test_integration_md_bindings_match_the_library():
         for k, (t, w) in enumerate(zip(toks, want)):
             assert short[t] is w, "%s argument %d: INTEGRATION.md says %s, the binding is %s" % (fn, k, t, w)
     assert "rl_abi_version() == %d" % _lib.lib.rl_abi_version() in text
+
+
+def _md_struct_fields(text):
+    """{class name: [(field, type token), ...]} of every ``class X(ctypes.Structure)`` printed in INTEGRATION.md."""
+    out = {}
+    for name, body in re.findall(r"class (\w+)\(ctypes\.Structure\):.*?_fields_\s*=\s*\[(.*?)\]\s*\n", text, flags=re.S):
+        out[name] = re.findall(r'\(\s*"(\w+)"\s*,\s*([^()]*?(?:\([^()]*\))?)\s*\)', body)
+    return out
+
+
+def test_integration_md_structs_are_the_library_structs():
+    """Every ctypes.Structure a maintainer would copy out of INTEGRATION.md has the fields, order and types of the
+    mirror in rllab_amd/_lib.py (which test_structs_match_header_layout ties to include/rllab_amd.h): a struct
+    printed short or stale shifts every pointer behind the gap and the device dereferences garbage."""
+    from rllab_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    types_ = {"f32": ctypes.c_float, "i32f": ctypes.c_int32, "ctypes.c_int32": ctypes.c_int32, "vp": ctypes.c_void_p,
+              "u64f": ctypes.c_uint64, "ctypes.c_uint64": ctypes.c_uint64, "f64": ctypes.c_double,
+              "ctypes.POINTER(EnvCfg)": ctypes.POINTER(_lib.EnvCfg), "cfgp": ctypes.POINTER(_lib.EnvCfg)}
+    printed = _md_struct_fields(text)
+    want = {"EnvCfg": _lib.EnvCfg, "RolloutArgs": _lib.RolloutArgs, "PolicyBatch": _lib.PolicyBatch}
+    assert set(printed) == set(want), sorted(printed)
+    for name, cls in want.items():
+        got = [(f, types_[t.strip()]) for f, t in printed[name]]
+        assert got == [(f, t) for f, t in cls._fields_], \
+            "%s in INTEGRATION.md differs from the library's struct:\n  printed %s\n  library %s" % (
+                name, [f for f, _ in got], [f for f, _ in cls._fields_])
+        # and the layout a copier would get: same size, same offset of the last field
+        rebuilt = type("Md" + name, (ctypes.Structure,), {"_fields_": got})
+        assert ctypes.sizeof(rebuilt) == ctypes.sizeof(cls)
+        assert getattr(rebuilt, got[-1][0]).offset == getattr(cls, cls._fields_[-1][0]).offset
+
+
+def _md_calls(text):
+    """(function, number of top-level arguments) of every ``lib.rl_*( ... )`` call printed in INTEGRATION.md."""
+    calls = []
+    for m in re.finditer(r"\blib\.(rl_\w+)\(", text):
+        i, depth, n_args, seen = m.end(), 1, 0, False
+        while depth:
+            c = text[i]
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+            elif c == "," and depth == 1:
+                n_args += 1
+            if depth and not c.isspace():
+                seen = True
+            i += 1
+        calls.append((m.group(1), n_args + 1 if seen else 0))
+    return calls
+
+
+def test_integration_md_example_calls_have_the_abi_arity():
+    """Every example call ``lib.rl_*(...)`` in INTEGRATION.md passes exactly as many arguments as the entry point
+    takes (an 8-argument rl_trpo_step against 9 argtypes went unnoticed for a round)."""
+    from rllab_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    calls = _md_calls(text)
+    assert len(calls) >= 15
+    checked = 0
+    for fn, n_args in calls:
+        argtypes = getattr(_lib.lib, fn).argtypes
+        if argtypes is None:
+            assert n_args == 0, fn
+            continue
+        assert n_args == len(argtypes), "INTEGRATION.md calls %s with %d arguments, the ABI takes %d" % (
+            fn, n_args, len(argtypes))
+        checked += 1
+    assert checked >= 15
+
+
+def test_struct_offsets_against_the_compiled_header(tmp_path):
+    """include/rllab_amd.h compiled as plain C (gcc): sizeof and every offsetof equal the ctypes mirrors' -- names
+    in the right order (test_structs_match_header_layout) do not catch a wrong width."""
+    import subprocess
+    from rllab_amd import _lib
+    structs = (("rl_env_cfg", _lib.EnvCfg), ("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch))
+    lines = ['#include "rllab_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for cname, cls in structs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+    for cname, cls in structs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)

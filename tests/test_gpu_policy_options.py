@@ -171,29 +171,52 @@ def test_running_obs_and_reward_normalisation_on_the_vectorised_path(quiet_logge
     assert env.vectorized
     n, T = 33, 40
     v = env.vec_env_executor(n_envs=n, max_path_length=15, seed=4)
-    raw = normalize(CartpoleEnv()).vec_env_executor(n_envs=n, max_path_length=15, seed=4)
+    # the twin replays the wrapper's own launch sequence on a raw executor: step without auto-reset (terminal
+    # observations), then a masked reset of the finished copies
+    raw = normalize(CartpoleEnv()).vec_env_executor(n_envs=n, max_path_length=15, seed=4, auto_reset=False)
     rng = np.random.RandomState(0)
     mean, var = np.zeros((n, 4)), np.ones((n, 4))
     rmean, rvar = np.zeros(n), np.ones(n)
 
-    def whiten(o):
+    def whiten(o, only=None):
         nonlocal mean, var
-        mean = 0.99 * mean + 0.01 * o
-        var = 0.99 * var + 0.01 * np.square(o - mean)
+        m = 0.99 * mean + 0.01 * o
+        s2 = 0.99 * var + 0.01 * np.square(o - m)
+        if only is not None:
+            m, s2 = np.where(only[:, None], m, mean), np.where(only[:, None], s2, var)
+        mean, var = m, s2
         return (o - mean) / (np.sqrt(var) + 1e-8)
     o = v.reset().cpu().numpy().astype(np.float64)
     o_raw = raw.reset().cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(o, whiten(o_raw), rtol=0, atol=1e-6)
+    n_done = 0
     for t in range(T):
         a = torch.as_tensor(rng.randn(n, 1).astype(np.float32), device="cuda")
         o, r, d, _ = v.step(a)
         o_raw, r_raw, d_raw, _ = raw.step(a)
         assert torch.equal(d, d_raw)
-        np.testing.assert_allclose(o.cpu().numpy(), whiten(o_raw.cpu().numpy().astype(np.float64)), rtol=0, atol=1e-5)
+        # reference order (vec_env_executor.py:16-28 over NormalizedEnv copies): every copy's estimate sees the
+        # observation its step produced, the terminal one included; a finished copy then resets, its estimate sees
+        # the reset observation as well and that one is returned
+        want = whiten(o_raw.cpu().numpy().astype(np.float64))
+        dn = d_raw.cpu().numpy()
+        o_reset = raw.reset(mask=d_raw).cpu().numpy().astype(np.float64)
+        want = np.where(dn[:, None], whiten(o_reset, only=dn), want)
+        n_done += int(dn.sum())
+        np.testing.assert_allclose(o.cpu().numpy(), want, rtol=0, atol=1e-5)
         rr = r_raw.cpu().numpy().astype(np.float64)
         rmean = 0.98 * rmean + 0.02 * rr
         rvar = 0.98 * rvar + 0.02 * np.square(rr - rmean)
         np.testing.assert_allclose(r.cpu().numpy(), rr / (np.sqrt(rvar) + 1e-8) * 0.1, rtol=1e-5, atol=1e-6)
+    assert n_done > n                                    # terminal observations were part of the stream
+    # the estimates travel with the env: pickling it (what every snapshot does) takes env copy 0's, and an executor
+    # made from the unpickled env resumes from them instead of mean 0 / var 1
+    import pickle
+    clone = pickle.loads(pickle.dumps(env))
+    np.testing.assert_allclose(clone._obs_stats.mean, mean[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(clone._obs_stats.var, var[0], rtol=0, atol=1e-12)
+    v2 = clone.vec_env_executor(n_envs=3, max_path_length=15, seed=4)
+    np.testing.assert_allclose(v2.obs_mean.cpu().numpy(), np.tile(mean[0][:, None], (1, 3)), rtol=0, atol=1e-12)
     # and the sampler takes such an env through the per-transition loop
     from rllab.algos.vpg import VPG
     from rllab.baselines.zero_baseline import ZeroBaseline

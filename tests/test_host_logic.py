@@ -462,9 +462,9 @@ def test_batch_dataset_and_flatten_tensor_variables():
 
 
 def test_small_helper_apis(tmp_path):
-    """tensor_utils / logger / ext helpers that scripts written against the reference call."""
+    """tensor_utils / logger helpers that scripts written against the reference call."""
     import json
-    from rllab_amd.misc import ext, logger, tensor_utils as tu
+    from rllab_amd.misc import logger, tensor_utils as tu
     d = dict(a=np.arange(24.).reshape(2, 3, 4), b=dict(c=np.arange(6.).reshape(2, 3)))
     f = tu.flatten_first_axis_tensor_dict(d)
     assert f["a"].shape == (6, 4) and f["b"]["c"].shape == (6,)
@@ -482,21 +482,6 @@ def test_small_helper_apis(tmp_path):
     logger.dump_tabular()
     logger.log_variant(str(tmp_path / "v" / "variant.json"), dict(lr=0.1, env=object))
     assert json.load(open(str(tmp_path / "v" / "variant.json")))["lr"] == 0.1
-    a = ext.AttrDict(x=1)
-    assert a.x == 1 and a["x"] == 1
-    assert ext.compact(dict(a=1, b=None)) == dict(a=1) and ext.compact([1, None, 2]) == [1, 2]
-    assert ext.flatten([[1, 2], [3]]) == [1, 2, 3] and ext.extract_dict(dict(a=1, b=2), "a", "z") == dict(a=1)
-    assert sorted(ext.shuffled([3, 1, 2])) == [1, 2, 3]
-    assert ext.scanl(lambda acc, x: acc + x, [1, 2, 3], 0) == [0, 1, 3, 6]
-    assert ext.scanr(lambda x, acc: acc + x, [1, 2, 3], 0) == [6, 5, 3, 0]
-    xs, ys = np.arange(10), np.arange(10) * 2
-    got = list(ext.iterate_minibatches_generic([xs, ys], batchsize=4))
-    assert [len(b[0]) for b in got] == [4, 4, 2] and all(np.array_equal(b[0] * 2, b[1]) for b in got)
-    parts = ext.unflatten_tensor_variables(torch.arange(10.), [(2, 3), (4,)])
-    assert parts[0].shape == (2, 3) and torch.equal(ext.flatten_tensor_variables(parts), torch.arange(10.))
-    p = dict(rewards=np.arange(5), observations=np.arange(10).reshape(5, 2))
-    assert ext.path_len(p) == 5 and len(ext.truncate_path(p, 3)["rewards"]) == 3
-    assert len(ext.concat_paths(p, p)["rewards"]) == 10
 
 
 def test_reparam_action_and_optimize_gen(quiet_logger):
@@ -557,3 +542,41 @@ def test_device_io_and_fold_stats_on_cpu():
     out = B.fold_stats(rows)
     assert out[B._COUNT] == 15 and out[B._ADVMIN] == -3.0 and out[B._UNDMAX] == 7.0 and out[B._PROGMIN] == 0.25
     assert np.array_equal(B.fold_stats(rows[:1]), rows[0])
+
+
+def test_sliced_fun_is_the_sample_weighted_mean():
+    """ext.sliced_fun (contract: rllab/misc/ext.py:341-370): chunks of max(1, n // k) samples, a ragged tail as one
+    more chunk, outputs averaged with the chunk lengths as weights, container kind of the output preserved."""
+    from rllab_amd.misc import ext
+    x = np.arange(10.0)
+    y = x * x
+    calls = []
+
+    def f(xs, ys, scale):
+        calls.append(len(xs))
+        return xs.mean() * scale, np.array([ys.mean(), ys.max()])
+    out = ext.sliced_fun(f, 3)([x, y], [2.0])
+    assert calls == [3, 3, 3, 1] and isinstance(out, tuple)
+    assert abs(out[0] - 2.0 * x.mean()) < 1e-12                       # a mean of means with the right weights
+    assert abs(out[1][0] - y.mean()) < 1e-12
+    assert abs(out[1][1] - (3 * 4 + 3 * 25 + 3 * 64 + 81) / 10.0) < 1e-12   # max is NOT averageable: weighted as is
+    assert ext.sliced_fun(lambda xs: xs.sum(), 1)([x]) == x.sum()      # one slice: the plain call, bare value
+    as_list = ext.sliced_fun(lambda xs: [xs.mean()], 2)([x], ())
+    assert isinstance(as_list, list) and abs(as_list[0] - 4.5) < 1e-12
+    assert abs(ext.sliced_fun(lambda xs: xs.mean(), 100)([x]) - 4.5) < 1e-12   # more slices than samples: size 1
+    assert ext.extract(dict(a=1, b=2), "b", "a") == (2, 1)
+    assert ext.extract([dict(a=1), dict(a=3)], "a") == ([1, 3],)
+
+
+def test_sliced_fun_against_the_reference_fixture():
+    """tests/golden/sliced_fun.npz: outputs of the REAL rllab.misc.ext.sliced_fun (oracle/make_golden.py)."""
+    from rllab_amd.misc import ext
+    from tests.golden_util import load
+    g = load("sliced_fun")
+
+    def target(xs, ys, w):
+        return (xs.dot(w) * ys).mean(), np.array([xs.mean(axis=0).sum(), (ys ** 2).mean()])
+    for k in (1, 2, 4, 5, 23, 40):
+        a, b = ext.sliced_fun(target, k)([g["x"], g["y"]], [g["w"]])
+        assert np.allclose(a, g["k%d_0" % k], rtol=1e-13, atol=0) and np.allclose(b, g["k%d_1" % k], rtol=1e-13, atol=0)
+    assert np.isclose(ext.sliced_fun(lambda xs: xs.mean(), 4)([g["y"]]), g["bare"], rtol=1e-13)

@@ -55,7 +55,7 @@ def test_minibatch_loss_is_the_minibatch_mean(quiet_logger):
         new = pol.dist_info_planes(obs, flat)
         return -(dist_.log_likelihood_sym(act, new, axis=0) * adv * w).sum() * inv.to(torch.float32)
     opt = FirstOrderOptimizer(batch_size=b, max_epochs=1)
-    opt.update_opt(surr, target=pol)
+    opt.update_opt(surr, target=pol, weighted_mean_inputs=True)      # what algos/vpg.py declares
     opt.optimize((obs, act, adv, w, torch.tensor(1.0 / float(w.sum()), dtype=torch.float64)))
     steps = [s for s in seen if s[2] == b]
     assert len(steps) == B // b
@@ -63,6 +63,25 @@ def test_minibatch_loss_is_the_minibatch_mean(quiet_logger):
         assert inv == pytest.approx(1.0 / wsum)
     full = [s for s in seen if s[2] == B]
     assert full and all(inv == pytest.approx(1.0 / float(w.sum())) for _, inv, _ in full)
+    # the convention is the caller's declaration, never inferred from tensor-ness: without it (and for extra_inputs
+    # appended behind the declared inputs) the last input reaches the closure untouched
+    marker = torch.tensor(123.0, dtype=torch.float64)
+    got = []
+
+    def plain(flat, xs, ys, tag):
+        got.append(float(tag))
+        return ((flat[:1] * xs).sum() - ys.sum()) ** 2
+    opt2 = FirstOrderOptimizer(batch_size=b, max_epochs=1)
+    opt2.update_opt(plain, target=pol)
+    opt2.optimize((adv, w, marker))
+    assert got and all(v == 123.0 for v in got)
+    del seen[:]
+    opt3 = FirstOrderOptimizer(batch_size=b, max_epochs=1)
+    opt3.update_opt(lambda flat, obs, act, adv, w, inv, extra: surr(flat, obs, act, adv, w, inv) * float(extra == 5.0),
+                    target=pol, weighted_mean_inputs=True)
+    opt3.optimize((obs, act, adv, w, torch.tensor(1.0, dtype=torch.float64)),
+                  extra_inputs=(torch.tensor(5.0, dtype=torch.float64),))
+    assert all(inv == pytest.approx(1.0 / wsum) for wsum, inv, n in seen if n == b)
 
 
 def test_logger_writes_only_on_the_primary_process(tmp_path, capsys):
