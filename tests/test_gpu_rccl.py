@@ -61,3 +61,25 @@ def test_bench_self_launches_its_ranks():
     assert d["config"]["samples_per_iteration"] == 2 * 256 * 500 and d["config"]["parallelism"] == "env-sharded dp2"
     assert 12 <= d["collectives_per_iter"] <= 40 and d["collective_ms_per_iter"] > 0
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(1500)
+def test_bench_self_launches_eight_ranks():
+    """The round-end scaling run's largest shape, `python bench.py --gpus 8`, rehearsed on the one-GPU box: eight ranks
+    share the device over gloo at a reduced --n-envs (the 8-GPU node runs one rank per GPU over RCCL at 4096).  Every
+    rank must get its own env index range, the exchange family must complete with eight peers, and the line must
+    report eight times one rank's samples."""
+    env = dict(os.environ, RLLAB_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--n-envs", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT,
+                       universal_newlines=True, timeout=1400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["config"]["samples_per_iteration"] == 8 * 64 * 500 and d["config"]["parallelism"] == "env-sharded dp8"
+    assert 12 <= d["collectives_per_iter"] <= 40 and d["collective_ms_per_iter"] > 0
+    assert d["value"] > 0 and "cpu_baseline" not in d
