@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="swimmer4096_trpo", choices=sorted(WORKLOADS))
     ap.add_argument("--n-envs", type=int, default=None, help="envs per GPU (default: the workload's 4096)")
+    ap.add_argument("--hidden", default=None, help="policy hidden sizes, e.g. 100,50,25 (side lines; default: the "
+                                                   "workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-port sampling")
     args = ap.parse_args()
@@ -175,7 +177,9 @@ def main():
     from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
     from rllab_amd.sampler import dist as D
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.hidden:
+        wl["hidden"] = tuple(int(h) for h in args.hidden.split(","))
     n_envs = args.n_envs or wl["n_envs"]
     T = wl["T"]
     ext.set_seed(1)
@@ -307,13 +311,25 @@ def main():
     # CG loop actually launches
     cached = True      # both net widths keep the activations (32 units: LDS-direct prefetch, 64: register prefetch)
     mfma_per_tile = (0 if cached else ht * (ks0 + ks1)) + ht * (ks0 + 2 * ks1) + ht * ks1 + ht * ht * 16
+    layout = policy.kernel_layout()
+    wide = layout is not None and layout.wide
+    if wide:
+        # the cooperative kernels of the wide / deep nets recompute the forward pass; algorithmic work of one FVP in
+        # multiply-adds per sample, on the REAL layer sizes (padding is the kernels' cost, not the algorithm's):
+        # forward + tangent (two products per layer beyond the first) + back-propagation + the outer products
+        ins = (do + 1,) + tuple(wl["hidden"])
+        pw = sum(ins[l] * ins[l + 1] for l in range(len(ins) - 1))
+        first = ins[0] * ins[1]
+        macs = pw + (2 * pw - first) + (pw - first) + pw
+        mfma_per_tile = macs * 32 / 2048.0             # one v_mfma_f32_32x32x2_f32 = 2048 multiply-adds
+        cached = False
     fvp_ms = None
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None
     if ops is not None:
         from rllab_amd.algos.npo import npo_inputs
         inp = npo_inputs(policy, last["samples"])
         v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
-        ops.loss_grad(inp, keep_activations=True)     # as ConjugateGradientOptimizer.optimize does before CG
+        ops.loss_grad(inp, keep_activations=not wide)     # as ConjugateGradientOptimizer.optimize does before CG
         for _ in range(3):
             ops.fvp(inp, v)
         torch.cuda.synchronize()
@@ -325,12 +341,13 @@ def main():
         torch.cuda.synchronize()
         fvp_ms = e0.elapsed_time(e1) / 20
         ops.release()
-    lane_group = wl["env"] == "swimmer" and not os.environ.get("RLLAB_SWIMMER_LANE_KERNEL")
-    envs_per_wave = 16 if lane_group else 64
+    lane_group = wl["env"] == "swimmer" and not wide and not os.environ.get("RLLAB_SWIMMER_LANE_KERNEL")
+    envs_per_wave = 16 if (lane_group or (wide and n_envs <= 16 * 1024)) else 64
     n_waves = (n_envs + envs_per_wave - 1) // envs_per_wave
     rollout_name = ("rollout_swimmer_quad_kernel (fused policy + env step + record; 16 envs per wavefront, four "
                     "lanes per env in the physics sub-steps)") if lane_group else \
-        "rollout_kernel (fused policy + env step + record; one env per lane)"
+        ("rollout_wide_kernel (fused wide / deep policy + env step + record; weight fragments in LDS)" if wide else
+         "rollout_kernel (fused policy + env step + record; one env per lane)")
     out = {
         "metric": "env steps/sec over full TRPO iterations (sample + process + update), 4096 envs per MI355X",
         "value": value, "unit": "env_steps/s", "n_gpus": world, "steps": args.steps,
@@ -366,7 +383,8 @@ def main():
     if fvp_ms is not None:
         tiles = (n_envs * T + 31) // 32
         tf = tiles * mfma_per_tile * 4096 / (fvp_ms * 1e-3) / 1e12
-        out["roofline_mfma"] = {"kernel": "policy_pass_kernel<FVP> (Fisher-vector product, v_mfma_f32_32x32x2_f32)",
+        out["roofline_mfma"] = {"kernel": ("wide_pass_kernel<FVP>" if wide else "policy_pass_kernel<FVP>") +
+                                " (Fisher-vector product, v_mfma_f32_32x32x2_f32)",
                                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
                                 "frac": tf / 157.3, "avg_launch_ms": fvp_ms, "mfma_per_32_samples": mfma_per_tile,
                                 "activations": "read from the gradient pass's cache" if cached else "recomputed",

@@ -170,7 +170,8 @@ typedef struct rl_rollout_args {
     int32_t max_path_length;  /* forced done when ts reaches it */
     int32_t normalize;        /* NormalizedEnv action map on/off */
     int32_t reset_at_start;   /* reset every env before step 0 */
-    int32_t hidden0, hidden1; /* tanh MLP hidden sizes (supported: 32x32, 64x64) */
+    int32_t hidden0, hidden1; /* tanh MLP hidden sizes: each 32, 64 or 128 (narrower layers: zero padding, exact) */
+    int32_t hidden2;          /* third hidden layer, 0 = two layers (network.py:36-101 takes any hidden_sizes tuple) */
     int32_t env_offset;       /* global index of env 0 (multi-GPU sharding) */
     float scale_reward;
     float log_min_std;        /* log_std floor, log(min_std) (gaussian_mlp_policy.py:100-101) */
@@ -178,7 +179,7 @@ typedef struct rl_rollout_args {
     uint64_t step_counter;    /* global step index of t = 0 (RNG counter base) */
     float* state;             /* float[state_dim][n]  in/out */
     int32_t* ts;              /* int32[n]             in/out */
-    const float* theta;       /* flat policy params, reference layout W0,b0,W1,b1,Wout,bout,log_std,
+    const float* theta;       /* flat policy params, reference layout W0,b0,W1,b1,[W2,b2,]Wout,bout,log_std,
                                  W stored [in][out] row-major (parameterized.py:54-58) */
     const float* eps;         /* NULL or float[act_dim][T][n] injected N(0,1) policy noise */
     const float* reset_draws; /* NULL or float[T+1][reset_draws][n] injected reset draws;
@@ -269,7 +270,8 @@ int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs, const int3
 typedef struct rl_policy_batch {
     int32_t n_samples;         /* B */
     int32_t obs_dim, act_dim;  /* Do, Da */
-    int32_t hidden0, hidden1;  /* tanh MLP hidden sizes */
+    int32_t hidden0, hidden1;  /* tanh MLP hidden sizes: each 32, 64 or 128 */
+    int32_t hidden2;           /* third hidden layer, 0 = two layers */
     float inv_count;           /* 1 / (global number of valid samples) */
     float log_min_std;         /* log_std floor */
     const float* theta;        /* [P] flat params, reference layout (see rl_rollout_args.theta) */
@@ -279,7 +281,8 @@ typedef struct rl_policy_batch {
     const float* old_means;    /* [Da][B]  agent_infos["mean"] */
     const float* old_log_std;  /* [Da]     agent_infos["log_std"] (one constant row) */
     const float* weights;      /* [B] 0/1 validity */
-    float* activations;        /* NULL, or rl_policy_activation_bytes() of device scratch: rl_policy_grad (vpg == 0)
+    float* activations;        /* NULL (always, when rl_policy_activation_bytes() is 0 for the net), or that many bytes
+                                * of device scratch: rl_policy_grad (vpg == 0)
                                 * leaves the hidden activations of every sample there and rl_policy_fvp reads them
                                 * instead of re-evaluating the forward pass.  The caller guarantees that an FVP call
                                 * which passes the buffer uses the same obs / theta as the gradient call that filled
@@ -299,9 +302,10 @@ typedef struct rl_policy_batch {
 enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1 };
 
 /* Scratch the three calls below need (device memory, caller-owned, reusable). */
-size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1);
+size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1, int hidden2);
 
-/* Size of rl_policy_batch.activations for a batch of n_samples (2 * hidden floats per sample, tile padded). */
+/* Size of rl_policy_batch.activations for a batch of n_samples (2 * hidden floats per sample, tile padded); 0 for
+ * nets without the cache (anything but two equal layers of 32 or 64 units). */
 size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1);
 
 /* out4 (device, 4 doubles) = [ sum_b w lr adv, sum_b w KL, sum_b w logp adv, max_b KL ] at theta:
@@ -339,7 +343,7 @@ int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspac
  *                z = fvp + reg_coeff p; v = rdotr / p.z; x += v p; r -= v z; mu = r.r / rdotr;
  *                p = r + mu p; p32 = (float)p; the `rdotr < residual_tol: break` of the reference
  *                freezes x, r, p from then on (scal[1] = 0) instead of returning to the host.
- * n <= 16384; b, x, r, p, fvp: double[n]; p32: float[n]; scal: double[4] = {rdotr, active,
+ * n <= 65536; b, x, r, p, fvp: double[n]; p32: float[n]; scal: double[4] = {rdotr, active,
  * last p.Ap, steps taken}.  All device pointers. */
 int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p32, double* scal,
                void* stream);

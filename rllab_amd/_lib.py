@@ -52,7 +52,7 @@ class RolloutArgs(ctypes.Structure):
         ("kind", ctypes.c_int32), ("n_envs", ctypes.c_int32), ("horizon", ctypes.c_int32),
         ("max_path_length", ctypes.c_int32), ("normalize", ctypes.c_int32),
         ("reset_at_start", ctypes.c_int32), ("hidden0", ctypes.c_int32), ("hidden1", ctypes.c_int32),
-        ("env_offset", ctypes.c_int32), ("scale_reward", ctypes.c_float),
+        ("hidden2", ctypes.c_int32), ("env_offset", ctypes.c_int32), ("scale_reward", ctypes.c_float),
         ("log_min_std", ctypes.c_float), ("seed", ctypes.c_uint64), ("step_counter", ctypes.c_uint64),
         ("state", ctypes.c_void_p), ("ts", ctypes.c_void_p), ("theta", ctypes.c_void_p),
         ("eps", ctypes.c_void_p), ("reset_draws", ctypes.c_void_p), ("obs", ctypes.c_void_p),
@@ -65,7 +65,8 @@ class PolicyBatch(ctypes.Structure):
     """Mirror of ``rl_policy_batch`` (include/rllab_amd.h)."""
     _fields_ = [
         ("n_samples", ctypes.c_int32), ("obs_dim", ctypes.c_int32), ("act_dim", ctypes.c_int32),
-        ("hidden0", ctypes.c_int32), ("hidden1", ctypes.c_int32), ("inv_count", ctypes.c_float),
+        ("hidden0", ctypes.c_int32), ("hidden1", ctypes.c_int32), ("hidden2", ctypes.c_int32),
+        ("inv_count", ctypes.c_float),
         ("log_min_std", ctypes.c_float), ("theta", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
         ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
@@ -105,7 +106,7 @@ def _load():
     lib.rl_debug_philox.argtypes = [u32, u32, u32, u32, u32, u32, i32, vp, vp]
     pb = ctypes.POINTER(PolicyBatch)
     lib.rl_policy_workspace_bytes.restype = ctypes.c_size_t
-    lib.rl_policy_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.rl_policy_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.rl_policy_activation_bytes.restype = ctypes.c_size_t
     lib.rl_policy_activation_bytes.argtypes = [i32, i32, i32]
     lib.rl_policy_loss_kl.argtypes = [pb, vp, ctypes.c_size_t, vp, vp]

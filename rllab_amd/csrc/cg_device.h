@@ -9,7 +9,8 @@
 namespace rl {
 
 constexpr int CG_THREADS = 1024;
-constexpr int CG_MAX_PER_THREAD = 16;   // n <= 16384 parameters
+constexpr int CG_MAX_PER_THREAD = 16;   // n <= 16384 parameters: operands cached in registers between the passes
+constexpr int CG_MAX_N = 1 << 16;       // beyond that and up to here: the re-reading form (cg_step_body_large)
 
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     // wavefront butterfly, then the 16 wave sums in order
@@ -81,5 +82,47 @@ __device__ __forceinline__ void cg_step_body(int n, const double* fp, double reg
     }
 }
 
+
+// The same iteration for LARGE parameter vectors (n > CG_THREADS * CG_MAX_PER_THREAD: the 128-unit policy nets of
+// policy_wide_kernels.hip have up to ~37 k parameters): nothing is cached in registers, every pass re-reads its
+// operands.  Same expressions, same per-thread strided partial sums, same fixed-order fold -- so for a size both
+// forms accept they agree bit for bit.
+__device__ __forceinline__ void cg_step_body_large(int n, const double* fp, double reg, double tol,
+                                                   double* __restrict__ x, double* __restrict__ r,
+                                                   double* __restrict__ p, float* __restrict__ p32,
+                                                   double* __restrict__ scal, double* scratch) {
+    const double rdotr = scal[0];
+    const bool active = scal[1] != 0.0;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += CG_THREADS) {
+        const double pv = p[i];
+        acc += pv * (ld_agent(fp + i) + reg * pv);
+    }
+    const double pz = block_sum(acc, scratch);
+    if (!active) return;
+    const double v = rdotr / pz;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += CG_THREADS) {
+        const double pv = p[i];
+        const double z = ld_agent(fp + i) + reg * pv;
+        x[i] += v * pv;
+        const double rn = r[i] - v * z;
+        r[i] = rn;
+        acc += rn * rn;
+    }
+    const double newrdotr = block_sum(acc, scratch);
+    const double mu = newrdotr / rdotr;
+    for (int i = threadIdx.x; i < n; i += CG_THREADS) {
+        const double pn = r[i] + mu * p[i];
+        p[i] = pn;
+        p32[i] = (float)pn;
+    }
+    if (threadIdx.x == 0) {
+        scal[0] = newrdotr;
+        scal[1] = (newrdotr >= tol) ? 1.0 : 0.0;
+        scal[2] = pz;
+        scal[3] += 1.0;
+    }
+}
 
 }  // namespace rl

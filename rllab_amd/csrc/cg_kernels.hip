@@ -42,6 +42,35 @@ __global__ void __launch_bounds__(CG_THREADS) cg_step_kernel(int n, const double
     cg_step_body(n, fp, reg, tol, x, r, p, p32, scal, scratch);
 }
 
+__global__ void __launch_bounds__(CG_THREADS) cg_step_large_kernel(int n, const double* __restrict__ fp, double reg,
+                                                                   double tol, double* __restrict__ x,
+                                                                   double* __restrict__ r, double* __restrict__ p,
+                                                                   float* __restrict__ p32,
+                                                                   double* __restrict__ scal) {
+    __shared__ double scratch[CG_THREADS / 64];
+    cg_step_body_large(n, fp, reg, tol, x, r, p, p32, scal, scratch);
+}
+
+// trpo_step_kernel for n beyond the register-cached form
+__global__ void __launch_bounds__(CG_THREADS) trpo_step_large_kernel(int n, const double* __restrict__ x,
+                                                                     const double* __restrict__ a,
+                                                                     const double* __restrict__ b, double reg,
+                                                                     double delta, double* __restrict__ step,
+                                                                     double* __restrict__ out) {
+    __shared__ double scratch[CG_THREADS / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += CG_THREADS) {
+        const double xv = x[i];
+        const double hx = (b ? a[i] - b[i] : a[i]) + reg * xv;
+        acc += xv * hx;
+    }
+    const double xHx = block_sum(acc, scratch);
+    double beta = sqrt(2.0 * delta * (1.0 / (xHx + 1e-8)));
+    if (beta != beta) beta = 1.0;
+    for (int i = threadIdx.x; i < n; i += CG_THREADS) step[i] = beta * x[i];
+    if (threadIdx.x == 0) { out[0] = xHx; out[1] = beta; }
+}
+
 // After CG (conjugate_gradient_optimizer.py:257-262):  xHx = x . (a - b + reg x),
 // beta = sqrt(2 delta * (1 / (xHx + 1e-8)))  (NaN -> 1),  step = beta x.   out = {xHx, beta}
 //   a = F x (rl_policy_fvp), b = null, reg = reg_coeff : H x evaluated afresh, as the reference does;
@@ -113,10 +142,14 @@ extern "C" int rl_adam_step(int n, float* theta, const double* grad, double* m, 
 
 extern "C" int rl_trpo_step(int n, const double* x, const double* a, const double* b, double reg_coeff,
                             double max_constraint, double* step, double* out, void* stream) {
-    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !x || !a || !step || !out)
-        return set_error(RL_ERR_ARG, "rl_trpo_step: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
-    hipLaunchKernelGGL(trpo_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, x, a, b, reg_coeff,
-                       max_constraint, step, out);
+    if (n <= 0 || n > CG_MAX_N || !x || !a || !step || !out)
+        return set_error(RL_ERR_ARG, "rl_trpo_step: bad argument (n = %d, max %d)", n, CG_MAX_N);
+    if (n <= CG_THREADS * CG_MAX_PER_THREAD)
+        hipLaunchKernelGGL(trpo_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, x, a, b, reg_coeff,
+                           max_constraint, step, out);
+    else
+        hipLaunchKernelGGL(trpo_step_large_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, x, a, b,
+                           reg_coeff, max_constraint, step, out);
     return check_launch("trpo_step_kernel");
 }
 
@@ -130,17 +163,21 @@ extern "C" int rl_line_search_point(int n, const float* prev, const double* step
 
 extern "C" int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p32, double* scal,
                           void* stream) {
-    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !b || !x || !r || !p || !p32 || !scal)
-        return set_error(RL_ERR_ARG, "rl_cg_init: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
+    if (n <= 0 || n > CG_MAX_N || !b || !x || !r || !p || !p32 || !scal)
+        return set_error(RL_ERR_ARG, "rl_cg_init: bad argument (n = %d, max %d)", n, CG_MAX_N);
     hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, b, x, r, p, p32, scal);
     return check_launch("cg_init_kernel");
 }
 
 extern "C" int rl_cg_step(int n, const double* fvp, double reg_coeff, double residual_tol, double* x, double* r,
                           double* p, float* p32, double* scal, void* stream) {
-    if (n <= 0 || n > CG_THREADS * CG_MAX_PER_THREAD || !fvp || !x || !r || !p || !p32 || !scal)
-        return set_error(RL_ERR_ARG, "rl_cg_step: bad argument (n = %d, max %d)", n, CG_THREADS * CG_MAX_PER_THREAD);
-    hipLaunchKernelGGL(cg_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, fvp, reg_coeff,
-                       residual_tol, x, r, p, p32, scal);
+    if (n <= 0 || n > CG_MAX_N || !fvp || !x || !r || !p || !p32 || !scal)
+        return set_error(RL_ERR_ARG, "rl_cg_step: bad argument (n = %d, max %d)", n, CG_MAX_N);
+    if (n <= CG_THREADS * CG_MAX_PER_THREAD)
+        hipLaunchKernelGGL(cg_step_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, fvp, reg_coeff,
+                           residual_tol, x, r, p, p32, scal);
+    else
+        hipLaunchKernelGGL(cg_step_large_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, n, fvp, reg_coeff,
+                           residual_tol, x, r, p, p32, scal);
     return check_launch("cg_step_kernel");
 }

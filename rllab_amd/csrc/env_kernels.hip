@@ -14,6 +14,7 @@
 #include "device_rng.h"
 #include "envs.h"
 #include "policy_mfma.h"
+#include "policy_wide.h"
 
 namespace rl {
 
@@ -409,6 +410,147 @@ struct RolloutPolicy16 {
     }
 };
 
+// The mean network of the WIDE / DEEP policies (two or three tanh layers of 32 / 64 / 128 units after zero padding,
+// policy_wide.h; GaussianMLPPolicy(hidden_sizes=...) is free-form, gaussian_mlp_policy.py:21-58): the chain of
+// RolloutPolicy with the shape at run time.  Per layer the weight fragments sit in LDS as [row tile][k-step][lane]
+// (k in the register order of the producing fragment, so activations stay in registers between layers); a wavefront
+// carries up to 4 fragments per layer (row-tile loops are bounded by 4 and predicated on the wave-uniform tile count).
+// One env-step costs sum_l HT_l * KS_l matrix instructions per block of 32 envs -- 284 for (13 -> 128 -> 128) -- so
+// these rollouts are bound by the policy, not by the physics.
+template <class Env>
+struct RolloutPolicyWide {
+    static constexpr int DO = Env::OBS, DA = Env::ACT;
+    static constexpr int KS0 = (DO + 2) / 2;
+    static constexpr int XROWS = 2 * KS0;
+    WideShape s;
+    float* f[WIDE_MAX_L];
+    float* tail;
+    float* xbuf;
+
+    static size_t lds_floats(const WideShape& s, int threads) {
+        size_t n = (size_t)s.HT[0] * KS0 * WV;
+        for (int l = 1; l < s.L; ++l) n += (size_t)s.HT[l] * (s.H[l - 1] / 2) * WV;
+        n += s.tail;
+        n += (size_t)XROWS * threads;                       // one [input][lane] tile per wavefront
+        return n;
+    }
+
+    __device__ __forceinline__ void init(float* smem, const float* __restrict__ th, const WideShape& shape) {
+        s = shape;
+        const int nt = blockDim.x;
+        float* o = smem;
+        f[0] = o; o += s.HT[0] * KS0 * WV;
+        for (int l = 1; l < WIDE_MAX_L; ++l) { f[l] = o; o += (l < s.L) ? s.HT[l] * (s.H[l - 1] / 2) * WV : 0; }
+        tail = o; o += s.tail;
+        xbuf = o + (threadIdx.x >> 6) * XROWS * WV;
+        for (int e = threadIdx.x; e < s.HT[0] * KS0 * WV; e += nt) {
+            const int l_ = e % WV, m = (e / WV) % KS0, t = e / (WV * KS0);
+            const int i = 32 * t + (l_ & 31), d = 2 * m + (l_ >> 5);
+            f[0][e] = d < DO ? th[s.oW[0] + d * s.H[0] + i] : (d == DO ? th[s.ob[0] + i] : 0.0f);
+        }
+        // every index into the shape's arrays is a compile-time constant (a run-time index would move the whole
+        // struct to scratch memory)
+#pragma unroll
+        for (int l = 1; l < WIDE_MAX_L; ++l)
+            if (l < s.L) {
+                const int ks = s.H[l - 1] / 2;
+                for (int e = threadIdx.x; e < s.HT[l] * ks * WV; e += nt) {
+                    const int l_ = e % WV, m = (e / WV) % ks, t = e / (WV * ks);
+                    const int i = 32 * t + (l_ & 31), k = 32 * (m / 16) + frag_unit(m % 16, l_ >> 5);
+                    f[l][e] = th[s.oW[l] + k * s.H[l] + i];
+                }
+            }
+        for (int k = threadIdx.x; k < s.tail; k += nt) {
+            int src;
+            if (k < s.tWo) {
+                if (s.L > 2 && k >= s.tb[2]) src = s.ob[2] + (k - s.tb[2]);
+                else src = s.ob[1] + (k - s.tb[1]);
+            } else if (k < s.tbo) src = s.oWo + (k - s.tWo);
+            else if (k < s.tls) src = s.obo + (k - s.tbo);
+            else src = (k - s.tls) < DA ? s.ols + (k - s.tls) : -1;
+            tail[k] = src >= 0 ? th[src] : 0.0f;
+        }
+        for (int k = threadIdx.x & 63; k < XROWS * WV; k += WV) xbuf[k] = (k / WV == DO) ? 1.0f : 0.0f;
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ float log_std(int k) const { return tail[s.tls + k]; }
+    __device__ __forceinline__ void forward16(const float* o, float* mean) const { run<1>(o, mean); }
+    __device__ __forceinline__ void forward(const float* o, float* mean) const { run<2>(o, mean); }
+
+    template <int NBLK>
+    __device__ __forceinline__ void run(const float* o, float* mean) const {
+        const int lane = threadIdx.x & 63, lj = lane & 31, lh = lane >> 5;
+        wave_sync();
+#pragma unroll
+        for (int d = 0; d < DO; ++d) xbuf[d * WV + lane] = o[d];
+        wave_sync();
+        const int L = s.L;
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            float xb[KS0];
+#pragma unroll
+            for (int m = 0; m < KS0; ++m) xb[m] = xbuf[(2 * m + lh) * WV + 32 * blk + lj];
+            f32x16 h[2][4];                                  // ping-pong: layer l reads h[(l + 1) & 1], writes h[l & 1]
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < s.HT[0]) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                    for (int m = 0; m < KS0; ++m) acc = mfma(f[0][(t * KS0 + m) * WV + lane], xb[m], acc);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h[0][t][r] = ftanh(acc[r]);
+                }
+#pragma unroll
+            for (int l = 1; l < WIDE_MAX_L; ++l)
+                if (l < L) {
+                    const int ks = s.H[l - 1] / 2;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < s.HT[l]) {
+                            f32x16 acc;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[r] = tail[s.tb[l] + 32 * t + frag_unit(r, 0) + 4 * lh];
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+                                if (tt < s.HT[l - 1]) {
+#pragma unroll
+                                    for (int mm = 0; mm < 16; ++mm)
+                                        acc = mfma(f[l][(t * ks + 16 * tt + mm) * WV + lane], h[(l + 1) & 1][tt][mm], acc);
+                                }
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) h[l & 1][t][r] = ftanh(acc[r]);
+                        }
+                }
+            // the last hidden layer sits in h[(L - 1) & 1]: both cases spelled out, a run-time index would send the
+            // fragments to scratch memory
+            if (L == 3) head<NBLK>(h[0], blk, mean);
+            else head<NBLK>(h[1], blk, mean);
+        }
+    }
+
+    template <int NBLK>
+    __device__ __forceinline__ void head(const f32x16 (&hl)[4], int blk, float* mean) const {
+        const int lane = threadIdx.x & 63, lh = lane >> 5;
+        const int HTL = s.L == 3 ? s.HT[2] : s.HT[1];
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            float pm = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < HTL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pm = __builtin_fmaf(hl[t][r], tail[s.tWo + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], pm);
+                }
+            const float mk = tail[s.tbo + k] + half_sum(pm);
+            if (NBLK == 1 || lh == blk) mean[k] = mk;
+        }
+    }
+};
+
 struct RolloutDev {
     int n, T, max_path_length, normalize, reset_at_start, env_offset;
     float scale_reward, log_min_std;
@@ -458,19 +600,8 @@ __device__ __forceinline__ void store_planes(V* row_ptr, size_t plane, uint32_t&
     }
 }
 
-template <class Env, int H0, int H1, int EPW>
-__global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(RolloutDev a) {
-    static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
-    static_assert(EPW == 64 || EPW == 16, "64 (env per lane) or 16 (four replicas)");
-    using Pol = typename std::conditional<EPW == 16, RolloutPolicy16<Env, H0>, RolloutPolicy<Env, H0>>::type;
-    Pol pol;
-    if constexpr (EPW == 16) {
-        pol.init(a.theta);
-    } else {
-        __shared__ __attribute__((aligned(16))) float smem[RolloutPolicy<Env, H0>::LDS_FLOATS];
-        pol.init(smem, a.theta);
-    }
-
+template <class Env, class Pol, int EPW>
+__device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol) {
     const int n = a.n, T = a.T;
     // every lane stays alive (the matrix instructions and the cross-lane exchanges need the whole
     // wavefront); lanes past the last env shadow env n-1 and only their stores are masked
@@ -561,6 +692,30 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
             for (int k = 0; k < Env::OBS; ++k) a.last_obs[(size_t)k * n + i] = o[k];
         }
     }
+}
+
+template <class Env, int H0, int H1, int EPW>
+__global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(RolloutDev a) {
+    static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
+    static_assert(EPW == 64 || EPW == 16, "64 (env per lane) or 16 (four replicas)");
+    using Pol = typename std::conditional<EPW == 16, RolloutPolicy16<Env, H0>, RolloutPolicy<Env, H0>>::type;
+    Pol pol;
+    if constexpr (EPW == 16) {
+        pol.init(a.theta);
+    } else {
+        __shared__ __attribute__((aligned(16))) float smem[RolloutPolicy<Env, H0>::LDS_FLOATS];
+        pol.init(smem, a.theta);
+    }
+    rollout_body<Env, Pol, EPW>(a, pol);
+}
+
+// the same rollout for the wide / deep policies (RolloutPolicyWide: shape at run time, weight fragments in LDS)
+template <class Env, int EPW>
+__global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_wide_kernel(RolloutDev a, WideShape shape) {
+    extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+    RolloutPolicyWide<Env> pol;
+    pol.init(wide_smem, a.theta, shape);
+    rollout_body<Env, RolloutPolicyWide<Env>, EPW>(a, pol);
 }
 
 // ---------------------------------------------------------------------------
@@ -1098,7 +1253,8 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
         const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;   // per launch: tests switch shapes
         const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
-        if (!lane_kernel && small_offsets && (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
+        if (!lane_kernel && small_offsets && g->hidden2 == 0 && (g->hidden0 == g->hidden1) &&
+            (g->hidden0 == 32 || g->hidden0 == 64)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
             dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
             if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, qblock, 0, st, a);
@@ -1112,7 +1268,7 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         const char* tl = getenv("RLLAB_TWO_LEG_LANE_KERNEL");
         const bool lanes_on = !(tl && tl[0] == '0') && getenv("RLLAB_ROLLOUT_EPW") == nullptr;
         const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
-        if (lanes_on && small_offsets && a.n <= 16 * 1024 && (g->hidden0 == g->hidden1) &&
+        if (lanes_on && small_offsets && a.n <= 16 * 1024 && g->hidden2 == 0 && (g->hidden0 == g->hidden1) &&
             (g->hidden0 == 32 || g->hidden0 == 64)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
             dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
@@ -1128,17 +1284,43 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     const int epw = (epw_env == 16 || epw_env == 64) ? epw_env : (a.n <= 16 * 1024 ? 16 : 64);
     const int waves = (a.n + epw - 1) / epw, wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
     dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
-    if (g->hidden0 == 32 && g->hidden1 == 32) {
+    if (g->hidden2 == 0 && g->hidden0 == 32 && g->hidden1 == 32) {
         if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, block, 0, st, a);
-    } else if (g->hidden0 == 64 && g->hidden1 == 64) {
+    } else if (g->hidden2 == 0 && g->hidden0 == 64 && g->hidden1 == 64) {
         if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, block, 0, st, a);
     } else {
-        return set_error(RL_ERR_UNSUPPORTED,
-                         "rl_rollout_gaussian_mlp: hidden sizes (%d,%d) have no fused kernel "
-                         "(built: 32x32, 64x64); use the per-step rl_vecenv_step path",
-                         g->hidden0, g->hidden1);
+        // wide / deep policies: two or three layers of 32 / 64 / 128 units, weight fragments in (dynamic) LDS
+        WideShape shape;
+        if (!wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape))
+            return set_error(RL_ERR_UNSUPPORTED,
+                             "rl_rollout_gaussian_mlp: hidden sizes (%d,%d,%d) have no fused kernel (two or three tanh "
+                             "layers of 32 / 64 / 128 units each); use the per-step rl_vecenv_step path",
+                             g->hidden0, g->hidden1, g->hidden2);
+        const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
+        if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "wide rollout policy needs %zu B of LDS", lds);
+        static bool attr16 = false, attr64 = false;
+        if (epw == 16) {
+            auto kern = rollout_wide_kernel<Env, 16>;
+            if (!attr16) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr16 = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, a, shape);
+        } else {
+            auto kern = rollout_wide_kernel<Env, 64>;
+            if (!attr64) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr64 = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, a, shape);
+        }
+        return check_launch("rollout_wide_kernel");
     }
     return check_launch("rollout_kernel");
 }

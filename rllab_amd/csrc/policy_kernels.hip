@@ -750,6 +750,21 @@ __global__ void __launch_bounds__(LOSS_COLS * WV) reduce_loss_kernel(const doubl
 
 constexpr int MAX_GRID = 256 * 3;   // workgroups of a pass: <= 3 per CU
 
+// the same fixed-order float64 reductions for the wide / deep nets' passes (policy_wide_kernels.hip)
+int launch_reduce_rows(const float* partial, int rows, int cols, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + WV - 1) / WV), dim3(RR_WAVES * WV), 0, st, partial, rows, cols,
+                       out);
+    return check_launch("reduce_rows_kernel");
+}
+int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(LOSS_COLS * WV), 0, st, partial, rows, out);
+    return check_launch("reduce_loss_kernel");
+}
+int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
+                  hipStream_t st, double* loss_out);                       // policy_wide_kernels.hip
+struct WideShape;
+size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not a wide shape
+
 template <class N, int MODE, bool CACHE = false, bool RELU = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
                        double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr) {
@@ -836,6 +851,11 @@ static int dispatch_relu(int mode, const rl_policy_batch* g, void* ws, size_t ws
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
                         double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
+    if (g->hidden2 < 0) return set_error(RL_ERR_ARG, "rl_policy_batch.hidden2 = %d", g->hidden2);
+    if (g->hidden2 > 0) {              // three hidden layers: the cooperative kernels (policy_wide_kernels.hip)
+        if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
+        return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, loss_out);
+    }
     if (g->activation == RL_ACT_RECTIFY) {
 #define RELUCASE(DO) \
         if (d == DO && k == 1 && h0 == 32 && h1 == 32) return dispatch_relu<Net<DO, 1, 32>>(mode, g, ws, ws_bytes, out, st, loss_out);
@@ -867,9 +887,9 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     NETCASE(20, 1, 32)
     NETCASE(21, 1, 32)
 #undef NETCASE
-    return set_error(RL_ERR_UNSUPPORTED,
-                     "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d); the torch autograd "
-                     "path handles arbitrary networks", d, k, h0, h1);
+    // anything else with tanh layers of 32 / 64 / 128 units: the cooperative kernels
+    if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
+    return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }
 
 }  // namespace rl
@@ -883,7 +903,9 @@ static int check_batch(const rl_policy_batch* g, const char* who) {
     return 0;
 }
 
-extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1) {
+extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1, int hidden2) {
+    const bool narrow = hidden2 == 0 && hidden0 == hidden1 && (hidden0 == 32 || hidden0 == 64);
+    if (!narrow) return wide_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
     // one partial row per workgroup: P floats (or LOSS_COLS doubles)
     const size_t P = (size_t)obs_dim * hidden0 + hidden0 + (size_t)hidden0 * hidden1 + hidden1 +
                      (size_t)hidden1 * act_dim + 2 * (size_t)act_dim;

@@ -1,0 +1,651 @@
+// policy_wide_kernels.hip -- the TRPO / VPG update passes of policy_kernels.hip for WIDE and DEEP GaussianMLPPolicy
+// mean networks: two or three tanh hidden layers of 32 / 64 / 128 units each (after zero padding), e.g. the
+// (100, 50, 25) nets of rllab's MuJoCo experiments -> (128, 64, 32), or (128, 128).
+// (GaussianMLPPolicy(hidden_sizes=...) is free-form: rllab/policies/gaussian_mlp_policy.py:21-58,
+//  rllab/core/network.py:36-101; the functions evaluated are the f_loss / f_grad / f_Hx_plain of
+//  rllab/optimizers/conjugate_gradient_optimizer.py:27-46,194-215 on rllab/algos/npo.py:72-82, exactly as in
+//  policy_kernels.hip -- see its header for the four modes.)
+//
+// Why a second kernel family.  policy_kernels.hip gives every wavefront a whole 32-sample tile: all weight
+// fragments in LDS, all activations and the persistent outer-product accumulators in its registers.  At 128 units
+// neither fits (W1 + its tangent + W1 for back-propagation = 192 KB of LDS; the W1-gradient accumulator alone is 256
+// registers per lane).  Here the four wavefronts of a workgroup COOPERATE on one 32-sample tile:
+//   * wavefront w owns row tile w (units 32 w .. 32 w + 31) of every layer: it runs that tile's MFMA chain
+//     (v_mfma_f32_32x32x2_f32, Z^T[unit][sample] = A[unit][k] B[k][sample]), applies tanh / the derivative, keeps its
+//     own fragment in registers for later phases and publishes it as a [unit][33] tile in LDS -- the B operand of
+//     the next layer for ALL wavefronts;
+//   * A operands (weights, tangents, untransposed weights for back-propagation) are "fragment images" in global
+//     memory, built once per pass by wide_stage_kernel from the flat parameters: one k-step = one coalesced 256-byte
+//     load, software-prefetched eight k-steps ahead; a few hundred KB, L2-resident for the whole pass;
+//   * the batch reductions gW_l = sum_s h_{l-1,s} (x) gz_{l,s} are MFMAs with the SAMPLE axis as K: both operands are
+//     column reads of the same LDS tiles (stride 33: conflict-free both ways); wavefront w accumulates row tile w
+//     (up to four 32x32 fragments per layer, persistent registers for the whole launch);
+//   * thin products (bias gradients, the DA output columns) run on the vector ALU, one thread per unit.
+// One workgroup per CU, grid-stride over tiles; every workgroup writes ONE partial row, reduce_rows_kernel sums
+// the rows in float64 in a fixed order (deterministic, identical on all ranks) -- as in policy_kernels.hip.
+//
+// Roofline: MFMA-bound.  A Fisher-vector product of (DO -> 128 -> 128 -> DA) is ~1400 matrix instructions per
+// 32-sample tile (forward 284 + tangent 540 + back-propagation 256 + outer products 272 + input layer), 350 per
+// wavefront; HBM sees 4 (DO + 1) bytes per sample per pass.
+#include <hip/hip_runtime.h>
+#include "../../include/rllab_amd.h"
+#include "capi_util.h"
+#include "policy_mfma.h"
+#include "policy_wide.h"
+
+namespace rl {
+
+int launch_reduce_rows(const float* partial, int rows, int cols, double* out, hipStream_t st);   // policy_kernels.hip
+int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t st);
+
+constexpr int WW = 4;                  // wavefronts per workgroup = row tiles of the widest layer
+constexpr int WNT = WW * WV;
+constexpr int BS = WIDE_BS;
+constexpr int MAXDA = WIDE_MAX_DA;
+enum { WMODE_LOSS = 0, WMODE_GRAD = 1, WMODE_FVP = 2, WMODE_VPG = 3 };
+constexpr int WLOSS_COLS = 4;
+
+struct WideBatch {
+    int B;
+    const float* theta;
+    const float* vec;
+    const float* img;          // fragment images of theta: forward (+ backward for the gradient-like modes)
+    const float* dimg;         // forward images of vec (FVP)
+    const float* obs;
+    const float* act;
+    const float* adv;
+    const float* old_mean;
+    const float* old_log_std;
+    const float* weight;
+    float inv_count, log_min_std, kl_penalty;
+    float* partial;            // [grid][P]
+    double* partial_loss;      // [grid][4] or null
+    WideShape s;
+};
+
+// ---- fragment images ------------------------------------------------------------------------------------------
+// forward image of layer l:  e = (t * KS + m) * 64 + lane  ->  A[i = 32 t + lane % 32][k = 2 m + lane / 32] = W_l[k][i]
+//   (layer 0: k = input slot; slot DO carries b0 -- the input tile holds a 1 there -- slots beyond are zero)
+// backward image through layer l >= 1:  A[i][k] = W_l[i][k],  i = unit of layer l-1 (row tile), k = unit of layer l
+__global__ void __launch_bounds__(256) wide_stage_kernel(WideShape s, const float* __restrict__ th,
+                                                         float* __restrict__ img, int with_backward) {
+    const int total = with_backward ? s.img_all : s.img_fwd;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        float v = 0.0f;
+        if (e < s.img_fwd) {
+            int l = 0;
+            if (s.L > 1 && e >= s.oF[1]) l = 1;
+            if (s.L > 2 && e >= s.oF[2]) l = 2;
+            const int r = e - s.oF[l];
+            const int lane = r & 63, m = (r >> 6) % s.KS[l], t = (r >> 6) / s.KS[l];
+            const int i = 32 * t + (lane & 31), k = 2 * m + (lane >> 5);
+            if (l == 0) v = k < s.DO ? th[s.oW[0] + k * s.H[0] + i] : (k == s.DO ? th[s.ob[0] + i] : 0.0f);
+            else v = th[s.oW[l] + k * s.H[l] + i];
+        } else {
+            int l = 1;
+            if (s.L > 2 && e >= s.oT[2]) l = 2;
+            const int r = e - s.oT[l];
+            const int lane = r & 63, m = (r >> 6) % s.KT[l], t = (r >> 6) / s.KT[l];
+            const int i = 32 * t + (lane & 31), k = 2 * m + (lane >> 5);
+            v = th[s.oW[l] + i * s.H[l] + k];
+        }
+        img[e] = v;
+    }
+}
+
+// ---- LDS plan ---------------------------------------------------------------------------------------------------
+struct WideLds {
+    int X, Hb[WIDE_MAX_L], Db[WIDE_MAX_L], tail, dtail, part, gmu, red, total;
+};
+__host__ __device__ inline WideLds wide_lds(const WideShape& s, int mode) {
+    WideLds p;
+    int o = 0;
+    p.X = o; o += 32 * BS;
+    for (int l = 0; l < WIDE_MAX_L; ++l) { p.Hb[l] = o; o += s.H[l] * BS; }
+    for (int l = 0; l < WIDE_MAX_L; ++l) { p.Db[l] = o; o += (mode != WMODE_LOSS) ? s.H[l] * BS : 0; }
+    o = (o + 3) & ~3;
+    p.tail = o; o += s.tail;
+    p.dtail = o; o += (mode == WMODE_FVP) ? s.tail : 0;
+    p.part = o; o += WW * MAXDA * 32;            // per-wavefront partial dot products of the output layer
+    p.gmu = o; o += MAXDA * 32;                  // gmu[k][sample] for the thread-per-unit accumulation
+    p.red = o; o += 256 + 64;                    // small cross-thread folds at the end of the launch
+    p.total = o;
+    return p;
+}
+
+// eight k-steps per round, the A operands of the next round in flight while this one runs on the matrix pipe
+template <int U>
+__device__ __forceinline__ f32x16 wide_gemm(const float* __restrict__ img, int ks, const float* bt, int lane,
+                                            f32x16 acc) {
+    const int lj = lane & 31, lh = lane >> 5;
+    const float* bp = bt + lh * BS + lj;
+    float a_cur[U], a_nxt[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) a_cur[j] = img[j * WV + lane];
+    for (int base = 0; base < ks; base += U) {
+        const bool more = base + U < ks;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) a_nxt[j] = img[(base + U + j) * WV + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc = mfma(a_cur[j], bp[(2 * (base + j)) * BS], acc);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) a_cur[j] = a_nxt[j];
+        }
+    }
+    return acc;
+}
+
+// publish an output fragment (lane = sample lj + 32 half, register r = unit frag_unit(r, half) of row tile t)
+__device__ __forceinline__ void wide_put(float* bt, int t, int lane, const f32x16& v) {
+    const int lj = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bt[(32 * t + frag_unit(r, 0) + 4 * lh) * BS + lj] = v[r];
+}
+
+template <int L, int MODE>
+__global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
+    constexpr bool FVP = (MODE == WMODE_FVP), GRADLIKE = (MODE != WMODE_LOSS);
+    const WideShape& s = a.s;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WideLds p = wide_lds(s, MODE);
+    const int tid = threadIdx.x, wave = tid / WV, lane = tid % WV, lj = lane & 31, lh = lane >> 5;
+    const int DO = s.DO, DA = s.DA, HL = s.H[L - 1];
+    float* const X = smem + p.X;
+    float* const tail = smem + p.tail;
+    float* const dtail = smem + p.dtail;
+    float* const part = smem + p.part;
+    float* const gmub = smem + p.gmu;
+
+    // ---- once per launch: zero the tiles, stage the tail parameters ---------------------------------------------
+    for (int k = tid; k < p.tail; k += WNT) smem[k] = 0.0f;
+    for (int k = tid; k < s.tail; k += WNT) {
+        int src;
+        if (k < s.tWo) {                                   // biases of layers >= 1
+            int l = 1;
+            if (L > 2 && k >= s.tb[2]) l = 2;
+            src = s.ob[l] + (k - s.tb[l]);
+        } else if (k < s.tbo) src = s.oWo + (k - s.tWo);
+        else if (k < s.tls) src = s.obo + (k - s.tbo);
+        else src = (k - s.tls) < DA ? s.ols + (k - s.tls) : -1;
+        tail[k] = src >= 0 ? a.theta[src] : 0.0f;
+        if (FVP) dtail[k] = src >= 0 ? a.vec[src] : 0.0f;
+    }
+    __syncthreads();
+    if (tid < 32) X[DO * BS + tid] = 1.0f;                 // the bias slot of the input tile
+    float lstd[MAXDA], inv_std[MAXDA], var_[MAXDA];
+    bool floored[MAXDA];
+#pragma unroll
+    for (int k = 0; k < MAXDA; ++k) {
+        const float raw = k < DA ? tail[s.tls + k] : 0.0f;
+        floored[k] = raw < a.log_min_std;
+        lstd[k] = fmaxf(raw, a.log_min_std);
+        inv_std[k] = __expf(-lstd[k]);
+        var_[k] = __expf(2.0f * lstd[k]);
+    }
+
+    // ---- persistent accumulators ---------------------------------------------------------------------------------
+    f32x16 gW[L - 1][4];          // row tile `wave` of dW_l, l = 1 .. L-1, column tiles 0 .. HT[l]-1
+    f32x16 gW0;                   // column tile `wave` of [dW0 ; db0] (rows = input slots)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gW0[r] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gW[l][j][r] = 0.0f;
+    }
+    float gbv[L];                 // thread-per-unit partial sums of db_l (l >= 1; l = 0 rides in gW0's bias row)
+    float gWo[MAXDA];             // thread-per-unit partial sums of dWo[unit][k]
+#pragma unroll
+    for (int l = 0; l < L; ++l) gbv[l] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXDA; ++k) gWo[k] = 0.0f;
+    float gbo[MAXDA], gls[MAXDA];  // per-sample-lane sums (wavefront 0)
+#pragma unroll
+    for (int k = 0; k < MAXDA; ++k) { gbo[k] = 0.0f; gls[k] = 0.0f; }
+    double acc_loss = 0.0, acc_kl = 0.0, acc_vpg = 0.0;
+    float max_kl = -INFINITY, wsum = 0.0f;
+
+    const int B = a.B, n_tiles = (B + 31) / 32;
+    const bool want_loss = (MODE == WMODE_LOSS) || (a.partial_loss != nullptr);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile * 32 + lj;
+        const int bi = b < B ? b : B - 1;
+        const float wgt = b < B ? a.weight[bi] : 0.0f;
+        __syncthreads();                                   // everybody is done with the previous tile's buffers
+        for (int e = tid; e < DO * 32; e += WNT) {
+            const int d = e >> 5, sm = e & 31;
+            const int bb = tile * 32 + sm;
+            X[d * BS + sm] = a.obs[(size_t)d * B + (bb < B ? bb : B - 1)];
+        }
+        __syncthreads();
+
+        // ---- forward (+ tangent) through the hidden layers; wavefront w owns row tile w ---------------------------
+        f32x16 h[L], dh[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float* bin = (l == 0) ? X : smem + p.Hb[l - 1];
+            if (wave < s.HT[l]) {
+                f32x16 acc;
+                if (l == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    acc = wide_gemm<4>(a.img + s.oF[0] + wave * s.KS[0] * WV, s.KS[0], bin, lane, acc);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = tail[s.tb[l] + 32 * wave + frag_unit(r, 0) + 4 * lh];
+                    acc = wide_gemm<8>(a.img + s.oF[l] + wave * s.KS[l] * WV, s.KS[l], bin, lane, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[l][r] = ftanh(acc[r]);
+                wide_put(smem + p.Hb[l], wave, lane, h[l]);
+                if (FVP) {
+                    f32x16 dacc;
+                    if (l == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+                        dacc = wide_gemm<4>(a.dimg + s.oF[0] + wave * s.KS[0] * WV, s.KS[0], bin, lane, dacc);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dacc[r] = dtail[s.tb[l] + 32 * wave + frag_unit(r, 0) + 4 * lh];
+                        dacc = wide_gemm<8>(a.dimg + s.oF[l] + wave * s.KS[l] * WV, s.KS[l], bin, lane, dacc);   // dW^T h
+                        dacc = wide_gemm<8>(a.img + s.oF[l] + wave * s.KS[l] * WV, s.KS[l], smem + p.Db[l - 1], lane,
+                                            dacc);                                                                 // W^T dh
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dh[l][r] = dacc[r] * (1.0f - h[l][r] * h[l][r]);
+                    wide_put(smem + p.Db[l], wave, lane, dh[l]);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- output layer: partial dot products over this wavefront's quarter of the last hidden layer -----------
+        // lane (sample lj, half lh) covers units [q0, q0 + HL / 8) of the quarter, halves are folded by half_sum
+        {
+            const int per = HL / 8, q0 = wave * (HL / 4) + lh * per;
+            const float* hb = smem + p.Hb[L - 1];
+            const float* db = smem + p.Db[L - 1];
+            float pm[MAXDA];
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k) pm[k] = 0.0f;
+            for (int u = q0; u < q0 + per; ++u) {
+                const float hv = hb[u * BS + lj];
+                const float dv = FVP ? db[u * BS + lj] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < MAXDA; ++k)
+                    if (k < DA) {
+                        if (FVP) {
+                            pm[k] = __builtin_fmaf(hv, dtail[s.tWo + u * DA + k], pm[k]);
+                            pm[k] = __builtin_fmaf(dv, tail[s.tWo + u * DA + k], pm[k]);
+                        } else {
+                            pm[k] = __builtin_fmaf(hv, tail[s.tWo + u * DA + k], pm[k]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k)
+                if (k < DA) {
+                    const float v = half_sum(pm[k]);
+                    if (lh == 0) part[(wave * MAXDA + k) * 32 + lj] = v;
+                }
+        }
+        __syncthreads();
+
+        // ---- per-sample cotangent on the mean (every wavefront, redundantly: lane = sample) ------------------------
+        float gmu[MAXDA];
+#pragma unroll
+        for (int k = 0; k < MAXDA; ++k) gmu[k] = 0.0f;
+        const bool keeper = (wave == 0 && lh == 0);        // the one lane that counts this sample in the scalar sums
+        if (!FVP) {
+            float mean[MAXDA];
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k)
+                mean[k] = k < DA ? tail[s.tbo + k] + ((part[(0 * MAXDA + k) * 32 + lj] + part[(1 * MAXDA + k) * 32 + lj]) +
+                                                      (part[(2 * MAXDA + k) * 32 + lj] + part[(3 * MAXDA + k) * 32 + lj]))
+                                 : 0.0f;
+            const float advb = a.adv[bi];
+            float zz_new = 0.0f, zz_old = 0.0f, sls_new = 0.0f, sls_old = 0.0f, kl = 0.0f;
+            float znew[MAXDA], dmv[MAXDA], numv[MAXDA];
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k) {
+                znew[k] = 0.0f; dmv[k] = 0.0f; numv[k] = 0.0f;
+                if (k < DA) {
+                    const float ak = a.act[(size_t)k * B + bi];
+                    const float mo = a.old_mean[(size_t)k * B + bi];
+                    const float lo = a.old_log_std[k];
+                    const float so = __expf(lo);
+                    znew[k] = (ak - mean[k]) * inv_std[k];
+                    const float zo = (ak - mo) / so;
+                    zz_new = __builtin_fmaf(znew[k], znew[k], zz_new);
+                    zz_old = __builtin_fmaf(zo, zo, zz_old);
+                    sls_new += lstd[k];
+                    sls_old += lo;
+                    const float dm = mo - mean[k];
+                    const float num = dm * dm + so * so - var_[k];
+                    const float den = 2.0f * var_[k] + 1e-8f;
+                    kl += num / den + lstd[k] - lo;
+                    dmv[k] = dm;
+                    numv[k] = num;
+                }
+            }
+            const float logp_new = -sls_new - 0.5f * zz_new;
+            const float dlog = logp_new - (-sls_old - 0.5f * zz_old);
+            const float lr = __expf(dlog);
+            const float w1 = keeper ? wgt : 0.0f;
+            if (want_loss) {
+                acc_loss += (double)(w1 * lr * advb);
+                acc_kl += (double)(w1 * kl);
+                acc_vpg += (double)(w1 * (logp_new - 0.5f * (float)DA * 1.8378770664093453f) * advb);
+                if (w1 > 0.0f) max_kl = fmaxf(max_kl, kl);
+            }
+            if (MODE != WMODE_LOSS) {
+                const float c = -wgt * advb * (MODE == WMODE_GRAD ? lr : 1.0f) * a.inv_count;
+                const float c1 = keeper ? c : 0.0f;
+#pragma unroll
+                for (int k = 0; k < MAXDA; ++k)
+                    if (k < DA) {
+                        gmu[k] = c * znew[k] * inv_std[k];
+                        if (!floored[k]) gls[k] += c1 * (znew[k] * znew[k] - 1.0f);
+                    }
+                if (a.kl_penalty != 0.0f) {
+                    const float pp = a.kl_penalty * wgt * a.inv_count;
+                    const float p1 = keeper ? pp : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < MAXDA; ++k)
+                        if (k < DA) {
+                            const float den = 2.0f * var_[k] + 1e-8f;
+                            const float dkl_mu = -2.0f * dmv[k] / den;
+                            const float dkl_ls = 1.0f - (2.0f * var_[k] * den + 4.0f * var_[k] * numv[k]) / (den * den);
+                            gmu[k] = __builtin_fmaf(pp, dkl_mu, gmu[k]);
+                            if (!floored[k]) gls[k] += p1 * dkl_ls;
+                        }
+                }
+            }
+        } else {
+            const float c = wgt * a.inv_count;
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k)
+                if (k < DA) {
+                    const float dmu = dtail[s.tbo + k] + ((part[(0 * MAXDA + k) * 32 + lj] + part[(1 * MAXDA + k) * 32 + lj]) +
+                                                          (part[(2 * MAXDA + k) * 32 + lj] + part[(3 * MAXDA + k) * 32 + lj]));
+                    gmu[k] = c * dmu * (2.0f / (2.0f * var_[k] + 1e-8f));
+                }
+            if (keeper) wsum += c;
+        }
+        if (!GRADLIKE) continue;                            // MODE_LOSS: forward only (barrier at the loop head)
+
+        if (keeper) {
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k) gbo[k] += gmu[k];
+        }
+        if (wave == 0 && lh == 0) {
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k)
+                if (k < DA) gmub[k * 32 + lj] = gmu[k];
+        }
+
+        // ---- back-propagation: gz_{L-1} = (Wo gmu) (1 - h^2), then gz_{l-1} = (W_l gz_l) (1 - h_{l-1}^2) -----------
+        f32x16 gz;
+        if (wave < s.HT[L - 1]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = 32 * wave + frag_unit(r, 0) + 4 * lh;
+                float g = 0.0f;
+#pragma unroll
+                for (int k = 0; k < MAXDA; ++k)
+                    if (k < DA) g = __builtin_fmaf(tail[s.tWo + u * DA + k], gmu[k], g);
+                gz[r] = g * (1.0f - h[L - 1][r] * h[L - 1][r]);
+            }
+            wide_put(smem + p.Db[L - 1], wave, lane, gz);      // the tangent of this layer is consumed: reuse its tile
+        }
+        __syncthreads();
+        // thread-per-unit sums over the samples of the tile: dWo[u][k] += h_{L-1}[u][s] gmu[k][s], db_{L-1}[u] += gz[u][s]
+        {
+            const int u = tid % HL, prt = tid / HL, nprt = WNT / HL;
+            const float* hb = smem + p.Hb[L - 1] + u * BS;
+            const float* gb = smem + p.Db[L - 1] + u * BS;
+            float sb = 0.0f;
+            for (int sm = prt; sm < 32; sm += nprt) {
+                const float hv = hb[sm];
+                sb += gb[sm];
+#pragma unroll
+                for (int k = 0; k < MAXDA; ++k)
+                    if (k < DA) gWo[k] = __builtin_fmaf(hv, gmub[k * 32 + sm], gWo[k]);
+            }
+            gbv[L - 1] += sb;
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {
+            if (wave < s.HT[l - 1]) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                acc = wide_gemm<8>(a.img + s.oT[l] + wave * s.KT[l] * WV, s.KT[l], smem + p.Db[l], lane, acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gz[r] = acc[r] * (1.0f - h[l - 1][r] * h[l - 1][r]);
+                wide_put(smem + p.Db[l - 1], wave, lane, gz);
+            }
+            __syncthreads();
+            if (l - 1 >= 1) {
+                const int H = s.H[l - 1], u = tid % H, prt = tid / H, nprt = WNT / H;
+                const float* gb = smem + p.Db[l - 1] + u * BS;
+                float sb = 0.0f;
+                for (int sm = prt; sm < 32; sm += nprt) sb += gb[sm];
+                gbv[l - 1] += sb;
+            }
+        }
+
+        // ---- outer products over the sample axis (K = 32 samples = 16 k-steps) ------------------------------------
+        // operand m of lane (c, half): value of unit c (of the row / column tile) at sample 2 m + half
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            if (wave < s.HT[l - 1]) {
+                const float* ap = smem + p.Hb[l - 1] + (32 * wave + lj) * BS + lh;
+                float aop[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) aop[m] = ap[2 * m];
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    if (tj < s.HT[l]) {
+                        const float* bp = smem + p.Db[l] + (32 * tj + lj) * BS + lh;
+#pragma unroll
+                        for (int m = 0; m < 16; ++m) gW[l - 1][tj] = mfma(aop[m], bp[2 * m], gW[l - 1][tj]);
+                    }
+            }
+        }
+        if (wave < s.HT[0]) {
+            const float* ap = X + lj * BS + lh;                        // rows = input slots (slot DO = 1: the bias row)
+            const float* bp = smem + p.Db[0] + (32 * wave + lj) * BS + lh;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) gW0 = mfma(ap[2 * m], bp[2 * m], gW0);
+        }
+    }
+
+    // ---- one partial row per workgroup ------------------------------------------------------------------------------
+    auto fold_loss = [&]() {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);
+        const double l = wave_sum(acc_loss), k = wave_sum(acc_kl), v = wave_sum(acc_vpg);
+        const float mk = wave_max(max_kl);
+        if (tid == 0) {                                    // only wavefront 0 holds counted samples
+            double* o = a.partial_loss + (size_t)blockIdx.x * WLOSS_COLS;
+            o[0] = l; o[1] = k; o[2] = v; o[3] = (double)mk;
+        }
+        (void)red;
+    };
+    if (MODE == WMODE_LOSS) {
+        fold_loss();
+        return;
+    }
+    float* row = a.partial + (size_t)blockIdx.x * s.P;
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+        if (wave < s.HT[l - 1]) {
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                if (tj < s.HT[l]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        row[s.oW[l] + (32 * wave + frag_unit(r, 0) + 4 * lh) * s.H[l] + 32 * tj + lj] = gW[l - 1][tj][r];
+                }
+        }
+    if (wave < s.HT[0]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = frag_unit(r, 0) + 4 * lh;
+            if (d < DO) row[s.oW[0] + d * s.H[0] + 32 * wave + lj] = gW0[r];
+            else if (d == DO) row[s.ob[0] + 32 * wave + lj] = gW0[r];
+        }
+    }
+    // thread-per-unit partials: the `nprt` threads of a unit meet in LDS in a fixed order
+    __syncthreads();
+    float* red = smem + p.red;
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        const int H = s.H[l], u = tid % H, prt = tid / H, nprt = WNT / H;
+        red[tid] = gbv[l];
+        __syncthreads();
+        if (prt == 0) {
+            float t = red[u];
+            for (int q = 1; q < nprt; ++q) t += red[q * H + u];
+            row[s.ob[l] + u] = t;
+        }
+        __syncthreads();
+    }
+    {
+        const int u = tid % HL, prt = tid / HL, nprt = WNT / HL;
+#pragma unroll
+        for (int k = 0; k < MAXDA; ++k) {
+            if (k < DA) {                                   // wave-uniform
+                red[tid] = gWo[k];
+                __syncthreads();
+                if (prt == 0) {
+                    float t = red[u];
+                    for (int q = 1; q < nprt; ++q) t += red[q * HL + u];
+                    row[s.oWo + u * DA + k] = t;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (wave == 0) {
+        const float ws = wave_sum(wsum);
+#pragma unroll
+        for (int k = 0; k < MAXDA; ++k)
+            if (k < DA) {
+                const float b2 = wave_sum(gbo[k]), ls = wave_sum(gls[k]);
+                if (lane == 0) {
+                    row[s.obo + k] = b2;
+                    if (FVP) {
+                        // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
+                        const float vv = var_[k], e = 1e-8f;
+                        const float c = floored[k] ? 0.0f : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+                        row[s.ols + k] = c * a.vec[s.ols + k] * ws;
+                    } else {
+                        row[s.ols + k] = ls;
+                    }
+                }
+            }
+    }
+    if ((MODE == WMODE_GRAD || MODE == WMODE_VPG) && a.partial_loss != nullptr) fold_loss();
+}
+
+constexpr int WIDE_GRID = 256;         // one workgroup per CU
+
+size_t wide_workspace_bytes(const WideShape& s) {
+    const size_t rows = ((size_t)WIDE_GRID * s.P * sizeof(float) + 15) & ~(size_t)15;
+    const size_t loss = (size_t)WIDE_GRID * WLOSS_COLS * sizeof(double);
+    const size_t imgs = ((size_t)s.img_all + (size_t)s.img_fwd) * sizeof(float);
+    return rows + loss + imgs + 64;
+}
+
+size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2) {
+    WideShape s;
+    if (!wide_shape(obs_dim, act_dim, h0, h1, h2, s)) return 0;
+    return wide_workspace_bytes(s);
+}
+
+template <int L, int MODE>
+static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float* vec, void* workspace,
+                       size_t workspace_bytes, double* out, hipStream_t st, double* loss_out) {
+    if (workspace_bytes < wide_workspace_bytes(s))
+        return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", workspace_bytes,
+                         wide_workspace_bytes(s));
+    WideBatch a;
+    a.s = s;
+    a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
+    a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
+    a.inv_count = g->inv_count; a.log_min_std = g->log_min_std; a.kl_penalty = g->kl_penalty;
+    const int n_tiles = (a.B + 31) / 32;
+    const int grid = n_tiles < WIDE_GRID ? n_tiles : WIDE_GRID;
+    const size_t rows = ((size_t)WIDE_GRID * s.P * sizeof(float) + 15) & ~(size_t)15;
+    const bool with_loss = (MODE == WMODE_GRAD || MODE == WMODE_VPG) && loss_out != nullptr;
+    a.partial = (float*)workspace;
+    double* lossp = (double*)((char*)workspace + rows);
+    a.partial_loss = (MODE == WMODE_LOSS || with_loss) ? lossp : nullptr;
+    float* img = (float*)((char*)workspace + rows + (size_t)WIDE_GRID * WLOSS_COLS * sizeof(double));
+    float* dimg = img + s.img_all;
+    a.img = img; a.dimg = dimg;
+    const int with_bwd = (MODE != WMODE_LOSS) ? 1 : 0;
+    const int n_img = with_bwd ? s.img_all : s.img_fwd;
+    hipLaunchKernelGGL(wide_stage_kernel, dim3((n_img + 255) / 256 < 512 ? (n_img + 255) / 256 : 512), dim3(256), 0, st,
+                       s, g->theta, img, with_bwd);
+    if (MODE == WMODE_FVP)
+        hipLaunchKernelGGL(wide_stage_kernel, dim3((s.img_fwd + 255) / 256 < 512 ? (s.img_fwd + 255) / 256 : 512),
+                           dim3(256), 0, st, s, vec, dimg, 0);
+    int rc = check_launch("wide_stage_kernel");
+    if (rc) return rc;
+    const WideLds p = wide_lds(s, MODE);
+    const size_t lds = (size_t)p.total * sizeof(float);
+    if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "wide policy pass needs %zu B of LDS", lds);
+    auto kern = wide_pass_kernel<L, MODE>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_lds = 160 * 1024;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WNT), lds, st, a);
+    rc = check_launch("wide_pass_kernel");
+    if (rc) return rc;
+    if (MODE == WMODE_LOSS) return launch_reduce_loss(a.partial_loss, grid, out, st);
+    rc = launch_reduce_rows(a.partial, grid, s.P, out, st);
+    if (rc) return rc;
+    if (with_loss) return launch_reduce_loss(a.partial_loss, grid, loss_out, st);
+    return 0;
+}
+
+template <int L>
+static int wide_mode(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
+                     size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
+    switch (mode) {
+        case WMODE_LOSS: return launch_wide<L, WMODE_LOSS>(s, g, vec, ws, ws_bytes, out, st, nullptr);
+        case WMODE_GRAD: return launch_wide<L, WMODE_GRAD>(s, g, vec, ws, ws_bytes, out, st, loss_out);
+        case WMODE_FVP: return launch_wide<L, WMODE_FVP>(s, g, vec, ws, ws_bytes, out, st, nullptr);
+        case WMODE_VPG: return launch_wide<L, WMODE_VPG>(s, g, vec, ws, ws_bytes, out, st, loss_out);
+    }
+    return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
+}
+
+// entry point for policy_kernels.hip's dispatcher: nets that the one-wavefront-per-tile kernels are not built for
+int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
+                  hipStream_t st, double* loss_out) {
+    WideShape s;
+    if (g->activation != RL_ACT_TANH || !wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, s))
+        return set_error(RL_ERR_UNSUPPORTED,
+                         "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d,%d): two or three tanh layers "
+                         "of 32 / 64 / 128 units, obs_dim <= %d, act_dim <= %d",
+                         g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, WIDE_MAX_DO, WIDE_MAX_DA);
+    if (g->activations)
+        return set_error(RL_ERR_ARG, "the activation cache belongs to the 32 / 64-unit two-layer kernels");
+    return s.L == 2 ? wide_mode<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
+                    : wide_mode<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
+}
+
+}  // namespace rl

@@ -196,9 +196,9 @@ class HipVecEnv(object):
         do, da = self.q["obs_dim"], self.q["act_dim"]
         layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
         if layout is None:
-            raise NotImplementedError("fused rollout needs a GaussianMLPPolicy with two tanh hidden layers of at "
-                                      "most 64 units (policies/kernel_layout.py)")
-        hs = (layout.H, layout.H)
+            raise NotImplementedError("fused rollout needs a GaussianMLPPolicy with two or three tanh hidden layers of "
+                                      "at most 128 units (policies/kernel_layout.py)")
+        hs = layout.hidden3
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         obs = torch.empty((do, T, n), **f32)
@@ -221,7 +221,7 @@ class HipVecEnv(object):
         args = _lib.RolloutArgs(
             kind=self.kind, n_envs=n, horizon=T, max_path_length=self.max_path_length,
             normalize=int(self.normalize), reset_at_start=int(reset_at_start),
-            hidden0=hs[0], hidden1=hs[1], env_offset=self.env_offset,
+            hidden0=hs[0], hidden1=hs[1], hidden2=hs[2], env_offset=self.env_offset,
             scale_reward=self.scale_reward, log_min_std=log_min_std, seed=self.seed,
             step_counter=self.step_counter,
             state=self.state.data_ptr(), ts=self.ts.data_ptr(), theta=theta.data_ptr(),

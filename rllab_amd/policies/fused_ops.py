@@ -21,8 +21,8 @@ class FusedGaussianMLPOps(object):
         self.policy = policy
         self.layout = policy.kernel_layout()
         assert self.layout is not None
-        # what the kernels are told: the padded hidden width (policies/kernel_layout.py); P_pad parameters
-        self.dims = (policy.obs_dim, policy.action_dim, self.layout.H, self.layout.H)
+        # what the kernels are told: the padded hidden widths (policies/kernel_layout.py); P_pad parameters
+        self.dims = (policy.obs_dim, policy.action_dim) + self.layout.hidden3
         self.n_kernel = self.layout.P_pad
         self._ws = None
         self._loss_cache = None
@@ -40,13 +40,19 @@ class FusedGaussianMLPOps(object):
     def _epoch(self, value):
         self.policy._raw_writes = value
 
+    # (obs_dim, action_dim) pairs the equal-width two-layer kernels are instantiated for (the HIP-native envs');
+    # the cooperative kernels of the wide / deep nets take the widths at run time
+    NARROW_PAIRS = ((4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6))
+
     @staticmethod
     def supported(policy):
-        """Two tanh hidden layers of at most 64 units each (zero-padded to the kernels' tiles), learned
-        state-independent std, one of the (obs_dim, action_dim) pairs the kernels are instantiated for -- the
-        HIP-native envs' -- and parameters on the device."""
-        return (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None and policy.learn_std
-                and (policy.obs_dim, policy.action_dim) in ((4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6)))
+        """Two or three tanh hidden layers of at most 128 units each (zero-padded to the kernels' tiles), learned
+        state-independent std, parameters on the device; for the equal-width two-layer family additionally one of
+        the (obs_dim, action_dim) pairs it is instantiated for."""
+        layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
+        if layout is None or not policy.learn_std:
+            return False
+        return layout.wide or (policy.obs_dim, policy.action_dim) in FusedGaussianMLPOps.NARROW_PAIRS
 
     def accepts(self, inputs):
         """The kernels take ONE old log_std row (state-independent std)."""
@@ -76,7 +82,7 @@ class FusedGaussianMLPOps(object):
         inv = float(inv_count)
         b = _lib.PolicyBatch(
             n_samples=obs.shape[-1], obs_dim=self.dims[0], act_dim=self.dims[1], hidden0=self.dims[2],
-            hidden1=self.dims[3], inv_count=inv,
+            hidden1=self.dims[3], hidden2=self.dims[4], inv_count=inv,
             log_min_std=math.log(pol.min_std) if pol.min_std is not None else -1e30,
             theta=theta.data_ptr(), obs=obs.data_ptr(), actions=act.data_ptr(), advantages=adv.data_ptr(),
             old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(), weights=w.data_ptr())
@@ -172,7 +178,7 @@ class FusedGaussianMLPOps(object):
         out = torch.empty(self.n_kernel, dtype=torch.float64, device=keep[0].device)
         self._acts_tag = None
         b.activations = None
-        if keep_activations and not vpg:
+        if keep_activations and not vpg and not self.layout.wide:     # the cache belongs to the equal-width family
             need = _lib.lib.rl_policy_activation_bytes(b.n_samples, self.dims[2], self.dims[3])
             if self._acts is None or self._acts.numel() < need or self._acts.device != keep[0].device:
                 self._acts = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
@@ -245,7 +251,7 @@ class FusedGaussianMLPOps(object):
         release / acquire, which on an 8-XCD part writes back and invalidates the per-XCD L2s -- more than the
         launch boundary it saves.  Kept as a tested alternative, off by default."""
         n = self.n_kernel
-        if D.is_distributed() or not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
+        if D.is_distributed() or self.layout.wide or not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
             for _ in range(cg_iters):
                 self._fvp_into(b, ws, p32, z, inputs)
                 _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),

@@ -1,28 +1,37 @@
 """How a GaussianMLPPolicy's flat parameter vector is presented to the HIP kernels.
 
-The fused rollout and update kernels (csrc/env_kernels.hip, csrc/policy_kernels.hip) are instantiated for two
-equal hidden layers of H = 32 or H = 64 tanh units -- the tile sizes of the matrix cores.  The reference's
-``GaussianMLPPolicy(hidden_sizes=...)`` is free-form (rllab/policies/gaussian_mlp_policy.py:24), so any two-layer
-tanh policy with hidden sizes (h0, h1), h0, h1 <= 64, is run on the kernel of the next tile size by ZERO PADDING:
+The reference's ``GaussianMLPPolicy(hidden_sizes=...)`` is free-form (rllab/policies/gaussian_mlp_policy.py:21-38,
+rllab/core/network.py:36-101; its MuJoCo experiments use (100, 50, 25)).  The kernels come in two families:
 
-    W0 [Do, h0] -> [Do, H]   b0 [h0] -> [H]   W1 [h0, h1] -> [H, H]   b1 [h1] -> [H]   Wout [h1, Da] -> [H, Da]
+  * two EQUAL hidden layers of H = 32 or 64 tanh units, one wavefront per 32-sample tile with everything on chip
+    (csrc/policy_kernels.hip, the lane-group rollouts of csrc/env_kernels.hip) -- any two-layer policy with both
+    sizes <= 64 runs there;
+  * two or three hidden layers of 32 / 64 / 128 units EACH, four wavefronts cooperating on a tile
+    (csrc/policy_wide_kernels.hip, ``rollout_wide_kernel``) -- everything else up to 128 units per layer.
+
+Either way a policy whose sizes are not tile sizes runs on the next tile size by ZERO PADDING:
+
+    W_l [in, h_l] -> [in_pad, H_l]      b_l [h_l] -> [H_l]      Wout [h_last, Da] -> [H_last, Da]
 
 A padded unit has zero input weights and zero bias, so its activation is tanh(0) = 0, it feeds nothing (zero
 outgoing weights), and every gradient / Fisher-vector-product entry of a padded parameter is exactly zero; what the
 real parameters see is the unpadded arithmetic plus exact zeros.  The policy keeps its parameters in the
 reference's layout (``flat_params``, what ``get_param_values`` / snapshots / the optimizers see); ``KernelLayout``
 owns the padded copy, refreshes it when the parameters have moved, scatters vectors into the padded space
-(``pack``) and gathers results back (``unpack``).  For (32, 32) and (64, 64) it is the identity and hands out
-``flat_params`` itself.
+(``pack``) and gathers results back (``unpack``).  For sizes that are tile sizes already it is the identity and hands
+out ``flat_params`` itself.
 """
 import numpy as np
 import torch
 
-TILE_SIZES = (32, 64)
+TILE_SIZES = (32, 64)            # the equal-width two-layer kernels
+WIDE_TILE_SIZES = (32, 64, 128)  # per-layer widths of the cooperative kernels
+MAX_OBS_DIM = 30                 # obs_dim + 1 (bias slot) must fit one 32-row input tile
+MAX_ACT_DIM = 8
 
 
 def tile_for(hidden_sizes):
-    """Hidden width H of the kernel that runs ``hidden_sizes`` (two layers), or None."""
+    """Hidden width H of the equal-width two-layer kernel that runs ``hidden_sizes``, or None."""
     hs = tuple(int(h) for h in hidden_sizes)
     if len(hs) != 2 or min(hs) < 1:
         return None
@@ -32,43 +41,62 @@ def tile_for(hidden_sizes):
     return None
 
 
+def padded_sizes(hidden_sizes):
+    """The kernels' hidden widths for ``hidden_sizes``: (H, H) of the equal-width family when it applies, else every
+    layer on its own next size of 32 / 64 / 128 (two or three layers); None when no kernel runs the net."""
+    hs = tuple(int(h) for h in hidden_sizes)
+    H = tile_for(hs)
+    if H is not None:
+        return (H, H)
+    if len(hs) not in (2, 3) or min(hs) < 1 or max(hs) > WIDE_TILE_SIZES[-1]:
+        return None
+    return tuple(next(t for t in WIDE_TILE_SIZES if h <= t) for h in hs)
+
+
 class KernelLayout(object):
     def __init__(self, policy):
         self.policy = policy
-        h0, h1 = (int(h) for h in policy.hidden_sizes)
+        hs = tuple(int(h) for h in policy.hidden_sizes)
         do, da = policy.obs_dim, policy.action_dim
-        H = tile_for((h0, h1))
-        assert H is not None
-        self.H = H
-        self.exact = (h0 == H and h1 == H)
+        Hs = padded_sizes(hs)
+        assert Hs is not None
+        self.hidden = Hs                         # what the kernels are told (rl_policy_batch.hidden0..2)
+        self.H = Hs[0]                           # kept for callers of the equal-width family
+        self.wide = not (len(Hs) == 2 and Hs[0] == Hs[1] and Hs[0] in TILE_SIZES)
+        self.exact = (hs == Hs)
         self.P = policy.flat_params.numel()
-        self.P_pad = do * H + H + H * H + H + H * da + 2 * da
+        ins_real, ins_pad = (do,) + hs, (do,) + Hs
+        self.P_pad = sum(ins_pad[l] * Hs[l] + Hs[l] for l in range(len(Hs))) + Hs[-1] * da + 2 * da
         if self.exact:
             assert self.P == self.P_pad
             self.index = None
             return
         # position of every real parameter inside the padded vector, in the reference's flat order
-        off_b0 = do * H
-        off_w1 = off_b0 + H
-        off_b1 = off_w1 + H * H
-        off_w2 = off_b1 + H
-        off_b2 = off_w2 + H * da
-        off_ls = off_b2 + da
-        idx = [
-            (np.arange(do)[:, None] * H + np.arange(h0)[None, :]).reshape(-1),                 # W0 [Do, h0]
-            off_b0 + np.arange(h0),                                                           # b0
-            off_w1 + (np.arange(h0)[:, None] * H + np.arange(h1)[None, :]).reshape(-1),       # W1 [h0, h1]
-            off_b1 + np.arange(h1),                                                           # b1
-            off_w2 + (np.arange(h1)[:, None] * da + np.arange(da)[None, :]).reshape(-1),      # Wout [h1, Da]
-            off_b2 + np.arange(da),                                                           # bout
-            off_ls + np.arange(da),                                                           # log_std
-        ]
+        idx, off = [], 0
+        for l in range(len(Hs)):
+            rows, cols, cols_pad = ins_real[l], hs[l], Hs[l]
+            idx.append(off + (np.arange(rows)[:, None] * cols_pad + np.arange(cols)[None, :]).reshape(-1))   # W_l
+            off += ins_pad[l] * cols_pad
+            idx.append(off + np.arange(cols))                                                               # b_l
+            off += cols_pad
+        idx.append(off + (np.arange(hs[-1])[:, None] * da + np.arange(da)[None, :]).reshape(-1))            # Wout
+        off += Hs[-1] * da
+        idx.append(off + np.arange(da))                                                                     # bout
+        off += da
+        idx.append(off + np.arange(da))                                                                     # log_std
+        off += da
+        assert off == self.P_pad
         idx = np.concatenate(idx)
         assert idx.size == self.P and len(set(idx.tolist())) == self.P
         dev = policy.flat_params.device
         self.index = torch.as_tensor(idx, dtype=torch.long, device=dev)
         self._theta = torch.zeros(self.P_pad, dtype=torch.float32, device=dev)
         self._tag = None
+
+    @property
+    def hidden3(self):
+        """(hidden0, hidden1, hidden2) as the C ABI takes them (hidden2 = 0: two layers)."""
+        return tuple(self.hidden) + (0,) * (3 - len(self.hidden))
 
     # -- the parameter vector the kernels read --------------------------------------------------------------------
     def theta(self):

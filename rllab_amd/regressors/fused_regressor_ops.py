@@ -28,7 +28,7 @@ class FusedRegressorOps(object):
     def __init__(self, regressor):
         self.reg = regressor
         net = regressor._mean_network
-        self.dims = (net.input_dim, net.output_dim, net.hidden_sizes[0], net.hidden_sizes[1])
+        self.dims = (net.input_dim, net.output_dim, net.hidden_sizes[0], net.hidden_sizes[1], 0)
         self.activation = _lib.ACT_RECTIFY if net.hidden_nonlinearity is rectify else _lib.ACT_TANH
         self._ws = None
         self._bound = None

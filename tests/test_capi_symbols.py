@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.rl_abi_version() == 6
+    assert _lib.lib.rl_abi_version() == 7
 
 
 def test_env_query_and_errors():
@@ -48,7 +48,11 @@ def test_env_query_and_errors():
     assert _lib.lib.rl_gae(0, 0, None, None, None, 0.99, 1.0, None, None, None, None) == -1
     assert _lib.lib.rl_rollout_gaussian_mlp(None, None) == -1
     assert _lib.lib.rl_policy_fvp(None, None, None, 0, None, None) == -1
-    assert _lib.lib.rl_policy_workspace_bytes(13, 2, 32, 32) > 0
+    assert _lib.lib.rl_policy_workspace_bytes(13, 2, 32, 32, 0) > 0
+    # the wide / deep family: two or three layers of 32 / 64 / 128 units
+    assert _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 64, 32) > _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 64, 0) > 0
+    assert _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 96, 0) == 0 and _lib.lib.rl_policy_workspace_bytes(13, 2, 256, 32, 0) == 0
+    assert _lib.lib.rl_policy_activation_bytes(1000, 128, 128) == 0
 
 
 def test_env_default_cfg():

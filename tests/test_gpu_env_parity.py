@@ -292,7 +292,7 @@ def test_stepwise_rollout_through_a_hip_graph(quiet_logger):
     ext.set_seed(3)
     torch.manual_seed(3)
     env = normalize(CartpoleEnv())
-    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(16, 16, 16))    # three layers: no fused kernel
+    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(16, 16, 16, 16))    # four layers: no fused kernel
     assert pol.kernel_layout() is None
     n, T = 512, 60
     algo = TRPO(env=env, policy=pol, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=n * T,
