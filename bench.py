@@ -43,20 +43,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (env module, env class, horizon T, hidden, algo, gae_lambda, algorithmic bytes / env-step, flops / env-step)
+    # name: (env module, env class, horizon T, hidden, algo, gae_lambda, algorithmic bytes / env-step)
     "swimmer4096_trpo": dict(env="swimmer", n_envs=4096, T=500, hidden=(32, 32), algo="trpo", lam=1.0,
-                             step_bytes=145, record_bytes=72,
-                             # 50 sub-steps x ~0.55 kflop articulated-body pass + 3008 flop policy (8d)
-                             flops_per_step=50 * 550 + 3008),
+                             step_bytes=145, record_bytes=72),
     "cartpole4096_vpg": dict(env="cartpole", n_envs=4096, T=100, hidden=(32, 32), algo="vpg", lam=1.0,
-                             step_bytes=153, record_bytes=28, flops_per_step=3000 + 2368),
+                             step_bytes=153, record_bytes=28),
     # parity-config side lines (not the headline): DoublePendulum, and BASELINE config C5's per-GPU shard
     # (8192 envs / 8 GPUs = 1024 envs per GPU, GaussianMLPPolicy(64,64), TRPO + GAE lambda 0.97)
     "double_pendulum4096_trpo": dict(env="double_pendulum", n_envs=4096, T=100, hidden=(32, 32), algo="trpo",
-                                     lam=1.0, step_bytes=4 * (2 * 17 + 1 + 6 + 1) + 1, record_bytes=36,
-                                     flops_per_step=2 * 2500 + 2496),
+                                     lam=1.0, step_bytes=4 * (2 * 17 + 1 + 6 + 1) + 1, record_bytes=36),
     "cheetah1024_trpo_gae": dict(env="half_cheetah", n_envs=1024, T=500, hidden=(64, 64), algo="trpo", lam=0.97,
-                                 step_bytes=253, record_bytes=132, flops_per_step=4 * 6000 + 11520),
+                                 step_bytes=253, record_bytes=132),
 }
 ENVS = {  # name -> (module, class, rl_env_kind)
     "cartpole": ("rllab_amd.envs.box2d.cartpole_env", "CartpoleEnv", 0),
@@ -293,12 +290,15 @@ def main():
     # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc summary of this command
     # (profiles/run_profile.sh; separate FETCH_SIZE / WRITE_SIZE passes), bytes per launch
     traffic, traffic_src = None, None
+    compute_axis = None      # the rollout's vector-instruction counters, same stamped file
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not args.hidden:
         rec = json.load(open(tpath)).get(args.workload)
         if rec and rec.get("n_envs") == n_envs:
             if rec.get("kernel_source_hash") == kernel_source_hash():
                 traffic, traffic_src = rec["rollout_bytes_per_launch"], rec["source"]
+                if rec.get("rollout_insts_valu"):
+                    compute_axis = rec
             else:
                 traffic_src = ("stale: profiles/pmc_traffic.json was taken from kernel sources %s, this build is %s "
                                "(re-run profiles/run_profile.sh)" % (rec.get("kernel_source_hash"), kernel_source_hash()))
@@ -370,8 +370,7 @@ def main():
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_rollout_s * 1e3,
-                     "valu_tflops": wl["flops_per_step"] * n_envs * T / avg_rollout_s / 1e12,
-                     "valu_peak_tflops": 157.3, "wavefronts": n_waves, "simds": 1024,
+                     "wavefronts": n_waves, "simds": 1024,
                      "envs_per_wavefront": envs_per_wave,
                      "note": "issue-bound, not HBM-bound: %d envs per wavefront => %d wavefronts on 1024 SIMDs, each "
                              "a single instruction stream (physics sub-steps fused in registers); a lone wavefront "
@@ -380,6 +379,23 @@ def main():
                              "time = issue slots per wavefront x 4 cycles x T and the HBM fraction is small by "
                              "construction (SURVEY.md 8d, DESIGN.md 3.1)" % (envs_per_wave, n_waves)},
     }
+    if compute_axis is not None:
+        # the compute axis from the kernel's own counters (profiles/pmc_traffic.json, stamped with the kernel-source
+        # hash): vector instructions x 64 lanes / launch time against the vector peak in the same unit (157.3 TFLOP/s
+        # counts a fused multiply-add as two: 78.65 T lane-instructions/s), and the floor of this design -- a lone
+        # wavefront pays 4 cycles per issued vector instruction -- at the clock the launch ran at
+        insts, waves_c = compute_axis["rollout_insts_valu"], compute_axis["rollout_waves"]
+        clock_hz = compute_axis["rollout_gui_active"] / 8.0 / avg_rollout_s
+        per_wave_step = insts / waves_c / T
+        out["roofline"].update({
+            "valu_tflops": insts * 64.0 / avg_rollout_s / 1e12, "valu_peak_tflops": 157.3 / 2.0,
+            "valu_unit": "T lane-instructions/s (SQ_INSTS_VALU x 64 / launch time; an FMA counts once)",
+            "valu_insts_per_wavefront_and_env_step": per_wave_step,
+            "clock_ghz": clock_hz / 1e9,
+            "issue_slot_floor_ms": per_wave_step * 4.0 * T / clock_hz * 1e3,
+            "valu_issue_frac": compute_axis["rollout_active_inst_valu"] / compute_axis["rollout_wave_cycles"],
+            "compute_source": compute_axis["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_WAVES / "
+                                                             "GRBM_GUI_ACTIVE")})
     if fvp_ms is not None:
         tiles = (n_envs * T + 31) // 32
         tf = tiles * mfma_per_tile * 4096 / (fvp_ms * 1e-3) / 1e12

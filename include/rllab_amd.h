@@ -382,6 +382,33 @@ int rl_line_search_point(int n, const float* prev, const double* step, double ra
 int rl_adam_step(int n, float* theta, const double* grad, double* m, double* v, double a_t, double beta1,
                  double beta2, double epsilon, void* stream);
 
+/* ---- one-shot peer all-reduce (one node, <= 8 GPUs, one process per GPU) ------------------------------------
+ * The sharded update's only exchange is a sum over ranks of small float64 vectors -- the flat gradient and each
+ * Fisher-vector product of CG (the reference is single-process, its counterpart is the sum
+ * inside f_grad / f_Hx_plain, rllab/optimizers/conjugate_gradient_optimizer.py:194-215,27-46).  Instead of a
+ * host-issued collective per vector, every rank writes its row into every peer's MAILBOX over xGMI, raises a flag,
+ * waits for the world's flags in its own mailbox and sums the rows in rank order: one launch on the update's
+ * stream, bit-identical on all ranks, no host call between the product and the CG algebra.
+ *   rl_peer_mailbox_bytes  size of one rank's mailbox for vectors of up to max_n doubles (0: bad arguments)
+ *   rl_peer_alloc / free   device memory that can be exported (fine-grained, zero-filled; the ONE place the library
+ *                          allocates: IPC needs an allocation of its own, not a slice of a caching allocator's)
+ *   rl_peer_export         64-byte IPC handle of a mailbox (host buffer out) -- ship it to the peers with any host
+ *                          channel (torch.distributed.all_gather_object at start-up)
+ *   rl_peer_open / close   map a peer's mailbox from its handle
+ *   rl_peer_allreduce_sum  data[0..n) <- sum over ranks, in rank order.  mailboxes: HOST array of `world` device
+ *                          pointers (entry `rank` = own mailbox, the others = rl_peer_open results); seq = 1, 2, 3 ...
+ *                          the same on every rank for the same reduction; err_dev: one device int, zero before the
+ *                          first call, set non-zero (1 + missing rank) if a peer's row did not arrive in time.
+ * Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) in the environment of every rank. */
+size_t rl_peer_mailbox_bytes(int world, int max_n);
+int rl_peer_alloc(size_t bytes, void** dev_ptr_out);
+int rl_peer_free(void* dev_ptr);
+int rl_peer_export(void* dev_ptr, void* handle_out64_host);
+int rl_peer_open(const void* handle64_host, void** dev_ptr_out);
+int rl_peer_close(void* dev_ptr);
+int rl_peer_allreduce_sum(int n, double* data, int rank, int world, void* const* mailboxes_host, int max_n,
+                          uint64_t seq, int* err_dev, void* stream);
+
 /* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
  * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */
 int rl_debug_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

@@ -2,7 +2,7 @@
 # Profile recipe (run on the GPU box through gpurun):  profiles/run_profile.sh <tag>
 #   kernel-trace/stats pass and SEPARATE --pmc passes of the same bench command, condensed
 #   into gpurun_out/<tag>_*.csv by profiles/summarize.py (raw traces are too large to keep).
-TAG=${1:-r02}
+TAG=${1:-r03}
 set -x
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
 python profiles/summarize.py pmc $P/sq gpurun_out/${TAG}_pmc_sq.csv
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $P/sq2 -- $BENCH2 > /dev/null 2>&1
 python profiles/summarize.py pmc $P/sq2 gpurun_out/${TAG}_pmc_sq2.csv
-python profiles/summarize.py traffic gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/pmc_traffic.json swimmer4096_trpo 4096 ${TAG}
+python profiles/summarize.py traffic gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/pmc_traffic.json swimmer4096_trpo 4096 ${TAG} gpurun_out/${TAG}_pmc_sq.csv
 head -6 gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv
 # the per-step VecEnv boundary kernel at a chip-filling size: the kernel the HBM roofline applies to
 python tools/step_kernel_roofline.py 2>&1 | grep "^{" > gpurun_out/${TAG}_step_kernel_roofline.jsonl

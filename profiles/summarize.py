@@ -73,7 +73,7 @@ def pmc(d, out):
             w.writerow([short(k), n] + ["%.6g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k][c] else "" for c in counters])
 
 
-def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=4096, tag=""):
+def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=4096, tag="", sq_csv=None):
     """HBM bytes per launch of the rollout kernel from the FETCH_SIZE / WRITE_SIZE summaries (KB).
     Reads are 4 B/lane plane loads (not the 16 B/lane streams MI355X_MICROARCH.md's x2 correction
     was calibrated on) and are < 1 % of the total here, so they are taken as reported."""
@@ -93,6 +93,17 @@ def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=
     rec[workload] = dict(n_envs=int(n_envs), rollout_bytes_per_launch=rd + wr, fetch_bytes=rd, write_bytes=wr,
                          kernel_source_hash=bench.kernel_source_hash(),
                          source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (%s)" % tag)
+    if sq_csv:
+        # the compute axis of the same kernel from its own counters (SQ pass): vector instructions issued, wavefronts,
+        # and GRBM_GUI_ACTIVE (summed over the 8 XCDs) for the clock the launch actually ran at
+        for r in csv.DictReader(open(sq_csv)):
+            if "rollout_" in r["kernel"]:
+                rec[workload].update(rollout_insts_valu=float(r["mean_SQ_INSTS_VALU"]),
+                                     rollout_waves=float(r["mean_SQ_WAVES"]),
+                                     rollout_gui_active=float(r["mean_GRBM_GUI_ACTIVE"]),
+                                     rollout_active_inst_valu=float(r["mean_SQ_ACTIVE_INST_VALU"]),
+                                     rollout_wave_cycles=float(r["mean_SQ_WAVE_CYCLES"]))
+                break
     json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
 
 

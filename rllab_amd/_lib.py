@@ -31,6 +31,8 @@ SYMBOLS = [
     "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
     "rl_lfb_normal_eq",
+    "rl_peer_mailbox_bytes", "rl_peer_alloc", "rl_peer_free", "rl_peer_export", "rl_peer_open", "rl_peer_close",
+    "rl_peer_allreduce_sum",
 ]
 
 
@@ -127,6 +129,15 @@ def _load():
     lib.rl_sample_stats.argtypes = [sz, vp, vp, vp, vp, vp, vp, f64, f64, vp, i32, vp, sz, vp, vp]
     lib.rl_adv_finish.argtypes = [sz, vp, vp, f64, f64, f64, vp, vp]
     lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, vp]
+    vpp = ctypes.POINTER(ctypes.c_void_p)
+    lib.rl_peer_mailbox_bytes.restype = sz
+    lib.rl_peer_mailbox_bytes.argtypes = [i32, i32]
+    lib.rl_peer_alloc.argtypes = [sz, vpp]
+    lib.rl_peer_free.argtypes = [vp]
+    lib.rl_peer_export.argtypes = [vp, vp]
+    lib.rl_peer_open.argtypes = [vp, vpp]
+    lib.rl_peer_close.argtypes = [vp]
+    lib.rl_peer_allreduce_sum.argtypes = [i32, vp, i32, i32, vpp, i32, u64, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = header / library mismatch
     return lib

@@ -100,15 +100,16 @@ struct WideLds {
 __host__ __device__ inline WideLds wide_lds(const WideShape& s, int mode) {
     WideLds p;
     int o = 0;
-    p.X = o; o += 32 * BS;
+    p.X = o; o += 2 * s.KS[0] * BS;              // input slots (obs, the bias slot, zero slots up to the k-step count)
     for (int l = 0; l < WIDE_MAX_L; ++l) { p.Hb[l] = o; o += s.H[l] * BS; }
     for (int l = 0; l < WIDE_MAX_L; ++l) { p.Db[l] = o; o += (mode != WMODE_LOSS) ? s.H[l] * BS : 0; }
     o = (o + 3) & ~3;
     p.tail = o; o += s.tail;
     p.dtail = o; o += (mode == WMODE_FVP) ? s.tail : 0;
-    p.part = o; o += WW * MAXDA * 32;            // per-wavefront partial dot products of the output layer
-    p.gmu = o; o += MAXDA * 32;                  // gmu[k][sample] for the thread-per-unit accumulation
-    p.red = o; o += 256 + 64;                    // small cross-thread folds at the end of the launch
+    p.part = o;                                   // per-wavefront partial dot products of the output layer [WW][DA][32]
+    p.red = o;                                    // ... whose space serves the cross-thread folds at the end of the launch
+    o += (WW * s.DA * 32 > 256 + 64) ? WW * s.DA * 32 : 256 + 64;
+    p.gmu = o; o += s.DA * 32;                    // gmu[k][sample] for the thread-per-unit accumulation
     p.total = o;
     return p;
 }
@@ -145,8 +146,18 @@ __device__ __forceinline__ void wide_put(float* bt, int t, int lane, const f32x1
     for (int r = 0; r < 16; ++r) bt[(32 * t + frag_unit(r, 0) + 4 * lh) * BS + lj] = v[r];
 }
 
+// Workgroups per CU the register budget is declared for.  Two (two wavefronts per SIMD, 256 registers each): one
+// workgroup's waits -- operand loads from L2, barriers -- are the other's matrix time (measured on (13 -> 128 -> 128 -> 2):
+// matrix pipe busy 40 % with one workgroup per CU, waits 39 %).  The three-layer gradient-like passes carry two sets of
+// outer-product accumulators (144 persistent registers) and keep one workgroup per CU with 512 registers.
+#ifndef RL_WIDE_WPS_L2
+#define RL_WIDE_WPS_L2 2
+#endif
 template <int L, int MODE>
-__global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
+constexpr int wide_wps() { return (L == 2 || MODE == WMODE_LOSS) ? RL_WIDE_WPS_L2 : 1; }
+
+template <int L, int MODE>
+__global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(WideBatch a) {
     constexpr bool FVP = (MODE == WMODE_FVP), GRADLIKE = (MODE != WMODE_LOSS);
     const WideShape& s = a.s;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -291,7 +302,7 @@ __global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
             for (int k = 0; k < MAXDA; ++k)
                 if (k < DA) {
                     const float v = half_sum(pm[k]);
-                    if (lh == 0) part[(wave * MAXDA + k) * 32 + lj] = v;
+                    if (lh == 0) part[(wave * DA + k) * 32 + lj] = v;
                 }
         }
         __syncthreads();
@@ -305,8 +316,8 @@ __global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
             float mean[MAXDA];
 #pragma unroll
             for (int k = 0; k < MAXDA; ++k)
-                mean[k] = k < DA ? tail[s.tbo + k] + ((part[(0 * MAXDA + k) * 32 + lj] + part[(1 * MAXDA + k) * 32 + lj]) +
-                                                      (part[(2 * MAXDA + k) * 32 + lj] + part[(3 * MAXDA + k) * 32 + lj]))
+                mean[k] = k < DA ? tail[s.tbo + k] + ((part[(0 * DA + k) * 32 + lj] + part[(1 * DA + k) * 32 + lj]) +
+                                                      (part[(2 * DA + k) * 32 + lj] + part[(3 * DA + k) * 32 + lj]))
                                  : 0.0f;
             const float advb = a.adv[bi];
             float zz_new = 0.0f, zz_old = 0.0f, sls_new = 0.0f, sls_old = 0.0f, kl = 0.0f;
@@ -371,8 +382,8 @@ __global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
 #pragma unroll
             for (int k = 0; k < MAXDA; ++k)
                 if (k < DA) {
-                    const float dmu = dtail[s.tbo + k] + ((part[(0 * MAXDA + k) * 32 + lj] + part[(1 * MAXDA + k) * 32 + lj]) +
-                                                          (part[(2 * MAXDA + k) * 32 + lj] + part[(3 * MAXDA + k) * 32 + lj]));
+                    const float dmu = dtail[s.tbo + k] + ((part[(0 * DA + k) * 32 + lj] + part[(1 * DA + k) * 32 + lj]) +
+                                                          (part[(2 * DA + k) * 32 + lj] + part[(3 * DA + k) * 32 + lj]));
                     gmu[k] = c * dmu * (2.0f / (2.0f * var_[k] + 1e-8f));
                 }
             if (keeper) wsum += c;
@@ -459,7 +470,9 @@ __global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
             }
         }
         if (wave < s.HT[0]) {
-            const float* ap = X + lj * BS + lh;                        // rows = input slots (slot DO = 1: the bias row)
+            // rows = input slots (slot DO = 1: the bias row); the tile holds 2 KS0 of them, lanes beyond read row 0
+            // (finite; their output rows are never stored)
+            const float* ap = X + (lj < 2 * s.KS[0] ? lj : 0) * BS + lh;
             const float* bp = smem + p.Db[0] + (32 * wave + lj) * BS + lh;
 #pragma unroll
             for (int m = 0; m < 16; ++m) gW0 = mfma(ap[2 * m], bp[2 * m], gW0);
@@ -555,7 +568,7 @@ __global__ void __launch_bounds__(WNT, 1) wide_pass_kernel(WideBatch a) {
     if ((MODE == WMODE_GRAD || MODE == WMODE_VPG) && a.partial_loss != nullptr) fold_loss();
 }
 
-constexpr int WIDE_GRID = 256;         // one workgroup per CU
+constexpr int WIDE_GRID = 512;         // up to two workgroups per CU (wide_wps)
 
 size_t wide_workspace_bytes(const WideShape& s) {
     const size_t rows = ((size_t)WIDE_GRID * s.P * sizeof(float) + 15) & ~(size_t)15;
@@ -582,7 +595,13 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std; a.kl_penalty = g->kl_penalty;
     const int n_tiles = (a.B + 31) / 32;
-    const int grid = n_tiles < WIDE_GRID ? n_tiles : WIDE_GRID;
+    const WideLds p = wide_lds(s, MODE);
+    const size_t lds = (size_t)p.total * sizeof(float);
+    if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "wide policy pass needs %zu B of LDS", lds);
+    int per_cu = wide_wps<L, MODE>();
+    if ((size_t)per_cu * lds > 160 * 1024) per_cu = 1;
+    const int max_grid = 256 * per_cu;
+    const int grid = n_tiles < max_grid ? n_tiles : max_grid;
     const size_t rows = ((size_t)WIDE_GRID * s.P * sizeof(float) + 15) & ~(size_t)15;
     const bool with_loss = (MODE == WMODE_GRAD || MODE == WMODE_VPG) && loss_out != nullptr;
     a.partial = (float*)workspace;
@@ -600,9 +619,6 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
                            dim3(256), 0, st, s, vec, dimg, 0);
     int rc = check_launch("wide_stage_kernel");
     if (rc) return rc;
-    const WideLds p = wide_lds(s, MODE);
-    const size_t lds = (size_t)p.total * sizeof(float);
-    if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "wide policy pass needs %zu B of LDS", lds);
     auto kern = wide_pass_kernel<L, MODE>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

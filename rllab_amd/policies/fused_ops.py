@@ -199,7 +199,7 @@ class FusedGaussianMLPOps(object):
                 self._acts_tag = tag
         finally:
             b.activations = None
-        return D.all_reduce_sum_(self.layout.unpack(out))
+        return self.layout.unpack(D.update_sum_(out))
 
     def value_and_grad(self, inputs, penalty=0.0):
         """float64 (value, flat gradient over the trainable parameters) of  surrogate loss + penalty * mean KL  in ONE
@@ -233,7 +233,7 @@ class FusedGaussianMLPOps(object):
                                               _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
         finally:
             b.activations = None
-        return D.all_reduce_sum_(out)
+        return D.update_sum_(out)
 
     def fvp(self, inputs, vec):
         b, keep, _ = self._batch(inputs)

@@ -19,11 +19,11 @@ _FORCE = bool(os.environ.get("RLLAB_DIST_FORCE"))
 # Collective accounting (bench.py's "collectives_per_iter" / "collective_ms_per_iter").  Counting is
 # free; timing brackets every collective with a device synchronise on both sides, so it is only ever
 # switched on for a few extra iterations AFTER the timed region.
-_acct = dict(count=0, seconds=0.0, timing=False, bytes=0)
+_acct = dict(count=0, seconds=0.0, timing=False, bytes=0, peer=0)
 
 
 def reset_accounting(timing=False):
-    _acct.update(count=0, seconds=0.0, timing=bool(timing), bytes=0)
+    _acct.update(count=0, seconds=0.0, timing=bool(timing), bytes=0, peer=0)
 
 
 def accounting():
@@ -88,6 +88,103 @@ def _all_reduce(t, op):
 def all_reduce_sum_(t):
     """In-place sum all-reduce (no-op on a single process).  Returns ``t``."""
     return _all_reduce(t, dist.ReduceOp.SUM)
+
+
+# -- one-shot peer all-reduce inside the update's launch train (csrc/peer_kernels.hip) ---------------------------------
+# The sums on CG's critical path -- the flat gradient and each Fisher-vector product, float64 vectors of P doubles --
+# need not return to the host: every rank writes its row into every peer's mailbox (hipIpc-mapped device memory, xGMI
+# on a multi-GPU node), raises a flag and sums the world's rows in rank order, one small launch on the update's stream.
+# Opt-in (RLLAB_PEER_ALLREDUCE=1) until an 8-GPU run has confirmed it against RCCL; everything else (statistics,
+# normal equations, loss sums) stays a torch.distributed collective.
+_peer = None
+
+
+class PeerReducer(object):
+    """Mailboxes of the world, exchanged once at start-up (host side, torch.distributed.all_gather_object)."""
+
+    def __init__(self, max_n=1 << 16):
+        import ctypes
+        from rllab_amd import _lib
+        self._lib, self._ct = _lib, ctypes
+        self.rank, self.world, self.max_n = dist.get_rank(), dist.get_world_size(), int(max_n)
+        if self.world > 8:
+            raise RuntimeError("peer all-reduce: one node, at most 8 ranks (got %d)" % self.world)
+        nbytes = _lib.lib.rl_peer_mailbox_bytes(self.world, self.max_n)
+        own = ctypes.c_void_p()
+        _lib.check(_lib.lib.rl_peer_alloc(nbytes, ctypes.byref(own)), "rl_peer_alloc")
+        self._own = own
+        handle = (ctypes.c_char * 64)()
+        _lib.check(_lib.lib.rl_peer_export(own, handle), "rl_peer_export")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw))
+        self._table = (ctypes.c_void_p * self.world)()
+        self._opened = []
+        for r in range(self.world):
+            if r == self.rank:
+                self._table[r] = own.value
+            else:
+                p = ctypes.c_void_p()
+                buf = ctypes.create_string_buffer(handles[r], 64)
+                _lib.check(_lib.lib.rl_peer_open(buf, ctypes.byref(p)), "rl_peer_open")
+                self._table[r] = p.value
+                self._opened.append(p)
+        self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.seq = 0
+        self.count = 0
+        dist.barrier()                      # nobody writes into a mailbox that is not mapped everywhere yet
+
+    def all_reduce_sum_(self, t):
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= self.max_n
+        self.seq += 1
+        self.count += 1
+        lib = self._lib
+        lib.check(lib.lib.rl_peer_allreduce_sum(t.numel(), lib.ptr(t), self.rank, self.world, self._table, self.max_n,
+                                                self.seq, lib.ptr(self.err), lib.stream_ptr()), "rl_peer_allreduce_sum")
+        return t
+
+    def check(self):
+        """Blocking: raises if any reduction so far gave up waiting for a peer."""
+        e = int(self.err.item())
+        if e:
+            raise RuntimeError("peer all-reduce: rank %d never delivered a row (reduction <= %d)" % (e - 1, self.seq))
+
+    def close(self):
+        torch.cuda.synchronize()
+        dist.barrier()
+        for p in self._opened:
+            self._lib.lib.rl_peer_close(p)
+        self._opened = []
+        if self._own is not None:
+            self._lib.lib.rl_peer_free(self._own)
+            self._own = None
+
+
+def peer_reducer():
+    """The process's PeerReducer when RLLAB_PEER_ALLREDUCE=1 and the run is distributed, else None (created on first
+    use: every rank reaches its first sharded gradient at the same point of the same program)."""
+    global _peer
+    if _peer is None and os.environ.get("RLLAB_PEER_ALLREDUCE") and is_distributed() and torch.cuda.is_available():
+        _peer = PeerReducer()
+    return _peer
+
+
+def peer_shutdown():
+    global _peer
+    if _peer is not None:
+        _peer.close()
+        _peer = None
+
+
+def update_sum_(t):
+    """Sum over ranks of a float64 device vector on the update's critical path (gradient, Fisher-vector product):
+    the in-stream peer all-reduce when enabled, the backend's all-reduce otherwise."""
+    if not is_distributed():
+        return t
+    pr = peer_reducer()
+    if pr is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= pr.max_n:
+        _acct["peer"] += 1                  # in-stream reductions are not host-issued collectives: counted apart
+        return pr.all_reduce_sum_(t)
+    return all_reduce_sum_(t)
 
 
 def all_reduce_min_(t):

@@ -53,6 +53,10 @@ def test_env_query_and_errors():
     assert _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 64, 32) > _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 64, 0) > 0
     assert _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 96, 0) == 0 and _lib.lib.rl_policy_workspace_bytes(13, 2, 256, 32, 0) == 0
     assert _lib.lib.rl_policy_activation_bytes(1000, 128, 128) == 0
+    # peer all-reduce: argument errors without touching a device
+    assert _lib.lib.rl_peer_mailbox_bytes(8, 1572) == 128 + 2 * 8 * 1572 * 8 and _lib.lib.rl_peer_mailbox_bytes(9, 4) == 0
+    assert _lib.lib.rl_peer_allreduce_sum(0, None, 0, 1, None, 4, 1, None, None) == -1
+    assert _lib.lib.rl_peer_export(None, None) == -1 and _lib.lib.rl_peer_open(None, None) == -1
 
 
 def test_env_default_cfg():

@@ -142,3 +142,69 @@ def _initial_theta(env_name):
     ext.set_seed(3)
     env = normalize(SwimmerEnv() if env_name == "swimmer" else CartpoleEnv())
     return GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32)).get_param_values()
+
+
+def _peer_worker(rank, world, port, outdir, peer):
+    """One TRPO iteration with the default optimizer settings (cg_iters 10): parameters + what crossed ranks how."""
+    torch.cuda.set_device(0)
+    if peer:
+        os.environ["RLLAB_PEER_ALLREDUCE"] = "1"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from rllab_amd.algos.trpo import TRPO
+    from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.misc import ext, logger
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.sampler import dist as D
+    ext.set_seed(3)
+    logger.set_quiet(True)
+    env = normalize(SwimmerEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    D.broadcast_(policy.flat_params)
+    T, n = 40, 64
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=n * T,
+                max_path_length=T, n_itr=3, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=n, seed=17))
+    algo.start_worker()
+    algo.init_opt()
+    counts = []
+    for itr in range(3):
+        D.reset_accounting()
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.optimize_policy(itr, sd)
+        acct = D.accounting()
+        counts.append([acct["count"], acct["peer"]])
+        logger.dump_tabular()
+    torch.cuda.synchronize()
+    if peer:
+        assert D.peer_reducer() is not None and D.peer_reducer().count == sum(c[1] for c in counts)
+        D.peer_reducer().check()                    # no reduction gave up waiting for its peer
+    tag = "peer" if peer else "host"
+    np.save(os.path.join(outdir, "theta_%s_%d.npy" % (tag, rank)), policy.get_param_values())
+    np.save(os.path.join(outdir, "counts_%s_%d.npy" % (tag, rank)), np.array(counts))
+    D.peer_shutdown()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_the_in_stream_peer_allreduce(tmp_path):
+    """RLLAB_PEER_ALLREDUCE=1: the gradient and the ten Fisher-vector products of a TRPO update are summed across ranks
+    by rl_peer_allreduce_sum -- every rank writes its row into the peer's hipIpc-mapped mailbox, flags it and sums in
+    rank order, on the update's stream -- instead of eleven host-issued collectives.  Two processes share the one
+    GPU of the box (the mailboxes are then plain device memory; on a node they are peer memory over xGMI).  The
+    parameters after three iterations are BIT-IDENTICAL on both ranks and to the run that reduces through the host
+    backend, and at most six collectives per iteration are left to torch.distributed."""
+    world = 2
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path), False), nprocs=world, join=True)
+    tp = [np.load(str(tmp_path / ("theta_peer_%d.npy" % r))) for r in range(world)]
+    th = [np.load(str(tmp_path / ("theta_host_%d.npy" % r))) for r in range(world)]
+    assert np.array_equal(tp[0], tp[1]) and np.array_equal(th[0], th[1])
+    assert np.array_equal(tp[0], th[0])             # rank-order sum of two rows == the backend's a + b, bit for bit
+    cp = np.load(str(tmp_path / "counts_peer_0.npy"))
+    ch = np.load(str(tmp_path / "counts_host_0.npy"))
+    assert np.all(cp[:, 1] == 11) and np.all(ch[:, 1] == 0)          # gradient + cg_iters products, every iteration
+    assert np.all(cp[:, 0] <= 6), cp                                   # statistics, normal equations, 1-3 loss reads ...
+    assert np.all(ch[:, 0] == cp[:, 0] + 11), (ch, cp)

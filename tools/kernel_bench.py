@@ -38,10 +38,12 @@ def main():
     from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
     from rllab_amd.spaces import Box
     for cfg in args.configs.split(";"):
-        do, da, h, B = (int(x) for x in cfg.split(","))
+        do, da, h, B = cfg.split(",")
+        do, da, B = int(do), int(da), int(B)
+        hidden = tuple(int(x) for x in h.split("-")) if "-" in h else (int(h), int(h))   # "100-50-25": wide / deep nets
         np.random.seed(0)
         spec = EnvSpec(Box(-np.ones(do), np.ones(do)), Box(-np.ones(da), np.ones(da)))
-        pol = GaussianMLPPolicy(spec, hidden_sizes=(h, h))
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hidden)
         ops = pol.fused_ops()
         dev = pol.flat_params.device
         g = torch.Generator(device=dev).manual_seed(0)
@@ -54,12 +56,13 @@ def main():
         w = torch.ones(B, device=dev)
         inp = (obs, act, adv, mean, ls.reshape(-1, 1), w, 1.0 / B)
         v = torch.randn(pol.flat_params.numel(), device=dev, dtype=torch.float64, generator=g)
-        fwd_flops = 2 * (do * h + h * h + h * da)
+        sizes = (do,) + hidden + (da,)
+        fwd_flops = 2 * sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
         for name, fn, mult in (("loss_kl", lambda: (pol.note_raw_write(), ops.loss_stats(inp)), 1.0),
                                ("grad", lambda: ops.loss_grad(inp), 3.0),
                                ("fvp", lambda: ops.fvp(inp, v), 6.0)):
             ms = timeit(fn)
-            print(json.dumps(dict(kernel=name, net=[do, da, h], samples=B, ms=round(ms, 4),
+            print(json.dumps(dict(kernel=name, net=[do, da, list(hidden)], samples=B, ms=round(ms, 4),
                                   tflops=round(mult * fwd_flops * B / ms / 1e9, 2),
                                   gbps=round(4 * (do + 3 * da + 1) * B / ms / 1e6, 1))))
 
