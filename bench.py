@@ -28,6 +28,8 @@ Extra objects on the JSON line:
                   oracle/make_ref.py, driven by oracle/ref_sampler.py) on all host cores and
                   on one, timed on a bounded sample in the same run (rank 0, N == 1 only); the
                   re-typed port (oracle/cpu_sampler.py) rides along as a cross-check.
+  peer_reductions_per_iter -- with RLLAB_PEER_ALLREDUCE=1: sums of the gradient / Fisher-vector products done by the
+                  in-stream peer all-reduce (csrc/peer_kernels.hip) instead of host-issued collectives.
   ranks / backend / collectives_per_iter / collective_ms_per_iter -- what torch.distributed
                   actually saw (N > 1), the collectives one iteration issues and their
                   host-bracketed cost measured on extra iterations after the timed region.
@@ -260,6 +262,7 @@ def main():
     elapsed = time.perf_counter() - t0
     acct = D.accounting()
     collectives_per_iter = acct["count"] / float(args.steps)
+    peer_reductions_per_iter = acct.get("peer", 0) / float(args.steps)   # in-stream rl_peer_allreduce_sum launches
     collective_bytes_per_iter = acct["bytes"] / float(args.steps)
     collective_ms_per_iter = None
     if D.is_distributed():
@@ -361,6 +364,7 @@ def main():
         "backend": ("%s (RCCL)" % D.backend() if D.backend() == "nccl" else D.backend()) if dist.is_initialized()
         else None,
         "collectives_per_iter": collectives_per_iter, "collective_bytes_per_iter": collective_bytes_per_iter,
+        "peer_reductions_per_iter": peer_reductions_per_iter,
         "collective_ms_per_iter": collective_ms_per_iter,
         "trpo_iter_ms": elapsed / args.steps * 1e3,
         "phase_ms": {k: v / args.steps for k, v in phase_ms.items()},
@@ -486,6 +490,10 @@ def main():
                         "the sampling time at the reference sampler's measured rate"}
     dist_on = dist.is_initialized()
     if dist_on:
+        pr = D.peer_reducer()
+        if pr is not None:
+            pr.check()                      # no in-stream reduction gave up waiting for a peer
+            D.peer_shutdown()
         # RCCL leaves a banner (its version, the HIP version, hostname, library path) in the C stdio buffer of every
         # rank; flushed at exit it would follow the JSON line.  Every rank pushes it out BEFORE the last barrier, rank 0
         # prints the line after it, and all leave without the exit-time flushes: the one JSON line is the last line

@@ -40,6 +40,11 @@ def test_bench_iteration_over_rccl_single_rank():
     assert forced["collective_bytes_per_iter"] < 1 << 20
     assert forced["collective_ms_per_iter"] is not None and 0 < forced["collective_ms_per_iter"] < 50
     assert forced["value"] > 0 and forced["config"]["n_envs_per_gpu"] == 512
+    # the same with the in-stream peer all-reduce: the eleven sums on CG's critical path leave the host
+    peer = _bench({"RLLAB_DIST_FORCE": "1", "RLLAB_PEER_ALLREDUCE": "1"})
+    assert peer["peer_reductions_per_iter"] == 11 and forced["peer_reductions_per_iter"] == 0
+    assert abs(peer["collectives_per_iter"] - (forced["collectives_per_iter"] - 11)) < 1e-9
+    assert peer["collectives_per_iter"] <= 6
 
 
 def test_bench_self_launches_its_ranks():
