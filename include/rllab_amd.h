@@ -336,6 +336,43 @@ int rl_policy_grad_loss(const rl_policy_batch* batch, int vpg, void* workspace, 
 int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspace,
                   size_t workspace_bytes, double* fvp_out, void* stream);
 
+/* ---- policies whose log-std is a NETWORK (GaussianMLPPolicy(adaptive_std=True) / std_network=...,
+ * rllab/policies/gaussian_mlp_policy.py:60-98; the reference's regression test tests/regression_tests/test_issue_3.py).
+ * Mean and log-std networks run as plain functions on planes, the Gaussian head sits between them:
+ *   loss / KL        rl_mlp_forward (mean net), rl_mlp_forward (std net), rl_gaussian_head(g = NULL)
+ *   gradient         ... rl_gaussian_head(g_mean, g_log_std), rl_mlp_backward x 2; flat gradient = [mean net | std net]
+ *   Fisher x vector  rl_mlp_forward with `vec` x 2 (tangents), rl_gaussian_fisher, rl_mlp_backward x 2
+ * rl_policy_batch carries the network: n_samples, obs_dim, act_dim, hidden0/1 (two equal tanh layers of 32 or 64,
+ * hidden2 = 0), theta = [W0,b0,W1,b1,Wout,bout | act_dim unused floats] (the policy layout with its log_std row
+ * ignored), obs, weights; the other fields are not read. */
+
+/* out[act_dim][B] = network(obs); with vec (same layout as theta) also dout = d/d eps network_{theta + eps vec}(obs). */
+int rl_mlp_forward(const rl_policy_batch* batch, const float* vec, float* out, float* dout, void* stream);
+
+/* grad_out (device, P doubles; the trailing act_dim entries are zero) = d/dtheta sum_b sum_k cotangent[k][b] out_k(b).
+ * workspace: rl_policy_workspace_bytes. */
+int rl_mlp_backward(const rl_policy_batch* batch, const float* cotangent, void* workspace, size_t workspace_bytes,
+                    double* grad_out, void* stream);
+
+/* The diagonal-Gaussian head on planes [act_dim][B] (rllab/distributions/diagonal_gaussian.py:14-69,
+ * rllab/algos/npo.py:72-82, rllab/algos/vpg.py:91): out4 as rl_policy_loss_kl; when g_mean / g_log_std are given,
+ * the cotangents of (-sum_b w {lr | logp} adv + kl_penalty sum_b w KL) * inv_count on the mean / log-std planes
+ * (vpg != 0: logp instead of lr).  log_std is the raw network output, floored at log_min_std here (the floor's
+ * zero derivative included).  workspace: rl_gaussian_head_workspace_bytes(). */
+size_t rl_gaussian_head_workspace_bytes(void);
+int rl_gaussian_head(size_t n_samples, int act_dim, const float* mean, const float* log_std, const float* actions,
+                     const float* advantages, const float* old_means, const float* old_log_stds,
+                     const float* weights, float inv_count, float log_min_std, int vpg, float kl_penalty,
+                     float* g_mean, float* g_log_std, void* workspace, size_t workspace_bytes, double* out4,
+                     void* stream);
+
+/* The Fisher metric of the mean KL at old == new, applied to output tangents (it is diagonal in (mean, log_std)):
+ *   g_mean = w inv_count dmean 2 / (2 v + 1e-8),   g_log_std = w inv_count dlog_std 4 v (2 v - e) / (2 v + e)^2,
+ * v = exp(2 max(log_std, log_min_std)), e = 1e-8; g_log_std = 0 where the floor is active. */
+int rl_gaussian_fisher(size_t n_samples, int act_dim, const float* dmean, const float* dlog_std, const float* log_std,
+                       const float* weights, float inv_count, float log_min_std, float* g_mean, float* g_log_std,
+                       void* stream);
+
 /* Vector algebra of krylov.cg (rllab/misc/krylov.py:7-39) for the TRPO descent direction
  * (conjugate_gradient_optimizer.py:253-256), one launch per iteration, float64 like the reference.
  *   rl_cg_init : x = 0, r = p = b, p32 = (float)p, scal = {r.r, active = 1, 0, 0}

@@ -33,6 +33,7 @@ SYMBOLS = [
     "rl_lfb_normal_eq",
     "rl_peer_mailbox_bytes", "rl_peer_alloc", "rl_peer_free", "rl_peer_export", "rl_peer_open", "rl_peer_close",
     "rl_peer_allreduce_sum",
+    "rl_mlp_forward", "rl_mlp_backward", "rl_gaussian_head_workspace_bytes", "rl_gaussian_head", "rl_gaussian_fisher",
 ]
 
 
@@ -129,6 +130,12 @@ def _load():
     lib.rl_sample_stats.argtypes = [sz, vp, vp, vp, vp, vp, vp, f64, f64, vp, i32, vp, sz, vp, vp]
     lib.rl_adv_finish.argtypes = [sz, vp, vp, f64, f64, f64, vp, vp]
     lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, vp]
+    lib.rl_mlp_forward.argtypes = [pb, vp, vp, vp, vp]
+    lib.rl_mlp_backward.argtypes = [pb, vp, vp, sz, vp, vp]
+    lib.rl_gaussian_head_workspace_bytes.restype = sz
+    lib.rl_gaussian_head_workspace_bytes.argtypes = []
+    lib.rl_gaussian_head.argtypes = [sz, i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, f32, vp, vp, vp, sz, vp, vp]
+    lib.rl_gaussian_fisher.argtypes = [sz, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp]
     vpp = ctypes.POINTER(ctypes.c_void_p)
     lib.rl_peer_mailbox_bytes.restype = sz
     lib.rl_peer_mailbox_bytes.argtypes = [i32, i32]

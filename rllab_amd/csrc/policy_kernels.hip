@@ -46,24 +46,29 @@
 
 namespace rl {
 
-constexpr int WAVES = 4;      // wavefronts per workgroup (one per SIMD)
 
-enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_FVP = 2, MODE_VPG = 3 };
+// MODE_OUT / MODE_OUT_TAN / MODE_BWD: the mean network as a plain function on planes -- forward (and tangent) values
+// OUT to [DA][B] planes, and back-propagation of an externally supplied output cotangent -- for policies whose
+// distribution head is not the one fused here (adaptive_std: mean and log_std come from two networks,
+// rllab/policies/gaussian_mlp_policy.py:60-98; rl_mlp_forward / rl_mlp_backward + rl_gaussian_head).
+enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_FVP = 2, MODE_VPG = 3, MODE_OUT = 4, MODE_OUT_TAN = 5, MODE_BWD = 6 };
 constexpr int LOSS_COLS = 4;  // sum w*lr*adv, sum w*kl, sum w*logp*adv, max kl
 
 template <class N, int MODE, bool CACHE = false>
 struct Smem {
-    static constexpr bool GRADLIKE = (MODE != MODE_LOSS);
+    static constexpr bool GRADLIKE = (MODE == MODE_GRAD || MODE == MODE_FVP || MODE == MODE_VPG || MODE == MODE_BWD);
     static constexpr bool FVP = (MODE == MODE_FVP);
+    static constexpr bool TAN = (MODE == MODE_FVP || MODE == MODE_OUT_TAN);      // tangent fragments staged
     static constexpr int ACT_FLOATS = 2 * N::H * TS;              // h0 | h1 fragments of one 32-sample tile
     static constexpr int A0 = 0;
     static constexpr int A1 = A0 + N::FA0;
     static constexpr int A1T = A1 + N::FA1;                       // backward fragments (W1 untransposed)
     static constexpr int DA0 = A1T + (GRADLIKE ? N::FA1 : 0);     // tangent fragments
-    static constexpr int DA1 = DA0 + (FVP ? N::FA0 : 0);
-    static constexpr int TAIL = DA1 + (FVP ? N::FA1 : 0);
+    static constexpr int DA1 = DA0 + (TAN ? N::FA0 : 0);
+    static constexpr int TAIL = DA1 + (TAN ? N::FA1 : 0);
     static constexpr int DTAIL = TAIL + N::TAILP;
-    static constexpr int WAVE0 = DTAIL + (FVP ? N::TAILP : 0);
+    static constexpr int WAVE0 = DTAIL + (TAN ? N::TAILP : 0);
+    static constexpr int WAVES = N::WAVES;
     static constexpr int ACTQ = WAVE0 + WAVES * N::WAVE_LDS;      // [WAVES][ACT_FLOATS] landing zone (cached FVP)
     static constexpr int TOTAL = ACTQ + ((FVP && CACHE && N::ACT_LDS_PREFETCH) ? WAVES * ACT_FLOATS : 0);
     static constexpr int RED = 0;                                 // [P] cross-wave fold, aliases the fragments
@@ -85,6 +90,9 @@ struct PolicyBatch {
     float log_min_std;
     float kl_penalty;          // MODE_GRAD / MODE_VPG: the gradient gains  + kl_penalty * d(sum w KL(old || new)) / dtheta
                                // (PenaltyLbfgsOptimizer's objective: PPO on the surrogate, regressors on the log-likelihood)
+    const float* cot;          // MODE_BWD: [DA][B] cotangent on the network output (weights / normalisation included)
+    float* out_mean;           // MODE_OUT / MODE_OUT_TAN: [DA][B] network output
+    float* out_dmean;          // MODE_OUT_TAN: [DA][B] tangent of the output in direction vec
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
 };
@@ -97,12 +105,15 @@ template <bool RELU> __device__ __forceinline__ float act_dz(float h) {
 }
 
 template <class N, int MODE, bool CACHE, bool RELU = false>
-__global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
+__global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
+    constexpr int WAVES = N::WAVES;
     static_assert(!CACHE || MODE == MODE_GRAD || MODE == MODE_FVP, "activation cache: grad writes, FVP reads");
     static_assert(!RELU || MODE == MODE_LOSS || MODE == MODE_VPG, "rectify nets: loss and log-likelihood gradient");
     using S = Smem<N, MODE, CACHE>;
     constexpr int DO = N::DO, DA = N::DA, H = N::H, HT = N::HT, KS0 = N::KS0, KS1 = N::KS1, P = N::P;
-    constexpr bool GRADLIKE = S::GRADLIKE, FVP = S::FVP;
+    constexpr bool GRADLIKE = S::GRADLIKE, FVP = S::FVP, TAN = S::TAN;
+    constexpr bool OUTMODE = (MODE == MODE_OUT || MODE == MODE_OUT_TAN), BWD = (MODE == MODE_BWD);
+    constexpr bool HEAD = (MODE == MODE_LOSS || MODE == MODE_GRAD || MODE == MODE_VPG);   // the fused distribution head
     constexpr bool LOAD_ACTS = CACHE && FVP, STORE_ACTS = CACHE && !FVP;
     constexpr int TSTR = N::TSTR, XS = N::XS, GS = N::GS;
     // activation cache: per 32-sample tile, [h0 | h1][HT][4] rows of 64 lanes x float4 (registers 4q .. 4q+3 of a
@@ -124,10 +135,10 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
     float* const tbg = tbx + TS * XS;                         // [32][GS]   gmu rows
 
     stage_fragments<N, WAVES * WV>(a.theta, fa0, fa1, GRADLIKE ? fa1t : nullptr);
-    if (FVP) stage_fragments<N, WAVES * WV>(a.vec, fda0, fda1, nullptr);
+    if (TAN) stage_fragments<N, WAVES * WV>(a.vec, fda0, fda1, nullptr);
     for (int k = threadIdx.x; k < N::TAIL; k += WAVES * WV) {
         tail[k] = a.theta[N::B1 + k];
-        if (FVP) dtail[k] = a.vec[N::B1 + k];
+        if (TAN) dtail[k] = a.vec[N::B1 + k];
     }
     for (int k = lane; k < N::WAVE_LDS; k += WV) tb[k] = 0.0f;
     __syncthreads();
@@ -304,8 +315,8 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
         float gmu[DA];
 #pragma unroll
         for (int k = 0; k < DA; ++k) gmu[k] = 0.0f;
-        if (!FVP) {
-            float mean[DA];
+        float mean[DA];
+        if constexpr (HEAD || OUTMODE) {
 #pragma unroll
             for (int k = 0; k < DA; ++k) {
                 float pm = 0.0f;
@@ -316,6 +327,8 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                         pm = __builtin_fmaf(h1[t][r], tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], pm);
                 mean[k] = tail[T_B2 + k] + half_sum(pm);
             }
+        }
+        if constexpr (HEAD) {
             const float advb = a.adv[bi];
             float zz_new = 0.0f, zz_old = 0.0f, sls_new = 0.0f, sls_old = 0.0f, kl = 0.0f;
             float znew[DA], dmv[DA], numv[DA];          // the last two: pieces of the KL the penalty gradient reuses
@@ -373,7 +386,9 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                     }
                 }
             }
-        } else {
+        }
+        float dmu_[DA];
+        if constexpr (TAN) {
             // tangent forward: dmu = J v
             f32x16 dh0[HT], dh1[HT];
 #pragma unroll
@@ -412,9 +427,24 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
                         pd = __builtin_fmaf(dh1[t][r], tail[T_W2 + u], pd);
                     }
                 const float dmu = dtail[T_B2 + k] + half_sum(pd);
-                gmu[k] = c * dmu * (2.0f / (2.0f * var_[k] + 1e-8f));
+                dmu_[k] = dmu;
+                if constexpr (FVP) gmu[k] = c * dmu * (2.0f / (2.0f * var_[k] + 1e-8f));
             }
-            if (lh == 0) wsum += c;
+            if (FVP && lh == 0) wsum += c;
+        }
+        if constexpr (OUTMODE) {
+            // the network as a function on planes: every sample's output (and tangent), nothing else
+            if (live && lh == 0) {
+#pragma unroll
+                for (int k = 0; k < DA; ++k) {
+                    a.out_mean[(size_t)k * B + b] = mean[k];
+                    if constexpr (MODE == MODE_OUT_TAN) a.out_dmean[(size_t)k * B + b] = dmu_[k];
+                }
+            }
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int k = 0; k < DA; ++k) gmu[k] = live ? a.cot[(size_t)k * B + bi] : 0.0f;
         }
 
         if (GRADLIKE) {
@@ -564,7 +594,9 @@ __global__ void __launch_bounds__(WAVES * WV, N::WPS) policy_pass_kernel(PolicyB
             a.partial_loss[(size_t)blockIdx.x * LOSS_COLS + c] = s;
         }
     };
-    if (MODE == MODE_LOSS) {
+    if (OUTMODE) {
+        // nothing to fold: the planes are the result
+    } else if (MODE == MODE_LOSS) {
         fold_loss();
     } else {
         float* red = smem + S::RED;
@@ -765,11 +797,21 @@ int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws
 struct WideShape;
 size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not a wide shape
 
+struct PlaneArgs {                 // MODE_OUT / MODE_OUT_TAN / MODE_BWD
+    const float* cot = nullptr;
+    float* out_mean = nullptr;
+    float* out_dmean = nullptr;
+};
+
 template <class N, int MODE, bool CACHE = false, bool RELU = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
-                       double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr) {
+                       double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr,
+                       const PlaneArgs* planes = nullptr) {
     using S = Smem<N, MODE, CACHE>;
     PolicyBatch a;
+    a.cot = planes ? planes->cot : nullptr;
+    a.out_mean = planes ? planes->out_mean : nullptr;
+    a.out_dmean = planes ? planes->out_dmean : nullptr;
     a.acts = g->activations;
     a.kl_penalty = g->kl_penalty;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
@@ -778,16 +820,19 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     const int n_tiles = (a.B + TS - 1) / TS;
     const size_t lds = (size_t)S::TOTAL * sizeof(float);
     if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "policy pass needs %zu B of LDS", lds);
+    constexpr int WAVES = N::WAVES;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu > N::WPS) blocks_per_cu = N::WPS;
+    if (blocks_per_cu > N::WPS * 4 / WAVES) blocks_per_cu = N::WPS * 4 / WAVES;
     int grid = 256 * blocks_per_cu;
     const int need = (n_tiles + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
     if (grid > MAX_GRID) grid = MAX_GRID;
     const bool with_loss = (MODE == MODE_GRAD || MODE == MODE_VPG) && loss_out != nullptr;
     const size_t row_bytes = (((size_t)grid * N::P * sizeof(float)) + 15) & ~(size_t)15;
-    const size_t need_bytes = (MODE == MODE_LOSS) ? (size_t)grid * LOSS_COLS * sizeof(double)
-                                                  : row_bytes + (with_loss ? (size_t)grid * LOSS_COLS * sizeof(double) : 0);
+    constexpr bool OUTMODE = (MODE == MODE_OUT || MODE == MODE_OUT_TAN);
+    const size_t need_bytes = OUTMODE ? 0 : (MODE == MODE_LOSS)
+        ? (size_t)grid * LOSS_COLS * sizeof(double)
+        : row_bytes + (with_loss ? (size_t)grid * LOSS_COLS * sizeof(double) : 0);
     if (workspace_bytes < need_bytes)
         return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", workspace_bytes,
                          need_bytes);
@@ -805,6 +850,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * WV), lds, st, a);
     int rc = check_launch("policy_pass_kernel");
     if (rc) return rc;
+    if (OUTMODE) return 0;
     if (MODE == MODE_LOSS) {
         hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(LOSS_COLS * WV), 0, st, a.partial_loss, grid, out);
     } else if (cg != nullptr) {
@@ -837,6 +883,18 @@ static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, v
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
 }
 
+// the network as a function on planes (rl_mlp_forward / rl_mlp_backward)
+template <class N>
+static int dispatch_planes(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
+                           hipStream_t st, const PlaneArgs* pl) {
+    switch (mode) {
+        case MODE_OUT: return launch_pass<N, MODE_OUT>(g, vec, ws, ws_bytes, out, st, nullptr, nullptr, pl);
+        case MODE_OUT_TAN: return launch_pass<N, MODE_OUT_TAN>(g, vec, ws, ws_bytes, out, st, nullptr, nullptr, pl);
+        case MODE_BWD: return launch_pass<N, MODE_BWD>(g, vec, ws, ws_bytes, out, st, nullptr, nullptr, pl);
+    }
+    return set_error(RL_ERR_ARG, "unknown plane mode %d", mode);
+}
+
 // rectify nets (regressors): loss / log-likelihood gradient only, one output, 32 hidden units
 template <class N>
 static int dispatch_relu(int mode, const rl_policy_batch* g, void* ws, size_t ws_bytes, double* out, hipStream_t st,
@@ -849,8 +907,22 @@ static int dispatch_relu(int mode, const rl_policy_batch* g, void* ws, size_t ws
 }
 
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
-                        double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr) {
+                        double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr,
+                        const PlaneArgs* pl = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
+    if (mode >= MODE_OUT) {
+        if (g->hidden2 != 0 || g->activation != RL_ACT_TANH)
+            return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: two equal tanh layers of 32 or 64 units");
+#define PLANECASE(DO, DA, H) \
+        if (d == DO && k == DA && h0 == H && h1 == H) return dispatch_planes<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, pl);
+        PLANECASE(4, 1, 32) PLANECASE(6, 1, 32) PLANECASE(11, 1, 32) PLANECASE(13, 2, 32) PLANECASE(20, 3, 32)
+        PLANECASE(20, 6, 32) PLANECASE(21, 6, 32)
+        PLANECASE(4, 1, 64) PLANECASE(6, 1, 64) PLANECASE(11, 1, 64) PLANECASE(13, 2, 64) PLANECASE(20, 3, 64)
+        PLANECASE(20, 6, 64) PLANECASE(21, 6, 64)
+#undef PLANECASE
+        return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: no kernel for obs_dim=%d act_dim=%d "
+                         "hidden=(%d,%d)", d, k, h0, h1);
+    }
     if (g->hidden2 < 0) return set_error(RL_ERR_ARG, "rl_policy_batch.hidden2 = %d", g->hidden2);
     if (g->hidden2 > 0) {              // three hidden layers: the cooperative kernels (policy_wide_kernels.hip)
         if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
@@ -969,4 +1041,27 @@ extern "C" int rl_policy_fvp(const rl_policy_batch* g, const float* vec, void* w
     if (rc) return rc;
     if (!vec || !fvp_out) return set_error(RL_ERR_ARG, "rl_policy_fvp: bad argument");
     return dispatch_net(MODE_FVP, g, vec, workspace, workspace_bytes, fvp_out, (hipStream_t)stream);
+}
+
+extern "C" int rl_mlp_forward(const rl_policy_batch* g, const float* vec, float* out, float* dout, void* stream) {
+    int rc = check_batch(g, "rl_mlp_forward");
+    if (rc) return rc;
+    if (!out || ((vec == nullptr) != (dout == nullptr)))
+        return set_error(RL_ERR_ARG, "rl_mlp_forward: out is required; vec and dout come together");
+    PlaneArgs pl;
+    pl.out_mean = out;
+    pl.out_dmean = dout;
+    return dispatch_net(vec ? MODE_OUT_TAN : MODE_OUT, g, vec, nullptr, 0, nullptr, (hipStream_t)stream, nullptr, nullptr,
+                        &pl);
+}
+
+extern "C" int rl_mlp_backward(const rl_policy_batch* g, const float* cotangent, void* workspace, size_t workspace_bytes,
+                               double* grad_out, void* stream) {
+    int rc = check_batch(g, "rl_mlp_backward");
+    if (rc) return rc;
+    if (!cotangent || !grad_out) return set_error(RL_ERR_ARG, "rl_mlp_backward: bad argument");
+    PlaneArgs pl;
+    pl.cot = cotangent;
+    return dispatch_net(MODE_BWD, g, nullptr, workspace, workspace_bytes, grad_out, (hipStream_t)stream, nullptr, nullptr,
+                        &pl);
 }

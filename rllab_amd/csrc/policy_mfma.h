@@ -64,6 +64,14 @@ struct Net {
     static constexpr int WAVE_LDS = TS * TSTR + TS * XS + TS * GS;
     // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
     static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
+    // wavefronts per workgroup of the update passes.  -DRL_POLICY_WAVES8=1: the nets that run two wavefronts per SIMD
+    // take them from ONE workgroup of eight (one staging of the weight fragments and one partial row per CU instead of
+    // two) -- measured neutral on MI355X (FVP 0.311 vs 0.3125 ms, gradient 0.220 vs 0.217 ms at 2.048 M samples,
+    // profiles/r03_notes.md): staging and the row count are not what bounds these passes.  Off.
+#ifndef RL_POLICY_WAVES8
+#define RL_POLICY_WAVES8 0
+#endif
+    static constexpr int WAVES = (WPS == 2 && RL_POLICY_WAVES8) ? 8 : 4;
     // the update kernels can keep the hidden activations of a batch in HBM between the gradient and the FVP passes
     static constexpr bool ACT_CACHE = true;
     // how the cached fragments of the NEXT tile travel to the FVP pass: LDS-direct loads into a wave-private landing

@@ -1,0 +1,159 @@
+"""GaussianMLPPolicy(adaptive_std=True) -- the log-std is a second network on the observation
+(rllab/policies/gaussian_mlp_policy.py:60-98; the reference's tests/regression_tests/test_issue_3.py:12-29 runs TRPO on
+it) -- with loss / KL / gradient / Fisher-vector product on the HIP kernels: both networks through rl_mlp_forward /
+rl_mlp_backward, the Gaussian head on planes (rl_gaussian_head / rl_gaussian_fisher).  Parity against float64 autograd
+of the reference formulas (npo.py:72-82, diagonal_gaussian.py:14-69): 2e-5, Fisher-vector product 5e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4, 1, 32, 32), (13, 2, 32, 32), (13, 2, 64, 32), (20, 6, 32, 64)]    # (Do, Da, mean hidden, std hidden)
+
+
+def _policy(do, da, hm, hs, min_std=1e-6, seed=0):
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    np.random.seed(seed)
+    spec = EnvSpec(Box(-np.ones(do), np.ones(do)), Box(-np.ones(da), np.ones(da)))
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(hm, hm), adaptive_std=True, std_hidden_sizes=(hs, hs), min_std=min_std)
+    theta = pol.get_param_values()
+    theta += 0.1 * np.random.randn(theta.size)
+    pol.set_param_values(theta)
+    return pol
+
+
+def _inputs(pol, B, seed=1, old_equals_new=False):
+    rng = np.random.RandomState(seed)
+    dev = pol.flat_params.device
+    do, da = pol.obs_dim, pol.action_dim
+    obs = torch.as_tensor(rng.randn(do, B).astype(np.float32), device=dev)
+    with torch.no_grad():
+        d = pol.dist_info_planes(obs.double(), pol.flat_params.double())
+    if old_equals_new:
+        old_mean, old_ls = d["mean"].float(), d["log_std"].float()
+    else:
+        old_mean = (d["mean"] + 0.05 * torch.as_tensor(rng.randn(da, B), device=dev)).float()
+        old_ls = (d["log_std"] + 0.03 * torch.as_tensor(rng.randn(da, B), device=dev)).float()
+    act = old_mean + torch.exp(old_ls) * torch.as_tensor(rng.randn(da, B).astype(np.float32), device=dev)
+    adv = torch.as_tensor(rng.randn(B).astype(np.float32), device=dev)
+    w = torch.ones(B, dtype=torch.float32, device=dev)
+    w[torch.as_tensor(rng.rand(B) < 0.1, device=dev)] = 0.0
+    w[0] = 1.0
+    return (obs, act, adv, old_mean, old_ls, w, 1.0 / w.double().sum())
+
+
+def _closures(pol):
+    dist = pol.distribution
+
+    def surr(flat, obs, act, adv, om, ols, w, inv):
+        new = pol.dist_info_planes(obs.double(), flat)
+        lr = dist.likelihood_ratio_sym(act.double(), dict(mean=om.double(), log_std=ols.double()), new, axis=0)
+        return -(lr * adv.double() * w.double()).sum() * inv
+
+    def kl(flat, obs, act, adv, om, ols, w, inv):
+        new = pol.dist_info_planes(obs.double(), flat)
+        return (dist.kl_sym(dict(mean=om.double(), log_std=ols.double()), new, axis=0) * w.double()).sum() * inv
+
+    def vpg(flat, obs, act, adv, om, ols, w, inv):
+        new = pol.dist_info_planes(obs.double(), flat)
+        return -(dist.log_likelihood_sym(act.double(), new, axis=0) * adv.double() * w.double()).sum() * inv
+    return surr, kl, vpg
+
+
+@pytest.mark.parametrize("do,da,hm,hs", SHAPES)
+@pytest.mark.parametrize("B", [63, 1000, 70001])
+def test_loss_kl_grad_vs_float64_autograd(do, da, hm, hs, B):
+    pol = _policy(do, da, hm, hs)
+    ops = pol.fused_ops()
+    assert ops is not None and type(ops).__name__ == "FusedAdaptiveStdOps"
+    inp = _inputs(pol, B)
+    assert ops.accepts(inp)
+    surr, kl, vpg = _closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    l64, k64, v64 = surr(flat64, *inp), kl(flat64, *inp), vpg(flat64, *inp)
+    s = ops.loss_stats(inp)
+    assert abs(float(-s[0]) - float(l64.detach())) <= 2e-5 * max(1.0, abs(float(l64.detach())))
+    assert abs(float(s[1]) - float(k64.detach())) <= 2e-5 * max(1e-2, abs(float(k64.detach())))
+    assert abs(float(-s[2]) - float(v64.detach())) <= 2e-5 * max(1.0, abs(float(v64.detach())))
+    g64 = torch.autograd.grad(l64, flat64, retain_graph=True)[0]
+    g = ops.loss_grad(inp)
+    assert float((g - g64).abs().max()) <= 2e-5 * max(1e-3, float(g64.abs().max()))
+    n_mean = ops.nets[0][1]
+    assert float(g[n_mean:].abs().max()) > 0                      # the std network gets its gradient
+    gv64 = torch.autograd.grad(v64, flat64, retain_graph=True)[0]
+    gv = ops.loss_grad(inp, vpg=True)
+    assert float((gv - gv64).abs().max()) <= 2e-5 * max(1e-3, float(gv64.abs().max()))
+    # PPO's penalised objective from the same passes
+    obj = l64 + 2.5 * k64
+    go64 = torch.autograd.grad(obj, flat64)[0].cpu().numpy()
+    val, go = ops.value_and_grad(inp, 2.5)
+    assert abs(val - float(obj.detach())) <= 2e-5 * max(1.0, abs(float(obj.detach())))
+    assert np.abs(go - go64).max() <= 3e-5 * max(1e-3, np.abs(go64).max())
+
+
+@pytest.mark.parametrize("do,da,hm,hs", SHAPES)
+def test_fvp_equals_kl_hessian_at_theta_old(do, da, hm, hs):
+    pol = _policy(do, da, hm, hs)
+    ops = pol.fused_ops()
+    inp = _inputs(pol, 5000, old_equals_new=True)
+    _, kl, _ = _closures(pol)
+    rng = np.random.RandomState(3)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    with torch.no_grad():
+        d64 = pol.dist_info_planes(inp[0].double(), flat64.detach())
+    inp64 = (inp[0], inp[1], inp[2], d64["mean"], d64["log_std"], inp[5], inp[6])
+    g = torch.autograd.grad(kl(flat64, *inp64), flat64, create_graph=True)[0]
+    for trial in range(2):
+        v = torch.as_tensor(rng.randn(flat64.numel()), device=flat64.device)
+        hv64 = torch.autograd.grad((g * v).sum(), flat64, retain_graph=True)[0]
+        hv = ops.fvp(inp, v)
+        assert float((hv - hv64).abs().max()) <= 5e-5 * float(hv64.abs().max())
+
+
+def test_min_std_floor_has_zero_derivative():
+    """Where the log-std network's output is below log(min_std) the floor is active (gaussian_mlp_policy.py:100-101):
+    the std network gets no gradient from those entries -- with a floor above every output, none at all."""
+    pol = _policy(13, 2, 32, 32, min_std=50.0)
+    ops = pol.fused_ops()
+    inp = _inputs(pol, 4000)
+    surr, _, _ = _closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    g64 = torch.autograd.grad(surr(flat64, *inp), flat64)[0]
+    g = ops.loss_grad(inp)
+    n_mean = ops.nets[0][1]
+    assert float(g64[n_mean:].abs().max()) == 0.0 and float(g[n_mean:].abs().max()) == 0.0
+    assert float((g - g64).abs().max()) <= 2e-5 * float(g64.abs().max())
+
+
+def test_trpo_with_adaptive_std_updates_on_the_kernels(quiet_logger):
+    """The configuration of the reference's test_issue_3 (TRPO + adaptive_std on Cartpole), several iterations: the
+    optimizer runs the fused passes (device CG included) and the std network moves."""
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.zero_baseline import ZeroBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(4)
+    env = CartpoleEnv()
+    policy = GaussianMLPPolicy(env_spec=env.spec, adaptive_std=True)
+    algo = TRPO(env=env, policy=policy, baseline=ZeroBaseline(env_spec=env.spec), batch_size=256 * 50,
+                max_path_length=50, n_itr=3, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    assert type(algo.optimizer._fused).__name__ == "FusedAdaptiveStdOps"
+    theta0 = policy.get_param_values().copy()
+    for itr in range(3):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        from rllab_amd.algos.npo import npo_inputs
+        assert algo.optimizer._fused.accepts(npo_inputs(policy, sd))
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        assert float(tab["MeanKL"]) <= 0.0101 and float(tab["LossAfter"]) < float(tab["LossBefore"])
+        logger.dump_tabular()
+    moved = np.abs(policy.get_param_values() - theta0)
+    n_mean = algo.optimizer._fused.nets[0][1]
+    assert moved[:n_mean].max() > 0 and moved[n_mean:].max() > 0
