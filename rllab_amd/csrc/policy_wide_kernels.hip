@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) wide_stage_kernel(WideShape s, const floa
 
 // ---- LDS plan ---------------------------------------------------------------------------------------------------
 struct WideLds {
-    int X, Hb[WIDE_MAX_L], Db[WIDE_MAX_L], tail, dtail, part, gmu, red, total;
+    int X, Hb[WIDE_MAX_L], Db[WIDE_MAX_L], tail, dtail, part, gmu, red, kred, total;
 };
 __host__ __device__ inline WideLds wide_lds(const WideShape& s, int mode) {
     WideLds p;
@@ -110,24 +110,48 @@ __host__ __device__ inline WideLds wide_lds(const WideShape& s, int mode) {
     p.red = o;                                    // ... whose space serves the cross-thread folds at the end of the launch
     o += (WW * s.DA * 32 > 256 + 64) ? WW * s.DA * 32 : 256 + 64;
     p.gmu = o; o += s.DA * 32;                    // gmu[k][sample] for the thread-per-unit accumulation
+    // partial accumulators of the k-split (layers with fewer than 4 row tiles): up to 3 x one fragment
+    bool narrow = false;
+    for (int l = 1; l < WIDE_MAX_L; ++l) narrow = narrow || (s.H[l] > 0 && s.HT[l] < 4);
+    for (int l = 0; l + 1 < WIDE_MAX_L; ++l) narrow = narrow || (s.H[l + 1] > 0 && s.HT[l] < 4 && mode != WMODE_LOSS);
+    p.kred = o; o += narrow ? 3 * 16 * 64 : 0;
     p.total = o;
     return p;
 }
 
-// eight k-steps per round, the A operands of the next round in flight while this one runs on the matrix pipe
+// U k-steps per round, the A operands of the next round in flight while this one runs on the matrix pipe.  The chain
+// does not stop at a call boundary: during its LAST round a call fetches the first four operands of the NEXT chain of
+// this wavefront (`next`, may be null) into `pre`, and a call whose operands were prefetched (`pv`) starts on them --
+// otherwise every chain would begin with an exposed L2 round trip (~10 chains per tile).
+struct WidePre {
+    float v[4];
+    bool valid;
+};
 template <int U>
 __device__ __forceinline__ f32x16 wide_gemm(const float* __restrict__ img, int ks, const float* bt, int lane,
-                                            f32x16 acc) {
+                                            f32x16 acc, WidePre& pre, const float* __restrict__ next) {
     const int lj = lane & 31, lh = lane >> 5;
     const float* bp = bt + lh * BS + lj;
     float a_cur[U], a_nxt[U];
+    if (pre.valid) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) a_cur[j] = img[j * WV + lane];
+        for (int j = 0; j < 4; ++j) a_cur[j] = pre.v[j];
+#pragma unroll
+        for (int j = 4; j < U; ++j) a_cur[j] = img[j * WV + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) a_cur[j] = img[j * WV + lane];
+    }
+    pre.valid = false;
     for (int base = 0; base < ks; base += U) {
         const bool more = base + U < ks;
         if (more) {
 #pragma unroll
             for (int j = 0; j < U; ++j) a_nxt[j] = img[(base + U + j) * WV + lane];
+        } else if (next != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre.v[j] = next[j * WV + lane];
+            pre.valid = true;
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) acc = mfma(a_cur[j], bp[(2 * (base + j)) * BS], acc);
@@ -137,6 +161,12 @@ __device__ __forceinline__ f32x16 wide_gemm(const float* __restrict__ img, int k
         }
     }
     return acc;
+}
+// the chunk length picks the round size (wave-uniform)
+__device__ __forceinline__ f32x16 wide_gemm_any(const float* __restrict__ img, int ks, const float* bt, int lane,
+                                                f32x16 acc, WidePre& pre, const float* __restrict__ next) {
+    if ((ks & 7) == 0) return wide_gemm<8>(img, ks, bt, lane, acc, pre, next);
+    return wide_gemm<4>(img, ks, bt, lane, acc, pre, next);
 }
 
 // publish an output fragment (lane = sample lj + 32 half, register r = unit frag_unit(r, half) of row tile t)
@@ -153,16 +183,27 @@ __device__ __forceinline__ void wide_put(float* bt, int t, int lane, const f32x1
 #ifndef RL_WIDE_WPS_L2
 #define RL_WIDE_WPS_L2 2
 #endif
-template <int L, int MODE>
-constexpr int wide_wps() { return (L == 2 || MODE == WMODE_LOSS) ? RL_WIDE_WPS_L2 : 1; }
+// KSPLIT: some layer has fewer than four row tiles and its k-steps are split over wavefronts (below); MT: the largest
+// number of column tiles of a hidden-to-hidden weight matrix (2: no layer beyond the first is wider than 64), which
+// sizes the persistent outer-product accumulators.
+#ifndef RL_WIDE_WPS_L3M2
+#define RL_WIDE_WPS_L3M2 2
+#endif
+template <int L, int MODE, bool KSPLIT, int MT>
+constexpr int wide_wps() {
+    return (L == 2 || MODE == WMODE_LOSS) ? RL_WIDE_WPS_L2 : (MT == 2 ? RL_WIDE_WPS_L3M2 : 1);
+}
 
-template <int L, int MODE>
-__global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(WideBatch a) {
+template <int L, int MODE, bool KSPLIT, int MT>
+__global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_pass_kernel(WideBatch a) {
     constexpr bool FVP = (MODE == WMODE_FVP), GRADLIKE = (MODE != WMODE_LOSS);
     const WideShape& s = a.s;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WideLds p = wide_lds(s, MODE);
-    const int tid = threadIdx.x, wave = tid / WV, lane = tid % WV, lj = lane & 31, lh = lane >> 5;
+    // the wavefront index as a SCALAR (readfirstlane): everything derived from it -- tile ownership, operand image
+    // pointers, k-ranges -- then lives in scalar registers and is computed by the scalar unit
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / WV), lane = tid % WV, lj = lane & 31,
+              lh = lane >> 5;
     const int DO = s.DO, DA = s.DA, HL = s.H[L - 1];
     float* const X = smem + p.X;
     float* const tail = smem + p.tail;
@@ -186,19 +227,10 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
     }
     __syncthreads();
     if (tid < 32) X[DO * BS + tid] = 1.0f;                 // the bias slot of the input tile
-    float lstd[MAXDA], inv_std[MAXDA], var_[MAXDA];
-    bool floored[MAXDA];
-#pragma unroll
-    for (int k = 0; k < MAXDA; ++k) {
-        const float raw = k < DA ? tail[s.tls + k] : 0.0f;
-        floored[k] = raw < a.log_min_std;
-        lstd[k] = fmaxf(raw, a.log_min_std);
-        inv_std[k] = __expf(-lstd[k]);
-        var_[k] = __expf(2.0f * lstd[k]);
-    }
-
+    // (the per-action constants of the head -- log_std, 1 / sigma, sigma^2 -- are re-derived from the staged log_std row
+    //  where they are used: a handful of transcendentals per tile instead of 32 registers for the whole launch)
     // ---- persistent accumulators ---------------------------------------------------------------------------------
-    f32x16 gW[L - 1][4];          // row tile `wave` of dW_l, l = 1 .. L-1, column tiles 0 .. HT[l]-1
+    f32x16 gW[L - 1][MT];         // row tile `wave` of dW_l, l = 1 .. L-1, column tiles 0 .. HT[l]-1 (<= MT)
     f32x16 gW0;                   // column tile `wave` of [dW0 ; db0] (rows = input slots)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -206,7 +238,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
 #pragma unroll
         for (int l = 0; l < L - 1; ++l)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gW[l][j][r] = 0.0f;
+            for (int j = 0; j < MT; ++j) gW[l][j][r] = 0.0f;
     }
     float gbv[L];                 // thread-per-unit partial sums of db_l (l >= 1; l = 0 rides in gW0's bias row)
     float gWo[MAXDA];             // thread-per-unit partial sums of dWo[unit][k]
@@ -223,6 +255,32 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
     const int B = a.B, n_tiles = (B + 31) / 32;
     const bool want_loss = (MODE == WMODE_LOSS) || (a.partial_loss != nullptr);
 
+    // what this wavefront does in the GEMM phase of each layer (tile-invariant): its row tile t, its part q of the
+    // k-steps (k-split) and where its operand images start
+    struct LayerJob {
+        int HT, ksp, t, q, chunk, k0;
+        bool busy;
+        const float* im;       // forward image (theta), at this wavefront's first k-step
+        const float* dim;      // the same of the tangent image (FVP)
+    };
+    LayerJob job[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        LayerJob& J = job[l];
+        J.HT = s.HT[l];
+        const bool split = KSPLIT && l >= 1;
+        J.ksp = split ? 4 / J.HT : 1;
+        J.t = split ? (wave & (J.HT - 1)) : wave;
+        J.q = split ? wave / J.HT : 0;
+        J.busy = split ? true : (wave < J.HT);
+        J.chunk = s.KS[l] / J.ksp;
+        J.k0 = J.q * J.chunk;
+        J.im = a.img + s.oF[l] + (J.t * s.KS[l] + J.k0) * WV;
+        J.dim = FVP ? a.dimg + s.oF[l] + (J.t * s.KS[l] + J.k0) * WV : nullptr;
+    }
+    WidePre pre;
+    pre.valid = false;
+
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile * 32 + lj;
         const int bi = b < B ? b : B - 1;
@@ -235,41 +293,77 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
         }
         __syncthreads();
 
-        // ---- forward (+ tangent) through the hidden layers; wavefront w owns row tile w ---------------------------
-        f32x16 h[L], dh[L];
+        // ---- forward (+ tangent) through the hidden layers ---------------------------------------------------------
+        // Layer l has HT row tiles.  HT = 4: wavefront w owns tile w.  HT < 4 (layers >= 1, KSPLIT): the k-steps of a
+        // tile are SPLIT over 4 / HT wavefronts -- wavefront w works on tile t = w % HT, k-range q = w / HT -- the
+        // partial accumulators of q >= 1 meet in LDS and the owner (q = 0) finishes the tile, so every SIMD's matrix
+        // pipe works in the narrow layers of nets like (128, 64, 32) too.
+        f32x16 h[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const float* bin = (l == 0) ? X : smem + p.Hb[l - 1];
-            if (wave < s.HT[l]) {
-                f32x16 acc;
-                if (l == 0) {
+            const LayerJob& J = job[l];
+            // the chain this wavefront runs next (for the operand prefetch): the tangent chains of this layer, else the
+            // first chain of the next layer, else (last layer, gradient-like modes) nothing -- the head sits in between
+            const float* nxt_h = FVP ? J.dim : (l + 1 < L && job[l + 1].busy ? job[l + 1].im : nullptr);
+            f32x16 acc;
+            if (J.busy) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    acc = wide_gemm<4>(a.img + s.oF[0] + wave * s.KS[0] * WV, s.KS[0], bin, lane, acc);
-                } else {
+                for (int r = 0; r < 16; ++r)
+                    acc[r] = (l >= 1 && J.q == 0) ? tail[s.tb[l] + 32 * J.t + frag_unit(r, 0) + 4 * lh] : 0.0f;
+                acc = wide_gemm_any(J.im, J.chunk, bin + 2 * J.k0 * BS, lane, acc, pre, nxt_h);
+            }
+            if (KSPLIT && J.ksp > 1) {                              // wave-uniform: partial accumulators -> the owner
+                float* kr = smem + p.kred;
+                if (J.q > 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = tail[s.tb[l] + 32 * wave + frag_unit(r, 0) + 4 * lh];
-                    acc = wide_gemm<8>(a.img + s.oF[l] + wave * s.KS[l] * WV, s.KS[l], bin, lane, acc);
+                    for (int r = 0; r < 16; ++r) kr[((wave - J.HT) * 16 + r) * WV + lane] = acc[r];
                 }
+                __syncthreads();
+                if (J.q == 0) {
+                    for (int qq = 1; qq < J.ksp; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += kr[((J.t + J.HT * qq - J.HT) * 16 + r) * WV + lane];
+                }
+            }
+            if (J.busy && J.q == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[l][r] = ftanh(acc[r]);
-                wide_put(smem + p.Hb[l], wave, lane, h[l]);
-                if (FVP) {
-                    f32x16 dacc;
+                wide_put(smem + p.Hb[l], J.t, lane, h[l]);
+            }
+            if (FVP) {
+                f32x16 dacc;
+                if (J.busy) {
+                    const float* nxt_d = (l + 1 < L && job[l + 1].busy) ? job[l + 1].im : nullptr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dacc[r] = (l >= 1 && J.q == 0) ? dtail[s.tb[l] + 32 * J.t + frag_unit(r, 0) + 4 * lh] : 0.0f;
                     if (l == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
-                        dacc = wide_gemm<4>(a.dimg + s.oF[0] + wave * s.KS[0] * WV, s.KS[0], bin, lane, dacc);
+                        dacc = wide_gemm_any(J.dim, J.chunk, bin, lane, dacc, pre, nxt_d);                       // dW0^T x
                     } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dacc[r] = dtail[s.tb[l] + 32 * wave + frag_unit(r, 0) + 4 * lh];
-                        dacc = wide_gemm<8>(a.dimg + s.oF[l] + wave * s.KS[l] * WV, s.KS[l], bin, lane, dacc);   // dW^T h
-                        dacc = wide_gemm<8>(a.img + s.oF[l] + wave * s.KS[l] * WV, s.KS[l], smem + p.Db[l - 1], lane,
-                                            dacc);                                                                 // W^T dh
+                        dacc = wide_gemm_any(J.dim, J.chunk, bin + 2 * J.k0 * BS, lane, dacc, pre, J.im);        // dW^T h
+                        dacc = wide_gemm_any(J.im, J.chunk, smem + p.Db[l - 1] + 2 * J.k0 * BS, lane, dacc, pre,
+                                             nxt_d);                                                             // W^T dh
                     }
+                }
+                if (KSPLIT && J.ksp > 1) {
+                    float* kr = smem + p.kred;
+                    __syncthreads();                                // the owners are done reading the h partials
+                    if (J.q > 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dh[l][r] = dacc[r] * (1.0f - h[l][r] * h[l][r]);
-                    wide_put(smem + p.Db[l], wave, lane, dh[l]);
+                        for (int r = 0; r < 16; ++r) kr[((wave - J.HT) * 16 + r) * WV + lane] = dacc[r];
+                    }
+                    __syncthreads();
+                    if (J.q == 0) {
+                        for (int qq = 1; qq < J.ksp; ++qq)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) dacc[r] += kr[((J.t + J.HT * qq - J.HT) * 16 + r) * WV + lane];
+                    }
+                }
+                if (J.busy && J.q == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dacc[r] *= (1.0f - h[l][r] * h[l][r]);
+                    wide_put(smem + p.Db[l], J.t, lane, dacc);
                 }
             }
             __syncthreads();
@@ -312,6 +406,16 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
 #pragma unroll
         for (int k = 0; k < MAXDA; ++k) gmu[k] = 0.0f;
         const bool keeper = (wave == 0 && lh == 0);        // the one lane that counts this sample in the scalar sums
+        float lstd[MAXDA], inv_std[MAXDA], var_[MAXDA];
+        bool floored[MAXDA];
+#pragma unroll
+        for (int k = 0; k < MAXDA; ++k) {
+            const float raw = k < DA ? tail[s.tls + k] : 0.0f;
+            floored[k] = raw < a.log_min_std;
+            lstd[k] = fmaxf(raw, a.log_min_std);
+            inv_std[k] = __expf(-lstd[k]);
+            var_[k] = __expf(2.0f * lstd[k]);
+        }
         if (!FVP) {
             float mean[MAXDA];
 #pragma unroll
@@ -432,14 +536,36 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
         }
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
-            if (wave < s.HT[l - 1]) {
-                f32x16 acc;
+            // gz_{l-1} = (W_l gz_l) (1 - h_{l-1}^2): HT[l-1] output tiles, the k-steps split over 4 / HT[l-1] wavefronts
+            const int HTo = s.HT[l - 1], ksp = KSPLIT ? 4 / HTo : 1;
+            const int t = KSPLIT ? (wave & (HTo - 1)) : wave, q = KSPLIT ? wave / HTo : 0;
+            const bool bbusy = KSPLIT ? true : (wave < HTo);
+            const int chunk = s.KT[l] / ksp, k0 = q * chunk;
+            f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = wide_gemm<8>(a.img + s.oT[l] + wave * s.KT[l] * WV, s.KT[l], smem + p.Db[l], lane, acc);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if (bbusy) {
+                const float* im = a.img + s.oT[l] + (t * s.KT[l] + k0) * WV;
+                const float* bk = smem + p.Db[l] + 2 * k0 * BS;
+                acc = wide_gemm_any(im, chunk, bk, lane, acc, pre, nullptr);
+            }
+            if (KSPLIT && ksp > 1) {
+                float* kr = smem + p.kred;
+                if (q > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) kr[((wave - HTo) * 16 + r) * WV + lane] = acc[r];
+                }
+                __syncthreads();
+                if (q == 0) {
+                    for (int qq = 1; qq < ksp; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += kr[((t + HTo * qq - HTo) * 16 + r) * WV + lane];
+                }
+            }
+            if (bbusy && q == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gz[r] = acc[r] * (1.0f - h[l - 1][r] * h[l - 1][r]);
-                wide_put(smem + p.Db[l - 1], wave, lane, gz);
+                wide_put(smem + p.Db[l - 1], t, lane, gz);
             }
             __syncthreads();
             if (l - 1 >= 1) {
@@ -461,7 +587,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
 #pragma unroll
                 for (int m = 0; m < 16; ++m) aop[m] = ap[2 * m];
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj)
+                for (int tj = 0; tj < MT; ++tj)
                     if (tj < s.HT[l]) {
                         const float* bp = smem + p.Db[l] + (32 * tj + lj) * BS + lh;
 #pragma unroll
@@ -500,7 +626,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
     for (int l = 1; l < L; ++l)
         if (wave < s.HT[l - 1]) {
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < MT; ++tj)
                 if (tj < s.HT[l]) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -556,8 +682,10 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE>())) wide_pass_kernel(W
                     row[s.obo + k] = b2;
                     if (FVP) {
                         // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
-                        const float vv = var_[k], e = 1e-8f;
-                        const float c = floored[k] ? 0.0f : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+                        const float raw = tail[s.tls + k];
+                        const float vv = __expf(2.0f * fmaxf(raw, a.log_min_std)), e = 1e-8f;
+                        const float c = raw < a.log_min_std ? 0.0f
+                                                            : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
                         row[s.ols + k] = c * a.vec[s.ols + k] * ws;
                     } else {
                         row[s.ols + k] = ls;
@@ -583,7 +711,7 @@ size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2
     return wide_workspace_bytes(s);
 }
 
-template <int L, int MODE>
+template <int L, int MODE, bool KSPLIT, int MT>
 static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float* vec, void* workspace,
                        size_t workspace_bytes, double* out, hipStream_t st, double* loss_out) {
     if (workspace_bytes < wide_workspace_bytes(s))
@@ -598,7 +726,7 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     const WideLds p = wide_lds(s, MODE);
     const size_t lds = (size_t)p.total * sizeof(float);
     if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "wide policy pass needs %zu B of LDS", lds);
-    int per_cu = wide_wps<L, MODE>();
+    int per_cu = wide_wps<L, MODE, KSPLIT, MT>();
     if ((size_t)per_cu * lds > 160 * 1024) per_cu = 1;
     const int max_grid = 256 * per_cu;
     const int grid = n_tiles < max_grid ? n_tiles : max_grid;
@@ -619,7 +747,7 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
                            dim3(256), 0, st, s, vec, dimg, 0);
     int rc = check_launch("wide_stage_kernel");
     if (rc) return rc;
-    auto kern = wide_pass_kernel<L, MODE>;
+    auto kern = wide_pass_kernel<L, MODE, KSPLIT, MT>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -637,16 +765,31 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     return 0;
 }
 
-template <int L>
+template <int L, bool KSPLIT, int MT>
 static int wide_mode(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
                      size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
     switch (mode) {
-        case WMODE_LOSS: return launch_wide<L, WMODE_LOSS>(s, g, vec, ws, ws_bytes, out, st, nullptr);
-        case WMODE_GRAD: return launch_wide<L, WMODE_GRAD>(s, g, vec, ws, ws_bytes, out, st, loss_out);
-        case WMODE_FVP: return launch_wide<L, WMODE_FVP>(s, g, vec, ws, ws_bytes, out, st, nullptr);
-        case WMODE_VPG: return launch_wide<L, WMODE_VPG>(s, g, vec, ws, ws_bytes, out, st, loss_out);
+        case WMODE_LOSS: return launch_wide<L, WMODE_LOSS, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, nullptr);
+        case WMODE_GRAD: return launch_wide<L, WMODE_GRAD, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, loss_out);
+        case WMODE_FVP: return launch_wide<L, WMODE_FVP, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, nullptr);
+        case WMODE_VPG: return launch_wide<L, WMODE_VPG, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, loss_out);
     }
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
+}
+
+template <int L>
+static int wide_shape_class(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
+                            size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
+    bool ksplit = false;
+    int mt = 1;
+    for (int l = 0; l < s.L; ++l) {
+        if (s.HT[l] < 4 && (l >= 1 || l + 1 < s.L)) ksplit = true;      // forward of layer l >= 1, backward INTO layer l
+        if (l >= 1 && s.HT[l] > mt) mt = s.HT[l];
+    }
+    if (mt <= 2) return ksplit ? wide_mode<L, true, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
+                               : wide_mode<L, false, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
+    return ksplit ? wide_mode<L, true, 4>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
+                  : wide_mode<L, false, 4>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }
 
 // entry point for policy_kernels.hip's dispatcher: nets that the one-wavefront-per-tile kernels are not built for
@@ -660,8 +803,8 @@ int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws
                          g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, WIDE_MAX_DO, WIDE_MAX_DA);
     if (g->activations)
         return set_error(RL_ERR_ARG, "the activation cache belongs to the 32 / 64-unit two-layer kernels");
-    return s.L == 2 ? wide_mode<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
-                    : wide_mode<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
+    return s.L == 2 ? wide_shape_class<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
+                    : wide_shape_class<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }
 
 }  // namespace rl
