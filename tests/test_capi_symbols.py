@@ -119,9 +119,10 @@ def test_integration_md_bindings_match_the_library():
              "f64": ctypes.c_double, "sz": ctypes.c_size_t, "u32": ctypes.c_uint32,
              "cfgp": ctypes.POINTER(_lib.EnvCfg), "pb": ctypes.POINTER(_lib.PolicyBatch),
              "ctypes.POINTER(RolloutArgs)": ctypes.POINTER(_lib.RolloutArgs),
-             "ip": ctypes.POINTER(ctypes.c_int), "fp": ctypes.POINTER(ctypes.c_float)}
+             "ip": ctypes.POINTER(ctypes.c_int), "fp": ctypes.POINTER(ctypes.c_float),
+             "vpp": ctypes.POINTER(ctypes.c_void_p)}
     found = re.findall(r"^\s*lib\.(rl_\w+)\.argtypes\s*= \[([^\]]*)\]", text, flags=re.M)
-    assert len(found) >= 15
+    assert len(found) >= 24
     for fn, args in found:
         toks = [a.strip() for a in args.split(",") if a.strip()]
         want = list(getattr(_lib.lib, fn).argtypes)
