@@ -92,12 +92,12 @@ extern "C" int rl_peer_alloc(size_t bytes, void** dev_ptr_out) {
     void* p = nullptr;
     // fine-grained device memory: visible to peers inside a running kernel (what a flag protocol needs); plain
     // hipMalloc is coarse-grained, coherent across devices only at kernel boundaries
+    // (no fallback to hipMalloc: a coarse-grained mailbox would pass every single-GPU test and hand peers stale rows)
     hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        e = hipMalloc(&p, bytes);
+        return set_error(RL_ERR_HIP, "rl_peer_alloc: fine-grained device memory unavailable (%s)", hipGetErrorString(e));
     }
-    if (e != hipSuccess) return set_error(RL_ERR_HIP, "rl_peer_alloc: %s", hipGetErrorString(e));
     e = hipMemset(p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(p); return set_error(RL_ERR_HIP, "rl_peer_alloc: %s", hipGetErrorString(e)); }

@@ -111,3 +111,50 @@ def test_logger_decides_who_writes_at_write_time(tmp_path, monkeypatch):
         logger.remove_text_output(txt_path)
         logger.set_primary(None)
         logger.set_quiet(False)
+
+
+def _cpu_policy(do, da, hidden):
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    import torch
+    np.random.seed(0)
+    spec = EnvSpec(Box(-np.ones(do), np.ones(do)), Box(-np.ones(da), np.ones(da)))
+    pol = GaussianMLPPolicy(spec, hidden_sizes=hidden)
+    pol.flat_params = pol.flat_params.cpu()
+    theta = pol.get_param_values()
+    pol.set_param_values(theta + 0.1 * np.random.randn(theta.size))
+    return pol, torch
+
+
+@pytest.mark.parametrize("hidden,want", [((100, 50, 25), (128, 64, 32)), ((128, 128), (128, 128)), ((40, 100, 40), (64, 128, 64)),
+                                         ((48, 20), (64, 64)), ((32, 128), (32, 128))])
+def test_zero_padded_kernel_layout_is_the_same_network(hidden, want):
+    """policies/kernel_layout.py for two- and three-layer nets: the padded parameter vector, read back in the kernels'
+    layout (W_l [in_pad, H_l] row-major, b_l, ..., Wout [H_last, Da], bout, log_std), is a network with exactly the
+    same outputs as the policy's own; pack / unpack are inverse on the real entries and leave zeros elsewhere."""
+    from rllab_amd.policies.kernel_layout import KernelLayout, padded_sizes
+    pol, torch = _cpu_policy(7, 3, hidden)
+    assert padded_sizes(hidden) == want
+    lay = KernelLayout(pol)
+    assert lay.hidden == want and lay.hidden3 == want + (0,) * (3 - len(want))
+    th = lay.theta().double()
+    assert th.numel() == lay.P_pad
+    # walk the padded vector as the kernels do
+    x = torch.as_tensor(np.random.RandomState(1).randn(7, 11))
+    h, off, rows = x, 0, 7
+    for H in want:
+        W = th[off:off + rows * H].reshape(rows, H); off += rows * H
+        b = th[off:off + H]; off += H
+        h = torch.tanh(W.t() @ h + b[:, None])
+        rows = H
+    Wo = th[off:off + rows * 3].reshape(rows, 3); off += rows * 3
+    mean = Wo.t() @ h + th[off:off + 3][:, None]; off += 3
+    assert off + 3 == lay.P_pad
+    want_mean = pol.mean_planes(x, pol.flat_params.double())
+    assert torch.allclose(mean, want_mean, rtol=0, atol=1e-12)
+    assert torch.equal(th[off:off + 3].float(), pol.effective_log_std().detach())
+    v = torch.arange(1.0, lay.P + 1.0, dtype=torch.float64)
+    assert torch.equal(lay.unpack(lay.pack(v)), v)
+    assert float(lay.pack(v).sum()) == float(v.sum()) and int((lay.pack(v) != 0).sum()) == lay.P
+    assert lay.exact == (tuple(hidden) == want)
