@@ -41,7 +41,7 @@ int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t
 constexpr int WW = 4;                  // wavefronts per workgroup = row tiles of the widest layer
 constexpr int WNT = WW * WV;
 constexpr int BS = WIDE_BS;
-constexpr int MAXDA = WIDE_MAX_DA;
+constexpr int MAXDA_LIMIT = WIDE_MAX_DA;      // the kernels are instantiated for up to 2 or up to 8 action dims (MD)
 enum { WMODE_LOSS = 0, WMODE_GRAD = 1, WMODE_FVP = 2, WMODE_VPG = 3 };
 constexpr int WLOSS_COLS = 4;
 
@@ -190,12 +190,15 @@ __device__ __forceinline__ void wide_put(float* bt, int t, int lane, const f32x1
 #define RL_WIDE_WPS_L3M2 2
 #endif
 template <int L, int MODE, bool KSPLIT, int MT>
-constexpr int wide_wps() {
+constexpr int wide_wps() {   // (independent of MD: the same register budget is declared, narrow heads simply do not spill)
     return (L == 2 || MODE == WMODE_LOSS) ? RL_WIDE_WPS_L2 : (MT == 2 ? RL_WIDE_WPS_L3M2 : 1);
 }
 
-template <int L, int MODE, bool KSPLIT, int MT>
+// MD: how many action dimensions the per-action register arrays of the head are sized for (2 or 8): at 8 they are the
+// largest single source of register pressure (a (13 -> 128 -> 128 -> 2) gradient pass: 72 spilled registers with 8, none with 2).
+template <int L, int MODE, bool KSPLIT, int MT, int MD>
 __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_pass_kernel(WideBatch a) {
+    constexpr int MAXDA = MD;
     constexpr bool FVP = (MODE == WMODE_FVP), GRADLIKE = (MODE != WMODE_LOSS);
     const WideShape& s = a.s;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -711,7 +714,7 @@ size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2
     return wide_workspace_bytes(s);
 }
 
-template <int L, int MODE, bool KSPLIT, int MT>
+template <int L, int MODE, bool KSPLIT, int MT, int MD>
 static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float* vec, void* workspace,
                        size_t workspace_bytes, double* out, hipStream_t st, double* loss_out) {
     if (workspace_bytes < wide_workspace_bytes(s))
@@ -747,7 +750,7 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
                            dim3(256), 0, st, s, vec, dimg, 0);
     int rc = check_launch("wide_stage_kernel");
     if (rc) return rc;
-    auto kern = wide_pass_kernel<L, MODE, KSPLIT, MT>;
+    auto kern = wide_pass_kernel<L, MODE, KSPLIT, MT, MD>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -765,16 +768,23 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     return 0;
 }
 
+template <int L, bool KSPLIT, int MT, int MD>
+static int wide_mode_md(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
+                        size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
+    switch (mode) {
+        case WMODE_LOSS: return launch_wide<L, WMODE_LOSS, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr);
+        case WMODE_GRAD: return launch_wide<L, WMODE_GRAD, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, loss_out);
+        case WMODE_FVP: return launch_wide<L, WMODE_FVP, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr);
+        case WMODE_VPG: return launch_wide<L, WMODE_VPG, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, loss_out);
+    }
+    return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
+}
+
 template <int L, bool KSPLIT, int MT>
 static int wide_mode(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
                      size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
-    switch (mode) {
-        case WMODE_LOSS: return launch_wide<L, WMODE_LOSS, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, nullptr);
-        case WMODE_GRAD: return launch_wide<L, WMODE_GRAD, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, loss_out);
-        case WMODE_FVP: return launch_wide<L, WMODE_FVP, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, nullptr);
-        case WMODE_VPG: return launch_wide<L, WMODE_VPG, KSPLIT, MT>(s, g, vec, ws, ws_bytes, out, st, loss_out);
-    }
-    return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
+    return s.DA <= 2 ? wide_mode_md<L, KSPLIT, MT, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
+                     : wide_mode_md<L, KSPLIT, MT, 8>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }
 
 template <int L>
