@@ -743,13 +743,10 @@ __device__ __forceinline__ float prefix3(const DppQuad& x, float v, int b) {
 
 constexpr int QUAD_ENVS = 16;   // envs per wavefront
 
-template <int H>
-__global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutDev a) {
+template <class Pol>
+__device__ __forceinline__ void swimmer_quad_body(const RolloutDev& a, const Pol& pol) {
     using Env = Swimmer;
     using Chain = Env::Chain;
-    using Pol = RolloutPolicy16<Env, H>;
-    Pol pol;
-    pol.init(a.theta);
 
     const int n = a.n, T = a.T;
     const int lane = threadIdx.x & 63;
@@ -935,6 +932,21 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutD
     }
 }
 
+template <int H>
+__global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutDev a) {
+    RolloutPolicy16<Swimmer, H> pol;
+    pol.init(a.theta);
+    swimmer_quad_body(a, pol);
+}
+
+// the lane-group Swimmer under a wide / deep policy (RolloutPolicyWide::forward16: weight fragments in LDS)
+__global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_wide_kernel(RolloutDev a, WideShape shape) {
+    extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+    RolloutPolicyWide<Swimmer> pol;
+    pol.init(wide_smem, a.theta, shape);
+    swimmer_quad_body(a, pol);
+}
+
 // ---------------------------------------------------------------------------
 // Lane-group rollout of the two-legged envs (HalfCheetah, Walker2D): 16 envs per wavefront, everything per
 // env-step env-per-lane on four replicas exactly as in rollout_kernel, and the physics sub-steps ONE LEG PER LANE
@@ -949,13 +961,10 @@ struct DppPair {
     }
 };
 
-template <class Env, int H>
-__global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutDev a) {
+template <class Env, class Pol>
+__device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol& pol) {
     using Legs = typename Env::Legs;
     using Tree = typename Env::Tree;
-    using Pol = RolloutPolicy16<Env, H>;
-    Pol pol;
-    pol.init(a.theta);
 
     const int n = a.n, T = a.T;
     const int lane = threadIdx.x & 63;
@@ -1151,6 +1160,21 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutD
     }
 }
 
+template <class Env, int H>
+__global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutDev a) {
+    RolloutPolicy16<Env, H> pol;
+    pol.init(a.theta);
+    two_leg_quad_body<Env>(a, pol);
+}
+
+template <class Env>
+__global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_wide_kernel(RolloutDev a, WideShape shape) {
+    extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+    RolloutPolicyWide<Env> pol;
+    pol.init(wide_smem, a.theta, shape);
+    two_leg_quad_body<Env>(a, pol);
+}
+
 __global__ void philox_debug_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                     uint32_t k1, int count, uint32_t* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1261,6 +1285,26 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), qgrid, qblock, 0, st, a);
             return check_launch("rollout_swimmer_quad_kernel");
         }
+        // the same lane-group physics under a wide / deep policy (RLLAB_ROLLOUT_EPW set: the generic shapes, for tests)
+        WideShape shape;
+        if (!lane_kernel && small_offsets && getenv("RLLAB_ROLLOUT_EPW") == nullptr &&
+            wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
+            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
+            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
+            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
+            if (lds <= 160 * 1024) {
+                auto kern = rollout_swimmer_quad_wide_kernel;
+                static bool attr = false;
+                if (!attr) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    attr = true;
+                }
+                hipLaunchKernelGGL(kern, qgrid, qblock, lds, st, a, shape);
+                return check_launch("rollout_swimmer_quad_wide_kernel");
+            }
+        }
     }
     if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
         // one leg per lane while every lane-group wavefront still gets a SIMD of its own (RLLAB_TWO_LEG_LANE_KERNEL=0:
@@ -1275,6 +1319,25 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32>), qgrid, qblock, 0, st, a);
             else hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64>), qgrid, qblock, 0, st, a);
             return check_launch("rollout_two_leg_quad_kernel");
+        }
+        WideShape shape;
+        if (lanes_on && small_offsets && a.n <= 16 * 1024 &&
+            wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
+            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
+            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
+            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
+            if (lds <= 160 * 1024) {
+                auto kern = rollout_two_leg_quad_wide_kernel<Env>;
+                static bool attr = false;
+                if (!attr) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    attr = true;
+                }
+                hipLaunchKernelGGL(kern, qgrid, qblock, lds, st, a, shape);
+                return check_launch("rollout_two_leg_quad_wide_kernel");
+            }
         }
     }
     // 16 envs per wavefront while that still leaves every wavefront a SIMD of its own (1024 SIMDs); beyond, the

@@ -137,14 +137,18 @@ def test_device_cg_beyond_the_register_cached_size():
 
 
 @pytest.mark.parametrize("kind,hidden", [(2, (100, 50, 25)), (0, (128, 128)), (3, (100, 50, 25)), (6, (64, 32, 32))])
-@pytest.mark.parametrize("epw", ["16", "64"])
+@pytest.mark.parametrize("epw", ["auto", "16", "64"])
 def test_fused_rollout_of_a_wide_policy(kind, hidden, epw, monkeypatch):
-    """rollout_wide_kernel in both launch shapes: env dynamics replayed on the host build from the recorded actions,
-    bit for bit; recorded means against a float64 torch forward of the same parameters."""
+    """The wide policies' rollouts in every launch shape -- "auto": what a run takes (the lane-group kernels of the
+    Swimmer and the two-legged envs with the policy's weight fragments in LDS, 16 envs per wavefront for the rest),
+    "16" / "64": the generic rollout_wide_kernel shapes: env dynamics replayed on the host build from the recorded
+    actions, bit for bit; recorded means against a float64 torch forward of the same parameters."""
     from rllab_amd.envs.hip_env import HipVecEnv
     from oracle.replay import replay_check
     from tests.test_gpu_env_parity import _make_policy
-    monkeypatch.setenv("RLLAB_ROLLOUT_EPW", epw)
+    monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
+    if epw != "auto":
+        monkeypatch.setenv("RLLAB_ROLLOUT_EPW", epw)
     rng = np.random.RandomState(1)
     n, T, mpl = 130, 40, 17
     policy = _make_policy(kind, hidden)
