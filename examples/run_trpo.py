@@ -57,7 +57,8 @@ def main():
     ap.add_argument("--n-envs", type=int, default=1024)
     ap.add_argument("--n-itr", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--hidden", default="32", help="hidden sizes: one number H for (H, H), or a list like 100,50,25")
+    ap.add_argument("--adaptive-std", action="store_true", help="GaussianMLPPolicy(adaptive_std=True)")
     ap.add_argument("--gae-lambda", type=float, default=1.0)
     ap.add_argument("--csv", default=None, help="write the tabular log (one row per iteration) to this file")
     ap.add_argument("--quiet", action="store_true")
@@ -69,7 +70,9 @@ def main():
         logger.set_quiet(True)
     ext.set_seed(args.seed)
     env, horizon = make_env(args.env)
-    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(args.hidden, args.hidden))
+    hs = tuple(int(h) for h in str(args.hidden).split(","))
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=hs * 2 if len(hs) == 1 else hs,
+                               adaptive_std=args.adaptive_std)
     baseline = LinearFeatureBaseline(env_spec=env.spec)
     kw = dict(env=env, policy=policy, baseline=baseline, batch_size=args.n_envs * horizon,
               max_path_length=horizon, n_itr=args.n_itr, discount=0.99, gae_lambda=args.gae_lambda,
