@@ -191,6 +191,13 @@ typedef struct rl_rollout_args {
     uint8_t* dones;           /* uint8[T][n]  env done OR ts == max_path_length */
     float* last_obs;          /* NULL or float[obs_dim][n]: observation after the last step (post-reset) */
     const rl_env_cfg* cfg;    /* host; NULL = the env's defaults */
+    const float* theta_std;   /* NULL (log_std is the last row of theta), or the parameters of a log-std NETWORK on the
+                                 observation -- GaussianMLPPolicy(adaptive_std=True) / std_network=...
+                                 (gaussian_mlp_policy.py:60-98) -- in the same layout as theta (W0,b0,..,Wout,bout and
+                                 act_dim unused floats); theta then holds the mean network the same way */
+    float* log_stds;          /* with theta_std: float[act_dim][T][n] agent_info "log_std" (floored at log_min_std) */
+    int32_t std_hidden0, std_hidden1, std_hidden2;   /* hidden sizes of the log-std network (as hidden0..2) */
+    int32_t reserved;
 } rl_rollout_args;
 
 int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);

@@ -61,6 +61,8 @@ class RolloutArgs(ctypes.Structure):
         ("eps", ctypes.c_void_p), ("reset_draws", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("means", ctypes.c_void_p), ("rewards", ctypes.c_void_p),
         ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p), ("cfg", ctypes.POINTER(EnvCfg)),
+        ("theta_std", ctypes.c_void_p), ("log_stds", ctypes.c_void_p), ("std_hidden0", ctypes.c_int32),
+        ("std_hidden1", ctypes.c_int32), ("std_hidden2", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 

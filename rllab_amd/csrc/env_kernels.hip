@@ -569,7 +569,31 @@ struct RolloutDev {
     EnvCfg cfg;
     const float* act_noise_z;   // [T][Da][n] injected N(0,1) draws of the env's action noise, or null (Philox)
     const float* obs_noise_z;   // [T+1][Do][n]: slice 0 = the first observation, slice t + 1 = the one after step t
+    float* log_stds;            // [Da][T][n] agent_info "log_std" of a policy with a log-std NETWORK (else unused)
 };
+
+// A policy whose log-std is a second network on the observation (GaussianMLPPolicy(adaptive_std=True) / std_network=...,
+// gaussian_mlp_policy.py:60-98): two RolloutPolicyWide side by side in LDS, the same observation through both.
+template <class Env>
+struct RolloutPolicyDual {
+    RolloutPolicyWide<Env> mean_net, std_net;
+    static size_t lds_floats(const WideShape& ms, const WideShape& ss, int threads) {
+        return RolloutPolicyWide<Env>::lds_floats(ms, threads) + RolloutPolicyWide<Env>::lds_floats(ss, threads);
+    }
+    __device__ __forceinline__ void init(float* smem, const float* __restrict__ th_mean, const WideShape& ms,
+                                         const float* __restrict__ th_std, const WideShape& ss, size_t mean_floats) {
+        mean_net.init(smem, th_mean, ms);
+        std_net.init(smem + mean_floats, th_std, ss);
+    }
+    __device__ __forceinline__ float log_std(int) const { return 0.0f; }      // per step instead: log_std16 / log_std64
+    __device__ __forceinline__ void forward16(const float* o, float* mean) const { mean_net.forward16(o, mean); }
+    __device__ __forceinline__ void forward(const float* o, float* mean) const { mean_net.forward(o, mean); }
+    __device__ __forceinline__ void log_std16(const float* o, float* ls) const { std_net.forward16(o, ls); }
+    __device__ __forceinline__ void log_std64(const float* o, float* ls) const { std_net.forward(o, ls); }
+};
+template <class P> struct state_std : std::false_type {};
+template <class Env> struct state_std<RolloutPolicyDual<Env>> : std::true_type {};
+
 
 // EPW = envs per wavefront.  64: one env per lane, the throughput shape (every lane does useful physics).
 // 16: env e lives on lanes e, e+16, e+32, e+48 -- the physics is replicated (free: a lone wavefront is bound by its
@@ -639,6 +663,18 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
         if constexpr (EPW == 16) pol.forward16(o, mean);
         else pol.forward(o, mean);
+        if constexpr (state_std<Pol>::value) {
+            // the log-std network on the same observation, floored (gaussian_mlp_policy.py:100-101,120-121), recorded
+            float ls[Env::ACT];
+            if constexpr (EPW == 16) pol.log_std16(o, ls);
+            else pol.log_std64(o, ls);
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) {
+                ls[k] = fmaxf(ls[k], a.log_min_std);
+                std_[k] = __expf(ls[k]);
+            }
+            if (live) store_planes<Env::ACT>(a.log_stds + row, plane, lane_f32, ls);
+        }
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
@@ -716,6 +752,18 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_wide_ker
     RolloutPolicyWide<Env> pol;
     pol.init(wide_smem, a.theta, shape);
     rollout_body<Env, RolloutPolicyWide<Env>, EPW>(a, pol);
+}
+
+// ... and for policies with a log-std network: both networks' weight fragments in LDS
+template <class Env, int EPW>
+__global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_dual_kernel(RolloutDev a, WideShape mean_shape,
+                                                                                    WideShape std_shape,
+                                                                                    const float* __restrict__ theta_std,
+                                                                                    int mean_floats) {
+    extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+    RolloutPolicyDual<Env> pol;
+    pol.init(wide_smem, a.theta, mean_shape, theta_std, std_shape, (size_t)mean_floats);
+    rollout_body<Env, RolloutPolicyDual<Env>, EPW>(a, pol);
 }
 
 // ---------------------------------------------------------------------------
@@ -1273,6 +1321,47 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     if (rc) return rc;
     a.act_noise_z = g->cfg ? g->cfg->action_noise_z : nullptr;
     a.obs_noise_z = g->cfg ? g->cfg->obs_noise_z : nullptr;
+    a.log_stds = g->log_stds;
+    if (g->theta_std != nullptr) {
+        // a log-std NETWORK (adaptive_std / std_network): both networks in the kernel, log_std planes recorded
+        if (!g->log_stds) return set_error(RL_ERR_ARG, "rl_rollout_gaussian_mlp: theta_std without log_stds");
+        WideShape ms, ss;
+        if (!wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, ms) ||
+            !wide_shape(Env::OBS, Env::ACT, g->std_hidden0, g->std_hidden1, g->std_hidden2, ss))
+            return set_error(RL_ERR_UNSUPPORTED,
+                             "rl_rollout_gaussian_mlp: mean net (%d,%d,%d) / log-std net (%d,%d,%d): each two or three tanh "
+                             "layers of 32 / 64 / 128 units", g->hidden0, g->hidden1, g->hidden2, g->std_hidden0,
+                             g->std_hidden1, g->std_hidden2);
+        const char* es = getenv("RLLAB_ROLLOUT_EPW");
+        const int ee = es ? atoi(es) : 0;
+        const int epw = (ee == 16 || ee == 64) ? ee : (a.n <= 16 * 1024 ? 16 : 64);
+        const int waves = (a.n + epw - 1) / epw, wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
+        dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
+        const size_t mean_floats = RolloutPolicyWide<Env>::lds_floats(ms, 64 * wpb);
+        const size_t lds = RolloutPolicyDual<Env>::lds_floats(ms, ss, 64 * wpb) * sizeof(float);
+        if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "rollout of the two networks needs %zu B of LDS", lds);
+        static bool attr16 = false, attr64 = false;
+        if (epw == 16) {
+            auto kern = rollout_dual_kernel<Env, 16>;
+            if (!attr16) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr16 = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, a, ms, ss, g->theta_std, (int)mean_floats);
+        } else {
+            auto kern = rollout_dual_kernel<Env, 64>;
+            if (!attr64) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr64 = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, a, ms, ss, g->theta_std, (int)mean_floats);
+        }
+        return check_launch("rollout_dual_kernel");
+    }
     if constexpr (std::is_same<Env, Swimmer>::value) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
         const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;   // per launch: tests switch shapes

@@ -195,10 +195,11 @@ class HipVecEnv(object):
         T, n = int(horizon), self.n
         do, da = self.q["obs_dim"], self.q["act_dim"]
         layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
-        if layout is None:
+        dual = policy.rollout_networks() if (layout is None and hasattr(policy, "rollout_networks")) else None
+        if layout is None and dual is None:
             raise NotImplementedError("fused rollout needs a GaussianMLPPolicy with two or three tanh hidden layers of "
                                       "at most 128 units (policies/kernel_layout.py)")
-        hs = layout.hidden3
+        hs = layout.hidden3 if dual is None else dual[1]
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         obs = torch.empty((do, T, n), **f32)
@@ -206,7 +207,11 @@ class HipVecEnv(object):
         mean = torch.empty((da, T, n), **f32)
         rew = torch.empty((T, n), **f32)
         done = torch.empty((T, n), dtype=torch.uint8, device=dev)
-        theta = layout.theta()              # the parameters in the kernels' layout (zero-padded hidden units)
+        # the parameters in the kernels' layout (zero-padded hidden units); with a log-std network: the two networks
+        theta = layout.theta() if dual is None else dual[0]
+        theta_std = None if dual is None else dual[2]
+        hs_std = (0, 0, 0) if dual is None else dual[3]
+        log_stds = None if dual is None else torch.empty((da, T, n), **f32)
         assert theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous()
         if eps is not None:
             eps = torch.as_tensor(eps, **f32).contiguous()
@@ -229,12 +234,15 @@ class HipVecEnv(object):
             reset_draws=reset_draws.data_ptr() if reset_draws is not None else None,
             obs=obs.data_ptr(), actions=act.data_ptr(), means=mean.data_ptr(),
             rewards=rew.data_ptr(), dones=done.data_ptr(), last_obs=self._obs.data_ptr(),
-            cfg=ctypes.pointer(self.cfg))
+            cfg=ctypes.pointer(self.cfg),
+            theta_std=None if theta_std is None else theta_std.data_ptr(),
+            log_stds=None if log_stds is None else log_stds.data_ptr(),
+            std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2])
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1
         return Trajectories(obs, act, mean, policy.recorded_log_std(), rew, done,
-                            self.max_path_length)
+                            self.max_path_length, log_std_planes=log_stds)
 
 
 class HipEnv(Env, Serializable):

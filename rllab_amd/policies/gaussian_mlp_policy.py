@@ -134,6 +134,39 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
             self._kernel_layout = KernelLayout(self) if ok else None
         return self._kernel_layout
 
+    def rollout_networks(self):
+        """For a policy with a log-std NETWORK (adaptive_std / std_network) whose two networks the rollout kernels take
+        as they are -- tanh hidden layers of exactly 32 / 64 / 128 units (two or three), linear outputs, float32
+        parameters on the device: ``(theta_mean, hidden3_mean, theta_std, hidden3_std)`` with each theta in the kernels'
+        policy layout [network parameters | action_dim unused floats] (persistent buffers, refreshed when the
+        parameters have moved).  None otherwise (such policies are sampled through the per-transition loop)."""
+        if not self.state_dependent_std:
+            return None
+        if not hasattr(self, "_rollout_nets"):
+            from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM, padded_sizes
+            nets = (self._mean_network, self._std_network)
+            ok = (self.flat_params.is_cuda and self.flat_params.dtype == torch.float32
+                  and self.obs_dim <= MAX_OBS_DIM and self.action_dim <= MAX_ACT_DIM
+                  and all(n.hidden_nonlinearity is tanh and n.output_nonlinearity is None
+                          and padded_sizes(n.hidden_sizes) == tuple(n.hidden_sizes) for n in nets))
+            self._rollout_nets = None
+            if ok:
+                spans = [(n.params[0].offset, n.end_offset - n.params[0].offset) for n in nets]
+                bufs = [torch.zeros(size + self.action_dim, dtype=torch.float32, device=self.flat_params.device)
+                        for _, size in spans]
+                hid = [tuple(n.hidden_sizes) + (0,) * (3 - len(n.hidden_sizes)) for n in nets]
+                self._rollout_nets = dict(spans=spans, bufs=bufs, hidden=hid, tag=None)
+        r = self._rollout_nets
+        if r is None:
+            return None
+        tag = self.param_version()
+        if r["tag"] != tag:
+            flat = self.flat_params.detach()
+            for (off, size), buf in zip(r["spans"], r["bufs"]):
+                buf[:size].copy_(flat[off:off + size])
+            r["tag"] = tag
+        return r["bufs"][0], r["hidden"][0], r["bufs"][1], r["hidden"][1]
+
     def effective_log_std(self, flat=None):
         if self._log_std_param is None:
             raise AttributeError("this policy's log_std depends on the observation (adaptive_std): use "

@@ -64,8 +64,9 @@ class VectorizedSampler(BaseSampler):
 
     def _takes_fused_rollout(self, policy):
         """True when ``obtain_samples`` is ONE asynchronous launch for this policy (the fused rollout kernels)."""
-        return (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None
-                and self.vec_env is not None and self.vec_env.position_ids is None
+        fusable = (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None) or \
+            (hasattr(policy, "rollout_networks") and policy.rollout_networks() is not None)
+        return (fusable and self.vec_env is not None and self.vec_env.position_ids is None
                 and getattr(self.vec_env, "graphable", True))
 
     def prefetch(self, itr):

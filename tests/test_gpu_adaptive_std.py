@@ -157,3 +157,81 @@ def test_trpo_with_adaptive_std_updates_on_the_kernels(quiet_logger):
     moved = np.abs(policy.get_param_values() - theta0)
     n_mean = algo.optimizer._fused.nets[0][1]
     assert moved[:n_mean].max() > 0 and moved[n_mean:].max() > 0
+
+
+@pytest.mark.parametrize("kind,hm,hs", [(0, (32, 32), (32, 32)), (2, (64, 64), (32, 32)), (3, (128, 64, 32), (32, 32)),
+                                        (6, (32, 32), (64, 64))])
+@pytest.mark.parametrize("epw", ["16", "64"])
+def test_fused_rollout_with_a_log_std_network(kind, hm, hs, epw, monkeypatch):
+    """rl_rollout_gaussian_mlp with rl_rollout_args.theta_std: mean AND log-std network evaluated in the kernel every
+    step (gaussian_mlp_policy.py:60-98,132-137), the floored log-stds recorded as agent_info.  Env dynamics replayed on
+    the host build bit for bit; means and log-stds against a float64 torch forward of the two networks;
+    action == mean + eps * exp(log_std)."""
+    from rllab_amd import _lib
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    from oracle.replay import replay_check
+    monkeypatch.setenv("RLLAB_ROLLOUT_EPW", epw)
+    q = _lib.env_query(kind)
+    np.random.seed(2)
+    spec = EnvSpec(Box(-1e6 * np.ones(q["obs_dim"]), 1e6 * np.ones(q["obs_dim"])),
+                   Box(-np.ones(q["act_dim"]), np.ones(q["act_dim"])))
+    policy = GaussianMLPPolicy(spec, hidden_sizes=hm, adaptive_std=True, std_hidden_sizes=hs, min_std=1.0)
+    theta = policy.get_param_values()
+    policy.set_param_values(theta + 0.2 * np.random.randn(theta.size))      # log-stds on both sides of the floor
+    assert policy.kernel_layout() is None and policy.rollout_networks() is not None
+    rng = np.random.RandomState(1)
+    n, T, mpl = 130, 40, 17
+    v = HipVecEnv(kind, n, mpl, normalize=True, seed=11)
+    eps = rng.randn(q["act_dim"], T, n).astype(np.float32)
+    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    traj = v.rollout(policy, T, reset_at_start=True, eps=eps, reset_draws=draws)
+    torch.cuda.synchronize()
+    assert traj.log_std is None and traj.log_std_planes.shape == (q["act_dim"], T, n)
+    assert replay_check(v, traj, max_envs=n, reset_draws=draws) == n * T
+    obs64 = traj.obs.reshape(q["obs_dim"], -1).double()
+    with torch.no_grad():
+        d64 = policy.dist_info_planes(obs64, policy.flat_params.double())
+    got_m = traj.means.reshape(q["act_dim"], -1).double()
+    got_ls = traj.log_std_planes.reshape(q["act_dim"], -1).double()
+    assert float((got_m - d64["mean"]).abs().max()) <= 2e-5
+    assert float((got_ls - d64["log_std"]).abs().max()) <= 2e-5
+    at_floor = float((got_ls == 0.0).double().mean())           # min_std = 1: the floor log(min_std) is exactly 0
+    assert 0.0 < at_floor < 1.0 and float(got_ls.min()) >= 0.0      # the floor is active somewhere, not everywhere
+    act64 = got_m + torch.as_tensor(eps, device=got_m.device).reshape(q["act_dim"], -1).double() * torch.exp(got_ls)
+    # (the kernel's exp is the hardware's: a few ulp of a std of up to ~3, times |eps| up to ~4)
+    err = (traj.actions.reshape(q["act_dim"], -1).double() - act64).abs() / act64.abs().clamp_min(1.0)
+    assert float(err.max()) <= 1e-5
+
+
+def test_adaptive_std_is_sampled_by_the_fused_rollout(quiet_logger):
+    """TRPO + adaptive_std end to end with NOTHING left to the per-transition loop: one rollout launch per iteration."""
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(6)
+    env = normalize(CartpoleEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, adaptive_std=True)
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=512 * 100,
+                max_path_length=100, n_itr=12, sampler_args=dict(n_envs=512))
+    algo.start_worker()
+    algo.init_opt()
+    assert algo.sampler._takes_fused_rollout(policy) and type(algo.optimizer._fused).__name__ == "FusedAdaptiveStdOps"
+    rets = []
+    for itr in range(12):
+        paths = algo.sampler.obtain_samples(itr)
+        assert getattr(algo.sampler, "_step_graph", None) is None               # the hipGraph loop was never built
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.log_diagnostics(paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        rets.append(float(tab["AverageReturn"]))
+        assert float(tab["MeanKL"]) <= 0.0101 and np.isfinite(float(tab["Entropy"]))
+        assert 0.0 < float(tab["AveragePolicyStd"]) < 10.0
+        logger.dump_tabular()
+    assert np.mean(rets[-3:]) > 1.5 * np.mean(rets[:3]), rets
