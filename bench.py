@@ -315,7 +315,7 @@ def main():
     cached = True      # both net widths keep the activations (32 units: LDS-direct prefetch, 64: register prefetch)
     mfma_per_tile = (0 if cached else ht * (ks0 + ks1)) + ht * (ks0 + 2 * ks1) + ht * ks1 + ht * ht * 16
     layout = policy.kernel_layout()
-    wide = layout is not None and layout.wide
+    wide = layout is not None and layout.wide        # (the HIP envs' (obs, action) pairs all have the equal-width kernels)
     if wide:
         # the cooperative kernels of the wide / deep nets recompute the forward pass; algorithmic work of one FVP in
         # multiply-adds per sample, on the REAL layer sizes (padding is the kernels' cost, not the algorithm's):

@@ -984,7 +984,10 @@ extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden
     const size_t rows = MAX_GRID;
     // rl_policy_grad_loss keeps both kinds of partial rows at once
     const size_t a = (rows * P * sizeof(float) + 15) & ~(size_t)15, b = rows * LOSS_COLS * sizeof(double);
-    return a + b;
+    // a net of these widths on an (obs_dim, act_dim) pair the kernels above are not instantiated for runs on the
+    // cooperative kernels (dispatch_net): the workspace covers both
+    const size_t w = wide_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
+    return a + b > w ? a + b : w;
 }
 
 extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1) {

@@ -24,6 +24,10 @@ class FusedGaussianMLPOps(object):
         # what the kernels are told: the padded hidden widths (policies/kernel_layout.py); P_pad parameters
         self.dims = (policy.obs_dim, policy.action_dim) + self.layout.hidden3
         self.n_kernel = self.layout.P_pad
+        # which kernel family the library picks for these dimensions (csrc/policy_kernels.hip::dispatch_net): the
+        # cooperative kernels for wide / deep nets AND for equal-width nets on (obs_dim, action_dim) pairs the
+        # one-wavefront-per-tile kernels are not instantiated for (they take the dimensions at run time)
+        self.wide_kernels = self.layout.wide or (policy.obs_dim, policy.action_dim) not in self.NARROW_PAIRS
         self._ws = None
         self._loss_cache = None
         self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
@@ -47,12 +51,9 @@ class FusedGaussianMLPOps(object):
     @staticmethod
     def supported(policy):
         """Two or three tanh hidden layers of at most 128 units each (zero-padded to the kernels' tiles), learned
-        state-independent std, parameters on the device; for the equal-width two-layer family additionally one of
-        the (obs_dim, action_dim) pairs it is instantiated for."""
+        state-independent std, parameters on the device, obs_dim <= 30, action_dim <= 8 (policy.kernel_layout())."""
         layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
-        if layout is None or not policy.learn_std:
-            return False
-        return layout.wide or (policy.obs_dim, policy.action_dim) in FusedGaussianMLPOps.NARROW_PAIRS
+        return layout is not None and bool(policy.learn_std)
 
     def accepts(self, inputs):
         """The kernels take ONE old log_std row (state-independent std)."""
@@ -178,7 +179,7 @@ class FusedGaussianMLPOps(object):
         out = torch.empty(self.n_kernel, dtype=torch.float64, device=keep[0].device)
         self._acts_tag = None
         b.activations = None
-        if keep_activations and not vpg and not self.layout.wide:     # the cache belongs to the equal-width family
+        if keep_activations and not vpg and not self.wide_kernels:    # the cache belongs to the equal-width family
             need = _lib.lib.rl_policy_activation_bytes(b.n_samples, self.dims[2], self.dims[3])
             if self._acts is None or self._acts.numel() < need or self._acts.device != keep[0].device:
                 self._acts = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
@@ -251,7 +252,7 @@ class FusedGaussianMLPOps(object):
         release / acquire, which on an 8-XCD part writes back and invalidates the per-XCD L2s -- more than the
         launch boundary it saves.  Kept as a tested alternative, off by default."""
         n = self.n_kernel
-        if D.is_distributed() or self.layout.wide or not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
+        if D.is_distributed() or self.wide_kernels or not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
             for _ in range(cg_iters):
                 self._fvp_into(b, ws, p32, z, inputs)
                 _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),

@@ -198,3 +198,35 @@ def test_trpo_on_the_kernels_with_the_reference_experiment_net(hidden, quiet_log
         assert abs(float(tab["MeanKLBefore"])) < 1e-6
         logger.dump_tabular()
     assert np.isfinite(policy.get_param_values()).all() and np.abs(policy.get_param_values() - theta0).max() > 0
+
+
+@pytest.mark.parametrize("do,da,h", [(7, 3, 32), (17, 8, 64), (30, 1, 32), (3, 2, 48)])
+def test_any_observation_and_action_width_stays_on_the_kernels(do, da, h):
+    """The one-wavefront-per-tile kernels are instantiated for the HIP envs' (obs_dim, action_dim) pairs; an equal-width
+    net on ANY other pair (obs_dim <= 30, action_dim <= 8: a user's own env sampled through BatchSampler, say) is
+    dispatched to the cooperative kernels, which take the widths at run time.  Same parity bar."""
+    pol = _policy(do, da, (h, h))
+    ops = pol.fused_ops()
+    assert ops is not None and ops.wide_kernels and not ops.layout.wide
+    inp = U._inputs(pol, 9001)
+    surr, kl, vpg = U._closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    l64, k64 = surr(flat64, *inp), kl(flat64, *inp)
+    s = ops.loss_stats(inp)
+    assert abs(float(-s[0]) - float(l64.detach())) <= 2e-5 * max(1.0, abs(float(l64.detach())))
+    assert abs(float(s[1]) - float(k64.detach())) <= 2e-5 * max(1e-2, abs(float(k64.detach())))
+    g64 = torch.autograd.grad(l64, flat64)[0]
+    g = ops.loss_grad(inp, keep_activations=True)           # the request for the activation cache is simply not taken up
+    assert ops._acts_tag is None
+    assert float((g - g64).abs().max()) <= 2e-5 * max(1e-3, float(g64.abs().max()))
+    inp0 = U._inputs(pol, 5000, old_equals_new=True)
+    with torch.no_grad():
+        om64 = pol.mean_planes(inp0[0].double(), flat64.detach())
+    inp64 = (inp0[0], inp0[1], inp0[2], om64, pol.effective_log_std().detach().double().reshape(-1, 1), inp0[5], inp0[6])
+    gk = torch.autograd.grad(kl(flat64, *inp64), flat64, create_graph=True)[0]
+    v = torch.as_tensor(np.random.RandomState(3).randn(flat64.numel()), device=flat64.device)
+    hv64 = torch.autograd.grad((gk * v).sum(), flat64)[0]
+    hv = ops.fvp(inp0, v)
+    assert float((hv - hv64).abs().max()) <= 5e-5 * float(hv64.abs().max())
+    x, _ = ops.cg(inp0, ops.loss_grad(inp0), 3, 1e-5)
+    assert bool(torch.isfinite(x).all())
