@@ -63,7 +63,11 @@ struct Net {
     static constexpr int FA1 = HT * KS1 * WV;         // floats per layer-1 weight fragment set
     static constexpr int WAVE_LDS = TS * TSTR + TS * XS + TS * GS;
     // wavefronts per SIMD the register budget is declared for (2 x 256 or 1 x 512 registers)
-    static constexpr int WPS = (HT == 1 && DO <= 13) ? 2 : 1;
+    // (-DRL_POLICY_FORCE_WPS1=1: one wavefront per SIMD for every net -- an A/B knob, profiles/r03_notes.md)
+#ifndef RL_POLICY_FORCE_WPS1
+#define RL_POLICY_FORCE_WPS1 0
+#endif
+    static constexpr int WPS = (HT == 1 && DO <= 13 && !RL_POLICY_FORCE_WPS1) ? 2 : 1;
     // wavefronts per workgroup of the update passes.  -DRL_POLICY_WAVES8=1: the nets that run two wavefronts per SIMD
     // take them from ONE workgroup of eight (one staging of the weight fragments and one partial row per CU instead of
     // two) -- measured neutral on MI355X (FVP 0.311 vs 0.3125 ms, gradient 0.220 vs 0.217 ms at 2.048 M samples,
