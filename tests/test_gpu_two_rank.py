@@ -188,6 +188,27 @@ def _peer_worker(rank, world, port, outdir, peer):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(900)
+def test_four_ranks_with_the_in_stream_peer_allreduce(tmp_path):
+    """The same protocol with FOUR processes on the one GPU: every rank writes into three peers' mailboxes and waits for
+    three flags per reduction, the two slots alternate 33 times.  All four ranks end on bit-identical parameters, and
+    they are the host-backend run's to the rounding of a four-term sum taken in a different order."""
+    world = 4
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path), False), nprocs=world, join=True)
+    tp = [np.load(str(tmp_path / ("theta_peer_%d.npy" % r))) for r in range(world)]
+    th = [np.load(str(tmp_path / ("theta_host_%d.npy" % r))) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(tp[0], tp[r]) and np.array_equal(th[0], th[r])
+    # gloo's ring adds the four rows in its own order; the peer kernel in rank order: same sums to float64 rounding,
+    # which three TRPO iterations (CG on an ill-conditioned matrix, a discrete line search) may amplify a little
+    theta0 = _initial_theta("swimmer")
+    moved = np.abs(th[0] - theta0).max()
+    assert moved > 0 and np.abs(tp[0] - th[0]).max() <= 1e-3 * moved, (np.abs(tp[0] - th[0]).max(), moved)
+    cp = np.load(str(tmp_path / "counts_peer_0.npy"))
+    assert np.all(cp[:, 1] == 11) and np.all(cp[:, 0] <= 6), cp
+
+
 @pytest.mark.timeout(600)
 def test_two_ranks_with_the_in_stream_peer_allreduce(tmp_path):
     """RLLAB_PEER_ALLREDUCE=1: the gradient and the ten Fisher-vector products of a TRPO update are summed across ranks
