@@ -344,13 +344,33 @@ def main():
         torch.cuda.synchronize()
         fvp_ms = e0.elapsed_time(e1) / 20
         ops.release()
-    lane_group = wl["env"] == "swimmer" and not wide and not os.environ.get("RLLAB_SWIMMER_LANE_KERNEL")
-    envs_per_wave = 16 if (lane_group or (wide and n_envs <= 16 * 1024)) else 64
+    # which rollout kernel rl_rollout_gaussian_mlp picks (csrc/env_kernels.hip, the launch rules at the end of the file):
+    # the lane-group kernels (16 envs per wavefront, four lanes per env in the physics sub-steps) for the Swimmer and
+    # for the two-leg envs up to 16 384 envs; otherwise 16 envs per wavefront while every wavefront still gets a SIMD
+    # of its own (<= 16 384 envs), one env per lane beyond
+    forced_epw = os.environ.get("RLLAB_ROLLOUT_EPW")
+    equal_hidden = len(wl["hidden"]) == 2 and wl["hidden"][0] == wl["hidden"][1] and wl["hidden"][0] in (32, 64)
+    if wl["env"] == "swimmer":
+        lane_group = not os.environ.get("RLLAB_SWIMMER_LANE_KERNEL") and 13 * T * n_envs * 4 < 2 ** 32 and (
+            equal_hidden or (wide and forced_epw is None))
+    elif wl["env"] in ("half_cheetah", "walker2d"):
+        lane_group = os.environ.get("RLLAB_TWO_LEG_LANE_KERNEL", "1")[:1] != "0" and forced_epw is None and \
+            n_envs <= 16 * 1024 and (equal_hidden or wide)
+    else:
+        lane_group = False
+    envs_per_wave = 16 if lane_group else (int(forced_epw) if forced_epw in ("16", "64") else
+                                           (16 if n_envs <= 16 * 1024 else 64))
     n_waves = (n_envs + envs_per_wave - 1) // envs_per_wave
-    rollout_name = ("rollout_swimmer_quad_kernel (fused policy + env step + record; 16 envs per wavefront, four "
-                    "lanes per env in the physics sub-steps)") if lane_group else \
-        ("rollout_wide_kernel (fused wide / deep policy + env step + record; weight fragments in LDS)" if wide else
-         "rollout_kernel (fused policy + env step + record; one env per lane)")
+    if lane_group:
+        rollout_name = "rollout_%s_quad_%skernel (fused policy + env step + record; 16 envs per wavefront, %s)" % (
+            "swimmer" if wl["env"] == "swimmer" else "two_leg", "wide_" if wide else "",
+            "four lanes per env in the physics sub-steps" if wl["env"] == "swimmer" else
+            "a lane group per env with one leg per lane in the physics sub-steps")
+    elif wide:
+        rollout_name = "rollout_wide_kernel (fused wide / deep policy + env step + record; weight fragments in LDS)"
+    else:
+        rollout_name = "rollout_kernel (fused policy + env step + record; %s)" % (
+            "one env per lane" if envs_per_wave == 64 else "16 envs per wavefront, the physics replicated in four lanes")
     out = {
         "metric": "env steps/sec over full TRPO iterations (sample + process + update), 4096 envs per MI355X",
         "value": value, "unit": "env_steps/s", "n_gpus": world, "steps": args.steps,
