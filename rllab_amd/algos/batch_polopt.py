@@ -12,6 +12,7 @@ import time
 import rllab_amd.misc.logger as logger
 from rllab_amd.algos.base import RLAlgorithm
 from rllab_amd.sampler.base import BaseSampler
+from rllab_amd.sampler import dist as D
 from rllab_amd.sampler import parallel_sampler
 from rllab_amd.sampler.utils import truncate_paths
 
@@ -119,6 +120,7 @@ class BatchPolopt(RLAlgorithm):
         for itr in range(self.current_itr, self.n_itr):
             self.train_iteration(itr)
         self.shutdown_worker()
+        D.peer_shutdown()
 
     def train_iteration(self, itr):
         """One pass of the reference's loop body (batch_polopt.py:119-132)."""
@@ -128,6 +130,7 @@ class BatchPolopt(RLAlgorithm):
             samples_data = self.sampler.process_samples(itr, paths)
             self.log_diagnostics(paths)
             self.optimize_policy(itr, samples_data)
+            D.peer_poll()           # in-stream peer all-reduce (RLLAB_PEER_ALLREDUCE=1): did a peer stop answering?
             # the next rollout depends on nothing below: start it before the host turns to snapshot and log
             if itr + 1 < self.n_itr and hasattr(self.sampler, "prefetch") and not self.store_paths \
                     and getattr(self, "prefetch_rollout", True):

@@ -19,6 +19,7 @@
 // seq + 1, which it does after it finished reading seq.
 // Every spin is bounded (a missing peer sets *err and the launch completes; the host raises at its next check).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/rllab_amd.h"
 #include "capi_util.h"
@@ -149,7 +150,13 @@ extern "C" int rl_peer_allreduce_sum(int n, double* data, int rank, int world, v
     for (int p = 0; p < PEER_MAX_WORLD; ++p) a.box[p] = p < world ? (char*)mailboxes[p] : nullptr;
     for (int p = 0; p < world; ++p)
         if (!a.box[p]) return set_error(RL_ERR_ARG, "rl_peer_allreduce_sum: mailbox %d is null", p);
-    a.spin_limit = 4000000;          // x (s_sleep 8 + one load) ~ seconds: a peer that never arrives is an error
+    // x (s_sleep 8 + one load) ~ seconds: a peer that never arrives is an error.  RLLAB_PEER_SPIN_LIMIT: tests of the
+    // give-up path make it milliseconds.
+    a.spin_limit = 4000000;
+    if (const char* sl = getenv("RLLAB_PEER_SPIN_LIMIT")) {
+        const long long v = atoll(sl);
+        if (v > 0) a.spin_limit = v;
+    }
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(PEER_THREADS), 0, (hipStream_t)stream, a);
     return check_launch("peer_allreduce_kernel");
 }

@@ -131,6 +131,7 @@ class PeerReducer(object):
         self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
         self.seq = 0
         self.count = 0
+        self._pending = None                # (async read of the error flag, reduction count it covers)
         dist.barrier()                      # nobody writes into a mailbox that is not mapped everywhere yet
 
     def all_reduce_sum_(self, t):
@@ -142,14 +143,30 @@ class PeerReducer(object):
                                                 self.seq, lib.ptr(self.err), lib.stream_ptr()), "rl_peer_allreduce_sum")
         return t
 
+    def _raise(self, e, upto):
+        raise RuntimeError("peer all-reduce: rank %d never delivered a row (a reduction <= %d of this process gave up "
+                           "waiting; the sums since then are not the world's)" % (e - 1, upto))
+
     def check(self):
         """Blocking: raises if any reduction so far gave up waiting for a peer."""
         e = int(self.err.item())
         if e:
-            raise RuntimeError("peer all-reduce: rank %d never delivered a row (reduction <= %d)" % (e - 1, self.seq))
+            self._raise(e, self.seq)
+
+    def poll(self):
+        """Non-blocking form for the training loop, once per iteration: starts reading the error flag behind the
+        launches queued so far and raises on what the PREVIOUS poll read (that copy finished an iteration ago), so
+        a peer that stopped answering ends the run within one iteration instead of training on partial sums."""
+        from rllab_amd.misc.device_io import read_async
+        prev, self._pending = self._pending, (read_async(self.err), self.seq)
+        if prev is not None:
+            e = int(prev[0].get()[0])
+            if e:
+                self._raise(e, prev[1])
 
     def close(self):
         torch.cuda.synchronize()
+        e = int(self.err.item())            # the reductions no poll has covered yet
         dist.barrier()
         for p in self._opened:
             self._lib.lib.rl_peer_close(p)
@@ -157,6 +174,8 @@ class PeerReducer(object):
         if self._own is not None:
             self._lib.lib.rl_peer_free(self._own)
             self._own = None
+        if e:
+            self._raise(e, self.seq)
 
 
 def peer_reducer():
@@ -168,11 +187,18 @@ def peer_reducer():
     return _peer
 
 
+def peer_poll():
+    """Once per training iteration (BatchPolopt.train_iteration): see PeerReducer.poll.  Free when the peer path is off."""
+    if _peer is not None:
+        _peer.poll()
+
+
 def peer_shutdown():
+    """Unmap the mailboxes (collective: every rank calls it); raises if a reduction gave up waiting for a peer."""
     global _peer
     if _peer is not None:
-        _peer.close()
-        _peer = None
+        pr, _peer = _peer, None
+        pr.close()
 
 
 def update_sum_(t):

@@ -179,6 +179,7 @@ def _peer_worker(rank, world, port, outdir, peer):
     torch.cuda.synchronize()
     if peer:
         assert D.peer_reducer() is not None and D.peer_reducer().count == sum(c[1] for c in counts)
+        D.peer_poll()
         D.peer_reducer().check()                    # no reduction gave up waiting for its peer
     tag = "peer" if peer else "host"
     np.save(os.path.join(outdir, "theta_%s_%d.npy" % (tag, rank)), policy.get_param_values())
