@@ -317,22 +317,22 @@ def main():
     layout = policy.kernel_layout()
     wide = layout is not None and layout.wide        # (the HIP envs' (obs, action) pairs all have the equal-width kernels)
     if wide:
-        # the cooperative kernels of the wide / deep nets recompute the forward pass; algorithmic work of one FVP in
-        # multiply-adds per sample, on the REAL layer sizes (padding is the kernels' cost, not the algorithm's):
-        # forward + tangent (two products per layer beyond the first) + back-propagation + the outer products
+        # the cooperative kernels of the wide / deep nets: algorithmic work of one FVP in multiply-adds per sample, on
+        # the REAL layer sizes (padding is the kernels' cost, not the algorithm's): tangent (two products per layer
+        # beyond the first) + back-propagation + the outer products; the forward pass is read back from the gradient
+        # pass's activation cache, as for the equal-width nets
         ins = (do + 1,) + tuple(wl["hidden"])
         pw = sum(ins[l] * ins[l + 1] for l in range(len(ins) - 1))
         first = ins[0] * ins[1]
-        macs = pw + (2 * pw - first) + (pw - first) + pw
+        macs = (2 * pw - first) + (pw - first) + pw
         mfma_per_tile = macs * 32 / 2048.0             # one v_mfma_f32_32x32x2_f32 = 2048 multiply-adds
-        cached = False
     fvp_ms = None
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None
     if ops is not None:
         from rllab_amd.algos.npo import npo_inputs
         inp = npo_inputs(policy, last["samples"])
         v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
-        ops.loss_grad(inp, keep_activations=not wide)     # as ConjugateGradientOptimizer.optimize does before CG
+        ops.loss_grad(inp, keep_activations=True)     # as ConjugateGradientOptimizer.optimize does before CG
         for _ in range(3):
             ops.fvp(inp, v)
         torch.cuda.synchronize()

@@ -288,7 +288,7 @@ typedef struct rl_policy_batch {
     const float* old_means;    /* [Da][B]  agent_infos["mean"] */
     const float* old_log_std;  /* [Da]     agent_infos["log_std"] (one constant row) */
     const float* weights;      /* [B] 0/1 validity */
-    float* activations;        /* NULL (always, when rl_policy_activation_bytes() is 0 for the net), or that many bytes
+    float* activations;        /* NULL, or rl_policy_activation_bytes() bytes
                                 * of device scratch: rl_policy_grad (vpg == 0)
                                 * leaves the hidden activations of every sample there and rl_policy_fvp reads them
                                 * instead of re-evaluating the forward pass.  The caller guarantees that an FVP call
@@ -311,9 +311,9 @@ enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1 };
 /* Scratch the three calls below need (device memory, caller-owned, reusable). */
 size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1, int hidden2);
 
-/* Size of rl_policy_batch.activations for a batch of n_samples (2 * hidden floats per sample, tile padded); 0 for
- * nets without the cache (anything but two equal layers of 32 or 64 units). */
-size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1);
+/* Size of rl_policy_batch.activations for a batch of n_samples (one float per sample and hidden unit, padded to
+ * 32-sample tiles); 0 for hidden sizes the kernels do not take (each layer 32 / 64 / 128 units, hidden2 = 0: two layers). */
+size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1, int hidden2);
 
 /* out4 (device, 4 doubles) = [ sum_b w lr adv, sum_b w KL, sum_b w logp adv, max_b KL ] at theta:
  * surrogate loss = -out4[0]*inv_count, mean KL = out4[1]*inv_count.  Replaces the compiled

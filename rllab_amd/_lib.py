@@ -113,7 +113,7 @@ def _load():
     lib.rl_policy_workspace_bytes.restype = ctypes.c_size_t
     lib.rl_policy_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.rl_policy_activation_bytes.restype = ctypes.c_size_t
-    lib.rl_policy_activation_bytes.argtypes = [i32, i32, i32]
+    lib.rl_policy_activation_bytes.argtypes = [i32, i32, i32, i32]
     lib.rl_policy_loss_kl.argtypes = [pb, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_grad.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_grad_loss.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp, vp]

@@ -990,10 +990,13 @@ extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden
     return a + b > w ? a + b : w;
 }
 
-extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1) {
-    if (n_samples <= 0 || hidden0 != hidden1 || (hidden0 != 32 && hidden0 != 64)) return 0;
+extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1, int hidden2) {
+    // one float per sample and hidden unit, in 32-sample tiles -- the same size for both kernel families (two equal
+    // layers of 32 / 64 units: 2 * (hidden / 32) fragments of 16 x 64 floats per tile)
+    auto ok = [](int h) { return h == 32 || h == 64 || h == 128; };
+    if (n_samples <= 0 || !ok(hidden0) || !ok(hidden1) || (hidden2 != 0 && !ok(hidden2))) return 0;
     const size_t n_tiles = ((size_t)n_samples + TS - 1) / TS;
-    return n_tiles * 2 * (size_t)(hidden0 / 32) * 16 * WV * sizeof(float);
+    return n_tiles * (size_t)TS * (size_t)(hidden0 + hidden1 + hidden2) * sizeof(float);
 }
 
 extern "C" int rl_policy_loss_kl(const rl_policy_batch* g, void* workspace, size_t workspace_bytes,

@@ -38,6 +38,7 @@ namespace rl {
 int launch_reduce_rows(const float* partial, int rows, int cols, double* out, hipStream_t st);   // policy_kernels.hip
 int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t st);
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int WW = 4;                  // wavefronts per workgroup = row tiles of the widest layer
 constexpr int WNT = WW * WV;
 constexpr int BS = WIDE_BS;
@@ -60,6 +61,10 @@ struct WideBatch {
     float inv_count, log_min_std, kl_penalty;
     float* partial;            // [grid][P]
     double* partial_loss;      // [grid][4] or null
+    float* cache;              // hidden activations of every tile (rl_policy_batch.activations): the gradient pass writes
+                               // them, the Fisher-vector products of the same point read them instead of re-running the
+                               // forward chains; null = none.  Per tile 32 (H0 + H1 + H2) floats, layer after layer, each
+                               // row tile in the register layout of its owner: [quarter j][lane][4] = h[4 j .. 4 j + 3]
     WideShape s;
 };
 
@@ -283,6 +288,13 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
     }
     WidePre pre;
     pre.valid = false;
+    // activation cache (wave-uniform kernel argument): GRAD writes, FVP reads
+    const bool cache_rd = FVP && a.cache != nullptr, cache_wr = (MODE == WMODE_GRAD) && a.cache != nullptr;
+    int coff[L];
+    coff[0] = 0;
+#pragma unroll
+    for (int l = 1; l < L; ++l) coff[l] = coff[l - 1] + 32 * s.H[l - 1];
+    const size_t ctile = (size_t)coff[L - 1] + 32 * s.H[L - 1];
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile * 32 + lj;
@@ -302,6 +314,21 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
         // partial accumulators of q >= 1 meet in LDS and the owner (q = 0) finishes the tile, so every SIMD's matrix
         // pipe works in the narrow layers of nets like (128, 64, 32) too.
         f32x16 h[L];
+        if (cache_rd) {
+            // the owners fetch their fragments now; the loads land under the first tangent chain
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if (job[l].busy && job[l].q == 0) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(a.cache + (size_t)tile * ctile + coff[l]) +
+                                       (size_t)job[l].t * 4 * WV + lane;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = src[j * WV];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) h[l][4 * j + c] = v[c];
+                    }
+                }
+        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const float* bin = (l == 0) ? X : smem + p.Hb[l - 1];
@@ -309,35 +336,51 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             // the chain this wavefront runs next (for the operand prefetch): the tangent chains of this layer, else the
             // first chain of the next layer, else (last layer, gradient-like modes) nothing -- the head sits in between
             const float* nxt_h = FVP ? J.dim : (l + 1 < L && job[l + 1].busy ? job[l + 1].im : nullptr);
-            f32x16 acc;
-            if (J.busy) {
+            if (cache_rd) {
+                // forward pass read back from the gradient pass's cache: publish the fragment, no chain, no tanh
+                if (J.busy && J.q == 0) wide_put(smem + p.Hb[l], J.t, lane, h[l]);
+            } else {
+                f32x16 acc;
+                if (J.busy) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[r] = (l >= 1 && J.q == 0) ? tail[s.tb[l] + 32 * J.t + frag_unit(r, 0) + 4 * lh] : 0.0f;
-                acc = wide_gemm_any(J.im, J.chunk, bin + 2 * J.k0 * BS, lane, acc, pre, nxt_h);
-            }
-            if (KSPLIT && J.ksp > 1) {                              // wave-uniform: partial accumulators -> the owner
-                float* kr = smem + p.kred;
-                if (J.q > 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) kr[((wave - J.HT) * 16 + r) * WV + lane] = acc[r];
+                    for (int r = 0; r < 16; ++r)
+                        acc[r] = (l >= 1 && J.q == 0) ? tail[s.tb[l] + 32 * J.t + frag_unit(r, 0) + 4 * lh] : 0.0f;
+                    acc = wide_gemm_any(J.im, J.chunk, bin + 2 * J.k0 * BS, lane, acc, pre, nxt_h);
                 }
-                __syncthreads();
-                if (J.q == 0) {
-                    for (int qq = 1; qq < J.ksp; ++qq)
+                if (KSPLIT && J.ksp > 1) {                              // wave-uniform: partial accumulators -> the owner
+                    float* kr = smem + p.kred;
+                    if (J.q > 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] += kr[((J.t + J.HT * qq - J.HT) * 16 + r) * WV + lane];
+                        for (int r = 0; r < 16; ++r) kr[((wave - J.HT) * 16 + r) * WV + lane] = acc[r];
+                    }
+                    __syncthreads();
+                    if (J.q == 0) {
+                        for (int qq = 1; qq < J.ksp; ++qq)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[r] += kr[((J.t + J.HT * qq - J.HT) * 16 + r) * WV + lane];
+                    }
                 }
-            }
-            if (J.busy && J.q == 0) {
+                if (J.busy && J.q == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h[l][r] = ftanh(acc[r]);
-                wide_put(smem + p.Hb[l], J.t, lane, h[l]);
+                    for (int r = 0; r < 16; ++r) h[l][r] = ftanh(acc[r]);
+                    wide_put(smem + p.Hb[l], J.t, lane, h[l]);
+                    if (cache_wr) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(a.cache + (size_t)tile * ctile + coff[l]) +
+                                     (size_t)J.t * 4 * WV + lane;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 v;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = h[l][4 * j + c];
+                            dst[j * WV] = v;
+                        }
+                    }
+                }
             }
             if (FVP) {
                 f32x16 dacc;
                 if (J.busy) {
-                    const float* nxt_d = (l + 1 < L && job[l + 1].busy) ? job[l + 1].im : nullptr;
+                    const float* nxt_d = (l + 1 < L && job[l + 1].busy) ? (cache_rd ? job[l + 1].dim : job[l + 1].im) : nullptr;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         dacc[r] = (l >= 1 && J.q == 0) ? dtail[s.tb[l] + 32 * J.t + frag_unit(r, 0) + 4 * lh] : 0.0f;
@@ -725,6 +768,7 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std; a.kl_penalty = g->kl_penalty;
+    a.cache = (MODE == WMODE_GRAD || MODE == WMODE_FVP) ? g->activations : nullptr;
     const int n_tiles = (a.B + 31) / 32;
     const WideLds p = wide_lds(s, MODE);
     const size_t lds = (size_t)p.total * sizeof(float);
@@ -811,8 +855,6 @@ int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws
                          "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d,%d): two or three tanh layers "
                          "of 32 / 64 / 128 units, obs_dim <= %d, act_dim <= %d",
                          g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, WIDE_MAX_DO, WIDE_MAX_DA);
-    if (g->activations)
-        return set_error(RL_ERR_ARG, "the activation cache belongs to the 32 / 64-unit two-layer kernels");
     return s.L == 2 ? wide_shape_class<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
                     : wide_shape_class<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }

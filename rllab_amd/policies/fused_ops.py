@@ -179,8 +179,9 @@ class FusedGaussianMLPOps(object):
         out = torch.empty(self.n_kernel, dtype=torch.float64, device=keep[0].device)
         self._acts_tag = None
         b.activations = None
-        if keep_activations and not vpg and not self.wide_kernels:    # the cache belongs to the equal-width family
-            need = _lib.lib.rl_policy_activation_bytes(b.n_samples, self.dims[2], self.dims[3])
+        need = _lib.lib.rl_policy_activation_bytes(b.n_samples, self.dims[2], self.dims[3], self.dims[4]) \
+            if keep_activations and not vpg else 0
+        if need:
             if self._acts is None or self._acts.numel() < need or self._acts.device != keep[0].device:
                 self._acts = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
             b.activations = self._acts.data_ptr()

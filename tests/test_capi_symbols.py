@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.rl_abi_version() == 8
+    assert _lib.lib.rl_abi_version() == 9
 
 
 def test_env_query_and_errors():
@@ -52,7 +52,8 @@ def test_env_query_and_errors():
     # the wide / deep family: two or three layers of 32 / 64 / 128 units
     assert _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 64, 32) > _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 64, 0) > 0
     assert _lib.lib.rl_policy_workspace_bytes(13, 2, 128, 96, 0) == 0 and _lib.lib.rl_policy_workspace_bytes(13, 2, 256, 32, 0) == 0
-    assert _lib.lib.rl_policy_activation_bytes(1000, 128, 128) == 0
+    assert _lib.lib.rl_policy_activation_bytes(1000, 128, 128, 0) == 32 * 32 * 256 * 4      # 1000 samples -> 32 tiles
+    assert _lib.lib.rl_policy_activation_bytes(1000, 100, 50, 25) == 0                        # the caller pads first
     # peer all-reduce: argument errors without touching a device
     assert _lib.lib.rl_peer_mailbox_bytes(8, 1572) == 128 + 2 * 8 * 1572 * 8 and _lib.lib.rl_peer_mailbox_bytes(9, 4) == 0
     assert _lib.lib.rl_peer_allreduce_sum(0, None, 0, 1, None, 4, 1, None, None) == -1

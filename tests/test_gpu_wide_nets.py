@@ -102,6 +102,40 @@ def test_fvp_equals_kl_hessian_at_theta_old(do, da, hidden):
     assert abs(a - b) <= 1e-4 * max(abs(a), abs(b))
 
 
+@pytest.mark.parametrize("do,da,hidden", WIDE_SHAPES + [(7, 3, (32, 32)), (17, 8, (64, 64))])
+@pytest.mark.parametrize("B", [1, 63, 1000, 70001])
+def test_fvp_on_cached_activations_is_the_same_product(do, da, hidden, B):
+    """The cooperative kernels' form of tests/test_gpu_update_parity.py's cache test: rl_policy_grad with
+    batch.activations set leaves every layer's activations in device memory (rl_policy_activation_bytes: one float per
+    sample and PADDED hidden unit), rl_policy_fvp then runs no forward chain -- the same gradient and the same product
+    bit for bit, through CG as well; a parameter update drops the cache."""
+    pol = _policy(do, da, hidden)
+    ops = pol.fused_ops()
+    assert ops.wide_kernels
+    inp = U._inputs(pol, B, old_equals_new=True)
+    v = torch.as_tensor(np.random.RandomState(5).randn(pol.flat_params.numel()), device="cuda")
+    want_g, want_hv = ops.loss_grad(inp), ops.fvp(inp, v)
+    assert ops._acts_tag is None
+    g = ops.loss_grad(inp, keep_activations=True)
+    padded = ops.dims[2] + ops.dims[3] + ops.dims[4]
+    assert ops._acts_tag is not None and ops._acts.numel() == ((B + 31) // 32) * 32 * padded * 4
+    hv = ops.fvp(inp, v)
+    assert torch.equal(g, want_g)
+    assert torch.equal(hv, want_hv)
+    x, xhx = ops.cg(inp, want_g, 3, 1e-5)
+    ops._acts_tag = None
+    x2, xhx2 = ops.cg(inp, want_g, 3, 1e-5)
+    assert torch.equal(x, x2) and torch.equal(xhx, xhx2)
+    ops.loss_grad(inp, keep_activations=True)
+    with torch.no_grad():
+        pol.flat_params.add_(0.01)
+    hv_new = ops.fvp(inp, v)
+    ops._acts_tag = None
+    assert torch.equal(hv_new, ops.fvp(inp, v)) and not torch.equal(hv_new, want_hv)
+    ops.loss_grad(inp, vpg=True, keep_activations=True)
+    assert ops._acts_tag is None
+
+
 @pytest.mark.parametrize("do,da,hidden", [(13, 2, (100, 50, 25)), (20, 6, (128, 128))])
 def test_penalised_surrogate_value_and_gradient(do, da, hidden):
     """PPO's objective (surrogate + penalty * mean KL, penalty_lbfgs_optimizer.py:66-79) from one pass."""
@@ -216,8 +250,8 @@ def test_any_observation_and_action_width_stays_on_the_kernels(do, da, h):
     assert abs(float(-s[0]) - float(l64.detach())) <= 2e-5 * max(1.0, abs(float(l64.detach())))
     assert abs(float(s[1]) - float(k64.detach())) <= 2e-5 * max(1e-2, abs(float(k64.detach())))
     g64 = torch.autograd.grad(l64, flat64)[0]
-    g = ops.loss_grad(inp, keep_activations=True)           # the request for the activation cache is simply not taken up
-    assert ops._acts_tag is None
+    g = ops.loss_grad(inp, keep_activations=True)
+    assert ops._acts_tag is not None                        # the cooperative kernels keep their activations too
     assert float((g - g64).abs().max()) <= 2e-5 * max(1e-3, float(g64.abs().max()))
     inp0 = U._inputs(pol, 5000, old_equals_new=True)
     with torch.no_grad():

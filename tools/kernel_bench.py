@@ -65,6 +65,14 @@ def main():
             print(json.dumps(dict(kernel=name, net=[do, da, list(hidden)], samples=B, ms=round(ms, 4),
                                   tflops=round(mult * fwd_flops * B / ms / 1e9, 2),
                                   gbps=round(4 * (do + 3 * da + 1) * B / ms / 1e6, 1))))
+        # what TRPO launches: the gradient pass leaves its activations, the products read them back
+        ms = timeit(lambda: ops.loss_grad(inp, keep_activations=True))
+        print(json.dumps(dict(kernel="grad+cache", net=[do, da, list(hidden)], samples=B, ms=round(ms, 4))))
+        ops.loss_grad(inp, keep_activations=True)
+        ms = timeit(lambda: ops.fvp(inp, v))
+        print(json.dumps(dict(kernel="fvp cached", net=[do, da, list(hidden)], samples=B, ms=round(ms, 4),
+                              tflops=round(5.0 * fwd_flops * B / ms / 1e9, 2))))
+        ops.release()
 
 
 if __name__ == "__main__":
