@@ -63,8 +63,8 @@ struct WideBatch {
     double* partial_loss;      // [grid][4] or null
     float* cache;              // hidden activations of every tile (rl_policy_batch.activations): the gradient pass writes
                                // them, the Fisher-vector products of the same point read them instead of re-running the
-                               // forward chains; null = none.  Per tile 32 (H0 + H1 + H2) floats, layer after layer, each
-                               // row tile in the register layout of its owner: [quarter j][lane][4] = h[4 j .. 4 j + 3]
+                               // forward chains; null = none.  Per tile 32 (H0 + H1 + H2) floats: [unit, layer after
+                               // layer][32 samples], the image of the LDS tiles Hb without their padding column
     WideShape s;
 };
 
@@ -132,6 +132,64 @@ struct WidePre {
     float v[4];
     bool valid;
 };
+// RL_WIDE_PINGPONG=1: two operand buffers used in turn instead of one refilled by register moves.  Measured (MI355X,
+// 2.048 M samples, on the activation cache): neutral for two layers ((128,128) FVP 3.76 vs 3.74 ms), worse for three
+// ((128,64,32) 3.72 vs 3.16 ms: the duplicated chain bodies cost 45 spilled registers) -- off.
+#ifndef RL_WIDE_PINGPONG
+#define RL_WIDE_PINGPONG 0
+#endif
+#if RL_WIDE_PINGPONG
+template <int U>
+__device__ __forceinline__ f32x16 wide_gemm(const float* __restrict__ img, int ks, const float* bt, int lane,
+                                            f32x16 acc, WidePre& pre, const float* __restrict__ next) {
+    const int lj = lane & 31, lh = lane >> 5;
+    const float* bp = bt + lh * BS + lj;
+    // two operand buffers used in turn (no register rotation): while round n runs on one, the loads of round n + 1
+    // fill the other
+    float a0[U], a1[U];
+    if (pre.valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] = pre.v[j];
+#pragma unroll
+        for (int j = 4; j < U; ++j) a0[j] = img[j * WV + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) a0[j] = img[j * WV + lane];
+    }
+    pre.valid = false;
+    int base = 0;
+    while (true) {
+        const bool more_a = base + U < ks;
+        if (more_a) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) a1[j] = img[(base + U + j) * WV + lane];
+        } else if (next != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre.v[j] = next[j * WV + lane];
+            pre.valid = true;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc = mfma(a0[j], bp[(2 * (base + j)) * BS], acc);
+        if (!more_a) break;
+        base += U;
+        const bool more_b = base + U < ks;
+        if (more_b) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) a0[j] = img[(base + U + j) * WV + lane];
+        } else if (next != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre.v[j] = next[j * WV + lane];
+            pre.valid = true;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc = mfma(a1[j], bp[(2 * (base + j)) * BS], acc);
+        if (!more_b) break;
+        base += U;
+    }
+    return acc;
+}
+#else
+// (A/B form: one operand buffer refilled by register moves from the prefetch buffer -- one v_mov per k-step)
 template <int U>
 __device__ __forceinline__ f32x16 wide_gemm(const float* __restrict__ img, int ks, const float* bt, int lane,
                                             f32x16 acc, WidePre& pre, const float* __restrict__ next) {
@@ -167,6 +225,7 @@ __device__ __forceinline__ f32x16 wide_gemm(const float* __restrict__ img, int k
     }
     return acc;
 }
+#endif
 // the chunk length picks the round size (wave-uniform)
 __device__ __forceinline__ f32x16 wide_gemm_any(const float* __restrict__ img, int ks, const float* bt, int lane,
                                                 f32x16 acc, WidePre& pre, const float* __restrict__ next) {
@@ -179,6 +238,17 @@ __device__ __forceinline__ void wide_put(float* bt, int t, int lane, const f32x1
     const int lj = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bt[(32 * t + frag_unit(r, 0) + 4 * lh) * BS + lj] = v[r];
+}
+
+// ... and read it back (the owner of a row tile re-reads its own publication where the tanh derivative is needed, instead
+// of holding 16 registers per layer from the forward pass to the end of back-propagation; LDS operations of one
+// wavefront complete in order, no barrier between its write and its read)
+__device__ __forceinline__ f32x16 wide_get(const float* bt, int t, int lane) {
+    const int lj = lane & 31, lh = lane >> 5;
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = bt[(32 * t + frag_unit(r, 0) + 4 * lh) * BS + lj];
+    return v;
 }
 
 // Workgroups per CU the register budget is declared for.  Two (two wavefronts per SIMD, 256 registers each): one
@@ -306,6 +376,26 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             const int bb = tile * 32 + sm;
             X[d * BS + sm] = a.obs[(size_t)d * B + (bb < B ? bb : B - 1)];
         }
+        if (cache_rd) {
+            // the forward pass of this tile as the gradient pass left it: every layer's activations straight into their
+            // LDS tiles (consecutive: Hb[l] = Hb[0] + BS * (units before layer l)), in flight together with the input tile
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.cache + (size_t)tile * ctile);
+            float* hb0 = smem + p.Hb[0];
+            const int n4 = (int)(ctile / 4);
+            for (int e0 = tid; e0 < n4; e0 += 4 * WNT) {     // four 16-byte loads in flight per thread and round
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = src[e0 + j * WNT < n4 ? e0 + j * WNT : e0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j * WNT;
+                    if (e < n4) {
+                        float* dst = hb0 + (e >> 3) * BS + 4 * (e & 7);
+                        dst[0] = v[j][0]; dst[1] = v[j][1]; dst[2] = v[j][2]; dst[3] = v[j][3];
+                    }
+                }
+            }
+        }
         __syncthreads();
 
         // ---- forward (+ tangent) through the hidden layers ---------------------------------------------------------
@@ -313,22 +403,6 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
         // tile are SPLIT over 4 / HT wavefronts -- wavefront w works on tile t = w % HT, k-range q = w / HT -- the
         // partial accumulators of q >= 1 meet in LDS and the owner (q = 0) finishes the tile, so every SIMD's matrix
         // pipe works in the narrow layers of nets like (128, 64, 32) too.
-        f32x16 h[L];
-        if (cache_rd) {
-            // the owners fetch their fragments now; the loads land under the first tangent chain
-#pragma unroll
-            for (int l = 0; l < L; ++l)
-                if (job[l].busy && job[l].q == 0) {
-                    const f32x4* src = reinterpret_cast<const f32x4*>(a.cache + (size_t)tile * ctile + coff[l]) +
-                                       (size_t)job[l].t * 4 * WV + lane;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 v = src[j * WV];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) h[l][4 * j + c] = v[c];
-                    }
-                }
-        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const float* bin = (l == 0) ? X : smem + p.Hb[l - 1];
@@ -337,8 +411,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             // first chain of the next layer, else (last layer, gradient-like modes) nothing -- the head sits in between
             const float* nxt_h = FVP ? J.dim : (l + 1 < L && job[l + 1].busy ? job[l + 1].im : nullptr);
             if (cache_rd) {
-                // forward pass read back from the gradient pass's cache: publish the fragment, no chain, no tanh
-                if (J.busy && J.q == 0) wide_put(smem + p.Hb[l], J.t, lane, h[l]);
+                // (nothing: the activations of every layer are in their tiles since the staging of this tile)
             } else {
                 f32x16 acc;
                 if (J.busy) {
@@ -362,18 +435,12 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                 }
                 if (J.busy && J.q == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) h[l][r] = ftanh(acc[r]);
-                    wide_put(smem + p.Hb[l], J.t, lane, h[l]);
+                    for (int r = 0; r < 16; ++r) acc[r] = ftanh(acc[r]);
+                    wide_put(smem + p.Hb[l], J.t, lane, acc);
                     if (cache_wr) {
-                        f32x4* dst = reinterpret_cast<f32x4*>(a.cache + (size_t)tile * ctile + coff[l]) +
-                                     (size_t)J.t * 4 * WV + lane;
+                        float* dst = a.cache + (size_t)tile * ctile + coff[l] + (32 * J.t + 4 * lh) * 32 + lj;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4 v;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) v[c] = h[l][4 * j + c];
-                            dst[j * WV] = v;
-                        }
+                        for (int r = 0; r < 16; ++r) dst[frag_unit(r, 0) * 32] = acc[r];
                     }
                 }
             }
@@ -407,8 +474,9 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                     }
                 }
                 if (J.busy && J.q == 0) {
+                    const f32x16 hl = wide_get(smem + p.Hb[l], J.t, lane);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dacc[r] *= (1.0f - h[l][r] * h[l][r]);
+                    for (int r = 0; r < 16; ++r) dacc[r] *= (1.0f - hl[r] * hl[r]);
                     wide_put(smem + p.Db[l], J.t, lane, dacc);
                 }
             }
@@ -553,6 +621,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
         // ---- back-propagation: gz_{L-1} = (Wo gmu) (1 - h^2), then gz_{l-1} = (W_l gz_l) (1 - h_{l-1}^2) -----------
         f32x16 gz;
         if (wave < s.HT[L - 1]) {
+            const f32x16 hlast = wide_get(smem + p.Hb[L - 1], wave, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int u = 32 * wave + frag_unit(r, 0) + 4 * lh;
@@ -560,7 +629,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
 #pragma unroll
                 for (int k = 0; k < MAXDA; ++k)
                     if (k < DA) g = __builtin_fmaf(tail[s.tWo + u * DA + k], gmu[k], g);
-                gz[r] = g * (1.0f - h[L - 1][r] * h[L - 1][r]);
+                gz[r] = g * (1.0f - hlast[r] * hlast[r]);
             }
             wide_put(smem + p.Db[L - 1], wave, lane, gz);      // the tangent of this layer is consumed: reuse its tile
         }
@@ -609,8 +678,9 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                 }
             }
             if (bbusy && q == 0) {
+                const f32x16 hb = wide_get(smem + p.Hb[l - 1], t, lane);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gz[r] = acc[r] * (1.0f - h[l - 1][r] * h[l - 1][r]);
+                for (int r = 0; r < 16; ++r) gz[r] = acc[r] * (1.0f - hb[r] * hb[r]);
                 wide_put(smem + p.Db[l - 1], t, lane, gz);
             }
             __syncthreads();
