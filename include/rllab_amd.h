@@ -343,6 +343,13 @@ int rl_policy_grad_loss(const rl_policy_batch* batch, int vpg, void* workspace, 
 int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspace,
                   size_t workspace_bytes, double* fvp_out, void* stream);
 
+/* Which arithmetic rl_policy_fvp runs this batch's products in (host query, launches nothing):
+ *   0  f32 matrix instructions (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): bit-identical with or without `activations`;
+ *   1  bf16 matrix instructions on three-way split operands with f32 accumulation (six cross terms per product, the
+ *      dropped ones below 2^-26 of |a b|): cached products of two 32-unit tanh layers on a batch of whole 32-sample
+ *      tiles.  Same result to f32 rounding, not bit for bit.  RLLAB_FVP_SPLIT=0 in the environment selects 0. */
+int rl_policy_fvp_variant(const rl_policy_batch* batch);
+
 /* ---- policies whose log-std is a NETWORK (GaussianMLPPolicy(adaptive_std=True) / std_network=...,
  * rllab/policies/gaussian_mlp_policy.py:60-98; the reference's regression test tests/regression_tests/test_issue_3.py).
  * Mean and log-std networks run as plain functions on planes, the Gaussian head sits between them:

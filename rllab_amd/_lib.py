@@ -28,7 +28,7 @@ SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
-    "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
+    "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_variant", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
     "rl_lfb_normal_eq",
     "rl_peer_mailbox_bytes", "rl_peer_alloc", "rl_peer_free", "rl_peer_export", "rl_peer_open", "rl_peer_close",
@@ -118,6 +118,7 @@ def _load():
     lib.rl_policy_grad.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp]
     lib.rl_policy_grad_loss.argtypes = [pb, i32, vp, ctypes.c_size_t, vp, vp, vp]
     lib.rl_policy_fvp.argtypes = [pb, vp, vp, ctypes.c_size_t, vp, vp]
+    lib.rl_policy_fvp_variant.argtypes = [pb]
     lib.rl_policy_fvp_cg_step.argtypes = [pb, vp, ctypes.c_size_t, f64, f64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rl_cg_init.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.rl_cg_step.argtypes = [i32, vp, f64, f64, vp, vp, vp, vp, vp, vp]

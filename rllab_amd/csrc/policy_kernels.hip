@@ -795,6 +795,9 @@ int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t
 int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
                   hipStream_t st, double* loss_out);                       // policy_wide_kernels.hip
 struct WideShape;
+// policy_split_kernels.hip: the cached Fisher-vector product of the 32-unit nets on the bf16 matrix pipe (three-way
+// split operands, f32 accuracy); RL_SPLIT_NOT_TAKEN when the launch is not its to make
+int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
 size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not a wide shape
 
 struct PlaneArgs {                 // MODE_OUT / MODE_OUT_TAN / MODE_BWD
@@ -938,6 +941,10 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     if (g->activation != RL_ACT_TANH) return set_error(RL_ERR_ARG, "unknown activation %d", g->activation);
     if (g->kl_penalty != 0.0f && mode != MODE_VPG && mode != MODE_GRAD)
         return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the gradient passes only");
+    if (mode == MODE_FVP && cg == nullptr) {
+        const int rc = split_fvp_dispatch(g, vec, ws, ws_bytes, out, st);
+        if (rc != RL_SPLIT_NOT_TAKEN) return rc;
+    }
 #define NETCASE(DO, DA, H) \
     if (d == DO && k == DA && h0 == H && h1 == H) \
         return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out, cg);

@@ -13,6 +13,7 @@
 namespace rl {
 
 constexpr int WV = 64;        // wavefront
+constexpr int RL_SPLIT_NOT_TAKEN = 1 << 20;   // split_fvp_dispatch: this launch belongs to policy_pass_kernel
 constexpr int TS = 32;        // samples per MFMA tile
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;

@@ -1,0 +1,105 @@
+"""The split-operand Fisher-vector product (csrc/policy_split_kernels.hip: bf16 matrix instructions on three-way split
+f32 operands, six cross terms, f32 accumulation) against float64 autograd of the reference's mean KL (PerlmutterHvp,
+rllab/optimizers/conjugate_gradient_optimizer.py:27-55) and against the f32-matrix-instruction product of the same
+batch: it must be an f32-accurate product, not a reduced-precision one."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import test_gpu_update_parity as U
+
+pytestmark = pytest.mark.gpu
+
+SPLIT_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (13, 1), (20, 1), (21, 1)]
+
+
+def _variant(ops, inp):
+    from rllab_amd import _lib
+    b, keep, inv = ops._batch(inp)
+    b.activations = ops._acts.data_ptr() if ops._acts_tag is not None else None
+    try:
+        return _lib.lib.rl_policy_fvp_variant(ctypes.byref(b))
+    finally:
+        b.activations = None
+
+
+def _f64_products(pol, inp, vs):
+    _, kl, _ = U._closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    with torch.no_grad():
+        om64 = pol.mean_planes(inp[0].double(), flat64.detach())
+    inp64 = (inp[0], inp[1], inp[2], om64, pol.effective_log_std().detach().double().reshape(-1, 1), inp[5], inp[6])
+    g = torch.autograd.grad(kl(flat64, *inp64), flat64, create_graph=True)[0]
+    return [torch.autograd.grad((g * v).sum(), flat64, retain_graph=True)[0] for v in vs]
+
+
+def _blocks(pol):
+    do, da, h = pol.obs_dim, pol.action_dim, 32
+    names, sizes = ("W0", "b0", "W1", "b1", "W2", "b2", "log_std"), (do * h, h, h * h, h, h * da, da, da)
+    out, o = [], 0
+    for n, s in zip(names, sizes):
+        out.append((n, o, o + s))
+        o += s
+    return out
+
+
+@pytest.mark.parametrize("do,da", SPLIT_SHAPES)
+@pytest.mark.parametrize("B", [32, 4096, 64000])
+def test_split_product_is_an_f32_accurate_product(do, da, B, monkeypatch):
+    pol = U._policy(do, da, 32)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, B, old_equals_new=True)
+    rng = np.random.RandomState(7)
+    vs = [torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2)]
+    want = _f64_products(pol, inp, vs)
+    ops.loss_grad(inp, keep_activations=True)
+    assert ops._acts_tag is not None
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
+    assert _variant(ops, inp) == 0
+    plain = [ops.fvp(inp, v) for v in vs]
+    monkeypatch.delenv("RLLAB_FVP_SPLIT")
+    assert _variant(ops, inp) == 1                       # the launch below IS the split kernel
+    split = [ops.fvp(inp, v) for v in vs]
+    assert ops._acts_tag is not None
+    for hv_s, hv_p, hv64 in zip(split, plain, want):
+        scale = float(hv64.abs().max())
+        err_s, err_p = float((hv_s - hv64).abs().max()) / scale, float((hv_p - hv64).abs().max()) / scale
+        worst = [(n, float((hv_s - hv64)[a:b].abs().max()) / scale) for n, a, b in _blocks(pol)]
+        assert err_s <= 5e-5, worst                                    # the reference tolerance of the product
+        assert err_s <= 2.0 * err_p + 2e-6, (err_s, err_p, worst)      # and no worse than the f32 matrix instructions
+        assert not torch.equal(hv_s, hv_p)                             # (two different kernels did run)
+
+
+def test_split_product_takes_only_its_batches(monkeypatch):
+    """Whole 32-sample tiles, cached activations, two 32-unit tanh layers; everything else stays on the f32 matrix
+    instructions and keeps the cached product bit-identical to the recomputed one."""
+    pol = U._policy(13, 2, 32)
+    ops = pol.fused_ops()
+    for B, want in ((4096, 1), (4100, 0), (63, 0)):
+        inp = U._inputs(pol, B, old_equals_new=True)
+        ops.release()
+        assert _variant(ops, inp) == 0                   # nothing cached yet
+        ops.loss_grad(inp, keep_activations=True)
+        assert _variant(ops, inp) == want
+    pol64 = U._policy(13, 2, 64)
+    ops64 = pol64.fused_ops()
+    inp = U._inputs(pol64, 4096, old_equals_new=True)
+    ops64.loss_grad(inp, keep_activations=True)
+    assert _variant(ops64, inp) == 0
+
+
+def test_cg_on_the_split_product_solves_the_same_system(monkeypatch):
+    """Ten CG iterations (krylov.cg, rllab/misc/krylov.py:7-39) on either product: the same solution to f32 accuracy."""
+    pol = U._policy(13, 2, 32)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, 64000, old_equals_new=True)
+    g = ops.loss_grad(inp, keep_activations=True)
+    assert _variant(ops, inp) == 1
+    x_s, xhx_s = ops.cg(inp, g, 10, 1e-5)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
+    x_p, xhx_p = ops.cg(inp, g, 10, 1e-5)
+    assert float((x_s - x_p).abs().max()) <= 1e-4 * float(x_p.abs().max())
+    assert abs(float(xhx_s) - float(xhx_p)) <= 1e-5 * abs(float(xhx_p))
