@@ -327,12 +327,23 @@ def main():
         macs = (2 * pw - first) + (pw - first) + pw
         mfma_per_tile = macs * 32 / 2048.0             # one v_mfma_f32_32x32x2_f32 = 2048 multiply-adds
     fvp_ms = None
+    fvp_variant = 0
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None
     if ops is not None:
+        import ctypes
+        from rllab_amd import _lib
         from rllab_amd.algos.npo import npo_inputs
         inp = npo_inputs(policy, last["samples"])
         v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
         ops.loss_grad(inp, keep_activations=True)     # as ConjugateGradientOptimizer.optimize does before CG
+        # which arithmetic the library runs these products in (0: f32 matrix instructions, 1: bf16 matrix
+        # instructions on three-way split f32 operands -- csrc/policy_split_kernels.hip)
+        b = ops._batch(inp)[0]
+        b.activations = ops._acts.data_ptr() if ops._acts_tag is not None else None
+        try:
+            fvp_variant = int(_lib.lib.rl_policy_fvp_variant(ctypes.byref(b)))
+        finally:
+            b.activations = None
         for _ in range(3):
             ops.fvp(inp, v)
         torch.cuda.synchronize()
@@ -423,13 +434,27 @@ def main():
     if fvp_ms is not None:
         tiles = (n_envs * T + 31) // 32
         tf = tiles * mfma_per_tile * 4096 / (fvp_ms * 1e-3) / 1e12
-        out["roofline_mfma"] = {"kernel": ("wide_pass_kernel<FVP>" if wide else "policy_pass_kernel<FVP>") +
-                                " (Fisher-vector product, v_mfma_f32_32x32x2_f32)",
-                                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
-                                "frac": tf / 157.3, "avg_launch_ms": fvp_ms, "mfma_per_32_samples": mfma_per_tile,
-                                "activations": "read from the gradient pass's cache" if cached else "recomputed",
-                                "note": "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); time "
-                                        "includes the partial-row reduce kernel"}
+        if fvp_variant == 1:
+            # the split product: the SAME algorithmic f32 work (mfma_per_tile f32-matrix-instruction equivalents per tile)
+            # priced against the same f32 matrix peak, so that the number is comparable with earlier rounds; what the
+            # bf16 pipe executes for it is 6 cross terms per product + 21 transposition products per tile
+            kern = "fvp_split_kernel (Fisher-vector product, v_mfma_f32_32x32x16_bf16 on three-way split f32 operands)"
+            bf16_mfma = 66 + 21
+            extra = {"arithmetic": "f32 operands split hi + mid + lo (exact), six bf16 cross terms per product, f32 "
+                                   "accumulation: dropped terms < 2^-26 |a b| (tests/test_gpu_fvp_split.py)",
+                     "bf16_mfma_per_32_samples": bf16_mfma,
+                     "bf16_pipe_frac": tiles * bf16_mfma * 32768 / (fvp_ms * 1e-3) / 2.5e15}
+        else:
+            kern = ("wide_pass_kernel<FVP>" if wide else "policy_pass_kernel<FVP>") + \
+                " (Fisher-vector product, v_mfma_f32_32x32x2_f32)"
+            extra = {}
+        out["roofline_mfma"] = dict({"kernel": kern,
+                                     "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                                     "frac": tf / 157.3, "avg_launch_ms": fvp_ms, "mfma_per_32_samples": mfma_per_tile,
+                                     "activations": "read from the gradient pass's cache" if cached else "recomputed",
+                                     "note": "algorithmic f32 flops (mfma_per_32_samples x 4096 per tile) against the "
+                                             "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); time "
+                                             "includes the partial-row reduce kernel"}, **extra)
     if os.environ.get("RLLAB_BENCH_HOSTTIMES") and rank == 0:
         names = ["events", "obtain_samples (enqueue)", "process_samples (incl. its wait)", "optimize_policy (incl. waits)",
                  "dump_tabular", "loop overhead to next iteration"]

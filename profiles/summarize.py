@@ -65,12 +65,18 @@ def pmc(d, out):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = sorted({c for k in acc for c in acc[k]})
+    # the kernel durations of the SAME pass (counter collection slows a launch: clocks must be derived from these)
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(out, "w") as fh:
         w = csv.writer(fh)
-        w.writerow(["kernel", "dispatches"] + ["mean_" + c for c in counters])
+        w.writerow(["kernel", "dispatches"] + ["mean_" + c for c in counters] + ["mean_ns_this_pass"])
         for k in sorted(acc, key=lambda k: -max(len(v) for v in acc[k].values())):
             n = max(len(v) for v in acc[k].values())
-            w.writerow([short(k), n] + ["%.6g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k][c] else "" for c in counters])
+            w.writerow([short(k), n] + ["%.6g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k][c] else "" for c in counters]
+                       + ["%d" % (sum(dur[k]) // len(dur[k])) if dur.get(k) else ""])
 
 
 def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=4096, tag="", sq_csv=None):

@@ -14,14 +14,19 @@
 // theta_new == theta_old, see policy_kernels.hip's header) -- same inputs, same partial-row / float64 row reduction,
 // a result that differs from policy_pass_kernel<N, MODE_FVP, true> by rounding only.
 //
-// Mapping.  One wavefront per SIMD (512 registers) owns tiles of 32 samples; every loop-invariant operand (the split
-// fragments of dW0^T, dW1^T, W1^T, W1 and the output layer's rows) lives in registers.  All f32 fragments are
-// "sample-major": lane (s = lane & 31, half = lane >> 5) holds sample s and the 16 units frag_unit(r, half) -- the
-// layout the matrix pipe produces and the layout the gradient pass left the activations in.  The products whose
-// contraction runs over SAMPLES (gW1 += h0^T gz1, gW0 += x^T gz0) need their operands unit-major: the bf16 parts
-// are written to a wave-private [32 samples][72 B] LDS image and come back through ds_read_b64_tr_b16, the
-// transposing read (4 samples of one unit per lane and instruction).  The thin products of the output layer
-// accumulate per lane and are reduced over the lanes once per launch.
+// Mapping.  A wavefront owns tiles of 32 samples.  All f32 fragments are "sample-major": lane (s = lane & 31,
+// half = lane >> 5) holds sample s and the 16 units frag_unit(r, half) -- the layout the matrix pipe produces and the
+// layout the gradient pass left the activations in; a fragment's split parts are directly the B operand of the next
+// layer (k-block kb = registers 8 kb .. 8 kb + 7).  The products whose contraction runs over SAMPLES (gW1 += h0^T gz1,
+// gW0 += x^T gz0) need their operands unit-major: a part is transposed ON THE MATRIX PIPE, part (as the A operand:
+// rows = samples) x identity = the same numbers with lane = unit, register = sample, exactly (every output is one
+// product with 1), and eight conversions per part pack them back to bf16.  No LDS round trip, no cross-lane
+// instruction; the matrix pipe has the slack (24 % busy before, 32 % with the 21 transposition products per tile).
+// The thin products of the output layer accumulate per lane and are reduced over the lanes once per launch.
+// Two wavefronts per SIMD (eight per workgroup, one workgroup per CU): the stages of a tile are one dependency chain
+// (split -> product -> element-wise -> split ...), so the second wavefront is what fills the first one's waits.  With
+// 256 registers each the loop-invariant operands (the split fragments of dW0^T, dW1^T, W1^T, W1 and the output layer's
+// rows) are staged in LDS once per workgroup and read per use.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "../../include/rllab_amd.h"
@@ -35,25 +40,18 @@ int launch_reduce_rows(const float* partial, int rows, int cols, double* out, hi
 namespace split {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int H = 32;
-constexpr int WAVES = 4;                       // one per SIMD
 constexpr int LAND_BYTES = 2 * H * TS * 4;     // h0 | h1 fragments of one tile, as the gradient pass stored them
-constexpr int TR_STRIDE = 72;                  // bytes per sample row of a transposition image (32 bf16 + 8 B: the
-                                               // 8-byte writes of 16 consecutive samples fall on 16 different slots)
-constexpr int TR_PART = TS * TR_STRIDE;        // one part (hi / mid / lo) of a 32 x 32 fragment
-constexpr int TR_BYTES = 3 * TR_PART;
-constexpr int N_TR = 4;                        // h0, x, gz1, gz0
-constexpr int WAVE_BYTES = LAND_BYTES + N_TR * TR_BYTES;
-constexpr int LDS_BYTES = WAVES * WAVE_BYTES;
+// LDS image of the loop-invariant operands (two wavefronts per SIMD): 7 operand blocks (A1, A2[2], A3[2], A4[2]) x 3
+// parts x 64 lanes x 16 B, then the output layer per lane half: [half][W2 rows 16 x DA | dW2 rows 16 x DA | db1 16]
+constexpr int N_OPS = 7;
+constexpr int OPS_BYTES = N_OPS * 3 * WV * 16;
 
 struct Args {
     int B;
@@ -83,6 +81,12 @@ __device__ __forceinline__ f32x16 mm6(const Parts& A, const Parts& B, f32x16 c) 
     return c;
 }
 
+// value + the value of the same sample in the other lane half, without an LDS round trip (v_permlane32_swap)
+__device__ __forceinline__ float half_sum_swap(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // x = hi + mid + lo, each a bf16: successive round-to-nearest residuals (every subtraction is exact)
 __device__ __forceinline__ void split_pair(float a0, float a1, Parts& out, int j) {
     const f32x2 a = {a0, a1};
@@ -106,104 +110,131 @@ __device__ __forceinline__ void split_frag(const f32x16& v, Parts (&out)[2]) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) split_pair(v[8 * kb + j], v[8 * kb + j + 1], out[kb], j);
 }
-
-// sample-major parts -> the transposition image: row = sample, column = unit; a lane's eight units of k-block kb are
-// the two runs 16 kb + 8 h2 + 4 half + (0 .. 3)
-__device__ __forceinline__ void store_parts_units(char* img, int lj, int lh, const Parts (&f)[2]) {
+// an f32 fragment whose values ARE bf16 numbers (a transposed part) -> the operands of its two k-blocks
+__device__ __forceinline__ void pack_exact(const f32x16& d, Parts (&out)[2], int p) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const bf16x4 v = {f[kb].p[p][4 * h2], f[kb].p[p][4 * h2 + 1], f[kb].p[p][4 * h2 + 2], f[kb].p[p][4 * h2 + 3]};
-                *reinterpret_cast<bf16x4*>(img + p * TR_PART + lj * TR_STRIDE + 2 * (16 * kb + 8 * h2 + 4 * lh)) = v;
-            }
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 a = {d[8 * kb + j], d[8 * kb + j + 1]};
+            const bf16x2 h = __builtin_convertvector(a, bf16x2);
+            out[kb].p[p][j] = h[0]; out[kb].p[p][j + 1] = h[1];
+        }
 }
-// the x fragment: a lane's eight inputs of k-block kb are the run 16 kb + 8 half + (0 .. 7)
-template <int KB0>
-__device__ __forceinline__ void store_parts_inputs(char* img, int lj, int lh, const Parts (&f)[KB0]) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int kb = 0; kb < KB0; ++kb)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const bf16x4 v = {f[kb].p[p][4 * h2], f[kb].p[p][4 * h2 + 1], f[kb].p[p][4 * h2 + 2], f[kb].p[p][4 * h2 + 3]};
-                *reinterpret_cast<bf16x4*>(img + p * TR_PART + lj * TR_STRIDE + 2 * (16 * kb + 8 * lh + 4 * h2)) = v;
-            }
-}
-// unit-major operand of sample k-block kb: lane (unit = lane & 31, half) receives samples frag_unit(8 kb + j, half).
-// `lane_off` = (4 half + ((lane & 15) >> 2)) * TR_STRIDE + 32 ((lane >> 4) & 1) + 8 (lane & 3)   (tools/ubench/bf16_split_layout.hip)
-__device__ __forceinline__ void load_parts_transposed(const char* img, int lane_off, int kb, Parts& out) {
+// sample-major parts of a 32-unit fragment -> unit-major parts: lane (unit, half) receives the samples
+// frag_unit(8 kb + j, half) as k-block kb.  part (A: rows = samples, k = units) x identity, on the matrix pipe, exact.
+__device__ __forceinline__ void transpose_units(const Parts (&f)[2], const bf16x8 (&Id)[2], Parts (&out)[2]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const char* a = img + p * TR_PART + lane_off + (2 * kb) * 8 * TR_STRIDE;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 8 * TR_STRIDE));
-        const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-        out.p[p] = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+        d = mfma16(f[0].p[p], Id[0], d);
+        d = mfma16(f[1].p[p], Id[1], d);
+        pack_exact(d, out, p);
+    }
+}
+// the x fragment (one k-block of inputs): lane (input d, half); lanes d >= 16 receive zeros
+__device__ __forceinline__ void transpose_inputs(const Parts& f, const bf16x8& Idx, Parts (&out)[2]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+        d = mfma16(f.p[p], Idx, d);
+        pack_exact(d, out, p);
     }
 }
 
-template <int DO, int DA>
-__global__ void __launch_bounds__(WAVES * WV, 1) fvp_split_kernel(Args a) {
+template <int DO, int DA, int WPS>
+__global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     using N = Net<DO, DA, H>;
     constexpr int P = N::P;
-    constexpr int KB0 = (DO + 1 + 15) / 16;        // k-blocks of the input layer (inputs + the bias slot)
-    static_assert(DO + 1 <= 32 && LDS_BYTES >= P * 4, "");
+    constexpr int WAVES = 4 * WPS;
+    constexpr bool INV_LDS = (WPS == 2);           // loop-invariant operands in LDS (256 registers per wavefront)
+    constexpr int TAILV = 16 * DA * 2 + 16;        // floats per lane half: W2 rows | dW2 rows | db1
+    constexpr int SPILL_BYTES = INV_LDS ? 2 * 3 * WV * 16 : 0;   // a wavefront's h0 parts wait here for the back-propagation
+    constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES;
+    constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + (INV_LDS ? OPS_BYTES + 2 * TAILV * 4 : 0);
+    static_assert(DO + 1 <= 16, "one k-block of inputs + the bias slot");
+    static_assert(LDS_TOTAL >= P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold buffer aliases the landing zones");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
     const int lj = lane & 31, lh = lane >> 5;
     char* const land = smem + wave * WAVE_BYTES;
-    char* const img_h0 = land + LAND_BYTES;
-    char* const img_x = img_h0 + TR_BYTES;
-    char* const img_g1 = img_x + TR_BYTES;
-    char* const img_g0 = img_g1 + TR_BYTES;
-    const int lane_off = (4 * lh + ((lane & 15) >> 2)) * TR_STRIDE + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    char* const spill = land + LAND_BYTES;
+    char* const ops = smem + WAVES * WAVE_BYTES;                       // [N_OPS][3][64] x 16 B
+    float* const tailv = reinterpret_cast<float*>(ops + OPS_BYTES);    // [2][TAILV]
 
-    // the images start as zeros: columns no fragment writes (inputs beyond the bias slot) stay zero operands
-    for (int k = lane * 16; k < N_TR * TR_BYTES; k += WV * 16) *reinterpret_cast<f32x4*>(img_h0 + k) = f32x4{0, 0, 0, 0};
-    wave_sync();
-
-    // ---- loop-invariant operands, split once per launch, register resident ---------------------------------------
     const float* __restrict__ th = a.theta;
     const float* __restrict__ vc = a.vec;
-    Parts A1[KB0], A2[2], A3[2], A4[2];
-    {
+    // ---- loop-invariant operands, split once per launch ------------------------------------------------------------------
+    // operand block o: 0 = dW0^T (+ db0 in the bias slot), 1 + kb = dW1^T, 3 + kb = W1^T, 5 + kb = W1
+    auto make_op = [&](int o, Parts& out) {
         float t[8];
 #pragma unroll
-        for (int kb = 0; kb < KB0; ++kb) {            // A1[i = lj][d] = dW0[d][i] (d < DO), db0[i] (d == DO)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 16 * kb + 8 * lh + j;
+        for (int j = 0; j < 8; ++j) {
+            if (o == 0) {
+                const int d = 8 * lh + j;                    // A[i = lj][d] = dW0[d][i] (d < DO), db0[i] (d == DO)
                 t[j] = d < DO ? vc[N::W0 + d * H + lj] : (d == DO ? vc[N::B0 + lj] : 0.0f);
+            } else {
+                const int kb = (o - 1) & 1, u = frag_unit(8 * kb + j, lh);
+                t[j] = o < 3 ? vc[N::W1 + u * H + lj]        // dW1^T: A[i][k] = dW1[k][i]
+                     : o < 5 ? th[N::W1 + u * H + lj]        // W1^T
+                             : th[N::W1 + lj * H + u];       // W1:    A[k][i] = W1[k][i]
             }
-            split8(t, A1[kb]);
         }
+        split8(t, out);
+    };
+    Parts R_ops[INV_LDS ? 1 : N_OPS];
+    float R_db1[INV_LDS ? 1 : 16], R_W2[INV_LDS ? 1 : 16][DA], R_dW2[INV_LDS ? 1 : 16][DA];
+    if constexpr (INV_LDS) {
+        if (wave < N_OPS) {
+            Parts t;
+            make_op(wave, t);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(ops + ((wave * 3 + p) * WV + lane) * 16) = t.p[p];
+        } else {
+            for (int e = lane; e < 2 * 16; e += WV) {
+                const int hh = e / 16, r = e % 16, u = frag_unit(r, hh);
+                float* tv = tailv + hh * TAILV;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = vc[N::W1 + frag_unit(8 * kb + j, lh) * H + lj];     // dW1^T: A[i][k] = dW1[k][i]
-            split8(t, A2[kb]);
+                for (int k = 0; k < DA; ++k) {             // [W2 column k | dW2 column k] rows of this half, then db1
+                    tv[k * 16 + r] = th[N::W2 + u * DA + k];
+                    tv[(DA + k) * 16 + r] = vc[N::W2 + u * DA + k];
+                }
+                tv[2 * DA * 16 + r] = vc[N::B1 + u];
+            }
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = th[N::W1 + frag_unit(8 * kb + j, lh) * H + lj];     // W1^T
-            split8(t, A3[kb]);
+        for (int o = 0; o < N_OPS; ++o) make_op(o, R_ops[o]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = th[N::W1 + lj * H + frag_unit(8 * kb + j, lh)];     // W1: A[k][i] = W1[k][i]
-            split8(t, A4[kb]);
+        for (int r = 0; r < 16; ++r) {
+            const int u = frag_unit(r, lh);
+            R_db1[r] = vc[N::B1 + u];
+#pragma unroll
+            for (int k = 0; k < DA; ++k) { R_W2[r][k] = th[N::W2 + u * DA + k]; R_dW2[r][k] = vc[N::W2 + u * DA + k]; }
         }
     }
-    float db1r[16], W2r[16][DA], dW2r[16][DA];
+    auto op = [&](int o) -> Parts {
+        if constexpr (INV_LDS) {
+            Parts t;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int u = frag_unit(r, lh);
-        db1r[r] = vc[N::B1 + u];
-#pragma unroll
-        for (int k = 0; k < DA; ++k) {
-            W2r[r][k] = th[N::W2 + u * DA + k];
-            dW2r[r][k] = vc[N::W2 + u * DA + k];
+            for (int p = 0; p < 3; ++p) t.p[p] = *reinterpret_cast<const bf16x8*>(ops + ((o * 3 + p) * WV + lane) * 16);
+            return t;
+        } else {
+            return R_ops[o];
         }
+    };
+    // identity operands of the transpositions: B[k][n] = (k == n) in the k order of the fragment they meet
+    bf16x8 Id[2], Idx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        Id[0][j] = (__bf16)(frag_unit(j, lh) == lj ? 1.0f : 0.0f);
+        Id[1][j] = (__bf16)(frag_unit(8 + j, lh) == lj ? 1.0f : 0.0f);
+        Idx[j] = (__bf16)(8 * lh + j == lj ? 1.0f : 0.0f);
     }
     float db2[DA], fk[DA], var_[DA];
     bool floored[DA];
@@ -235,16 +266,16 @@ __global__ void __launch_bounds__(WAVES * WV, 1) fvp_split_kernel(Args a) {
     const int waves_total = gridDim.x * WAVES;
 
     // one tile ahead: the observation slots and the weight in registers, the cached activations by LDS-direct loads
-    auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
+    // (branch-free: a lane half beyond the inputs reads a clamped row and selects the constant)
+    auto fetch = [&](int tile, float (&xq)[8], float& wq) {
         const int b = tile * TS + lj;
         wq = a.weight[b];
 #pragma unroll
-        for (int kb = 0; kb < KB0; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 16 * kb + 8 * lh + j;
-                xq[kb][j] = d < DO ? a.obs[(size_t)d * B + b] : (d == DO ? 1.0f : 0.0f);
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int d = 8 * lh + j;
+            const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
+            xq[j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
+        }
     };
     auto fetch_acts = [&](int tile) {
         const float* src = a.acts + ((size_t)tile * 8 * WV + lane) * 4;
@@ -252,7 +283,7 @@ __global__ void __launch_bounds__(WAVES * WV, 1) fvp_split_kernel(Args a) {
         for (int q = 0; q < 8; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(land + q * WV * 16), 16, 0, 0);
     };
-    float xb[KB0][8], xb_next[KB0][8];
+    float xb[8], xb_next[8];
     float wgt = 0.0f, wgt_next = 0.0f;
     if (wave_global < n_tiles) {
         fetch(wave_global, xb_next, wgt_next);
@@ -271,63 +302,71 @@ __global__ void __launch_bounds__(WAVES * WV, 1) fvp_split_kernel(Args a) {
             for (int e = 0; e < 4; ++e) { h0[4 * q + e] = v0[e]; h1[4 * q + e] = v1[e]; }
         }
 #pragma unroll
-        for (int kb = 0; kb < KB0; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xb[kb][j] = xb_next[kb][j];
+        for (int j = 0; j < 8; ++j) xb[j] = xb_next[j];
         wgt = wgt_next;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the landing zone is in registers before it is refilled
-        if (tile + waves_total < n_tiles) {
-            fetch(tile + waves_total, xb_next, wgt_next);
-            fetch_acts(tile + waves_total);
+        {   // the wavefront's last tile prefetches itself again (no branch in the loop body)
+            const int nxt = tile + waves_total < n_tiles ? tile + waves_total : tile;
+            fetch(nxt, xb_next, wgt_next);
+            fetch_acts(nxt);
         }
+        // the output layer's rows of this lane half, read where they are used (two wavefronts per SIMD: from LDS)
+        const float* tv = tailv + lh * TAILV;
+        auto W2_ = [&](int r, int k) { if constexpr (INV_LDS) return tv[k * 16 + r]; else return R_W2[r][k]; };
+        auto dW2_ = [&](int r, int k) { if constexpr (INV_LDS) return tv[(DA + k) * 16 + r]; else return R_dW2[r][k]; };
+        auto db1_ = [&](int r) { if constexpr (INV_LDS) return tv[2 * DA * 16 + r]; else return R_db1[r]; };
+        // keeps the LDS reads of a stage inside it (the compiler would otherwise start every loop-invariant read at the
+        // top of the tile and hold 160 registers for them)
+        auto stage = [&]() { if constexpr (INV_LDS) asm volatile("" ::: "memory"); };
 
-        // ---- operands of this tile: x, h0 (their unit-major forms start through LDS now) -----------------------------
-        Parts Xs[KB0], H0s[2];
-#pragma unroll
-        for (int kb = 0; kb < KB0; ++kb) split8(xb[kb], Xs[kb]);
+        // ---- operands of this tile ---------------------------------------------------------------------------------------
+        Parts Xs, H0s[2];
+        split8(xb, Xs);
         split_frag(h0, H0s);
-        store_parts_inputs<KB0>(img_x, lj, lh, Xs);
-        store_parts_units(img_h0, lj, lh, H0s);
-        f32x16 dz0, dz1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dz0[r] = 1.0f - h0[r] * h0[r];
-            dz1[r] = 1.0f - h1[r] * h1[r];
-        }
 
         // ---- tangent forward: dmu = J v ---------------------------------------------------------------------------------
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int kb = 0; kb < KB0; ++kb) acc = mm6(A1[kb], Xs[kb], acc);          // dW0^T x + db0
+        acc = mm6(op(0), Xs, acc);                                                // dW0^T x + db0
         f32x16 dh0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh0[r] = acc[r] * dz0[r];
+        for (int r = 0; r < 16; ++r) dh0[r] = acc[r] * (1.0f - h0[r] * h0[r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = db1r[r];
+        for (int r = 0; r < 16; ++r) acc[r] = db1_(r);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mm6(A2[kb], H0s[kb], acc);           // dW1^T h0
+        for (int kb = 0; kb < 2; ++kb) acc = mm6(op(1 + kb), H0s[kb], acc);       // dW1^T h0
+        if constexpr (INV_LDS) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(spill + ((kb * 3 + p) * WV + lane) * 16) = H0s[kb].p[p];
+        }
+        stage();
         {
             Parts D0s[2];
             split_frag(dh0, D0s);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) acc = mm6(A3[kb], D0s[kb], acc);       // W1^T dh0
+            for (int kb = 0; kb < 2; ++kb) acc = mm6(op(3 + kb), D0s[kb], acc);   // W1^T dh0
         }
-        f32x16 dh1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh1[r] = acc[r] * dz1[r];
+        stage();
         const float c = wgt * a.inv_count;
+        f32x16 dz1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dz1[r] = 1.0f - h1[r] * h1[r];
+            acc[r] *= dz1[r];                                                     // dh1
+        }
         float gmu[DA];
 #pragma unroll
         for (int k = 0; k < DA; ++k) {
             float pd = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pd = __builtin_fmaf(h1[r], dW2r[r][k], pd);
-                pd = __builtin_fmaf(dh1[r], W2r[r][k], pd);
+                pd = __builtin_fmaf(h1[r], dW2_(r, k), pd);
+                pd = __builtin_fmaf(acc[r], W2_(r, k), pd);
             }
-            const float dmu = db2[k] + half_sum(pd);
+            const float dmu = db2[k] + half_sum_swap(pd);
             gmu[k] = c * dmu * fk[k];
         }
         if (lh == 0) {
@@ -343,45 +382,44 @@ __global__ void __launch_bounds__(WAVES * WV, 1) fvp_split_kernel(Args a) {
             float g = 0.0f;
 #pragma unroll
             for (int k = 0; k < DA; ++k) {
-                g = __builtin_fmaf(W2r[r][k], gmu[k], g);
+                g = __builtin_fmaf(W2_(r, k), gmu[k], g);
                 gW2l[r][k] = __builtin_fmaf(h1[r], gmu[k], gW2l[r][k]);
             }
             gz1[r] = g * dz1[r];
             gb1l[r] += gz1[r];
         }
+        stage();
         Parts G1s[2];
         split_frag(gz1, G1s);
-        store_parts_units(img_g1, lj, lh, G1s);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mm6(A4[kb], G1s[kb], acc);           // W1 gz1
+        for (int kb = 0; kb < 2; ++kb) acc = mm6(op(5 + kb), G1s[kb], acc);       // W1 gz1
+        stage();
+        {
+            if constexpr (INV_LDS) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) H0s[kb].p[p] = *reinterpret_cast<const bf16x8*>(spill + ((kb * 3 + p) * WV + lane) * 16);
+            }
+            Parts H0t[2], G1t[2];
+            transpose_units(H0s, Id, H0t);                                        // h0 unit-major
+            transpose_units(G1s, Id, G1t);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) gW1 = mm6(H0t[kb], G1t[kb], gW1);      // gW1 += h0^T gz1 (samples are K)
+        }
         f32x16 gz0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gz0[r] = acc[r] * dz0[r];
+        for (int r = 0; r < 16; ++r) gz0[r] = acc[r] * (1.0f - h0[r] * h0[r]);
         {
-            Parts G0s[2];
+            Parts G0s[2], G0t[2], Xt[2];
             split_frag(gz0, G0s);
-            store_parts_units(img_g0, lj, lh, G0s);
-        }
-
-        // ---- the batch reductions: gW1 += h0^T gz1, gW0 += x_ext^T gz0 (samples are K, operands unit-major) ---------------
-        wave_sync();
+            transpose_units(G0s, Id, G0t);
+            transpose_inputs(Xs, Idx, Xt);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            Parts At, Bt;
-            load_parts_transposed(img_h0, lane_off, kb, At);
-            load_parts_transposed(img_g1, lane_off, kb, Bt);
-            gW1 = mm6(At, Bt, gW1);
+            for (int kb = 0; kb < 2; ++kb) gW0 = mm6(Xt[kb], G0t[kb], gW0);       // gW0 += x_ext^T gz0
         }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            Parts At, Bt;
-            load_parts_transposed(img_x, lane_off, kb, At);
-            load_parts_transposed(img_g0, lane_off, kb, Bt);
-            gW0 = mm6(At, Bt, gW0);
-        }
-        wave_sync();
     }
 
     // ---- fold the wavefronts of this workgroup in a fixed order, write ONE partial row ----------------------------------
@@ -444,9 +482,12 @@ __global__ void __launch_bounds__(WAVES * WV, 1) fvp_split_kernel(Args a) {
     for (int k = threadIdx.x; k < P; k += WAVES * WV) row[k] = red[k];
 }
 
-template <int DO, int DA>
+template <int DO, int DA, int WPS>
 static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     using N = Net<DO, DA, H>;
+    constexpr int WAVES = 4 * WPS;
+    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0)) +
+                              (WPS == 2 ? OPS_BYTES + 2 * (16 * DA * 2 + 16) * 4 : 0);
     Args a;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.acts = g->activations; a.obs = g->obs; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
@@ -456,7 +497,7 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
     const size_t need = (size_t)grid * N::P * sizeof(float);
     if (ws_bytes < need) return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", ws_bytes, need);
     a.partial = (float*)ws;
-    auto kern = fvp_split_kernel<DO, DA>;
+    auto kern = fvp_split_kernel<DO, DA, WPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -475,7 +516,7 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
 // The split product takes a cached Fisher-vector product of a two-layer 32-unit tanh net whose batch is a whole number
 // of tiles; everything else stays on policy_pass_kernel.  RLLAB_FVP_SPLIT=0 switches it off (A/B runs, tests of the
 // bit-identical cached / recomputed pair).  Returns RL_SPLIT_NOT_TAKEN when the launch is not its to make.
-#define SPLIT_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1) X(20, 1) X(21, 1)
+#define SPLIT_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1)
 bool split_fvp_takes(const rl_policy_batch* g) {
     if (!g->activations || g->hidden2 != 0 || g->hidden0 != 32 || g->hidden1 != 32 || g->activation != RL_ACT_TANH ||
         g->n_samples <= 0 || g->n_samples % TS != 0)
@@ -489,7 +530,11 @@ bool split_fvp_takes(const rl_policy_batch* g) {
 }
 int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     if (!split_fvp_takes(g)) return RL_SPLIT_NOT_TAKEN;
-#define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return split::launch<DO, DA>(g, vec, ws, ws_bytes, out, st);
+    // two wavefronts per SIMD (operands in LDS) unless RLLAB_FVP_SPLIT_WPS=1 asks for the one-wavefront, register-resident form
+    const char* e = getenv("RLLAB_FVP_SPLIT_WPS");
+    const bool one = e && e[0] == '1';
+#define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) \
+        return one ? split::launch<DO, DA, 1>(g, vec, ws, ws_bytes, out, st) : split::launch<DO, DA, 2>(g, vec, ws, ws_bytes, out, st);
     SPLIT_SHAPES(SPLITCASE)
 #undef SPLITCASE
     return RL_SPLIT_NOT_TAKEN;

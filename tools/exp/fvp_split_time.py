@@ -26,9 +26,11 @@ for do, da, B in shapes:
     v = torch.randn(pol.flat_params.numel(), device="cuda", dtype=torch.float64)
     ops.loss_grad(inp, keep_activations=True)
     out = dict(net=[do, da, 32], B=B)
-    for tag, val in (("f32_ms", "0"), ("split_ms", "1"), ("f32_again_ms", "0"), ("split_again_ms", "1")):
+    for tag, val, wps in (("f32_ms", "0", "2"), ("split_wps1_ms", "1", "1"), ("split_ms", "1", "2"), ("f32_again_ms", "0", "2"),
+                          ("split_wps1_again_ms", "1", "1"), ("split_again_ms", "1", "2")):
         os.environ["RLLAB_FVP_SPLIT"] = val
+        os.environ["RLLAB_FVP_SPLIT_WPS"] = wps
         out[tag] = round(timed(lambda: ops.fvp(inp, v)), 4)
     flops = 71 * 4096 * (B / 32)
-    out["split_frac_of_f32_matrix_peak"] = round(flops / (out["split_again_ms"] * 1e-3) / 157.3e12, 3)
+    out["split_frac_of_f32_matrix_peak"] = round(flops / (min(out["split_again_ms"], out["split_wps1_again_ms"]) * 1e-3) / 157.3e12, 3)
     print(json.dumps(out), flush=True)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# tools/prof_split.sh <tag>: SQ counters of the split Fisher-vector product (GPU box, through gpurun)
+TAG=${1:-r03s}
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+P=/tmp/prof_$TAG; rm -rf $P; mkdir -p $P gpurun_out
+CMD="python tools/exp/fvp_split_time.py 1"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $P/sq -- $CMD > /dev/null 2>&1
+python profiles/summarize.py pmc $P/sq gpurun_out/${TAG}_pmc_sq.csv
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/sq2 -- $CMD > /dev/null 2>&1
+python profiles/summarize.py pmc $P/sq2 gpurun_out/${TAG}_pmc_sq2.csv
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_TRANS SQ_THREAD_CYCLES_VALU --output-format csv -d $P/sq3 -- $CMD > /dev/null 2>&1
+python profiles/summarize.py pmc $P/sq3 gpurun_out/${TAG}_pmc_sq3.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $CMD > /dev/null 2>&1
+python profiles/summarize.py stats $P/stats gpurun_out/${TAG}_kernel_stats.csv
+grep -h "fvp_split\|>, 2, true\|^kernel" gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv gpurun_out/${TAG}_pmc_sq3.csv gpurun_out/${TAG}_kernel_stats.csv | cut -c1-400
