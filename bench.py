@@ -441,7 +441,7 @@ def main():
             kern = "fvp_split_kernel (Fisher-vector product, v_mfma_f32_32x32x16_bf16 on three-way split f32 operands)"
             bf16_mfma = 66 + 21
             extra = {"arithmetic": "f32 operands split hi + mid + lo (exact), six bf16 cross terms per product, f32 "
-                                   "accumulation: dropped terms < 2^-26 |a b| (tests/test_gpu_fvp_split.py)",
+                                   "accumulation: dropped terms <= 2^-23 |a b| worst case, 2^-28 mean (tests/test_split_arithmetic.py, test_gpu_fvp_split.py)",
                      "bf16_mfma_per_32_samples": bf16_mfma,
                      "bf16_pipe_frac": tiles * bf16_mfma * 32768 / (fvp_ms * 1e-3) / 2.5e15}
         else:

@@ -346,7 +346,7 @@ int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspac
 /* Which arithmetic rl_policy_fvp runs this batch's products in (host query, launches nothing):
  *   0  f32 matrix instructions (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): bit-identical with or without `activations`;
  *   1  bf16 matrix instructions on three-way split operands with f32 accumulation (six cross terms per product, the
- *      dropped ones below 2^-26 of |a b|): cached products of two 32-unit tanh layers on a batch of whole 32-sample
+ *      dropped ones at most 2^-23 of |a b|, 2^-28 in the mean): cached products of two 32-unit tanh layers on a batch of whole 32-sample
  *      tiles.  Same result to f32 rounding, not bit for bit.  RLLAB_FVP_SPLIT=0 in the environment selects 0. */
 int rl_policy_fvp_variant(const rl_policy_batch* batch);
 

@@ -2,7 +2,8 @@
 // pipe at f32 accuracy: every f32 operand is split three ways, x = hi + mid + lo with each part a bf16 (exact: the
 // parts are successive round-to-nearest residuals), and a product of two operands is the sum of the six cross terms
 // hi hi + hi mid + mid hi + hi lo + lo hi + mid mid on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  The dropped
-// terms are below 2^-26 of |a b| (an f32 fused multiply-add rounds at 2^-24); measured against float64 the six-term
+// terms (mid lo + lo mid + lo lo) are at most 2^-23 of |a b| -- two f32 roundings -- when every part sits at its bound, 2^-28
+// in the mean and of either sign (tests/test_split_arithmetic.py); measured on the device against float64 the six-term
 // dot product is three times closer than an f32 fma chain (tools/ubench/bf16_split_layout.hip).
 //
 // Why: v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and shares the vector datapath (policy_kernels.hip's
