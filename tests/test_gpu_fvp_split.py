@@ -103,3 +103,25 @@ def test_cg_on_the_split_product_solves_the_same_system(monkeypatch):
     x_p, xhx_p = ops.cg(inp, g, 10, 1e-5)
     assert float((x_s - x_p).abs().max()) <= 1e-4 * float(x_p.abs().max())
     assert abs(float(xhx_s) - float(xhx_p)) <= 1e-5 * abs(float(xhx_p))
+
+
+def test_full_size_products_are_linear_symmetric_and_positive():
+    """At BASELINE config C3's batch (4096 envs x 500 steps = 2 048 000 samples, ragged weights): the split product is
+    linear in the vector, symmetric (v . F w == w . F v) and positive (v . F v > 0) -- properties of the Fisher matrix of
+    rllab/optimizers/conjugate_gradient_optimizer.py:27-55 that do not need a float64 pass over two million samples."""
+    pol = U._policy(13, 2, 32)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, 4096 * 500, old_equals_new=True)
+    ops.loss_grad(inp, keep_activations=True)
+    assert _variant(ops, inp) == 1
+    rng = np.random.RandomState(11)
+    v, w = (torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2))
+    Fv, Fw = ops.fvp(inp, v), ops.fvp(inp, w)
+    scale = float(Fv.abs().max())
+    # the kernel takes the vector in f32: compare against the product of the f32-rounded combination
+    comb = (0.7 * v - 1.3 * w).float().double()
+    lin = ops.fvp(inp, comb) - (0.7 * ops.fvp(inp, v.float().double()) - 1.3 * ops.fvp(inp, w.float().double()))
+    assert float(lin.abs().max()) <= 2e-5 * scale
+    vFw, wFv = float(v.dot(Fw)), float(w.dot(Fv))
+    assert abs(vFw - wFv) <= 2e-5 * max(abs(vFw), float(v.dot(Fv)))
+    assert float(v.dot(Fv)) > 0 and float(w.dot(Fw)) > 0
