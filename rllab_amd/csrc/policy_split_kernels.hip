@@ -423,6 +423,10 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         }
     }
 
+    // the last tile's (redundant) prefetch is still travelling into this wavefront's landing zone, which the fold buffer
+    // aliases: let it land first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
     // ---- fold the wavefronts of this workgroup in a fixed order, write ONE partial row ----------------------------------
     // per-lane accumulators of the thin products: sum over the 32 samples of a lane half
     float b1s[16], w2s[16][DA];
