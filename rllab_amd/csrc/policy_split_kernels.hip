@@ -49,10 +49,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int H = 32;
 constexpr int LAND_BYTES = 2 * H * TS * 4;     // h0 | h1 fragments of one tile, as the gradient pass stored them
-// LDS image of the loop-invariant operands (two wavefronts per SIMD): 7 operand blocks (A1, A2[2], A3[2], A4[2]) x 3
-// parts x 64 lanes x 16 B, then the output layer per lane half: [half][W2 rows 16 x DA | dW2 rows 16 x DA | db1 16]
-constexpr int N_OPS = 7;
-constexpr int OPS_BYTES = N_OPS * 3 * WV * 16;
+// LDS image of the loop-invariant operands (two wavefronts per SIMD): KB0 + 6 operand blocks (A1[KB0], A2[2], A3[2],
+// A4[2]) x 3 parts x 64 lanes x 16 B, then the output layer per lane half: [half][W2 column k: 16 rows | dW2 ... | db1 16]
+constexpr int ops_count(int kb0) { return kb0 + 6; }          // dW0^T: one block per 16 inputs; dW1^T, W1^T, W1: two each
+constexpr int ops_bytes(int kb0) { return ops_count(kb0) * 3 * WV * 16; }
 
 struct Args {
     int B;
@@ -135,14 +135,16 @@ __device__ __forceinline__ void transpose_units(const Parts (&f)[2], const bf16x
         pack_exact(d, out, p);
     }
 }
-// the x fragment (one k-block of inputs): lane (input d, half); lanes d >= 16 receive zeros
-__device__ __forceinline__ void transpose_inputs(const Parts& f, const bf16x8& Idx, Parts (&out)[2]) {
+// the x fragment (KB0 k-blocks of 16 inputs): lane (input d, half); lanes beyond the inputs receive zeros
+template <int KB0>
+__device__ __forceinline__ void transpose_inputs(const Parts (&f)[KB0], const bf16x8 (&Idx)[KB0], Parts (&out)[2]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         f32x16 d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[r] = 0.0f;
-        d = mfma16(f.p[p], Idx, d);
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) d = mfma16(f[kb].p[p], Idx[kb], d);
         pack_exact(d, out, p);
     }
 }
@@ -152,12 +154,15 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     using N = Net<DO, DA, H>;
     constexpr int P = N::P;
     constexpr int WAVES = 4 * WPS;
-    constexpr bool INV_LDS = (WPS == 2);           // loop-invariant operands in LDS (256 registers per wavefront)
+    constexpr int KB0 = (DO + 1 + 15) / 16;        // k-blocks of the input layer (inputs + the bias slot)
+    constexpr int N_OPS = ops_count(KB0), OPS_BYTES = ops_bytes(KB0);
+    constexpr bool INV_LDS = (WPS == 2);           // matrix operands in LDS (256 registers per wavefront)
+    constexpr bool TAIL_LDS = INV_LDS || DA > 2;   // the output layer's rows in LDS (wide heads: 32 DA registers otherwise)
     constexpr int TAILV = 16 * DA * 2 + 16;        // floats per lane half: W2 rows | dW2 rows | db1
     constexpr int SPILL_BYTES = INV_LDS ? 2 * 3 * WV * 16 : 0;   // a wavefront's h0 parts wait here for the back-propagation
     constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES;
-    constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + (INV_LDS ? OPS_BYTES + 2 * TAILV * 4 : 0);
-    static_assert(DO + 1 <= 16, "one k-block of inputs + the bias slot");
+    constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + (INV_LDS ? OPS_BYTES : 0) + (TAIL_LDS ? 2 * TAILV * 4 : 0);
+    static_assert(DO + 1 <= 32, "two k-blocks of inputs + the bias slot");
     static_assert(LDS_TOTAL >= P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold buffer aliases the landing zones");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
@@ -165,52 +170,53 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     char* const land = smem + wave * WAVE_BYTES;
     char* const spill = land + LAND_BYTES;
     char* const ops = smem + WAVES * WAVE_BYTES;                       // [N_OPS][3][64] x 16 B
-    float* const tailv = reinterpret_cast<float*>(ops + OPS_BYTES);    // [2][TAILV]
+    float* const tailv = reinterpret_cast<float*>(ops + (INV_LDS ? OPS_BYTES : 0));    // [2][TAILV]
 
     const float* __restrict__ th = a.theta;
     const float* __restrict__ vc = a.vec;
     // ---- loop-invariant operands, split once per launch ------------------------------------------------------------------
-    // operand block o: 0 = dW0^T (+ db0 in the bias slot), 1 + kb = dW1^T, 3 + kb = W1^T, 5 + kb = W1
+    // operand block o: 0 .. KB0 - 1 = dW0^T (+ db0 in the bias slot), KB0 + kb = dW1^T, KB0 + 2 + kb = W1^T, KB0 + 4 + kb = W1
     auto make_op = [&](int o, Parts& out) {
         float t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (o == 0) {
-                const int d = 8 * lh + j;                    // A[i = lj][d] = dW0[d][i] (d < DO), db0[i] (d == DO)
+            if (o < KB0) {
+                const int d = 16 * o + 8 * lh + j;           // A[i = lj][d] = dW0[d][i] (d < DO), db0[i] (d == DO)
                 t[j] = d < DO ? vc[N::W0 + d * H + lj] : (d == DO ? vc[N::B0 + lj] : 0.0f);
             } else {
-                const int kb = (o - 1) & 1, u = frag_unit(8 * kb + j, lh);
-                t[j] = o < 3 ? vc[N::W1 + u * H + lj]        // dW1^T: A[i][k] = dW1[k][i]
-                     : o < 5 ? th[N::W1 + u * H + lj]        // W1^T
+                const int q = o - KB0, kb = q & 1, u = frag_unit(8 * kb + j, lh);
+                t[j] = q < 2 ? vc[N::W1 + u * H + lj]        // dW1^T: A[i][k] = dW1[k][i]
+                     : q < 4 ? th[N::W1 + u * H + lj]        // W1^T
                              : th[N::W1 + lj * H + u];       // W1:    A[k][i] = W1[k][i]
             }
         }
         split8(t, out);
     };
     Parts R_ops[INV_LDS ? 1 : N_OPS];
-    float R_db1[INV_LDS ? 1 : 16], R_W2[INV_LDS ? 1 : 16][DA], R_dW2[INV_LDS ? 1 : 16][DA];
+    float R_db1[TAIL_LDS ? 1 : 16], R_W2[TAIL_LDS ? 1 : 16][DA], R_dW2[TAIL_LDS ? 1 : 16][DA];
     if constexpr (INV_LDS) {
-        if (wave < N_OPS) {
+        for (int o = wave; o < N_OPS; o += WAVES) {
             Parts t;
-            make_op(wave, t);
+            make_op(o, t);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(ops + ((wave * 3 + p) * WV + lane) * 16) = t.p[p];
-        } else {
-            for (int e = lane; e < 2 * 16; e += WV) {
-                const int hh = e / 16, r = e % 16, u = frag_unit(r, hh);
-                float* tv = tailv + hh * TAILV;
-#pragma unroll
-                for (int k = 0; k < DA; ++k) {             // [W2 column k | dW2 column k] rows of this half, then db1
-                    tv[k * 16 + r] = th[N::W2 + u * DA + k];
-                    tv[(DA + k) * 16 + r] = vc[N::W2 + u * DA + k];
-                }
-                tv[2 * DA * 16 + r] = vc[N::B1 + u];
-            }
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(ops + ((o * 3 + p) * WV + lane) * 16) = t.p[p];
         }
-        __syncthreads();
     } else {
 #pragma unroll
         for (int o = 0; o < N_OPS; ++o) make_op(o, R_ops[o]);
+    }
+    if constexpr (TAIL_LDS) {
+        for (int e = threadIdx.x; e < 2 * 16; e += WAVES * WV) {
+            const int hh = e / 16, r = e % 16, u = frag_unit(r, hh);
+            float* tv = tailv + hh * TAILV;
+#pragma unroll
+            for (int k = 0; k < DA; ++k) {                 // [W2 column k | dW2 column k] rows of this half, then db1
+                tv[k * 16 + r] = th[N::W2 + u * DA + k];
+                tv[(DA + k) * 16 + r] = vc[N::W2 + u * DA + k];
+            }
+            tv[2 * DA * 16 + r] = vc[N::B1 + u];
+        }
+    } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = frag_unit(r, lh);
@@ -219,6 +225,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             for (int k = 0; k < DA; ++k) { R_W2[r][k] = th[N::W2 + u * DA + k]; R_dW2[r][k] = vc[N::W2 + u * DA + k]; }
         }
     }
+    if constexpr (TAIL_LDS) __syncthreads();
     auto op = [&](int o) -> Parts {
         if constexpr (INV_LDS) {
             Parts t;
@@ -230,12 +237,13 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         }
     };
     // identity operands of the transpositions: B[k][n] = (k == n) in the k order of the fragment they meet
-    bf16x8 Id[2], Idx;
+    bf16x8 Id[2], Idx[KB0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         Id[0][j] = (__bf16)(frag_unit(j, lh) == lj ? 1.0f : 0.0f);
         Id[1][j] = (__bf16)(frag_unit(8 + j, lh) == lj ? 1.0f : 0.0f);
-        Idx[j] = (__bf16)(8 * lh + j == lj ? 1.0f : 0.0f);
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) Idx[kb][j] = (__bf16)(16 * kb + 8 * lh + j == lj ? 1.0f : 0.0f);
     }
     float db2[DA], fk[DA], var_[DA];
     bool floored[DA];
@@ -268,15 +276,17 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
 
     // one tile ahead: the observation slots and the weight in registers, the cached activations by LDS-direct loads
     // (branch-free: a lane half beyond the inputs reads a clamped row and selects the constant)
-    auto fetch = [&](int tile, float (&xq)[8], float& wq) {
+    auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
         const int b = tile * TS + lj;
         wq = a.weight[b];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 8 * lh + j;
-            const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
-            xq[j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
-        }
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * kb + 8 * lh + j;
+                const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
+                xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
+            }
     };
     auto fetch_acts = [&](int tile) {
         const float* src = a.acts + ((size_t)tile * 8 * WV + lane) * 4;
@@ -284,7 +294,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         for (int q = 0; q < 8; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(land + q * WV * 16), 16, 0, 0);
     };
-    float xb[8], xb_next[8];
+    float xb[KB0][8], xb_next[KB0][8];
     float wgt = 0.0f, wgt_next = 0.0f;
     if (wave_global < n_tiles) {
         fetch(wave_global, xb_next, wgt_next);
@@ -303,7 +313,9 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             for (int e = 0; e < 4; ++e) { h0[4 * q + e] = v0[e]; h1[4 * q + e] = v1[e]; }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xb[j] = xb_next[j];
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xb[kb][j] = xb_next[kb][j];
         wgt = wgt_next;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the landing zone is in registers before it is refilled
         {   // the wavefront's last tile prefetches itself again (no branch in the loop body)
@@ -313,30 +325,32 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         }
         // the output layer's rows of this lane half, read where they are used (two wavefronts per SIMD: from LDS)
         const float* tv = tailv + lh * TAILV;
-        auto W2_ = [&](int r, int k) { if constexpr (INV_LDS) return tv[k * 16 + r]; else return R_W2[r][k]; };
-        auto dW2_ = [&](int r, int k) { if constexpr (INV_LDS) return tv[(DA + k) * 16 + r]; else return R_dW2[r][k]; };
-        auto db1_ = [&](int r) { if constexpr (INV_LDS) return tv[2 * DA * 16 + r]; else return R_db1[r]; };
+        auto W2_ = [&](int r, int k) { if constexpr (TAIL_LDS) return tv[k * 16 + r]; else return R_W2[r][k]; };
+        auto dW2_ = [&](int r, int k) { if constexpr (TAIL_LDS) return tv[(DA + k) * 16 + r]; else return R_dW2[r][k]; };
+        auto db1_ = [&](int r) { if constexpr (TAIL_LDS) return tv[2 * DA * 16 + r]; else return R_db1[r]; };
         // keeps the LDS reads of a stage inside it (the compiler would otherwise start every loop-invariant read at the
         // top of the tile and hold 160 registers for them)
-        auto stage = [&]() { if constexpr (INV_LDS) asm volatile("" ::: "memory"); };
+        auto stage = [&]() { if constexpr (TAIL_LDS) asm volatile("" ::: "memory"); };
 
         // ---- operands of this tile ---------------------------------------------------------------------------------------
-        Parts Xs, H0s[2];
-        split8(xb, Xs);
+        Parts Xs[KB0], H0s[2];
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) split8(xb[kb], Xs[kb]);
         split_frag(h0, H0s);
 
         // ---- tangent forward: dmu = J v ---------------------------------------------------------------------------------
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = mm6(op(0), Xs, acc);                                                // dW0^T x + db0
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) acc = mm6(op(kb), Xs[kb], acc);          // dW0^T x + db0
         f32x16 dh0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh0[r] = acc[r] * (1.0f - h0[r] * h0[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = db1_(r);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mm6(op(1 + kb), H0s[kb], acc);       // dW1^T h0
+        for (int kb = 0; kb < 2; ++kb) acc = mm6(op(KB0 + kb), H0s[kb], acc);       // dW1^T h0
         if constexpr (INV_LDS) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -348,7 +362,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             Parts D0s[2];
             split_frag(dh0, D0s);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) acc = mm6(op(3 + kb), D0s[kb], acc);   // W1^T dh0
+            for (int kb = 0; kb < 2; ++kb) acc = mm6(op(KB0 + 2 + kb), D0s[kb], acc);   // W1^T dh0
         }
         stage();
         const float c = wgt * a.inv_count;
@@ -395,7 +409,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc = mm6(op(5 + kb), G1s[kb], acc);       // W1 gz1
+        for (int kb = 0; kb < 2; ++kb) acc = mm6(op(KB0 + 4 + kb), G1s[kb], acc);       // W1 gz1
         stage();
         {
             if constexpr (INV_LDS) {
@@ -417,7 +431,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             Parts G0s[2], G0t[2], Xt[2];
             split_frag(gz0, G0s);
             transpose_units(G0s, Id, G0t);
-            transpose_inputs(Xs, Idx, Xt);
+            transpose_inputs<KB0>(Xs, Idx, Xt);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) gW0 = mm6(Xt[kb], G0t[kb], gW0);       // gW0 += x_ext^T gz0
         }
@@ -491,8 +505,9 @@ template <int DO, int DA, int WPS>
 static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     using N = Net<DO, DA, H>;
     constexpr int WAVES = 4 * WPS;
-    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0)) +
-                              (WPS == 2 ? OPS_BYTES + 2 * (16 * DA * 2 + 16) * 4 : 0);
+    constexpr int KB0 = (DO + 1 + 15) / 16;
+    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0)) + (WPS == 2 ? ops_bytes(KB0) : 0) +
+                              ((WPS == 2 || DA > 2) ? 2 * (16 * DA * 2 + 16) * 4 : 0);
     Args a;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.acts = g->activations; a.obs = g->obs; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
@@ -521,7 +536,10 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
 // The split product takes a cached Fisher-vector product of a two-layer 32-unit tanh net whose batch is a whole number
 // of tiles; everything else stays on policy_pass_kernel.  RLLAB_FVP_SPLIT=0 switches it off (A/B runs, tests of the
 // bit-identical cached / recomputed pair).  Returns RL_SPLIT_NOT_TAKEN when the launch is not its to make.
-#define SPLIT_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1)
+// (obs_dim, act_dim) of the HIP-native envs (a (32, 32) net is rllab's default policy for every one of them) + the
+// one-output net on the Swimmer's observations.  Heads wider than two outputs run one wavefront per SIMD: their
+// per-lane sums of the thin products (16 x act_dim registers) do not fit beside 256.
+#define SPLIT_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1) X(20, 3) X(20, 6) X(21, 6)
 bool split_fvp_takes(const rl_policy_batch* g) {
     if (!g->activations || g->hidden2 != 0 || g->hidden0 != 32 || g->hidden1 != 32 || g->activation != RL_ACT_TANH ||
         g->n_samples <= 0 || g->n_samples % TS != 0)
@@ -538,8 +556,9 @@ int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, siz
     // two wavefronts per SIMD (operands in LDS) unless RLLAB_FVP_SPLIT_WPS=1 asks for the one-wavefront, register-resident form
     const char* e = getenv("RLLAB_FVP_SPLIT_WPS");
     const bool one = e && e[0] == '1';
-#define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) \
-        return one ? split::launch<DO, DA, 1>(g, vec, ws, ws_bytes, out, st) : split::launch<DO, DA, 2>(g, vec, ws, ws_bytes, out, st);
+#define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) { \
+        if constexpr (DA > 2) return split::launch<DO, DA, 1>(g, vec, ws, ws_bytes, out, st); \
+        else return one ? split::launch<DO, DA, 1>(g, vec, ws, ws_bytes, out, st) : split::launch<DO, DA, 2>(g, vec, ws, ws_bytes, out, st); }
     SPLIT_SHAPES(SPLITCASE)
 #undef SPLITCASE
     return RL_SPLIT_NOT_TAKEN;

@@ -13,7 +13,7 @@ from tests import test_gpu_update_parity as U
 
 pytestmark = pytest.mark.gpu
 
-SPLIT_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (13, 1)]
+SPLIT_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (13, 1), (20, 3), (20, 6), (21, 6)]   # every HIP-native env's default (32, 32) policy
 
 
 def _variant(ops, inp):

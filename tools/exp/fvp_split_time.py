@@ -16,7 +16,7 @@ def timed(fn, n=40):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-shapes = [(13, 2, 2048000), (4, 1, 409600), (13, 2, 8192000)]
+shapes = [(13, 2, 2048000), (4, 1, 409600), (13, 2, 8192000), (20, 6, 512000), (20, 3, 512000)]
 if len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
 for do, da, B in shapes:
