@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES;
     constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + (INV_LDS ? OPS_BYTES : 0) + (TAIL_LDS ? 2 * TAILV * 4 : 0);
     static_assert(DO + 1 <= 32, "two k-blocks of inputs + the bias slot");
-    static_assert(LDS_TOTAL >= P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold buffer aliases the landing zones");
+    static_assert(LDS_TOTAL >= WAVES * P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold rows alias the landing zones");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
     const int lj = lane & 31, lh = lane >> 5;
@@ -171,6 +171,39 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     char* const spill = land + LAND_BYTES;
     char* const ops = smem + WAVES * WAVE_BYTES;                       // [N_OPS][3][64] x 16 B
     float* const tailv = reinterpret_cast<float*>(ops + (INV_LDS ? OPS_BYTES : 0));    // [2][TAILV]
+
+    const int B = a.B;
+    const int n_tiles = B / TS;
+    const int wave_global = blockIdx.x * WAVES + wave;
+    const int waves_total = gridDim.x * WAVES;
+
+    // one tile ahead: the observation slots and the weight in registers, the cached activations by LDS-direct loads
+    // (branch-free: a lane half beyond the inputs reads a clamped row and selects the constant)
+    auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
+        const int b = tile * TS + lj;
+        wq = a.weight[b];
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * kb + 8 * lh + j;
+                const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
+                xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
+            }
+    };
+    auto fetch_acts = [&](int tile) {
+        const float* src = a.acts + ((size_t)tile * 8 * WV + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(land + q * WV * 16), 16, 0, 0);
+    };
+    float xb[KB0][8], xb_next[KB0][8];
+    float wgt = 0.0f, wgt_next = 0.0f;
+    if (wave_global < n_tiles) {
+        fetch(wave_global, xb_next, wgt_next);
+        fetch_acts(wave_global);
+    }
+    asm volatile("" ::: "memory");   // (the first tile's inputs travel while the operands below are staged)
 
     const float* __restrict__ th = a.theta;
     const float* __restrict__ vc = a.vec;
@@ -269,37 +302,6 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
 #pragma unroll
     for (int k = 0; k < DA; ++k) gb2[k] = 0.0f;
 
-    const int B = a.B;
-    const int n_tiles = B / TS;
-    const int wave_global = blockIdx.x * WAVES + wave;
-    const int waves_total = gridDim.x * WAVES;
-
-    // one tile ahead: the observation slots and the weight in registers, the cached activations by LDS-direct loads
-    // (branch-free: a lane half beyond the inputs reads a clamped row and selects the constant)
-    auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
-        const int b = tile * TS + lj;
-        wq = a.weight[b];
-#pragma unroll
-        for (int kb = 0; kb < KB0; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 16 * kb + 8 * lh + j;
-                const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
-                xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
-            }
-    };
-    auto fetch_acts = [&](int tile) {
-        const float* src = a.acts + ((size_t)tile * 8 * WV + lane) * 4;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(land + q * WV * 16), 16, 0, 0);
-    };
-    float xb[KB0][8], xb_next[KB0][8];
-    float wgt = 0.0f, wgt_next = 0.0f;
-    if (wave_global < n_tiles) {
-        fetch(wave_global, xb_next, wgt_next);
-        fetch_acts(wave_global);
-    }
 
     for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
         // ---- this tile's inputs; the next tile's start travelling ------------------------------------------------
@@ -463,42 +465,44 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     for (int k = 0; k < DA; ++k) b2s[k] = wave_sum(gb2[k]);
     const float ws = wave_sum(wsum);
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    for (int k = threadIdx.x; k < P; k += WAVES * WV) red[k] = 0.0f;
-    __syncthreads();
-    for (int w = 0; w < WAVES; ++w) {
-        if (wave == w) {
+    // every wavefront lays its contribution out as one row (each parameter has exactly one contributor per wavefront),
+    // then the columns are summed in wavefront order -- the same sums as folding the wavefronts one after the other,
+    // with two workgroup barriers instead of WAVES + 2
+    float* const myrow = reinterpret_cast<float*>(smem) + wave * P;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int u = frag_unit(r, lh);
-                red[N::W1 + u * H + lj] += gW1[r];                    // row = unit of h0, column = unit of gz1
-                if (u < DO) red[N::W0 + u * H + lj] += gW0[r];        // row = input (or the bias slot)
-                else if (u == DO) red[N::B0 + lj] += gW0[r];
-            }
-            if (lj == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int u = frag_unit(r, lh);
-                    red[N::B1 + u] += b1s[r];
-#pragma unroll
-                    for (int k = 0; k < DA; ++k) red[N::W2 + u * DA + k] += w2s[r][k];
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < DA; ++k) {
-                    red[N::B2 + k] += b2s[k];
-                    // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
-                    const float vv = var_[k], e = 1e-8f;
-                    const float cc = floored[k] ? 0.0f : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
-                    red[N::LSTD + k] += cc * vc[N::LSTD + k] * ws;
-                }
-            }
-        }
-        __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+        const int u = frag_unit(r, lh);
+        myrow[N::W1 + u * H + lj] = gW1[r];                           // row = unit of h0, column = unit of gz1
+        if (u < DO) myrow[N::W0 + u * H + lj] = gW0[r];               // row = input (or the bias slot)
+        else if (u == DO) myrow[N::B0 + lj] = gW0[r];
     }
+    if (lj == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = frag_unit(r, lh);
+            myrow[N::B1 + u] = b1s[r];
+#pragma unroll
+            for (int k = 0; k < DA; ++k) myrow[N::W2 + u * DA + k] = w2s[r][k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            myrow[N::B2 + k] = b2s[k];
+            // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
+            const float vv = var_[k], e = 1e-8f;
+            const float cc = floored[k] ? 0.0f : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+            myrow[N::LSTD + k] = cc * vc[N::LSTD + k] * ws;
+        }
+    }
+    __syncthreads();
     float* row = a.partial + (size_t)blockIdx.x * P;
-    for (int k = threadIdx.x; k < P; k += WAVES * WV) row[k] = red[k];
+    for (int k = threadIdx.x; k < P; k += WAVES * WV) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += reinterpret_cast<const float*>(smem)[w * P + k];
+        row[k] = t;
+    }
 }
 
 template <int DO, int DA, int WPS>
