@@ -330,20 +330,13 @@ def main():
     fvp_variant = 0
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None
     if ops is not None:
-        import ctypes
-        from rllab_amd import _lib
         from rllab_amd.algos.npo import npo_inputs
         inp = npo_inputs(policy, last["samples"])
         v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
         ops.loss_grad(inp, keep_activations=True)     # as ConjugateGradientOptimizer.optimize does before CG
         # which arithmetic the library runs these products in (0: f32 matrix instructions, 1: bf16 matrix
         # instructions on three-way split f32 operands -- csrc/policy_split_kernels.hip)
-        b = ops._batch(inp)[0]
-        b.activations = ops._acts.data_ptr() if ops._acts_tag is not None else None
-        try:
-            fvp_variant = int(_lib.lib.rl_policy_fvp_variant(ctypes.byref(b)))
-        finally:
-            b.activations = None
+        fvp_variant = ops.fvp_variant(inp)
         def timed20(fn):
             for _ in range(3):
                 fn()

@@ -237,6 +237,18 @@ class FusedGaussianMLPOps(object):
             b.activations = None
         return D.update_sum_(out)
 
+    def fvp_variant(self, inputs):
+        """Which arithmetic ``rl_policy_fvp`` would run the next product of this batch in (rl_policy_fvp_variant): 0 = f32
+        matrix instructions, 1 = bf16 matrix instructions on three-way split f32 operands (csrc/policy_split_kernels.hip;
+        cached activations, two 32-unit layers, whole 32-sample tiles).  A host query: launches nothing."""
+        b, _, _ = self._batch(inputs)
+        cached = self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
+        b.activations = self._acts.data_ptr() if cached else None
+        try:
+            return int(_lib.lib.rl_policy_fvp_variant(ctypes.byref(b)))
+        finally:
+            b.activations = None
+
     def fvp(self, inputs, vec):
         b, keep, _ = self._batch(inputs)
         ws = self._workspace(keep[0].device)

@@ -2,9 +2,6 @@
 f32 operands, six cross terms, f32 accumulation) against float64 autograd of the reference's mean KL (PerlmutterHvp,
 rllab/optimizers/conjugate_gradient_optimizer.py:27-55) and against the f32-matrix-instruction product of the same
 batch: it must be an f32-accurate product, not a reduced-precision one."""
-import ctypes
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -17,13 +14,7 @@ SPLIT_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (13, 1), (20, 3), (20, 6), (21
 
 
 def _variant(ops, inp):
-    from rllab_amd import _lib
-    b, keep, inv = ops._batch(inp)
-    b.activations = ops._acts.data_ptr() if ops._acts_tag is not None else None
-    try:
-        return _lib.lib.rl_policy_fvp_variant(ctypes.byref(b))
-    finally:
-        b.activations = None
+    return ops.fvp_variant(inp)
 
 
 def _f64_products(pol, inp, vs):
