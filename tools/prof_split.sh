@@ -11,6 +11,10 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_A
 python profiles/summarize.py pmc $P/sq2 gpurun_out/${TAG}_pmc_sq2.csv
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_TRANS SQ_THREAD_CYCLES_VALU --output-format csv -d $P/sq3 -- $CMD > /dev/null 2>&1
 python profiles/summarize.py pmc $P/sq3 gpurun_out/${TAG}_pmc_sq3.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -- $CMD > /dev/null 2>&1
+python profiles/summarize.py pmc $P/fetch gpurun_out/${TAG}_pmc_fetch_size.csv
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -- $CMD > /dev/null 2>&1
+python profiles/summarize.py pmc $P/write gpurun_out/${TAG}_pmc_write_size.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $CMD > /dev/null 2>&1
 python profiles/summarize.py stats $P/stats gpurun_out/${TAG}_kernel_stats.csv
-grep -h "fvp_split\|>, 2, true\|^kernel" gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv gpurun_out/${TAG}_pmc_sq3.csv gpurun_out/${TAG}_kernel_stats.csv | cut -c1-400
+grep -h "fvp_split\|>, 2, true\|^kernel" gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv gpurun_out/${TAG}_pmc_sq3.csv gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/${TAG}_kernel_stats.csv | cut -c1-400
