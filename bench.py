@@ -496,6 +496,7 @@ def main():
         if ref is None:
             out["cpu_baseline"] = {
                 "value": base["steps_per_s"], "unit": "env_steps/s", "cores": base["cores"], "kind": "port",
+                "hw_threads": os.cpu_count(), "physical_cores": ref_sampler.physical_cores(),
                 "cpu_model": ref_sampler.cpu_model(),
                 "sample": "%d env steps in %.1f s of oracle/cpu_sampler.py (the reference's sampler re-typed); the "
                           "reference's own modules were not available: %s" % (base["steps"], base["seconds"], ref_error),
@@ -510,6 +511,9 @@ def main():
                          "layers (NormalizedEnv.step, Box.flatten, Step namedtuple, tensor_utils stacking)")
             out["cpu_baseline"] = {
                 "value": ref["steps_per_s"], "unit": "env_steps/s", "cores": ref["cores"], "kind": "reference",
+                # "cores" = worker processes used = one per HARDWARE THREAD of the box (os.cpu_count()); the sockets'
+                # physical cores are half of that on an SMT-2 part
+                "hw_threads": os.cpu_count(), "physical_cores": ref_sampler.physical_cores(),
                 "cpu_model": ref["cpu_model"],
                 "sample": "%d env steps (%d paths) in %.1f s of the reference's unmodified parallel_sampler.sample_paths "
                           "/ StatefulPool.run_collect / rollout / NormalizedEnv (%s, staged by oracle/make_ref.py) with "

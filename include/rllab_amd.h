@@ -202,6 +202,16 @@ typedef struct rl_rollout_args {
 
 int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);
 
+/* LDS bytes the fused rollout of a WIDE / DEEP policy (any hidden sizes other than (32,32) / (64,64): two or three tanh
+ * layers of 32 / 64 / 128 units, weight fragments in LDS) or of a policy with a log-std NETWORK (std_hidden0 != 0:
+ * both networks' fragments in LDS) needs at its smallest launch shape (one wavefront per workgroup), and the limit of
+ * a CU (160 KB).  *bytes = 0: the sizes are not a kernel shape at all.  rl_rollout_gaussian_mlp lowers its
+ * wavefronts-per-workgroup until the workgroup fits and returns RL_ERR_UNSUPPORTED when *bytes > *limit; a caller asks
+ * here first and samples such a policy through rl_vecenv_step instead (rllab/policies/gaussian_mlp_policy.py:21-98 is
+ * free-form in its hidden sizes; e.g. mean (128,128) + log-std (128,128) on a 20-observation env needs 172 KB). */
+int rl_rollout_lds_bytes(int env_kind, int hidden0, int hidden1, int hidden2, int std_hidden0, int std_hidden1,
+                         int std_hidden2, size_t* bytes, size_t* limit);
+
 /* Segmented reverse linear-recurrence scans over [T][n] planes, fused:
  *   delta[t] = r[t] + gamma * V[t+1] * (1 - end[t]) - V[t]
  *   adv[t]   = delta[t] + gamma*lambda * (1 - end[t]) * adv[t+1]

@@ -194,6 +194,26 @@ def run(kind, theta, T, max_samples, n_parallel, hidden=(32, 32), seed=1, dump_p
                                                                            p.stderr[-4000:]))
 
 
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo: what ``os.cpu_count()`` (hardware threads) is not."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""profiles/make_index.py -- regenerate profiles/INDEX.md: every tracked file under profiles/ with the commit that last
+wrote it and the command that produces it.  Run from the repo root after committing new evidence:
+    python profiles/make_index.py && git add profiles/INDEX.md
+The command column comes from the table below (first matching pattern wins); a file no pattern matches is listed as
+"(no recipe recorded)" so that it shows up in review."""
+import fnmatch
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# pattern -> (what it is, command that writes it on the GPU box)
+RECIPES = [
+    ("pmc_traffic.json", "HBM bytes + vector-instruction counters of the rollout kernels per workload, stamped with sha256(csrc/*); bench.py reads it",
+     "profiles/run_profile.sh <tag> (traffic step: profiles/summarize.py traffic ...)"),
+    ("*_bench_line.json", "the default bench line of that tree", "python bench.py"),
+    ("*_bench_under_rocprof.log", "bench stdout under the kernel-trace pass", "profiles/run_profile.sh <tag>"),
+    ("*_c5_kernel_stats.csv", "kernel stats of C5's per-GPU shard", "profiles/run_profile.sh <tag> cheetah1024_trpo_gae"),
+    ("*_c5_pmc_*.csv", "PMC passes of C5's per-GPU shard (one counter group per pass)", "profiles/run_profile.sh <tag> cheetah1024_trpo_gae"),
+    ("*_c2_*.csv", "kernel stats / PMC passes of C2 (Cartpole 4096 envs, VPG)", "profiles/run_profile.sh <tag> cartpole4096_vpg"),
+    ("*_split_kernel_stats.csv", "kernel stats of the three Fisher-vector-product kernels back to back", "tools/prof_split.sh"),
+    ("*_split_pmc_*.csv", "PMC passes of the product kernels", "tools/prof_split.sh"),
+    ("*_split64_*.csv", "kernel stats / PMC passes of the 64-unit split product", "tools/prof_split.sh 64"),
+    ("*_wide*_pmc_*.csv", "PMC passes of the wide / deep kernels", "tools/prof_wide.sh"),
+    ("*_wide*_stats.csv", "kernel stats of the wide / deep kernels", "tools/prof_wide.sh"),
+    ("*_fvp_fixed_cost_stats.csv", "50 cached products back to back per batch size", "python tools/exp/fvp_fixed_cost.py under rocprofv3 --kernel-trace --stats"),
+    ("*_step_kernel_roofline.jsonl", "rl_vecenv_step at 4 M envs, HIP-event timing", "python tools/step_kernel_roofline.py"),
+    ("*_step_kernel_stats.csv", "the same under rocprofv3 --kernel-trace --stats", "profiles/run_profile.sh <tag>"),
+    ("*_timeline.csv", "one iteration's dispatch timeline (start, duration, idle gap)", "profiles/run_profile.sh <tag> (summarize.py timeline)"),
+    ("*_kernel_stats.csv", "rocprofv3 --kernel-trace --stats summary of `bench.py --steps 5 --warmup 2`", "profiles/run_profile.sh <tag>"),
+    ("*_cheetah_pmc_*.csv", "PMC passes of the HalfCheetah shard", "profiles/run_profile.sh <tag> (cheetah leg)"),
+    ("*_pmc_fetch_size.csv", "FETCH_SIZE pass (own run)", "profiles/run_profile.sh <tag>"),
+    ("*_pmc_write_size.csv", "WRITE_SIZE pass (own run)", "profiles/run_profile.sh <tag>"),
+    ("*_pmc_sq*.csv", "SQ_* counter passes (own runs)", "profiles/run_profile.sh <tag>"),
+    ("*_bench_*.json", "side bench line: workload / size / switch in the file name", "python bench.py --workload ... | --n-envs ... | --hidden ... (tools/exp/r0N_final_bench.sh)"),
+    ("*_resource_usage.txt", "-Rpass-analysis=kernel-resource-usage lines (registers, spills, LDS) of the named kernels", "tools/resource_usage.sh"),
+    ("*_preflight*.json", "multi-GPU pre-flight record", "python tools/preflight_multigpu.py"),
+    ("*_notes.md", "the round's measurements, experiments and dead ends in prose", "(written by hand from the files of that round)"),
+    ("curves/*", "tabular training logs of the learning-curve runs", "tools/learning_curves.sh, tools/exp/r03_*curves*.sh"),
+    ("run_profile.sh", "the profile recipe", "-"),
+    ("summarize.py", "condenses rocprofv3 output directories into the CSVs kept here", "-"),
+    ("make_index.py", "writes this index", "-"),
+    ("INDEX.md", "this file", "python profiles/make_index.py"),
+]
+
+ROUND_SETS = """\
+One evidence set per round (older intermediate sets `r01a … r01l` were pruned in round 4; `git log -- profiles/` has them):
+
+| round | set | kernel-source state |
+|---|---|---|
+| 1 | `r01_kernel_stats.csv` (first build, VALU design) and `r01m_*` (end of round 1), `r01n_bench_line.json` | the commits in the table below |
+| 2 | `r02_*` | end of round 2 |
+| 3 | `r03_*` (headline), `r03_split_*` (product kernels), `r03_wide_*` | HEAD of round 3 = `8bd729a`; `pmc_traffic.json` carries the sha256 of `rllab_amd/csrc/*` it was taken at |
+| 4 | `r04_*` | see the stamp in `pmc_traffic.json` and `r04_notes.md` |
+"""
+
+
+def main():
+    files = subprocess.check_output(["git", "ls-files", "profiles"], cwd=ROOT, text=True).split()
+    rows = []
+    for f in sorted(files):
+        rel = f[len("profiles/"):]
+        log = subprocess.check_output(["git", "log", "-1", "--format=%h %ad", "--date=short", "--", f], cwd=ROOT, text=True).strip()
+        what, cmd = "(no recipe recorded)", ""
+        for pat, w, c in RECIPES:
+            if fnmatch.fnmatch(rel, pat):
+                what, cmd = w, c
+                break
+        rows.append((rel, log or "(uncommitted)", what, cmd))
+    with open(os.path.join(ROOT, "profiles", "INDEX.md"), "w") as fh:
+        fh.write("# profiles/ index (generated by `python profiles/make_index.py`)\n\n")
+        fh.write(ROUND_SETS + "\n")
+        fh.write("| file | last written by (commit, date) | what | command |\n|---|---|---|---|\n")
+        for r in rows:
+            fh.write("| `%s` | %s | %s | `%s` |\n" % r)
+    print("profiles/INDEX.md: %d files" % len(rows))
+
+
+if __name__ == "__main__":
+    main()

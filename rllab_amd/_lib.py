@@ -26,7 +26,7 @@ ENV_INVERTED_DOUBLE_PENDULUM = 7
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
-    "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_gae",
+    "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_rollout_lds_bytes", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_variant", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
@@ -106,6 +106,8 @@ def _load():
     lib.rl_counter_add.argtypes = [vp, u64, vp]
     lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, cfgp, vp, vp, vp, vp]
     lib.rl_rollout_gaussian_mlp.argtypes = [ctypes.POINTER(RolloutArgs), vp]
+    lib.rl_rollout_lds_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_size_t),
+                                         ctypes.POINTER(ctypes.c_size_t)]
     lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp, vp]
     lib.rl_discount_cumsum.argtypes = [i32, i32, vp, vp, f64, vp, vp]
     lib.rl_debug_philox.argtypes = [u32, u32, u32, u32, u32, u32, i32, vp, vp]
@@ -181,6 +183,18 @@ def env_query(kind):
                            ctypes.byref(nrm)), "rl_env_query")
     return dict(obs_dim=o.value, act_dim=a.value, state_dim=s.value, reset_draws=r.value,
                 reset_is_normal=bool(nrm.value))
+
+
+def rollout_lds_fits(kind, hidden3, std_hidden3=(0, 0, 0)):
+    """Does the fused rollout of these hidden sizes (and, with ``std_hidden3``, of a log-std network next to the mean
+    network) fit the LDS of a CU for env ``kind``?  rl_rollout_lds_bytes; equal-width (32, 32) / (64, 64) nets keep
+    their weights in registers and always fit."""
+    if tuple(std_hidden3) == (0, 0, 0) and tuple(hidden3) in ((32, 32, 0), (64, 64, 0)):
+        return True
+    b, lim = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib.rl_rollout_lds_bytes(kind, hidden3[0], hidden3[1], hidden3[2], std_hidden3[0], std_hidden3[1],
+                                   std_hidden3[2], ctypes.byref(b), ctypes.byref(lim)), "rl_rollout_lds_bytes")
+    return 0 < b.value <= lim.value
 
 
 def env_default_cfg(kind, **overrides):

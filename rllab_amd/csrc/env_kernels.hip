@@ -1307,6 +1307,27 @@ static int lane_group_wpb(int waves) {
     return waves <= 256 ? 1 : LANE_TPB / 64;
 }
 
+constexpr size_t LDS_LIMIT = 160 * 1024;
+// The wide / dual rollouts keep their weight fragments in LDS next to one [input][lane] tile per wavefront: a workgroup
+// of several wavefronts may not fit where a single-wavefront one does.  Largest wavefronts-per-workgroup <= wpb whose
+// workgroup fits the 160 KB of a CU; 0 when not even one wavefront does (the caller then reports UNSUPPORTED and the
+// Python side samples such a policy through the per-transition loop, rl_rollout_lds_bytes tells it beforehand).
+template <class LdsFn>
+static int fit_wpb(int wpb, LdsFn lds_bytes) {
+    for (; wpb >= 1; wpb >>= 1)
+        if (lds_bytes(64 * wpb) <= LDS_LIMIT) return wpb;
+    return 0;
+}
+
+template <class Env>
+static size_t rollout_lds_bytes(int h0, int h1, int h2, int s0, int s1, int s2) {
+    WideShape ms, ss;
+    if (!wide_shape(Env::OBS, Env::ACT, h0, h1, h2, ms)) return 0;
+    if (s0 == 0) return RolloutPolicyWide<Env>::lds_floats(ms, 64) * sizeof(float);
+    if (!wide_shape(Env::OBS, Env::ACT, s0, s1, s2, ss)) return 0;
+    return RolloutPolicyDual<Env>::lds_floats(ms, ss, 64) * sizeof(float);
+}
+
 template <class Env>
 static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     RolloutDev a;
@@ -1335,11 +1356,15 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         const char* es = getenv("RLLAB_ROLLOUT_EPW");
         const int ee = es ? atoi(es) : 0;
         const int epw = (ee == 16 || ee == 64) ? ee : (a.n <= 16 * 1024 ? 16 : 64);
-        const int waves = (a.n + epw - 1) / epw, wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
+        const int waves = (a.n + epw - 1) / epw;
+        const int wpb = fit_wpb((epw == 16) ? lane_group_wpb(waves) : 1, [&](int threads) {
+            return RolloutPolicyDual<Env>::lds_floats(ms, ss, threads) * sizeof(float); });
+        if (wpb == 0)
+            return set_error(RL_ERR_UNSUPPORTED, "rollout of the two networks needs %zu B of LDS (a CU has %zu)",
+                             RolloutPolicyDual<Env>::lds_floats(ms, ss, 64) * sizeof(float), LDS_LIMIT);
         dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
         const size_t mean_floats = RolloutPolicyWide<Env>::lds_floats(ms, 64 * wpb);
         const size_t lds = RolloutPolicyDual<Env>::lds_floats(ms, ss, 64 * wpb) * sizeof(float);
-        if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "rollout of the two networks needs %zu B of LDS", lds);
         static bool attr16 = false, attr64 = false;
         if (epw == 16) {
             auto kern = rollout_dual_kernel<Env, 16>;
@@ -1378,10 +1403,12 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         WideShape shape;
         if (!lane_kernel && small_offsets && getenv("RLLAB_ROLLOUT_EPW") == nullptr &&
             wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
-            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
-            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
-            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
-            if (lds <= 160 * 1024) {
+            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS;
+            const int wpb = fit_wpb(lane_group_wpb(waves), [&](int threads) {
+                return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
+            dim3 qgrid((waves + (wpb ? wpb : 1) - 1) / (wpb ? wpb : 1)), qblock(64 * (wpb ? wpb : 1));
+            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * (wpb ? wpb : 1)) * sizeof(float);
+            if (wpb > 0) {
                 auto kern = rollout_swimmer_quad_wide_kernel;
                 static bool attr = false;
                 if (!attr) {
@@ -1412,10 +1439,12 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         WideShape shape;
         if (lanes_on && small_offsets && a.n <= 16 * 1024 &&
             wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
-            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
-            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
-            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
-            if (lds <= 160 * 1024) {
+            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS;
+            const int wpb = fit_wpb(lane_group_wpb(waves), [&](int threads) {
+                return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
+            dim3 qgrid((waves + (wpb ? wpb : 1) - 1) / (wpb ? wpb : 1)), qblock(64 * (wpb ? wpb : 1));
+            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * (wpb ? wpb : 1)) * sizeof(float);
+            if (wpb > 0) {
                 auto kern = rollout_two_leg_quad_wide_kernel<Env>;
                 static bool attr = false;
                 if (!attr) {
@@ -1434,7 +1463,8 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     const char* epw_str = getenv("RLLAB_ROLLOUT_EPW");      // read per launch: tests switch shapes inside one process
     const int epw_env = epw_str ? atoi(epw_str) : 0;
     const int epw = (epw_env == 16 || epw_env == 64) ? epw_env : (a.n <= 16 * 1024 ? 16 : 64);
-    const int waves = (a.n + epw - 1) / epw, wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
+    const int waves = (a.n + epw - 1) / epw;
+    int wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
     dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
     if (g->hidden2 == 0 && g->hidden0 == 32 && g->hidden1 == 32) {
         if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, block, 0, st, a);
@@ -1450,8 +1480,12 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
                              "rl_rollout_gaussian_mlp: hidden sizes (%d,%d,%d) have no fused kernel (two or three tanh "
                              "layers of 32 / 64 / 128 units each); use the per-step rl_vecenv_step path",
                              g->hidden0, g->hidden1, g->hidden2);
+        wpb = fit_wpb(wpb, [&](int threads) { return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
+        if (wpb == 0)
+            return set_error(RL_ERR_UNSUPPORTED, "wide rollout policy needs %zu B of LDS (a CU has %zu)",
+                             RolloutPolicyWide<Env>::lds_floats(shape, 64) * sizeof(float), LDS_LIMIT);
+        grid = dim3((waves + wpb - 1) / wpb); block = dim3(64 * wpb);
         const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
-        if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "wide rollout policy needs %zu B of LDS", lds);
         static bool attr16 = false, attr64 = false;
         if (epw == 16) {
             auto kern = rollout_wide_kernel<Env, 16>;
@@ -1577,6 +1611,15 @@ extern "C" int rl_rollout_gaussian_mlp(const rl_rollout_args* g, void* stream) {
         !g->means || !g->rewards || !g->dones)
         return set_error(RL_ERR_ARG, "rl_rollout_gaussian_mlp: bad argument");
     RL_DISPATCH_ENV(g->kind, launch_rollout<E>(g, (hipStream_t)stream))
+}
+
+extern "C" int rl_rollout_lds_bytes(int kind, int hidden0, int hidden1, int hidden2, int std_hidden0, int std_hidden1,
+                                    int std_hidden2, size_t* bytes, size_t* limit) {
+    if (!bytes) return set_error(RL_ERR_ARG, "rl_rollout_lds_bytes: null output");
+    if (limit) *limit = LDS_LIMIT;
+#define Q (*bytes = rollout_lds_bytes<E>(hidden0, hidden1, hidden2, std_hidden0, std_hidden1, std_hidden2), (int)RL_OK)
+    RL_DISPATCH_ENV(kind, Q)
+#undef Q
 }
 
 extern "C" int rl_debug_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

@@ -17,7 +17,10 @@
 // Reduction number seq (1, 2, 3, ...; identical on all ranks, they issue the same launch train) uses slot seq & 1.
 // Two slots suffice: a rank can start writing reduction seq + 2 into a peer only after that peer raised its flag for
 // seq + 1, which it does after it finished reading seq.
-// Every spin is bounded (a missing peer sets *err and the launch completes; the host raises at its next check).
+// Every spin is bounded BY WALL CLOCK (s_memrealtime, 100 MHz: a straggler's GC pause or first-launch module load is
+// milliseconds, the limit is seconds); a missing peer sets *err, the launch completes and its output is POISONED with
+// NaN -- the consumer (CG / the line search) then rejects the step instead of applying an update computed from stale
+// rows; the host raises at its next check of the error word.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,7 +39,8 @@ struct PeerArgs {
     double* data;
     char* box[PEER_MAX_WORLD];     // box[rank] = own mailbox, box[p] = peer p's (IPC mapping)
     int* err;
-    long long spin_limit;
+    long long spin_limit;          // iterations (tests of the give-up path)
+    long long tick_limit;          // 100 MHz wall-clock ticks
 };
 
 __device__ __forceinline__ unsigned long long* flag_of(char* box, int slot, int src) {
@@ -59,15 +63,29 @@ __global__ void __launch_bounds__(PEER_THREADS) peer_allreduce_kernel(PeerArgs a
     if (threadIdx.x < a.world)
         __hip_atomic_store(flag_of(a.box[threadIdx.x], slot, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // 2. wait for the world's rows in MY mailbox (one lane per source rank, bounded)
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    __syncthreads();
     if (threadIdx.x < a.world) {
         unsigned long long* f = flag_of(a.box[a.rank], slot, threadIdx.x);
         long long spins = 0;
+        const long long t0 = (long long)wall_clock64();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > a.spin_limit) { atomicExch(a.err, 1 + (int)threadIdx.x); break; }
+            if (++spins > a.spin_limit || (long long)wall_clock64() - t0 > a.tick_limit) {
+                atomicExch(a.err, 1 + (int)threadIdx.x);
+                atomicExch(&gave_up, 1);
+                break;
+            }
         }
     }
     __syncthreads();
+    if (gave_up) {
+        // a row of the world never arrived: whatever sits in the mailbox is stale.  NaN out the result so that nothing
+        // downstream (CG's dot products, the line search's acceptance test) can mistake it for a sum.
+        for (int i = threadIdx.x; i < a.n; i += PEER_THREADS) a.data[i] = __builtin_nan("");
+        return;
+    }
     __threadfence_system();                       // acquire: the rows behind the flags
     // 3. fixed-order sum: the same bits on every rank
     for (int i = threadIdx.x; i < a.n; i += PEER_THREADS) {
@@ -150,9 +168,10 @@ extern "C" int rl_peer_allreduce_sum(int n, double* data, int rank, int world, v
     for (int p = 0; p < PEER_MAX_WORLD; ++p) a.box[p] = p < world ? (char*)mailboxes[p] : nullptr;
     for (int p = 0; p < world; ++p)
         if (!a.box[p]) return set_error(RL_ERR_ARG, "rl_peer_allreduce_sum: mailbox %d is null", p);
-    // x (s_sleep 8 + one load) ~ seconds: a peer that never arrives is an error.  RLLAB_PEER_SPIN_LIMIT: tests of the
-    // give-up path make it milliseconds.
-    a.spin_limit = 4000000;
+    // a peer that has not delivered after 10 s of wall clock is an error.  RLLAB_PEER_SPIN_LIMIT (iterations of
+    // s_sleep 8 + one load): tests of the give-up path make it milliseconds.
+    a.tick_limit = 10ll * 100000000ll;
+    a.spin_limit = 1ll << 62;
     if (const char* sl = getenv("RLLAB_PEER_SPIN_LIMIT")) {
         const long long v = atoll(sl);
         if (v > 0) a.spin_limit = v;

@@ -453,8 +453,9 @@ extern "C" int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs,
         return set_error(RL_ERR_ARG, "rl_lfb_normal_eq: workspace too small");
     const size_t lds = (size_t)NE_WAVES * NE_TILE * (FE + 2) * sizeof(double);
     hipError_t e = hipSuccess;
-    // RLLAB_LFB_VALU=1 selects the register-blocked vector kernel (A/B timing; same sums up to association)
-    static const bool valu = getenv("RLLAB_LFB_VALU") != nullptr;
+    // RLLAB_LFB_VALU=1 selects the register-blocked vector kernel (A/B timing; same sums up to association); read per
+    // launch so that the parity test can run both forms in one process
+    const bool valu = getenv("RLLAB_LFB_VALU") != nullptr;
     if (FE == 32 && !valu) {
         static bool set = false;
         if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }

@@ -183,6 +183,19 @@ class HipVecEnv(object):
         self.ts.zero_()
 
     # -- fused rollout ---------------------------------------------------------
+    def takes_rollout_of(self, policy):
+        """True when ``rollout(policy, ..)`` has a kernel for this policy ON THIS ENV: the policy offers a kernel
+        layout (or its two networks) and the weight fragments of a wide / deep / dual-network shape fit the LDS of a CU
+        next to the env's observation tile (rl_rollout_lds_bytes) -- e.g. a (128,128) mean net + a (128,128) log-std
+        net on a 20-observation env needs 172 KB and is sampled through the per-transition loop instead."""
+        layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
+        if layout is not None:
+            return _lib.rollout_lds_fits(self.kind, layout.hidden3)
+        dual = policy.rollout_networks() if hasattr(policy, "rollout_networks") else None
+        if dual is not None:
+            return _lib.rollout_lds_fits(self.kind, dual[1], dual[3])
+        return False
+
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
                 obs_noise_z=None):
         """``horizon`` lock-step iterations of get_actions -> step -> record ->

@@ -73,6 +73,7 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         assert self.nets[1][0] + self.nets[1][1] == policy.flat_params.numel()
         self.dims = (do, da, self.nets[0][2], self.nets[0][2], 0)
         self.n_kernel = self.layout.P_pad
+        self.wide_kernels = False                        # (the base __init__ is not run: every attribute it sets is set here)
         self._ws = None
         self._loss_cache = None
         self._bound = {}
@@ -134,7 +135,12 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
                 log_min_std=log_min, theta=None, obs=obs.data_ptr(), actions=act.data_ptr(),
                 advantages=adv.data_ptr(), old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(),
                 weights=w.data_ptr()))
-        b = dict(structs=structs, planes=planes, log_min=log_min, B=B, tensors=dict(obs=obs, act=act, adv=adv,
+        # per-network scratch of the passes, allocated once per bound batch (ten Fisher-vector products per update
+        # would otherwise allocate and fill four tensors each): the tangent in the kernels' policy layout
+        # [network parameters | Da zeros] and the float64 gradient row rl_mlp_backward writes
+        scratch = [dict(tangent=torch.zeros(size + da, **f32),
+                        grad=torch.empty(size + da, dtype=torch.float64, device=dev)) for _, size, _ in self.nets]
+        b = dict(structs=structs, planes=planes, log_min=log_min, B=B, scratch=scratch, tensors=dict(obs=obs, act=act, adv=adv,
                                                                                       old_mean=old_mean, old_ls=old_ls, w=w))
         self._point_at_current_parameters(b)
         if len(self._bound) >= 2:
@@ -169,7 +175,7 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         p, st = b["planes"], _lib.stream_ptr()
         for i, gname in enumerate(("gmean", "glstd")):
             off, size, _ = self.nets[i]
-            g = torch.empty(size + self.dims[1], dtype=torch.float64, device=out.device)
+            g = b["scratch"][i]["grad"]
             _lib.check(_lib.lib.rl_mlp_backward(ctypes.byref(b["structs"][i]), _lib.ptr(p[gname]), _lib.ptr(ws),
                                                 ws.numel(), _lib.ptr(g), st), "rl_mlp_backward")
             out[off:off + size].copy_(g[:size])
@@ -212,10 +218,9 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         """F vec: tangents of both networks, the (diagonal) Fisher metric of the head, back through both networks."""
         da = self.dims[1]
         tangents = []
-        for off, size, _ in self.nets:
-            t = torch.zeros(size + da, dtype=torch.float32, device=vec32.device)
-            t[:size].copy_(vec32[off:off + size])
-            tangents.append(t)
+        for (off, size, _), sc in zip(self.nets, b["scratch"]):
+            sc["tangent"][:size].copy_(vec32[off:off + size])     # (the Da trailing floats stay zero)
+            tangents.append(sc["tangent"])
         self._forward(b, tangents)
         p, t_ = b["planes"], b["tensors"]
         _lib.check(_lib.lib.rl_gaussian_fisher(
@@ -223,6 +228,10 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
             float(b["structs"][0].inv_count), b["log_min"], _lib.ptr(p["gmean"]), _lib.ptr(p["glstd"]),
             _lib.stream_ptr()), "rl_gaussian_fisher")
         return D.update_sum_(self._backward(b, ws, out))
+
+    def fvp_variant(self, inputs):
+        """The networks-on-planes products run on the f32 matrix instructions (variant 0)."""
+        return 0
 
     def _cg_loop(self, b, ws, inputs, cg_iters, reg_coeff, residual_tol, x, r, p, p32, z, scal, st):
         for _ in range(cg_iters):

@@ -64,10 +64,14 @@ class VectorizedSampler(BaseSampler):
 
     def _takes_fused_rollout(self, policy):
         """True when ``obtain_samples`` is ONE asynchronous launch for this policy (the fused rollout kernels)."""
-        fusable = (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None) or \
+        ve = self.vec_env
+        if ve is None or ve.position_ids is not None or not getattr(ve, "graphable", True):
+            return False
+        if hasattr(ve, "takes_rollout_of"):
+            # the kernels' own answer: a layout exists AND its weight fragments fit the LDS of a CU on this env
+            return ve.takes_rollout_of(policy)
+        return (hasattr(policy, "kernel_layout") and policy.kernel_layout() is not None) or \
             (hasattr(policy, "rollout_networks") and policy.rollout_networks() is not None)
-        return (fusable and self.vec_env is not None and self.vec_env.position_ids is None
-                and getattr(self.vec_env, "graphable", True))
 
     def prefetch(self, itr):
         """Enqueue iteration ``itr``'s rollout NOW and keep the lazy batch for ``obtain_samples(itr)``: BatchPolopt

@@ -224,3 +224,29 @@ def test_struct_offsets_against_the_compiled_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for f, _ in cls._fields_:
             assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+
+
+def test_every_env_switch_is_documented():
+    """Every RLLAB_* environment switch the product (package, bench.py, the build entry) reads has a row in
+    INTEGRATION.md section 4, and every test file that row names exists and mentions the switch (or the attribute the
+    row says stands for it)."""
+    import glob
+    import re
+    names = set()
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for ext_ in ("py", "hip", "h"):
+        files += glob.glob(os.path.join(ROOT, "rllab_amd", "**", "*." + ext_), recursive=True)
+    for f in files:
+        names |= set(re.findall(r"RLLAB_[A-Z0-9_]+", open(f, errors="replace").read()))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = text[text.index("## 4. Environment switches"):]
+    rows = {m.group(1): m.group(0) for m in re.finditer(r"^\| `(RLLAB_[A-Z0-9_]+)` \|.*$", section, re.M)}
+    assert names, "no switches found: the grep is broken"
+    missing = sorted(names - set(rows))
+    assert not missing, "switches read by the product but absent from INTEGRATION.md section 4: %s" % missing
+    stale = sorted(set(rows) - names)
+    assert not stale, "INTEGRATION.md documents switches nothing reads: %s" % stale
+    for name, row in rows.items():
+        for tf in re.findall(r"`((?:tests/)?test_[a-z0-9_]+\.py)", row):
+            path = os.path.join(ROOT, tf if tf.startswith("tests/") else os.path.join("tests", tf))
+            assert os.path.exists(path), (name, tf)

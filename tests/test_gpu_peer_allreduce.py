@@ -74,6 +74,9 @@ def test_a_peer_that_never_arrives_sets_the_error_word(monkeypatch):
                                                   _lib.stream_ptr()), "rl_peer_allreduce_sum")
         torch.cuda.synchronize()                             # the launch COMPLETES: nothing hangs
         assert int(err.item()) == 1 + 1                      # 1 + the rank whose flag never came
+        # and its output is poisoned, not a sum over stale rows: CG / the line search reject a NaN step
+        assert bool(torch.isnan(x).all())
+        x = torch.arange(n, dtype=torch.float64, device="cuda")
         # sticky: a later, complete reduction does not clear it
         y = torch.ones(n, dtype=torch.float64, device="cuda")
         s1 = torch.cuda.Stream()

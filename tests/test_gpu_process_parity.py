@@ -266,9 +266,15 @@ def _np_features(obs, tin):
 
 @pytest.mark.parametrize("T,n,do", [(1, 1, 4), (7, 3, 6), (100, 257, 13), (513, 64, 20)])
 @pytest.mark.parametrize("whole_paths", [True, False])
-def test_path_scan_and_normal_equations_vs_numpy(T, n, do, whole_paths):
+@pytest.mark.parametrize("valu_form", [False, True])
+def test_path_scan_and_normal_equations_vs_numpy(T, n, do, whole_paths, valu_form, monkeypatch):
     """rl_path_scan (path index, validity, fused baseline prediction) and rl_lfb_normal_eq
-    (Phi^T W Phi, Phi^T W y) against per-column numpy loops / a float64 feature matrix."""
+    (Phi^T W Phi, Phi^T W y) against per-column numpy loops / a float64 feature matrix; the normal equations in both
+    of their forms (f64 matrix instructions by default, RLLAB_LFB_VALU=1: the f64 vector-ALU kernel)."""
+    if valu_form:
+        monkeypatch.setenv("RLLAB_LFB_VALU", "1")
+    else:
+        monkeypatch.delenv("RLLAB_LFB_VALU", raising=False)
     from rllab_amd import _lib
     from rllab_amd.sampler.base import _workspace
     rng = np.random.RandomState(T * 100 + n)

@@ -1,6 +1,7 @@
 """Host-side logic of the product on CPU tensors (no kernel launches): API seams,
 parameter layout, optimizer control flow against the golden fixtures of the real
 reference."""
+import os
 import pickle
 
 import numpy as np
@@ -580,3 +581,13 @@ def test_sliced_fun_against_the_reference_fixture():
         a, b = ext.sliced_fun(target, k)([g["x"], g["y"]], [g["w"]])
         assert np.allclose(a, g["k%d_0" % k], rtol=1e-13, atol=0) and np.allclose(b, g["k%d_1" % k], rtol=1e-13, atol=0)
     assert np.isclose(ext.sliced_fun(lambda xs: xs.mean(), 4)([g["y"]]), g["bare"], rtol=1e-13)
+
+
+def test_log_dir_switch(tmp_path):
+    """RLLAB_LOG_DIR moves config.LOG_DIR (read at import: checked in a child interpreter)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RLLAB_LOG_DIR=str(tmp_path))
+    out = subprocess.check_output([sys.executable, "-c", "from rllab_amd import config; print(config.LOG_DIR)"],
+                                  env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.decode().strip() == str(tmp_path)
