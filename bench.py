@@ -193,6 +193,14 @@ def main():
     common = dict(env=env, policy=policy, baseline=baseline, batch_size=n_envs * T, max_path_length=T,
                   n_itr=10 ** 9, discount=0.99, gae_lambda=wl["lam"], sampler_args=dict(n_envs=n_envs))
     algo = TRPO(step_size=0.01, **common) if wl["algo"] == "trpo" else VPG(**common)
+    preflight_rec = None
+    if world > 1:
+        # multi-GPU pre-flight (rllab_amd/sampler/preflight.py; seconds): devices, peer-access matrix, the in-stream
+        # peer all-reduce across the ranks' devices bit for bit against the backend, 100-call latency of both, and the
+        # path every rank takes (all-reduce-min of the verdicts) -- before any warm-up, reported in the JSON line.
+        # In child processes: a topology the peer path has never seen cannot take the measurement with it.
+        from rllab_amd.sampler import preflight
+        preflight_rec = preflight.run_isolated(n=policy.flat_params.numel())
     algo.start_worker()
     algo.init_opt()
 
@@ -399,6 +407,8 @@ def main():
         "collectives_per_iter": collectives_per_iter, "collective_bytes_per_iter": collective_bytes_per_iter,
         "peer_reductions_per_iter": peer_reductions_per_iter,
         "collective_ms_per_iter": collective_ms_per_iter,
+        "update_sum_path": D.peer_status()[0] if dist.is_initialized() else None,
+        "preflight": preflight_rec,
         "trpo_iter_ms": elapsed / args.steps * 1e3,
         "phase_ms": {k: v / args.steps for k, v in phase_ms.items()},
         "update_ms_and_backtracks_per_iteration": per_iter,

@@ -79,7 +79,7 @@ def pmc(d, out):
                        + ["%d" % (sum(dur[k]) // len(dur[k])) if dur.get(k) else ""])
 
 
-def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=4096, tag="", sq_csv=None):
+def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=4096, tag="", sq_csv=None, sq2_csv=None):
     """HBM bytes per launch of the rollout kernel from the FETCH_SIZE / WRITE_SIZE summaries (KB).
     Reads are 4 B/lane plane loads (not the 16 B/lane streams MI355X_MICROARCH.md's x2 correction
     was calibrated on) and are < 1 % of the total here, so they are taken as reported."""
@@ -109,6 +109,19 @@ def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=
                                      rollout_gui_active=float(r["mean_GRBM_GUI_ACTIVE"]),
                                      rollout_active_inst_valu=float(r["mean_SQ_ACTIVE_INST_VALU"]),
                                      rollout_wave_cycles=float(r["mean_SQ_WAVE_CYCLES"]))
+                break
+    if sq2_csv:
+        # second SQ pass: scalar instructions, matrix instructions and the matrix pipe's busy cycles, time parked at
+        # s_waitcnt -- what the issue-slot accounting of a lone wavefront needs beside the vector instructions
+        for r in csv.DictReader(open(sq2_csv)):
+            if "rollout_" in r["kernel"]:
+                for key, col in (("rollout_insts_salu", "mean_SQ_INSTS_SALU"), ("rollout_insts_mfma", "mean_SQ_INSTS_MFMA"),
+                                 ("rollout_mfma_busy_cycles", "mean_SQ_VALU_MFMA_BUSY_CYCLES"),
+                                 ("rollout_wait_any", "mean_SQ_WAIT_ANY"), ("rollout_insts_vmem", "mean_SQ_INSTS_VMEM"),
+                                 ("rollout_insts_smem", "mean_SQ_INSTS_SMEM"),
+                                 ("rollout_active_inst_any", "mean_SQ_ACTIVE_INST_ANY")):
+                    if r.get(col):
+                        rec[workload][key] = float(r[col])
                 break
     json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
 

@@ -97,10 +97,27 @@ def all_reduce_sum_(t):
 # Opt-in (RLLAB_PEER_ALLREDUCE=1) until an 8-GPU run has confirmed it against RCCL; everything else (statistics,
 # normal equations, loss sums) stays a torch.distributed collective.
 _peer = None
+_peer_refused = None      # why the peer path was refused by the start-up checks (all ranks agree), or None
+
+
+def _agree(ok):
+    """min over ranks of a local success flag, through the backend (every rank takes the same branch afterwards)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
 
 
 class PeerReducer(object):
-    """Mailboxes of the world, exchanged once at start-up (host side, torch.distributed.all_gather_object)."""
+    """Mailboxes of the world, exchanged once at start-up (host side, torch.distributed.all_gather_object).
+
+    Construction is a COLLECTIVE that cannot leave a rank behind: every stage that may fail on one rank only
+    (fine-grained allocation, hipIpc export, mapping a peer's handle across devices) ends in an all-reduce-min of the
+    stage's success, and a failure anywhere makes every rank release what it holds and raise ``PeerUnavailable`` --
+    ``peer_reducer()`` then logs the reason and the run stays on the backend's all-reduce (RCCL)."""
+
+    class PeerUnavailable(RuntimeError):
+        pass
 
     def __init__(self, max_n=1 << 16):
         import ctypes
@@ -109,30 +126,104 @@ class PeerReducer(object):
         self.rank, self.world, self.max_n = dist.get_rank(), dist.get_world_size(), int(max_n)
         if self.world > 8:
             raise RuntimeError("peer all-reduce: one node, at most 8 ranks (got %d)" % self.world)
-        nbytes = _lib.lib.rl_peer_mailbox_bytes(self.world, self.max_n)
-        own = ctypes.c_void_p()
-        _lib.check(_lib.lib.rl_peer_alloc(nbytes, ctypes.byref(own)), "rl_peer_alloc")
-        self._own = own
+        self._own, self._opened, self.err = None, [], None
+        why = None
+        # stage 1: own mailbox (fine-grained device memory) and its IPC handle
         handle = (ctypes.c_char * 64)()
-        _lib.check(_lib.lib.rl_peer_export(own, handle), "rl_peer_export")
+        try:
+            nbytes = _lib.lib.rl_peer_mailbox_bytes(self.world, self.max_n)
+            own = ctypes.c_void_p()
+            _lib.check(_lib.lib.rl_peer_alloc(nbytes, ctypes.byref(own)), "rl_peer_alloc")
+            self._own = own
+            _lib.check(_lib.lib.rl_peer_export(own, handle), "rl_peer_export")
+        except RuntimeError as e:
+            why = str(e)
+        if not _agree(why is None):
+            self._release()
+            raise PeerReducer.PeerUnavailable(why or "a peer could not allocate / export its mailbox")
+        # stage 2: map every peer's mailbox (across DEVICES on a multi-GPU node: hipIpcOpenMemHandle + peer access)
         handles = [None] * self.world
         dist.all_gather_object(handles, bytes(handle.raw))
         self._table = (ctypes.c_void_p * self.world)()
-        self._opened = []
-        for r in range(self.world):
-            if r == self.rank:
-                self._table[r] = own.value
-            else:
-                p = ctypes.c_void_p()
-                buf = ctypes.create_string_buffer(handles[r], 64)
-                _lib.check(_lib.lib.rl_peer_open(buf, ctypes.byref(p)), "rl_peer_open")
-                self._table[r] = p.value
-                self._opened.append(p)
+        try:
+            for r in range(self.world):
+                if r == self.rank:
+                    self._table[r] = self._own.value
+                else:
+                    p = ctypes.c_void_p()
+                    buf = ctypes.create_string_buffer(handles[r], 64)
+                    _lib.check(_lib.lib.rl_peer_open(buf, ctypes.byref(p)), "rl_peer_open")
+                    self._table[r] = p.value
+                    self._opened.append(p)
+        except RuntimeError as e:
+            why = str(e)
+        if not _agree(why is None):
+            self._release()
+            raise PeerReducer.PeerUnavailable(why or "a peer could not map a mailbox of the world")
         self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
         self.seq = 0
         self.count = 0
         self._pending = None                # (async read of the error flag, reduction count it covers)
         dist.barrier()                      # nobody writes into a mailbox that is not mapped everywhere yet
+        # stage 3: one reduction of known rows, bit for bit against the rank-ordered sum of the gathered rows
+        ok, why = self.self_check()
+        if not _agree(ok):
+            self._release()
+            raise PeerReducer.PeerUnavailable(why or "a peer's check reduction differed from the rank-ordered sum")
+
+    def _release(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for p in self._opened:
+            self._lib.lib.rl_peer_close(p)
+        self._opened = []
+        if self._own is not None:
+            self._lib.lib.rl_peer_free(self._own)
+            self._own = None
+
+    def self_check(self, n=1572):
+        """One peer reduction of per-rank pseudo-random float64 rows against (a) the sum of the same rows gathered by
+        the backend and added in rank order -- what the kernel defines -- bit for bit, and (b) for integer-valued rows
+        (exact in any order) the backend's own all-reduce, bit for bit.  Local verdict + reason; callers make it
+        collective with ``_agree``."""
+        n = min(int(n), self.max_n)
+        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        real = torch.randn(n, generator=g, dtype=torch.float64)
+        ints = torch.randint(-(1 << 40), 1 << 40, (n,), generator=g).to(torch.float64)
+        why = None
+        for name, row in (("real-valued", real), ("integer-valued", ints)):
+            mine = row.cuda()
+            got = self.all_reduce_sum_(mine.clone())
+            rows = [torch.empty_like(row) for _ in range(self.world)]
+            if dist.get_backend() == "gloo":
+                dist.all_gather(rows, row)
+                rows = [r.cuda() for r in rows]
+            else:
+                rows = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(rows, mine)
+            want = torch.zeros_like(mine)
+            for r in rows:                                   # rank order, starting from 0.0: the kernel's own order
+                want = want + r
+            torch.cuda.synchronize()
+            if int(self.err.item()) != 0:
+                why = "check reduction (%s rows) timed out waiting for rank %d" % (name, int(self.err.item()) - 1)
+                break
+            if not torch.equal(got, want):
+                why = "check reduction (%s rows) differs from the rank-ordered sum in %d of %d entries" % (
+                    name, int((got != want).sum()), n)
+                break
+            if name == "integer-valued":
+                back = mine.clone()
+                if dist.get_backend() == "gloo":
+                    h = back.cpu()
+                    dist.all_reduce(h)
+                    back = h.cuda()
+                else:
+                    dist.all_reduce(back)
+                if not torch.equal(got, back):
+                    why = "check reduction (integer-valued rows) differs from the backend's all-reduce"
+                    break
+        return why is None, why
 
     def all_reduce_sum_(self, t):
         assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= self.max_n
@@ -168,12 +259,7 @@ class PeerReducer(object):
         torch.cuda.synchronize()
         e = int(self.err.item())            # the reductions no poll has covered yet
         dist.barrier()
-        for p in self._opened:
-            self._lib.lib.rl_peer_close(p)
-        self._opened = []
-        if self._own is not None:
-            self._lib.lib.rl_peer_free(self._own)
-            self._own = None
+        self._release()
         if e:
             self._raise(e, self.seq)
 
@@ -181,10 +267,26 @@ class PeerReducer(object):
 def peer_reducer():
     """The process's PeerReducer when RLLAB_PEER_ALLREDUCE=1 and the run is distributed, else None (created on first
     use: every rank reaches its first sharded gradient at the same point of the same program)."""
-    global _peer
-    if _peer is None and os.environ.get("RLLAB_PEER_ALLREDUCE") and is_distributed() and torch.cuda.is_available():
-        _peer = PeerReducer()
+    global _peer, _peer_refused
+    if _peer is None and _peer_refused is None and os.environ.get("RLLAB_PEER_ALLREDUCE") and is_distributed() \
+            and torch.cuda.is_available():
+        try:
+            _peer = PeerReducer()
+        except PeerReducer.PeerUnavailable as e:
+            # every rank is here (the constructor's stages are collective): the run stays on the backend's all-reduce
+            _peer_refused = str(e)
+            import sys
+            sys.stderr.write("[rllab_amd] rank %d: RLLAB_PEER_ALLREDUCE=1 but the peer path is unavailable (%s); "
+                             "using the %s all-reduce\n" % (dist.get_rank(), _peer_refused, dist.get_backend()))
     return _peer
+
+
+def peer_status():
+    """("peer" | "backend", reason): which path ``update_sum_`` takes and, when the peer path was asked for and refused,
+    why (bench.py prints it)."""
+    if _peer is not None:
+        return "peer", None
+    return "backend", _peer_refused
 
 
 def peer_poll():
@@ -195,7 +297,8 @@ def peer_poll():
 
 def peer_shutdown():
     """Unmap the mailboxes (collective: every rank calls it); raises if a reduction gave up waiting for a peer."""
-    global _peer
+    global _peer, _peer_refused
+    _peer_refused = None
     if _peer is not None:
         pr, _peer = _peer, None
         pr.close()

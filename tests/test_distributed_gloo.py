@@ -193,3 +193,54 @@ def test_two_rank_gloo_update_equals_single_process(tmp_path):
     b0, b1 = (np.load(str(tmp_path / ("init_before_%d.npy" % r))) for r in range(2))
     a0, a1 = (np.load(str(tmp_path / ("init_after_%d.npy" % r))) for r in range(2))
     assert not np.array_equal(b0, b1) and np.array_equal(a0, b0) and np.array_equal(a1, b0)
+
+
+def _peer_refusal_worker(rank, world, port, outdir):
+    """No GPU here: rank 0's mailbox stage is made to 'succeed' (stubbed), rank 1's fails for real -- every rank must
+    leave the constructor with PeerUnavailable after the SAME stage, nobody waits for a peer that gave up."""
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from rllab_amd import _lib
+    from rllab_amd.sampler import dist as D
+    released = []
+    if rank == 0:
+        class _FakeLib(object):
+            def __getattr__(self, name):
+                if name == "rl_peer_mailbox_bytes":
+                    return lambda w, n: 1024
+                if name in ("rl_peer_alloc", "rl_peer_export"):
+                    return lambda *a: 0
+                if name in ("rl_peer_free", "rl_peer_close"):
+                    return lambda *a: released.append(name) or 0
+                return getattr(_lib.lib, name)
+        real = _lib.lib
+        _lib.lib = _FakeLib()
+    orig_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    orig_avail = torch.cuda.is_available
+    try:
+        try:
+            D.PeerReducer(max_n=64)
+            outcome = "constructed"
+        except D.PeerReducer.PeerUnavailable as e:
+            outcome = "refused: %s" % e
+    finally:
+        torch.cuda.synchronize = orig_sync
+        if rank == 0:
+            _lib.lib = real
+    with open(os.path.join(outdir, "peer_%d.txt" % rank), "w") as fh:
+        fh.write(outcome + "\n" + ",".join(released))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_peer_reducer_refuses_on_every_rank_when_one_rank_cannot_build_its_mailbox(tmp_path):
+    """The pre-flight's contract (every rank takes the same branch): a stage of the peer
+    all-reduce's construction that fails on ONE rank ends in PeerUnavailable on EVERY rank, after an all-reduce-min of
+    the stage's verdict, with the successful rank's mailbox released."""
+    world, port = 2, _free_port()
+    mp.spawn(_peer_refusal_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    out = [open(str(tmp_path / ("peer_%d.txt" % r))).read().split("\n") for r in range(2)]
+    assert out[0][0].startswith("refused") and out[1][0].startswith("refused"), out
+    assert "rl_peer_free" in out[0][1]                     # rank 0 released the mailbox it had allocated
+    assert "fine-grained" in out[1][0] or "rl_peer_alloc" in out[1][0] or "HIP" in out[1][0], out[1][0]

@@ -116,3 +116,56 @@ def test_full_size_products_are_linear_symmetric_and_positive():
     vFw, wFv = float(v.dot(Fw)), float(w.dot(Fv))
     assert abs(vFw - wFv) <= 2e-5 * max(abs(vFw), float(v.dot(Fv)))
     assert float(v.dot(Fv)) > 0 and float(w.dot(Fw)) > 0
+
+
+def _f64_products_chunked(pol, inp, vs, chunk=256 * 1024):
+    """Float64 double-backward of the reference's mean KL over the WHOLE batch, in sample chunks: the mean KL is a
+    weighted sum over samples with one global 1 / count, so the Hessian-vector product is the sum of the chunks'."""
+    _, kl, _ = U._closures(pol)
+    B = inp[0].shape[-1]
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    ls64 = pol.effective_log_std().detach().double().reshape(-1, 1)
+    out = [torch.zeros_like(flat64) for _ in vs]
+    for a in range(0, B, chunk):
+        b = min(B, a + chunk)
+        with torch.no_grad():
+            om64 = pol.mean_planes(inp[0][:, a:b].double(), flat64.detach())
+        c64 = (inp[0][:, a:b], inp[1][:, a:b], inp[2][a:b], om64, ls64, inp[5][a:b], inp[6])
+        g = torch.autograd.grad(kl(flat64, *c64), flat64, create_graph=True)[0]
+        for o, v in zip(out, vs):
+            o += torch.autograd.grad((g * v).sum(), flat64, retain_graph=True)[0]
+        del g
+    return out
+
+
+@pytest.mark.parametrize("do,da,h,n_envs", [(13, 2, 32, 4096), (20, 6, 64, 1024)])
+def test_full_size_product_against_float64_double_backward(do, da, h, n_envs, monkeypatch):
+    """The product at the FULL batch of BASELINE configs C3 (4096 Swimmer envs x 500 steps = 2 048 000 samples, (32, 32))
+    and C5's per-GPU shard (1024 HalfCheetah envs x 500 = 512 000 samples, (64, 64)) against a float64 double-backward of
+    the reference's mean KL over every sample (PerlmutterHvp, conjugate_gradient_optimizer.py:27-55): the reference
+    tolerance of the product (5e-5 of its largest entry), and, where the split-operand arithmetic runs, no worse than
+    the f32-matrix-instruction product of the same batch."""
+    pol = U._policy(do, da, h)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, n_envs * 500, old_equals_new=True)
+    rng = np.random.RandomState(13)
+    vs = [torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2)]
+    want = _f64_products_chunked(pol, inp, vs)
+    ops.loss_grad(inp, keep_activations=True)
+    variant = _variant(ops, inp)
+    got = [ops.fvp(inp, v) for v in vs]
+    plain = None
+    if variant == 1:
+        monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
+        assert _variant(ops, inp) == 0
+        plain = [ops.fvp(inp, v) for v in vs]
+        monkeypatch.delenv("RLLAB_FVP_SPLIT")
+    for i, (hv, hv64) in enumerate(zip(got, want)):
+        scale = float(hv64.abs().max())
+        err = float((hv - hv64).abs().max()) / scale
+        print("full-size FVP (%d, %d) -> (%d, %d) on %d samples, variant %d: max error %.3g of the largest entry"
+              % (do, da, h, h, n_envs * 500, variant, err))
+        assert err <= 5e-5
+        if plain is not None:
+            err_p = float((plain[i] - hv64).abs().max()) / scale
+            assert err <= 2.0 * err_p + 2e-6, (err, err_p)

@@ -88,3 +88,45 @@ def test_bench_self_launches_eight_ranks():
     assert d["config"]["samples_per_iteration"] == 8 * 64 * 500 and d["config"]["parallelism"] == "env-sharded dp8"
     assert 12 <= d["collectives_per_iter"] <= 40 and d["collective_ms_per_iter"] > 0
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_preflight_two_ranks_on_one_device():
+    """tools/preflight_multigpu.py with a world of two (the box has one device: the ranks share it over gloo): devices
+    and peer-access matrix reported, the in-stream peer all-reduce passes its staged check -- fine-grained hipIpc
+    mailboxes mapped by the peer, a reduction of real-valued and of integer-valued rows bit for bit equal to the
+    rank-ordered sum of the gathered rows and to the backend's all-reduce -- both paths timed over 100 calls, and the
+    decision is the backend unless the peer path was asked for."""
+    for asked in (False, True):
+        env = dict(os.environ, RLLAB_DIST_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RLLAB_PEER_ALLREDUCE"):
+            env.pop(k, None)
+        if asked:
+            env["RLLAB_PEER_ALLREDUCE"] = "1"
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "preflight_multigpu.py"), "--gpus", "2"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, universal_newlines=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["world"] == 2 and d["device_of_rank"] == [0, 0] and d["distinct_devices"] is False
+        assert d["peer_access_between_ranks"] is True and d["peer_access_matrix"][0][0] is True
+        assert d["peer_check"]["passed"] is True, d["peer_check"]
+        assert d["backend_allreduce_us"] > 0 and d["peer_allreduce_us"] > 0 and len(d["per_rank_latency_us"]) == 2
+        assert d["decision"] == ("peer" if asked else "backend") and d["peer_requested"] is asked
+
+
+def test_bench_runs_the_preflight_before_warmup():
+    """`bench.py --gpus 2` carries the pre-flight record (taken in child processes) in its JSON line, and a requested
+    peer path that passed it is the path the update's sums took."""
+    env = dict(os.environ, RLLAB_DIST_BACKEND="gloo", RLLAB_PEER_ALLREDUCE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--n-envs", "256"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT,
+                       universal_newlines=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    pf = d["preflight"]
+    assert pf["isolated"] is True and pf["world"] == 2 and pf["peer_check"]["passed"] is True
+    assert pf["decision"] == "peer" and d["update_sum_path"] == "peer" and d["peer_reductions_per_iter"] == 11
