@@ -170,6 +170,7 @@ class PeerReducer(object):
         if not _agree(ok):
             self._release()
             raise PeerReducer.PeerUnavailable(why or "a peer's check reduction differed from the rank-ordered sum")
+        self.count = 0                      # (`count` is the reductions of the RUN; the sequence number goes on)
 
     def _release(self):
         if torch.cuda.is_available():
