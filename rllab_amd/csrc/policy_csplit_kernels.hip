@@ -1,0 +1,745 @@
+// policy_csplit_kernels.hip -- the Fisher-vector product of the 64-unit, WIDE and DEEP GaussianMLPPolicy mean networks
+// (two or three tanh layers of 32 / 64 / 128 units, at least one of them wider than 32) on the bf16 matrix pipe at f32
+// accuracy: the split-operand arithmetic of policy_split_kernels.hip (every f32 operand = hi + mid + lo, three bf16
+// parts, exactly; six cross terms per product on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- dropped terms
+// <= 2^-23 |a b|, tests/test_split_arithmetic.py) in the COOPERATIVE tiling of policy_wide_kernels.hip.
+//
+// What it computes: rl_policy_fvp on cached activations -- f_Hx_plain of rllab/optimizers/
+// conjugate_gradient_optimizer.py:27-55 at theta_new == theta_old, for GaussianMLPPolicy(hidden_sizes=...) of
+// rllab/policies/gaussian_mlp_policy.py:21-58 -- the same inputs and partial-row / float64 row reduction as
+// policy_pass_kernel<.., MODE_FVP, cached> and wide_pass_kernel<.., WMODE_FVP>, a result that differs from theirs by
+// rounding only.  TRPO launches it cg_iters times per update on the activations its gradient pass cached.
+//
+// Why: the f32-input matrix instruction runs at the f32 VECTOR rate on the vector datapath; at these widths its cycles
+// are most of a tile ((20 -> 64 -> 64 -> 6): 17.8 k of 41 k cycles per 32 samples; a (128 x 128) layer product: 65.5 k),
+// the bf16 pipe does the six terms in 6/16 of them, beside the vector ALU.
+//
+// Mapping.  A workgroup of WW wavefronts (WW = row tiles of the widest layer: 2 or 4) owns tiles of 32 samples; wavefront
+// w owns row tile w (32 units) of every layer that has one.  All f32 fragments are sample-major (lane = sample + 32 half,
+// register r = unit frag_unit(r, half) of the row tile: what the matrix pipe produces and what the gradient pass cached).
+//   * A fragment's owner splits it ONCE and publishes the parts in LDS as a "parts image": chunk (k-block kbg = 2 t + kb',
+//     part p) = 64 lanes x 16 B, lane (sample, half) holding the 8 units frag_unit(8 kb' + j, half) of row tile t --
+//     directly the B operand of the next layer's products for every wavefront (one ds_read_b128 per part and k-block;
+//     the K permutation is absorbed into the weight images).
+//   * The same images serve the products that contract over SAMPLES (gW_l += h_{l-1}^T gz_l): ds_read_b64_tr_b16, the
+//     transposing LDS read, hands a lane the four samples of ONE unit, so two reads per part are a unit-major operand --
+//     no transposition products, no second split, no extra LDS image (tools/ubench/bf16_split_layout.hip pins the
+//     read's lane map on the device).
+//   * A operands (tangent weights dW^T, weights W^T, untransposed W for back-propagation, and the output layer in all
+//     three roles) are split once per launch by cs_stage_kernel into operand images in global memory (a few hundred KB,
+//     L2-resident): one k-block = three coalesced 1 KB loads, fetched one k-block ahead and across chain boundaries.
+//   * The output layer is matrix work as well -- dmu = dWo^T h + Wo^T dh (each wavefront contracts over ITS 32 units, the
+//     partial sums meet in LDS), gz = (Wo gmu)(1 - h^2) with the cotangent on the mean published as one more parts
+//     image, gWo += h^T gmu over the sample axis -- so the vector ALU is left with the splits, the tanh derivatives and
+//     the bias sums (per lane, folded over the lanes once per launch).
+// One partial row per workgroup (every parameter has exactly one owner wavefront), reduce_rows_kernel sums the rows in
+// float64 in a fixed order, as in the other families.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "../../include/rllab_amd.h"
+#include "capi_util.h"
+#include "policy_mfma.h"
+#include "policy_wide.h"
+
+namespace rl {
+
+int launch_reduce_rows(const float* partial, int rows, int cols, double* out, hipStream_t st);   // policy_kernels.hip
+bool net_has_narrow_kernel(int obs_dim, int act_dim, int h0, int h1, int h2);                    // policy_kernels.hip
+
+namespace cs {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int CH = 1088;        // bytes of one parts chunk: 64 lanes x 16 B, lane half 1 displaced (below)
+constexpr int HSTR = 576;       // byte offset of lane half 1 inside a chunk (512 + 64: the transposing reads of the
+                                // two halves' rows then fall on different banks)
+constexpr int TILE_IMG = 6 * CH;   // one row tile of a parts image: two k-blocks x three parts
+constexpr int MAX_IMG = 10;     // operand images of one launch
+constexpr int CS_MAX_GRID = 512;
+
+// kind 0: dW_l^T (vec)    1: W_l^T (theta)    2: W_l (theta; back-propagation through layer l)
+//      3: dWo^T (vec)     4: Wo^T (theta)     rows = action slots (one row tile, rows >= DA zero), k = units of layer L-1
+//      5: Wo (theta)      rows = units of layer L-1, k = action slots (one k-block: slots 0..7 in lane half 0, zeros beyond)
+struct CsImage { int kind, l, base16, items, kb; };
+
+struct CsShape {
+    int L, DO, DA;
+    int H[3], HT[3];
+    int P, oW[3], ob[3], oWo, obo, ols;
+    int KB[3];                      // k-blocks of 16 feeding layer l (KB[0]: input slots incl. the bias slot, 1 or 2)
+    int iFD[3], iFT[3], iBT[3];     // operand images, offsets in 16-byte units (iFT[0] / iBT[0] unused)
+    int iDO, iTO, iWO;              // ... of the output layer: dWo^T, Wo^T, Wo
+    int img16;                      // 16-byte units of all images
+    CsImage im[MAX_IMG];
+    int n_im, stage_items;
+    int lX, lH[3], lG[3], lM, ldb[3], lpart, lds_total;    // LDS byte offsets (lM: the image of the cotangent on the mean)
+    int fmt;                        // activation cache: 0 = fragment rows (policy_kernels.hip), 1 = unit rows (wide)
+    int frow[3];                    // fmt 0: first 16-byte row of layer l inside a tile; fmt 1: float offset of layer l
+    int rows, ctile;                // fmt 0: 16-byte rows per tile; fmt 1: floats per tile
+};
+
+struct CsArgs {
+    int B;
+    const float* theta;
+    const float* vec;
+    const bf16x8* img;
+    const float* acts;
+    const float* obs;
+    const float* weight;
+    float inv_count, log_min_std;
+    float* partial;                 // [grid][P]
+    CsShape s;
+};
+
+struct Parts { bf16x8 p[3]; };
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// c += A B to f32 accuracy: the six cross terms, smallest first
+__device__ __forceinline__ f32x16 mm6(const Parts& A, const Parts& B, f32x16 c) {
+    c = mfma16(A.p[1], B.p[1], c);
+    c = mfma16(A.p[0], B.p[2], c);
+    c = mfma16(A.p[2], B.p[0], c);
+    c = mfma16(A.p[0], B.p[1], c);
+    c = mfma16(A.p[1], B.p[0], c);
+    c = mfma16(A.p[0], B.p[0], c);
+    return c;
+}
+// x = hi + mid + lo, each a bf16: successive round-to-nearest residuals (every subtraction is exact)
+__device__ __forceinline__ void split_pair(float a0, float a1, Parts& out, int j) {
+    const f32x2 a = {a0, a1};
+    const bf16x2 h = __builtin_convertvector(a, bf16x2);
+    const f32x2 r = a - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r, bf16x2);
+    const f32x2 l = r - __builtin_convertvector(m, f32x2);
+    const bf16x2 q = __builtin_convertvector(l, bf16x2);
+    out.p[0][j] = h[0]; out.p[0][j + 1] = h[1];
+    out.p[1][j] = m[0]; out.p[1][j + 1] = m[1];
+    out.p[2][j] = q[0]; out.p[2][j + 1] = q[1];
+}
+__device__ __forceinline__ void split8(const float* v, Parts& out) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) split_pair(v[j], v[j + 1], out, j);
+}
+
+// unit of the row tile that lane l32 (= lane & 31) of a transposing read's result holds (see cs_tr)
+__host__ __device__ constexpr int tr_unit(int l32) {
+    return frag_unit(8 * ((l32 >> 4) & 1) + 4 * ((l32 >> 2) & 1) + (l32 & 3), (l32 >> 3) & 1);
+}
+
+// ---- operand images ---------------------------------------------------------------------------------------------------
+// image element ((t * KB + kbg) * 3 + p) * 64 + lane: what lane (i = lane & 31, half) feeds k-block kbg of output row tile
+// t, part p.  k of (kbg, half, j): layer-0 input slot 16 kbg + 8 half + j (slot DO carries the bias, the slots beyond
+// are zero), action slot 8 half + j (kind 5), otherwise unit 32 (kbg >> 1) + frag_unit(8 (kbg & 1) + j, half) of the
+// feeding fragment.
+__global__ void __launch_bounds__(256) cs_stage_kernel(CsShape s, const float* __restrict__ th,
+                                                       const float* __restrict__ vec, bf16x8* __restrict__ img) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < s.stage_items; e += gridDim.x * 256) {
+        int q = 0, r = e;
+        while (q + 1 < s.n_im && r >= s.im[q].items) { r -= s.im[q].items; ++q; }
+        const CsImage im = s.im[q];
+        const int lane = r & 63, kbg = (r >> 6) % im.kb, t = (r >> 6) / im.kb;
+        const int i = lane & 31, half = lane >> 5, l = im.l;
+        const float* src = (im.kind == 0 || im.kind == 3) ? vec : th;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ku = 32 * (kbg >> 1) + frag_unit(8 * (kbg & 1) + j, half);      // a unit of the feeding fragment
+            if (im.kind <= 1 && l == 0) {
+                const int d = 16 * kbg + 8 * half + j, o = 32 * t + i;
+                v[j] = d < s.DO ? src[s.oW[0] + d * s.H[0] + o] : (d == s.DO ? src[s.ob[0] + o] : 0.0f);
+            } else if (im.kind <= 1) {
+                v[j] = src[s.oW[l] + ku * s.H[l] + 32 * t + i];                          // A[i][k] = W_l[k][i]
+            } else if (im.kind == 2) {
+                v[j] = src[s.oW[l] + (32 * t + i) * s.H[l] + ku];                        // A[i][k] = W_l[i][k]
+            } else if (im.kind <= 4) {
+                v[j] = i < s.DA ? src[s.oWo + ku * s.DA + i] : 0.0f;                     // A[i][k] = Wo[k][i]
+            } else {
+                const int k = 8 * half + j;
+                v[j] = k < s.DA ? src[s.oWo + (32 * t + i) * s.DA + k] : 0.0f;           // A[i][k] = Wo[i][k]
+            }
+        }
+        Parts pr;
+        split8(v, pr);
+        bf16x8* dst = img + im.base16 + (size_t)((t * im.kb + kbg) * 3) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p * 64] = pr.p[p];
+    }
+}
+
+// ---- LDS parts images --------------------------------------------------------------------------------------------------
+// publish a fragment (lane = sample + 32 half) as the two k-blocks of its row tile, three parts each;
+// slot = image + row tile * TILE_IMG + this lane's offset
+__device__ __forceinline__ void cs_publish(char* slot, const f32x16& v) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        Parts q;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) split_pair(v[8 * kb + j], v[8 * kb + j + 1], q, j);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(slot + (kb * 3 + p) * CH) = q.p[p];
+    }
+}
+// unit-major operand of sample block kbs (16 samples) of a row tile of a parts image: lane (l32 = lane & 31, hh = lane >> 5)
+// receives unit tr_unit(l32) at samples 16 kbs + 8 hh + j.  Each 16-lane group reads a 4 x 16 block (rows = samples):
+// lane 4 r + q of the group supplies the address of row r, columns 4 q .. 4 q + 3, and receives column (lane & 15), rows
+// 0..3.  src = image + row tile * TILE_IMG + the lane's transposing-read offset (tr_off in the kernel: chunk of its
+// 16-lane group's k-block, its row, the lane half and the 8 bytes of its column group).
+__device__ __forceinline__ Parts cs_tr(char* src, int kbs) {
+    Parts out;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(src + p * CH + kbs * 256));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(src + p * CH + kbs * 256 + 64));
+        const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { out.p[p][e] = l4[e]; out.p[p][4 + e] = h4[e]; }
+    }
+    return out;
+}
+
+// ---- the matrix chains ------------------------------------------------------------------------------------------------
+// acc += A B over nkb k-blocks: A from the operand image (this lane's column; the next k-block's parts in flight while
+// this one runs; during the last k-block the first parts of the wavefront's NEXT chain are fetched, so that every chain
+// starts on operands that are already there: `pre`), B from a parts image in LDS (this lane's slot).
+struct CsPre { bf16x8 v[3]; };
+
+__device__ __forceinline__ f32x16 cs_gemm(const bf16x8* __restrict__ A, int nkb, const char* B, f32x16 acc, CsPre& pre,
+                                          const bf16x8* __restrict__ next) {
+    bf16x8 a_cur[3], a_nxt[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a_cur[p] = pre.v[p];
+    for (int kb = 0; kb < nkb; ++kb) {
+        const bf16x8* src = (kb + 1 < nkb) ? A + (size_t)(kb + 1) * 3 * 64 : next;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a_nxt[p] = src[p * 64];
+        Parts Aop, Bop;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            Aop.p[p] = a_cur[p];
+            Bop.p[p] = *reinterpret_cast<const bf16x8*>(B + (kb * 3 + p) * CH);
+        }
+        acc = mm6(Aop, Bop, acc);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pre.v[p] = a_cur[p];
+    return acc;
+}
+
+// L hidden layers; WW wavefronts per workgroup; MT = most output tiles of a hidden-to-hidden weight gradient one
+// wavefront accumulates
+template <int L, int WW, int MT>
+__global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
+    const CsShape& s = a.s;
+    constexpr int NT = WW * WV;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / WV), lane = tid % WV;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int DO = s.DO, DA = s.DA;
+    const float* __restrict__ th = a.theta;
+    const float* __restrict__ vc = a.vec;
+    // per-lane offsets inside a parts image: the lane's own slot (publish / B operand), and the slot it addresses in a
+    // transposing read (column group q = lane & 3 of row (lane & 15) >> 2 of its 16-lane group: chunk of k-block
+    // (lane >> 4) & 1, lane half q >> 1, 8 bytes q & 1; rows = samples 8 (lane >> 5) + ...)
+    const int lane_off = lj * 16 + lh * HSTR;
+    const int tr_off = (((lane >> 4) & 1) * 3) * CH + (8 * lh + ((lane & 15) >> 2)) * 16 + ((lane & 3) >> 1) * HSTR +
+                       (lane & 1) * 8;
+    char* const own = smem + lane_off + wave * TILE_IMG;       // + image offset: this wavefront's row tile, this lane's slot
+
+    // ---- once per launch: zero the input image and the image of the mean's cotangent (their unused lanes stay zero),
+    // stage the bias tangents in fragment order --------------------------------------------------------------------
+    for (int k = tid; k < TILE_IMG / 4; k += NT) {
+        reinterpret_cast<float*>(smem + s.lX)[k] = 0.0f;
+        reinterpret_cast<float*>(smem + s.lM)[k] = 0.0f;
+    }
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        float* db = reinterpret_cast<float*>(smem + s.ldb[l]);
+        for (int e = tid; e < s.HT[l] * 32; e += NT) {                // [(t * 2 + half) * 16 + r]
+            const int r = e & 15, hf_ = (e >> 4) & 1, t = e >> 5;
+            db[e] = vc[s.ob[l] + 32 * t + frag_unit(r, hf_)];
+        }
+    }
+    __syncthreads();
+
+    // ---- this wavefront's chains, in the order it runs them (for the operand prefetch): offsets into the operand
+    // images in 16-byte units (wave-uniform), -1 = not this wavefront's ------------------------------------------------
+    constexpr int NSEQ = 3 * L + 1;
+    int seq[NSEQ], nxt[NSEQ];
+    {
+        auto rowimg = [&](int base16, int kb, bool busy) -> int { return busy ? base16 + wave * kb * 3 * 64 : -1; };
+        const bool last = wave < s.HT[L - 1];
+        seq[0] = rowimg(s.iFD[0], s.KB[0], wave < s.HT[0]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            seq[2 * l - 1] = rowimg(s.iFD[l], s.KB[l], wave < s.HT[l]);
+            seq[2 * l] = rowimg(s.iFT[l], s.KB[l], wave < s.HT[l]);
+        }
+        // output layer: ONE row tile (the action slots), k-blocks 2 w and 2 w + 1 = this wavefront's units
+        seq[2 * L - 1] = last ? s.iDO + 2 * wave * 3 * 64 : -1;
+        seq[2 * L] = last ? s.iTO + 2 * wave * 3 * 64 : -1;
+        seq[2 * L + 1] = rowimg(s.iWO, 1, last);
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) seq[2 * L + 2 + (L - 1 - l)] = rowimg(s.iBT[l], s.H[l] / 16, wave < s.HT[l - 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NSEQ; ++i) {
+        nxt[i] = seq[i];
+#pragma unroll
+        for (int k = NSEQ; k >= 1; --k) {
+            const int c = seq[(i + k) % NSEQ];
+            if (c >= 0) nxt[i] = c;
+        }
+    }
+    const bf16x8* const imgl = a.img + lane;
+    CsPre pre;
+    {
+        int first = 0;
+#pragma unroll
+        for (int i = NSEQ - 1; i >= 0; --i)
+            if (seq[i] >= 0) first = seq[i];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pre.v[p] = imgl[first + p * 64];
+    }
+
+    // ---- accumulators ------------------------------------------------------------------------------------------------
+    f32x16 gW[L - 1][MT], gW0, gWo;      // gWo: row tile `wave` of dWo (columns = action slots; beyond DA: zero)
+    float gb[L - 1][16], gbo4[4], wsum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gW0[r] = 0.0f;
+        gWo[r] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L - 1; ++l) {
+            gb[l][r] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) gW[l][m][r] = 0.0f;
+        }
+    }
+    // this lane's four action slots in the output layer's products: rows frag_unit(r, half), r < 4 = slots r + 4 half
+    float fk4[4], dbo4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = r + 4 * lh;
+        const float raw = k < DA ? th[s.ols + k] : 0.0f;
+        const float var = __expf(2.0f * fmaxf(raw, a.log_min_std));
+        fk4[r] = k < DA ? 2.0f / (2.0f * var + 1e-8f) : 0.0f;
+        dbo4[r] = k < DA ? vc[s.obo + k] : 0.0f;
+        gbo4[r] = 0.0f;
+    }
+
+    const int B = a.B, n_tiles = B / TS;
+    char* const Xp = smem + s.lX;
+    float* const part = reinterpret_cast<float*>(smem + s.lpart);
+
+    // one tile ahead: the cached fragments of the layers this wavefront owns, the observation slots of this thread's
+    // item of the input image, the sample weight
+    f32x16 hq[L];
+    float xq[8], wq = 0.0f;
+    const bool x_item = tid < s.KB[0] * WV;
+    const int x_kb = tid >> 6;
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (wave < s.HT[l]) {
+                if (s.fmt == 0) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(a.acts) +
+                                       ((size_t)tile * s.rows + s.frow[l] + 4 * wave) * WV + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = __builtin_nontemporal_load(src + q * WV);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hq[l][4 * q + e] = v[e];
+                    }
+                } else {
+                    const float* src = a.acts + (size_t)tile * s.ctile + s.frow[l] + (32 * wave + 4 * lh) * 32 + lj;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hq[l][r] = __builtin_nontemporal_load(src + frag_unit(r, 0) * 32);
+                }
+            }
+        }
+        wq = a.weight[tile * TS + lj];
+        if (x_item) {
+            const int b = tile * TS + lj;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * x_kb + 8 * lh + j;
+                const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
+                xq[j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
+            }
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        f32x16 hf[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) hf[l] = hq[l];
+        const float wgt = wq;
+        __syncthreads();                                    // everybody is done with the previous tile's images
+        // ---- the tile's inputs: observation parts, the parts of the fragments this wavefront owns ----------------------
+        if (x_item) {
+            Parts q;
+            split8(xq, q);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(Xp + (x_kb * 3 + p) * CH + lane_off) = q.p[p];
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            if (wave < s.HT[l]) cs_publish(own + s.lH[l], hf[l]);
+        {   // the next tile starts travelling (the workgroup's last tile fetches itself again: no branch around the loads)
+            const int nx = tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile;
+            fetch(nx);
+        }
+        __syncthreads();
+
+        // ---- tangent forward: dh_0 = (dW0^T x + db0) (1 - h0^2), dh_l = (dW_l^T h_{l-1} + W_l^T dh_{l-1} + db_l) (1 - h_l^2);
+        // every layer's tangent is published (its image passes to the cotangent later) ----------------------------------
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (wave < s.HT[l]) {
+                f32x16 acc;
+                if (l == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    acc = cs_gemm(imgl + seq[0], s.KB[0], Xp + lane_off, acc, pre, imgl + nxt[0]);
+                } else {
+                    const f32x4* db = reinterpret_cast<const f32x4*>(smem + s.ldb[l]) + (wave * 2 + lh) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = db[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * q + e] = v[e];
+                    }
+                    acc = cs_gemm(imgl + seq[2 * l - 1], s.KB[l], smem + s.lH[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l - 1]);
+                    acc = cs_gemm(imgl + seq[2 * l], s.KB[l], smem + s.lG[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= (1.0f - hf[l][r] * hf[l][r]);
+                cs_publish(own + s.lG[l], acc);
+            }
+            if (l + 1 < L) __syncthreads();
+        }
+
+        // ---- output layer: dmu = dWo^T h + Wo^T dh + dbo.  Each wavefront contracts over its own 32 units (the two
+        // k-blocks it has just published: its LDS operations complete in order, no barrier), partial sums meet in LDS ----
+        if (wave < s.HT[L - 1]) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = cs_gemm(imgl + seq[2 * L - 1], 2, own + s.lH[L - 1], acc, pre, imgl + nxt[2 * L - 1]);
+            acc = cs_gemm(imgl + seq[2 * L], 2, own + s.lG[L - 1], acc, pre, imgl + nxt[2 * L]);
+            f32x4 v4;                                        // rows frag_unit(r, half), r < 4 = action slots r + 4 half
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = acc[r];
+            *reinterpret_cast<f32x4*>(part + (wave * WV + lane) * 4) = v4;
+        }
+        __syncthreads();
+        {
+            const float c = wgt * a.inv_count;
+            f32x4 g4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int w = 0; w < s.HT[L - 1]; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(part + (w * WV + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g4[r] += v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g4[r] = c * (g4[r] + dbo4[r]) * fk4[r];           // cotangent on the mean, slots r + 4 half
+            if (wave == 0) {
+                // its image: one chunk per part, lane (sample, half 0) = the sample's 8 slots (the other half's four by a
+                // half swap), and the per-lane sums of dbo and of the weights
+                float o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o4[r] = __shfl_xor(g4[r], 32, WV);
+                    gbo4[r] += g4[r];
+                }
+                if (lh == 0) {
+                    float g8[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { g8[r] = g4[r]; g8[4 + r] = o4[r]; }
+                    Parts q;
+                    split8(g8, q);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(smem + s.lM + p * CH + lj * 16) = q.p[p];
+                    wsum += c;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- back-propagation: gz_{L-1} = (Wo gmu) (1 - h^2), gz_{l-1} = (W_l gz_l) (1 - h_{l-1}^2) ----------------------
+        if (wave < s.HT[L - 1]) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = cs_gemm(imgl + seq[2 * L + 1], 1, smem + s.lM + lane_off, acc, pre, imgl + nxt[2 * L + 1]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] *= (1.0f - hf[L - 1][r] * hf[L - 1][r]);
+                gb[L - 2][r] += acc[r];
+            }
+            cs_publish(own + s.lG[L - 1], acc);                // (its tangent was consumed by this wavefront's own chain above)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = L - 1; l >= 1; --l) {
+            if (wave < s.HT[l - 1]) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const int si = 2 * L + 2 + (L - 1 - l);
+                acc = cs_gemm(imgl + seq[si], s.H[l] / 16, smem + s.lG[l] + lane_off, acc, pre, imgl + nxt[si]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[r] *= (1.0f - hf[l - 1][r] * hf[l - 1][r]);
+                    if (l >= 2) gb[l >= 2 ? l - 2 : 0][r] += acc[r];            // (db0 rides in gW0's bias row)
+                }
+                cs_publish(own + s.lG[l - 1], acc);                             // the tangent of layer l-1 is consumed
+            }
+            __syncthreads();
+        }
+
+        // ---- the products over the sample axis (K = 32 samples = two sample blocks): gW_l += h_{l-1}^T gz_l,
+        // gWo += h_{L-1}^T gmu, gW0 += x_ext^T gz_0 ------------------------------------------------------------------
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            const int HTa = s.HT[l - 1], nt = HTa * s.HT[l];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int tau = wave + WW * m;
+                if (tau < nt) {
+                    const int ti = tau % HTa, tj = tau / HTa;
+#pragma unroll
+                    for (int kbs = 0; kbs < 2; ++kbs) {
+                        const Parts A = cs_tr(smem + s.lH[l - 1] + ti * TILE_IMG + tr_off, kbs);
+                        const Parts Bq = cs_tr(smem + s.lG[l] + tj * TILE_IMG + tr_off, kbs);
+                        gW[l - 1][m] = mm6(A, Bq, gW[l - 1][m]);
+                    }
+                }
+            }
+        }
+        if (wave < s.HT[L - 1]) {
+#pragma unroll
+            for (int kbs = 0; kbs < 2; ++kbs) {
+                const Parts A = cs_tr(smem + s.lH[L - 1] + wave * TILE_IMG + tr_off, kbs);
+                const Parts Bq = cs_tr(smem + s.lM + tr_off, kbs);               // columns: lane l32 < 8 = action slot l32
+                gWo = mm6(A, Bq, gWo);
+            }
+        }
+        if (wave < s.HT[0]) {
+#pragma unroll
+            for (int kbs = 0; kbs < 2; ++kbs) {
+                const Parts A = cs_tr(Xp + tr_off, kbs);                          // rows: lane l32 = input slot l32
+                const Parts Bq = cs_tr(smem + s.lG[0] + wave * TILE_IMG + tr_off, kbs);
+                gW0 = mm6(A, Bq, gW0);
+            }
+        }
+    }
+
+    // ---- one partial row per workgroup: every parameter has exactly one owner -------------------------------------------
+    float* row = a.partial + (size_t)blockIdx.x * s.P;
+    const int cu = tr_unit(lj);
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        const int HTa = s.HT[l - 1], nt = HTa * s.HT[l];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int tau = wave + WW * m;
+            if (tau < nt) {
+                const int ti = tau % HTa, tj = tau / HTa;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    row[s.oW[l] + (32 * ti + tr_unit(frag_unit(r, lh))) * s.H[l] + 32 * tj + cu] = gW[l - 1][m][r];
+            }
+        }
+    }
+    if (wave < s.HT[0]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = frag_unit(r, lh);                  // input slot (the input image's units are its slots)
+            if (d < DO) row[s.oW[0] + d * s.H[0] + 32 * wave + cu] = gW0[r];
+            else if (d == DO) row[s.ob[0] + 32 * wave + cu] = gW0[r];
+        }
+    }
+    if (wave < s.HT[L - 1] && lj < DA) {                      // column lj of the product = action slot lj
+#pragma unroll
+        for (int r = 0; r < 16; ++r) row[s.oWo + (32 * wave + tr_unit(frag_unit(r, lh))) * DA + lj] = gWo[r];
+    }
+    // per-lane sums of the bias gradients: fold the 32 samples of a lane half
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        if (wave < s.HT[l]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = gb[l - 1][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
+                if (lj == 0) row[s.ob[l] + 32 * wave + frag_unit(r, lh)] = v;
+            }
+        }
+    }
+    if (wave == 0) {
+        const float ws = wave_sum(wsum);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = gbo4[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
+            const int k = r + 4 * lh;
+            if (lj == 0 && k < DA) {
+                row[s.obo + k] = v;
+                // log_std block of the Fisher: d2KL/ds2 = 4 v (2 v - eps) / (2 v + eps)^2, v = sigma^2
+                const float raw = th[s.ols + k];
+                const float vv = __expf(2.0f * fmaxf(raw, a.log_min_std)), e = 1e-8f;
+                const float cc = raw < a.log_min_std ? 0.0f : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+                row[s.ols + k] = cc * vc[s.ols + k] * ws;
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+static bool cs_shape(const rl_policy_batch* g, CsShape& s) {
+    WideShape w;
+    if (!wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, w)) return false;
+    s.L = w.L; s.DO = w.DO; s.DA = w.DA; s.P = w.P; s.oWo = w.oWo; s.obo = w.obo; s.ols = w.ols;
+    int maxht = 0;
+    for (int l = 0; l < 3; ++l) {
+        s.H[l] = w.H[l]; s.HT[l] = w.HT[l]; s.oW[l] = w.oW[l]; s.ob[l] = w.ob[l];
+        if (w.HT[l] > maxht) maxht = w.HT[l];
+    }
+    if (maxht < 2) return false;                       // all layers 32 wide: policy_split_kernels.hip / policy_kernels.hip
+    s.KB[0] = (s.DO + 1 + 15) / 16;
+    for (int l = 1; l < 3; ++l) s.KB[l] = l < s.L ? s.H[l - 1] / 16 : 0;
+    // operand images
+    int off = 0, n = 0, items = 0;
+    auto add = [&](int kind, int l, int ht_out, int kb) {
+        CsImage& im = s.im[n++];
+        im.kind = kind; im.l = l; im.base16 = off; im.kb = kb; im.items = ht_out * kb * 64;
+        off += ht_out * kb * 3 * 64;
+        items += im.items;
+        return im.base16;
+    };
+    for (int l = 0; l < 3; ++l) { s.iFD[l] = s.iFT[l] = s.iBT[l] = 0; }
+    const int lastl = s.L - 1;
+    for (int l = 0; l < s.L; ++l) s.iFD[l] = add(0, l, s.HT[l], s.KB[l]);
+    for (int l = 1; l < s.L; ++l) s.iFT[l] = add(1, l, s.HT[l], s.KB[l]);
+    for (int l = 1; l < s.L; ++l) s.iBT[l] = add(2, l, s.HT[l - 1], s.H[l] / 16);
+    s.iDO = add(3, lastl, 1, s.H[lastl] / 16);
+    s.iTO = add(4, lastl, 1, s.H[lastl] / 16);
+    s.iWO = add(5, lastl, s.HT[lastl], 1);
+    s.n_im = n; s.stage_items = items; s.img16 = off;
+    // LDS plan
+    int o = 0;
+    s.lX = o; o += TILE_IMG;
+    for (int l = 0; l < 3; ++l) { s.lH[l] = o; o += (l < s.L) ? s.HT[l] * TILE_IMG : 0; }
+    for (int l = 0; l < 3; ++l) { s.lG[l] = o; o += (l < s.L) ? s.HT[l] * TILE_IMG : 0; }
+    s.lM = o; o += TILE_IMG;
+    for (int l = 0; l < 3; ++l) { s.ldb[l] = o; o += (l >= 1 && l < s.L) ? s.HT[l] * 128 : 0; }
+    s.lpart = o; o += 4 * WV * 4 * (int)sizeof(float);
+    s.lds_total = o;
+    // activation cache, as the gradient pass of the same net wrote it
+    s.fmt = net_has_narrow_kernel(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2) ? 0 : 1;
+    int rows = 0, fl = 0;
+    for (int l = 0; l < 3; ++l) {
+        s.frow[l] = s.fmt == 0 ? rows : fl;
+        rows += (l < s.L) ? 4 * s.HT[l] : 0;
+        fl += (l < s.L) ? 32 * s.H[l] : 0;
+    }
+    s.rows = rows; s.ctile = fl;
+    return o <= 160 * 1024;
+}
+
+static size_t cs_workspace(const CsShape& s) {
+    const size_t rows = ((size_t)CS_MAX_GRID * s.P * sizeof(float) + 15) & ~(size_t)15;
+    return rows + (size_t)s.img16 * 16 + 64;
+}
+
+template <int L, int WW, int MT>
+static int launch(const CsShape& s, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
+                  hipStream_t st) {
+    if (ws_bytes < cs_workspace(s))
+        return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", ws_bytes, cs_workspace(s));
+    CsArgs a;
+    a.s = s;
+    a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.acts = g->activations; a.obs = g->obs; a.weight = g->weights;
+    a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
+    const size_t rows = ((size_t)CS_MAX_GRID * s.P * sizeof(float) + 15) & ~(size_t)15;
+    a.partial = (float*)ws;
+    bf16x8* img = reinterpret_cast<bf16x8*>((char*)ws + rows);
+    a.img = img;
+    const int sg = (s.stage_items + 255) / 256;
+    hipLaunchKernelGGL(cs_stage_kernel, dim3(sg < 1024 ? sg : 1024), dim3(256), 0, st, s, g->theta, vec, img);
+    int rc = check_launch("cs_stage_kernel");
+    if (rc) return rc;
+    const int n_tiles = a.B / TS;
+    int per_cu = (160 * 1024) / s.lds_total;
+    if (per_cu > 4 / WW) per_cu = 4 / WW;              // one wavefront per SIMD (512 registers each)
+    if (per_cu < 1) per_cu = 1;
+    int grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    if (grid > CS_MAX_GRID) grid = CS_MAX_GRID;
+    auto kern = csplit_fvp_kernel<L, WW, MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WW * WV), s.lds_total, st, a);
+    rc = check_launch("csplit_fvp_kernel");
+    if (rc) return rc;
+    return launch_reduce_rows(a.partial, grid, s.P, out, st);
+}
+
+template <int L>
+static int launch_class(const CsShape& s, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
+                        double* out, hipStream_t st) {
+    int maxht = 0, mt4 = 0;
+    for (int l = 0; l < s.L; ++l) {
+        if (s.HT[l] > maxht) maxht = s.HT[l];
+        if (l >= 1 && s.HT[l - 1] * s.HT[l] > 8) mt4 = 1;
+    }
+    if (maxht == 2) return launch<L, 2, 2>(s, g, vec, ws, ws_bytes, out, st);
+    return mt4 ? launch<L, 4, 4>(s, g, vec, ws, ws_bytes, out, st) : launch<L, 4, 2>(s, g, vec, ws, ws_bytes, out, st);
+}
+
+}  // namespace cs
+
+// The cooperative split product takes a cached Fisher-vector product of a tanh net with two or three layers of 32 / 64 /
+// 128 units, at least one wider than 32, whose batch is a whole number of 32-sample tiles.  RLLAB_FVP_SPLIT=0 switches it
+// off (A/B runs; the f32-matrix-instruction kernels then keep cached == recomputed bit for bit).
+bool csplit_fvp_takes(const rl_policy_batch* g) {
+    if (!g->activations || g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0) return false;
+    const char* e = getenv("RLLAB_FVP_SPLIT");
+    if (e && e[0] == '0') return false;
+    cs::CsShape s;
+    return cs::cs_shape(g, s);
+}
+size_t csplit_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2) {
+    rl_policy_batch g = {};
+    g.obs_dim = obs_dim; g.act_dim = act_dim; g.hidden0 = h0; g.hidden1 = h1; g.hidden2 = h2;
+    cs::CsShape s;
+    if (!cs::cs_shape(&g, s)) return 0;
+    return cs::cs_workspace(s);
+}
+int csplit_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
+    if (!csplit_fvp_takes(g)) return RL_SPLIT_NOT_TAKEN;
+    cs::CsShape s;
+    cs::cs_shape(g, s);
+    return s.L == 2 ? cs::launch_class<2>(s, g, vec, ws, ws_bytes, out, st)
+                    : cs::launch_class<3>(s, g, vec, ws, ws_bytes, out, st);
+}
+
+}  // namespace rl

@@ -798,6 +798,8 @@ struct WideShape;
 // policy_split_kernels.hip: the cached Fisher-vector product of the 32-unit nets on the bf16 matrix pipe (three-way
 // split operands, f32 accuracy); RL_SPLIT_NOT_TAKEN when the launch is not its to make
 int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
+int csplit_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
+size_t csplit_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not its shape
 size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not a wide shape
 
 struct PlaneArgs {                 // MODE_OUT / MODE_OUT_TAN / MODE_BWD
@@ -909,6 +911,21 @@ static int dispatch_relu(int mode, const rl_policy_batch* g, void* ws, size_t ws
     return set_error(RL_ERR_UNSUPPORTED, "rectify networks: only the loss and the log-likelihood gradient are built");
 }
 
+// (obs_dim, act_dim, H) of the one-wavefront-per-tile kernels (two equal tanh layers): every HIP-native env's pair at 32
+// and 64 units + the one-output value nets.  Everything else runs on the cooperative kernels -- and the two families
+// cache their activations in different layouts, which is what the split Fisher-vector products ask this for.
+#define RL_NARROW_NETS(X) \
+    X(4, 1, 32) X(6, 1, 32) X(11, 1, 32) X(13, 2, 32) X(20, 3, 32) X(20, 6, 32) X(21, 6, 32) \
+    X(4, 1, 64) X(6, 1, 64) X(11, 1, 64) X(13, 2, 64) X(20, 3, 64) X(20, 6, 64) X(21, 6, 64) \
+    X(13, 1, 32) X(20, 1, 32) X(21, 1, 32)
+bool net_has_narrow_kernel(int d, int k, int h0, int h1, int h2) {
+    if (h2 != 0) return false;
+#define NARROWCASE(DO, DA, H) if (d == DO && k == DA && h0 == H && h1 == H) return true;
+    RL_NARROW_NETS(NARROWCASE)
+#undef NARROWCASE
+    return false;
+}
+
 static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
                         double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr,
                         const PlaneArgs* pl = nullptr) {
@@ -929,6 +946,10 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     if (g->hidden2 < 0) return set_error(RL_ERR_ARG, "rl_policy_batch.hidden2 = %d", g->hidden2);
     if (g->hidden2 > 0) {              // three hidden layers: the cooperative kernels (policy_wide_kernels.hip)
         if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
+        if (mode == MODE_FVP && g->activation == RL_ACT_TANH) {
+            const int rc = csplit_fvp_dispatch(g, vec, ws, ws_bytes, out, st);    // split-operand arithmetic (cached products)
+            if (rc != RL_SPLIT_NOT_TAKEN) return rc;
+        }
         return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, loss_out);
     }
     if (g->activation == RL_ACT_RECTIFY) {
@@ -942,29 +963,15 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     if (g->kl_penalty != 0.0f && mode != MODE_VPG && mode != MODE_GRAD)
         return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the gradient passes only");
     if (mode == MODE_FVP && cg == nullptr) {
-        const int rc = split_fvp_dispatch(g, vec, ws, ws_bytes, out, st);
+        int rc = split_fvp_dispatch(g, vec, ws, ws_bytes, out, st);          // (32, 32): one wavefront per tile
+        if (rc != RL_SPLIT_NOT_TAKEN) return rc;
+        rc = csplit_fvp_dispatch(g, vec, ws, ws_bytes, out, st);             // 64-unit and wide nets: cooperative
         if (rc != RL_SPLIT_NOT_TAKEN) return rc;
     }
 #define NETCASE(DO, DA, H) \
     if (d == DO && k == DA && h0 == H && h1 == H) \
         return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out, cg);
-    NETCASE(4, 1, 32)    // Cartpole
-    NETCASE(6, 1, 32)    // DoublePendulum
-    NETCASE(11, 1, 32)   // InvertedDoublePendulum
-    NETCASE(13, 2, 32)   // Swimmer
-    NETCASE(20, 3, 32)   // Hopper
-    NETCASE(20, 6, 32)   // HalfCheetah
-    NETCASE(21, 6, 32)   // Walker2D
-    NETCASE(4, 1, 64)
-    NETCASE(6, 1, 64)
-    NETCASE(11, 1, 64)
-    NETCASE(13, 2, 64)
-    NETCASE(20, 3, 64)
-    NETCASE(20, 6, 64)
-    NETCASE(21, 6, 64)
-    NETCASE(13, 1, 32)   // one-output nets: value-function regressors on the Swimmer / HalfCheetah / Walker2D observations
-    NETCASE(20, 1, 32)
-    NETCASE(21, 1, 32)
+    RL_NARROW_NETS(NETCASE)
 #undef NETCASE
     // anything else with tanh layers of 32 / 64 / 128 units: the cooperative kernels
     if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
@@ -984,7 +991,11 @@ static int check_batch(const rl_policy_batch* g, const char* who) {
 
 extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1, int hidden2) {
     const bool narrow = hidden2 == 0 && hidden0 == hidden1 && (hidden0 == 32 || hidden0 == 64);
-    if (!narrow) return wide_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
+    if (!narrow) {
+        const size_t w = wide_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
+        const size_t c = csplit_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
+        return w > c ? w : c;
+    }
     // one partial row per workgroup: P floats (or LOSS_COLS doubles)
     const size_t P = (size_t)obs_dim * hidden0 + hidden0 + (size_t)hidden0 * hidden1 + hidden1 +
                      (size_t)hidden1 * act_dim + 2 * (size_t)act_dim;
@@ -994,7 +1005,9 @@ extern "C" size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden
     // a net of these widths on an (obs_dim, act_dim) pair the kernels above are not instantiated for runs on the
     // cooperative kernels (dispatch_net): the workspace covers both
     const size_t w = wide_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
-    return a + b > w ? a + b : w;
+    const size_t c = csplit_workspace_bytes_for(obs_dim, act_dim, hidden0, hidden1, hidden2);
+    const size_t m = a + b > w ? a + b : w;
+    return m > c ? m : c;
 }
 
 extern "C" size_t rl_policy_activation_bytes(int n_samples, int hidden0, int hidden1, int hidden2) {

@@ -570,7 +570,10 @@ int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, siz
 
 }  // namespace rl
 
+namespace rl { bool csplit_fvp_takes(const rl_policy_batch* g); }     // policy_csplit_kernels.hip
+
 extern "C" int rl_policy_fvp_variant(const rl_policy_batch* g) {
     if (!g) return rl::set_error(RL_ERR_ARG, "rl_policy_fvp_variant: null batch");
-    return rl::split_fvp_takes(g) ? 1 : 0;
+    if (rl::split_fvp_takes(g)) return 1;
+    return rl::csplit_fvp_takes(g) ? 2 : 0;
 }

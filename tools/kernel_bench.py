@@ -71,7 +71,7 @@ def main():
         ops.loss_grad(inp, keep_activations=True)
         ms = timeit(lambda: ops.fvp(inp, v))
         print(json.dumps(dict(kernel="fvp cached", net=[do, da, list(hidden)], samples=B, ms=round(ms, 4),
-                              tflops=round(5.0 * fwd_flops * B / ms / 1e9, 2))))
+                              tflops=round(5.0 * fwd_flops * B / ms / 1e9, 2), variant=ops.fvp_variant(inp))))
         ops.release()
 
 
