@@ -62,6 +62,23 @@ constexpr int HSTR = 576;       // byte offset of lane half 1 inside a chunk (51
 constexpr int TILE_IMG = 6 * CH;   // one row tile of a parts image: two k-blocks x three parts
 constexpr int MAX_IMG = 10;     // operand images of one launch
 constexpr int CS_MAX_GRID = 512;
+// experiment knobs (timing ablations; tools/exp/csplit_variants.sh).  CS_FETCH_LATE: the next tile's cached fragments
+// start travelling after the tile's last operand-image load instead of before its first.
+#ifndef CS_FETCH_LATE
+#define CS_FETCH_LATE 0
+#endif
+#ifndef CS_ABLATE_FETCH     // 1: no per-tile HBM loads at all (the first tile's registers are reused): wrong results
+#define CS_ABLATE_FETCH 0
+#endif
+#ifndef CS_ABLATE_AIMG      // 1: operand images are not re-fetched per k-block: wrong results
+#define CS_ABLATE_AIMG 0
+#endif
+#ifndef CS_ABLATE_OUTER     // 1: no products over the sample axis: wrong results
+#define CS_ABLATE_OUTER 0
+#endif
+#ifndef CS_ABLATE_MFMA      // 1: no matrix instructions in the chains: wrong results
+#define CS_ABLATE_MFMA 0
+#endif
 
 // kind 0: dW_l^T (vec)    1: W_l^T (theta)    2: W_l (theta; back-propagation through layer l)
 //      3: dWo^T (vec)     4: Wo^T (theta)     rows = action slots (one row tile, rows >= DA zero), k = units of layer L-1
@@ -219,14 +236,19 @@ __device__ __forceinline__ f32x16 cs_gemm(const bf16x8* __restrict__ A, int nkb,
     for (int kb = 0; kb < nkb; ++kb) {
         const bf16x8* src = (kb + 1 < nkb) ? A + (size_t)(kb + 1) * 3 * 64 : next;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a_nxt[p] = src[p * 64];
+        for (int p = 0; p < 3; ++p) a_nxt[p] = CS_ABLATE_AIMG ? a_cur[p] : src[p * 64];
         Parts Aop, Bop;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             Aop.p[p] = a_cur[p];
             Bop.p[p] = *reinterpret_cast<const bf16x8*>(B + (kb * 3 + p) * CH);
         }
+#if CS_ABLATE_MFMA
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] += (float)Aop.p[p][0] * (float)Bop.p[p][0];
+#else
         acc = mm6(Aop, Bop, acc);
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
     }
@@ -396,7 +418,8 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
 #pragma unroll
         for (int l = 0; l < L; ++l)
             if (wave < s.HT[l]) cs_publish(own + s.lH[l], hf[l]);
-        {   // the next tile starts travelling (the workgroup's last tile fetches itself again: no branch around the loads)
+        if (!CS_FETCH_LATE && !CS_ABLATE_FETCH) {
+            // the next tile starts travelling (the workgroup's last tile fetches itself again: no branch around the loads)
             const int nx = tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile;
             fetch(nx);
         }
@@ -509,8 +532,16 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
             __syncthreads();
         }
 
+        if (CS_FETCH_LATE && !CS_ABLATE_FETCH) {
+            // the next tile starts travelling now: the products below read LDS only, and a wait for an operand-image load
+            // (the memory queue answers in order) can no longer land behind these HBM loads
+            // (the workgroup's last tile fetches itself again: no branch around the loads)
+            const int nx = tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile;
+            fetch(nx);
+        }
         // ---- the products over the sample axis (K = 32 samples = two sample blocks): gW_l += h_{l-1}^T gz_l,
         // gWo += h_{L-1}^T gmu, gW0 += x_ext^T gz_0 ------------------------------------------------------------------
+        if (!CS_ABLATE_OUTER) {
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             const int HTa = s.HT[l - 1], nt = HTa * s.HT[l];
@@ -543,6 +574,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
                 const Parts Bq = cs_tr(smem + s.lG[0] + wave * TILE_IMG + tr_off, kbs);
                 gW0 = mm6(A, Bq, gW0);
             }
+        }
         }
     }
 
@@ -718,14 +750,20 @@ static int launch_class(const CsShape& s, const rl_policy_batch* g, const float*
 }  // namespace cs
 
 // The cooperative split product takes a cached Fisher-vector product of a tanh net with two or three layers of 32 / 64 /
-// 128 units, at least one wider than 32, whose batch is a whole number of 32-sample tiles.  RLLAB_FVP_SPLIT=0 switches it
-// off (A/B runs; the f32-matrix-instruction kernels then keep cached == recomputed bit for bit).
+// 128 units whose batch is a whole number of 32-sample tiles.  By default only nets with a 128-unit layer (four
+// wavefronts per tile): measured on MI355X (profiles/r04_notes.md) it is 13-16 % faster than wide_pass_kernel there and
+// 20 % SLOWER than policy_pass_kernel on (64, 64) nets, where LDS lets only two tiles be in flight per CU on two
+// wavefronts each.  RLLAB_FVP_SPLIT=0 switches it off (A/B runs; the f32-matrix-instruction kernels then keep cached ==
+// recomputed bit for bit), RLLAB_FVP_SPLIT=2 takes every shape it is built for (the parity tests of the two-wavefront
+// class run that way).
 bool csplit_fvp_takes(const rl_policy_batch* g) {
     if (!g->activations || g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0) return false;
     const char* e = getenv("RLLAB_FVP_SPLIT");
     if (e && e[0] == '0') return false;
     cs::CsShape s;
-    return cs::cs_shape(g, s);
+    if (!cs::cs_shape(g, s)) return false;
+    if (e && e[0] == '2') return true;
+    return s.HT[0] == 4 || s.HT[1] == 4 || s.HT[2] == 4;
 }
 size_t csplit_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2) {
     rl_policy_batch g = {};

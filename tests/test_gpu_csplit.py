@@ -43,6 +43,9 @@ def test_cooperative_split_product_is_an_f32_accurate_product(do, da, hidden, B,
     assert _variant(ops, inp) == 0
     plain = [ops.fvp(inp, v) for v in vs]
     monkeypatch.delenv("RLLAB_FVP_SPLIT")
+    # by default the kernel takes the nets with a 128-unit layer (where it is the faster one); RLLAB_FVP_SPLIT=2: every shape
+    assert _variant(ops, inp) == (2 if max(pol.kernel_layout().hidden3) == 128 else 0)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "2")
     assert _variant(ops, inp) == 2                       # the launch below IS the cooperative split kernel
     split = [ops.fvp(inp, v) for v in vs]
     for hv_s, hv_p, hv64 in zip(split, plain, want):
@@ -57,6 +60,7 @@ def test_cooperative_split_product_takes_only_its_batches(monkeypatch):
     """Whole 32-sample tiles and cached activations; everything else stays on the f32 matrix instructions."""
     pol = _policy(13, 2, (128, 64))
     ops = pol.fused_ops()
+    assert max(pol.kernel_layout().hidden3) == 128
     for B, want in ((4096, 2), (4100, 0), (63, 0)):
         inp = U._inputs(pol, B, old_equals_new=True)
         ops.release()
@@ -72,6 +76,7 @@ def test_cg_on_the_cooperative_split_product_solves_the_same_system(do, da, hidd
     ops = pol.fused_ops()
     inp = U._inputs(pol, 64000, old_equals_new=True)
     g = ops.loss_grad(inp, keep_activations=True)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "2")
     assert _variant(ops, inp) == 2
     x_s, xhx_s = ops.cg(inp, g, 10, 1e-5)
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
@@ -80,12 +85,13 @@ def test_cg_on_the_cooperative_split_product_solves_the_same_system(do, da, hidd
     assert abs(float(xhx_s) - float(xhx_p)) <= 2e-5 * abs(float(xhx_p))
 
 
-def test_products_are_linear_symmetric_and_positive_at_c5_size():
+def test_products_are_linear_symmetric_and_positive_at_c5_size(monkeypatch):
     """C5's per-GPU batch (1024 envs x 500 steps, (20 -> 64 -> 64 -> 6)), ragged weights."""
     pol = _policy(20, 6, (64, 64))
     ops = pol.fused_ops()
     inp = U._inputs(pol, 1024 * 500, old_equals_new=True)
     ops.loss_grad(inp, keep_activations=True)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "2")
     assert _variant(ops, inp) == 2
     rng = np.random.RandomState(11)
     v, w = (torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2))
