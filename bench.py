@@ -379,10 +379,17 @@ def main():
             n_envs <= 16 * 1024 and (equal_hidden or wide)
     else:
         lane_group = False
-    envs_per_wave = 16 if lane_group else (int(forced_epw) if forced_epw in ("16", "64") else
-                                           (16 if n_envs <= 16 * 1024 else 64))
+    # ... and one env per wavefront for the two-legged envs while the wavefronts still find a SIMD each
+    tw = os.environ.get("RLLAB_TWO_LEG_WAVE_KERNEL")
+    env_per_wave = lane_group and wl["env"] in ("half_cheetah", "walker2d") and equal_hidden and \
+        (tw[:1] == "1" if tw else n_envs <= 2048)
+    envs_per_wave = 1 if env_per_wave else 16 if lane_group else (int(forced_epw) if forced_epw in ("16", "64") else
+                                                                  (16 if n_envs <= 16 * 1024 else 64))
     n_waves = (n_envs + envs_per_wave - 1) // envs_per_wave
-    if lane_group:
+    if env_per_wave:
+        rollout_name = ("rollout_two_leg_wave_kernel (fused policy + env step + record; ONE env per wavefront: the policy's "
+                        "units on the lanes, one leg per lane in the physics sub-steps, the trajectory stored lane-distributed)")
+    elif lane_group:
         rollout_name = "rollout_%s_quad_%skernel (fused policy + env step + record; 16 envs per wavefront, %s)" % (
             "swimmer" if wl["env"] == "swimmer" else "two_leg", "wide_" if wide else "",
             "four lanes per env in the physics sub-steps" if wl["env"] == "swimmer" else
@@ -419,7 +426,7 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_rollout_s * 1e3,
                      "wavefronts": n_waves, "simds": 1024,
                      "envs_per_wavefront": envs_per_wave,
-                     "note": "issue-bound, not HBM-bound: %d envs per wavefront => %d wavefronts on 1024 SIMDs, each "
+                     "note": "issue-bound, not HBM-bound: %d env(s) per wavefront => %d wavefronts on 1024 SIMDs, each "
                              "a single instruction stream (physics sub-steps fused in registers); a lone wavefront "
                              "pays 4 cycles per issue slot whatever it issues (vector, scalar, each s_nop wait "
                              "state; packed f32 5, transcendental 8 -- tools/ubench/valu_latency.hip), so launch "

@@ -1223,6 +1223,272 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_wide_kernel(Rol
     two_leg_quad_body<Env>(a, pol);
 }
 
+// ---------------------------------------------------------------------------
+// ONE ENV PER WAVEFRONT (HalfCheetah, Walker2D at small env counts: C5's per-GPU shard is 1024 envs, i.e. 64
+// wavefronts of 16 envs on 1024 SIMDs).  A lone wavefront pays per issued instruction whatever its lanes do, so the
+// 16-env shape spends its env-step on work that is per-ENV in one instruction stream (profiles/r04_notes.md: 3.2 k
+// vector + 88 matrix instructions per step).  With a wavefront per env the chip's idle SIMDs take the envs and the
+// lanes take the policy's UNITS:
+//   * policy (RolloutPolicyLane): lane u holds column u of W0 / W1 (unit u of both hidden layers), lane a column a of the
+//     output layer; a layer is H fused multiply-adds per lane on the previous layer's activations, which every lane reads
+//     back from a 256-byte LDS row as broadcast 16-byte reads.  No matrix instruction (a matrix-vector product wastes
+//     its columns), ~130 instructions per step instead of 88 matrix + ~370 vector;
+//   * everything per env (state, observation, action map, reward, reset) is computed by all lanes alike (wave-uniform
+//     values); the trajectory goes out lane-distributed: lane k stores observation row k, lane a action / mean row a --
+//     one store instruction per array;
+//   * policy noise: lane j draws the Philox block of step t + j every 64 steps (the same (seed; env, step, POLICY)
+//     blocks as every other shape), a step reads its row with v_readlane;
+//   * physics: the one-leg-per-lane program of dyn_two_legs.h unchanged (even lanes the back leg, odd lanes the front
+//     leg; 32 identical copies), state resident across env-steps, hand-over to the per-env arithmetic by v_readlane.
+// Dynamics are bit-identical to every other shape (same leaf functions; replayed against the host build in the parity
+// tests); the policy's means agree with the other shapes to rounding (a different summation order), as between any two
+// of them.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) float rl_f32x2;
+typedef __attribute__((ext_vector_type(4))) float rl_f32x4;
+
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {          // src_lane wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+template <class Env, int H>
+struct RolloutPolicyLane {
+    using N = Net<Env::OBS, Env::ACT, H>;
+    static constexpr int DO = Env::OBS, DA = Env::ACT;
+    static constexpr int DOP = (DO + 1) & ~1;
+    float w0[DOP], b0;         // column u of W0 (u = lane % H), b0[u]
+    float w1[H], b1;           // column u of W1, b1[u]
+    float w2[H], b2;           // column a of W2 (a = min(lane, DA - 1)), b2[a]
+    float lstd;                // log_std[a]
+    float* hbuf;               // LDS: H floats of this wavefront
+
+    __device__ __forceinline__ void init(const float* __restrict__ th, float* lds_row) {
+        const int lane = threadIdx.x & 63, u = lane & (H - 1), a = lane < DA ? lane : DA - 1;
+        hbuf = lds_row;
+#pragma unroll
+        for (int k = 0; k < DOP; ++k) w0[k] = k < DO ? th[N::W0 + k * H + u] : 0.0f;
+        b0 = th[N::B0 + u];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            w1[k] = th[N::W1 + k * H + u];
+            w2[k] = th[N::W2 + k * DA + a];
+        }
+        b1 = th[N::B1 + u];
+        b2 = th[N::B2 + a];
+        lstd = th[N::LSTD + a];
+    }
+    // sum_k w[k] v[k] with v read back from the wavefront's LDS row (every lane the same addresses: broadcast reads),
+    // two products per packed instruction
+    __device__ __forceinline__ float dot_row(const float* w) const {
+        rl_f32x2 acc = {0.0f, 0.0f};
+        const rl_f32x4* hv = reinterpret_cast<const rl_f32x4*>(hbuf);
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) {
+            const rl_f32x4 v = hv[q];
+            acc = __builtin_elementwise_fma((rl_f32x2){w[4 * q], w[4 * q + 1]}, (rl_f32x2){v[0], v[1]}, acc);
+            acc = __builtin_elementwise_fma((rl_f32x2){w[4 * q + 2], w[4 * q + 3]}, (rl_f32x2){v[2], v[3]}, acc);
+        }
+        return acc[0] + acc[1];
+    }
+    // o: the env's observation (the same on every lane); returns mean[a] on lane a < DA
+    __device__ __forceinline__ float forward(const float* o) const {
+        const int lane = threadIdx.x & 63;
+        rl_f32x2 acc = {b0, 0.0f};
+#pragma unroll
+        for (int k = 0; k < DOP; k += 2)
+            acc = __builtin_elementwise_fma((rl_f32x2){w0[k], w0[k + 1]}, (rl_f32x2){o[k], k + 1 < DO ? o[k + 1] : 0.0f}, acc);
+        const float h0 = ftanh(acc[0] + acc[1]);
+        if (lane < H) hbuf[lane] = h0;
+        wave_sync();
+        const float h1 = ftanh(b1 + dot_row(w1));
+        wave_sync();                                  // (the reads of h0 are issued; LDS runs a wavefront's operations in order)
+        if (lane < H) hbuf[lane] = h1;
+        wave_sync();
+        const float m = b2 + dot_row(w2);
+        wave_sync();
+        return m;
+    }
+};
+
+template <class Env, int H>
+__global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutDev a) {
+    using Legs = typename Env::Legs;
+    __shared__ __attribute__((aligned(16))) float hrows[LANE_TPB / 64][H];
+    RolloutPolicyLane<Env, H> pol;
+    pol.init(a.theta, hrows[threadIdx.x >> 6]);
+
+    const int n = a.n, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int i_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // this wavefront's env
+    const bool alive = i_raw < n;
+    const int i = alive ? i_raw : n - 1;
+    const uint32_t env_global = (uint32_t)(a.env_offset + i);
+    const size_t plane = (size_t)T * n;
+    const int leg = lane & 1;
+    const typename Legs::template LegK<float> kc = Legs::template leg_constants<float>(leg);
+    const DppPair dpp;
+    const bool obs_lane = alive && lane < Env::OBS, act_lane = alive && lane < Env::ACT, lane0 = alive && lane == 0;
+
+    const float std_l = __expf(fmaxf(pol.lstd, a.log_min_std));          // lane a: exp(log_std[a])
+
+    float s[Env::STATE];
+    load_state<Env>(a.state, n, i, s);
+    int ts = a.ts[i];
+    const size_t draws_slice = (size_t)Env::RESET_DRAWS * n;
+    if (a.reset_at_start) {
+        reset_one<Env>(s, a.reset_draws, n, i, a.seed, env_global, a.step_counter, a.cfg);
+        ts = 0;
+    }
+    float o[Env::OBS];
+    float zq[Env::ACT] = {};      // policy noise of 64 steps, one step per lane
+    Env::template observe<float>(s, o);
+    const size_t obs_z_slice = (size_t)Env::OBS * n;
+    observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
+    // lane-distributed output addressing: uniform base per array advanced by a row per env-step + the 32-bit byte offset
+    // of this lane's plane (the dispatcher keeps OBS * T * n * 4 < 2^32 for this kernel)
+    uint32_t vo_obs = (uint32_t)(((size_t)(lane < Env::OBS ? lane : 0) * plane + (size_t)i) * 4);
+    uint32_t vo_act = (uint32_t)(((size_t)(lane < Env::ACT ? lane : 0) * plane + (size_t)i) * 4);
+    uint32_t vo_row = (uint32_t)i * 4, vo_done = (uint32_t)i;
+    auto at = [](auto* base, size_t row_elems, uint32_t& byte_off) {
+        using P = decltype(base);
+        asm volatile("" : "+v"(byte_off));
+        return reinterpret_cast<P>(reinterpret_cast<char*>(base + row_elems) + byte_off);
+    };
+
+    typename Legs::template State<float> ls;        // resident across env-steps (valid until the env is reset)
+    bool chain_valid = false;
+    const StepOpts<float> base_opts = opts_from_cfg<float>(a.cfg);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * n;
+        {   // observation row k from lane k
+            float ov = o[0];
+#pragma unroll
+            for (int k = 1; k < Env::OBS; ++k) ov = (lane == k) ? o[k] : ov;
+            if (obs_lane) *at(a.obs, row, vo_obs) = ov;
+        }
+        const float mean_l = pol.forward(o);
+        float zs[Env::ACT];
+        if (a.eps) {
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) zs[k] = a.eps[k * plane + row + i];
+        } else {
+            // lane j draws the block of step t + j once per 64 steps; every step reads its row
+            if ((t & 63) == 0)
+                philox_draws<Env::ACT, true>(zq, a.seed, env_global, a.step_counter + (uint64_t)(t + lane), RNG_POLICY);
+#pragma unroll
+            for (int k = 0; k < Env::ACT; ++k) zs[k] = lane_bcast(zq[k], t & 63);
+        }
+        float z_l = zs[0];
+#pragma unroll
+        for (int k = 1; k < Env::ACT; ++k) z_l = (lane == k) ? zs[k] : z_l;
+        const float act_l = __builtin_fmaf(z_l, std_l, mean_l);            // rnd * exp(log_std) + mean, action a on lane a
+        if (act_lane) {
+            *at(a.actions, row, vo_act) = act_l;
+            *at(a.means, row, vo_act) = mean_l;
+        }
+        float act[Env::ACT];
+#pragma unroll
+        for (int k = 0; k < Env::ACT; ++k) act[k] = lane_bcast(act_l, k);
+
+        // ---- Env.step: begin (per env, all lanes alike) -> sub-steps (one leg per lane) -> end (per env) ----
+        float eact[Env::ACT_BUF], tau[7];
+        StepOpts<float> opts = base_opts;
+        float dact[Env::ACT];
+        if (a.cfg.action_noise != 0.0f) {      // wave-uniform: MujocoEnv(action_noise=..) (mujoco_env.py:175-187)
+            float zn[Env::ACT];
+            noise_draws<Env::ACT>(zn, a.act_noise_z ? a.act_noise_z + (size_t)t * Env::ACT * n : nullptr, n, i, a.seed,
+                                  env_global, a.step_counter + (uint64_t)t, RNG_ACT_NOISE);
+            action_perturbation<Env, float>(a.cfg, zn, dact);
+            opts.dact = dact;
+        }
+        Env::template step_begin<float>(act, a.normalize, opts, eact, tau);
+        float com4[4];
+        {
+            float lact[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) lact[j] = leg ? tau[4 + j] : tau[1 + j];
+            if (!chain_valid) {
+                // hand the env to the leg lanes (first step, and after a reset)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    ls.qr[r] = s[r];
+                    ls.qdr[r] = s[9 + r];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ls.q[j] = leg ? s[6 + j] : s[3 + j];
+                    ls.qd[j] = leg ? s[15 + j] : s[12 + j];
+                }
+                // exact sines of the chain's absolute angles (PlanarTree::angles: phi_child = phi_parent + hinge)
+                float phi = ls.qr[2];
+                rl_sincos(phi, ls.sn[0], ls.cs[0]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    phi = phi + ls.q[j];
+                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
+                }
+            }
+            for (int it = 0; it < Env::SUBSTEPS; ++it)
+                Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
+            {   // the sines of the new angles: step_end's centre of mass needs them now, the next step's sub-steps start from them
+                float phi = ls.qr[2];
+                rl_sincos(phi, ls.sn[0], ls.cs[0]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    phi = phi + ls.q[j];
+                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
+                }
+            }
+            chain_valid = true;
+            float lc[4];
+            Legs::template com<float, float, DppPair>(dpp, kc, ls, lc[0], lc[1], lc[2], lc[3]);
+            // back to the per-env copy: lane 0 holds the back leg, lane 1 the front leg
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                s[r] = lane_bcast(ls.qr[r], 0);
+                s[9 + r] = lane_bcast(ls.qdr[r], 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                s[3 + j] = lane_bcast(ls.q[j], 0);
+                s[6 + j] = lane_bcast(ls.q[j], 1);
+                s[12 + j] = lane_bcast(ls.qd[j], 0);
+                s[15 + j] = lane_bcast(ls.qd[j], 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) com4[k] = lane_bcast(lc[k], 0);
+        }
+        float r;
+        bool d;
+        Env::template step_end_com<float>(s, eact, com4[0], com4[1], com4[2], com4[3], o, r, d, opts);
+
+        ts += 1;
+        if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
+        if (lane0) {
+            *at(a.rewards, row, vo_row) = r * a.scale_reward;
+            *at(a.dones, row, vo_done) = d ? 1 : 0;
+        }
+        if (d) {
+            const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
+            reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg);
+            Env::template observe<float>(s, o);
+            ts = 0;
+            chain_valid = false;
+        }
+        observed<Env>(o, a.cfg, a.obs_noise_z ? a.obs_noise_z + (size_t)(t + 1) * obs_z_slice : nullptr, n, i, a.seed,
+                      env_global, a.step_counter + (uint64_t)t + 1);
+    }
+    if (lane0) {
+        store_state<Env>(a.state, n, i, s);
+        a.ts[i] = ts;
+        if (a.last_obs) {
+#pragma unroll
+            for (int k = 0; k < Env::OBS; ++k) a.last_obs[(size_t)k * n + i] = o[k];
+        }
+    }
+}
+
 __global__ void philox_debug_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                     uint32_t k1, int count, uint32_t* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1428,6 +1694,18 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         const char* tl = getenv("RLLAB_TWO_LEG_LANE_KERNEL");
         const bool lanes_on = !(tl && tl[0] == '0') && getenv("RLLAB_ROLLOUT_EPW") == nullptr;
         const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
+        // one env per wavefront while the wavefronts still find (about) a SIMD each (RLLAB_TWO_LEG_WAVE_KERNEL = 1 / 0
+        // forces / forbids the shape: A/B timing, and the tests that compare shapes)
+        const char* tw = getenv("RLLAB_TWO_LEG_WAVE_KERNEL");
+        const bool wave_shape = tw ? tw[0] == '1' : a.n <= 2048;
+        if (lanes_on && wave_shape && small_offsets && g->hidden2 == 0 &&
+            (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
+            const int waves = a.n, wpb = lane_group_wpb(waves);
+            dim3 wgrid((waves + wpb - 1) / wpb), wblock(64 * wpb);
+            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 32>), wgrid, wblock, 0, st, a);
+            else hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 64>), wgrid, wblock, 0, st, a);
+            return check_launch("rollout_two_leg_wave_kernel");
+        }
         if (lanes_on && small_offsets && a.n <= 16 * 1024 && g->hidden2 == 0 && (g->hidden0 == g->hidden1) &&
             (g->hidden0 == 32 || g->hidden0 == 64)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);

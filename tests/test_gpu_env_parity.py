@@ -74,18 +74,23 @@ def _make_policy(kind, hidden=(32, 32), seed=0):
     return GaussianMLPPolicy(spec, hidden_sizes=hidden)
 
 
-@pytest.fixture(params=["auto", "64", "wpb4"])
+@pytest.fixture(params=["auto", "64", "wpb4", "leg16"])
 def rollout_shape(request, monkeypatch):
-    """The launch shapes of the fused rollout: "auto" = 16 envs per wavefront at these sizes (policy on
-    16x16x4 tiles, physics replicated on four lanes) in single-wavefront workgroups, "64" = one env per lane,
-    "wpb4" = 16 envs per wavefront in workgroups of four wavefronts (what launches beyond 256 wavefronts
-    use; csrc/env_kernels.hip)."""
+    """The launch shapes of the fused rollout: "auto" = at these sizes 16 envs per wavefront (policy on 16x16x4 tiles,
+    physics replicated on four lanes; the Swimmer four lanes per env) in single-wavefront workgroups -- and ONE ENV PER
+    WAVEFRONT for the two-legged envs (policy units on the lanes, rollout_two_leg_wave_kernel); "64" = one env per lane;
+    "wpb4" = the auto shapes in workgroups of four wavefronts (what launches beyond 256 wavefronts use);
+    "leg16" = the two-legged envs in their 16-envs-per-wavefront shape (what they use beyond 2048 envs;
+    csrc/env_kernels.hip)."""
     monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
     monkeypatch.delenv("RLLAB_ROLLOUT_WPB", raising=False)
+    monkeypatch.delenv("RLLAB_TWO_LEG_WAVE_KERNEL", raising=False)
     if request.param == "64":
         monkeypatch.setenv("RLLAB_ROLLOUT_EPW", "64")
     elif request.param == "wpb4":
         monkeypatch.setenv("RLLAB_ROLLOUT_WPB", "4")
+    elif request.param == "leg16":
+        monkeypatch.setenv("RLLAB_TWO_LEG_WAVE_KERNEL", "0")
     return request.param
 
 
@@ -329,14 +334,16 @@ def test_stepwise_rollout_through_a_hip_graph(quiet_logger, monkeypatch):
     assert t_graph < t_eager
 
 
-@pytest.mark.parametrize("kind", [0, 2, 3])
-def test_policy_noise_stream_is_the_same_in_every_launch_shape(kind, monkeypatch):
+@pytest.mark.parametrize("kind,T", [(0, 23), (2, 23), (3, 23), (3, 150), (5, 70)])
+def test_policy_noise_stream_is_the_same_in_every_launch_shape(kind, T, monkeypatch):
     """In-kernel policy noise is a function of (seed, global env index, step) only: the lane-group shapes draw four
-    steps at once on the four replicas of an env, the env-per-lane shape one step per launch iteration -- the
-    standardised noise (action - mean) / std must agree (to the rounding of the two policy forward passes)."""
+    steps at once on the four replicas of an env, the one-env-per-wavefront shape of the two-legged envs 64 steps at once
+    on its 64 lanes (T = 150, 70: more than one such group, the last partly unused), the env-per-lane shape one step per
+    launch iteration -- the standardised noise (action - mean) / std must agree (to the rounding of the two policy
+    forward passes)."""
     from rllab_amd.envs.hip_env import HipVecEnv
     policy = _make_policy(kind, (32, 32))
-    n, T = 100, 23                    # T not a multiple of four: the last group of draws is partly unused
+    n = 100                           # T = 23: not a multiple of four, the last group of draws is partly unused
 
     def run():
         v = HipVecEnv(kind, n, 9, normalize=True, seed=21)
@@ -345,6 +352,7 @@ def test_policy_noise_stream_is_the_same_in_every_launch_shape(kind, monkeypatch
         return ((tr.actions - tr.means) / std).cpu().numpy(), tr.obs.cpu().numpy()
     monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
     monkeypatch.delenv("RLLAB_SWIMMER_LANE_KERNEL", raising=False)
+    monkeypatch.delenv("RLLAB_TWO_LEG_WAVE_KERNEL", raising=False)
     z16, o16 = run()
     monkeypatch.setenv("RLLAB_ROLLOUT_EPW", "64")
     monkeypatch.setenv("RLLAB_SWIMMER_LANE_KERNEL", "1")

@@ -85,8 +85,13 @@ def _update_partials(policy, traj, q, mean_a, denom, inv_count, vec):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("name,hidden,n,lam", [("swimmer", (32, 32), 4096, 1.0),        # C4: 8 x 4096, TRPO
                                                ("half_cheetah", (64, 64), 1024, 0.97)])   # C5: 8 x 1024, TRPO + GAE
-def test_union_of_eight_shards_is_the_single_process_batch(name, hidden, n, lam):
+def test_union_of_eight_shards_is_the_single_process_batch(name, hidden, n, lam, monkeypatch):
     from rllab_amd.sampler.base import _ADV, _ADV2, _COUNT, fold_stats
+    # Bit-identity of a shard and its slice holds within ONE launch shape of the rollout (the shapes' policy forward
+    # passes sum in different orders).  1024 HalfCheetah envs per rank run one env per wavefront (csrc/env_kernels.hip:
+    # rollout_two_leg_wave_kernel, n <= 2048) -- on every rank of an 8-GPU run alike; the single-process reference batch of
+    # 8192 envs is rolled out in the same shape here.
+    monkeypatch.setenv("RLLAB_TWO_LEG_WAVE_KERNEL", "1")
     T, gamma, N = 500, 0.99, WORLD * n
     env, policy = _env_policy(name, hidden)
     counter = 3 * (T + 1)
