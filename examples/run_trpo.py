@@ -29,6 +29,9 @@ def make_env(name):
     if name == "swimmer":
         from rllab.envs.mujoco.swimmer_env import SwimmerEnv
         return normalize(SwimmerEnv()), 500
+    if name == "swimmer_mujoco_limits":     # engine option: joint limits by MuJoCo's soft-constraint model
+        from rllab.envs.mujoco.swimmer_env import SwimmerEnv
+        return normalize(SwimmerEnv(limit_model="mujoco")), 500
     if name == "half_cheetah":
         from rllab.envs.mujoco.half_cheetah_env import HalfCheetahEnv
         return normalize(HalfCheetahEnv()), 500

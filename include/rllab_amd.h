@@ -97,8 +97,15 @@ enum rl_env_cfg_flags {
     RL_CFG_POLE_FOLLOWS_CART = 1, /* CartpoleEnv / CartpoleSwingupEnv: reset moves the pole body with the cart, so
                                    * the hinge starts closed (engine option; the reference's reset leaves the pole
                                    * origin at the XML pose, cartpole_env.py:28-43 -- DESIGN.md section 5) */
-    RL_CFG_FIXED_START = 2        /* InvertedDoublePendulumEnv(random_start=False)
+    RL_CFG_FIXED_START = 2,       /* InvertedDoublePendulumEnv(random_start=False)
                                    * (inverted_double_pendulum_env.py:20,47-58) */
+    RL_CFG_LIMIT_MUJOCO = 4       /* SwimmerEnv(limit_model="mujoco") (engine option): the two hinge limits act through
+                                   * MuJoCo's documented soft-constraint model with the MJCF's own solreflimit = "0.02 1"
+                                   * and solimplimit = "0 .8 .03" (vendor/mujoco_models/swimmer.xml:31,34): reference
+                                   * acceleration + impedance, constraint forces f >= 0 minimising
+                                   * 1/2 f'(A + R)f + f'(a0 - a_ref), solved exactly for the (at most two) active rows --
+                                   * instead of the default penalty spring-damper.  Swimmer only; such launches run the
+                                   * scalar sub-step program (the four-lanes-per-env rollout is built for the default). */
 };
 
 /* The options env `kind` runs with by default (host struct out). */

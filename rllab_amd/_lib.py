@@ -46,7 +46,7 @@ class EnvCfg(ctypes.Structure):
     ]
 
 
-CFG_POLE_FOLLOWS_CART, CFG_FIXED_START = 1, 2
+CFG_POLE_FOLLOWS_CART, CFG_FIXED_START, CFG_LIMIT_MUJOCO = 1, 2, 4
 
 
 class RolloutArgs(ctypes.Structure):

@@ -18,7 +18,9 @@
 // frame at the COM):  viscous  f = -3*pi*d*mu*v, t = -pi*d^3*mu*w  and inertial
 // drag  f_i = -0.5*rho*b_j*b_k*|v_i|*v_i, t_z = -rho*b_z*(b_x^4+b_y^4)*|w|*w/64,
 // with b the equivalent inertia box of the capsule and d its mean edge.
-// Joint limits: spring-damper penalty, not MuJoCo's soft-constraint solver.
+// Joint limits: spring-damper penalty by default; SwimmerEnv(limit_model="mujoco") = rl_env_cfg flag
+// RL_CFG_LIMIT_MUJOCO: MuJoCo's documented soft-constraint model from the MJCF's own solreflimit / solimplimit
+// (dyn_swimmer_chain.h), on the scalar program (VecEnv kernels, generic rollout shapes, host build).
 //
 // State (10 reals per env): qpos[5] = x, y, torso angle, rot2, rot3; qvel[5].
 #pragma once
@@ -195,7 +197,11 @@ struct Swimmer {
         // rates, joint angles, carried sin / cos of the absolute body angles
         R r4[4], th[3], om[3], sn[3], cs[3];
         to_chain(s, s + 5, r4, th, om, sn, cs);
-        for (int it = 0; it < FRAME_SKIP; ++it) Chain::template substep_scalar<R>(r4, cs, sn, om, th, ctrl, (R)0.001);
+        if (o.flags & CFG_LIMIT_MUJOCO) {
+            for (int it = 0; it < FRAME_SKIP; ++it) Chain::template substep_scalar<R, true>(r4, cs, sn, om, th, ctrl, (R)0.001);
+        } else {
+            for (int it = 0; it < FRAME_SKIP; ++it) Chain::template substep_scalar<R>(r4, cs, sn, om, th, ctrl, (R)0.001);
+        }
         from_chain(r4, th, om, s, s + 5);
         step_end(s, act, obs, reward, done, o.ctrl_cost_coeff);
     }

@@ -85,10 +85,47 @@ struct SwimChain {
         return num * rl_recip_normal(det);
     }
 
+    // ---- joint limits by MuJoCo's soft-constraint model (SwimmerEnv(limit_model="mujoco"), scalar program only) -------
+    // vendor/mujoco_models/swimmer.xml:31,34 put solreflimit = (timeconst 0.02, dampratio 1) and solimplimit = (dmin 0,
+    // dmax 0.8, width 0.03) on the two hinges.  MuJoCo's documented model (Computation chapter: "Constraint model",
+    // "Solver parameters"; the binary itself, version 1.31, is absent -- this follows the published text):
+    //   * a limit is active when dist = q - lo (lower) or hi - q (upper) is negative; its Jacobian row J is +-1 on the hinge;
+    //   * reference acceleration  a_ref = -b (J v) - k dist,  b = 2 / (dmax timeconst),
+    //     k = d(dist) / (dmax^2 timeconst^2 dampratio^2);
+    //   * impedance d(dist) in [dmin, dmax]: x = min(|dist| / width, 1), y = 2 x^2 (x < 1/2), 1 - 2 (1 - x)^2 otherwise
+    //     (the fixed sigmoid of the three-number solimp; MuJoCo 2's five-number form names it midpoint 0.5, power 2),
+    //     d = dmin + y (dmax - dmin), kept inside [mjMINIMP, mjMAXIMP] = [1e-4, 0.9999];
+    //   * constraint forces f >= 0 minimise  1/2 f^T (A + R) f + f^T (a0 - a_ref),  A = J M^-1 J^T, a0 = J qacc_unconstrained,
+    //     R = diag((1 - d_i) / d_i A_ii);  qacc = qacc_unconstrained + M^-1 J^T f.
+    // MuJoCo reaches the minimum by projected Gauss-Seidel (swimmer.xml: 1000 iterations); with at most two rows it is
+    // found exactly by enumerating the active sets.  In the absolute-angle coordinates of this file the translations are
+    // already eliminated, so M^-1 restricted to the hinges is the inverse of the 3 x 3 system solved below and
+    // J = e_j - e_{j-1}.
+    static constexpr double MJ_TIMECONST = 0.02, MJ_DAMPRATIO = 1.0, MJ_DMIN = 0.0, MJ_DMAX = 0.8, MJ_WIDTH = 0.03;
+    static constexpr double MJ_B = 2.0 / (MJ_DMAX * MJ_TIMECONST);
+    static constexpr double MJ_KD = 1.0 / (MJ_DMAX * MJ_DMAX * MJ_TIMECONST * MJ_TIMECONST * MJ_DAMPRATIO * MJ_DAMPRATIO);
+    template <typename R>
+    RL_HD static R mj_impedance(R dist) {
+        const R x0 = rl_abs(dist) * (R)(1.0 / MJ_WIDTH);
+        const R x = x0 < (R)1 ? x0 : (R)1;
+        const R omx = (R)1 - x;
+        const R y = x < (R)0.5 ? (R)2 * (x * x) : (R)1 - (R)2 * (omx * omx);
+        const R d = (R)MJ_DMIN + y * (R)(MJ_DMAX - MJ_DMIN);
+        return rl_clamp(d, (R)1e-4, (R)0.9999);
+    }
+    // one hinge: sign (+1 lower limit active, -1 upper, 0 none), dist (< 0 when active)
+    template <typename R>
+    RL_HD static void mj_limit_state(R th, R& sign, R& dist) {
+        const R dlo = th - (R)Mdl::lo(1), dhi = (R)Mdl::hi(1) - th;
+        sign = dlo < (R)0 ? (R)1 : (dhi < (R)0 ? (R)-1 : (R)0);
+        dist = dlo < (R)0 ? dlo : (dhi < (R)0 ? dhi : (R)0);
+    }
+
     // ---- scalar program ---------------------------------------------------------------------------------------------
     // r = [rx, ry, vx, vy]; per body b: cs, sn, om (absolute rate), th (th[0] = root angle, th[1..2] = hinge angles);
     // act[b] = motor torque of hinge b (act[0] unused)
-    template <typename R>
+    // MJ: joint limits by the soft-constraint model above instead of the penalty torque (everything else unchanged)
+    template <typename R, bool MJ = false>
     RL_HD static void substep_scalar(R* r, R* cs, R* sn, R* om, R* th, const R* act, R h) {
         const R VL = (R)Mdl::VISC_LIN, DAX = (R)Mdl::DRAG_AX, DPERP = (R)Mdl::DRAG_PERP, VA = (R)Mdl::VISC_ANG,
                 DANG = (R)Mdl::DRAG_ANG;
@@ -114,8 +151,13 @@ struct SwimChain {
         }
         R tau[3];
         tau[0] = (R)0;
-        tau[1] = joint_torque(th[1], om[1] - om[0], act[1], LK, LB);
-        tau[2] = joint_torque(th[2], om[2] - om[1], act[2], LK, LB);
+        if constexpr (MJ) {
+            tau[1] = act[1];                                   // the limits act as constraint forces after the solve
+            tau[2] = act[2];
+        } else {
+            tau[1] = joint_torque(th[1], om[1] - om[0], act[1], LK, LB);
+            tau[2] = joint_torque(th[2], om[2] - om[1], act[2], LK, LB);
+        }
         // subtree force sums and generalised forces on the absolute angles
         R Fsx[3], Fsy[3], Q[3];
         Fsx[2] = Fx[2];                      Fsy[2] = Fy[2];
@@ -169,6 +211,66 @@ struct SwimChain {
             const int p = nxt(b), q = nx2(b);
             thb[b] = solve_row((R)sdiag(b), (R)dpq(b), (R)sdiag(p), (R)sdiag(q), Sbp[b], Sbp[q], Sbp[p], rb[b], rb[p],
                                rb[q]);
+        }
+        if constexpr (MJ) {
+            // thb = the unconstrained accelerations of the absolute angles.  Limit rows of hinge j (= 1, 2): J = sg_j (e_j - e_{j-1})
+            R sg[2], dist[2];
+            mj_limit_state(th[1], sg[0], dist[0]);
+            mj_limit_state(th[2], sg[1], dist[1]);
+            if (sg[0] != (R)0 || sg[1] != (R)0) {
+                // X_c = S^-1 J_c^T (three more right-hand sides per row through the same cofactor solve)
+                R X[2][3];
+                RL_UNROLL
+                for (int c = 0; c < 2; ++c) {
+                    R e[3];
+                    e[0] = c == 0 ? -sg[0] : (R)0;
+                    e[1] = c == 0 ? sg[0] : -sg[1];
+                    e[2] = c == 0 ? (R)0 : sg[1];
+                    RL_UNROLL
+                    for (int b = 0; b < 3; ++b) {
+                        const int p = nxt(b), q = nx2(b);
+                        X[c][b] = solve_row((R)sdiag(b), (R)dpq(b), (R)sdiag(p), (R)sdiag(q), Sbp[b], Sbp[q], Sbp[p], e[b], e[p],
+                                            e[q]);
+                    }
+                }
+                // A = J S^-1 J^T, a0 = J thb, a_ref, impedances
+                const R A00 = sg[0] * (X[0][1] - X[0][0]);
+                const R A01 = sg[0] * (X[1][1] - X[1][0]);
+                const R A11 = sg[1] * (X[1][2] - X[1][1]);
+                R c_[2], D[2];
+                RL_UNROLL
+                for (int c = 0; c < 2; ++c) {
+                    const R a0 = sg[c] * (thb[c + 1] - thb[c]);
+                    const R v = sg[c] * (om[c + 1] - om[c]);
+                    const R d = mj_impedance(dist[c]);
+                    const R aref = -((R)MJ_B * v) - ((R)MJ_KD * d) * dist[c];
+                    c_[c] = aref - a0;                          // the solver minimises 1/2 f (A + R) f - f . c_
+                    D[c] = (c == 0 ? A00 : A11) / d;            // A_ii + R_ii = A_ii / d_i
+                }
+                // exact minimum over f >= 0 of the (strictly convex) two-row problem, by active set
+                R f0 = (R)0, f1 = (R)0;
+                const bool on0 = sg[0] != (R)0, on1 = sg[1] != (R)0;
+                if (on0 && on1) {
+                    const R det = D[0] * D[1] - A01 * A01;
+                    const R g0 = (c_[0] * D[1] - A01 * c_[1]) / det;
+                    const R g1 = (D[0] * c_[1] - A01 * c_[0]) / det;
+                    if (g0 >= (R)0 && g1 >= (R)0) {
+                        f0 = g0; f1 = g1;
+                    } else {
+                        const R s0 = c_[0] / D[0], s1 = c_[1] / D[1];
+                        if (s0 > (R)0 && A01 * s0 - c_[1] >= (R)0) f0 = s0;              // row 1 inactive: its gradient >= 0
+                        else if (s1 > (R)0 && A01 * s1 - c_[0] >= (R)0) f1 = s1;
+                    }
+                } else if (on0) {
+                    const R s0 = c_[0] / D[0];
+                    f0 = s0 > (R)0 ? s0 : (R)0;
+                } else {
+                    const R s1 = c_[1] / D[1];
+                    f1 = s1 > (R)0 ? s1 : (R)0;
+                }
+                RL_UNROLL
+                for (int b = 0; b < 3; ++b) thb[b] = thb[b] + (X[0][b] * f0 + X[1][b] * f1);
+            }
         }
         // translations
         R cxp[3], cyp[3];

@@ -1514,6 +1514,9 @@ static int device_cfg(const rl_env_cfg* cfg, EnvCfg& c) {
     c.action_noise = cfg->action_noise; c.obs_noise = cfg->obs_noise;
     if (cfg->frame_skip > 0) c.frame_skip = cfg->frame_skip;
     c.flags = cfg->flags;
+    if ((cfg->flags & RL_CFG_LIMIT_MUJOCO) && !std::is_same<Env, Swimmer>::value)
+        return set_error(RL_ERR_UNSUPPORTED, "rl_env_cfg.flags: RL_CFG_LIMIT_MUJOCO (soft-constraint joint limits) is built "
+                                             "for the Swimmer only");
     if (cfg->link_len < 0.0f || cfg->link_len > 8.0f)
         return set_error(RL_ERR_ARG, "rl_env_cfg.link_len = %g (0 = the model's, else (0, 8])", (double)cfg->link_len);
     if (cfg->link_len > 0.0f) c.link_len = cfg->link_len;
@@ -1655,7 +1658,9 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     }
     if constexpr (std::is_same<Env, Swimmer>::value) {
         // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
-        const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr;   // per launch: tests switch shapes
+        // (RL_CFG_LIMIT_MUJOCO: the soft-constraint limits live in the scalar sub-step program only)
+        const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr ||   // per launch: tests switch shapes
+                                 (a.cfg.flags & CFG_LIMIT_MUJOCO) != 0;
         const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
         if (!lane_kernel && small_offsets && g->hidden2 == 0 && (g->hidden0 == g->hidden1) &&
             (g->hidden0 == 32 || g->hidden0 == 64)) {

@@ -216,6 +216,9 @@ using EnvCfg = EnvCfgT<float>;
 enum EnvCfgFlags : int {
     CFG_POLE_FOLLOWS_CART = 1,   // CartpoleEnv.reset moves the pole with the cart (hinge starts closed)
     CFG_FIXED_START = 2,         // InvertedDoublePendulumEnv(random_start=False)
+    CFG_LIMIT_MUJOCO = 4,        // SwimmerEnv(limit_model="mujoco"): joint limits by MuJoCo's documented soft-constraint
+                                 // model from the MJCF's own solreflimit / solimplimit (dyn_swimmer_chain.h) instead
+                                 // of the penalty spring-damper
 };
 template <typename R>
 struct StepOpts {
@@ -223,12 +226,14 @@ struct StepOpts {
     int frame_skip;
     const R* dact;               // per-dimension additive perturbation of the applied action, or null
     R link_len;
+    int flags;                   // EnvCfgFlags
 };
 template <typename R>
 RL_HD StepOpts<R> make_opts(double ctrl_cost_coeff, double alive_coeff, int frame_skip) {
     StepOpts<R> o;
     o.ctrl_cost_coeff = (R)ctrl_cost_coeff; o.alive_coeff = (R)alive_coeff; o.frame_skip = frame_skip; o.dact = nullptr;
     o.link_len = (R)1;
+    o.flags = 0;
     return o;
 }
 // the options an env runs with when the caller gives none
@@ -245,6 +250,7 @@ RL_HD StepOpts<R> opts_from_cfg(const EnvCfgT<R>& c) {
     StepOpts<R> o;
     o.ctrl_cost_coeff = c.ctrl_cost_coeff; o.alive_coeff = c.alive_coeff; o.frame_skip = c.frame_skip; o.dact = nullptr;
     o.link_len = c.link_len;
+    o.flags = c.flags;
     return o;
 }
 // Box2DEnv._inject_action_noise / MujocoEnv.inject_action_noise (box2d_env.py:219-226, mujoco_env.py:175-182):

@@ -14,9 +14,18 @@ class SwimmerEnv(MujocoEnv, Serializable):
 
     PLANE = "xy"
 
-    def __init__(self, ctrl_cost_coeff=1e-2, *args, **kwargs):
+    def __init__(self, ctrl_cost_coeff=1e-2, limit_model="penalty", *args, **kwargs):
+        """``limit_model`` (engine option; the reference delegates joint limits to MuJoCo 1.31): "penalty" = the
+        spring-damper of csrc/dyn_swimmer.h (default; the four-lanes-per-env rollout kernel), "mujoco" = MuJoCo's
+        documented soft-constraint model with the MJCF's own solreflimit / solimplimit
+        (vendor/mujoco_models/swimmer.xml:31,34; csrc/dyn_swimmer_chain.h), on the scalar sub-step program."""
+        if limit_model not in ("penalty", "mujoco"):
+            raise ValueError("SwimmerEnv(limit_model=%r): 'penalty' or 'mujoco'" % (limit_model,))
         self.ctrl_cost_coeff = ctrl_cost_coeff
+        self.limit_model = limit_model
         Serializable.quick_init(self, locals())
+        if limit_model == "mujoco":
+            kwargs = dict(kwargs, flags=int(kwargs.get("flags", 0)) | _lib.CFG_LIMIT_MUJOCO)
         super(SwimmerEnv, self).__init__(*args, ctrl_cost_coeff=float(ctrl_cost_coeff), **kwargs)
 
     def get_ori(self):

@@ -18,6 +18,7 @@ CASES = [
     (1, dict(link_len=1.37)), (1, dict(link_len=0.6, action_noise=0.1, frame_skip=3)),
     (4, dict(action_noise=0.5, obs_noise=0.3, flags=1)),
     (2, dict(ctrl_cost_coeff=0.7)), (2, dict(action_noise=0.25)), (2, dict(ctrl_cost_coeff=0.0, action_noise=0.1)),
+    (2, dict(flags=4)), (2, dict(flags=4, action_noise=0.2)),     # SwimmerEnv(limit_model="mujoco"): RL_CFG_LIMIT_MUJOCO
     (3, dict(action_noise=0.4)),
     (5, dict(ctrl_cost_coeff=0.3, action_noise=0.05)),
     (6, dict(ctrl_cost_coeff=0.2, alive_coeff=2.5, action_noise=0.05)),
@@ -69,6 +70,7 @@ def test_vecenv_step_with_options_bit_exact(kind, cfg):
     (1, dict(link_len=0.75, action_noise=0.05), (32, 32)),
     (2, dict(ctrl_cost_coeff=0.4, action_noise=0.15), (32, 32)),      # the lane-group (quad) kernel
     (2, dict(ctrl_cost_coeff=0.4, action_noise=0.15), (64, 64)),
+    (2, dict(flags=4), (32, 32)),                                     # soft-constraint joint limits: the scalar program
     (3, dict(action_noise=0.3), (64, 64)),
     (6, dict(ctrl_cost_coeff=0.2, alive_coeff=0.5, action_noise=0.05), (32, 32)),
 ])

@@ -591,3 +591,18 @@ def test_log_dir_switch(tmp_path):
     out = subprocess.check_output([sys.executable, "-c", "from rllab_amd import config; print(config.LOG_DIR)"],
                                   env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.decode().strip() == str(tmp_path)
+
+
+def test_swimmer_limit_model_option_travels_with_the_env():
+    """SwimmerEnv(limit_model="mujoco") sets rl_env_cfg flag RL_CFG_LIMIT_MUJOCO, survives pickling (snapshots,
+    workers) and cloning; anything but the two models is rejected."""
+    from rllab_amd import _lib
+    from rllab_amd.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab_amd.envs.normalized_env import normalize
+    assert SwimmerEnv()._cfg.get("flags", 0) == 0 and SwimmerEnv().limit_model == "penalty"
+    env = SwimmerEnv(limit_model="mujoco", ctrl_cost_coeff=0.02)
+    assert env._cfg["flags"] == _lib.CFG_LIMIT_MUJOCO and env._cfg["ctrl_cost_coeff"] == 0.02
+    back = pickle.loads(pickle.dumps(normalize(env)))
+    assert back.wrapped_env.limit_model == "mujoco" and back.wrapped_env._cfg["flags"] == _lib.CFG_LIMIT_MUJOCO
+    with pytest.raises(ValueError):
+        SwimmerEnv(limit_model="lcp")

@@ -62,6 +62,41 @@ def test_swimmer_dynamics_vs_independent_lagrangian():
         assert abs(r - r2) < 1e-12 and d is False and d2 is False
 
 
+def test_swimmer_mujoco_limit_model_vs_independent_restatement():
+    """SwimmerEnv(limit_model="mujoco") (rl_env_cfg flag RL_CFG_LIMIT_MUJOCO): the joint limits as MuJoCo's documented
+    soft-constraint model with the MJCF's own solreflimit / solimplimit (vendor/mujoco_models/swimmer.xml:31,34).  The
+    product solves it in absolute body angles with the translations eliminated and an exact active-set solve of the two
+    rows (csrc/dyn_swimmer_chain.h); oracle/np_swimmer.py restates it in MuJoCo's own coordinates -- full 5 x 5 inertia
+    from the autodiff Lagrangian, unit rows on the hinge coordinates, scipy's non-negative least squares.  One env step
+    (50 sub-steps) from states with none, one and both hinges beyond their range, towards and away from the limit."""
+    from oracle import np_swimmer as S
+    rng = np.random.RandomState(4)
+    e = H.HostEnv(2, np.float64, normalize=True, cfg=dict(flags=4))
+    e_pen = H.HostEnv(2, np.float64, normalize=True)
+    lim = np.deg2rad(100.0)
+    hinges = [(0.3, -0.8), (lim + 0.02, 0.1), (-lim - 0.01, lim + 0.025), (lim + 0.004, -lim - 0.05), (1.2, -lim - 0.002)]
+    for trial, (h1, h2) in enumerate(hinges):
+        st = np.concatenate([rng.randn(2), rng.uniform(-3, 3, 1), [h1, h2], rng.randn(5) * (0.5 if trial % 2 else 2.0)])
+        a = rng.randn(2) * (1.0 if trial % 2 else 3.0)
+        e.state[:] = st
+        o, r, d = e.step(a)
+        st2, o2, r2, d2 = S.step_mujoco_limits(st, a)
+        assert np.abs(e.state - st2).max() < 1e-9, (trial, np.abs(e.state - st2).max())
+        assert np.abs(o - o2).max() < 1e-9 and abs(r - r2) < 1e-10 and d is False
+        e_pen.state[:] = st
+        e_pen.step(a)
+        inside = abs(h1) < lim and abs(h2) < lim
+        if not inside:
+            assert np.abs(e.state - e_pen.state).max() > 1e-6          # (the two limit models are different dynamics)
+    # the constraint pushes back: released beyond the upper limit at rest, the hinge returns towards the range, and far
+    # more softly than the penalty spring (timeconst 0.02 s, critically damped)
+    st = np.zeros(10)
+    st[3] = lim + 0.02
+    e.state[:] = st
+    e.step(np.zeros(2))
+    assert lim - 0.01 < e.state[3] < lim + 0.02 and abs(e.state[8]) < 2.0
+
+
 def test_swimmer_f32_tracks_f64_and_conserves_momentum_without_fluid_forces():
     rng = np.random.RandomState(1)
     e32, e64 = H.HostEnv(2, np.float32, normalize=True), H.HostEnv(2, np.float64, normalize=True)
