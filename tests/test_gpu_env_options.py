@@ -85,6 +85,9 @@ def test_fused_rollout_with_options_replays_on_the_host(kind, cfg, hidden):
     q = v.q
     eps = rng.randn(q["act_dim"], T, n).astype(np.float32)
     draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    if cfg.get("flags", 0) & 4:
+        draws *= 150.0           # limit model: start far outside the reset distribution (hinge angles ~ 1.5 N(0,1) rad
+                                 # against limits of 1.745), so that the limit rows are active from the first sub-step
     za = rng.randn(T, q["act_dim"], n).astype(np.float32)
     zo = rng.randn(T + 1, q["obs_dim"], n).astype(np.float32)
     traj = v.rollout(policy, T, reset_at_start=True, eps=eps, reset_draws=draws, action_noise_z=za, obs_noise_z=zo)
