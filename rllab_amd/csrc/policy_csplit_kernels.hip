@@ -226,23 +226,36 @@ __device__ __forceinline__ Parts cs_tr(char* src, int kbs) {
 // acc += A B over nkb k-blocks: A from the operand image (this lane's column; the next k-block's parts in flight while
 // this one runs; during the last k-block the first parts of the wavefront's NEXT chain are fetched, so that every chain
 // starts on operands that are already there: `pre`), B from a parts image in LDS (this lane's slot).
-struct CsPre { bf16x8 v[3]; };
+struct CsPre { bf16x8 v[2][3]; };      // the first two k-blocks of the wavefront's next chain (the second only if it has one)
 
+// Two k-blocks of A in flight ahead of the one being multiplied (an L2 round trip is several six-term products long at
+// one wavefront per SIMD), B one k-block ahead (an LDS round trip is about one product).  The wavefront's chains form one
+// stream of k-blocks: `next` (of next_nkb >= 1 k-blocks) and `next2` are the chains it runs after this one, whose first
+// k-blocks are fetched during this chain's last two.
 __device__ __forceinline__ f32x16 cs_gemm(const bf16x8* __restrict__ A, int nkb, const char* B, f32x16 acc, CsPre& pre,
-                                          const bf16x8* __restrict__ next) {
-    bf16x8 a_cur[3], a_nxt[3];
+                                          const bf16x8* __restrict__ next, int next_nkb,
+                                          const bf16x8* __restrict__ next2) {
+    bf16x8 a0[3], a1[3], a2[3], b0[3], b1[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) a_cur[p] = pre.v[p];
+    for (int p = 0; p < 3; ++p) {
+        a0[p] = pre.v[0][p];
+        a1[p] = pre.v[1][p];
+        b0[p] = *reinterpret_cast<const bf16x8*>(B + p * CH);
+    }
     for (int kb = 0; kb < nkb; ++kb) {
-        const bf16x8* src = (kb + 1 < nkb) ? A + (size_t)(kb + 1) * 3 * 64 : next;
+        // k-block kb + 2 of the stream: of this chain, else k-block 0 / 1 of the next one, else (a next chain of ONE
+        // k-block) k-block 0 of the one after
+        const int ahead = kb + 2 - nkb;
+        const bf16x8* src = ahead < 0 ? A + (size_t)(kb + 2) * 3 * 64
+                                      : (ahead < next_nkb ? next + (size_t)ahead * 3 * 64 : next2);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a_nxt[p] = CS_ABLATE_AIMG ? a_cur[p] : src[p * 64];
+        for (int p = 0; p < 3; ++p) a2[p] = CS_ABLATE_AIMG ? a0[p] : src[p * 64];
+        const int kn = kb + 1 < nkb ? kb + 1 : kb;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b1[p] = *reinterpret_cast<const bf16x8*>(B + (kn * 3 + p) * CH);
         Parts Aop, Bop;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            Aop.p[p] = a_cur[p];
-            Bop.p[p] = *reinterpret_cast<const bf16x8*>(B + (kb * 3 + p) * CH);
-        }
+        for (int p = 0; p < 3; ++p) { Aop.p[p] = a0[p]; Bop.p[p] = b0[p]; }
 #if CS_ABLATE_MFMA
 #pragma unroll
         for (int p = 0; p < 3; ++p) acc[p] += (float)Aop.p[p][0] * (float)Bop.p[p][0];
@@ -250,10 +263,10 @@ __device__ __forceinline__ f32x16 cs_gemm(const bf16x8* __restrict__ A, int nkb,
         acc = mm6(Aop, Bop, acc);
 #endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a_cur[p] = a_nxt[p];
+        for (int p = 0; p < 3; ++p) { a0[p] = a1[p]; a1[p] = a2[p]; b0[p] = b1[p]; }
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) pre.v[p] = a_cur[p];
+    for (int p = 0; p < 3; ++p) { pre.v[0][p] = a0[p]; pre.v[1][p] = a1[p]; }
     return acc;
 }
 
@@ -296,41 +309,53 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
     // ---- this wavefront's chains, in the order it runs them (for the operand prefetch): offsets into the operand
     // images in 16-byte units (wave-uniform), -1 = not this wavefront's ------------------------------------------------
     constexpr int NSEQ = 3 * L + 1;
-    int seq[NSEQ], nxt[NSEQ];
+    int seq[NSEQ], skb[NSEQ], nxt[NSEQ], nkbn[NSEQ], nxt2[NSEQ];   // image offset and k-blocks of a chain; of the chain this
+                                                                   // wavefront runs next; offset of the one after that
     {
         auto rowimg = [&](int base16, int kb, bool busy) -> int { return busy ? base16 + wave * kb * 3 * 64 : -1; };
         const bool last = wave < s.HT[L - 1];
         seq[0] = rowimg(s.iFD[0], s.KB[0], wave < s.HT[0]);
+        skb[0] = s.KB[0];
 #pragma unroll
         for (int l = 1; l < L; ++l) {
             seq[2 * l - 1] = rowimg(s.iFD[l], s.KB[l], wave < s.HT[l]);
             seq[2 * l] = rowimg(s.iFT[l], s.KB[l], wave < s.HT[l]);
+            skb[2 * l - 1] = skb[2 * l] = s.KB[l];
         }
         // output layer: ONE row tile (the action slots), k-blocks 2 w and 2 w + 1 = this wavefront's units
         seq[2 * L - 1] = last ? s.iDO + 2 * wave * 3 * 64 : -1;
         seq[2 * L] = last ? s.iTO + 2 * wave * 3 * 64 : -1;
         seq[2 * L + 1] = rowimg(s.iWO, 1, last);
+        skb[2 * L - 1] = skb[2 * L] = 2;
+        skb[2 * L + 1] = 1;
 #pragma unroll
-        for (int l = L - 1; l >= 1; --l) seq[2 * L + 2 + (L - 1 - l)] = rowimg(s.iBT[l], s.H[l] / 16, wave < s.HT[l - 1]);
+        for (int l = L - 1; l >= 1; --l) {
+            seq[2 * L + 2 + (L - 1 - l)] = rowimg(s.iBT[l], s.H[l] / 16, wave < s.HT[l - 1]);
+            skb[2 * L + 2 + (L - 1 - l)] = s.H[l] / 16;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NSEQ; ++i) {
-        nxt[i] = seq[i];
+        nxt[i] = nxt2[i] = seq[i];
+        nkbn[i] = skb[i];
 #pragma unroll
-        for (int k = NSEQ; k >= 1; --k) {
+        for (int k = 2 * NSEQ; k >= 1; --k) {               // nearest last: (nxt2, nxt) end as the second-nearest and nearest
             const int c = seq[(i + k) % NSEQ];
-            if (c >= 0) nxt[i] = c;
+            if (c >= 0) { nxt2[i] = nxt[i]; nxt[i] = c; nkbn[i] = skb[(i + k) % NSEQ]; }
         }
     }
     const bf16x8* const imgl = a.img + lane;
     CsPre pre;
     {
-        int first = 0;
+        int first = 0, first_kb = 1, second = 0;            // the wavefront's first chain; the chain after it
 #pragma unroll
         for (int i = NSEQ - 1; i >= 0; --i)
-            if (seq[i] >= 0) first = seq[i];
+            if (seq[i] >= 0) { first = seq[i]; first_kb = skb[i]; second = nxt[i]; }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) pre.v[p] = imgl[first + p * 64];
+        for (int p = 0; p < 3; ++p) {
+            pre.v[0][p] = imgl[first + p * 64];
+            pre.v[1][p] = imgl[(first_kb > 1 ? first + 3 * 64 : second) + p * 64];
+        }
     }
 
     // ---- accumulators ------------------------------------------------------------------------------------------------
@@ -434,7 +459,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
                 if (l == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    acc = cs_gemm(imgl + seq[0], s.KB[0], Xp + lane_off, acc, pre, imgl + nxt[0]);
+                    acc = cs_gemm(imgl + seq[0], s.KB[0], Xp + lane_off, acc, pre, imgl + nxt[0], nkbn[0], imgl + nxt2[0]);
                 } else {
                     const f32x4* db = reinterpret_cast<const f32x4*>(smem + s.ldb[l]) + (wave * 2 + lh) * 4;
 #pragma unroll
@@ -443,8 +468,8 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[4 * q + e] = v[e];
                     }
-                    acc = cs_gemm(imgl + seq[2 * l - 1], s.KB[l], smem + s.lH[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l - 1]);
-                    acc = cs_gemm(imgl + seq[2 * l], s.KB[l], smem + s.lG[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l]);
+                    acc = cs_gemm(imgl + seq[2 * l - 1], s.KB[l], smem + s.lH[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l - 1], nkbn[2 * l - 1], imgl + nxt2[2 * l - 1]);
+                    acc = cs_gemm(imgl + seq[2 * l], s.KB[l], smem + s.lG[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l], nkbn[2 * l], imgl + nxt2[2 * l]);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] *= (1.0f - hf[l][r] * hf[l][r]);
@@ -459,8 +484,8 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = cs_gemm(imgl + seq[2 * L - 1], 2, own + s.lH[L - 1], acc, pre, imgl + nxt[2 * L - 1]);
-            acc = cs_gemm(imgl + seq[2 * L], 2, own + s.lG[L - 1], acc, pre, imgl + nxt[2 * L]);
+            acc = cs_gemm(imgl + seq[2 * L - 1], 2, own + s.lH[L - 1], acc, pre, imgl + nxt[2 * L - 1], nkbn[2 * L - 1], imgl + nxt2[2 * L - 1]);
+            acc = cs_gemm(imgl + seq[2 * L], 2, own + s.lG[L - 1], acc, pre, imgl + nxt[2 * L], nkbn[2 * L], imgl + nxt2[2 * L]);
             f32x4 v4;                                        // rows frag_unit(r, half), r < 4 = action slots r + 4 half
 #pragma unroll
             for (int r = 0; r < 4; ++r) v4[r] = acc[r];
@@ -505,7 +530,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = cs_gemm(imgl + seq[2 * L + 1], 1, smem + s.lM + lane_off, acc, pre, imgl + nxt[2 * L + 1]);
+            acc = cs_gemm(imgl + seq[2 * L + 1], 1, smem + s.lM + lane_off, acc, pre, imgl + nxt[2 * L + 1], nkbn[2 * L + 1], imgl + nxt2[2 * L + 1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[r] *= (1.0f - hf[L - 1][r] * hf[L - 1][r]);
@@ -521,7 +546,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 const int si = 2 * L + 2 + (L - 1 - l);
-                acc = cs_gemm(imgl + seq[si], s.H[l] / 16, smem + s.lG[l] + lane_off, acc, pre, imgl + nxt[si]);
+                acc = cs_gemm(imgl + seq[si], s.H[l] / 16, smem + s.lG[l] + lane_off, acc, pre, imgl + nxt[si], nkbn[si], imgl + nxt2[si]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[r] *= (1.0f - hf[l - 1][r] * hf[l - 1][r]);

@@ -33,7 +33,7 @@ for cfg in cfgs.split(";"):
     v32 = ops.layout.pack(v.to(torch.float32)).contiguous()
     out64 = torch.empty(ops.n_kernel, dtype=torch.float64, device=v.device)
     out = dict(net=[do, da, list(hidden)], B=B)
-    for tag, val in ((("split_ms", "1"),) if only_split else (("f32_ms", "0"), ("split_ms", "1"), ("f32_again_ms", "0"), ("split_again_ms", "1"))):
+    for tag, val in ((("split_ms", os.environ.get("CS_FORCE", "1")),) if only_split else (("f32_ms", "0"), ("split_ms", "1"), ("f32_again_ms", "0"), ("split_again_ms", "1"))):
         os.environ["RLLAB_FVP_SPLIT"] = val
         out[tag] = round(timed(lambda: ops._fvp_into(keep_[0], ws_, v32, out64, inp)), 4)
     os.environ.pop("RLLAB_FVP_SPLIT")
