@@ -47,7 +47,8 @@ enum rl_status {
 /* Human-readable description of the last error on this thread (host string). */
 const char* rl_last_error(void);
 
-/* Library / ABI version, bumped when a signature changes. */
+/* Library / ABI version, bumped when a signature changes.  11: rl_rollout_lds_bytes, rl_mlp_forward_ws (every network
+ * shape of the two kernel families as a function on planes), RL_CFG_LIMIT_MUJOCO, rl_policy_fvp_variant's value 2. */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -364,7 +365,10 @@ int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspac
  *   0  f32 matrix instructions (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): bit-identical with or without `activations`;
  *   1  bf16 matrix instructions on three-way split operands with f32 accumulation (six cross terms per product, the
  *      dropped ones at most 2^-23 of |a b|, 2^-28 in the mean): cached products of two 32-unit tanh layers on a batch of whole 32-sample
- *      tiles.  Same result to f32 rounding, not bit for bit.  RLLAB_FVP_SPLIT=0 in the environment selects 0. */
+ *      tiles.  Same result to f32 rounding, not bit for bit.  RLLAB_FVP_SPLIT=0 in the environment selects 0.
+ *   2  the same arithmetic in the cooperative tiling (csrc/policy_csplit_kernels.hip: parts images in LDS, transposing
+ *      reads for the sample-axis products): cached products of two or three tanh layers of 32 / 64 / 128 units with a
+ *      128-unit layer (RLLAB_FVP_SPLIT=2: every such net that is not all-32) on whole 32-sample tiles. */
 int rl_policy_fvp_variant(const rl_policy_batch* batch);
 
 /* ---- policies whose log-std is a NETWORK (GaussianMLPPolicy(adaptive_std=True) / std_network=...,
@@ -373,12 +377,19 @@ int rl_policy_fvp_variant(const rl_policy_batch* batch);
  *   loss / KL        rl_mlp_forward (mean net), rl_mlp_forward (std net), rl_gaussian_head(g = NULL)
  *   gradient         ... rl_gaussian_head(g_mean, g_log_std), rl_mlp_backward x 2; flat gradient = [mean net | std net]
  *   Fisher x vector  rl_mlp_forward with `vec` x 2 (tangents), rl_gaussian_fisher, rl_mlp_backward x 2
- * rl_policy_batch carries the network: n_samples, obs_dim, act_dim, hidden0/1 (two equal tanh layers of 32 or 64,
- * hidden2 = 0), theta = [W0,b0,W1,b1,Wout,bout | act_dim unused floats] (the policy layout with its log_std row
- * ignored), obs, weights; the other fields are not read. */
+ * rl_policy_batch carries the network: n_samples, obs_dim, act_dim, hidden0..2 (two or three tanh layers of 32 / 64 /
+ * 128 units, hidden2 = 0 for two), theta = [W0,b0,W1,b1,(W2,b2,)Wout,bout | act_dim unused floats] (the policy layout
+ * with its log_std row ignored), obs, weights; the other fields are not read.  Two equal layers of 32 / 64 units on a
+ * HIP-native (obs_dim, act_dim) pair run one wavefront per tile; every other shape runs the cooperative kernels, whose
+ * operand images live in the caller's workspace -- rl_mlp_forward_ws (rl_mlp_backward takes one anyway;
+ * rl_policy_workspace_bytes sizes it). */
 
 /* out[act_dim][B] = network(obs); with vec (same layout as theta) also dout = d/d eps network_{theta + eps vec}(obs). */
 int rl_mlp_forward(const rl_policy_batch* batch, const float* vec, float* out, float* dout, void* stream);
+/* The same with a workspace: any network shape of the two kernel families (rl_mlp_forward fails with RL_ERR_ARG for the
+ * shapes that need one). */
+int rl_mlp_forward_ws(const rl_policy_batch* batch, const float* vec, void* workspace, size_t workspace_bytes, float* out,
+                      float* dout, void* stream);
 
 /* grad_out (device, P doubles; the trailing act_dim entries are zero) = d/dtheta sum_b sum_k cotangent[k][b] out_k(b).
  * workspace: rl_policy_workspace_bytes. */

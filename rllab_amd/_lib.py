@@ -33,7 +33,7 @@ SYMBOLS = [
     "rl_lfb_normal_eq",
     "rl_peer_mailbox_bytes", "rl_peer_alloc", "rl_peer_free", "rl_peer_export", "rl_peer_open", "rl_peer_close",
     "rl_peer_allreduce_sum",
-    "rl_mlp_forward", "rl_mlp_backward", "rl_gaussian_head_workspace_bytes", "rl_gaussian_head", "rl_gaussian_fisher",
+    "rl_mlp_forward", "rl_mlp_forward_ws", "rl_mlp_backward", "rl_gaussian_head_workspace_bytes", "rl_gaussian_head", "rl_gaussian_fisher",
 ]
 
 
@@ -136,6 +136,7 @@ def _load():
     lib.rl_adv_finish.argtypes = [sz, vp, vp, f64, f64, f64, vp, vp]
     lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, vp]
     lib.rl_mlp_forward.argtypes = [pb, vp, vp, vp, vp]
+    lib.rl_mlp_forward_ws.argtypes = [pb, vp, vp, sz, vp, vp, vp]
     lib.rl_mlp_backward.argtypes = [pb, vp, vp, sz, vp, vp]
     lib.rl_gaussian_head_workspace_bytes.restype = sz
     lib.rl_gaussian_head_workspace_bytes.argtypes = []

@@ -793,7 +793,8 @@ int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t
     return check_launch("reduce_loss_kernel");
 }
 int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
-                  hipStream_t st, double* loss_out);                       // policy_wide_kernels.hip
+                  hipStream_t st, double* loss_out, const float* cot = nullptr, float* out_mean = nullptr,
+                  float* out_dmean = nullptr);                       // policy_wide_kernels.hip
 struct WideShape;
 // policy_split_kernels.hip: the cached Fisher-vector product of the 32-unit nets on the bf16 matrix pipe (three-way
 // split operands, f32 accuracy); RL_SPLIT_NOT_TAKEN when the launch is not its to make
@@ -931,17 +932,23 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
                         const PlaneArgs* pl = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
     if (mode >= MODE_OUT) {
-        if (g->hidden2 != 0 || g->activation != RL_ACT_TANH)
-            return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: two equal tanh layers of 32 or 64 units");
+        if (g->activation != RL_ACT_TANH)
+            return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: tanh networks");
 #define PLANECASE(DO, DA, H) \
-        if (d == DO && k == DA && h0 == H && h1 == H) return dispatch_planes<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, pl);
+        if (g->hidden2 == 0 && d == DO && k == DA && h0 == H && h1 == H) \
+            return dispatch_planes<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, pl);
         PLANECASE(4, 1, 32) PLANECASE(6, 1, 32) PLANECASE(11, 1, 32) PLANECASE(13, 2, 32) PLANECASE(20, 3, 32)
         PLANECASE(20, 6, 32) PLANECASE(21, 6, 32)
         PLANECASE(4, 1, 64) PLANECASE(6, 1, 64) PLANECASE(11, 1, 64) PLANECASE(13, 2, 64) PLANECASE(20, 3, 64)
         PLANECASE(20, 6, 64) PLANECASE(21, 6, 64)
 #undef PLANECASE
-        return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: no kernel for obs_dim=%d act_dim=%d "
-                         "hidden=(%d,%d)", d, k, h0, h1);
+        // anything else with two or three tanh layers of 32 / 64 / 128 units: the cooperative kernels, whose operand
+        // images need the caller's workspace (rl_mlp_forward_ws; rl_mlp_backward always had one)
+        if (ws == nullptr)
+            return set_error(RL_ERR_ARG, "rl_mlp_forward: obs_dim=%d act_dim=%d hidden=(%d,%d,%d) runs on the cooperative "
+                             "kernels, which need a workspace: call rl_mlp_forward_ws", d, k, h0, h1, g->hidden2);
+        return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, nullptr, pl ? pl->cot : nullptr,
+                             pl ? pl->out_mean : nullptr, pl ? pl->out_dmean : nullptr);
     }
     if (g->hidden2 < 0) return set_error(RL_ERR_ARG, "rl_policy_batch.hidden2 = %d", g->hidden2);
     if (g->hidden2 > 0) {              // three hidden layers: the cooperative kernels (policy_wide_kernels.hip)
@@ -1079,6 +1086,19 @@ extern "C" int rl_mlp_forward(const rl_policy_batch* g, const float* vec, float*
     pl.out_dmean = dout;
     return dispatch_net(vec ? MODE_OUT_TAN : MODE_OUT, g, vec, nullptr, 0, nullptr, (hipStream_t)stream, nullptr, nullptr,
                         &pl);
+}
+
+extern "C" int rl_mlp_forward_ws(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
+                                 float* out, float* dout, void* stream) {
+    int rc = check_batch(g, "rl_mlp_forward_ws");
+    if (rc) return rc;
+    if (!out || ((vec == nullptr) != (dout == nullptr)))
+        return set_error(RL_ERR_ARG, "rl_mlp_forward_ws: out is required; vec and dout come together");
+    PlaneArgs pl;
+    pl.out_mean = out;
+    pl.out_dmean = dout;
+    return dispatch_net(vec ? MODE_OUT_TAN : MODE_OUT, g, vec, workspace, workspace_bytes, nullptr, (hipStream_t)stream,
+                        nullptr, nullptr, &pl);
 }
 
 extern "C" int rl_mlp_backward(const rl_policy_batch* g, const float* cotangent, void* workspace, size_t workspace_bytes,

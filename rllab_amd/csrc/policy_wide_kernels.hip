@@ -43,7 +43,13 @@ constexpr int WW = 4;                  // wavefronts per workgroup = row tiles o
 constexpr int WNT = WW * WV;
 constexpr int BS = WIDE_BS;
 constexpr int MAXDA_LIMIT = WIDE_MAX_DA;      // the kernels are instantiated for up to 2 or up to 8 action dims (MD)
-enum { WMODE_LOSS = 0, WMODE_GRAD = 1, WMODE_FVP = 2, WMODE_VPG = 3 };
+// WMODE_OUT / WMODE_OUT_TAN / WMODE_BWD: the network as a plain function on planes (rl_mlp_forward / rl_mlp_backward, as in
+// policy_kernels.hip): forward (and tangent) values of the output, back-propagation of a given output cotangent -- what
+// a policy with a log-std NETWORK (gaussian_mlp_policy.py:60-98) composes with the Gaussian head kernels
+enum { WMODE_LOSS = 0, WMODE_GRAD = 1, WMODE_FVP = 2, WMODE_VPG = 3, WMODE_OUT = 4, WMODE_OUT_TAN = 5, WMODE_BWD = 6 };
+constexpr bool wmode_tan(int m) { return m == WMODE_FVP || m == WMODE_OUT_TAN; }          // tangent forward pass
+constexpr bool wmode_out(int m) { return m == WMODE_OUT || m == WMODE_OUT_TAN; }          // planes out, nothing else
+constexpr bool wmode_gradlike(int m) { return m == WMODE_GRAD || m == WMODE_FVP || m == WMODE_VPG || m == WMODE_BWD; }
 constexpr int WLOSS_COLS = 4;
 
 struct WideBatch {
@@ -61,6 +67,9 @@ struct WideBatch {
     float inv_count, log_min_std, kl_penalty;
     float* partial;            // [grid][P]
     double* partial_loss;      // [grid][4] or null
+    const float* cot;          // WMODE_BWD: [DA][B] cotangent on the network output (weights / normalisation included)
+    float* out_mean;           // WMODE_OUT / WMODE_OUT_TAN: [DA][B] network output
+    float* out_dmean;          // WMODE_OUT_TAN: [DA][B] tangent of the output in direction vec
     float* cache;              // hidden activations of every tile (rl_policy_batch.activations): the gradient pass writes
                                // them, the Fisher-vector products of the same point read them instead of re-running the
                                // forward chains; null = none.  Per tile 32 (H0 + H1 + H2) floats: [unit, layer after
@@ -100,25 +109,26 @@ __global__ void __launch_bounds__(256) wide_stage_kernel(WideShape s, const floa
 
 // ---- LDS plan ---------------------------------------------------------------------------------------------------
 struct WideLds {
-    int X, Hb[WIDE_MAX_L], Db[WIDE_MAX_L], tail, dtail, part, gmu, red, kred, total;
+    int X, Hb[WIDE_MAX_L], Db[WIDE_MAX_L], tail, dtail, part, part2, gmu, red, kred, total;
 };
 __host__ __device__ inline WideLds wide_lds(const WideShape& s, int mode) {
     WideLds p;
     int o = 0;
     p.X = o; o += 2 * s.KS[0] * BS;              // input slots (obs, the bias slot, zero slots up to the k-step count)
     for (int l = 0; l < WIDE_MAX_L; ++l) { p.Hb[l] = o; o += s.H[l] * BS; }
-    for (int l = 0; l < WIDE_MAX_L; ++l) { p.Db[l] = o; o += (mode != WMODE_LOSS) ? s.H[l] * BS : 0; }
+    for (int l = 0; l < WIDE_MAX_L; ++l) { p.Db[l] = o; o += (mode != WMODE_LOSS && mode != WMODE_OUT) ? s.H[l] * BS : 0; }
     o = (o + 3) & ~3;
     p.tail = o; o += s.tail;
-    p.dtail = o; o += (mode == WMODE_FVP) ? s.tail : 0;
+    p.dtail = o; o += wmode_tan(mode) ? s.tail : 0;
     p.part = o;                                   // per-wavefront partial dot products of the output layer [WW][DA][32]
     p.red = o;                                    // ... whose space serves the cross-thread folds at the end of the launch
     o += (WW * s.DA * 32 > 256 + 64) ? WW * s.DA * 32 : 256 + 64;
+    p.part2 = o; o += (mode == WMODE_OUT_TAN) ? WW * s.DA * 32 : 0;      // ... of the output's tangent next to the output
     p.gmu = o; o += s.DA * 32;                    // gmu[k][sample] for the thread-per-unit accumulation
     // partial accumulators of the k-split (layers with fewer than 4 row tiles): up to 3 x one fragment
     bool narrow = false;
     for (int l = 1; l < WIDE_MAX_L; ++l) narrow = narrow || (s.H[l] > 0 && s.HT[l] < 4);
-    for (int l = 0; l + 1 < WIDE_MAX_L; ++l) narrow = narrow || (s.H[l + 1] > 0 && s.HT[l] < 4 && mode != WMODE_LOSS);
+    for (int l = 0; l + 1 < WIDE_MAX_L; ++l) narrow = narrow || (s.H[l + 1] > 0 && s.HT[l] < 4 && wmode_gradlike(mode));
     p.kred = o; o += narrow ? 3 * 16 * 64 : 0;
     p.total = o;
     return p;
@@ -274,7 +284,8 @@ constexpr int wide_wps() {   // (independent of MD: the same register budget is 
 template <int L, int MODE, bool KSPLIT, int MT, int MD>
 __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_pass_kernel(WideBatch a) {
     constexpr int MAXDA = MD;
-    constexpr bool FVP = (MODE == WMODE_FVP), GRADLIKE = (MODE != WMODE_LOSS);
+    constexpr bool FVP = (MODE == WMODE_FVP), GRADLIKE = wmode_gradlike(MODE);
+    constexpr bool TAN = wmode_tan(MODE), OUTMODE = wmode_out(MODE), BWD = (MODE == WMODE_BWD);
     const WideShape& s = a.s;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WideLds p = wide_lds(s, MODE);
@@ -301,7 +312,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
         else if (k < s.tls) src = s.obo + (k - s.tbo);
         else src = (k - s.tls) < DA ? s.ols + (k - s.tls) : -1;
         tail[k] = src >= 0 ? a.theta[src] : 0.0f;
-        if (FVP) dtail[k] = src >= 0 ? a.vec[src] : 0.0f;
+        if (TAN) dtail[k] = src >= 0 ? a.vec[src] : 0.0f;
     }
     __syncthreads();
     if (tid < 32) X[DO * BS + tid] = 1.0f;                 // the bias slot of the input tile
@@ -354,7 +365,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
         J.chunk = s.KS[l] / J.ksp;
         J.k0 = J.q * J.chunk;
         J.im = a.img + s.oF[l] + (J.t * s.KS[l] + J.k0) * WV;
-        J.dim = FVP ? a.dimg + s.oF[l] + (J.t * s.KS[l] + J.k0) * WV : nullptr;
+        J.dim = TAN ? a.dimg + s.oF[l] + (J.t * s.KS[l] + J.k0) * WV : nullptr;
     }
     WidePre pre;
     pre.valid = false;
@@ -409,7 +420,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             const LayerJob& J = job[l];
             // the chain this wavefront runs next (for the operand prefetch): the tangent chains of this layer, else the
             // first chain of the next layer, else (last layer, gradient-like modes) nothing -- the head sits in between
-            const float* nxt_h = FVP ? J.dim : (l + 1 < L && job[l + 1].busy ? job[l + 1].im : nullptr);
+            const float* nxt_h = TAN ? J.dim : (l + 1 < L && job[l + 1].busy ? job[l + 1].im : nullptr);
             if (cache_rd) {
                 // (nothing: the activations of every layer are in their tiles since the staging of this tile)
             } else {
@@ -444,7 +455,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                     }
                 }
             }
-            if (FVP) {
+            if (TAN) {
                 f32x16 dacc;
                 if (J.busy) {
                     const float* nxt_d = (l + 1 < L && job[l + 1].busy) ? (cache_rd ? job[l + 1].dim : job[l + 1].im) : nullptr;
@@ -485,35 +496,58 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
 
         // ---- output layer: partial dot products over this wavefront's quarter of the last hidden layer -----------
         // lane (sample lj, half lh) covers units [q0, q0 + HL / 8) of the quarter, halves are folded by half_sum
-        {
+        // (FVP: the tangent of the output only; OUT_TAN: output and tangent; BWD: nothing -- the cotangent is given)
+        if (!BWD) {
             const int per = HL / 8, q0 = wave * (HL / 4) + lh * per;
             const float* hb = smem + p.Hb[L - 1];
             const float* db = smem + p.Db[L - 1];
-            float pm[MAXDA];
+            float pm[MAXDA], pd[MAXDA];
 #pragma unroll
-            for (int k = 0; k < MAXDA; ++k) pm[k] = 0.0f;
+            for (int k = 0; k < MAXDA; ++k) { pm[k] = 0.0f; pd[k] = 0.0f; }
             for (int u = q0; u < q0 + per; ++u) {
                 const float hv = hb[u * BS + lj];
-                const float dv = FVP ? db[u * BS + lj] : 0.0f;
+                const float dv = TAN ? db[u * BS + lj] : 0.0f;
 #pragma unroll
                 for (int k = 0; k < MAXDA; ++k)
                     if (k < DA) {
-                        if (FVP) {
-                            pm[k] = __builtin_fmaf(hv, dtail[s.tWo + u * DA + k], pm[k]);
-                            pm[k] = __builtin_fmaf(dv, tail[s.tWo + u * DA + k], pm[k]);
-                        } else {
-                            pm[k] = __builtin_fmaf(hv, tail[s.tWo + u * DA + k], pm[k]);
+                        if (TAN) {
+                            pd[k] = __builtin_fmaf(hv, dtail[s.tWo + u * DA + k], pd[k]);
+                            pd[k] = __builtin_fmaf(dv, tail[s.tWo + u * DA + k], pd[k]);
                         }
+                        if (!FVP) pm[k] = __builtin_fmaf(hv, tail[s.tWo + u * DA + k], pm[k]);
                     }
             }
 #pragma unroll
             for (int k = 0; k < MAXDA; ++k)
                 if (k < DA) {
-                    const float v = half_sum(pm[k]);
+                    const float v = half_sum(FVP ? pd[k] : pm[k]);
                     if (lh == 0) part[(wave * DA + k) * 32 + lj] = v;
+                    if (MODE == WMODE_OUT_TAN) {
+                        const float v2 = half_sum(pd[k]);
+                        if (lh == 0) smem[p.part2 + (wave * DA + k) * 32 + lj] = v2;
+                    }
                 }
         }
         __syncthreads();
+        if (OUTMODE) {
+            // the network as a function on planes: every sample's output (and tangent), nothing else
+            if (wave == 0 && lh == 0 && b < B) {
+#pragma unroll
+                for (int k = 0; k < MAXDA; ++k)
+                    if (k < DA) {
+                        a.out_mean[(size_t)k * B + b] =
+                            tail[s.tbo + k] + ((part[(0 * DA + k) * 32 + lj] + part[(1 * DA + k) * 32 + lj]) +
+                                               (part[(2 * DA + k) * 32 + lj] + part[(3 * DA + k) * 32 + lj]));
+                        if (MODE == WMODE_OUT_TAN) {
+                            const float* p2 = smem + p.part2;
+                            a.out_dmean[(size_t)k * B + b] =
+                                dtail[s.tbo + k] + ((p2[(0 * DA + k) * 32 + lj] + p2[(1 * DA + k) * 32 + lj]) +
+                                                    (p2[(2 * DA + k) * 32 + lj] + p2[(3 * DA + k) * 32 + lj]));
+                        }
+                    }
+            }
+            continue;                                       // (barrier at the loop head)
+        }
 
         // ---- per-sample cotangent on the mean (every wavefront, redundantly: lane = sample) ------------------------
         float gmu[MAXDA];
@@ -530,7 +564,11 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             inv_std[k] = __expf(-lstd[k]);
             var_[k] = __expf(2.0f * lstd[k]);
         }
-        if (!FVP) {
+        if (BWD) {
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k)
+                if (k < DA) gmu[k] = b < B ? a.cot[(size_t)k * B + bi] : 0.0f;
+        } else if (!FVP) {
             float mean[MAXDA];
 #pragma unroll
             for (int k = 0; k < MAXDA; ++k)
@@ -827,9 +865,12 @@ size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2
     return wide_workspace_bytes(s);
 }
 
+struct WidePlanes { const float* cot; float* out_mean; float* out_dmean; };
+
 template <int L, int MODE, bool KSPLIT, int MT, int MD>
 static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float* vec, void* workspace,
-                       size_t workspace_bytes, double* out, hipStream_t st, double* loss_out) {
+                       size_t workspace_bytes, double* out, hipStream_t st, double* loss_out,
+                       const WidePlanes* planes = nullptr) {
     if (workspace_bytes < wide_workspace_bytes(s))
         return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", workspace_bytes,
                          wide_workspace_bytes(s));
@@ -838,6 +879,9 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std; a.kl_penalty = g->kl_penalty;
+    a.cot = planes ? planes->cot : nullptr;
+    a.out_mean = planes ? planes->out_mean : nullptr;
+    a.out_dmean = planes ? planes->out_dmean : nullptr;
     a.cache = (MODE == WMODE_GRAD || MODE == WMODE_FVP) ? g->activations : nullptr;
     const int n_tiles = (a.B + 31) / 32;
     const WideLds p = wide_lds(s, MODE);
@@ -855,11 +899,11 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     float* img = (float*)((char*)workspace + rows + (size_t)WIDE_GRID * WLOSS_COLS * sizeof(double));
     float* dimg = img + s.img_all;
     a.img = img; a.dimg = dimg;
-    const int with_bwd = (MODE != WMODE_LOSS) ? 1 : 0;
+    const int with_bwd = wmode_gradlike(MODE) ? 1 : 0;
     const int n_img = with_bwd ? s.img_all : s.img_fwd;
     hipLaunchKernelGGL(wide_stage_kernel, dim3((n_img + 255) / 256 < 512 ? (n_img + 255) / 256 : 512), dim3(256), 0, st,
                        s, g->theta, img, with_bwd);
-    if (MODE == WMODE_FVP)
+    if (wmode_tan(MODE))
         hipLaunchKernelGGL(wide_stage_kernel, dim3((s.img_fwd + 255) / 256 < 512 ? (s.img_fwd + 255) / 256 : 512),
                            dim3(256), 0, st, s, vec, dimg, 0);
     int rc = check_launch("wide_stage_kernel");
@@ -875,6 +919,7 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WNT), lds, st, a);
     rc = check_launch("wide_pass_kernel");
     if (rc) return rc;
+    if (wmode_out(MODE)) return 0;                      // the planes are the result
     if (MODE == WMODE_LOSS) return launch_reduce_loss(a.partial_loss, grid, out, st);
     rc = launch_reduce_rows(a.partial, grid, s.P, out, st);
     if (rc) return rc;
@@ -884,8 +929,11 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
 
 template <int L, bool KSPLIT, int MT, int MD>
 static int wide_mode_md(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
-                        size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
+                        size_t ws_bytes, double* out, hipStream_t st, double* loss_out, const WidePlanes* pl) {
     switch (mode) {
+        case WMODE_OUT: return launch_wide<L, WMODE_OUT, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr, pl);
+        case WMODE_OUT_TAN: return launch_wide<L, WMODE_OUT_TAN, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr, pl);
+        case WMODE_BWD: return launch_wide<L, WMODE_BWD, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr, pl);
         case WMODE_LOSS: return launch_wide<L, WMODE_LOSS, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr);
         case WMODE_GRAD: return launch_wide<L, WMODE_GRAD, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, loss_out);
         case WMODE_FVP: return launch_wide<L, WMODE_FVP, KSPLIT, MT, MD>(s, g, vec, ws, ws_bytes, out, st, nullptr);
@@ -896,37 +944,39 @@ static int wide_mode_md(const WideShape& s, int mode, const rl_policy_batch* g, 
 
 template <int L, bool KSPLIT, int MT>
 static int wide_mode(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
-                     size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
-    return s.DA <= 2 ? wide_mode_md<L, KSPLIT, MT, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
-                     : wide_mode_md<L, KSPLIT, MT, 8>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
+                     size_t ws_bytes, double* out, hipStream_t st, double* loss_out, const WidePlanes* pl) {
+    return s.DA <= 2 ? wide_mode_md<L, KSPLIT, MT, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl)
+                     : wide_mode_md<L, KSPLIT, MT, 8>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl);
 }
 
 template <int L>
 static int wide_shape_class(const WideShape& s, int mode, const rl_policy_batch* g, const float* vec, void* ws,
-                            size_t ws_bytes, double* out, hipStream_t st, double* loss_out) {
+                            size_t ws_bytes, double* out, hipStream_t st, double* loss_out, const WidePlanes* pl) {
     bool ksplit = false;
     int mt = 1;
     for (int l = 0; l < s.L; ++l) {
         if (s.HT[l] < 4 && (l >= 1 || l + 1 < s.L)) ksplit = true;      // forward of layer l >= 1, backward INTO layer l
         if (l >= 1 && s.HT[l] > mt) mt = s.HT[l];
     }
-    if (mt <= 2) return ksplit ? wide_mode<L, true, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
-                               : wide_mode<L, false, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
-    return ksplit ? wide_mode<L, true, 4>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
-                  : wide_mode<L, false, 4>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
+    if (mt <= 2) return ksplit ? wide_mode<L, true, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl)
+                               : wide_mode<L, false, 2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl);
+    return ksplit ? wide_mode<L, true, 4>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl)
+                  : wide_mode<L, false, 4>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl);
 }
 
 // entry point for policy_kernels.hip's dispatcher: nets that the one-wavefront-per-tile kernels are not built for
 int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
-                  hipStream_t st, double* loss_out) {
+                  hipStream_t st, double* loss_out, const float* cot, float* out_mean, float* out_dmean) {
+    const WidePlanes planes = {cot, out_mean, out_dmean};
+    const WidePlanes* pl = &planes;
     WideShape s;
     if (g->activation != RL_ACT_TANH || !wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, s))
         return set_error(RL_ERR_UNSUPPORTED,
                          "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d,%d): two or three tanh layers "
                          "of 32 / 64 / 128 units, obs_dim <= %d, act_dim <= %d",
                          g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, WIDE_MAX_DO, WIDE_MAX_DA);
-    return s.L == 2 ? wide_shape_class<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out)
-                    : wide_shape_class<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out);
+    return s.L == 2 ? wide_shape_class<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl)
+                    : wide_shape_class<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl);
 }
 
 }  // namespace rl

@@ -11,8 +11,10 @@ diagonal-Gaussian head between them is ``rl_gaussian_head`` / ``rl_gaussian_fish
     F v        : forward-with-tangent x 2 -> Fisher head (diagonal in (mean, log_std) at old == new) -> backward x 2
 
 Everything else -- evaluation caching, the device CG, the line search writes, the sharded sums -- is inherited from
-``FusedGaussianMLPOps``; this class only replaces its three passes.  Both networks must be two equal tanh layers of
-32 or 64 units on one of the (obs_dim, action_dim) pairs the kernels are instantiated for.
+``FusedGaussianMLPOps``; this class only replaces its three passes.  Each network: two or three tanh layers of exactly
+32 / 64 / 128 units (two equal layers of 32 / 64 on a HIP-native (obs, action) pair run one wavefront per tile, every
+other shape the cooperative kernels of csrc/policy_wide_kernels.hip -- their modes OUT / OUT_TAN / BWD), obs_dim <= 30,
+action_dim <= 8.
 """
 import ctypes
 import math
@@ -46,7 +48,7 @@ class _IdentityLayout(object):
 
 def _net_ok(net, obs_dim, act_dim):
     hs = tuple(net.hidden_sizes)
-    return (len(hs) == 2 and hs[0] == hs[1] and hs[0] in (32, 64) and net.hidden_nonlinearity is tanh
+    return (len(hs) in (2, 3) and all(h in (32, 64, 128) for h in hs) and net.hidden_nonlinearity is tanh
             and net.output_nonlinearity is None and net.input_dim == obs_dim and net.output_dim == act_dim)
 
 
@@ -56,7 +58,8 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         if not getattr(policy, "state_dependent_std", False) or not policy.flat_params.is_cuda \
                 or policy.flat_params.dtype != torch.float32:
             return False
-        if (policy.obs_dim, policy.action_dim) not in FusedGaussianMLPOps.NARROW_PAIRS:
+        from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM
+        if policy.obs_dim > MAX_OBS_DIM or policy.action_dim > MAX_ACT_DIM:
             return False
         return _net_ok(policy._mean_network, policy.obs_dim, policy.action_dim) and \
             _net_ok(policy._std_network, policy.obs_dim, policy.action_dim)
@@ -68,10 +71,11 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         self.nets = []                                   # (offset, size, hidden) of [mean net, std net] in the flat vector
         for net in (policy._mean_network, policy._std_network):
             off = net.params[0].offset
-            self.nets.append((off, net.end_offset - off, net.hidden_sizes[0]))
+            hs = tuple(net.hidden_sizes)
+            self.nets.append((off, net.end_offset - off, hs + (0,) * (3 - len(hs))))
         assert self.nets[0][0] == 0 and self.nets[1][0] == self.nets[0][1]
         assert self.nets[1][0] + self.nets[1][1] == policy.flat_params.numel()
-        self.dims = (do, da, self.nets[0][2], self.nets[0][2], 0)
+        self.dims = (do, da) + self.nets[0][2]
         self.n_kernel = self.layout.P_pad
         self.wide_kernels = False                        # (the base __init__ is not run: every attribute it sets is set here)
         self._ws = None
@@ -104,7 +108,7 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
 
     def _workspace(self, device):
         if self._ws is None or self._ws.device != device:
-            n = max(_lib.lib.rl_policy_workspace_bytes(self.dims[0], self.dims[1], h, h, 0) for _, _, h in self.nets)
+            n = max(_lib.lib.rl_policy_workspace_bytes(self.dims[0], self.dims[1], h[0], h[1], h[2]) for _, _, h in self.nets)
             self._ws = torch.empty(n, dtype=torch.uint8, device=device)
             self._head_ws = torch.empty(_lib.lib.rl_gaussian_head_workspace_bytes(), dtype=torch.uint8, device=device)
         return self._ws
@@ -131,7 +135,7 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         structs = []
         for (_, _, h) in self.nets:
             structs.append(_lib.PolicyBatch(
-                n_samples=B, obs_dim=self.dims[0], act_dim=da, hidden0=h, hidden1=h, hidden2=0, inv_count=inv,
+                n_samples=B, obs_dim=self.dims[0], act_dim=da, hidden0=h[0], hidden1=h[1], hidden2=h[2], inv_count=inv,
                 log_min_std=log_min, theta=None, obs=obs.data_ptr(), actions=act.data_ptr(),
                 advantages=adv.data_ptr(), old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(),
                 weights=w.data_ptr()))
@@ -156,11 +160,12 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
     def _forward(self, b, tangents=None):
         """mean / lstd planes (and their tangents in direction ``tangents`` = two kernel-layout float32 vectors)."""
         p, st = b["planes"], _lib.stream_ptr()
+        ws = self._ws                                     # (the cooperative kernels keep their operand images there)
         for i, (name, dname) in enumerate((("mean", "dmean"), ("lstd", "dlstd"))):
             vec = None if tangents is None else _lib.ptr(tangents[i])
             dout = None if tangents is None else _lib.ptr(p[dname])
-            _lib.check(_lib.lib.rl_mlp_forward(ctypes.byref(b["structs"][i]), vec, _lib.ptr(p[name]), dout, st),
-                       "rl_mlp_forward")
+            _lib.check(_lib.lib.rl_mlp_forward_ws(ctypes.byref(b["structs"][i]), vec, _lib.ptr(ws), ws.numel(),
+                                                  _lib.ptr(p[name]), dout, st), "rl_mlp_forward_ws")
 
     def _head(self, b, inv, out4, vpg=False, penalty=0.0, with_cotangents=False):
         p, t = b["planes"], b["tensors"]

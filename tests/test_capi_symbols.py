@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.rl_abi_version() == 10
+    assert _lib.lib.rl_abi_version() == 11
 
 
 def test_env_query_and_errors():
@@ -121,7 +121,7 @@ def test_integration_md_bindings_match_the_library():
              "cfgp": ctypes.POINTER(_lib.EnvCfg), "pb": ctypes.POINTER(_lib.PolicyBatch),
              "ctypes.POINTER(RolloutArgs)": ctypes.POINTER(_lib.RolloutArgs),
              "ip": ctypes.POINTER(ctypes.c_int), "fp": ctypes.POINTER(ctypes.c_float),
-             "vpp": ctypes.POINTER(ctypes.c_void_p)}
+             "vpp": ctypes.POINTER(ctypes.c_void_p), "szp": ctypes.POINTER(ctypes.c_size_t)}
     found = re.findall(r"^\s*lib\.(rl_\w+)\.argtypes\s*= \[([^\]]*)\]", text, flags=re.M)
     assert len(found) >= 24
     for fn, args in found:

@@ -9,7 +9,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(4, 1, 32, 32), (13, 2, 32, 32), (13, 2, 64, 32), (20, 6, 32, 64)]    # (Do, Da, mean hidden, std hidden)
+# (Do, Da, mean hidden, std hidden); a number H = (H, H).  The last four run (partly) on the cooperative kernels'
+# OUT / OUT_TAN / BWD modes: wide and deep networks, and equal-width ones on an (obs, action) pair the one-wavefront-per-
+# tile kernels are not instantiated for
+SHAPES = [(4, 1, 32, 32), (13, 2, 32, 32), (13, 2, 64, 32), (20, 6, 32, 64),
+          (13, 2, (128, 64, 32), 32), (20, 6, (128, 128), (128, 64)), (17, 3, 64, 32), (11, 1, (64, 32), (32, 64, 32))]
 
 
 def _policy(do, da, hm, hs, min_std=1e-6, seed=0):
@@ -18,7 +22,9 @@ def _policy(do, da, hm, hs, min_std=1e-6, seed=0):
     from rllab_amd.spaces import Box
     np.random.seed(seed)
     spec = EnvSpec(Box(-np.ones(do), np.ones(do)), Box(-np.ones(da), np.ones(da)))
-    pol = GaussianMLPPolicy(spec, hidden_sizes=(hm, hm), adaptive_std=True, std_hidden_sizes=(hs, hs), min_std=min_std)
+    hm = (hm, hm) if isinstance(hm, int) else tuple(hm)
+    hs = (hs, hs) if isinstance(hs, int) else tuple(hs)
+    pol = GaussianMLPPolicy(spec, hidden_sizes=hm, adaptive_std=True, std_hidden_sizes=hs, min_std=min_std)
     theta = pol.get_param_values()
     theta += 0.1 * np.random.randn(theta.size)
     pol.set_param_values(theta)
@@ -235,3 +241,38 @@ def test_adaptive_std_is_sampled_by_the_fused_rollout(quiet_logger):
         assert 0.0 < float(tab["AveragePolicyStd"]) < 10.0
         logger.dump_tabular()
     assert np.mean(rets[-3:]) > 1.5 * np.mean(rets[:3]), rets
+
+
+def test_two_wide_networks_that_do_not_fit_lds_are_sampled_stepwise_and_updated_on_the_kernels(quiet_logger):
+    """GaussianMLPPolicy(adaptive_std=True) with a (128, 128) mean net and a (128, 128) log-std net on a 20-observation
+    env: the fused rollout would need 172 KB of LDS for the two networks' weight fragments (a CU has 160) -- the sampler asks
+    the library (rl_rollout_lds_bytes) and takes the per-transition loop instead of failing; the update still runs on the
+    kernels (both networks through the cooperative OUT / OUT_TAN / BWD modes)."""
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.mujoco.hopper_env import HopperEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(8)
+    env = normalize(HopperEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(128, 128), adaptive_std=True, std_hidden_sizes=(128, 128))
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=256 * 40,
+                max_path_length=40, n_itr=2, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    assert policy.rollout_networks() is not None                       # a kernel shape ...
+    assert not algo.sampler._takes_fused_rollout(policy)               # ... that does not fit the LDS of a CU on this env
+    assert type(algo.optimizer._fused).__name__ == "FusedAdaptiveStdOps"
+    theta0 = policy.get_param_values().copy()
+    for itr in range(2):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        assert float(tab["MeanKL"]) <= 0.0101 and np.isfinite(float(tab["LossAfter"]))
+        logger.dump_tabular()
+    assert np.abs(policy.get_param_values() - theta0).max() > 0
+    # and a pair of networks that does fit keeps the one-launch rollout
+    small = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(64, 64), adaptive_std=True, std_hidden_sizes=(32, 32))
+    assert algo.sampler.vec_env.takes_rollout_of(small)
