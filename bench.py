@@ -334,6 +334,13 @@ def main():
         first = ins[0] * ins[1]
         macs = (2 * pw - first) + (pw - first) + pw
         mfma_per_tile = macs * 32 / 2048.0             # one v_mfma_f32_32x32x2_f32 = 2048 multiply-adds
+    # ... and ONE convention for both families beside it: every multiply-add of the product on the REAL layer sizes, the
+    # output layer's three products and the input layer's outer product included (the 71-count above omits them)
+    ins_r = (do + 1,) + tuple(wl["hidden"])
+    pw_r = sum(ins_r[l] * ins_r[l + 1] for l in range(len(ins_r) - 1))
+    first_r = ins_r[0] * ins_r[1]
+    macs_real = (2 * pw_r - first_r) + (pw_r - first_r) + pw_r + 4 * ins_r[-1] * da
+    mfma_real_per_tile = macs_real * 32 / 2048.0
     fvp_ms = None
     fvp_variant = 0
     ops = policy.fused_ops() if wl["algo"] == "trpo" else None
@@ -463,6 +470,11 @@ def main():
                                    "accumulation: dropped terms <= 2^-23 |a b| worst case, 2^-28 mean (tests/test_split_arithmetic.py, test_gpu_fvp_split.py)",
                      "bf16_mfma_per_32_samples": bf16_mfma,
                      "bf16_pipe_frac": tiles * bf16_mfma * 32768 / (fvp_ms * 1e-3) / 2.5e15}
+        elif fvp_variant == 2:
+            kern = ("csplit_fvp_kernel (Fisher-vector product of a wide / deep net, cooperative tiling, "
+                    "v_mfma_f32_32x32x16_bf16 on three-way split f32 operands; parts images in LDS, transposing reads)")
+            extra = {"arithmetic": "f32 operands split hi + mid + lo (exact), six bf16 cross terms per product, f32 "
+                                   "accumulation (tests/test_split_arithmetic.py, test_gpu_csplit.py)"}
         else:
             kern = ("wide_pass_kernel<FVP>" if wide else "policy_pass_kernel<FVP>") + \
                 " (Fisher-vector product, v_mfma_f32_32x32x2_f32)"
@@ -472,12 +484,17 @@ def main():
                                      "frac": tf / 157.3, "avg_launch_ms": fvp_ms, "avg_public_call_ms": fvp_call_ms,
                                      "frac_public_call": tf * fvp_ms / fvp_call_ms / 157.3,
                                      "mfma_per_32_samples": mfma_per_tile,
+                                     "mfma_per_32_samples_real_macs": mfma_real_per_tile,
+                                     "frac_real_macs": tiles * mfma_real_per_tile * 4096 / (fvp_ms * 1e-3) / 1e12 / 157.3,
                                      "activations": "read from the gradient pass's cache" if cached else "recomputed",
                                      "note": "algorithmic f32 flops (mfma_per_32_samples x 4096 per tile) against the "
                                              "f32-input MFMA peak = the f32 vector peak (MI355X_MICROARCH.md); "
                                              "avg_launch_ms = product kernel + partial-row reduce kernel, the launches of "
                                              "one CG iteration (_fvp_into); avg_public_call_ms = rl-level fvp() with its "
-                                             "f64 <-> f32 conversion kernels, the quantity rounds 1-2 reported as frac"}, **extra)
+                                             "f64 <-> f32 conversion kernels, the quantity rounds 1-2 reported as frac; "
+                                             "frac_real_macs counts every multiply-add of the product on the real layer "
+                                             "sizes (output layer and input-layer outer product included) -- one "
+                                             "convention for the equal-width and the wide families"}, **extra)
     if os.environ.get("RLLAB_BENCH_HOSTTIMES") and rank == 0:
         names = ["events", "obtain_samples (enqueue)", "process_samples (incl. its wait)", "optimize_policy (incl. waits)",
                  "dump_tabular", "loop overhead to next iteration"]
