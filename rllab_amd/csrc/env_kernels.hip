@@ -551,6 +551,210 @@ struct RolloutPolicyWide {
     }
 };
 
+// The same wide / deep mean network for the lane-group Swimmer, evaluated by FOUR wavefronts per group of 16 envs
+// (rollout_swimmer_quad_coop_kernel).  A lone wavefront pays for every instruction it issues, so the 284 matrix
+// instructions of a (13 -> 128 -> 128) forward pass on 32-column tiles -- half of them idle: the group holds 16 envs --
+// cost more than the 50 physics sub-steps.  Here the workgroup is the group's four replicas-in-time: every wavefront
+// carries the same 16 envs through the same instruction stream (physics, noise, resets: identical values, wavefront 0
+// stores), and the network is split by OUTPUT UNITS: a layer of H units is H / 16 blocks of v_mfma_f32_16x16x4_f32
+// (16 units x 16 envs x 4 inputs), wavefront w takes blocks w, w + 4; activations cross the wavefronts through LDS
+// ([k / 16][env, k % 4][(k / 4) % 4]: a lane's operands of four k-steps are one 16-byte read), one barrier per layer.
+// The output layer is split by inputs instead (each wavefront contracts a quarter of the last hidden layer), the partial
+// means meet in LDS.  Two accumulators per block (even / odd k-steps), so dependent matrix instructions never queue.
+// Per env-step and wavefront: (13 -> 128 -> 128 -> 2) 8 + 64 + 8 matrix instructions instead of 284 of twice the length.
+constexpr int COOP_WAVES = 4;
+
+template <class Env>
+struct RolloutPolicyCoop {
+    static constexpr int DO = Env::OBS, DA = Env::ACT;
+    static constexpr int K0 = (DO + 3) & ~3;               // layer-0 inputs, padded to whole k-steps (b0 initialises the accumulator)
+    static_assert(K0 == 16 || K0 == 32, "whole groups of four k-steps");
+    WideShape s;
+    float* wf[WIDE_MAX_L];      // layer l: [block][k-step group][lane][k-step % 4] = W_l[4 m + lane / 16][16 block + lane % 16]
+    float* wo;                  // output layer: [k-step group][lane][k-step % 4] = Wo[4 m + lane / 16][lane % 16] (zero beyond DA)
+    float* bias[WIDE_MAX_L];    // b_l
+    float* tailo;               // bo [DA], log_std [DA]
+    float* act[2];              // activations (ping-pong)
+    float* part;                // partial means [action][env][wavefront]
+    int wave;
+
+    static size_t lds_floats(const WideShape& s) {
+        size_t n = (size_t)K0 * s.H[0];
+        int hmax = s.H[0];
+        for (int l = 1; l < s.L; ++l) {
+            n += (size_t)s.H[l - 1] * s.H[l];
+            if (s.H[l] > hmax) hmax = s.H[l];
+        }
+        n += (size_t)16 * s.H[s.L - 1];                    // wo
+        for (int l = 0; l < s.L; ++l) n += s.H[l];         // biases
+        n += 4 * ((2 * DA + 3) / 4);
+        n += 2 * (size_t)16 * hmax;                        // act
+        n += (size_t)DA * 16 * COOP_WAVES;                 // part
+        return n;
+    }
+
+    __device__ __forceinline__ void init(float* smem, const float* __restrict__ th, const WideShape& shape) {
+        s = shape;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nt = blockDim.x;
+        float* o = smem;
+        int hmax = s.H[0];
+#pragma unroll
+        for (int l = 0; l < WIDE_MAX_L; ++l) {
+            const int K = l == 0 ? K0 : s.H[l > 0 ? l - 1 : 0];
+            wf[l] = o;
+            o += (l < s.L) ? K * s.H[l] : 0;
+            if (l < s.L && s.H[l] > hmax) hmax = s.H[l];
+        }
+        const int HL = s.L == 3 ? s.H[2] : s.H[1];
+        wo = o; o += 16 * HL;
+#pragma unroll
+        for (int l = 0; l < WIDE_MAX_L; ++l) { bias[l] = o; o += (l < s.L) ? s.H[l] : 0; }
+        tailo = o; o += 4 * ((2 * DA + 3) / 4);
+        act[0] = o; o += 16 * hmax;
+        act[1] = o; o += 16 * hmax;
+        part = o;
+#pragma unroll
+        for (int l = 0; l < WIDE_MAX_L; ++l)
+            if (l < s.L) {
+                const int K = l == 0 ? K0 : s.H[l > 0 ? l - 1 : 0], G = K / 16, H = s.H[l];
+                for (int e = threadIdx.x; e < K * H; e += nt) {
+                    const int j = e & 3, ln = (e >> 2) & 63, mg = (e >> 8) % G, b = (e >> 8) / G;
+                    const int k = 4 * (4 * mg + j) + (ln >> 4), i = 16 * b + (ln & 15);
+                    wf[l][e] = (l > 0 || k < DO) ? th[s.oW[l] + k * H + i] : 0.0f;
+                }
+                for (int e = threadIdx.x; e < H; e += nt) bias[l][e] = th[s.ob[l] + e];
+            }
+        for (int e = threadIdx.x; e < 16 * HL; e += nt) {
+            const int j = e & 3, ln = (e >> 2) & 63, mg = e >> 8, k = 4 * (4 * mg + j) + (ln >> 4), a = ln & 15;
+            wo[e] = a < DA ? th[s.oWo + k * DA + a] : 0.0f;
+        }
+        for (int e = threadIdx.x; e < 2 * DA; e += nt) tailo[e] = e < DA ? th[s.obo + e] : th[s.ols + (e - DA)];
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ float log_std(int k) const { return tailo[DA + k]; }
+
+    // one layer's blocks of this wavefront: NBW = 1 or 2 (blocks wave, wave + 4); B operands: xg[g] = the lane's four
+    // k-steps of group g (registers: layer 0) or read from `src`
+    template <int NBW, bool FROM_REGS>
+    __device__ __forceinline__ void blocks(const float* wfl, const float* bl, int G, const f32x4* xg, const float* src,
+                                           float* dst) const {
+        const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+        const int lp = n * 4 + q;                               // the lane's slot inside an activation group
+        f32x4 acc[NBW][2];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            acc[j][0] = *reinterpret_cast<const f32x4*>(bl + 16 * (wave + COOP_WAVES * j) + 4 * q);
+            acc[j][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wfl) + lane;
+        const f32x4* sv = reinterpret_cast<const f32x4*>(src) + lp;
+        const int groups = FROM_REGS ? K0 / 16 : G;            // (a constant for the register operands: xg stays in registers)
+        // the operands of group g + 1 are read while the products of group g run (the last group reads itself again)
+        f32x4 bv, av[NBW];
+        if constexpr (FROM_REGS) bv = xg[0];
+        else bv = sv[0];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) av[j] = wv[(wave + COOP_WAVES * j) * G * 64];
+        for (int g = 0; g < groups; ++g) {
+            const int gn = g + 1 < groups ? g + 1 : g;
+            f32x4 bn, an[NBW];
+            if constexpr (FROM_REGS) bn = xg[K0 / 16 > 1 ? 1 : 0];
+            else bn = sv[gn * 64];
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) an[j] = wv[((wave + COOP_WAVES * j) * G + gn) * 64];
+            __builtin_amdgcn_sched_barrier(0);                  // (the reads stay in front of the products)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                acc[j][0] = mfma16(av[j][0], bv[0], acc[j][0]);
+                acc[j][1] = mfma16(av[j][1], bv[1], acc[j][1]);
+                acc[j][0] = mfma16(av[j][2], bv[2], acc[j][0]);
+                acc[j][1] = mfma16(av[j][3], bv[3], acc[j][1]);
+            }
+            bv = bn;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) av[j] = an[j];
+        }
+        // unit 16 b + 4 q + r of env n -> k-step m' = 4 b + q (group b, sub-step q), slot (n, r)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int b = wave + COOP_WAVES * j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[b * 256 + (n * 4 + r) * 4 + q] = ftanh(acc[j][0][r] + acc[j][1][r]);
+        }
+    }
+    template <bool FROM_REGS>
+    __device__ __forceinline__ void layer(int l, int K, const f32x4* xg, const float* src, float* dst) const {
+        const int nb = s.H[l] / 16;                            // 2, 4 or 8 blocks
+        if (wave + COOP_WAVES < nb) blocks<2, FROM_REGS>(wf[l], bias[l], K / 16, xg, src, dst);
+        else if (wave < nb) blocks<1, FROM_REGS>(wf[l], bias[l], K / 16, xg, src, dst);
+        __syncthreads();
+    }
+
+    // o: the observation of this lane's env (identical on its four replicas and on the four wavefronts); mean: its action
+    // mean, on all of them
+    __device__ __forceinline__ void forward16(const float* o, float* mean) const {
+        const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+        f32x4 xg[K0 / 16];
+#pragma unroll
+        for (int g = 0; g < K0 / 16; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = 4 * (4 * g + j);                  // k = d + q
+                const float c0 = d < DO ? o[d < DO ? d : 0] : 0.0f, c1 = d + 1 < DO ? o[d + 1 < DO ? d + 1 : 0] : 0.0f;
+                const float c2 = d + 2 < DO ? o[d + 2 < DO ? d + 2 : 0] : 0.0f, c3 = d + 3 < DO ? o[d + 3 < DO ? d + 3 : 0] : 0.0f;
+                xg[g][j] = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
+            }
+        layer<true>(0, K0, xg, nullptr, act[0]);
+        layer<false>(1, s.H[0], nullptr, act[0], act[1]);
+        const float* last = act[1];
+        int HL = s.H[1];
+        if (s.L == 3) {
+            layer<false>(2, s.H[1], nullptr, act[1], act[0]);
+            last = act[0];
+            HL = s.H[2];
+        }
+        // output layer: this wavefront's quarter of the k-steps (all operand reads in front of the products)
+        {
+            const int per = HL / 16;                            // k-steps per wavefront: 2, 4 or 8
+            const f32x4* wov = reinterpret_cast<const f32x4*>(wo) + lane;
+            const f32x4* lv = reinterpret_cast<const f32x4*>(last) + (n * 4 + q);
+            f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (per >= 4) {
+                const int g0 = wave * (per / 4), g1 = per == 8 ? g0 + 1 : g0;
+                const f32x4 a0 = wov[g0 * 64], b0 = lv[g0 * 64], a1 = wov[g1 * 64], b1 = lv[g1 * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = mfma16(a0[0], b0[0], acc0);
+                acc1 = mfma16(a0[1], b0[1], acc1);
+                acc0 = mfma16(a0[2], b0[2], acc0);
+                acc1 = mfma16(a0[3], b0[3], acc1);
+                if (per == 8) {
+                    acc0 = mfma16(a1[0], b1[0], acc0);
+                    acc1 = mfma16(a1[1], b1[1], acc1);
+                    acc0 = mfma16(a1[2], b1[2], acc0);
+                    acc1 = mfma16(a1[3], b1[3], acc1);
+                }
+            } else {                                            // half a group: k-steps 2 wave, 2 wave + 1
+                const int g0 = wave >> 1;
+                const bool hi = (wave & 1) != 0;
+                const f32x4 a0 = wov[g0 * 64], b0 = lv[g0 * 64];
+                acc0 = mfma16(hi ? a0[2] : a0[0], hi ? b0[2] : b0[0], acc0);
+                acc1 = mfma16(hi ? a0[3] : a0[1], hi ? b0[3] : b0[1], acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < DA) part[((4 * q + r) * 16 + n) * COOP_WAVES + wave] = acc0[r] + acc1[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(part + (k * 16 + n) * COOP_WAVES);
+            mean[k] = tailo[k] + ((p[0] + p[1]) + (p[2] + p[3]));
+        }
+    }
+};
+
 struct RolloutDev {
     int n, T, max_path_length, normalize, reset_at_start, env_offset;
     float scale_reward, log_min_std;
@@ -791,17 +995,18 @@ __device__ __forceinline__ float prefix3(const DppQuad& x, float v, int b) {
 
 constexpr int QUAD_ENVS = 16;   // envs per wavefront
 
-template <class Pol>
+// COOP: the workgroup's wavefronts all carry the SAME group of envs (RolloutPolicyCoop); wavefront 0 stores
+template <class Pol, bool COOP = false>
 __device__ __forceinline__ void swimmer_quad_body(const RolloutDev& a, const Pol& pol) {
     using Env = Swimmer;
     using Chain = Env::Chain;
 
     const int n = a.n, T = a.T;
     const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave_global = COOP ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int el = lane & (QUAD_ENVS - 1);            // env slot of this lane in the env-per-lane phases
     const int i_raw = wave_global * QUAD_ENVS + el;
-    const bool live = (i_raw < n) && (lane < QUAD_ENVS);   // one of the four copies stores
+    const bool live = (i_raw < n) && (lane < QUAD_ENVS) && (!COOP || threadIdx.x < 64);   // one of the copies stores
     const int i = (i_raw < n) ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
     const size_t plane = (size_t)T * n;
@@ -993,6 +1198,14 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_wide_kernel(Rol
     RolloutPolicyWide<Swimmer> pol;
     pol.init(wide_smem, a.theta, shape);
     swimmer_quad_body(a, pol);
+}
+
+// ... with the network split over the four wavefronts of a workgroup (RolloutPolicyCoop)
+__global__ void __launch_bounds__(64 * COOP_WAVES) rollout_swimmer_quad_coop_kernel(RolloutDev a, WideShape shape) {
+    extern __shared__ __attribute__((aligned(16))) float wide_smem[];
+    RolloutPolicyCoop<Swimmer> pol;
+    pol.init(wide_smem, a.theta, shape);
+    swimmer_quad_body<RolloutPolicyCoop<Swimmer>, true>(a, pol);
 }
 
 // ---------------------------------------------------------------------------
@@ -1251,6 +1464,41 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {          //
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
+// Sums over the 64 lanes of N independent values at once, each left wave-uniform: four rotations inside the rows of 16
+// (every lane of a row then holds the row's sum), then the row sums travel up (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3) and lane 63 is read -- seven issue slots per value with the lane move fused into the
+// add, no LDS.  The values advance in lock step, so a result is never the next instruction's DPP operand (two wait
+// states); with fewer than three values the asm blocks carry the wait themselves (the hazard recogniser does not look
+// inside them).
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ void wave_totals_uniform(float* v) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = dpp_ror_add<0x128>(v[k]);      // row_ror:8
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = dpp_ror_add<0x124>(v[k]);      // row_ror:4
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = dpp_ror_add<0x122>(v[k]);      // row_ror:2
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = dpp_ror_add<0x121>(v[k]);      // row_ror:1
+    // rows outside the row mask keep their value: the fused form of  v + (row enabled ? moved : 0)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (N < 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v[k]));
+        else asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (N < 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v[k]));
+        else asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = lane_bcast(v[k], 63);
+}
+
 template <class Env, int H>
 struct RolloutPolicyLane {
     using N = Net<Env::OBS, Env::ACT, H>;
@@ -1258,7 +1506,7 @@ struct RolloutPolicyLane {
     static constexpr int DOP = (DO + 1) & ~1;
     float w0[DOP], b0;         // column u of W0 (u = lane % H), b0[u]
     float w1[H], b1;           // column u of W1, b1[u]
-    float w2[H], b2;           // column a of W2 (a = min(lane, DA - 1)), b2[a]
+    float w2[DA], b2;          // row u of W2 (zero on the lanes that repeat a unit: H < 64), b2[a] (a = min(lane, DA - 1))
     float lstd;                // log_std[a]
     float* hbuf;               // LDS: H floats of this wavefront
 
@@ -1269,25 +1517,30 @@ struct RolloutPolicyLane {
         for (int k = 0; k < DOP; ++k) w0[k] = k < DO ? th[N::W0 + k * H + u] : 0.0f;
         b0 = th[N::B0 + u];
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            w1[k] = th[N::W1 + k * H + u];
-            w2[k] = th[N::W2 + k * DA + a];
-        }
+        for (int k = 0; k < H; ++k) w1[k] = th[N::W1 + k * H + u];
+#pragma unroll
+        for (int k = 0; k < DA; ++k) w2[k] = lane < H ? th[N::W2 + u * DA + k] : 0.0f;
         b1 = th[N::B1 + u];
         b2 = th[N::B2 + a];
         lstd = th[N::LSTD + a];
     }
     // sum_k w[k] v[k] with v read back from the wavefront's LDS row (every lane the same addresses: broadcast reads),
-    // two products per packed instruction
+    // two products per packed instruction.  All reads are issued before the first product waits for one (the wavefront
+    // is alone on its SIMD: a read issued behind a product would expose a full LDS round trip each).
     __device__ __forceinline__ float dot_row(const float* w) const {
-        rl_f32x2 acc = {0.0f, 0.0f};
         const rl_f32x4* hv = reinterpret_cast<const rl_f32x4*>(hbuf);
+        rl_f32x4 v[H / 4];
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) v[q] = hv[q];
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) asm volatile("" : "+v"(v[q]));
+        rl_f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
-            const rl_f32x4 v = hv[q];
-            acc = __builtin_elementwise_fma((rl_f32x2){w[4 * q], w[4 * q + 1]}, (rl_f32x2){v[0], v[1]}, acc);
-            acc = __builtin_elementwise_fma((rl_f32x2){w[4 * q + 2], w[4 * q + 3]}, (rl_f32x2){v[2], v[3]}, acc);
+            acc0 = __builtin_elementwise_fma((rl_f32x2){w[4 * q], w[4 * q + 1]}, (rl_f32x2){v[q][0], v[q][1]}, acc0);
+            acc1 = __builtin_elementwise_fma((rl_f32x2){w[4 * q + 2], w[4 * q + 3]}, (rl_f32x2){v[q][2], v[q][3]}, acc1);
         }
+        const rl_f32x2 acc = acc0 + acc1;
         return acc[0] + acc[1];
     }
     // o: the env's observation (the same on every lane); returns mean[a] on lane a < DA
@@ -1301,14 +1554,47 @@ struct RolloutPolicyLane {
         if (lane < H) hbuf[lane] = h0;
         wave_sync();
         const float h1 = ftanh(b1 + dot_row(w1));
-        wave_sync();                                  // (the reads of h0 are issued; LDS runs a wavefront's operations in order)
-        if (lane < H) hbuf[lane] = h1;
-        wave_sync();
-        const float m = b2 + dot_row(w2);
-        wave_sync();
-        return m;
+        wave_sync();                                  // (the reads of h0 are done before the next step's write)
+        // output layer: unit u's contribution to every action from its own lane, summed over the lanes
+        float p[DA];
+#pragma unroll
+        for (int k = 0; k < DA; ++k) p[k] = h1 * w2[k];
+        wave_totals_uniform<DA>(p);
+        float m = p[0];
+#pragma unroll
+        for (int k = 1; k < DA; ++k) m = (lane == k) ? p[k] : m;
+        return b2 + m;
     }
 };
+
+// lane k <- v[k] (k < N; every v[k] wave-uniform): a binary select tree over the bits of the lane number -- five masks
+// for any N <= 32, where a chain of N selects keeps N masks alive (they spill out of the scalar file)
+template <int N>
+__device__ __forceinline__ float lane_pick(const float* v, int lane) {
+    static_assert(N <= 32, "five lane bits");
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0, b4 = (lane & 16) != 0;
+    // (both candidates of a select are read into values first: "bit ? a[1] : a[0]" would come back as ONE load at a
+    //  per-lane index and send the whole array to scratch memory)
+    const float* t = v;
+    // level L entry j stands for the entries j 2^(L+1) .. of v; an upper half that starts past N is never a lane's pick
+    float l0[16], l1[8], l2[4], l3[2];
+#define RL_PICK_LEVEL(OUT, IN, CNT, BIT, SPAN)                                                      \
+    static_for<0, CNT>([&](auto J) {                                                              \
+        constexpr int j = decltype(J)::value;                                                     \
+        if constexpr ((2 * j + 1) * SPAN < N) {                                                   \
+            const float lo_ = IN[2 * j], hi_ = IN[2 * j + 1];      /* both read before the select */ \
+            OUT[j] = BIT ? hi_ : lo_;                                                             \
+        } else if constexpr (2 * j * SPAN < N) OUT[j] = IN[2 * j];                                \
+        else OUT[j] = 0.0f;                                                                       \
+    });
+    RL_PICK_LEVEL(l0, t, 16, b0, 1)
+    RL_PICK_LEVEL(l1, l0, 8, b1, 2)
+    RL_PICK_LEVEL(l2, l1, 4, b2, 4)
+    RL_PICK_LEVEL(l3, l2, 2, b3, 8)
+#undef RL_PICK_LEVEL
+    if constexpr (16 < N) return b4 ? l3[1] : l3[0];
+    else return l3[0];
+}
 
 template <class Env, int H>
 __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutDev a) {
@@ -1361,12 +1647,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
 
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * n;
-        {   // observation row k from lane k
-            float ov = o[0];
-#pragma unroll
-            for (int k = 1; k < Env::OBS; ++k) ov = (lane == k) ? o[k] : ov;
-            if (obs_lane) *at(a.obs, row, vo_obs) = ov;
-        }
+        if (obs_lane) *at(a.obs, row, vo_obs) = lane_pick<Env::OBS>(o, lane);   // observation row k from lane k
         const float mean_l = pol.forward(o);
         float zs[Env::ACT];
         if (a.eps) {
@@ -1675,6 +1956,22 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         if (!lane_kernel && small_offsets && getenv("RLLAB_ROLLOUT_EPW") == nullptr &&
             wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
             const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS;
+            // four wavefronts per group while every one of them still finds a SIMD of its own (RLLAB_SWIMMER_COOP = 1 / 0
+            // forces / forbids the shape: A/B timing, and the tests that compare shapes)
+            const char* cp = getenv("RLLAB_SWIMMER_COOP");
+            const size_t coop_lds = RolloutPolicyCoop<Env>::lds_floats(shape) * sizeof(float);
+            if ((cp ? cp[0] == '1' : waves * COOP_WAVES <= 1024) && coop_lds <= LDS_LIMIT) {
+                auto kern = rollout_swimmer_quad_coop_kernel;
+                static bool cattr = false;
+                if (!cattr) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    cattr = true;
+                }
+                hipLaunchKernelGGL(kern, dim3(waves), dim3(64 * COOP_WAVES), coop_lds, st, a, shape);
+                return check_launch("rollout_swimmer_quad_coop_kernel");
+            }
             const int wpb = fit_wpb(lane_group_wpb(waves), [&](int threads) {
                 return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
             dim3 qgrid((waves + (wpb ? wpb : 1) - 1) / (wpb ? wpb : 1)), qblock(64 * (wpb ? wpb : 1));

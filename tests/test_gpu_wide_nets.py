@@ -204,6 +204,50 @@ def test_fused_rollout_of_a_wide_policy(kind, hidden, epw, monkeypatch):
     assert float((traj.actions.reshape(q["act_dim"], -1).double() - act64).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("hidden", [(128, 128), (100, 50, 25), (64, 32), (32, 64, 128), (128, 128, 128)])
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_swimmer_rollout_with_the_network_split_over_four_wavefronts(hidden, coop, monkeypatch):
+    """rollout_swimmer_quad_coop_kernel (four wavefronts per group of 16 envs, the layers split by output units on
+    16 x 16 x 4 matrix tiles, activations through LDS) against the one-wavefront-per-group kernel it replaces for small
+    launches (RLLAB_SWIMMER_COOP=0): the same trajectories up to the rounding of the means (so: every recorded
+    transition replays on the host bit for bit from ITS recorded action, means within 2e-5 of float64), every layer
+    width in every position, and the (128, 128, 128) net whose weights do not fit the cooperative layout's LDS and
+    falls back."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from oracle.replay import replay_check
+    from tests.test_gpu_env_parity import _make_policy
+    monkeypatch.delenv("RLLAB_ROLLOUT_EPW", raising=False)
+    monkeypatch.setenv("RLLAB_SWIMMER_COOP", coop)
+    rng = np.random.RandomState(3)
+    n, T, mpl = 70, 60, 23                       # 4 full groups + one of 6 envs; resets inside the launch
+    policy = _make_policy(2, hidden)
+    v = HipVecEnv(2, n, mpl, normalize=True, seed=5)
+    q = v.q
+    eps = rng.randn(q["act_dim"], T, n).astype(np.float32)
+    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    traj = v.rollout(policy, T, reset_at_start=True, eps=eps, reset_draws=draws)
+    torch.cuda.synchronize()
+    assert replay_check(v, traj, max_envs=n, reset_draws=draws) == n * T
+    obs64 = traj.obs.reshape(q["obs_dim"], -1).double()
+    with torch.no_grad():
+        mean64 = policy.mean_planes(obs64, policy.flat_params.double())
+    got = traj.means.reshape(q["act_dim"], -1).double()
+    assert float((got - mean64).abs().max()) <= 2e-5
+    if coop == "1":
+        # Philox noise and resets inside the kernel: the same streams in both shapes -- the first transition (before
+        # the means' rounding can steer the trajectories apart) agrees: same reset state, same policy noise
+        a = HipVecEnv(2, n, mpl, normalize=True, seed=5).rollout(policy, T, reset_at_start=True)
+        monkeypatch.setenv("RLLAB_SWIMMER_COOP", "0")
+        v2 = HipVecEnv(2, n, mpl, normalize=True, seed=5)
+        b = v2.rollout(policy, T, reset_at_start=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs[:, 0], b.obs[:, 0])
+        za, zb = (a.actions - a.means)[:, 0], (b.actions - b.means)[:, 0]
+        assert float((za - zb).abs().max()) <= 1e-6 and float(za.abs().max()) > 0.1
+        assert float((a.means[:, 0] - b.means[:, 0]).abs().max()) <= 4e-5
+        assert bool(torch.isfinite(a.actions).all()) and bool(torch.isfinite(a.rewards).all())
+
+
 @pytest.mark.parametrize("hidden", [(100, 50, 25), (128, 128)])
 def test_trpo_on_the_kernels_with_the_reference_experiment_net(hidden, quiet_logger):
     """TRPO on the Swimmer with the (100, 50, 25) / (128, 128) policy: fused rollout, fused update, device CG."""
