@@ -65,6 +65,15 @@ ENVS = {  # name -> (module, class, rl_env_kind)
 }
 
 
+def _coop_lds_bytes(do, da, hidden):
+    """LDS of RolloutPolicyCoop (csrc/env_kernels.hip, lds_floats) for a net on the kernels' padded widths."""
+    pad = [32 if h <= 32 else 64 if h <= 64 else 128 for h in hidden]
+    k0 = (do + 3) & ~3
+    n = k0 * pad[0] + sum(a * b for a, b in zip(pad[:-1], pad[1:])) + 16 * pad[-1] + sum(pad)
+    n += 4 * ((2 * da + 3) // 4) + 2 * 16 * max(pad) + da * 16 * 4
+    return 4 * n
+
+
 def step_kernel_roofline(torch, kind, n=1 << 22, steps=20, warmup=3):
     from rllab_amd import _lib
     from rllab_amd.envs.hip_env import HipVecEnv
@@ -393,7 +402,17 @@ def main():
     envs_per_wave = 1 if env_per_wave else 16 if lane_group else (int(forced_epw) if forced_epw in ("16", "64") else
                                                                   (16 if n_envs <= 16 * 1024 else 64))
     n_waves = (n_envs + envs_per_wave - 1) // envs_per_wave
-    if env_per_wave:
+    # ... and, for the Swimmer under a wide / deep net, four wavefronts per group of 16 envs (the network split by output
+    # units) while that is at most 1024 wavefronts and the weights fit the layout's LDS (csrc/env_kernels.hip)
+    cp = os.environ.get("RLLAB_SWIMMER_COOP")
+    coop = lane_group and wide and wl["env"] == "swimmer" and (cp[:1] == "1" if cp else n_waves * 4 <= 1024) and \
+        _coop_lds_bytes(13, 2, wl["hidden"]) <= 160 * 1024
+    if coop:
+        n_waves *= 4
+        rollout_name = ("rollout_swimmer_quad_coop_kernel (fused wide / deep policy + env step + record; FOUR wavefronts per "
+                        "group of 16 envs: the layers split by output units on 16 x 16 x 4 matrix tiles, activations "
+                        "through LDS; four lanes per env in the physics sub-steps)")
+    elif env_per_wave:
         rollout_name = ("rollout_two_leg_wave_kernel (fused policy + env step + record; ONE env per wavefront: the policy's "
                         "units on the lanes, one leg per lane in the physics sub-steps, the trajectory stored lane-distributed)")
     elif lane_group:

@@ -12,7 +12,11 @@ bash tools/exp/r04_final_bench.sh
 for h in "100,50,25" "128,128"; do
   tag=$(echo $h | tr ',' '_')
   python bench.py --hidden $h --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r04_bench_swimmer4096_hidden_$tag.json
+  # A/B: the one-wavefront-per-group rollout the four-wavefront shape replaces; the f32-matrix-instruction products
+  env RLLAB_SWIMMER_COOP=0 python bench.py --hidden $h --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r04_bench_swimmer4096_hidden_${tag}_one_wavefront_rollout.json
+  env RLLAB_FVP_SPLIT=0 python bench.py --hidden $h --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r04_bench_swimmer4096_hidden_${tag}_f32_products.json
 done
+env RLLAB_TWO_LEG_WAVE_KERNEL=0 python bench.py --workload cheetah1024_trpo_gae --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r04_bench_cheetah1024_trpo_gae_16_envs_per_wavefront.json
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r04_bench_swimmer4096_hidden_*.json")):
