@@ -188,15 +188,21 @@ struct TwoLegs {
     RL_HD static V dot3(V a0, V a1, V a2, V b0, V b1, V b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
 
     // one capsule-end sphere of local body b against the floor P1 = 0 (the penalty model of dyn_cheetah.h /
-    // dyn_legged.h); a component (leg) that does not penetrate adds zeros
+    // dyn_legged.h), in two steps: where it is (sphere_pose), what it pushes with (sphere_force).  A component (leg)
+    // that does not penetrate adds exact (+)zeros to sums that are never -0, so WHETHER sphere_force runs for a sphere
+    // above the floor changes no bit: the sub-step tests the spheres of a body together and skips the body's force
+    // block when none of them touches -- one branch per body instead of one per sphere.  A branch on a vector compare
+    // costs a lone wavefront ~60 cycles when taken (tools/ubench/branch_cost.hip); ten of them per sub-step were a sixth
+    // of the one-env-per-wavefront rollout (profiles/r04_notes.md).  Here the compares also sit far ahead of the branches.
     template <typename R, typename V>
-    RL_HD static void sphere(V lx, V ly, V rad, V mu, V csb, V snb, V axb, V ayb, V pxb, V pyb, V vaxb, V vayb, V omb,
-                             V root_p1, V& fx, V& fy, V& tz) {
-        const V rx = csb * lx - snb * ly;           // sphere centre relative to the body anchor
-        const V ry = snb * lx + csb * ly;
-        const V depth = rad - ((root_p1 + axb) + rx);
-        // spheres above the floor contribute exact (+)zeros to sums that are never -0: skipping them changes no bit
-        if (!rl_any_pos(depth)) return;
+    RL_HD static void sphere_pose(V lx, V ly, V rad, V csb, V snb, V axb, V root_p1, V& rx, V& ry, V& depth) {
+        rx = csb * lx - snb * ly;                   // sphere centre relative to the body anchor
+        ry = snb * lx + csb * ly;
+        depth = rad - ((root_p1 + axb) + rx);
+    }
+    template <typename R, typename V>
+    RL_HD static void sphere_force(V rx, V ry, V depth, V rad, V mu, V axb, V ayb, V pxb, V pyb, V vaxb, V vayb, V omb,
+                                   V& fx, V& fy, V& tz) {
         const V vn = vaxb - omb * ry;               // velocity of the sphere centre
         const V vt = vayb + omb * rx;
         const V zero = Lanes<V>::splat((R)0);
@@ -300,17 +306,41 @@ struct TwoLegs {
         V fx[4], fy[4], tz[4];
         RL_UNROLL
         for (int i = 0; i < 4; ++i) { fx[i] = zero; fy[i] = zero; tz[i] = zero; }
+        // where the spheres are (all of them first: the tests below then wait for nothing) ...
+        V trx[NCT > 0 ? NCT : 1], try_[NCT > 0 ? NCT : 1], tdp[NCT > 0 ? NCT : 1], lrx[6], lry[6], ldp[6];
         static_for<0, NCT>([&](auto Cc) {
             constexpr int cc = decltype(Cc)::value;
-            sphere<R, V>(Lanes<V>::splat((R)Mdl::cpx(cc)), Lanes<V>::splat((R)Mdl::cpy(cc)),
-                         Lanes<V>::splat((R)Mdl::crad(cc)), Lanes<V>::splat((R)Mdl::cmu(cc)),
-                         s.cs[0], s.sn[0], ax[0], ay[0], px[0], py[0], vax[0], vay[0], om[0], s.qr[0], fx[0], fy[0], tz[0]);
+            sphere_pose<R, V>(Lanes<V>::splat((R)Mdl::cpx(cc)), Lanes<V>::splat((R)Mdl::cpy(cc)),
+                              Lanes<V>::splat((R)Mdl::crad(cc)), s.cs[0], s.sn[0], ax[0], s.qr[0], trx[cc], try_[cc], tdp[cc]);
         });
         RL_UNROLL
         for (int cc = 0; cc < 6; ++cc) {
             const int b = 1 + cc / 2;
-            sphere<R, V>(c.cpx[cc], c.cpy[cc], c.crad[cc], c.cmu[cc], s.cs[b], s.sn[b], ax[b], ay[b], px[b], py[b], vax[b],
-                         vay[b], om[b], s.qr[0], fx[b], fy[b], tz[b]);
+            sphere_pose<R, V>(c.cpx[cc], c.cpy[cc], c.crad[cc], s.cs[b], s.sn[b], ax[b], s.qr[0], lrx[cc], lry[cc], ldp[cc]);
+        }
+        // ... and what the touching ones push with, body by body (one group for all leg spheres but the feet's was
+        // measured as well: no faster)
+        if constexpr (NCT > 0) {
+            bool any = false;
+            static_for<0, NCT>([&](auto Cc) { any = any || rl_any_pos(tdp[decltype(Cc)::value]); });
+            if (any) {
+                static_for<0, NCT>([&](auto Cc) {
+                    constexpr int cc = decltype(Cc)::value;
+                    sphere_force<R, V>(trx[cc], try_[cc], tdp[cc], Lanes<V>::splat((R)Mdl::crad(cc)),
+                                       Lanes<V>::splat((R)Mdl::cmu(cc)), ax[0], ay[0], px[0], py[0], vax[0], vay[0], om[0],
+                                       fx[0], fy[0], tz[0]);
+                });
+            }
+        }
+        RL_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const int b = 1 + j, c0 = 2 * j, c1 = 2 * j + 1;
+            if (rl_any_pos(ldp[c0]) || rl_any_pos(ldp[c1])) {
+                sphere_force<R, V>(lrx[c0], lry[c0], ldp[c0], c.crad[c0], c.cmu[c0], ax[b], ay[b], px[b], py[b], vax[b],
+                                   vay[b], om[b], fx[b], fy[b], tz[b]);
+                sphere_force<R, V>(lrx[c1], lry[c1], ldp[c1], c.crad[c1], c.cmu[c1], ax[b], ay[b], px[b], py[b], vax[b],
+                                   vay[b], om[b], fx[b], fy[b], tz[b]);
+            }
         }
         // ---- velocity-product accelerations moved to the right-hand side, body wrenches about the own anchors ----------------
         V aax[4], aay[4], Fx[4], Fy[4], Nz[4];

@@ -31,6 +31,17 @@ __device__ __forceinline__ void store_state(float* __restrict__ state, int n, in
     for (int k = 0; k < Env::STATE; ++k) state[(size_t)k * n + i] = s[k];
 }
 
+// Values just loaded from global memory inside a wave-uniform branch are made to ARRIVE inside that branch.  The memory
+// counter (vmcnt) counts loads and stores alike and the compiler places the wait at the first use: behind the join that
+// is a conservative vmcnt(0) on EVERY path -- in the rollout loops it stood behind the step's trajectory stores and
+// exposed their full round trip every env-step (injected noise / reset planes are the parity runs' path; a training
+// run takes the other side of these branches and must not wait at all).
+template <int COUNT>
+__device__ __forceinline__ void landed(float* v) {
+#pragma unroll
+    for (int k = 0; k < COUNT; ++k) asm volatile("" : "+v"(v[k]));
+}
+
 template <class Env>
 __device__ __forceinline__ void reset_one(float* s, const float* __restrict__ draws, int n, int i,
                                           uint64_t seed, uint32_t env_global, uint64_t step, const EnvCfg& cfg) {
@@ -38,6 +49,7 @@ __device__ __forceinline__ void reset_one(float* s, const float* __restrict__ dr
     if (draws) {
 #pragma unroll
         for (int k = 0; k < Env::RESET_DRAWS; ++k) d[k] = draws[(size_t)k * n + i];
+        landed<Env::RESET_DRAWS>(d);
     } else {
         philox_draws<Env::RESET_DRAWS, Env::RESET_NORMAL>(d, seed, env_global, step, RNG_RESET);
     }
@@ -52,6 +64,7 @@ __device__ __forceinline__ void noise_draws(float* d, const float* __restrict__ 
     if (z) {
 #pragma unroll
         for (int k = 0; k < COUNT; ++k) d[k] = z[(size_t)k * n + i];
+        landed<COUNT>(d);
     } else {
         philox_draws<COUNT, true>(d, seed, env_global, step, purpose);
     }
@@ -882,6 +895,7 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
+            landed<Env::ACT>(z);
         } else if constexpr (EPW == 16) {
             // the four replicas of an env draw the noise of FOUR consecutive steps at once -- replica g that of step
             // t + g, the same Philox block (seed; env, step, POLICY) the one-draw-per-step form evaluates -- and
@@ -994,6 +1008,15 @@ __device__ __forceinline__ float prefix3(const DppQuad& x, float v, int b) {
 }
 
 constexpr int QUAD_ENVS = 16;   // envs per wavefront
+// Unroll factors of the sub-step loops: the Swimmer's lane-group kernels, the one-env-per-wavefront kernel of the two-legged
+// envs (its four sub-steps as one block: -3.7 % per rollout, tools/exp/rollout_lines.py; the 16-envs-per-wavefront kernels
+// keep the loop -- every unrolled copy of that 800-instruction body costs minutes of compile time per instantiation).
+#ifndef RL_SWIMMER_SUBSTEP_UNROLL
+#define RL_SWIMMER_SUBSTEP_UNROLL 5
+#endif
+#ifndef RL_TWO_LEG_SUBSTEP_UNROLL
+#define RL_TWO_LEG_SUBSTEP_UNROLL 4
+#endif
 
 // COOP: the workgroup's wavefronts all carry the SAME group of envs (RolloutPolicyCoop); wavefront 0 stores
 template <class Pol, bool COOP = false>
@@ -1074,10 +1097,11 @@ __device__ __forceinline__ void swimmer_quad_body(const RolloutDev& a, const Pol
             for (int k = 0; k < Env::OBS; ++k) *at(a.obs, row, vo_obs[k]) = o[k];
         }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
-        pol.forward16(o, mean);
+        // (the noise first: its lane moves travel while the policy runs)
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
+            landed<Env::ACT>(z);
         } else {
             // four steps' noise at once, one step per replica group (see rollout_kernel)
             if ((t & 3) == 0)
@@ -1086,6 +1110,7 @@ __device__ __forceinline__ void swimmer_quad_body(const RolloutDev& a, const Pol
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = __shfl(zq[k], el + 16 * (t & 3), 64);
         }
+        pol.forward16(o, mean);
 #pragma unroll
         for (int k = 0; k < Env::ACT; ++k) {
             act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
@@ -1132,7 +1157,7 @@ __device__ __forceinline__ void swimmer_quad_body(const RolloutDev& a, const Pol
             }
             ls.set_direction(cs_b, sn_b);
             ls.qd = Chain::joint_rate(dpp, ls.om);
-#pragma unroll 5
+#pragma unroll RL_SWIMMER_SUBSTEP_UNROLL
             for (int it = 0; it < Env::FRAME_SKIP; ++it)
                 Chain::template substep_quad<float>(dpp, kc, ls, lact, 0.001f);
             // exact sines of the new absolute angles, one body per lane: Swimmer::step_end's centre of mass needs
@@ -1290,10 +1315,11 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
             for (int k = 0; k < Env::OBS; ++k) *at(a.obs, row, vo_obs[k]) = o[k];
         }
         float mean[Env::ACT], act[Env::ACT], z[Env::ACT];
-        pol.forward16(o, mean);
+        // (the noise first: its lane moves travel while the policy runs)
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = a.eps[k * plane + off];
+            landed<Env::ACT>(z);
         } else {
             // four steps' noise at once, one step per replica group (see rollout_kernel)
             if ((t & 3) == 0)
@@ -1302,6 +1328,7 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) z[k] = __shfl(zq[k], el + 16 * (t & 3), 64);
         }
+        pol.forward16(o, mean);
 #pragma unroll
         for (int k = 0; k < Env::ACT; ++k) act[k] = __builtin_fmaf(z[k], std_[k], mean[k]);  // rnd * exp(log_std) + mean
         if (live) {
@@ -1358,6 +1385,7 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
                     rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
                 }
             }
+#pragma unroll 1
             for (int it = 0; it < Env::SUBSTEPS; ++it)
                 Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
             // the sines of the new angles: the centre of mass of step_end needs them now (each lane its chain's part,
@@ -1653,6 +1681,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
         if (a.eps) {
 #pragma unroll
             for (int k = 0; k < Env::ACT; ++k) zs[k] = a.eps[k * plane + row + i];
+            landed<Env::ACT>(zs);
         } else {
             // lane j draws the block of step t + j once per 64 steps; every step reads its row
             if ((t & 63) == 0)
@@ -1710,6 +1739,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
                     rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
                 }
             }
+#pragma unroll RL_TWO_LEG_SUBSTEP_UNROLL
             for (int it = 0; it < Env::SUBSTEPS; ++it)
                 Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
             {   // the sines of the new angles: step_end's centre of mass needs them now, the next step's sub-steps start from them
