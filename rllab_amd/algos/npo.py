@@ -84,8 +84,19 @@ class NPO(BatchPolopt):
                                   inputs=None, constraint_name="mean_kl", fused=fused)
         return dict()
 
+    def prefetch_update(self, samples_data):
+        """Called by ``process_samples`` once the advantages are on the device: hands the optimizer its inputs early so
+        that its first pass runs while the host logs (optimizers/conjugate_gradient_optimizer.py::prefetch)."""
+        self._prefetched = None
+        if not hasattr(self.optimizer, "prefetch") or not getattr(self, "prefetch_update_enabled", True):
+            return
+        values = npo_inputs(self.policy, samples_data)
+        self._prefetched = (samples_data, values)
+        self.optimizer.prefetch(values)
+
     def optimize_policy(self, itr, samples_data):
-        all_input_values = npo_inputs(self.policy, samples_data)
+        pre, self._prefetched = getattr(self, "_prefetched", None), None
+        all_input_values = pre[1] if pre is not None and pre[0] is samples_data else npo_inputs(self.policy, samples_data)
         if getattr(self.optimizer, "reports_before_values", False):
             self.optimizer.optimize(all_input_values)
             loss_before, mean_kl_before = self.optimizer.last_before

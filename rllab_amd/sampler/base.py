@@ -243,6 +243,10 @@ def process_dense(algo, itr, traj, log=True):
 
     paths = PathList(traj)
     samples_data = SamplesData(_traj=traj, paths=paths)
+    # everything the policy update reads is on the device now: let it start (algos/npo.py::prefetch_update) while the
+    # host fits a host-side baseline, writes the statistics below and the env / policy diagnostics
+    if hasattr(algo, "prefetch_update") and traj.obs.is_cuda:
+        algo.prefetch_update(samples_data)
 
     if not dense_fit:
         if log:
