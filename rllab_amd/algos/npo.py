@@ -10,6 +10,8 @@ old mean, old log_std] (:84-88) with the two batch-normalisation extras appended
 [..., weights, 1/W].  All per-sample tensors are "planes" with the sample axis
 LAST (obs [Do, B], actions [Da, B], ...).
 """
+import os
+
 import torch
 
 import rllab_amd.misc.logger as logger
@@ -88,7 +90,8 @@ class NPO(BatchPolopt):
         """Called by ``process_samples`` once the advantages are on the device: hands the optimizer its inputs early so
         that its first pass runs while the host logs (optimizers/conjugate_gradient_optimizer.py::prefetch)."""
         self._prefetched = None
-        if not hasattr(self.optimizer, "prefetch") or not getattr(self, "prefetch_update_enabled", True):
+        if not hasattr(self.optimizer, "prefetch") or not getattr(self, "prefetch_update_enabled", True) or \
+                os.environ.get("RLLAB_UPDATE_PREFETCH", "1")[:1] == "0":       # (A/B timing)
             return
         values = npo_inputs(self.policy, samples_data)
         self._prefetched = (samples_data, values)
