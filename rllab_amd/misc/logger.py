@@ -146,6 +146,8 @@ class Logger(object):
     def log(self, s, with_prefix=True, with_timestamp=True, color=None):
         if not self.is_primary():
             return
+        if (self.tabular_only or self.quiet) and not self.text_sinks:
+            return                        # nobody reads it: no timestamp, no string (these sit between kernel launches)
         line = ("".join(self.text_prefixes) if with_prefix else "") + s
         if with_timestamp:
             line = datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S.%f") + " | " + line
