@@ -331,6 +331,73 @@ def test_deferred_reads_give_the_same_numbers(quiet_logger):
     assert abs(k1 - float(kl(pol.flat_params.double(), *inp))) <= 2e-5 * max(1e-3, abs(k1))
 
 
+def test_prefetched_gradient_pass_changes_nothing_but_the_time(quiet_logger):
+    """optimizer.prefetch(inputs) launches the gradient pass of the next optimize(inputs) early (process_samples does,
+    through NPO.prefetch_update): the update that follows is bit-identical to one without it; a record made for other
+    inputs or other parameters is not used."""
+    from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+
+    def run(prefetch, disturb=None):
+        np.random.seed(4)
+        pol = _policy(13, 2, 32)
+        inp = _inputs(pol, 20000, old_equals_new=True, ragged=True)
+        surr, kl, _ = _closures(pol)
+        opt = ConjugateGradientOptimizer()
+        ops = pol.fused_ops()
+        opt.update_opt(loss=surr, target=pol, leq_constraint=(kl, 0.01), fused=ops)
+        if prefetch:
+            opt.prefetch(inp)
+            assert opt._pre is not None
+        if disturb == "params":
+            with torch.no_grad():
+                pol.flat_params.mul_(1.0)              # same values, a new parameter version: the record is stale
+        if disturb == "inputs":
+            inp = tuple(t.clone() if torch.is_tensor(t) else t for t in inp)
+        opt.optimize(inp)
+        assert opt._pre is None
+        return pol.get_param_values().copy(), opt.last_before, opt.last_backtrack_iters
+
+    base = run(False)
+    for kw in (dict(prefetch=True), dict(prefetch=True, disturb="params"), dict(prefetch=True, disturb="inputs")):
+        got = run(**kw)
+        assert np.array_equal(got[0], base[0]) and got[1] == base[1] and got[2] == base[2], kw
+
+
+def test_process_samples_starts_the_update(quiet_logger, monkeypatch):
+    """TRPO through BatchPolopt's pieces with and without RLLAB_UPDATE_PREFETCH: identical parameters after three
+    iterations, and with it on the optimizer really finds its gradient ready."""
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.optimizers import conjugate_gradient_optimizer as cgo
+
+    def run(flag):
+        monkeypatch.setenv("RLLAB_UPDATE_PREFETCH", flag)
+        ext.set_seed(3)
+        env = normalize(SwimmerEnv())
+        policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+        algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=128 * 50,
+                    max_path_length=50, n_itr=3, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=128))
+        algo.start_worker()
+        algo.init_opt()
+        used = []
+        for itr in range(3):
+            paths = algo.sampler.obtain_samples(itr)
+            sd = algo.sampler.process_samples(itr, paths)
+            used.append(getattr(algo.optimizer, "_pre", None) is not None)
+            algo.log_diagnostics(paths)
+            algo.optimize_policy(itr, sd)
+        return policy.get_param_values().copy(), used
+
+    p1, used1 = run("1")
+    p0, used0 = run("0")
+    assert used1 == [True, True, True] and used0 == [False, False, False]
+    assert np.array_equal(p1, p0)
+
+
 def test_cg_residual_gives_the_same_step_as_a_fresh_product():
     """d^T H d from CG's invariant (H d = g - r) vs from one more Fisher-vector product (what the reference
     evaluates, conjugate_gradient_optimizer.py:258-260): same step vector to ~1e-6 relative."""
