@@ -11,10 +11,11 @@ diagonal-Gaussian head between them is ``rl_gaussian_head`` / ``rl_gaussian_fish
     F v        : forward-with-tangent x 2 -> Fisher head (diagonal in (mean, log_std) at old == new) -> backward x 2
 
 Everything else -- evaluation caching, the device CG, the line search writes, the sharded sums -- is inherited from
-``FusedGaussianMLPOps``; this class only replaces its three passes.  Each network: two or three tanh layers of exactly
-32 / 64 / 128 units (two equal layers of 32 / 64 on a HIP-native (obs, action) pair run one wavefront per tile, every
-other shape the cooperative kernels of csrc/policy_wide_kernels.hip -- their modes OUT / OUT_TAN / BWD), obs_dim <= 30,
-action_dim <= 8.
+``FusedGaussianMLPOps``; this class only replaces its three passes.  Each network: two or three tanh layers of at most
+128 units, run zero-padded to 32 / 64 / 128 per layer (exact: a padded unit has zero weights and bias, tanh(0) = 0;
+policies/kernel_layout.py::mlp_pad_index; two equal layers of 32 / 64 on a HIP-native (obs, action) pair run one
+wavefront per tile, every other shape the cooperative kernels of csrc/policy_wide_kernels.hip -- their modes OUT /
+OUT_TAN / BWD), obs_dim <= 30, action_dim <= 8.
 """
 import ctypes
 import math
@@ -28,7 +29,8 @@ from rllab_amd.sampler import dist as D
 
 
 class _IdentityLayout(object):
-    """The kernels' parameter space IS the policy's flat vector (both networks have tile-sized layers)."""
+    """The optimizer-facing parameter space IS the policy's flat vector; the networks' zero padding happens per network,
+    where their kernel-layout copies are made (``FusedAdaptiveStdOps.nets``)."""
     wide = False
     exact = True
 
@@ -47,8 +49,8 @@ class _IdentityLayout(object):
 
 
 def _net_ok(net, obs_dim, act_dim):
-    hs = tuple(net.hidden_sizes)
-    return (len(hs) in (2, 3) and all(h in (32, 64, 128) for h in hs) and net.hidden_nonlinearity is tanh
+    from rllab_amd.policies.kernel_layout import layer_padded_sizes
+    return (layer_padded_sizes(net.hidden_sizes) is not None and net.hidden_nonlinearity is tanh
             and net.output_nonlinearity is None and net.input_dim == obs_dim and net.output_dim == act_dim)
 
 
@@ -68,11 +70,18 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         self.policy = policy
         self.layout = _IdentityLayout(policy)
         do, da = policy.obs_dim, policy.action_dim
-        self.nets = []                                   # (offset, size, hidden) of [mean net, std net] in the flat vector
+        from rllab_amd.policies.kernel_layout import layer_padded_sizes, mlp_pad_index
+        self.nets = []                   # (offset, size, padded hidden triple) of [mean net, std net] in the flat vector
+        self.pad = []                    # per network: (index of its real parameters in its padded copy or None, padded size)
         for net in (policy._mean_network, policy._std_network):
             off = net.params[0].offset
-            hs = tuple(net.hidden_sizes)
-            self.nets.append((off, net.end_offset - off, hs + (0,) * (3 - len(hs))))
+            hs = tuple(int(h) for h in net.hidden_sizes)
+            Hs = layer_padded_sizes(hs)
+            self.nets.append((off, net.end_offset - off, Hs + (0,) * (3 - len(Hs))))
+            idx, p_pad = mlp_pad_index(do, hs, Hs, da)
+            assert idx.size == net.end_offset - off
+            self.pad.append((None if hs == Hs else torch.as_tensor(idx, dtype=torch.long, device=policy.flat_params.device),
+                             int(p_pad)))
         assert self.nets[0][0] == 0 and self.nets[1][0] == self.nets[0][1]
         assert self.nets[1][0] + self.nets[1][1] == policy.flat_params.numel()
         self.dims = (do, da) + self.nets[0][2]
@@ -95,11 +104,25 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         if self._theta_tag != tag:
             flat = pol.flat_params.detach()
             for i, (off, size, _) in enumerate(self.nets):
-                if self._net_theta[i] is None:
-                    self._net_theta[i] = torch.zeros(size + pol.action_dim, dtype=torch.float32, device=flat.device)
-                self._net_theta[i][:size].copy_(flat[off:off + size])
+                idx, p_pad = self.pad[i]
+                if self._net_theta[i] is None:       # (padded positions and the Da trailing floats stay zero for good)
+                    self._net_theta[i] = torch.zeros(p_pad + pol.action_dim, dtype=torch.float32, device=flat.device)
+                self._scatter(i, self._net_theta[i], flat[off:off + size])
             self._theta_tag = tag
         return self._net_theta
+
+    def _scatter(self, i, dst, src):
+        """Real parameters of network i -> their places in its (padded) kernel-layout vector ``dst``."""
+        idx, _ = self.pad[i]
+        if idx is None:
+            dst[:src.numel()].copy_(src)
+        else:
+            dst.index_copy_(0, idx, src.to(dst.dtype))
+
+    def _gather(self, i, src):
+        """... and back: the real entries of a kernel-layout vector of network i."""
+        idx, _ = self.pad[i]
+        return src[:self.nets[i][1]] if idx is None else src.index_select(0, idx)
 
     def accepts(self, inputs):
         """Per-sample old log_std planes [Da, B] (what a state-dependent std records)."""
@@ -142,8 +165,8 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         # per-network scratch of the passes, allocated once per bound batch (ten Fisher-vector products per update
         # would otherwise allocate and fill four tensors each): the tangent in the kernels' policy layout
         # [network parameters | Da zeros] and the float64 gradient row rl_mlp_backward writes
-        scratch = [dict(tangent=torch.zeros(size + da, **f32),
-                        grad=torch.empty(size + da, dtype=torch.float64, device=dev)) for _, size, _ in self.nets]
+        scratch = [dict(tangent=torch.zeros(p_pad + da, **f32),
+                        grad=torch.empty(p_pad + da, dtype=torch.float64, device=dev)) for _, p_pad in self.pad]
         b = dict(structs=structs, planes=planes, log_min=log_min, B=B, scratch=scratch, tensors=dict(obs=obs, act=act, adv=adv,
                                                                                       old_mean=old_mean, old_ls=old_ls, w=w))
         self._point_at_current_parameters(b)
@@ -183,7 +206,7 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
             g = b["scratch"][i]["grad"]
             _lib.check(_lib.lib.rl_mlp_backward(ctypes.byref(b["structs"][i]), _lib.ptr(p[gname]), _lib.ptr(ws),
                                                 ws.numel(), _lib.ptr(g), st), "rl_mlp_backward")
-            out[off:off + size].copy_(g[:size])
+            out[off:off + size].copy_(self._gather(i, g))
         return out
 
     def _loss_eval(self, inputs):
@@ -223,8 +246,8 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         """F vec: tangents of both networks, the (diagonal) Fisher metric of the head, back through both networks."""
         da = self.dims[1]
         tangents = []
-        for (off, size, _), sc in zip(self.nets, b["scratch"]):
-            sc["tangent"][:size].copy_(vec32[off:off + size])     # (the Da trailing floats stay zero)
+        for i, ((off, size, _), sc) in enumerate(zip(self.nets, b["scratch"])):
+            self._scatter(i, sc["tangent"], vec32[off:off + size])      # (padded positions and the Da trailing floats stay zero)
             tangents.append(sc["tangent"])
         self._forward(b, tangents)
         p, t_ = b["planes"], b["tensors"]

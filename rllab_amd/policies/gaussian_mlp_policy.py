@@ -136,34 +136,43 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
 
     def rollout_networks(self):
         """For a policy with a log-std NETWORK (adaptive_std / std_network) whose two networks the rollout kernels take
-        as they are -- tanh hidden layers of exactly 32 / 64 / 128 units (two or three), linear outputs, float32
-        parameters on the device: ``(theta_mean, hidden3_mean, theta_std, hidden3_std)`` with each theta in the kernels'
+        -- two or three tanh hidden layers of at most 128 units each (zero-padded to 32 / 64 / 128 per layer), linear
+        outputs, float32 parameters on the device: ``(theta_mean, hidden3_mean, theta_std, hidden3_std)`` with each theta in the kernels'
         policy layout [network parameters | action_dim unused floats] (persistent buffers, refreshed when the
         parameters have moved).  None otherwise (such policies are sampled through the per-transition loop)."""
         if not self.state_dependent_std:
             return None
         if not hasattr(self, "_rollout_nets"):
-            from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM, padded_sizes
+            from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM, layer_padded_sizes, mlp_pad_index
             nets = (self._mean_network, self._std_network)
             ok = (self.flat_params.is_cuda and self.flat_params.dtype == torch.float32
                   and self.obs_dim <= MAX_OBS_DIM and self.action_dim <= MAX_ACT_DIM
                   and all(n.hidden_nonlinearity is tanh and n.output_nonlinearity is None
-                          and padded_sizes(n.hidden_sizes) == tuple(n.hidden_sizes) for n in nets))
+                          and layer_padded_sizes(n.hidden_sizes) is not None for n in nets))
             self._rollout_nets = None
             if ok:
+                dev = self.flat_params.device
                 spans = [(n.params[0].offset, n.end_offset - n.params[0].offset) for n in nets]
-                bufs = [torch.zeros(size + self.action_dim, dtype=torch.float32, device=self.flat_params.device)
-                        for _, size in spans]
-                hid = [tuple(n.hidden_sizes) + (0,) * (3 - len(n.hidden_sizes)) for n in nets]
-                self._rollout_nets = dict(spans=spans, bufs=bufs, hidden=hid, tag=None)
+                pads, hid, bufs = [], [], []
+                for n in nets:          # every layer zero-padded to 32 / 64 / 128 (exact: tanh(0) = 0)
+                    hs = tuple(int(h) for h in n.hidden_sizes)
+                    Hs = layer_padded_sizes(hs)
+                    idx, p_pad = mlp_pad_index(self.obs_dim, hs, Hs, self.action_dim)
+                    pads.append(None if hs == Hs else torch.as_tensor(idx, dtype=torch.long, device=dev))
+                    hid.append(Hs + (0,) * (3 - len(Hs)))
+                    bufs.append(torch.zeros(p_pad + self.action_dim, dtype=torch.float32, device=dev))
+                self._rollout_nets = dict(spans=spans, bufs=bufs, hidden=hid, pads=pads, tag=None)
         r = self._rollout_nets
         if r is None:
             return None
         tag = self.param_version()
         if r["tag"] != tag:
             flat = self.flat_params.detach()
-            for (off, size), buf in zip(r["spans"], r["bufs"]):
-                buf[:size].copy_(flat[off:off + size])
+            for (off, size), buf, idx in zip(r["spans"], r["bufs"], r["pads"]):
+                if idx is None:
+                    buf[:size].copy_(flat[off:off + size])
+                else:
+                    buf.index_copy_(0, idx, flat[off:off + size])
             r["tag"] = tag
         return r["bufs"][0], r["hidden"][0], r["bufs"][1], r["hidden"][1]
 

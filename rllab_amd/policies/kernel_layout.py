@@ -53,6 +53,34 @@ def padded_sizes(hidden_sizes):
     return tuple(next(t for t in WIDE_TILE_SIZES if h <= t) for h in hs)
 
 
+def layer_padded_sizes(hidden_sizes):
+    """Every layer on its own next size of 32 / 64 / 128 (two or three layers); None when no kernel runs the net.
+    (The networks-on-planes entry points -- adaptive_std -- take any such triple.)"""
+    hs = tuple(int(h) for h in hidden_sizes)
+    if len(hs) not in (2, 3) or min(hs) < 1 or max(hs) > WIDE_TILE_SIZES[-1]:
+        return None
+    return tuple(next(t for t in WIDE_TILE_SIZES if h <= t) for h in hs)
+
+
+def mlp_pad_index(in_dim, hidden_sizes, padded, out_dim):
+    """Position of every parameter of an MLP (flat order W_0, b_0, ..., W_out, b_out; W_l is [in, out] row-major) inside
+    the same net with its hidden widths zero-padded to ``padded``; returns (index array [P_real], P_pad)."""
+    hs, Hs = tuple(int(h) for h in hidden_sizes), tuple(int(h) for h in padded)
+    ins_real, ins_pad = (in_dim,) + hs, (in_dim,) + Hs
+    idx, off = [], 0
+    for l in range(len(Hs)):
+        rows, cols, cols_pad = ins_real[l], hs[l], Hs[l]
+        idx.append(off + (np.arange(rows)[:, None] * cols_pad + np.arange(cols)[None, :]).reshape(-1))
+        off += ins_pad[l] * cols_pad
+        idx.append(off + np.arange(cols))
+        off += cols_pad
+    idx.append(off + (np.arange(hs[-1])[:, None] * out_dim + np.arange(out_dim)[None, :]).reshape(-1))
+    off += Hs[-1] * out_dim
+    idx.append(off + np.arange(out_dim))
+    off += out_dim
+    return np.concatenate(idx), off
+
+
 class KernelLayout(object):
     def __init__(self, policy):
         self.policy = policy

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 # OUT / OUT_TAN / BWD modes: wide and deep networks, and equal-width ones on an (obs, action) pair the one-wavefront-per-
 # tile kernels are not instantiated for
 SHAPES = [(4, 1, 32, 32), (13, 2, 32, 32), (13, 2, 64, 32), (20, 6, 32, 64),
-          (13, 2, (128, 64, 32), 32), (20, 6, (128, 128), (128, 64)), (17, 3, 64, 32), (11, 1, (64, 32), (32, 64, 32))]
+          (13, 2, (128, 64, 32), 32), (20, 6, (128, 128), (128, 64)), (17, 3, 64, 32), (11, 1, (64, 32), (32, 64, 32)),
+          # widths that are not tile sizes: each network zero-padded per layer (rllab's own (100, 50, 25), a narrow std net)
+          (13, 2, (100, 50, 25), (20, 20)), (20, 6, (48, 48), (100, 50, 25)), (4, 1, (8, 8), (5, 7, 9))]
 
 
 def _policy(do, da, hm, hs, min_std=1e-6, seed=0):
@@ -165,8 +167,40 @@ def test_trpo_with_adaptive_std_updates_on_the_kernels(quiet_logger):
     assert moved[:n_mean].max() > 0 and moved[n_mean:].max() > 0
 
 
+def test_trpo_with_adaptive_std_and_free_form_widths_stays_on_the_kernels(quiet_logger):
+    """rllab's (100, 50, 25) mean network with adaptive_std (std net (32, 32) by default): both networks are zero-padded
+    per layer for the kernels -- the rollout is the fused one, the update runs the fused passes, MeanKL holds."""
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.mujoco.swimmer_env import SwimmerEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(5)
+    env = normalize(SwimmerEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(100, 50, 25), adaptive_std=True)
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=256 * 60,
+                max_path_length=60, n_itr=3, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    assert type(algo.optimizer._fused).__name__ == "FusedAdaptiveStdOps"
+    assert algo.sampler._takes_fused_rollout(policy)
+    assert [h for _, _, h in algo.optimizer._fused.nets] == [(128, 64, 32), (32, 32, 0)]
+    theta0 = policy.get_param_values().copy()
+    for itr in range(3):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.log_diagnostics(paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        assert float(tab["MeanKL"]) <= 0.0101 and float(tab["LossAfter"]) < float(tab["LossBefore"])
+        assert abs(float(tab["MeanKLBefore"])) < 1e-6
+        logger.dump_tabular()
+    assert np.isfinite(policy.get_param_values()).all() and np.abs(policy.get_param_values() - theta0).max() > 0
+
+
 @pytest.mark.parametrize("kind,hm,hs", [(0, (32, 32), (32, 32)), (2, (64, 64), (32, 32)), (3, (128, 64, 32), (32, 32)),
-                                        (6, (32, 32), (64, 64))])
+                                        (6, (32, 32), (64, 64)), (2, (100, 50, 25), (20, 20)), (0, (8, 8), (5, 7, 9))])
 @pytest.mark.parametrize("epw", ["16", "64"])
 def test_fused_rollout_with_a_log_std_network(kind, hm, hs, epw, monkeypatch):
     """rl_rollout_gaussian_mlp with rl_rollout_args.theta_std: mean AND log-std network evaluated in the kernel every
