@@ -157,8 +157,13 @@ class ConjugateGradientOptimizer(Serializable):
                                       reg_coeff=self._reg_coeff)
 
     # -- evaluations ------------------------------------------------------------
-    def _trainable_index(self):
-        return self._target._flat_index(trainable=True)
+    def _trainable_index(self, inputs=None):
+        idx = self._target._flat_index(trainable=True)
+        if idx is not None and inputs is not None and getattr(self._fused_for(inputs), "masks_frozen", False):
+            # the fused passes keep the gradient of the frozen entries (learn_std=False: the log_std row) at zero and
+            # the Fisher matrix does not couple them to the rest: work on the full vector, they never move
+            return None
+        return idx
 
     def _eval_scalar(self, fn, inputs):
         with torch.no_grad():
@@ -193,7 +198,7 @@ class ConjugateGradientOptimizer(Serializable):
             flat = _flat_for_grad(self._target)
             g = torch.autograd.grad(self._loss(flat, *inputs), flat)[0]
             g = D.all_reduce_sum_(g.to(torch.float64))
-        idx = self._trainable_index()
+        idx = self._trainable_index(inputs)
         return g if idx is None else g[idx]
 
     # -- the update ---------------------------------------------------------------
@@ -217,7 +222,7 @@ class ConjugateGradientOptimizer(Serializable):
     def optimize(self, inputs, extra_inputs=None, subsample_grouped_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())
         target = self._target
-        idx = self._trainable_index()
+        idx = self._trainable_index(inputs)
         pre, self._pre = getattr(self, "_pre", None), None
 
         if self._subsample_factor < 1:

@@ -50,10 +50,11 @@ class FusedGaussianMLPOps(object):
 
     @staticmethod
     def supported(policy):
-        """Two or three tanh hidden layers of at most 128 units each (zero-padded to the kernels' tiles), learned
-        state-independent std, parameters on the device, obs_dim <= 30, action_dim <= 8 (policy.kernel_layout())."""
+        """Two or three tanh hidden layers of at most 128 units each (zero-padded to the kernels' tiles),
+        state-independent std (learned or, ``learn_std=False``, frozen: see ``masks_frozen``), parameters on the device,
+        obs_dim <= 30, action_dim <= 8 (policy.kernel_layout())."""
         layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
-        return layout is not None and bool(policy.learn_std)
+        return layout is not None
 
     def accepts(self, inputs):
         """The kernels take ONE old log_std row (state-independent std)."""
@@ -201,7 +202,34 @@ class FusedGaussianMLPOps(object):
                 self._acts_tag = tag
         finally:
             b.activations = None
-        return self.layout.unpack(D.update_sum_(out))
+        return self._mask_frozen(self.layout.unpack(D.update_sum_(out)))
+
+    # ``GaussianMLPPolicy(learn_std=False)``: the log_std row is a parameter that is not trainable.  The passes compute
+    # its gradient like any other; it is zeroed here.  That is all a frozen row needs: at theta_old the Fisher matrix is
+    # block diagonal between the network and the log_std row (d2 KL / d mu d sigma = 0), so conjugate gradient started
+    # from a gradient with zeros there keeps zeros there exactly, the step leaves the row alone, and the optimizers
+    # may keep working on the full vector (device CG, line search kernels) -- ``masks_frozen`` tells them so.
+    @property
+    def masks_frozen(self):
+        return self._frozen_index() is not None
+
+    def _frozen_index(self):
+        if not hasattr(self, "_frozen_idx"):
+            pol = self.policy
+            tr = pol._flat_index(trainable=True)
+            if tr is None:
+                self._frozen_idx = None
+            else:
+                keep = torch.ones(pol.flat_params.numel(), dtype=torch.bool, device=pol.flat_params.device)
+                keep[tr] = False
+                self._frozen_idx = torch.nonzero(keep).reshape(-1)
+        return self._frozen_idx
+
+    def _mask_frozen(self, g):
+        idx = self._frozen_index()
+        if idx is not None:
+            g.index_fill_(0, idx, 0.0)
+        return g
 
     def value_and_grad(self, inputs, penalty=0.0):
         """float64 (value, flat gradient over the trainable parameters) of  surrogate loss + penalty * mean KL  in ONE

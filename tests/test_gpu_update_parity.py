@@ -57,17 +57,17 @@ def _closures(pol):
     dist = pol.distribution
 
     def surr(flat, obs, act, adv, om, ols, w, inv):
-        new = pol.dist_info_planes(obs.double(), flat)
+        new = pol.dist_info_planes(obs.double(), flat.double())
         lr = dist.likelihood_ratio_sym(act.double(), dict(mean=om.double(), log_std=ols.double()), new, axis=0)
         return -(lr * adv.double() * w.double()).sum() * inv
 
     def kl(flat, obs, act, adv, om, ols, w, inv):
-        new = pol.dist_info_planes(obs.double(), flat)
+        new = pol.dist_info_planes(obs.double(), flat.double())
         k = dist.kl_sym(dict(mean=om.double(), log_std=ols.double()), new, axis=0)
         return (k * w.double()).sum() * inv
 
     def vpg(flat, obs, act, adv, om, ols, w, inv):
-        new = pol.dist_info_planes(obs.double(), flat)
+        new = pol.dist_info_planes(obs.double(), flat.double())
         ll = dist.log_likelihood_sym(act.double(), new, axis=0)
         return -(ll * adv.double() * w.double()).sum() * inv
     return surr, kl, vpg
@@ -396,6 +396,50 @@ def test_process_samples_starts_the_update(quiet_logger, monkeypatch):
     p0, used0 = run("0")
     assert used1 == [True, True, True] and used0 == [False, False, False]
     assert np.array_equal(p1, p0)
+
+
+@pytest.mark.parametrize("hidden", [(32, 32), (100, 50, 25)])
+def test_frozen_log_std_updates_on_the_kernels(quiet_logger, hidden):
+    """GaussianMLPPolicy(learn_std=False): the log_std row is a parameter but not trainable
+    (gaussian_mlp_policy.py:21-58).  The fused passes zero its gradient, the Fisher matrix does not couple it to the
+    network at theta_old, so the device CG / line search on the full vector never move it -- and the network moves as
+    under the reference's computation in the trainable subspace (the same optimizer on float64 autograd closures)."""
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+
+    def make():
+        np.random.seed(7)
+        spec = EnvSpec(Box(-np.ones(13), np.ones(13)), Box(-np.ones(2), np.ones(2)))
+        pol = GaussianMLPPolicy(spec, hidden_sizes=hidden, learn_std=False, init_std=0.7)
+        theta = pol.get_param_values()                       # (trainable and frozen entries alike)
+        pol.set_param_values(theta + 0.1 * np.random.randn(theta.size))
+        return pol
+
+    results = []
+    for fused in (True, False):
+        pol = make()
+        assert pol._flat_index(trainable=True) is not None
+        inp = _inputs(pol, 30000, old_equals_new=True, ragged=True)
+        surr, kl, _ = _closures(pol)
+        opt = ConjugateGradientOptimizer()
+        ops = pol.fused_ops() if fused else None
+        if fused:
+            assert ops is not None and ops.masks_frozen
+        opt.update_opt(loss=surr, target=pol, leq_constraint=(kl, 0.01), fused=ops)
+        before = pol.flat_params.detach().clone()
+        opt.optimize(inp)
+        after = pol.flat_params.detach().clone()
+        frozen = torch.ones_like(before, dtype=torch.bool)
+        frozen[pol._flat_index(trainable=True)] = False
+        assert torch.equal(after[frozen], before[frozen])                 # the log_std row did not move, bit for bit
+        assert float((after - before).abs().max()) > 0
+        assert 0.0 < opt.constraint_val(inp) <= 0.01
+        results.append((after.double().cpu().numpy(), opt.last_backtrack_iters))
+    (a, ba), (b, bb) = results
+    assert ba == bb
+    assert np.abs(a - b).max() <= 2e-4 * max(1.0, np.abs(b).max())
 
 
 def test_cg_residual_gives_the_same_step_as_a_fresh_product():
