@@ -31,12 +31,12 @@ python profiles/summarize.py pmc $P/sq2 gpurun_out/${TAG}_pmc_sq2.csv
 [ -f gpurun_out/pmc_traffic.json ] || cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
 python profiles/summarize.py traffic gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/pmc_traffic.json $WORKLOAD $NENVS ${ROUND} gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv
 head -6 gpurun_out/${TAG}_pmc_fetch_size.csv gpurun_out/${TAG}_pmc_write_size.csv gpurun_out/${TAG}_pmc_sq.csv gpurun_out/${TAG}_pmc_sq2.csv
+# one iteration's dispatch timeline (start, duration, idle gap before each kernel)
+python profiles/summarize.py timeline $P/stats gpurun_out/${TAG}_timeline.csv
 if [ "$WORKLOAD" != "swimmer4096_trpo" ]; then ls -la gpurun_out; exit 0; fi
 # the per-step VecEnv boundary kernel at a chip-filling size: the kernel the HBM roofline applies to
 python tools/step_kernel_roofline.py 2>&1 | grep "^{" > gpurun_out/${TAG}_step_kernel_roofline.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/step -- python tools/step_kernel_roofline.py > /dev/null 2>&1
 python profiles/summarize.py stats $P/step gpurun_out/${TAG}_step_kernel_stats.csv
-# one iteration's dispatch timeline (start, duration, idle gap before each kernel)
-python profiles/summarize.py timeline $P/stats gpurun_out/${TAG}_timeline.csv
 tail -2 gpurun_out/${TAG}_bench_under_rocprof.log
 ls -la gpurun_out
