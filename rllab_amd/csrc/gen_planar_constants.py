@@ -171,7 +171,11 @@ def emit(model):
                   "constexpr double CMU[NC] = {%s};" % ", ".join("%.17g" % p[4] for p in pts)]
     lines.append("}}  // namespace rl::%s" % ns)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_constants.h" % ns)
-    open(path, "w").write("\n".join(lines) + "\n")
+    text = "\n".join(lines) + "\n"
+    # (an unchanged header is left alone: rewriting it would make every translation unit that includes it stale for
+    #  __graft_entry__.build() -- tests/test_oracle_physics.py runs this generator on every CPU test run)
+    if not (os.path.exists(path) and open(path).read() == text):
+        open(path, "w").write(text)
     return path
 
 
