@@ -159,9 +159,13 @@ class ConjugateGradientOptimizer(Serializable):
     # -- evaluations ------------------------------------------------------------
     def _trainable_index(self, inputs=None):
         idx = self._target._flat_index(trainable=True)
-        if idx is not None and inputs is not None and getattr(self._fused_for(inputs), "masks_frozen", False):
+        if (idx is not None and inputs is not None and not self._hvp_given
+                and getattr(self._fused_for(inputs), "masks_frozen", False)):
             # the fused passes keep the gradient of the frozen entries (learn_std=False: the log_std row) at zero and
-            # the Fisher matrix does not couple them to the rest: work on the full vector, they never move
+            # the Fisher matrix does not couple them to the rest: the device CG / line search work on the full vector,
+            # they never move.  Only that path is full-length: a caller-given ``hvp_approach`` (FiniteDifferenceHvp,
+            # a hand-built PerlmutterHvp) runs krylov.cg + set_param_values(trainable=True) in the trainable
+            # subspace like the reference, so it keeps the index.
             return None
         return idx
 

@@ -442,6 +442,46 @@ def test_frozen_log_std_updates_on_the_kernels(quiet_logger, hidden):
     assert np.abs(a - b).max() <= 2e-4 * max(1.0, np.abs(b).max())
 
 
+def test_frozen_log_std_with_a_caller_given_hvp(quiet_logger):
+    """learn_std=False + an explicit ``hvp_approach`` (conjugate_gradient_optimizer.py:118-140 of the reference lets the
+    caller pick FiniteDifferenceHvp): the fused passes still serve loss / gradient, but CG and the line search run in
+    the trainable subspace (no device CG), so every vector must have the trainable length -- the configuration the
+    round-4 advisor found broken.  The step must land where the default (device CG) path lands."""
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer, FiniteDifferenceHvp
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+
+    def make():
+        np.random.seed(7)
+        spec = EnvSpec(Box(-np.ones(13), np.ones(13)), Box(-np.ones(2), np.ones(2)))
+        pol = GaussianMLPPolicy(spec, hidden_sizes=(32, 32), learn_std=False, init_std=0.7)
+        pol.set_param_values(pol.get_param_values() + 0.1 * np.random.randn(pol.get_param_values().size))
+        return pol
+    out = []
+    for hvp in (None, FiniteDifferenceHvp(base_eps=1e-2)):
+        pol = make()
+        inp = _inputs(pol, 30000, old_equals_new=True, ragged=True)
+        surr, kl, _ = _closures(pol)
+        opt = ConjugateGradientOptimizer(hvp_approach=hvp)
+        ops = pol.fused_ops()
+        assert ops.masks_frozen
+        opt.update_opt(loss=surr, target=pol, leq_constraint=(kl, 0.01), fused=ops)
+        before = pol.flat_params.detach().clone()
+        opt.optimize(inp)
+        after = pol.flat_params.detach().clone()
+        frozen = torch.ones_like(before, dtype=torch.bool)
+        frozen[pol._flat_index(trainable=True)] = False
+        assert torch.equal(after[frozen], before[frozen]) and float((after - before).abs().max()) > 0
+        assert 0.0 < opt.constraint_val(inp) <= 0.01
+        out.append((after - before).double().cpu().numpy())
+    # finite differences of gradients at float32 parameters are noisy (the reference's are too): same direction, same
+    # trust-region length, not the same digits
+    a, b = out
+    assert a.dot(b) / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.9
+    assert 0.5 < np.linalg.norm(b) / np.linalg.norm(a) < 2.0
+
+
 def test_cg_residual_gives_the_same_step_as_a_fresh_product():
     """d^T H d from CG's invariant (H d = g - r) vs from one more Fisher-vector product (what the reference
     evaluates, conjugate_gradient_optimizer.py:258-260): same step vector to ~1e-6 relative."""
@@ -488,24 +528,87 @@ def test_grad_pass_also_returns_the_loss_sums(do, da, h):
     assert np.all(np.abs(s3[:3] - s2[:3]) <= 1e-12 * np.maximum(1.0, np.abs(s2[:3]))) and s3[3] == s2[3]
 
 
-def test_adam_step_kernel_matches_the_tensor_form():
-    """rl_adam_step (in place on the float32 parameters) == the float64 tensor arithmetic of _Adam.step
-    (lasagne.updates.adam), step after step, moments included."""
+def test_adam_step_kernel_matches_the_oracle_adam():
+    """rl_adam_step (in place on the float32 parameters, float64 moments) against oracle/np_reference.py::Adam -- the
+    restatement of lasagne.updates.adam (first_order_optimizer.py:21-22,62-76), itself pinned by hand-derived steps in
+    tests/test_oracle_golden.py -- over eight steps with changing gradients: moments to float64 rounding (the kernel
+    contracts b1 m + (1 - b1) g into a fused multiply-add), parameters to one float32 unit in the last place.  The
+    oracle carries its own float64 parameters forward; the kernel's float32 copy is compared with them every step and
+    may only drift by the accumulated roundings of its own stores."""
+    from oracle import np_reference as R
     from rllab_amd.optimizers.first_order_optimizer import _Adam
     rng = np.random.RandomState(2)
     n = 1250
-    theta0 = torch.as_tensor(rng.randn(n).astype(np.float32), device="cuda")
-    a, b = _Adam(learning_rate=1e-2), _Adam(learning_rate=1e-2)
-    ta, tb = theta0.clone(), theta0.clone()
-    for k in range(5):
-        g = torch.as_tensor(rng.randn(n), device="cuda")
-        ta = a.step(ta.double(), g).float()
-        b.step_in_place(tb, g)
-        # the kernel contracts b1 * m + (1 - b1) * g into an fma: float64 moments agree to rounding, the float32
-        # parameters to one unit in the last place
-        assert torch.allclose(a.m, b.m, rtol=1e-13, atol=1e-300) and torch.allclose(a.v, b.v, rtol=1e-13, atol=1e-300)
-        assert float((ta - tb).abs().max()) <= 2.4e-7 * float(ta.abs().max()), k
-        ta = tb.clone()
+    theta0 = rng.randn(n).astype(np.float32)
+    tb = torch.as_tensor(theta0, device="cuda")
+    b = _Adam(learning_rate=1e-2)
+    st = R.Adam([theta0.astype(np.float64)], learning_rate=1e-2)
+    want = theta0.astype(np.float64)
+    ulp = 0.0
+    for k in range(8):
+        g = rng.randn(n) * 10.0 ** rng.randint(-6, 2, size=n)       # gradients over eight decades, some below epsilon
+        g[rng.rand(n) < 0.02] = 0.0
+        want_prev = tb.double().cpu().numpy()                      # step the oracle from the kernel's own float32 point
+        want = R.adam_step(st, want_prev, g)
+        b.step_in_place(tb, torch.as_tensor(g, device="cuda"))
+        assert b.t == st.t == k + 1
+        assert np.allclose(b.m.cpu().numpy(), st.m[0], rtol=1e-13, atol=1e-300), k
+        assert np.allclose(b.v.cpu().numpy(), st.v[0], rtol=1e-13, atol=1e-300), k
+        got = tb.double().cpu().numpy()
+        # one float32 rounding of the stored result
+        assert np.all(np.abs(got - want) <= 6e-8 * np.maximum(np.abs(want), 1e-30) + 1e-45), (k, np.abs(got - want).max())
+    assert float(np.abs(tb.cpu().numpy() - theta0).max()) > 1e-3    # it moved
+
+
+def test_vpg_iterations_on_c2_shapes_against_the_oracle(quiet_logger):
+    """BASELINE config C2 (CartpoleEnv, 4096 parallel envs, VPG, GaussianMLPPolicy(32, 32), horizon 100): three
+    iterations of the product's VPG.  Each iteration's surrogate loss and gradient (rl_policy_grad_loss, vpg = 1) are
+    held to the oracle's float64 numpy back-propagation of vpg.py:66-76 on the same batch (1e-5 / 2e-5), and the
+    parameter step the product took to the oracle's Adam (persisting moments, one step per iteration, vpg.py:26-34)
+    driven by the oracle's own gradient."""
+    from oracle import np_reference as R
+    from rllab_amd.algos.npo import npo_inputs
+    from rllab_amd.algos.vpg import VPG
+    from rllab_amd.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab_amd.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab_amd.envs.normalized_env import normalize
+    from rllab_amd.misc import ext, logger
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(11)
+    env = normalize(CartpoleEnv())
+    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    lr = 1e-2
+    algo = VPG(env=env, policy=pol, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=4096 * 100,
+               max_path_length=100, n_itr=3, discount=0.99, optimizer_args=dict(learning_rate=lr),
+               sampler_args=dict(n_envs=4096, seed=11))
+    algo.start_worker()
+    algo.init_opt()
+    npol = R.NumpyGaussianMLP(4, 1, (32, 32), min_std=pol.min_std)
+    theta = pol.get_param_values().astype(np.float64)
+    st = R.Adam([theta], learning_rate=lr)
+    for itr in range(3):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        obs, act, adv, _, _, w, _ = [x.double().cpu().numpy() if torch.is_tensor(x) else x for x in npo_inputs(pol, sd)]
+        assert obs.shape == (4, 409600)
+        theta = pol.get_param_values().astype(np.float64)           # the float32 point the product steps from
+        loss64, g64 = R.vpg_surrogate_and_grad(npol, theta, obs.T, act.T, adv, w)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        assert abs(float(tab["LossBefore"]) - loss64) <= 1e-5 * max(1.0, abs(loss64)), (itr, tab["LossBefore"], loss64)
+        # the product's gradient at the same point (a second, deterministic evaluation of the pass optimize() ran)
+        pol_probe = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+        pol_probe.set_param_values(theta)
+        g = pol_probe.fused_ops().loss_grad(npo_inputs(pol, sd), vpg=True).cpu().numpy()
+        assert np.abs(g - g64).max() <= 2e-5 * np.abs(g64).max(), (itr, np.abs(g - g64).max(), np.abs(g64).max())
+        # the step: oracle Adam on the ORACLE's gradient.  Adam divides by sqrt(v): where |g| is within the gradient
+        # tolerance of zero the step direction is not determined, so those entries get the full step as slack
+        want = R.adam_step(st, theta, g64)
+        got = pol.get_param_values().astype(np.float64)
+        slack = np.where(np.abs(g64) > 1e-3 * np.abs(g64).max(), 0.02 * lr, 2.1 * lr)
+        assert np.all(np.abs(got - want) <= slack + 1e-6 * np.abs(want)), (itr, np.abs(got - want).max())
+        assert np.abs(got - theta).max() > 0.5 * lr                  # a real step was taken
+        logger.dump_tabular()
 
 
 @pytest.mark.parametrize("do,da,h", [(13, 2, 32), (20, 6, 64), (4, 1, 32)])

@@ -109,3 +109,63 @@ def test_flat_param_layout():
     for (W, b), kW, kb in zip(layers, ["W0", "W1", "W2"], ["b0", "b1", "b2"]):
         assert np.array_equal(W, g[kW]) and np.array_equal(b, g[kb])
     assert np.array_equal(log_std, g["log_std"])
+
+
+# -- lasagne.updates.adam (third party, absent): hand-derived known answers ------------------------------------------------
+def test_adam_first_steps_by_hand():
+    """With m = v = 0:  m_1 = (1 - b1) g,  v_1 = (1 - b2) g^2,  a_1 = lr sqrt(1 - b2) / (1 - b1), so the first step is
+    lr g / (|g| + eps / sqrt(1 - b2)); under a CONSTANT gradient m_t = (1 - b1^t) g and v_t = (1 - b2^t) g^2, so
+    every step is lr g / (|g| + eps / sqrt(1 - b2^t)) -- written out here without the recurrences."""
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    g = np.array([3.0, -0.5, 1e-3, -2e-9, 0.0])
+    theta = np.array([1.0, 2.0, -3.0, 0.5, 7.0])
+    st = R.Adam([theta], learning_rate=lr)
+    want = theta.copy()
+    for t in range(1, 6):
+        theta = R.adam_step(st, theta, g)
+        want = want - lr * g / (np.abs(g) + eps / np.sqrt(1.0 - b2 ** t))
+        assert np.allclose(theta, want, rtol=1e-13, atol=0), t
+        assert np.allclose(st.m[0], (1 - b1 ** t) * g, rtol=1e-13) and np.allclose(st.v[0], (1 - b2 ** t) * g * g, rtol=1e-12)
+    assert st.t == 5.0 and theta[4] == 7.0          # a zero gradient never moves its parameter (0 / (0 + eps))
+
+
+def test_adam_two_steps_with_changing_gradient_by_hand():
+    """Second step spelled out:  m_2 = b1 (1-b1) g1 + (1-b1) g2,  v_2 = b2 (1-b2) g1^2 + (1-b2) g2^2,
+    a_2 = lr sqrt(1 - b2^2) / (1 - b1^2)."""
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    g1, g2 = np.array([0.3, -1.2]), np.array([-0.7, 0.4])
+    th0 = np.array([0.1, 0.2])
+    st = R.Adam([th0])
+    th1 = R.adam_step(st, th0, g1)
+    th2 = R.adam_step(st, th1, g2)
+    m2 = b1 * (1 - b1) * g1 + (1 - b1) * g2
+    v2 = b2 * (1 - b2) * g1 ** 2 + (1 - b2) * g2 ** 2
+    a2 = lr * np.sqrt(1 - b2 ** 2) / (1 - b1 ** 2)
+    assert np.allclose(th2, th1 - a2 * m2 / (np.sqrt(v2) + eps), rtol=1e-14, atol=0)
+    # one counter for all arrays (lasagne shares t_prev): two arrays stepped together == the flat vector
+    st2 = R.Adam([th0[:1], th0[1:]])
+    a, b = st2.step([th0[:1], th0[1:]], [g1[:1], g1[1:]])
+    a, b = st2.step([a, b], [g2[:1], g2[1:]])
+    assert np.array_equal(np.concatenate([a, b]), th2)
+
+
+def test_vpg_gradient_against_central_differences():
+    """oracle's hand-written back-propagation of vpg.py's surrogate == central differences of its own loss."""
+    rng = np.random.RandomState(3)
+    pol = R.NumpyGaussianMLP(4, 2, (8, 8))
+    theta = 0.3 * rng.randn(pol.n_params)
+    theta[-1] = np.log(1e-6) - 1.0                 # one log_std below the floor: its gradient is blocked
+    obs, act, adv = rng.randn(50, 4), rng.randn(50, 2), rng.randn(50)
+    w = (rng.rand(50) > 0.2).astype(np.float64)
+    loss, g = R.vpg_surrogate_and_grad(pol, theta, obs, act, adv, w)
+    num = np.zeros_like(theta)
+    for i in range(theta.size):
+        e = np.zeros_like(theta)
+        e[i] = 1e-6
+        num[i] = (R.vpg_surrogate_and_grad(pol, theta + e, obs, act, adv, w)[0] -
+                  R.vpg_surrogate_and_grad(pol, theta - e, obs, act, adv, w)[0]) / 2e-6
+    assert g[-1] == 0.0
+    assert np.allclose(g, num, rtol=2e-6, atol=1e-4 * np.abs(g).max())
+    # the loss is the reference formula on the oracle's own log-likelihood
+    mean, ls = pol.dist_info(obs, theta)
+    assert np.isclose(loss, -np.sum(w * adv * R.gaussian_log_likelihood(act, mean, ls)) / w.sum(), rtol=1e-13)
