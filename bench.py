@@ -239,17 +239,33 @@ def main():
         h = [time.perf_counter()]
         e = [None, None, ev(), ev()]
         h.append(time.perf_counter())
-        e[0], e[1], paths = pending.pop(itr) if itr in pending else launch_rollout(itr)
+        e[0], e[1], paths = (pending.pop(itr) if itr in pending else launch_rollout(itr))[:3]
         h.append(time.perf_counter())
         samples = algo.sampler.process_samples(itr, paths)
         algo.log_diagnostics(paths)
         h.append(time.perf_counter())
         e[2].record()
-        algo.optimize_policy(itr, samples)
+        # an optimizer that decides its line search on the device calls this hook when the whole update is enqueued and
+        # before it reads the outcome (BatchPolopt.train_iteration wires sampler.prefetch the same way): the update's
+        # end event and the next rollout go in there; a rollout queued at parameters that moved on afterwards (no
+        # candidate among the device-decided ones accepted, or the step rejected) is thrown away and redone
+        version = getattr(algo.policy, "param_version", lambda: None)
+
+        def queue_next():
+            e[3].record()
+            pending[itr + 1] = launch_rollout(itr + 1) + (version(),)
+        algo._after_update_enqueued = queue_next if prefetch_next else None
+        try:
+            algo.optimize_policy(itr, samples)
+        finally:
+            algo._after_update_enqueued = None
         h.append(time.perf_counter())
-        e[3].record()
-        if prefetch_next:
-            pending[itr + 1] = launch_rollout(itr + 1)
+        nxt = pending.get(itr + 1)
+        if nxt is None or nxt[3] is None or nxt[3] != version():
+            e[3] = ev()
+            e[3].record()
+            if prefetch_next:
+                pending[itr + 1] = launch_rollout(itr + 1) + (version(),)
         last["samples"] = samples
         logger.dump_tabular()
         h.append(time.perf_counter())

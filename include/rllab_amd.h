@@ -48,7 +48,8 @@ enum rl_status {
 const char* rl_last_error(void);
 
 /* Library / ABI version, bumped when a signature changes.  11: rl_rollout_lds_bytes, rl_mlp_forward_ws (every network
- * shape of the two kernel families as a function on planes), RL_CFG_LIMIT_MUJOCO, rl_policy_fvp_variant's value 2. */
+ * shape of the two kernel families as a function on planes), RL_CFG_LIMIT_MUJOCO, rl_policy_fvp_variant's value 2.
+ * 12: rl_policy_batch.gate + rl_line_search_decide (the line search decided on the device). */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -322,6 +323,11 @@ typedef struct rl_policy_batch {
     int32_t activation;        /* RL_ACT_TANH (policies) or RL_ACT_RECTIFY (GaussianMLPRegressor's default hidden
                                 * nonlinearity, gaussian_mlp_regressor.py:31; loss and vpg gradient only, act_dim 1,
                                 * hidden 32x32) */
+    const int32_t* gate;       /* NULL, or a device word: rl_policy_loss_kl returns without evaluating anything when
+                                * *gate != 0 at the time the launch RUNS (its out4 is then unspecified).  The word is
+                                * rl_line_search_decide's "a candidate has been accepted" flag: the loss passes of
+                                * the candidates enqueued behind an accepted one cost a launch, not a pass over the
+                                * batch.  Ignored by every other entry point. */
 } rl_policy_batch;
 
 enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1 };
@@ -453,6 +459,28 @@ int rl_trpo_step(int n, const double* x, const double* a, const double* b, doubl
  * prev: float[n] (the parameters before the update), step: double[n], theta: float[n]. */
 int rl_line_search_point(int n, const float* prev, const double* step, double ratio, float* theta,
                          void* stream);
+
+/* The accept test of that line search ON THE DEVICE, so that several candidates (and whatever follows the update) can
+ * be enqueued without a host round trip per candidate (conjugate_gradient_optimizer.py:262-274:
+ *     for n_iter, ratio in enumerate(backtrack_ratio ** arange(max_backtracks)):
+ *         cur_param = prev_param - ratio * flat_descent_step;  set_param_values(cur_param)
+ *         loss, constraint_val = f_loss_constraint(...)
+ *         if loss < loss_before and constraint_val <= max_constraint_val: break ).
+ * One launch, one workgroup, after candidate `candidate`'s rl_policy_loss_kl (+ the gather of its sums over the ranks):
+ *   sums    double[rows][4]  the candidate's {sum w lr adv, sum w KL, sum w logp adv, max KL} per rank, rank order
+ *   before  double[rows][4]  the same sums at the parameters the search started from
+ *   loss = -(sum over rows of column 0) * inv_count, constraint = (sum of column 1) * inv_count -- the arithmetic of
+ *   the host path (float64, rows added in rank order), NaN compares false exactly as in the reference
+ *   state   double[2 + 4 * K]: state[0] = 1 once a candidate was accepted, state[1] = its index,
+ *           state[2 + 4 k .. 5 + 4 k] = candidate k's folded sums (three sums, one max) -- written for every candidate
+ *           that was actually evaluated (i.e. while state[0] was still 0 when its decide launch ran)
+ *   gate    int32[1]: mirrors state[0] (rl_policy_batch.gate of the later candidates' loss passes)
+ * If, after this decision, no candidate has been accepted and next_ratio > 0, the same launch writes the NEXT
+ * candidate  theta = (float)(prev - next_ratio * step)  (rl_line_search_point's arithmetic); pass next_ratio = 0 after
+ * the last speculative candidate.  The host reads `state` once, after everything is enqueued. */
+int rl_line_search_decide(int rows, const double* sums, const double* before, double inv_count, double max_constraint,
+                          int candidate, double* state, int32_t* gate, int n, const float* prev, const double* step,
+                          double next_ratio, float* theta, void* stream);
 
 /* One Adam step of FirstOrderOptimizer (rllab/optimizers/first_order_optimizer.py:21-22,62-76: lasagne.updates.adam
  * on the flat parameters), float64 arithmetic, in place:

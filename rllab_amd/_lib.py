@@ -28,7 +28,7 @@ SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_rollout_lds_bytes", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
-    "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_variant", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_adam_step",
+    "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_variant", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_line_search_decide", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
     "rl_lfb_normal_eq",
     "rl_peer_mailbox_bytes", "rl_peer_alloc", "rl_peer_free", "rl_peer_export", "rl_peer_open", "rl_peer_close",
@@ -75,7 +75,7 @@ class PolicyBatch(ctypes.Structure):
         ("log_min_std", ctypes.c_float), ("theta", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
         ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
-        ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32),
+        ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32), ("gate", ctypes.c_void_p),
     ]
 
 
@@ -126,6 +126,7 @@ def _load():
     lib.rl_cg_step.argtypes = [i32, vp, f64, f64, vp, vp, vp, vp, vp, vp]
     lib.rl_trpo_step.argtypes = [i32, vp, vp, vp, f64, f64, vp, vp, vp]
     lib.rl_line_search_point.argtypes = [i32, vp, vp, f64, vp, vp]
+    lib.rl_line_search_decide.argtypes = [i32, vp, vp, f64, f64, i32, vp, vp, i32, vp, vp, f64, vp, vp]
     lib.rl_adam_step.argtypes = [i32, vp, vp, vp, vp, f64, f64, f64, f64, vp]
     sz = ctypes.c_size_t
     lib.rl_path_scan.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]

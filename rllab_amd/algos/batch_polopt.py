@@ -129,11 +129,19 @@ class BatchPolopt(RLAlgorithm):
             paths = self.sampler.obtain_samples(itr)
             samples_data = self.sampler.process_samples(itr, paths)
             self.log_diagnostics(paths)
-            self.optimize_policy(itr, samples_data)
+            # the next rollout depends on nothing but the updated parameters: an optimizer that decides its line search
+            # on the device calls this hook once the whole update is enqueued (before it reads the outcome), so the
+            # rollout starts the moment the accepted candidate's pass ends; any other optimizer leaves it to the call
+            # below (a no-op after the hook ran at the final parameter version)
+            want_next = itr + 1 < self.n_itr and hasattr(self.sampler, "prefetch") and not self.store_paths \
+                and getattr(self, "prefetch_rollout", True)
+            self._after_update_enqueued = (lambda: self.sampler.prefetch(itr + 1)) if want_next else None
+            try:
+                self.optimize_policy(itr, samples_data)
+            finally:
+                self._after_update_enqueued = None
             D.peer_poll()           # in-stream peer all-reduce (RLLAB_PEER_ALLREDUCE=1): did a peer stop answering?
-            # the next rollout depends on nothing below: start it before the host turns to snapshot and log
-            if itr + 1 < self.n_itr and hasattr(self.sampler, "prefetch") and not self.store_paths \
-                    and getattr(self, "prefetch_rollout", True):
+            if want_next:
                 self.sampler.prefetch(itr + 1)
             logger.log("saving snapshot...")
             params = self.get_itr_snapshot(itr, samples_data)

@@ -36,6 +36,17 @@ def npo_inputs(policy, samples_data):
             traj.advantages.reshape(B), traj.means.reshape(traj.act_dim, B), old_ls, w, (1.0 / cnt))
 
 
+def log_update_path(policy, fused, why=None):
+    """One log line naming where loss / gradient / Fisher-vector products of the update run, and why when it is not
+    the HIP kernels (the autograd path costs 10-20x at the batch sizes this engine samples)."""
+    if fused is not None:
+        logger.log("update path: HIP kernels (%s)" % type(fused).__name__)
+        return
+    if why is None and hasattr(policy, "why_no_kernel_layout"):
+        why = policy.why_no_kernel_layout()
+    logger.log("update path: torch autograd%s" % ("" if why is None else " -- " + why))
+
+
 def pick_optimizer(optimizer, optimizer_args, default_cls, **default_args):
     """The optimizer an NPO variant runs with: the one handed in, else ``default_cls`` built from the
     variant's defaults overridden by ``optimizer_args``."""
@@ -82,6 +93,8 @@ class NPO(BatchPolopt):
         fused = None
         if trunc is None and hasattr(policy, "fused_ops") and getattr(self, "use_fused", True):
             fused = policy.fused_ops()
+        log_update_path(policy, fused, "truncate_local_is_ratio is set (the kernels evaluate the plain likelihood ratio)"
+                        if trunc is not None else None)
         self.optimizer.update_opt(loss=surr_loss, target=policy, leq_constraint=(mean_kl, self.step_size),
                                   inputs=None, constraint_name="mean_kl", fused=fused)
         return dict()
@@ -101,7 +114,12 @@ class NPO(BatchPolopt):
         pre, self._prefetched = getattr(self, "_prefetched", None), None
         all_input_values = pre[1] if pre is not None and pre[0] is samples_data else npo_inputs(self.policy, samples_data)
         if getattr(self.optimizer, "reports_before_values", False):
-            self.optimizer.optimize(all_input_values)
+            # (train_iteration's hook: what to enqueue behind the update before its outcome is read -- the next rollout)
+            self.optimizer._after_enqueue = getattr(self, "_after_update_enqueued", None)
+            try:
+                self.optimizer.optimize(all_input_values)
+            finally:
+                self.optimizer._after_enqueue = None
             loss_before, mean_kl_before = self.optimizer.last_before
         else:
             loss_before = self.optimizer.loss(all_input_values)

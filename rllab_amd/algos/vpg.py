@@ -8,7 +8,7 @@ import torch
 
 import rllab_amd.misc.logger as logger
 from rllab_amd.algos.batch_polopt import BatchPolopt
-from rllab_amd.algos.npo import npo_inputs
+from rllab_amd.algos.npo import log_update_path, npo_inputs
 from rllab_amd.core.serializable import Serializable
 from rllab_amd.optimizers.first_order_optimizer import FirstOrderOptimizer
 from rllab_amd.sampler import dist as D
@@ -47,6 +47,7 @@ class VPG(BatchPolopt, Serializable):
             return float(mean_kl), float(max_kl)
 
         fused = policy.fused_ops() if hasattr(policy, "fused_ops") and getattr(self, "use_fused", True) else None
+        log_update_path(policy, fused)
         if fused is not None:
             def f_kl(inputs):  # noqa: F811  (HIP kernel version of the same statistic)
                 s = fused.loss_stats_host(inputs)      # the evaluation's one host read (shared with loss())

@@ -112,6 +112,41 @@ __global__ void __launch_bounds__(256) line_search_point_kernel(int n, const flo
     if (i < n) theta[i] = (float)((double)prev[i] - ratio * step[i]);
 }
 
+// The accept test of one line-search candidate (conjugate_gradient_optimizer.py:262-274) and, when the search goes on,
+// the next candidate's parameters -- one workgroup, so the decision and the flag it reads are ordered without atomics.
+// state[0] = accepted (0 / 1), state[1] = accepted candidate, state[2 + 4 k ..] = candidate k's folded sums.
+__global__ void __launch_bounds__(CG_THREADS) line_search_decide_kernel(
+        int rows, const double* __restrict__ sums, const double* __restrict__ before, double inv_count, double delta,
+        int candidate, double* __restrict__ state, int32_t* __restrict__ gate, int n, const float* __restrict__ prev,
+        const double* __restrict__ step, double next_ratio, float* __restrict__ theta) {
+    __shared__ int go_on;
+    if (threadIdx.x == 0) {
+        bool accepted = state[0] != 0.0;
+        if (!accepted) {
+            // rows are added in rank order, then scaled: the host path's  h[:, :3].sum(axis=0) * inv
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, mx = -INFINITY, b0 = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                s0 += sums[4 * r]; s1 += sums[4 * r + 1]; s2 += sums[4 * r + 2];
+                mx = fmax(mx, sums[4 * r + 3]);            // (fmax drops a NaN like numpy's max does not -- the max is only logged)
+                b0 += before[4 * r];
+            }
+            double* rec = state + 2 + 4 * candidate;
+            rec[0] = s0; rec[1] = s1; rec[2] = s2; rec[3] = mx;
+            const double loss = -(s0 * inv_count), loss_before = -(b0 * inv_count), kl = s1 * inv_count;
+            if (loss < loss_before && kl <= delta) {       // NaN: false, as in the reference's comparison
+                accepted = true;
+                state[0] = 1.0;
+                state[1] = (double)candidate;
+                *gate = 1;
+            }
+        }
+        go_on = accepted ? 0 : 1;
+    }
+    __syncthreads();
+    if (go_on && next_ratio > 0.0)
+        for (int i = threadIdx.x; i < n; i += CG_THREADS) theta[i] = (float)((double)prev[i] - next_ratio * step[i]);
+}
+
 // One Adam step in Lasagne's form (lasagne.updates.adam, used by FirstOrderOptimizer, first_order_optimizer.py:21-22):
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  theta = (float)(theta - a_t m / (sqrt(v) + eps)),
 //   a_t = lr sqrt(1 - b2^t) / (1 - b1^t) computed by the caller.  float64 arithmetic on the float32 parameters.
@@ -159,6 +194,18 @@ extern "C" int rl_line_search_point(int n, const float* prev, const double* step
     hipLaunchKernelGGL(line_search_point_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, prev,
                        step, ratio, theta);
     return check_launch("line_search_point_kernel");
+}
+
+extern "C" int rl_line_search_decide(int rows, const double* sums, const double* before, double inv_count,
+                                     double max_constraint, int candidate, double* state, int32_t* gate, int n,
+                                     const float* prev, const double* step, double next_ratio, float* theta,
+                                     void* stream) {
+    if (rows <= 0 || !sums || !before || !state || !gate || candidate < 0 ||
+        (next_ratio > 0.0 && (n <= 0 || !prev || !step || !theta)))
+        return set_error(RL_ERR_ARG, "rl_line_search_decide: bad argument");
+    hipLaunchKernelGGL(line_search_decide_kernel, dim3(1), dim3(CG_THREADS), 0, (hipStream_t)stream, rows, sums, before,
+                       inv_count, max_constraint, candidate, state, gate, n, prev, step, next_ratio, theta);
+    return check_launch("line_search_decide_kernel");
 }
 
 extern "C" int rl_cg_init(int n, const double* b, double* x, double* r, double* p, float* p32, double* scal,

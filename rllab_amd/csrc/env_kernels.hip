@@ -1495,9 +1495,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {          //
 // Sums over the 64 lanes of N independent values at once, each left wave-uniform: four rotations inside the rows of 16
 // (every lane of a row then holds the row's sum), then the row sums travel up (row_bcast:15 into rows 1 and 3,
 // row_bcast:31 into rows 2 and 3) and lane 63 is read -- seven issue slots per value with the lane move fused into the
-// add, no LDS.  The values advance in lock step, so a result is never the next instruction's DPP operand (two wait
-// states); with fewer than three values the asm blocks carry the wait themselves (the hazard recogniser does not look
-// inside them).
+// add, no LDS.  The row_ror stages are builtins (the hazard recogniser spaces them); the two row_bcast stages are
+// inline asm, which it does not look into: each is one block that carries its own wait states (see below).
 template <int CTRL>
 __device__ __forceinline__ float dpp_ror_add(float v) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -1512,17 +1511,29 @@ __device__ __forceinline__ void wave_totals_uniform(float* v) {
     for (int k = 0; k < N; ++k) v[k] = dpp_ror_add<0x122>(v[k]);      // row_ror:2
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = dpp_ror_add<0x121>(v[k]);      // row_ror:1
-    // rows outside the row mask keep their value: the fused form of  v + (row enabled ? moved : 0)
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        if (N < 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v[k]));
-        else asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v[k]));
+    // rows outside the row mask keep their value: the fused form of  v + (row enabled ? moved : 0).  A DPP source
+    // written by the previous vector instruction needs two wait states, and the hazard recogniser does not look inside
+    // inline asm: each stage is ONE asm block that opens with its own s_nop 1, so its first add is safe whatever the
+    // scheduler placed in front of the block, and the later adds of a block read registers written before the block
+    // (or, in the second stage, at least N - 1 + 2 slots earlier).  Two issue slots per stage, independent of
+    // compiler version and scheduling flags.
+#define RL_BCAST_STAGE(CTL)                                                                                              \
+    if constexpr (N == 1) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTL : "+v"(v[0]));                          \
+    else if constexpr (N == 2) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTL "\n\tv_add_f32_dpp %1, %1, %1 " CTL \
+                                            : "+v"(v[0]), "+v"(v[1]));                                                   \
+    else if constexpr (N == 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTL "\n\tv_add_f32_dpp %1, %1, %1 " CTL \
+                                            "\n\tv_add_f32_dpp %2, %2, %2 " CTL : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));   \
+    else if constexpr (N == 6) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTL "\n\tv_add_f32_dpp %1, %1, %1 " CTL \
+                                            "\n\tv_add_f32_dpp %2, %2, %2 " CTL "\n\tv_add_f32_dpp %3, %3, %3 " CTL       \
+                                            "\n\tv_add_f32_dpp %4, %4, %4 " CTL "\n\tv_add_f32_dpp %5, %5, %5 " CTL       \
+                                            : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); \
+    else {                                                                                                               \
+        _Pragma("unroll") for (int k = 0; k < N; ++k)                                                                    \
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTL : "+v"(v[k]));                                        \
     }
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        if (N < 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v[k]));
-        else asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v[k]));
-    }
+    RL_BCAST_STAGE("row_bcast:15 row_mask:0xa")
+    RL_BCAST_STAGE("row_bcast:31 row_mask:0xc")
+#undef RL_BCAST_STAGE
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = lane_bcast(v[k], 63);
 }

@@ -95,6 +95,7 @@ struct PolicyBatch {
     float* out_dmean;          // MODE_OUT_TAN: [DA][B] tangent of the output in direction vec
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
+    const int* gate;           // MODE_LOSS: rl_policy_batch.gate -- non-zero word: the launch returns at once
 };
 
 // hidden nonlinearity: tanh (GaussianMLPPolicy, network.py:38-39 default) or rectify (GaussianMLPRegressor /
@@ -121,6 +122,10 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
     constexpr int ACT_ROWS = 2 * HT * 4;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (MODE == MODE_LOSS) {
+        // a line-search candidate enqueued behind an accepted one (rl_line_search_decide): nothing to evaluate
+        if (a.gate != nullptr && *a.gate != 0) return;
+    }
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
     const int lj = lane & 31, lh = lane >> 5;
     float* const fa0 = smem + S::A0;
@@ -823,6 +828,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.obs = g->obs; a.act = g->actions; a.adv = g->advantages;
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
+    a.gate = (MODE == MODE_LOSS) ? g->gate : nullptr;
     const int n_tiles = (a.B + TS - 1) / TS;
     const size_t lds = (size_t)S::TOTAL * sizeof(float);
     if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "policy pass needs %zu B of LDS", lds);

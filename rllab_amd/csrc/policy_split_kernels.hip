@@ -88,13 +88,35 @@ __device__ __forceinline__ float half_sum_swap(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Build-time switches of the round-5 instruction diet (tools/exp/r05_split_variants.sh times each against the other):
+//   RL_SPLIT_DOT2  the residual  a - bf16(a)  of a pair as two v_dot2c_f32_bf16 (packed rounding x (-1, 0) / (0, -1),
+//                  accumulated onto a) instead of two unpack instructions + one packed subtraction: every term is exactly
+//                  representable, so the dot product is the same number (tools/ubench/dot2_residual.hip checks it bit
+//                  for bit on the device, denormal residuals included)
+//   RL_SPLIT_PK    the element-wise stages (tanh derivatives, the output layer's thin products, bias sums) on packed
+//                  f32 instructions, two values per issue slot
+#ifndef RL_SPLIT_DOT2
+#define RL_SPLIT_DOT2 1
+#endif
+#ifndef RL_SPLIT_PK
+#define RL_SPLIT_PK 1
+#endif
+// a - h for a pair a and its packed bf16 rounding h (exact)
+__device__ __forceinline__ f32x2 residual(f32x2 a, bf16x2 h) {
+#if RL_SPLIT_DOT2
+    const bf16x2 e0 = {(__bf16)-1.0f, (__bf16)0.0f}, e1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    return f32x2{__builtin_amdgcn_fdot2_f32_bf16(h, e0, a[0], false), __builtin_amdgcn_fdot2_f32_bf16(h, e1, a[1], false)};
+#else
+    return a - __builtin_convertvector(h, f32x2);
+#endif
+}
 // x = hi + mid + lo, each a bf16: successive round-to-nearest residuals (every subtraction is exact)
 __device__ __forceinline__ void split_pair(float a0, float a1, Parts& out, int j) {
     const f32x2 a = {a0, a1};
     const bf16x2 h = __builtin_convertvector(a, bf16x2);
-    const f32x2 r = a - __builtin_convertvector(h, f32x2);
+    const f32x2 r = residual(a, h);
     const bf16x2 m = __builtin_convertvector(r, bf16x2);
-    const f32x2 l = r - __builtin_convertvector(m, f32x2);
+    const f32x2 l = residual(r, m);
     const bf16x2 q = __builtin_convertvector(l, bf16x2);
     out.p[0][j] = h[0]; out.p[0][j + 1] = h[1];
     out.p[1][j] = m[0]; out.p[1][j + 1] = m[1];
@@ -147,6 +169,24 @@ __device__ __forceinline__ void transpose_inputs(const Parts (&f)[KB0], const bf
         for (int kb = 0; kb < KB0; ++kb) d = mfma16(f[kb].p[p], Idx[kb], d);
         pack_exact(d, out, p);
     }
+}
+
+// registers (2 j, 2 j + 1) of a fragment as one packed value
+__device__ __forceinline__ f32x2 pair_of(const f32x16& v, int j) { return f32x2{v[2 * j], v[2 * j + 1]}; }
+__device__ __forceinline__ void set_pair(f32x16& v, int j, f32x2 p) { v[2 * j] = p[0]; v[2 * j + 1] = p[1]; }
+// out = acc * (1 - h h), element-wise over a fragment (the tanh derivative through the activation itself)
+__device__ __forceinline__ void times_dtanh(const f32x16& acc, const f32x16& h, f32x16& out) {
+#if RL_SPLIT_PK
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x2 hh = pair_of(h, j);
+        const f32x2 d = __builtin_elementwise_fma(-hh, hh, f32x2{1.0f, 1.0f});
+        set_pair(out, j, pair_of(acc, j) * d);
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = acc[r] * (1.0f - h[r] * h[r]);
+#endif
 }
 
 template <int DO, int DA, int WPS>
@@ -347,8 +387,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) acc = mm6(op(kb), Xs[kb], acc);          // dW0^T x + db0
         f32x16 dh0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh0[r] = acc[r] * (1.0f - h0[r] * h0[r]);
+        times_dtanh(acc, h0, dh0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = db1_(r);
 #pragma unroll
@@ -369,12 +408,56 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         stage();
         const float c = wgt * a.inv_count;
         f32x16 dz1;
+        float gmu[DA];
+        f32x16 gz1;
+#if RL_SPLIT_PK
+        // the same sums with two fragment registers per instruction: the per-lane dot products of the output layer run
+        // over register PAIRS (the two partial sums meet at the end), the outer-product and bias accumulators advance in pairs
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 hh = pair_of(h1, j);
+            const f32x2 d = __builtin_elementwise_fma(-hh, hh, f32x2{1.0f, 1.0f});
+            set_pair(dz1, j, d);
+            set_pair(acc, j, pair_of(acc, j) * d);                                // dh1
+        }
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            f32x2 pd = {0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pd = __builtin_elementwise_fma(pair_of(h1, j), f32x2{dW2_(2 * j, k), dW2_(2 * j + 1, k)}, pd);
+                pd = __builtin_elementwise_fma(pair_of(acc, j), f32x2{W2_(2 * j, k), W2_(2 * j + 1, k)}, pd);
+            }
+            const float dmu = db2[k] + half_sum_swap(pd[0] + pd[1]);
+            gmu[k] = c * dmu * fk[k];
+        }
+        if (lh == 0) {
+            wsum += c;
+#pragma unroll
+            for (int k = 0; k < DA; ++k) gb2[k] += gmu[k];
+        }
+        // ---- back-propagation, sample-major ---------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x2 g = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < DA; ++k) {
+                const f32x2 gk = {gmu[k], gmu[k]};
+                g = __builtin_elementwise_fma(f32x2{W2_(2 * j, k), W2_(2 * j + 1, k)}, gk, g);
+                const f32x2 w2 = __builtin_elementwise_fma(pair_of(h1, j), gk, f32x2{gW2l[2 * j][k], gW2l[2 * j + 1][k]});
+                gW2l[2 * j][k] = w2[0]; gW2l[2 * j + 1][k] = w2[1];
+            }
+            const f32x2 gz = g * pair_of(dz1, j);
+            set_pair(gz1, j, gz);
+            const f32x2 b1n = f32x2{gb1l[2 * j], gb1l[2 * j + 1]} + gz;
+            gb1l[2 * j] = b1n[0]; gb1l[2 * j + 1] = b1n[1];
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             dz1[r] = 1.0f - h1[r] * h1[r];
             acc[r] *= dz1[r];                                                     // dh1
         }
-        float gmu[DA];
 #pragma unroll
         for (int k = 0; k < DA; ++k) {
             float pd = 0.0f;
@@ -393,7 +476,6 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         }
 
         // ---- back-propagation, sample-major ---------------------------------------------------------------------------------
-        f32x16 gz1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float g = 0.0f;
@@ -405,6 +487,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             gz1[r] = g * dz1[r];
             gb1l[r] += gz1[r];
         }
+#endif
         stage();
         Parts G1s[2];
         split_frag(gz1, G1s);
@@ -427,8 +510,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             for (int kb = 0; kb < 2; ++kb) gW1 = mm6(H0t[kb], G1t[kb], gW1);      // gW1 += h0^T gz1 (samples are K)
         }
         f32x16 gz0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gz0[r] = acc[r] * (1.0f - h0[r] * h0[r]);
+        times_dtanh(acc, h0, gz0);
         {
             Parts G0s[2], G0t[2], Xt[2];
             split_frag(gz0, G0s);

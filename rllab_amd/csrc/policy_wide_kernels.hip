@@ -74,6 +74,7 @@ struct WideBatch {
                                // them, the Fisher-vector products of the same point read them instead of re-running the
                                // forward chains; null = none.  Per tile 32 (H0 + H1 + H2) floats: [unit, layer after
                                // layer][32 samples], the image of the LDS tiles Hb without their padding column
+    const int* gate;           // WMODE_LOSS: rl_policy_batch.gate -- non-zero word: the launch returns at once
     WideShape s;
 };
 
@@ -288,6 +289,10 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
     constexpr bool TAN = wmode_tan(MODE), OUTMODE = wmode_out(MODE), BWD = (MODE == WMODE_BWD);
     const WideShape& s = a.s;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (MODE == WMODE_LOSS) {
+        // a line-search candidate enqueued behind an accepted one (rl_line_search_decide): nothing to evaluate
+        if (a.gate != nullptr && *a.gate != 0) return;
+    }
     const WideLds p = wide_lds(s, MODE);
     // the wavefront index as a SCALAR (readfirstlane): everything derived from it -- tile ownership, operand image
     // pointers, k-ranges -- then lives in scalar registers and is computed by the scalar unit
@@ -883,6 +888,7 @@ static int launch_wide(const WideShape& s, const rl_policy_batch* g, const float
     a.out_mean = planes ? planes->out_mean : nullptr;
     a.out_dmean = planes ? planes->out_dmean : nullptr;
     a.cache = (MODE == WMODE_GRAD || MODE == WMODE_FVP) ? g->activations : nullptr;
+    a.gate = (MODE == WMODE_LOSS) ? g->gate : nullptr;
     const int n_tiles = (a.B + 31) / 32;
     const WideLds p = wide_lds(s, MODE);
     const size_t lds = (size_t)p.total * sizeof(float);

@@ -16,6 +16,8 @@ Differences, all below the numeric contract:
     global sample count, so one sum all-reduce (RCCL) per evaluation makes the
     sharded run identical to the single-process one.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -136,6 +138,10 @@ class ConjugateGradientOptimizer(Serializable):
             hvp_approach = PerlmutterHvp(num_slices)
         self._hvp_approach = hvp_approach
         self._fused = None
+        # fused device CG only: how many line-search candidates are decided on the device before the host looks
+        # (0 = the host decides after every candidate); RLLAB_DEVICE_LINE_SEARCH overrides (A/B timing)
+        self._device_line_search = int(os.environ.get("RLLAB_DEVICE_LINE_SEARCH", "3"))
+        self._after_enqueue = None   # called once the whole update is enqueued and before its outcome is read
         self.last_backtrack_iters = None
         self.last_before = None      # (loss, constraint value) at the parameters optimize() started from
 
@@ -294,7 +300,29 @@ class ConjugateGradientOptimizer(Serializable):
         n_iter = 0
         loss = constraint_val = float("nan")
         loss_before = None
-        for n_iter, ratio in enumerate(self._backtrack_ratio ** np.arange(self._max_backtracks)):
+        ratios = self._backtrack_ratio ** np.arange(self._max_backtracks)
+        first = 0
+        accepted = False
+        n_spec = min(int(getattr(self, "_device_line_search", 3)), self._max_backtracks)
+        if (step_vec is not None and n_spec > 0 and hasattr(self._fused, "line_search_device")
+                and getattr(before, "record", None) is not None and before.record.get("rows") is not None):
+            # the first candidates decided on the device: nothing between the CG launches and the end of the search
+            # waits for the host, and ``_after_enqueue`` (the next rollout, set by the algorithm) is queued behind the
+            # search before its outcome is read.  In the rare case that none of them is accepted the loop below
+            # goes on from candidate n_spec exactly as the reference does (and the speculative rollout is discarded by
+            # the sampler: the parameter version it was launched at is gone).
+            rec = self._fused.line_search_device(inputs, full_prev, step_vec, ratios[:n_spec],
+                                                 self._max_constraint_val, before.record)
+            hook = getattr(self, "_after_enqueue", None)
+            if hook is not None:
+                hook()
+            loss_before, constraint_before = before()
+            k_acc, evals = self._fused.line_search_resolve(rec, inputs)
+            accepted = k_acc is not None
+            n_iter = k_acc if accepted else n_spec - 1
+            loss, constraint_val = evals[n_iter]
+            first = n_spec
+        for n_iter, ratio in (() if accepted else list(enumerate(ratios))[first:]):
             if step_vec is not None:
                 self._fused.line_search_point(full_prev, step_vec, float(ratio))   # prev - ratio * step, in place
             else:

@@ -103,7 +103,8 @@ class FusedGaussianMLPOps(object):
     def _loss_record(self, tag, out, inv):
         """Cache entry of one loss / KL evaluation whose four per-rank sums are in ``out`` (device); starts the
         host read.  Sharded: ONE all-gather of the four numbers, folded on the host (sum of three, max of one)."""
-        c = dict(tag=tag, out=out, inv=inv, dev=None, read=read_async(D.all_gather_rows(out)), host=None)
+        rows = D.all_gather_rows(out)            # [world, 4], kept: the device-side line search compares against them
+        c = dict(tag=tag, out=out, rows=rows, inv=inv, dev=None, read=read_async(rows), host=None)
         self._loss_cache = c
         return c
 
@@ -162,6 +163,7 @@ class FusedGaussianMLPOps(object):
         def get():
             s = self._resolve(c)
             return -s[0], s[1]
+        get.record = c          # (the sums still on the device: line_search_device compares candidates with them there)
         return get
 
     def _eval_point(self, inputs):
@@ -378,6 +380,65 @@ class FusedGaussianMLPOps(object):
                                                  _lib.ptr(theta.detach()), _lib.stream_ptr()),
                    "rl_line_search_point")
         self._epoch += 1
+
+    # -- the backtracking line search decided on the device (conjugate_gradient_optimizer.py:262-274) -----------------
+    def line_search_device(self, inputs, prev32, step, ratios, max_constraint, before_record):
+        """Enqueue the first ``len(ratios)`` candidates of the line search WITHOUT a host read in between:
+        candidate k's parameters, its loss / KL pass, and rl_line_search_decide (accept test
+        ``loss < loss_before and kl <= max_constraint`` against ``before_record``'s sums; writes candidate k + 1's
+        parameters only if nothing has been accepted yet).  Once a candidate is accepted the later loss passes return
+        at once (rl_policy_batch.gate) and the parameters stay at the accepted point, so whatever the caller enqueues
+        next -- the next rollout -- already runs on the updated policy.  Returns a record for ``line_search_resolve``;
+        nothing here waits for the device.  Sharded: the candidate's sums are all-gathered like every loss evaluation,
+        each rank folds the same rows in the same order and takes the same decision."""
+        b, keep, inv = self._batch(inputs)
+        dev = keep[0].device
+        ws = self._workspace(dev)
+        K = len(ratios)
+        theta = self.policy.flat_params.detach()
+        assert prev32.dtype == torch.float32 and step.dtype == torch.float64 and theta.is_contiguous() and K >= 1
+        buf = getattr(self, "_ls_buf", None)
+        if buf is None or buf.numel() != 3 + 4 * K or buf.device != dev:
+            buf = self._ls_buf = torch.empty(3 + 4 * K, dtype=torch.float64, device=dev)
+        buf.zero_()
+        state, gate = buf[:2 + 4 * K], buf[2 + 4 * K:].view(torch.int32)      # {accepted, index, K x 4 sums} | gate word
+        outs = torch.empty((K, 4), dtype=torch.float64, device=dev)
+        n, st = theta.numel(), _lib.stream_ptr()
+        brows = before_record["rows"]
+        _lib.check(_lib.lib.rl_line_search_point(n, _lib.ptr(prev32), _lib.ptr(step), float(ratios[0]), _lib.ptr(theta),
+                                                 st), "rl_line_search_point")
+        self._epoch += 1
+        b.gate = gate.data_ptr()
+        try:
+            for k in range(K):
+                self.layout.theta()              # padded layouts: the kernels' copy follows the candidate
+                _lib.check(_lib.lib.rl_policy_loss_kl(ctypes.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(outs[k]),
+                                                      st), "rl_policy_loss_kl")
+                rows = D.all_gather_rows(outs[k])
+                nxt = float(ratios[k + 1]) if k + 1 < K else 0.0
+                _lib.check(_lib.lib.rl_line_search_decide(
+                    rows.shape[0], _lib.ptr(rows), _lib.ptr(brows), inv, float(max_constraint), k, _lib.ptr(state),
+                    _lib.ptr(gate), n, _lib.ptr(prev32), _lib.ptr(step), nxt, _lib.ptr(theta), st),
+                    "rl_line_search_decide")
+                self._epoch += 1                 # (the parameters MAY have moved: every cache keyed on them steps on)
+        finally:
+            b.gate = None
+        return dict(read=read_async(state), K=K, inv=inv)
+
+    def line_search_resolve(self, rec, inputs):
+        """Host side of ``line_search_device``: ONE read.  Returns (accepted candidate or None, [(loss, kl)] of the
+        candidates that were evaluated).  The accepted candidate's sums become the loss record of the current
+        parameters, so the LossAfter / MeanKL the algorithm logs next cost no pass."""
+        h = rec["read"].get()
+        K, inv = rec["K"], rec["inv"]
+        accepted = int(h[1]) if h[0] != 0.0 else None
+        n_eval = K if accepted is None else accepted + 1
+        sums = h[2:2 + 4 * K].reshape(K, 4)
+        evals = [(-(sums[k, 0] * inv), sums[k, 1] * inv) for k in range(n_eval)]
+        last = n_eval - 1                        # the parameters are at this candidate now
+        host = (float(sums[last, 0] * inv), float(sums[last, 1] * inv), float(sums[last, 2] * inv), float(sums[last, 3]))
+        self._loss_cache = dict(tag=self._eval_point(inputs), out=None, rows=None, inv=inv, dev=None, read=None, host=host)
+        return accepted, [(float(l), float(c)) for l, c in evals]
 
     def hvp_approach(self):
         return FusedFisherHvp(self)

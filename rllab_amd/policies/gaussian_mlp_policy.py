@@ -134,6 +134,31 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
             self._kernel_layout = KernelLayout(self) if ok else None
         return self._kernel_layout
 
+    def why_no_kernel_layout(self):
+        """One sentence naming what keeps this policy off the fused kernels (``kernel_layout() is None``), or None.
+        The sampler and the algorithms log it once, so that a 5-20x slower path is never taken silently."""
+        if self.kernel_layout() is not None:
+            return None
+        from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM, padded_sizes
+        hs = tuple(int(h) for h in self.hidden_sizes)
+        if self.state_dependent_std:
+            return "the log-std is a network (adaptive_std / std_network): the two-network kernels apply instead"
+        if self.hidden_nonlinearity is not tanh:
+            return "hidden_nonlinearity is %s (the kernels evaluate tanh layers)" % getattr(
+                self.hidden_nonlinearity, "__name__", repr(self.hidden_nonlinearity))
+        if self.output_nonlinearity is not None:
+            return "output_nonlinearity is not None (the kernels' output layer is linear)"
+        if padded_sizes(hs) is None:
+            if len(hs) not in (2, 3):
+                return "hidden_sizes=%r has %d hidden layer(s) (the kernels run two or three)" % (hs, len(hs))
+            return "hidden_sizes=%r has a layer wider than 128 units" % (hs,)
+        if not self.flat_params.is_cuda or self.flat_params.dtype != torch.float32:
+            return "the parameters are not float32 on a HIP device"
+        if self.obs_dim > MAX_OBS_DIM or self.action_dim > MAX_ACT_DIM:
+            return "obs_dim %d / action_dim %d exceed the kernels' %d / %d" % (self.obs_dim, self.action_dim, MAX_OBS_DIM,
+                                                                             MAX_ACT_DIM)
+        return "no kernel layout"
+
     def rollout_networks(self):
         """For a policy with a log-std NETWORK (adaptive_std / std_network) whose two networks the rollout kernels take
         -- two or three tanh hidden layers of at most 128 units each (zero-padded to 32 / 64 / 128 per layer), linear

@@ -50,6 +50,39 @@ class VectorizedSampler(BaseSampler):
             kw["seed"] = self.seed
         self.vec_env = algo.env.vec_env_executor(**kw)
         self.n_envs = n_envs
+        name, why = self.sampling_path(algo.policy)
+        logger.log("sampling path: %s%s" % (name, "" if why is None else " -- " + why))
+
+    def sampling_path(self, policy):
+        """(name, reason) of the way ``obtain_samples`` will sample ``policy`` on this executor: the fused rollout (one
+        launch per batch), or one of the per-transition loops (5-20x slower at thousands of envs) and WHY the fused
+        kernels do not take it -- logged once by ``start_worker``; tools/exp/fallback_probe.py prints it per option."""
+        ve = self.vec_env
+        if self._takes_fused_rollout(policy):
+            return "fused rollout kernel (one launch per batch of %d envs)" % ve.n, None
+        if ve is None:
+            return "none (no executor yet)", None
+        if not getattr(ve, "graphable", True):
+            why = "the env wrapper keeps running observation / reward estimates (NormalizedEnv(normalize_obs / " \
+                  "normalize_reward)) that change every step"
+        elif ve.position_ids is not None:
+            why = "Box2DEnv(position_only=True): the fused rollout feeds the policy the full observation"
+        else:
+            layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
+            dual = policy.rollout_networks() if hasattr(policy, "rollout_networks") else None
+            if layout is not None or dual is not None:
+                why = "the policy's weight fragments do not fit the 160 KB LDS of a CU next to this env's observation tile"
+            elif getattr(policy, "state_dependent_std", False):
+                why = "the policy's two networks have no rollout kernel (each: two or three tanh layers of at most 128 units)"
+            elif hasattr(policy, "why_no_kernel_layout"):
+                why = policy.why_no_kernel_layout()
+            else:
+                why = "%s is not a GaussianMLPPolicy" % type(policy).__name__
+        graph = self.use_graph and getattr(ve, "graphable", True) and not os.environ.get("RLLAB_NO_GRAPH") \
+            and hasattr(policy, "recorded_log_std")
+        name = "per-transition loop (%s), one policy evaluation + one env-step launch per step" % (
+            "hipGraph replay" if graph else "eager")
+        return name, why
 
     def shutdown_worker(self):
         if self.vec_env is not None:
@@ -81,10 +114,11 @@ class VectorizedSampler(BaseSampler):
         asynchronous launch: for any other policy (no version to check, or the host-bound per-transition loop,
         where nothing overlaps) this is a no-op, never a rollout that would be thrown away.
         ``BatchPolopt(prefetch_rollout=False)`` turns it off altogether."""
-        if getattr(self, "_prefetched", None) is not None and self._prefetched[0] == itr:
-            return
-        self._prefetched = None
         policy = self.algo.policy
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None and pre[0] == itr and hasattr(policy, "param_version") and pre[1] == policy.param_version():
+            return                               # already queued at these very parameters
+        self._prefetched = None                  # (a batch launched at parameters that have moved on is dropped here)
         if not hasattr(policy, "param_version") or not self._takes_fused_rollout(policy):
             return
         t_keep = self.last_sample_time          # the enqueue of the NEXT batch is not this iteration's sample time

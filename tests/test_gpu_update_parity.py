@@ -309,6 +309,104 @@ def test_trpo_step_and_line_search_point_kernels():
     assert float(out[1]) == 1.0 and np.array_equal(step.cpu().numpy(), x)
 
 
+@pytest.mark.parametrize("case", ["plain", "many_backtracks", "all_rejected", "padded_net", "hook"])
+def test_line_search_decided_on_the_device_is_the_host_search(quiet_logger, case):
+    """rl_line_search_decide (K = 3 candidates enqueued without a host read, later passes gated off) against the host
+    loop of conjugate_gradient_optimizer.py:262-296: the same accepted candidate, bit-identical parameters, the same
+    ``backtrack_iters``, the same LossAfter / MeanKL, also when more than K candidates are needed (the host loop takes
+    over at candidate K), when every candidate is rejected (parameters restored), and for a zero-padded layout (the
+    kernels' parameter copy has to follow each candidate).  ``hook``: the callback that queues the next rollout runs
+    exactly once, after the search is enqueued, and sees the FINAL parameters."""
+    from rllab_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+
+    def run(n_device):
+        np.random.seed(4)
+        if case == "padded_net":
+            spec = EnvSpec(Box(-np.ones(13), np.ones(13)), Box(-np.ones(2), np.ones(2)))
+            pol = GaussianMLPPolicy(spec, hidden_sizes=(24, 20))
+            pol.set_param_values(pol.get_param_values() + 0.1 * np.random.randn(pol.get_param_values().size))
+        else:
+            pol = _policy(13, 2, 32)
+        inp = _inputs(pol, 20000, old_equals_new=True, ragged=True)
+        surr, kl, _ = _closures(pol)
+        kw = {}
+        delta = 0.01
+        if case == "all_rejected":
+            kw = dict(backtrack_ratio=0.999, max_backtracks=5)
+        opt = ConjugateGradientOptimizer(**kw)
+        opt._device_line_search = n_device
+        ops = pol.fused_ops()
+        assert ops is not None
+        opt.update_opt(loss=surr, target=pol, leq_constraint=(kl, delta), fused=ops)
+        if case in ("many_backtracks", "all_rejected"):
+            # inflate the initial step threefold: KL ~ 9 delta ratio^2, so 0.8^k has to fall below 1/3 (k = 5) -- or never does
+            orig = ops.cg_step_vector
+
+            def big(*a, **k):
+                step, stats = orig(*a, **k)
+                return step * 3.0, stats
+            ops.cg_step_vector = big
+        seen = []
+        if case == "hook":
+            opt._after_enqueue = lambda: seen.append(pol.flat_params.detach().clone())
+        theta0 = pol.flat_params.detach().clone()
+        opt.optimize(inp)
+        after = pol.flat_params.detach().clone()
+        out = dict(after=after, n=opt.last_backtrack_iters, before=opt.last_before, loss=opt.loss(inp),
+                   kl=opt.constraint_val(inp), moved=not torch.equal(after, theta0), seen=seen)
+        return out
+    dev, host = run(3), run(0)
+    assert torch.equal(dev["after"], host["after"])
+    assert dev["n"] == host["n"] and dev["before"] == host["before"]
+    assert dev["loss"] == host["loss"] and dev["kl"] == host["kl"]
+    if case == "plain":
+        assert dev["moved"] and dev["n"] <= 2
+    if case == "many_backtracks":
+        assert dev["moved"] and dev["n"] >= 3, dev["n"]           # the host loop had to take over behind the device's three
+    if case == "all_rejected":
+        assert not dev["moved"] and dev["n"] == 4
+    if case == "hook":
+        assert len(dev["seen"]) == 1 and torch.equal(dev["seen"][0], dev["after"]) and host["seen"] == []
+
+
+def test_line_search_decide_kernel_by_hand():
+    """rl_line_search_decide on hand-made sums: rows folded in rank order, NaN never accepted, `<` on the loss and `<=`
+    on the constraint (conjugate_gradient_optimizer.py:272), later candidates leave an accepted state alone, the next
+    candidate's parameters are written only while nothing is accepted."""
+    from rllab_amd import _lib
+    dev = "cuda"
+    n = 5
+    prev = torch.arange(n, dtype=torch.float32, device=dev)
+    step = torch.ones(n, dtype=torch.float64, device=dev)
+    theta = torch.full((n,), -7.0, dtype=torch.float32, device=dev)
+    before = torch.tensor([[2.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]], dtype=torch.float64, device=dev)   # loss_before = -3 inv
+    inv, delta = 0.5, 0.01
+
+    def decide(state, gate, sums, k, nxt):
+        t = torch.tensor(sums, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib.rl_line_search_decide(t.shape[0], _lib.ptr(t), _lib.ptr(before), inv, delta, k, _lib.ptr(state),
+                                                  _lib.ptr(gate), n, _lib.ptr(prev), _lib.ptr(step), nxt, _lib.ptr(theta),
+                                                  _lib.stream_ptr()))
+    state = torch.zeros(2 + 4 * 4, dtype=torch.float64, device=dev)
+    gate = torch.zeros(1, dtype=torch.int32, device=dev)
+    decide(state, gate, [[2.0, 0.0, 1.0, 0.1], [1.0, 0.0, 1.0, 0.3]], 0, 0.5)       # equal loss: not `<` -> rejected
+    assert state[0] == 0 and gate[0] == 0 and torch.equal(theta, (prev.double() - 0.5).float())
+    assert state[2:6].tolist() == [3.0, 0.0, 2.0, 0.3]
+    decide(state, gate, [[float("nan"), 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]], 1, 0.25)   # NaN loss: rejected
+    assert state[0] == 0 and torch.equal(theta, (prev.double() - 0.25).float())
+    decide(state, gate, [[3.0, 0.03, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]], 2, 0.125)   # better loss, kl = 0.015 > delta: rejected
+    assert state[0] == 0 and torch.equal(theta, (prev.double() - 0.125).float())
+    decide(state, gate, [[3.0, 0.02, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]], 3, 0.0625)  # kl = 0.01 == delta: `<=` accepts
+    assert state[0] == 1 and state[1] == 3 and gate[0] == 1
+    assert torch.equal(theta, (prev.double() - 0.125).float())                      # the accepted point stays
+    keep = state.clone()
+    decide(state, gate, [[9.0, 0.0, 0.0, 0.0], [9.0, 0.0, 0.0, 0.0]], 2, 0.5)       # behind an accepted candidate: untouched
+    assert torch.equal(state, keep) and torch.equal(theta, (prev.double() - 0.125).float())
+
+
 def test_deferred_reads_give_the_same_numbers(quiet_logger):
     """The optimizer's asynchronous reads change when the host waits, not what it reads:
     last_before == loss / constraint evaluated up front, loss()/constraint_val() after the step come
