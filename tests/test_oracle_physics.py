@@ -153,6 +153,39 @@ def test_cartpole_island_solver_tracks_analytic_equations_of_motion():
     assert np.abs(o - s).max() < 0.05 and abs(o[0]) > 0.2          # still tracking after 0.5 s
 
 
+@pytest.mark.parametrize("x", [0.12, -0.12, 0.06, 0.01])
+def test_cartpole_open_hinge_at_reset_what_box2d_does_with_it(x):
+    """Decides the default of ``CartpoleEnv.reset`` (cartpole_env.py:28-43 moves the cart by up to +-0.12 m and leaves the
+    pole body at the XML pose: the revolute joint starts open by |x|).  An INDEPENDENT numpy restatement of Box2D 2.3's
+    published b2RevoluteJoint / b2PrismaticJoint::SolvePositionConstraints (oracle/np_box2d_joints.py, three position
+    iterations, joint order revolute -> prismatic) closes the gap mostly by SWINGING the light pole: 1.447 rad per
+    metre, 0.1737 rad of the 0.2 rad termination limit for the largest reset offset -- and the product's hand-restated
+    island solver (csrc/dyn_cartpole.h, host build, float64) lands on the same pole angle and cart position after its
+    first step (zero action, zero velocities; the velocity phase contributes nothing at theta = 0).  So the literal
+    reading of the reference at HEAD is what the default implements, the ~9 % of episodes that end within two steps are
+    Box2D's published arithmetic, and the documented itr-0 log (MinReturn 19.99: no such episode among 1278) cannot have
+    come from this reset code + Box2D 2.3 -- it predates it or ran another pybox2d; ``reset_pole_follows_cart=True``
+    stays the opt-in that reproduces that log (tests/test_gpu_reference_pins.py)."""
+    from oracle import np_box2d_joints as J
+    theta, cart_x, gap = J.cartpole_first_position_solve(x)
+    assert abs(theta / x - 1.45) < 0.012 and gap < 2e-4           # the hinge is closed (to the solver's slop) by rotation
+    if abs(x) == 0.12:
+        assert 0.17 < abs(theta) < 0.2                               # inside the limit after ONE step, at its edge
+    env = H.HostEnv(0, np.float64, normalize=False, cfg={})
+    u = 0.5 + x / 0.24                                             # reset draw that puts the cart at x (bounds +-0.12)
+    env.reset(np.array([u, 0.5, 0.5, 0.5], np.float32))
+    assert abs(env.observe()[0] - x) < 1e-7 and env.observe()[2] == 0.0
+    o, _, done = env.step(np.zeros(1, np.float32))
+    assert not done
+    assert abs(o[2] - theta) <= 2e-6 * max(1.0, abs(theta) / 0.1)   # pole angle: product == independent restatement
+    assert abs(o[0] - cart_x) <= 2e-6
+    # with the hinge closed at reset nothing swings
+    env2 = H.HostEnv(0, np.float64, normalize=False, cfg=dict(flags=H.CFG_POLE_FOLLOWS_CART))
+    env2.reset(np.array([u, 0.5, 0.5, 0.5], np.float32))
+    o2, _, _ = env2.step(np.zeros(1, np.float32))
+    assert abs(o2[2]) < 1e-9 and abs(o2[0] - x) < 1e-7
+
+
 def test_cartpole_reward_done_and_reset_contract():
     e = H.HostEnv(0, np.float64, normalize=True)
     o = e.reset(np.array([0.0, 1.0, 0.5, 0.25]))
