@@ -68,8 +68,30 @@ struct Args {
 
 struct Parts { bf16x8 p[3]; };                 // hi, mid, lo of eight values
 
+// Timing ablations (WRONG results, the rest of the instruction stream unchanged; tools/exp/r05_split_ablations.sh):
+//   RL_ABL_MFMA   no matrix instructions (operands and accumulator stay live through an empty asm)
+//   RL_ABL_SPLIT  no split arithmetic (the parts are left undefined)
+//   RL_ABL_FETCH  no per-tile global loads (the first tile's inputs are reused)
+//   RL_ABL_OPS    the loop-invariant operands are not re-read from LDS per use
+#ifndef RL_ABL_MFMA
+#define RL_ABL_MFMA 0
+#endif
+#ifndef RL_ABL_SPLIT
+#define RL_ABL_SPLIT 0
+#endif
+#ifndef RL_ABL_FETCH
+#define RL_ABL_FETCH 0
+#endif
+#ifndef RL_ABL_OPS
+#define RL_ABL_OPS 0
+#endif
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+#if RL_ABL_MFMA
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 // c += A B to f32 accuracy: the six cross terms, smallest first
 __device__ __forceinline__ f32x16 mm6(const Parts& A, const Parts& B, f32x16 c) {
@@ -102,9 +124,19 @@ __device__ __forceinline__ float half_sum_swap(float v) {
 #define RL_SPLIT_PK 1
 #endif
 // a - h for a pair a and its packed bf16 rounding h (exact)
+// The two selectors (-1, 0) and (0, -1) travel in REGISTERS: handed to the instruction as a constant, (-1, 0) is encoded as
+// the inline constant "-1.0", which the VOP2 form of v_dot2c_f32_bf16 reads as the f32 pattern 0xbf800000 = (0, -1) --
+// measured on the device (tools/ubench/dot2_residual.hip, first build: every low component wrong); an asm-opaque
+// register operand leaves the assembler nothing to encode.
+// (a pure asm: identical instances are merged and hoisted out of the tile loop -- two registers per wavefront)
+__device__ __forceinline__ bf16x2 dot2_selector(unsigned bits) {
+    unsigned v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(bits));
+    return __builtin_bit_cast(bf16x2, v);
+}
 __device__ __forceinline__ f32x2 residual(f32x2 a, bf16x2 h) {
 #if RL_SPLIT_DOT2
-    const bf16x2 e0 = {(__bf16)-1.0f, (__bf16)0.0f}, e1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    const bf16x2 e0 = dot2_selector(0x0000bf80u), e1 = dot2_selector(0xbf800000u);
     return f32x2{__builtin_amdgcn_fdot2_f32_bf16(h, e0, a[0], false), __builtin_amdgcn_fdot2_f32_bf16(h, e1, a[1], false)};
 #else
     return a - __builtin_convertvector(h, f32x2);
@@ -112,6 +144,17 @@ __device__ __forceinline__ f32x2 residual(f32x2 a, bf16x2 h) {
 }
 // x = hi + mid + lo, each a bf16: successive round-to-nearest residuals (every subtraction is exact)
 __device__ __forceinline__ void split_pair(float a0, float a1, Parts& out, int j) {
+#if RL_ABL_SPLIT
+    {
+        unsigned h, m, q;
+        asm volatile("" : "=v"(h), "=v"(m), "=v"(q) : "v"(a0), "v"(a1));
+        const bf16x2 hh = __builtin_bit_cast(bf16x2, h), mm = __builtin_bit_cast(bf16x2, m), qq = __builtin_bit_cast(bf16x2, q);
+        out.p[0][j] = hh[0]; out.p[0][j + 1] = hh[1];
+        out.p[1][j] = mm[0]; out.p[1][j + 1] = mm[1];
+        out.p[2][j] = qq[0]; out.p[2][j + 1] = qq[1];
+        return;
+    }
+#endif
     const f32x2 a = {a0, a1};
     const bf16x2 h = __builtin_convertvector(a, bf16x2);
     const f32x2 r = residual(a, h);
@@ -299,7 +342,14 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         }
     }
     if constexpr (TAIL_LDS) __syncthreads();
+#if RL_ABL_OPS
+    Parts abl_op;
+    for (int p = 0; p < 3; ++p) abl_op.p[p] = *reinterpret_cast<const bf16x8*>(ops + (p * WV + lane) * 16);
+#endif
     auto op = [&](int o) -> Parts {
+#if RL_ABL_OPS
+        if (o >= 0) { Parts t = abl_op; asm volatile("" : "+v"(t.p[0]), "+v"(t.p[1]), "+v"(t.p[2])); return t; }
+#endif
         if constexpr (INV_LDS) {
             Parts t;
 #pragma unroll
@@ -362,8 +412,12 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the landing zone is in registers before it is refilled
         {   // the wavefront's last tile prefetches itself again (no branch in the loop body)
             const int nxt = tile + waves_total < n_tiles ? tile + waves_total : tile;
+#if !RL_ABL_FETCH
             fetch(nxt, xb_next, wgt_next);
             fetch_acts(nxt);
+#else
+            (void)nxt;
+#endif
         }
         // the output layer's rows of this lane half, read where they are used (two wavefronts per SIMD: from LDS)
         const float* tv = tailv + lh * TAILV;

@@ -304,7 +304,7 @@ class ConjugateGradientOptimizer(Serializable):
         first = 0
         accepted = False
         n_spec = min(int(getattr(self, "_device_line_search", 3)), self._max_backtracks)
-        if (step_vec is not None and n_spec > 0 and hasattr(self._fused, "line_search_device")
+        if (step_vec is not None and n_spec > 0 and getattr(self._fused, "device_line_search", False)
                 and getattr(before, "record", None) is not None and before.record.get("rows") is not None):
             # the first candidates decided on the device: nothing between the CG launches and the end of the search
             # waits for the host, and ``_after_enqueue`` (the next rollout, set by the algorithm) is queued behind the

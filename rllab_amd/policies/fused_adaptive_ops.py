@@ -55,6 +55,10 @@ def _net_ok(net, obs_dim, act_dim):
 
 
 class FusedAdaptiveStdOps(FusedGaussianMLPOps):
+    # its loss evaluation is a chain of launches over two networks (no single rl_policy_loss_kl to gate): the host reads
+    # every line-search candidate, as the reference does
+    device_line_search = False
+
     @staticmethod
     def supported(policy):
         if not getattr(policy, "state_dependent_std", False) or not policy.flat_params.is_cuda \

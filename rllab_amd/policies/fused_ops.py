@@ -17,6 +17,8 @@ from rllab_amd.sampler import dist as D
 
 
 class FusedGaussianMLPOps(object):
+    device_line_search = True    # line_search_device / line_search_resolve are available (ConjugateGradientOptimizer asks)
+
     def __init__(self, policy):
         self.policy = policy
         self.layout = policy.kernel_layout()

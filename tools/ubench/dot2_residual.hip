@@ -15,7 +15,13 @@
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-__global__ void split_both(const float* a, int n, float* sub, float* dot) {
+__device__ __forceinline__ bf16x2 sel(unsigned bits) {
+    unsigned v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(bits));
+    return __builtin_bit_cast(bf16x2, v);
+}
+
+__global__ void split_both(const float* a, int n, float* sub, float* dot, float* cst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * i + 1 >= n) return;
     const f32x2 v = {a[2 * i], a[2 * i + 1]};
@@ -24,8 +30,13 @@ __global__ void split_both(const float* a, int n, float* sub, float* dot) {
     const f32x2 r = v - __builtin_convertvector(h, f32x2);
     const bf16x2 m = __builtin_convertvector(r, bf16x2);
     const f32x2 l = r - __builtin_convertvector(m, f32x2);
-    // dot form
-    const bf16x2 e0 = {(__bf16)-1.0f, (__bf16)0.0f}, e1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    // dot form, the two selectors handed over as CONSTANTS: the compiler encodes (-1, 0) as the inline constant "-1.0",
+    // which the VOP2 instruction reads as (0, -1) -- the .x results of this form are wrong (kept: it is the finding)
+    const bf16x2 c0 = {(__bf16)-1.0f, (__bf16)0.0f}, c1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    const f32x2 rc = {__builtin_amdgcn_fdot2_f32_bf16(h, c0, v[0], false), __builtin_amdgcn_fdot2_f32_bf16(h, c1, v[1], false)};
+    cst[2 * i + 0] = rc[0]; cst[2 * i + 1] = rc[1];
+    // dot form, selectors in registers (what policy_split_kernels.hip does)
+    const bf16x2 e0 = sel(0x0000bf80u), e1 = sel(0xbf800000u);
     const f32x2 rd = {__builtin_amdgcn_fdot2_f32_bf16(h, e0, v[0], false), __builtin_amdgcn_fdot2_f32_bf16(h, e1, v[1], false)};
     const bf16x2 md = __builtin_convertvector(rd, bf16x2);
     const f32x2 ld = {__builtin_amdgcn_fdot2_f32_bf16(md, e0, rd[0], false), __builtin_amdgcn_fdot2_f32_bf16(md, e1, rd[1], false)};
@@ -41,7 +52,7 @@ __global__ void __launch_bounds__(64) stage_time(float* out, uint64_t* cyc, int 
     f32x2 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = f32x2{threadIdx.x * 1e-3f + 1.f + j, 2.f + j};
-    const bf16x2 e0 = {(__bf16)-1.0f, (__bf16)0.0f}, e1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    const bf16x2 e0 = sel(0x0000bf80u), e1 = sel(0xbf800000u);
     const f32x2 big = {300.0f, 300.0f};
     unsigned acc = 0;
     const uint64_t t0 = __builtin_readcyclecounter();
@@ -90,10 +101,10 @@ int main() {
         if (i % 103 == 0) { uint32_t b; memcpy(&b, &v, 4); b &= 0xffff0000u; memcpy(&v, &b, 4); }   // already a bf16
         a[i] = v;
     }
-    float *da, *ds, *dd;
-    hipMalloc(&da, n * 4); hipMalloc(&ds, 2 * n * 4); hipMalloc(&dd, 2 * n * 4);
+    float *da, *ds, *dd, *dc;
+    hipMalloc(&da, n * 4); hipMalloc(&ds, 2 * n * 4); hipMalloc(&dd, 2 * n * 4); hipMalloc(&dc, n * 4);
     hipMemcpy(da, a.data(), n * 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(split_both, dim3(n / 2 / 256), dim3(256), 0, 0, da, n, ds, dd);
+    hipLaunchKernelGGL(split_both, dim3(n / 2 / 256), dim3(256), 0, 0, da, n, ds, dd, dc);
     std::vector<float> hs(2 * n), hd(2 * n);
     hipMemcpy(hs.data(), ds, 2 * n * 4, hipMemcpyDeviceToHost);
     hipMemcpy(hd.data(), dd, 2 * n * 4, hipMemcpyDeviceToHost);
@@ -103,6 +114,16 @@ int main() {
         const bool den = hs[i] != 0.0f && fabsf(hs[i]) < 1.17549435e-38f;
         denorm_cases += den;
         if (x != y && !(hs[i] == 0.0f && hd[i] == 0.0f)) { ++bad; bad_denorm += den; if (bad <= 5) printf("mismatch %d: sub %a dot %a (a = %a)\n", i, hs[i], hd[i], a[(i / 4) * 2 + (i & 1)]); }
+    }
+    {   // the constant-operand form against the subtraction form (first residual only)
+        std::vector<float> hc(n);
+        hipMemcpy(hc.data(), dc, n * 4, hipMemcpyDeviceToHost);
+        long bx = 0, by = 0;
+        for (int i = 0; i < n / 2; ++i) {
+            bx += memcmp(&hc[2 * i], &hs[4 * i], 4) != 0 && !(hc[2 * i] == 0.0f && hs[4 * i] == 0.0f);
+            by += memcmp(&hc[2 * i + 1], &hs[4 * i + 1], 4) != 0 && !(hc[2 * i + 1] == 0.0f && hs[4 * i + 1] == 0.0f);
+        }
+        printf("{\"selectors_as_constants\": {\"pairs\": %d, \"wrong_x\": %ld, \"wrong_y\": %ld}}\n", n / 2, bx, by);
     }
     printf("{\"exactness\": {\"values\": %d, \"mismatches\": %ld, \"mismatches_where_the_residual_is_denormal\": %ld, \"denormal_residuals\": %ld}}\n",
            2 * n, bad, bad_denorm, denorm_cases);
