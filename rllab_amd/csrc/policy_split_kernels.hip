@@ -123,6 +123,21 @@ __device__ __forceinline__ float half_sum_swap(float v) {
 #ifndef RL_SPLIT_PK
 #define RL_SPLIT_PK 1
 #endif
+//   RL_SPLIT_SCALAR_SUB  (with RL_SPLIT_DOT2 = 0) the residual as two plain v_sub_f32 instead of one v_pk_add_f32: packed
+//                  f32 instructions of one wavefront do not overlap the matrix instructions of another
+//                  (tools/ubench/mfma_bf16_valu_overlap.hip, profiles/r03_notes.md), plain ones do
+//   RL_SPLIT_ASM_DMA  the LDS-direct loads of the next tile's cached activations as inline asm.  Issued through the
+//                  builtin, the compiler has to assume that they write ANY LDS address and puts s_waitcnt vmcnt(0) in
+//                  front of the next LDS read it cannot tell apart -- the output layer's rows, a third of the way into
+//                  the tile: the wavefront then sits out the rest of the HBM round trip it had meant to hide
+//                  (timing ablation RL_ABL_FETCH: 19 % of the kernel).  The asm form is invisible to that pass; the
+//                  loop's own s_waitcnt vmcnt(0) at the top of the next tile is the (only) wait the data needs.
+#ifndef RL_SPLIT_SCALAR_SUB
+#define RL_SPLIT_SCALAR_SUB 0
+#endif
+#ifndef RL_SPLIT_ASM_DMA
+#define RL_SPLIT_ASM_DMA 1
+#endif
 // a - h for a pair a and its packed bf16 rounding h (exact)
 // The two selectors (-1, 0) and (0, -1) travel in REGISTERS: handed to the instruction as a constant, (-1, 0) is encoded as
 // the inline constant "-1.0", which the VOP2 form of v_dot2c_f32_bf16 reads as the f32 pattern 0xbf800000 = (0, -1) --
@@ -138,6 +153,11 @@ __device__ __forceinline__ f32x2 residual(f32x2 a, bf16x2 h) {
 #if RL_SPLIT_DOT2
     const bf16x2 e0 = dot2_selector(0x0000bf80u), e1 = dot2_selector(0xbf800000u);
     return f32x2{__builtin_amdgcn_fdot2_f32_bf16(h, e0, a[0], false), __builtin_amdgcn_fdot2_f32_bf16(h, e1, a[1], false)};
+#elif RL_SPLIT_SCALAR_SUB
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    float r0 = a[0] - hf[0], r1 = a[1] - hf[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));           // (keeps the two subtractions apart: no re-packing)
+    return f32x2{r0, r1};
 #else
     return a - __builtin_convertvector(h, f32x2);
 #endif
@@ -243,7 +263,9 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     constexpr bool TAIL_LDS = INV_LDS || DA > 2;   // the output layer's rows in LDS (wide heads: 32 DA registers otherwise)
     constexpr int TAILV = 16 * DA * 2 + 16;        // floats per lane half: W2 rows | dW2 rows | db1
     constexpr int SPILL_BYTES = INV_LDS ? 2 * 3 * WV * 16 : 0;   // a wavefront's h0 parts wait here for the back-propagation
-    constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES;
+    constexpr int XROWS = 8 * KB0 + 1;                           // observation slots of a lane + the weight
+    constexpr int XLAND_BYTES = RL_SPLIT_ASM_DMA ? XROWS * WV * 4 : 0;   // the next tile's observations land here too
+    constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES + XLAND_BYTES;
     constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + (INV_LDS ? OPS_BYTES : 0) + (TAIL_LDS ? 2 * TAILV * 4 : 0);
     static_assert(DO + 1 <= 32, "two k-blocks of inputs + the bias slot");
     static_assert(LDS_TOTAL >= WAVES * P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold rows alias the landing zones");
@@ -252,6 +274,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     const int lj = lane & 31, lh = lane >> 5;
     char* const land = smem + wave * WAVE_BYTES;
     char* const spill = land + LAND_BYTES;
+    char* const xland = spill + SPILL_BYTES;
     char* const ops = smem + WAVES * WAVE_BYTES;                       // [N_OPS][3][64] x 16 B
     float* const tailv = reinterpret_cast<float*>(ops + (INV_LDS ? OPS_BYTES : 0));    // [2][TAILV]
 
@@ -262,6 +285,39 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
 
     // one tile ahead: the observation slots and the weight in registers, the cached activations by LDS-direct loads
     // (branch-free: a lane half beyond the inputs reads a clamped row and selects the constant)
+#if RL_SPLIT_ASM_DMA
+    // The observation slots and the weight travel the same way as the activations: one global_load_lds_dword per slot
+    // (row i of the wavefront's x landing zone = 64 lanes x 4 B), hidden from the compiler's wait-count bookkeeping --
+    // a tracked load next to hidden ones would make every vmcnt(N) it computes wait for the younger hidden loads too.
+    // take_x() reads the rows back once the tile's s_waitcnt vmcnt(0) has passed.
+    const unsigned xland_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)xland);
+    auto dma_row = [&](const float* g, unsigned row) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(xland_lds + row * (WV * 4)) : "memory");
+    };
+    auto fetch = [&](int tile, float (&)[KB0][8], float&) {
+        const int b = tile * TS + lj;
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * kb + 8 * lh + j;
+                dma_row(a.obs + (size_t)(d < DO ? d : DO - 1) * B + b, 8 * kb + j);
+            }
+        dma_row(a.weight + b, 8 * KB0);
+    };
+    auto take_x = [&](float (&xq)[KB0][8], float& wq) {
+        const float* xl = reinterpret_cast<const float*>(xland);
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * kb + 8 * lh + j;
+                const float v = xl[(8 * kb + j) * WV + lane];
+                xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
+            }
+        wq = xl[8 * KB0 * WV + lane];
+    };
+#else
     auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
         const int b = tile * TS + lj;
         wq = a.weight[b];
@@ -274,11 +330,31 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
                 xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
             }
     };
+#endif
+#if RL_SPLIT_ASM_DMA
+    // LDS byte address of this wavefront's landing zone (wave-uniform): M0 for rows 0..3, + 4096 for rows 4..7; the
+    // instruction offset advances the global and the LDS address together (row q of a tile is 1 KB in both)
+    const unsigned land_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)land);
+#endif
     auto fetch_acts = [&](int tile) {
         const float* src = a.acts + ((size_t)tile * 8 * WV + lane) * 4;
+#if RL_SPLIT_ASM_DMA
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:3072\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:3072"
+                     :: "v"(src), "v"(src + 4 * WV * 4), "s"(land_lds), "s"(land_lds + 4096u) : "memory");
+#else
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(land + q * WV * 16), 16, 0, 0);
+#endif
     };
     float xb[KB0][8], xb_next[KB0][8];
     float wgt = 0.0f, wgt_next = 0.0f;
@@ -393,6 +469,13 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     for (int k = 0; k < DA; ++k) gb2[k] = 0.0f;
 
 
+#if RL_SPLIT_ASM_DMA
+    // every load the compiler knows of (parameters, tangent, the staging above) has landed before the loop is entered,
+    // and it is told so with an instruction it models: otherwise the loop header inherits "loads may be pending" from
+    // the preheader and a vmcnt(N) wait for a loop-invariant value survives inside the loop, where it would wait for
+    // the hidden loads of the next tile
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
     for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
         // ---- this tile's inputs; the next tile's start travelling ------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -404,11 +487,15 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { h0[4 * q + e] = v0[e]; h1[4 * q + e] = v1[e]; }
         }
+#if RL_SPLIT_ASM_DMA
+        take_x(xb, wgt);
+#else
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
             for (int j = 0; j < 8; ++j) xb[kb][j] = xb_next[kb][j];
         wgt = wgt_next;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the landing zone is in registers before it is refilled
         {   // the wavefront's last tile prefetches itself again (no branch in the loop body)
             const int nxt = tile + waves_total < n_tiles ? tile + waves_total : tile;
@@ -646,7 +733,8 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
     using N = Net<DO, DA, H>;
     constexpr int WAVES = 4 * WPS;
     constexpr int KB0 = (DO + 1 + 15) / 16;
-    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0)) + (WPS == 2 ? ops_bytes(KB0) : 0) +
+    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0) + (RL_SPLIT_ASM_DMA ? (8 * KB0 + 1) * WV * 4 : 0)) +
+                              (WPS == 2 ? ops_bytes(KB0) : 0) +
                               ((WPS == 2 || DA > 2) ? 2 * (16 * DA * 2 + 16) * 4 : 0);
     Args a;
     a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.acts = g->activations; a.obs = g->obs; a.weight = g->weights;

@@ -441,7 +441,9 @@ def test_prefetched_rollout_changes_nothing(quiet_logger, monkeypatch):
         return pol.get_param_values(), rows, calls
     th_a, rows_a, calls_a = run(True)
     th_b, rows_b, calls_b = run(False)
-    assert calls_a == [1, 2, 3] and calls_b == [("skipped", 1), ("skipped", 2), ("skipped", 3)]
+    # (twice per iteration since round 5: from the optimizer's hook once the update is enqueued -- the line search is
+    # decided on the device -- and from train_iteration afterwards, where it finds the batch already queued)
+    assert calls_a == [1, 1, 2, 2, 3, 3] and calls_b == [("skipped", i) for i in (1, 1, 2, 2, 3, 3)]
     assert np.array_equal(th_a, th_b)
     for ra, rb in zip(rows_a, rows_b):
         for k in ("AverageReturn", "LossBefore", "LossAfter", "MeanKL", "Entropy"):

@@ -404,7 +404,8 @@ def test_line_search_decide_kernel_by_hand():
     assert torch.equal(theta, (prev.double() - 0.125).float())                      # the accepted point stays
     keep = state.clone()
     decide(state, gate, [[9.0, 0.0, 0.0, 0.0], [9.0, 0.0, 0.0, 0.0]], 2, 0.5)       # behind an accepted candidate: untouched
-    assert torch.equal(state, keep) and torch.equal(theta, (prev.double() - 0.125).float())
+    assert torch.equal(state.view(torch.int64), keep.view(torch.int64))            # (bitwise: one record holds the NaN)
+    assert torch.equal(theta, (prev.double() - 0.125).float())
 
 
 def test_deferred_reads_give_the_same_numbers(quiet_logger):

@@ -1,13 +1,22 @@
 #!/bin/bash
-# round 5: the split Fisher-vector product's instruction diet, one library per switch combination
-#   build/exp/lib_split_<DOT2><PK>.so   (RL_SPLIT_DOT2, RL_SPLIT_PK of csrc/policy_split_kernels.hip)
-# run HERE (cross-compiles), then on the GPU box:  python tools/exp/with_libs.py tools/exp/fvp_split_time.py 1
+# round 5: the split Fisher-vector product's build switches, one library per combination -> build/exp/lib_v_*.so
+# (RL_SPLIT_ASM_DMA / RL_SPLIT_DOT2 / RL_SPLIT_PK / RL_SPLIT_SCALAR_SUB of csrc/policy_split_kernels.hip).
+# run HERE (cross-compiles), then on the GPU box:  python tools/exp/fvp_split_ab.py
 set -e
 cd "$(dirname "$0")/../.."
 rm -f build/exp/lib_*.so
-for v in "0 0" "1 0" "0 1" "1 1"; do
-  set -- $v
-  bash tools/exp/build_tu_variant.sh policy_split_kernels split_$1$2 -DRL_SPLIT_DOT2=$1 -DRL_SPLIT_PK=$2 "${@:3}" &
-done
+b() { bash tools/exp/build_tu_variant.sh policy_split_kernels "$@" > /dev/null; }
+b v_dma_dot_pk -DRL_SPLIT_ASM_DMA=1 -DRL_SPLIT_DOT2=1 -DRL_SPLIT_PK=1 &
+b v_dma_plain -DRL_SPLIT_ASM_DMA=1 -DRL_SPLIT_DOT2=0 -DRL_SPLIT_PK=0 &
+b v_dma_scalar -DRL_SPLIT_ASM_DMA=1 -DRL_SPLIT_DOT2=0 -DRL_SPLIT_PK=0 -DRL_SPLIT_SCALAR_SUB=1 &
+b v_dma_scalar_ilp -DRL_SPLIT_ASM_DMA=1 -DRL_SPLIT_DOT2=0 -DRL_SPLIT_PK=0 -DRL_SPLIT_SCALAR_SUB=1 -mllvm -amdgpu-sched-strategy=max-ilp &
 wait
-ls -la build/exp/lib_split_*.so
+b v_nodma_dot_pk -DRL_SPLIT_ASM_DMA=0 -DRL_SPLIT_DOT2=1 -DRL_SPLIT_PK=1 &
+b v_dma_dot -DRL_SPLIT_ASM_DMA=1 -DRL_SPLIT_DOT2=1 -DRL_SPLIT_PK=0 &
+b v_dma_dot_pk_ilp -DRL_SPLIT_ASM_DMA=1 -DRL_SPLIT_DOT2=1 -DRL_SPLIT_PK=1 -mllvm -amdgpu-sched-strategy=max-ilp &
+b v_dma_abl_mfma -DRL_SPLIT_ASM_DMA=1 -DRL_ABL_MFMA=1 &
+wait
+b v_dma_abl_split -DRL_SPLIT_ASM_DMA=1 -DRL_ABL_SPLIT=1 &
+b v_dma_abl_fetch -DRL_SPLIT_ASM_DMA=1 -DRL_ABL_FETCH=1 &
+wait
+ls build/exp/*.so
