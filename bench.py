@@ -499,8 +499,11 @@ def main():
             # the split product: the SAME algorithmic f32 work (mfma_per_tile f32-matrix-instruction equivalents per tile)
             # priced against the same f32 matrix peak, so that the number is comparable with earlier rounds; what the
             # bf16 pipe executes for it is 6 cross terms per product + 21 transposition products per tile
-            kern = "fvp_split_kernel (Fisher-vector product, v_mfma_f32_32x32x16_bf16 on three-way split f32 operands)"
-            bf16_mfma = 66 + 21
+            kern = "%s (Fisher-vector product, v_mfma_f32_32x32x16_bf16 on three-way split f32 operands)" % (
+                "fvp_split_kernel" if h == 32 else "fvp_split64_kernel")
+            # six terms per 32 x 32 x 16 block product + the transposition products of the sample-axis operands
+            kb0 = (do + 1 + 15) // 16
+            bf16_mfma = 6 * (ht * kb0 + 3 * ht * 2 * ht + 2 * ht * ht + 2 * ht) + 3 * (3 * 2 * ht + kb0)
             extra = {"arithmetic": "f32 operands split hi + mid + lo (exact), six bf16 cross terms per product, f32 "
                                    "accumulation: dropped terms <= 2^-23 |a b| worst case, 2^-28 mean (tests/test_split_arithmetic.py, test_gpu_fvp_split.py)",
                      "bf16_mfma_per_32_samples": bf16_mfma,

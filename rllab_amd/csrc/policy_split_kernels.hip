@@ -728,6 +728,427 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     }
 }
 
+// =====================================================================================================================
+// fvp_split64_kernel<DO, DA> -- the same product for two 64-unit tanh layers (BASELINE config C5's GaussianMLPPolicy(64, 64)),
+// round 5.  policy_pass_kernel<Net<.., 64>, FVP> spends 17.8 k of its 41 k cycles per 32-sample tile in f32 matrix
+// instructions that run at the vector rate; here every product is the six-term bf16 form of the kernel above (282 matrix
+// instructions of 32 cycles per tile).  One wavefront per SIMD owns a tile (512 registers; the cooperative two-wavefront
+// kernel of policy_csplit_kernels.hip pays seven workgroup barriers and an LDS hand-over per layer for the same tile and
+// measured slower than the f32 kernel, profiles/r04_notes.md):
+//   * fragments are arrays over the HT = 2 row tiles of a layer; a layer's B operand is 2 HT k-blocks of 16 units;
+//   * all loop-invariant operands (28 blocks x 3 parts x 1 KB = 84 KB) live in LDS, read per use;
+//   * the output layer's outer product gW2 += h1^T gmu does NOT accumulate per lane (32 units x DA values = 192 registers for
+//     six actions): lane u (= unit u of the 64) walks the tile's 32 samples, reading h1[s][u] straight from the landing
+//     zone of the cached fragments and the sample's cotangent gmu[s][.] from a 1 KB wave-private row buffer (broadcast
+//     reads) -- DA accumulators per lane, no reduction over the lanes at the end;
+//   * the next tile's fragments start travelling (LDS-direct loads) once that walk is done with the landing zone -- the
+//     back-propagation, transpositions and outer products behind it cover the HBM round trip.
+// Same inputs, same partial-row / float64 row reduction, a result that differs from the f32 kernel's by rounding only
+// (tests/test_gpu_fvp_split.py, tests/test_gpu_update_parity.py run both).
+template <int DO, int DA>
+__global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
+    constexpr int HT = 2, HH = 64;
+    using N = Net<DO, DA, HH>;
+    constexpr int P = N::P;
+    constexpr int WAVES = 4;
+    constexpr int KB0 = (DO + 1 + 15) / 16;        // k-blocks of the input layer (inputs + the bias slot)
+    constexpr int KBH = 2 * HT;                    // k-blocks of a hidden layer's output (16 units each)
+    constexpr int O_DW0 = 0, O_DW1 = O_DW0 + HT * KB0, O_W1T = O_DW1 + HT * KBH, O_W1 = O_W1T + HT * KBH,
+                  N_OPS = O_W1 + HT * KBH;
+    constexpr int OPS_BYTES = N_OPS * 3 * WV * 16;
+    constexpr int TAILV = HT * 16 * DA * 2 + HT * 16;            // floats per lane half: W2 | dW2 | db1, [k][t][16 rows]
+    constexpr int LAND64 = 2 * HH * TS * 4;                      // h0 | h1 fragments of one tile: 16 rows of 1 KB
+    constexpr int GMU_BYTES = TS * 8 * 4;                        // [sample][8] cotangents on the mean (DA <= 8)
+    constexpr int WAVE_BYTES = LAND64 + GMU_BYTES;
+    constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + OPS_BYTES + 2 * TAILV * 4;
+    static_assert(DO + 1 <= 32 && DA <= 8, "two k-blocks of inputs + the bias slot; at most eight actions");
+    static_assert(LDS_TOTAL >= WAVES * P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold rows alias everything");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
+    const int lj = lane & 31, lh = lane >> 5;
+    char* const land = smem + wave * WAVE_BYTES;
+    float* const gmub = reinterpret_cast<float*>(land + LAND64);
+    char* const ops = smem + WAVES * WAVE_BYTES;
+    float* const tailv = reinterpret_cast<float*>(ops + OPS_BYTES);
+
+    const int B = a.B;
+    const int n_tiles = B / TS;
+    const int wave_global = blockIdx.x * WAVES + wave;
+    const int waves_total = gridDim.x * WAVES;
+
+    auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
+        const int b = tile * TS + lj;
+        wq = a.weight[b];
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * kb + 8 * lh + j;
+                const float v = a.obs[(size_t)(d < DO ? d : DO - 1) * B + b];
+                xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
+            }
+    };
+    auto fetch_acts = [&](int tile) {
+        const float* src = a.acts + ((size_t)tile * (4 * 2 * HT) * WV + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < 4 * 2 * HT; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + q * WV * 4), (lptr_t)(land + q * WV * 16), 16, 0, 0);
+    };
+    float xb[KB0][8], xb_next[KB0][8];
+    float wgt = 0.0f, wgt_next = 0.0f;
+    if (wave_global < n_tiles) {
+        fetch(wave_global, xb_next, wgt_next);
+        fetch_acts(wave_global);
+    }
+    asm volatile("" ::: "memory");
+
+    const float* __restrict__ th = a.theta;
+    const float* __restrict__ vc = a.vec;
+    // ---- loop-invariant operands, split once per launch, in LDS ------------------------------------------------------
+    // block (row tile t, k-block): A[i = 32 t + lj][k-slot (lh, j)]
+    for (int o = wave; o < N_OPS; o += WAVES) {
+        float tv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (o < O_DW1) {                               // dW0^T (+ db0 in the bias slot): k = input 16 kb0 + 8 lh + j
+                const int t = o / KB0, kb0 = o % KB0, i = 32 * t + lj, d = 16 * kb0 + 8 * lh + j;
+                tv8[j] = d < DO ? vc[N::W0 + d * HH + i] : (d == DO ? vc[N::B0 + i] : 0.0f);
+            } else {
+                const int q = o - O_DW1, fam = q / (HT * KBH), r_ = q % (HT * KBH), t = r_ / KBH, kbg = r_ % KBH;
+                const int i = 32 * t + lj, u = 32 * (kbg >> 1) + frag_unit(8 * (kbg & 1) + j, lh);
+                tv8[j] = fam == 0 ? vc[N::W1 + u * HH + i]   // dW1^T: A[i][k] = dW1[k][i]
+                       : fam == 1 ? th[N::W1 + u * HH + i]   // W1^T
+                                  : th[N::W1 + i * HH + u];  // W1:    A[i][k] = W1[i][k]
+            }
+        }
+        Parts tp;
+        split8(tv8, tp);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(ops + ((o * 3 + p) * WV + lane) * 16) = tp.p[p];
+    }
+    for (int e = threadIdx.x; e < 2 * HT * 16; e += WAVES * WV) {
+        const int hh = e / (HT * 16), t = (e / 16) % HT, r = e % 16, u = 32 * t + frag_unit(r, hh);
+        float* tv = tailv + hh * TAILV;
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            tv[(k * HT + t) * 16 + r] = th[N::W2 + u * DA + k];
+            tv[((DA + k) * HT + t) * 16 + r] = vc[N::W2 + u * DA + k];
+        }
+        tv[2 * DA * HT * 16 + t * 16 + r] = vc[N::B1 + u];
+    }
+    __syncthreads();
+    auto op = [&](int o) -> Parts {
+        Parts t;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) t.p[p] = *reinterpret_cast<const bf16x8*>(ops + ((o * 3 + p) * WV + lane) * 16);
+        return t;
+    };
+    bf16x8 Id[2], Idx[KB0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        Id[0][j] = (__bf16)(frag_unit(j, lh) == lj ? 1.0f : 0.0f);
+        Id[1][j] = (__bf16)(frag_unit(8 + j, lh) == lj ? 1.0f : 0.0f);
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) Idx[kb][j] = (__bf16)(16 * kb + 8 * lh + j == lj ? 1.0f : 0.0f);
+    }
+    float db2[DA], fk[DA], var_[DA];
+    bool floored[DA];
+#pragma unroll
+    for (int k = 0; k < DA; ++k) {
+        const float raw = th[N::LSTD + k];
+        floored[k] = raw < a.log_min_std;
+        const float ls = fmaxf(raw, a.log_min_std);
+        var_[k] = __expf(2.0f * ls);
+        fk[k] = 2.0f / (2.0f * var_[k] + 1e-8f);
+        db2[k] = vc[N::B2 + k];
+    }
+    // where lane u = lane finds h1[s][u] in the landing zone: row (HT + t) * 4 + (r >> 2) of 1 KB, lane slot s + 32 half,
+    // element r & 3, with u = 32 t + frag_unit(r, half)
+    const int h1_off = (((HT + (lane >> 5)) * 4 + ((lane & 31) >> 3)) * WV + 32 * ((lane & 7) >> 2)) * 16 + (lane & 3) * 4;
+
+    // ---- accumulators ---------------------------------------------------------------------------------------------
+    f32x16 gW1[HT][HT], gW0[HT];
+    float gb1l[HT][16], gW2u[DA], gb2[DA], wsum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gW0[t][r] = 0.0f; gb1l[t][r] = 0.0f;
+#pragma unroll
+            for (int t2 = 0; t2 < HT; ++t2) gW1[t][t2][r] = 0.0f;
+        }
+#pragma unroll
+    for (int k = 0; k < DA; ++k) { gb2[k] = 0.0f; gW2u[k] = 0.0f; }
+
+    for (int tile = wave_global; tile < n_tiles; tile += waves_total) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f32x16 h0[HT], h1[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(land + ((t * 4 + q) * WV + lane) * 16);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(land + (((HT + t) * 4 + q) * WV + lane) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h0[t][4 * q + e] = v0[e]; h1[t][4 * q + e] = v1[e]; }
+            }
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xb[kb][j] = xb_next[kb][j];
+        wgt = wgt_next;
+        const int nxt = tile + waves_total < n_tiles ? tile + waves_total : tile;
+        fetch(nxt, xb_next, wgt_next);
+        const float* tv = tailv + lh * TAILV;
+        auto W2_ = [&](int t, int r, int k) { return tv[(k * HT + t) * 16 + r]; };
+        auto dW2_ = [&](int t, int r, int k) { return tv[((DA + k) * HT + t) * 16 + r]; };
+        auto db1_ = [&](int t, int r) { return tv[2 * DA * HT * 16 + t * 16 + r]; };
+        auto stage = [&]() { asm volatile("" ::: "memory"); };
+
+        // ---- operands of this tile ---------------------------------------------------------------------------------------
+        Parts Xs[KB0], H0s[KBH];
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) split8(xb[kb], Xs[kb]);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            Parts tmp[2];
+            split_frag(h0[t], tmp);
+            H0s[2 * t] = tmp[0]; H0s[2 * t + 1] = tmp[1];
+        }
+
+        // ---- tangent forward -----------------------------------------------------------------------------------------------
+        f32x16 acc[HT], dh0[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < KB0; ++kb) acc[t] = mm6(op(O_DW0 + t * KB0 + kb), Xs[kb], acc[t]);      // dW0^T x + db0
+            times_dtanh(acc[t], h0[t], dh0[t]);
+        }
+        stage();
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = db1_(t, r);
+#pragma unroll
+            for (int kbg = 0; kbg < KBH; ++kbg) acc[t] = mm6(op(O_DW1 + t * KBH + kbg), H0s[kbg], acc[t]);  // dW1^T h0
+        }
+        stage();
+        {
+            Parts D0s[KBH];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                Parts tmp[2];
+                split_frag(dh0[t], tmp);
+                D0s[2 * t] = tmp[0]; D0s[2 * t + 1] = tmp[1];
+            }
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int kbg = 0; kbg < KBH; ++kbg) acc[t] = mm6(op(O_W1T + t * KBH + kbg), D0s[kbg], acc[t]);   // W1^T dh0
+        }
+        stage();
+        const float c = wgt * a.inv_count;
+        f32x16 dz1[HT], gz1[HT];
+        float gmu[DA];
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x2 hh = pair_of(h1[t], j);
+                const f32x2 d = __builtin_elementwise_fma(-hh, hh, f32x2{1.0f, 1.0f});
+                set_pair(dz1[t], j, d);
+                set_pair(acc[t], j, pair_of(acc[t], j) * d);                          // dh1
+            }
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            f32x2 pd = {0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pd = __builtin_elementwise_fma(pair_of(h1[t], j), f32x2{dW2_(t, 2 * j, k), dW2_(t, 2 * j + 1, k)}, pd);
+                    pd = __builtin_elementwise_fma(pair_of(acc[t], j), f32x2{W2_(t, 2 * j, k), W2_(t, 2 * j + 1, k)}, pd);
+                }
+            const float dmu = db2[k] + half_sum_swap(pd[0] + pd[1]);
+            gmu[k] = c * dmu * fk[k];
+        }
+        if (lh == 0) {
+            wsum += c;
+#pragma unroll
+            for (int k = 0; k < DA; ++k) { gb2[k] += gmu[k]; gmub[lj * 8 + k] = gmu[k]; }
+        }
+        // ---- back-propagation through the output layer, sample-major --------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x2 g = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < DA; ++k)
+                    g = __builtin_elementwise_fma(f32x2{W2_(t, 2 * j, k), W2_(t, 2 * j + 1, k)}, f32x2{gmu[k], gmu[k]}, g);
+                const f32x2 gz = g * pair_of(dz1[t], j);
+                set_pair(gz1[t], j, gz);
+                const f32x2 b1n = f32x2{gb1l[t][2 * j], gb1l[t][2 * j + 1]} + gz;
+                gb1l[t][2 * j] = b1n[0]; gb1l[t][2 * j + 1] = b1n[1];
+            }
+        // ---- gW2 += h1^T gmu with the UNITS on the lanes: lane u walks the tile's samples ---------------------------------
+        wave_sync();                                                   // the cotangent rows are in the buffer
+        {
+            const char* hp = land + h1_off;
+#pragma unroll 8
+            for (int s_ = 0; s_ < TS; ++s_) {
+                const float hv = *reinterpret_cast<const float*>(hp + s_ * 16);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gmub + s_ * 8);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(gmub + s_ * 8 + 4);
+#pragma unroll
+                for (int k = 0; k < DA; ++k) gW2u[k] = __builtin_fmaf(hv, k < 4 ? g0[k] : g1[k - 4], gW2u[k]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the landing zone has been read: refill it
+        fetch_acts(nxt);
+        stage();
+        Parts G1s[KBH];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            Parts tmp[2];
+            split_frag(gz1[t], tmp);
+            G1s[2 * t] = tmp[0]; G1s[2 * t + 1] = tmp[1];
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+            for (int kbg = 0; kbg < KBH; ++kbg) acc[t] = mm6(op(O_W1 + t * KBH + kbg), G1s[kbg], acc[t]);       // W1 gz1
+        }
+        stage();
+        {
+            Parts H0t[HT][2], G1t[HT][2];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                const Parts hs[2] = {H0s[2 * t], H0s[2 * t + 1]}, gs[2] = {G1s[2 * t], G1s[2 * t + 1]};
+                transpose_units(hs, Id, H0t[t]);
+                transpose_units(gs, Id, G1t[t]);
+            }
+#pragma unroll
+            for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+                for (int tj2 = 0; tj2 < HT; ++tj2)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) gW1[ti][tj2] = mm6(H0t[ti][kb], G1t[tj2][kb], gW1[ti][tj2]);   // gW1 += h0^T gz1
+        }
+        stage();
+        {
+            Parts G0t[HT][2], Xt[2];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                f32x16 gz0;
+                times_dtanh(acc[t], h0[t], gz0);
+                Parts gs[2];
+                split_frag(gz0, gs);
+                transpose_units(gs, Id, G0t[t]);
+            }
+            transpose_inputs<KB0>(Xs, Idx, Xt);
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) gW0[t] = mm6(Xt[kb], G0t[t][kb], gW0[t]);                     // gW0 += x_ext^T gz0
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- fold the wavefronts of this workgroup in a fixed order, write ONE partial row ----------------------------------
+    float b1s[HT][16];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = gb1l[t][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, WV);
+            b1s[t][r] = v;
+        }
+    float b2s[DA];
+#pragma unroll
+    for (int k = 0; k < DA; ++k) b2s[k] = wave_sum(gb2[k]);
+    const float ws = wave_sum(wsum);
+    __syncthreads();
+    float* const myrow = reinterpret_cast<float*>(smem) + wave * P;
+#pragma unroll
+    for (int ti = 0; ti < HT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = 32 * ti + frag_unit(r, lh);
+#pragma unroll
+            for (int tj2 = 0; tj2 < HT; ++tj2) myrow[N::W1 + u * HH + 32 * tj2 + lj] = gW1[ti][tj2][r];
+        }
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = frag_unit(r, lh);
+            if (d < DO) myrow[N::W0 + d * HH + 32 * t + lj] = gW0[t][r];
+            else if (d == DO) myrow[N::B0 + 32 * t + lj] = gW0[t][r];
+        }
+    if (lj == 0) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) myrow[N::B1 + 32 * t + frag_unit(r, lh)] = b1s[t][r];
+    }
+#pragma unroll
+    for (int k = 0; k < DA; ++k) myrow[N::W2 + lane * DA + k] = gW2u[k];               // lane = unit
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            myrow[N::B2 + k] = b2s[k];
+            const float vv = var_[k], e = 1e-8f;
+            const float cc = floored[k] ? 0.0f : 4.0f * vv * (2.0f * vv - e) / ((2.0f * vv + e) * (2.0f * vv + e));
+            myrow[N::LSTD + k] = cc * vc[N::LSTD + k] * ws;
+        }
+    }
+    __syncthreads();
+    float* row = a.partial + (size_t)blockIdx.x * P;
+    for (int k = threadIdx.x; k < P; k += WAVES * WV) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += reinterpret_cast<const float*>(smem)[w * P + k];
+        row[k] = t;
+    }
+}
+
+template <int DO, int DA>
+static int launch64(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
+    using N = Net<DO, DA, 64>;
+    constexpr int HT = 2, WAVES = 4;
+    constexpr int KB0 = (DO + 1 + 15) / 16;
+    constexpr int N_OPS = HT * KB0 + 3 * HT * 2 * HT;
+    constexpr int LDS_BYTES = WAVES * (2 * 64 * TS * 4 + TS * 8 * 4) + N_OPS * 3 * WV * 16 + 2 * (HT * 16 * DA * 2 + HT * 16) * 4;
+    Args a;
+    a.B = g->n_samples; a.theta = g->theta; a.vec = vec; a.acts = g->activations; a.obs = g->obs; a.weight = g->weights;
+    a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
+    const int n_tiles = a.B / TS;
+    int grid = (n_tiles + WAVES - 1) / WAVES;
+    if (grid > 256) grid = 256;                   // one workgroup per CU, one wavefront per SIMD
+    const size_t need = (size_t)grid * N::P * sizeof(float);
+    if (ws_bytes < need) return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", ws_bytes, need);
+    a.partial = (float*)ws;
+    auto kern = fvp_split64_kernel<DO, DA>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_BYTES);
+        if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * WV), LDS_BYTES, st, a);
+    int rc = check_launch("fvp_split64_kernel");
+    if (rc) return rc;
+    return launch_reduce_rows(a.partial, grid, N::P, out, st);
+}
+
 template <int DO, int DA, int WPS>
 static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     using N = Net<DO, DA, H>;
@@ -768,12 +1189,21 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
 // one-output net on the Swimmer's observations.  Heads wider than two outputs run one wavefront per SIMD: their
 // per-lane sums of the thin products (16 x act_dim registers) do not fit beside 256.
 #define SPLIT_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1) X(20, 3) X(20, 6) X(21, 6)
+// ... and two 64-unit layers (fvp_split64_kernel): the pairs policy_pass_kernel<Net<.., 64>> caches activations for
+#define SPLIT64_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(20, 3) X(20, 6) X(21, 6)
 bool split_fvp_takes(const rl_policy_batch* g) {
-    if (!g->activations || g->hidden2 != 0 || g->hidden0 != 32 || g->hidden1 != 32 || g->activation != RL_ACT_TANH ||
-        g->n_samples <= 0 || g->n_samples % TS != 0)
+    if (!g->activations || g->hidden2 != 0 || g->hidden0 != g->hidden1 || (g->hidden0 != 32 && g->hidden0 != 64) ||
+        g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0)
         return false;
     const char* e = getenv("RLLAB_FVP_SPLIT");
     if (e && e[0] == '0') return false;
+    if (g->hidden0 == 64) {
+        if (e && e[0] == '2') return false;        // (the tests of the cooperative class run every shape on THAT kernel)
+#define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return true;
+        SPLIT64_SHAPES(SPLITCASE)
+#undef SPLITCASE
+        return false;
+    }
 #define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return true;
     SPLIT_SHAPES(SPLITCASE)
 #undef SPLITCASE
@@ -782,6 +1212,12 @@ bool split_fvp_takes(const rl_policy_batch* g) {
 int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     if (!split_fvp_takes(g)) return RL_SPLIT_NOT_TAKEN;
     // two wavefronts per SIMD (operands in LDS) unless RLLAB_FVP_SPLIT_WPS=1 asks for the one-wavefront, register-resident form
+    if (g->hidden0 == 64) {
+#define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return split::launch64<DO, DA>(g, vec, ws, ws_bytes, out, st);
+        SPLIT64_SHAPES(SPLITCASE)
+#undef SPLITCASE
+        return RL_SPLIT_NOT_TAKEN;
+    }
     const char* e = getenv("RLLAB_FVP_SPLIT_WPS");
     const bool one = e && e[0] == '1';
 #define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) { \

@@ -11,6 +11,8 @@ from tests import test_gpu_update_parity as U
 pytestmark = pytest.mark.gpu
 
 SPLIT_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (13, 1), (20, 3), (20, 6), (21, 6)]   # every HIP-native env's default (32, 32) policy
+SPLIT64_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6)]             # ... and (64, 64): fvp_split64_kernel
+ALL_SPLIT = [(d, a, 32) for d, a in SPLIT_SHAPES] + [(d, a, 64) for d, a in SPLIT64_SHAPES]
 
 
 def _variant(ops, inp):
@@ -27,8 +29,8 @@ def _f64_products(pol, inp, vs):
     return [torch.autograd.grad((g * v).sum(), flat64, retain_graph=True)[0] for v in vs]
 
 
-def _blocks(pol):
-    do, da, h = pol.obs_dim, pol.action_dim, 32
+def _blocks(pol, h=32):
+    do, da = pol.obs_dim, pol.action_dim
     names, sizes = ("W0", "b0", "W1", "b1", "W2", "b2", "log_std"), (do * h, h, h * h, h, h * da, da, da)
     out, o = [], 0
     for n, s in zip(names, sizes):
@@ -37,10 +39,10 @@ def _blocks(pol):
     return out
 
 
-@pytest.mark.parametrize("do,da", SPLIT_SHAPES)
+@pytest.mark.parametrize("do,da,h", ALL_SPLIT)
 @pytest.mark.parametrize("B", [32, 4096, 64000])
-def test_split_product_is_an_f32_accurate_product(do, da, B, monkeypatch):
-    pol = U._policy(do, da, 32)
+def test_split_product_is_an_f32_accurate_product(do, da, h, B, monkeypatch):
+    pol = U._policy(do, da, h)
     ops = pol.fused_ops()
     inp = U._inputs(pol, B, old_equals_new=True)
     rng = np.random.RandomState(7)
@@ -58,7 +60,7 @@ def test_split_product_is_an_f32_accurate_product(do, da, B, monkeypatch):
     for hv_s, hv_p, hv64 in zip(split, plain, want):
         scale = float(hv64.abs().max())
         err_s, err_p = float((hv_s - hv64).abs().max()) / scale, float((hv_p - hv64).abs().max()) / scale
-        worst = [(n, float((hv_s - hv64)[a:b].abs().max()) / scale) for n, a, b in _blocks(pol)]
+        worst = [(n, float((hv_s - hv64)[a:b].abs().max()) / scale) for n, a, b in _blocks(pol, h)]
         assert err_s <= 5e-5, worst                                    # the reference tolerance of the product
         assert err_s <= 2.0 * err_p + 2e-6, (err_s, err_p, worst)      # and no worse than the f32 matrix instructions
         assert not torch.equal(hv_s, hv_p)                             # (two different kernels did run)
@@ -79,14 +81,21 @@ def test_split_product_takes_only_its_batches(monkeypatch):
     ops64 = pol64.fused_ops()
     inp = U._inputs(pol64, 4096, old_equals_new=True)
     ops64.loss_grad(inp, keep_activations=True)
-    assert _variant(ops64, inp) == 0                     # 64-unit nets stay on the f32 matrix instructions by default
-    monkeypatch.setenv("RLLAB_FVP_SPLIT", "2")           # ... the cooperative split kernel takes them on request
+    assert _variant(ops64, inp) == 1                     # (64, 64): the one-wavefront-per-tile split kernel since round 5
+    inp_r = U._inputs(pol64, 4100, old_equals_new=True)
+    ops64.loss_grad(inp_r, keep_activations=True)
+    assert _variant(ops64, inp_r) == 0                   # ... whole tiles only, like the 32-unit kernel
+    ops64.loss_grad(inp, keep_activations=True)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "2")           # the cooperative split kernel takes them on request
     assert _variant(ops64, inp) == 2                     # (tests/test_gpu_csplit.py; slower there, profiles/r04_notes.md)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
+    assert _variant(ops64, inp) == 0
 
 
-def test_cg_on_the_split_product_solves_the_same_system(monkeypatch):
+@pytest.mark.parametrize("do,da,h", [(13, 2, 32), (20, 6, 64)])
+def test_cg_on_the_split_product_solves_the_same_system(do, da, h, monkeypatch):
     """Ten CG iterations (krylov.cg, rllab/misc/krylov.py:7-39) on either product: the same solution to f32 accuracy."""
-    pol = U._policy(13, 2, 32)
+    pol = U._policy(do, da, h)
     ops = pol.fused_ops()
     inp = U._inputs(pol, 64000, old_equals_new=True)
     g = ops.loss_grad(inp, keep_activations=True)
@@ -98,13 +107,14 @@ def test_cg_on_the_split_product_solves_the_same_system(monkeypatch):
     assert abs(float(xhx_s) - float(xhx_p)) <= 1e-5 * abs(float(xhx_p))
 
 
-def test_full_size_products_are_linear_symmetric_and_positive():
+@pytest.mark.parametrize("do,da,h,B", [(13, 2, 32, 4096 * 500), (20, 6, 64, 1024 * 500)])
+def test_full_size_products_are_linear_symmetric_and_positive(do, da, h, B):
     """At BASELINE config C3's batch (4096 envs x 500 steps = 2 048 000 samples, ragged weights): the split product is
     linear in the vector, symmetric (v . F w == w . F v) and positive (v . F v > 0) -- properties of the Fisher matrix of
     rllab/optimizers/conjugate_gradient_optimizer.py:27-55 that do not need a float64 pass over two million samples."""
-    pol = U._policy(13, 2, 32)
+    pol = U._policy(do, da, h)
     ops = pol.fused_ops()
-    inp = U._inputs(pol, 4096 * 500, old_equals_new=True)
+    inp = U._inputs(pol, B, old_equals_new=True)
     ops.loss_grad(inp, keep_activations=True)
     assert _variant(ops, inp) == 1
     rng = np.random.RandomState(11)
