@@ -65,15 +65,6 @@ ENVS = {  # name -> (module, class, rl_env_kind)
 }
 
 
-def _coop_lds_bytes(do, da, hidden):
-    """LDS of RolloutPolicyCoop (csrc/env_kernels.hip, lds_floats) for a net on the kernels' padded widths."""
-    pad = [32 if h <= 32 else 64 if h <= 64 else 128 for h in hidden]
-    k0 = (do + 3) & ~3
-    n = k0 * pad[0] + sum(a * b for a, b in zip(pad[:-1], pad[1:])) + 16 * pad[-1] + sum(pad)
-    n += 4 * ((2 * da + 3) // 4) + 2 * 16 * max(pad) + da * 16 * 4
-    return 4 * n
-
-
 def step_kernel_roofline(torch, kind, n=1 << 22, steps=20, warmup=3):
     from rllab_amd import _lib
     from rllab_amd.envs.hip_env import HipVecEnv
@@ -397,50 +388,27 @@ def main():
         out64 = torch.empty(ops.n_kernel, dtype=torch.float64, device=v.device)
         fvp_ms = timed20(lambda: ops._fvp_into(keep_[0], ws_, v32, out64, inp))
         ops.release()
-    # which rollout kernel rl_rollout_gaussian_mlp picks (csrc/env_kernels.hip, the launch rules at the end of the file):
-    # the lane-group kernels (16 envs per wavefront, four lanes per env in the physics sub-steps) for the Swimmer and
-    # for the two-leg envs up to 16 384 envs; otherwise 16 envs per wavefront while every wavefront still gets a SIMD
-    # of its own (<= 16 384 envs), one env per lane beyond
-    forced_epw = os.environ.get("RLLAB_ROLLOUT_EPW")
-    equal_hidden = len(wl["hidden"]) == 2 and wl["hidden"][0] == wl["hidden"][1] and wl["hidden"][0] in (32, 64)
-    if wl["env"] == "swimmer":
-        lane_group = not os.environ.get("RLLAB_SWIMMER_LANE_KERNEL") and 13 * T * n_envs * 4 < 2 ** 32 and (
-            equal_hidden or (wide and forced_epw is None))
-    elif wl["env"] in ("half_cheetah", "walker2d"):
-        lane_group = os.environ.get("RLLAB_TWO_LEG_LANE_KERNEL", "1")[:1] != "0" and forced_epw is None and \
-            n_envs <= 16 * 1024 and (equal_hidden or wide)
-    else:
-        lane_group = False
-    # ... and one env per wavefront for the two-legged envs while the wavefronts still find a SIMD each
-    tw = os.environ.get("RLLAB_TWO_LEG_WAVE_KERNEL")
-    env_per_wave = lane_group and wl["env"] in ("half_cheetah", "walker2d") and equal_hidden and \
-        (tw[:1] == "1" if tw else n_envs <= 2048)
-    envs_per_wave = 1 if env_per_wave else 16 if lane_group else (int(forced_epw) if forced_epw in ("16", "64") else
-                                                                  (16 if n_envs <= 16 * 1024 else 64))
-    n_waves = (n_envs + envs_per_wave - 1) // envs_per_wave
-    # ... and, for the Swimmer under a wide / deep net, four wavefronts per group of 16 envs (the network split by output
-    # units) while that is at most 1024 wavefronts and the weights fit the layout's LDS (csrc/env_kernels.hip)
-    cp = os.environ.get("RLLAB_SWIMMER_COOP")
-    coop = lane_group and wide and wl["env"] == "swimmer" and (cp[:1] == "1" if cp else n_waves * 4 <= 1024) and \
-        _coop_lds_bytes(13, 2, wl["hidden"]) <= 160 * 1024
-    if coop:
-        n_waves *= 4
-        rollout_name = ("rollout_swimmer_quad_coop_kernel (fused wide / deep policy + env step + record; FOUR wavefronts per "
-                        "group of 16 envs: the layers split by output units on 16 x 16 x 4 matrix tiles, activations "
-                        "through LDS; four lanes per env in the physics sub-steps)")
-    elif env_per_wave:
-        rollout_name = ("rollout_two_leg_wave_kernel (fused policy + env step + record; ONE env per wavefront: the policy's "
-                        "units on the lanes, one leg per lane in the physics sub-steps, the trajectory stored lane-distributed)")
-    elif lane_group:
-        rollout_name = "rollout_%s_quad_%skernel (fused policy + env step + record; 16 envs per wavefront, %s)" % (
-            "swimmer" if wl["env"] == "swimmer" else "two_leg", "wide_" if wide else "",
-            "four lanes per env in the physics sub-steps" if wl["env"] == "swimmer" else
-            "a lane group per env with one leg per lane in the physics sub-steps")
-    elif wide:
-        rollout_name = "rollout_wide_kernel (fused wide / deep policy + env step + record; weight fragments in LDS)"
-    else:
-        rollout_name = "rollout_kernel (fused policy + env step + record; %s)" % (
-            "one env per lane" if envs_per_wave == 64 else "16 envs per wavefront, the physics replicated in four lanes")
+    # which rollout kernel rl_rollout_gaussian_mlp launched, in which shape: the launcher's own plan (rl_rollout_plan_query --
+    # the launch rules as data; nothing is re-derived here)
+    plan = algo.sampler.vec_env.rollout_plan(policy, T)
+    assert plan is not None, "bench.py times the fused rollout"
+    envs_per_wave, n_waves = plan.envs_per_wavefront, plan.wavefronts
+    ROLLOUT_NOTES = {
+        1: "fused policy + env step + record; %s" % ("one env per lane" if envs_per_wave == 64 else
+                                                     "16 envs per wavefront, the physics replicated in four lanes"),
+        2: "fused wide / deep policy + env step + record; weight fragments in LDS",
+        3: "fused mean + log-std networks + env step + record",
+        4: "fused policy + env step + record; 16 envs per wavefront, four lanes per env in the physics sub-steps",
+        5: "fused wide / deep policy + env step + record; 16 envs per wavefront, four lanes per env in the physics sub-steps",
+        6: "fused wide / deep policy + env step + record; FOUR wavefronts per group of 16 envs: the layers split by output "
+           "units on 16 x 16 x 4 matrix tiles, activations through LDS; four lanes per env in the physics sub-steps",
+        7: "fused policy + env step + record; ONE env per wavefront: the policy's units on the lanes, one leg per lane in "
+           "the physics sub-steps, the trajectory stored lane-distributed",
+        8: "fused policy + env step + record; 16 envs per wavefront, a lane group per env with one leg per lane in the "
+           "physics sub-steps",
+        9: "fused wide / deep policy + env step + record; 16 envs per wavefront, one leg per lane in the physics sub-steps",
+    }
+    rollout_name = "%s (%s)" % (plan.name.decode(), ROLLOUT_NOTES.get(plan.kernel, ""))
     out = {
         "metric": "env steps/sec over full TRPO iterations (sample + process + update), 4096 envs per MI355X",
         "value": value, "unit": "env_steps/s", "n_gpus": world, "steps": args.steps,

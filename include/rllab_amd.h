@@ -49,7 +49,9 @@ const char* rl_last_error(void);
 
 /* Library / ABI version, bumped when a signature changes.  11: rl_rollout_lds_bytes, rl_mlp_forward_ws (every network
  * shape of the two kernel families as a function on planes), RL_CFG_LIMIT_MUJOCO, rl_policy_fvp_variant's value 2.
- * 12: rl_policy_batch.gate + rl_line_search_decide (the line search decided on the device). */
+ * 12: rl_policy_batch.gate + rl_line_search_decide (the line search decided on the device); rl_launch_opts (rl_rollout_args.opts,
+ * rl_policy_batch.opts, a trailing `variant` / `spin_limit` argument of rl_lfb_normal_eq / rl_peer_allreduce_sum) in place
+ * of the library's getenv reads; rl_rollout_plan_query. */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -165,6 +167,25 @@ int rl_vecenv_step(int kind, int n, int normalize, float scale_reward, int max_p
                    int env_offset, const rl_env_cfg* cfg, float* obs, float* reward, uint8_t* done,
                    void* stream);
 
+/* Launch-shape requests.  Every field: 0 = the library's own rule (what every production call passes).  The non-zero
+ * values exist for A/B timing and so that the parity tests can run every launch shape against the host build; the
+ * Python binding fills the struct from the RLLAB_* environment switches of INTEGRATION.md section 4 (rllab_amd/_lib.py::
+ * launch_opts) -- the library itself reads no environment variable.  rl_rollout_plan reports what a request resolves to. */
+typedef struct rl_launch_opts {
+    int32_t rollout_epw;          /* generic rollout kernels: 16 / 64 envs per wavefront (also keeps the Swimmer / two-leg
+                                   * lane-group kernels from being chosen) */
+    int32_t rollout_wpb;          /* lane-group shapes: 1 / 2 / 4 wavefronts per workgroup */
+    int32_t swimmer_lane_kernel;  /* 1: the generic env-per-lane kernel for the Swimmer */
+    int32_t swimmer_coop;         /* wide / deep policy on the Swimmer: 1 force, 2 forbid the four-wavefront shape */
+    int32_t two_leg_lane_kernel;  /* 2: forbid the one-leg-per-lane kernels (HalfCheetah / Walker2D) */
+    int32_t two_leg_wave_kernel;  /* 1 force, 2 forbid one env per wavefront */
+    int32_t fvp_split;            /* rl_policy_fvp: 1 = f32 matrix instructions only, 2 = the cooperative split kernel for
+                                   * every shape it is built for */
+    int32_t fvp_split_wps;        /* 1: fvp_split_kernel with one wavefront per SIMD (register-resident operands) */
+    int32_t lfb_valu;             /* rl_lfb_normal_eq: 1 = the register-blocked vector kernel */
+    int32_t reserved[7];
+} rl_launch_opts;
+
 /* Arguments of the fused rollout: T lock-step iterations of
  *   policy.get_actions -> env.step -> record -> auto-reset
  * for n envs in ONE launch (every env is independent, so no grid-wide
@@ -207,9 +228,39 @@ typedef struct rl_rollout_args {
     float* log_stds;          /* with theta_std: float[act_dim][T][n] agent_info "log_std" (floored at log_min_std) */
     int32_t std_hidden0, std_hidden1, std_hidden2;   /* hidden sizes of the log-std network (as hidden0..2) */
     int32_t reserved;
+    const rl_launch_opts* opts;   /* host; NULL = every launch rule the library's own */
 } rl_rollout_args;
 
 int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);
+
+/* Which kernel, in which shape, rl_rollout_gaussian_mlp(args) launches -- the launch rules as data (host query, launches
+ * nothing; only kind, n_envs, horizon, the hidden sizes, theta_std != NULL, cfg->flags and opts are read).  bench.py names
+ * the kernel of its roofline from here, HipVecEnv.takes_rollout_of asks `supported` before it commits a policy to the
+ * fused path, the parity tests assert the shape they meant to run. */
+enum rl_rollout_kernel {
+    RL_ROLLOUT_UNSUPPORTED = 0,      /* no fused kernel: sample through rl_vecenv_step */
+    RL_ROLLOUT_GENERIC = 1,          /* rollout_kernel<Env, H, H, EPW>: (32,32) / (64,64), weights in registers */
+    RL_ROLLOUT_WIDE = 2,             /* rollout_wide_kernel<Env, EPW>: two or three layers of 32 / 64 / 128, fragments in LDS */
+    RL_ROLLOUT_DUAL = 3,             /* rollout_dual_kernel<Env, EPW>: mean net + log-std net */
+    RL_ROLLOUT_SWIMMER_QUAD = 4,     /* rollout_swimmer_quad_kernel<H>: four lanes per env in the physics */
+    RL_ROLLOUT_SWIMMER_QUAD_WIDE = 5,
+    RL_ROLLOUT_SWIMMER_QUAD_COOP = 6,/* ... the network split over four wavefronts per group of 16 envs */
+    RL_ROLLOUT_TWO_LEG_WAVE = 7,     /* rollout_two_leg_wave_kernel<Env, H>: one env per wavefront */
+    RL_ROLLOUT_TWO_LEG_QUAD = 8,     /* rollout_two_leg_quad_kernel<Env, H>: one leg per lane, 16 envs per wavefront */
+    RL_ROLLOUT_TWO_LEG_QUAD_WIDE = 9
+};
+typedef struct rl_rollout_plan {
+    int32_t kernel;                    /* rl_rollout_kernel */
+    int32_t envs_per_wavefront;        /* 64, 16 or 1 */
+    int32_t wavefronts;                /* of the whole launch */
+    int32_t wavefronts_per_workgroup;
+    int32_t workgroups;
+    int32_t lds_bytes;                 /* dynamic LDS of one workgroup (0: static only) */
+    int32_t lds_limit;                 /* of a CU: 160 KB */
+    int32_t reserved;
+    char name[96];                     /* the kernel's name with its template arguments, e.g. "rollout_swimmer_quad_kernel<32>" */
+} rl_rollout_plan;
+int rl_rollout_plan_query(const rl_rollout_args* args, rl_rollout_plan* plan);
 
 /* LDS bytes the fused rollout of a WIDE / DEEP policy (any hidden sizes other than (32,32) / (64,64): two or three tanh
  * layers of 32 / 64 / 128 units, weight fragments in LDS) or of a policy with a log-std NETWORK (std_hidden0 != 0:
@@ -289,7 +340,8 @@ int rl_adv_finish(size_t n_samples, const float* adv_in, const uint8_t* valid, d
  *   out = [ Phi^T Phi (F*F, row-major) | Phi^T returns (F) ],  F = 2*obs_dim + 4. */
 int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs, const int32_t* tin,
                      const float* returns, const uint8_t* valid, void* workspace, size_t workspace_bytes,
-                     double* out, void* stream);
+                     double* out, int variant, void* stream);   /* variant: 0 = matrix-core kernel (the library's choice),
+                                                                 * 1 = register-blocked vector kernel (rl_launch_opts.lfb_valu) */
 
 /* One dense batch for the fused GaussianMLPPolicy update kernels.  Per-sample arrays
  * are planes with the sample axis last (B = n_samples). */
@@ -323,6 +375,7 @@ typedef struct rl_policy_batch {
     int32_t activation;        /* RL_ACT_TANH (policies) or RL_ACT_RECTIFY (GaussianMLPRegressor's default hidden
                                 * nonlinearity, gaussian_mlp_regressor.py:31; loss and vpg gradient only, act_dim 1,
                                 * hidden 32x32) */
+    const rl_launch_opts* opts;/* host; NULL = the library's own kernel choice (rl_policy_fvp_variant reports it) */
     const int32_t* gate;       /* NULL, or a device word: rl_policy_loss_kl returns without evaluating anything when
                                 * *gate != 0 at the time the launch RUNS (its out4 is then unspecified).  The word is
                                 * rl_line_search_decide's "a candidate has been accepted" flag: the loss passes of
@@ -514,7 +567,9 @@ int rl_peer_export(void* dev_ptr, void* handle_out64_host);
 int rl_peer_open(const void* handle64_host, void** dev_ptr_out);
 int rl_peer_close(void* dev_ptr);
 int rl_peer_allreduce_sum(int n, double* data, int rank, int world, void* const* mailboxes_host, int max_n,
-                          uint64_t seq, int* err_dev, void* stream);
+                          uint64_t seq, int* err_dev, int64_t spin_limit, void* stream);   /* spin_limit: 0 = give up on a
+                                                                 * silent peer after 10 s of wall clock only; > 0 also after
+                                                                 * that many polls (tests of the give-up path) */
 
 /* Debug / test hook: fill out[4*count] with Philox4x32-10 blocks for counters
  * (c0 + i, c1, c2, c3), key (k0, k1), i = 0..count-1.  Device buffer. */

@@ -26,7 +26,7 @@ ENV_INVERTED_DOUBLE_PENDULUM = 7
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
-    "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_rollout_lds_bytes", "rl_gae",
+    "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_rollout_plan_query", "rl_rollout_lds_bytes", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_variant", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_line_search_decide", "rl_adam_step",
     "rl_path_scan", "rl_process_workspace_bytes", "rl_sample_stats_cols", "rl_sample_stats", "rl_adv_finish",
@@ -63,6 +63,7 @@ class RolloutArgs(ctypes.Structure):
         ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p), ("cfg", ctypes.POINTER(EnvCfg)),
         ("theta_std", ctypes.c_void_p), ("log_stds", ctypes.c_void_p), ("std_hidden0", ctypes.c_int32),
         ("std_hidden1", ctypes.c_int32), ("std_hidden2", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("opts", ctypes.c_void_p),
     ]
 
 
@@ -75,11 +76,76 @@ class PolicyBatch(ctypes.Structure):
         ("log_min_std", ctypes.c_float), ("theta", ctypes.c_void_p), ("obs", ctypes.c_void_p),
         ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
         ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
-        ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32), ("gate", ctypes.c_void_p),
+        ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32), ("opts", ctypes.c_void_p),
+        ("gate", ctypes.c_void_p),
     ]
 
 
 ACT_TANH, ACT_RECTIFY = 0, 1
+
+
+class LaunchOpts(ctypes.Structure):
+    """Mirror of ``rl_launch_opts`` (include/rllab_amd.h): launch-shape requests, 0 = the library's own rule."""
+    _fields_ = [
+        ("rollout_epw", ctypes.c_int32), ("rollout_wpb", ctypes.c_int32), ("swimmer_lane_kernel", ctypes.c_int32),
+        ("swimmer_coop", ctypes.c_int32), ("two_leg_lane_kernel", ctypes.c_int32), ("two_leg_wave_kernel", ctypes.c_int32),
+        ("fvp_split", ctypes.c_int32), ("fvp_split_wps", ctypes.c_int32), ("lfb_valu", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 7),
+    ]
+
+
+class RolloutPlan(ctypes.Structure):
+    """Mirror of ``rl_rollout_plan``: which kernel, in which shape, a rollout call launches."""
+    _fields_ = [
+        ("kernel", ctypes.c_int32), ("envs_per_wavefront", ctypes.c_int32), ("wavefronts", ctypes.c_int32),
+        ("wavefronts_per_workgroup", ctypes.c_int32), ("workgroups", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
+        ("lds_limit", ctypes.c_int32), ("reserved", ctypes.c_int32), ("name", ctypes.c_char * 96),
+    ]
+
+
+ROLLOUT_UNSUPPORTED = 0
+_OPTS = LaunchOpts()        # ONE instance, refreshed in place: its address is what the argument structs carry
+
+
+def _env_int(name, allowed):
+    v = os.environ.get(name)
+    if v is None:
+        return 0
+    try:
+        v = int(v)
+    except ValueError:
+        return 0
+    return v if v in allowed else 0
+
+
+def launch_opts():
+    """Address of the process's ``rl_launch_opts``, refreshed from the RLLAB_* switches of INTEGRATION.md section 4 (read
+    HERE, per call -- the library reads no environment variable; tests flip the switches between two launches of one
+    process).  Unset switches leave every field 0 = the library's own launch rules."""
+    e, o = os.environ.get, _OPTS
+    o.rollout_epw = _env_int("RLLAB_ROLLOUT_EPW", (16, 64))
+    o.rollout_wpb = _env_int("RLLAB_ROLLOUT_WPB", (1, 2, 4))
+    o.swimmer_lane_kernel = 1 if e("RLLAB_SWIMMER_LANE_KERNEL") is not None else 0
+    v = e("RLLAB_SWIMMER_COOP")
+    o.swimmer_coop = 0 if not v else (1 if v[0] == "1" else 2)
+    v = e("RLLAB_TWO_LEG_LANE_KERNEL")
+    o.two_leg_lane_kernel = 2 if v and v[0] == "0" else 0
+    v = e("RLLAB_TWO_LEG_WAVE_KERNEL")
+    o.two_leg_wave_kernel = 0 if not v else (1 if v[0] == "1" else 2)
+    v = e("RLLAB_FVP_SPLIT")
+    o.fvp_split = 0 if not v else (1 if v[0] == "0" else 2 if v[0] == "2" else 0)
+    v = e("RLLAB_FVP_SPLIT_WPS")
+    o.fvp_split_wps = 1 if v and v[0] == "1" else 0
+    o.lfb_valu = 1 if e("RLLAB_LFB_VALU") is not None else 0
+    return ctypes.addressof(o)
+
+
+def peer_spin_limit():
+    """RLLAB_PEER_SPIN_LIMIT (polls before rl_peer_allreduce_sum gives up on a silent peer; tests), 0 = wall clock only."""
+    try:
+        return max(0, int(os.environ.get("RLLAB_PEER_SPIN_LIMIT", "0")))
+    except ValueError:
+        return 0
 
 
 def _load():
@@ -106,6 +172,7 @@ def _load():
     lib.rl_counter_add.argtypes = [vp, u64, vp]
     lib.rl_vecenv_step.argtypes = [i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, u64, u64, i32, cfgp, vp, vp, vp, vp]
     lib.rl_rollout_gaussian_mlp.argtypes = [ctypes.POINTER(RolloutArgs), vp]
+    lib.rl_rollout_plan_query.argtypes = [ctypes.POINTER(RolloutArgs), ctypes.POINTER(RolloutPlan)]
     lib.rl_rollout_lds_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_size_t),
                                          ctypes.POINTER(ctypes.c_size_t)]
     lib.rl_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp, vp, vp]
@@ -135,7 +202,7 @@ def _load():
     lib.rl_sample_stats_cols.restype = i32
     lib.rl_sample_stats.argtypes = [sz, vp, vp, vp, vp, vp, vp, f64, f64, vp, i32, vp, sz, vp, vp]
     lib.rl_adv_finish.argtypes = [sz, vp, vp, f64, f64, f64, vp, vp]
-    lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, vp]
+    lib.rl_lfb_normal_eq.argtypes = [sz, i32, vp, vp, vp, vp, vp, sz, vp, i32, vp]
     lib.rl_mlp_forward.argtypes = [pb, vp, vp, vp, vp]
     lib.rl_mlp_forward_ws.argtypes = [pb, vp, vp, sz, vp, vp, vp]
     lib.rl_mlp_backward.argtypes = [pb, vp, vp, sz, vp, vp]
@@ -151,7 +218,7 @@ def _load():
     lib.rl_peer_export.argtypes = [vp, vp]
     lib.rl_peer_open.argtypes = [vp, vpp]
     lib.rl_peer_close.argtypes = [vp]
-    lib.rl_peer_allreduce_sum.argtypes = [i32, vp, i32, i32, vpp, i32, u64, vp, vp]
+    lib.rl_peer_allreduce_sum.argtypes = [i32, vp, i32, i32, vpp, i32, u64, vp, ctypes.c_int64, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError here = header / library mismatch
     return lib
@@ -187,17 +254,33 @@ def env_query(kind):
                 reset_is_normal=bool(nrm.value))
 
 
-def rollout_lds_fits(kind, hidden3, std_hidden3=(0, 0, 0)):
-    """Does the fused rollout of these hidden sizes (and, with ``std_hidden3``, of a log-std network next to the mean
-    network) fit the LDS of a CU for env ``kind``?  rl_rollout_lds_bytes; equal-width (32, 32) / (64, 64) nets keep
-    their weights in registers and always fit."""
-    if tuple(std_hidden3) == (0, 0, 0) and tuple(hidden3) in ((32, 32, 0), (64, 64, 0)):
-        return True
-    b, lim = ctypes.c_size_t(), ctypes.c_size_t()
-    check(lib.rl_rollout_lds_bytes(kind, hidden3[0], hidden3[1], hidden3[2], std_hidden3[0], std_hidden3[1],
-                                   std_hidden3[2], ctypes.byref(b), ctypes.byref(lim)), "rl_rollout_lds_bytes")
-    return 0 < b.value <= lim.value
+def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0):
+    """``RolloutPlan`` of a fused rollout of these sizes under the current launch options (rl_rollout_plan_query), or None
+    when the library has no kernel for it (the reason is then in ``lib.rl_last_error()``)."""
+    a = RolloutArgs(kind=kind, n_envs=int(n_envs), horizon=int(horizon), hidden0=hidden3[0], hidden1=hidden3[1],
+                    hidden2=hidden3[2], std_hidden0=std_hidden3[0], std_hidden1=std_hidden3[1], std_hidden2=std_hidden3[2])
+    cfg = None
+    if cfg_flags:
+        cfg = EnvCfg()
+        check(lib.rl_env_default_cfg(kind, ctypes.byref(cfg)), "rl_env_default_cfg")
+        cfg.flags = int(cfg_flags)
+        a.cfg = ctypes.pointer(cfg)
+    if tuple(std_hidden3) != (0, 0, 0):
+        a.theta_std = 1          # (only its being non-NULL is read by the query: a log-std network is present)
+        a.log_stds = 1
+    a.opts = launch_opts()
+    plan = RolloutPlan()
+    rc = lib.rl_rollout_plan_query(ctypes.byref(a), ctypes.byref(plan))
+    if rc != 0 or plan.kernel == ROLLOUT_UNSUPPORTED:
+        return None
+    return plan
 
+
+def rollout_lds_fits(kind, hidden3, std_hidden3=(0, 0, 0), n_envs=64, horizon=1):
+    """Does the library have a fused rollout for these hidden sizes (and, with ``std_hidden3``, a log-std network next to the
+    mean network) on env ``kind`` -- the launcher's own answer (rl_rollout_plan_query: the shape it would choose fits
+    the LDS of a CU), not a copy of its rules."""
+    return rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3) is not None
 
 def env_default_cfg(kind, **overrides):
     """``EnvCfg`` of env ``kind``: its defaults (rl_env_default_cfg) with ``overrides`` (field = value) applied."""

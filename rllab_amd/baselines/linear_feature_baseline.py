@@ -8,6 +8,8 @@ normal equations Phi^T Phi and Phi^T y are accumulated on the device in float64
 (all-reduced across ranks when sharded -- every rank then solves the same
 (2*Do+4)^2 system with the reference's lstsq + regularisation-retry rule).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -125,7 +127,9 @@ class LinearFeatureBaseline(Baseline):
             packed = torch.empty((F + 1) * F, dtype=torch.float64, device=traj.device)
             _lib.check(_lib.lib.rl_lfb_normal_eq(traj.B, traj.obs_dim, _lib.ptr(traj.obs), _lib.ptr(tin),
                                                  _lib.ptr(traj.returns), _lib.ptr(valid_u8), _lib.ptr(ws),
-                                                 ws.numel(), _lib.ptr(packed), _lib.stream_ptr()),
+                                                 ws.numel(), _lib.ptr(packed),
+                                                 1 if os.environ.get("RLLAB_LFB_VALU") is not None else 0,
+                                                 _lib.stream_ptr()),
                        "rl_lfb_normal_eq")
         else:
             phi = self._features_dense(traj)

@@ -1890,10 +1890,20 @@ static int launch_step(int n, int normalize, float scale_reward, int mpl, int au
     return check_launch("vecenv_step_kernel");
 }
 
-// wavefronts per workgroup of the lane-group shapes (RLLAB_ROLLOUT_WPB = 1 / 2 / 4 forces one, for A/B timing)
-static int lane_group_wpb(int waves) {
-    const char* e = getenv("RLLAB_ROLLOUT_WPB");
-    const int v = e ? atoi(e) : 0;
+// ---- launch rules as data ----------------------------------------------------------------------------------------------
+// plan_rollout<Env> decides kernel and shape from the arguments (and rl_launch_opts: 0 = these rules, anything else an
+// explicit request of a test or an A/B run); launch_rollout<Env> executes the plan; rl_rollout_plan_query hands the plan to
+// the caller.  Nothing here reads the environment.
+static const rl_launch_opts NO_OPTS = {};
+static const char* env_name(int kind) {
+    static const char* const names[] = {"Cartpole", "DoublePendulum", "Swimmer", "HalfCheetah", "CartpoleSwingup", "Walker2D",
+                                        "Hopper", "InvertedDoublePendulum"};
+    return (kind >= 0 && kind < 8) ? names[kind] : "?";
+}
+
+// wavefronts per workgroup of the lane-group shapes
+static int lane_group_wpb(int waves, const rl_launch_opts& o) {
+    const int v = o.rollout_wpb;
     if (v == 1 || v == 2 || v == 4) return v;
     return waves <= 256 ? 1 : LANE_TPB / 64;
 }
@@ -1901,8 +1911,8 @@ static int lane_group_wpb(int waves) {
 constexpr size_t LDS_LIMIT = 160 * 1024;
 // The wide / dual rollouts keep their weight fragments in LDS next to one [input][lane] tile per wavefront: a workgroup
 // of several wavefronts may not fit where a single-wavefront one does.  Largest wavefronts-per-workgroup <= wpb whose
-// workgroup fits the 160 KB of a CU; 0 when not even one wavefront does (the caller then reports UNSUPPORTED and the
-// Python side samples such a policy through the per-transition loop, rl_rollout_lds_bytes tells it beforehand).
+// workgroup fits the 160 KB of a CU; 0 when not even one wavefront does (the plan is then UNSUPPORTED and the Python side
+// samples such a policy through the per-transition loop).
 template <class LdsFn>
 static int fit_wpb(int wpb, LdsFn lds_bytes) {
     for (; wpb >= 1; wpb >>= 1)
@@ -1919,21 +1929,31 @@ static size_t rollout_lds_bytes(int h0, int h1, int h2, int s0, int s1, int s2) 
     return RolloutPolicyDual<Env>::lds_floats(ms, ss, 64) * sizeof(float);
 }
 
+static void plan_fill(rl_rollout_plan* p, int kernel, int epw, int waves, int wpb, size_t lds, const char* name) {
+    p->kernel = kernel;
+    p->envs_per_wavefront = epw;
+    p->wavefronts = waves;
+    p->wavefronts_per_workgroup = wpb;
+    p->workgroups = wpb > 0 ? (waves + wpb - 1) / wpb : 0;
+    p->lds_bytes = (int32_t)lds;
+    p->lds_limit = (int32_t)LDS_LIMIT;
+    p->reserved = 0;
+    snprintf(p->name, sizeof(p->name), "%s", name);
+}
+
+// returns RL_OK with plan->kernel != RL_ROLLOUT_UNSUPPORTED, or RL_ERR_UNSUPPORTED (plan->kernel = UNSUPPORTED, the error
+// string says why), or RL_ERR_ARG
 template <class Env>
-static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
-    RolloutDev a;
-    a.n = g->n_envs; a.T = g->horizon; a.max_path_length = g->max_path_length;
-    a.normalize = g->normalize; a.reset_at_start = g->reset_at_start; a.env_offset = g->env_offset;
-    a.scale_reward = g->scale_reward; a.log_min_std = g->log_min_std;
-    a.seed = g->seed; a.step_counter = g->step_counter;
-    a.state = g->state; a.ts = g->ts; a.theta = g->theta; a.eps = g->eps; a.reset_draws = g->reset_draws;
-    a.obs = g->obs; a.actions = g->actions; a.means = g->means; a.rewards = g->rewards; a.dones = g->dones;
-    a.last_obs = g->last_obs;
-    int rc = device_cfg<Env>(g->cfg, a.cfg);
-    if (rc) return rc;
-    a.act_noise_z = g->cfg ? g->cfg->action_noise_z : nullptr;
-    a.obs_noise_z = g->cfg ? g->cfg->obs_noise_z : nullptr;
-    a.log_stds = g->log_stds;
+static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
+    const rl_launch_opts& o = g->opts ? *g->opts : NO_OPTS;
+    const int n = g->n_envs, T = g->horizon;
+    const int cfg_flags = g->cfg ? g->cfg->flags : 0;
+    plan_fill(p, RL_ROLLOUT_UNSUPPORTED, 0, 0, 0, 0, "");
+    char nm[96];
+    const bool equal = g->hidden2 == 0 && g->hidden0 == g->hidden1 && (g->hidden0 == 32 || g->hidden0 == 64);
+    const bool small_offsets = (size_t)Env::OBS * (size_t)T * (size_t)n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
+    const int epw_req = (o.rollout_epw == 16 || o.rollout_epw == 64) ? o.rollout_epw : 0;
+    const int epw_generic = epw_req ? epw_req : (n <= 16 * 1024 ? 16 : 64);
     if (g->theta_std != nullptr) {
         // a log-std NETWORK (adaptive_std / std_network): both networks in the kernel, log_std planes recorded
         if (!g->log_stds) return set_error(RL_ERR_ARG, "rl_rollout_gaussian_mlp: theta_std without log_stds");
@@ -1944,192 +1964,204 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
                              "rl_rollout_gaussian_mlp: mean net (%d,%d,%d) / log-std net (%d,%d,%d): each two or three tanh "
                              "layers of 32 / 64 / 128 units", g->hidden0, g->hidden1, g->hidden2, g->std_hidden0,
                              g->std_hidden1, g->std_hidden2);
-        const char* es = getenv("RLLAB_ROLLOUT_EPW");
-        const int ee = es ? atoi(es) : 0;
-        const int epw = (ee == 16 || ee == 64) ? ee : (a.n <= 16 * 1024 ? 16 : 64);
-        const int waves = (a.n + epw - 1) / epw;
-        const int wpb = fit_wpb((epw == 16) ? lane_group_wpb(waves) : 1, [&](int threads) {
+        const int epw = epw_generic, waves = (n + epw - 1) / epw;
+        const int wpb = fit_wpb((epw == 16) ? lane_group_wpb(waves, o) : 1, [&](int threads) {
             return RolloutPolicyDual<Env>::lds_floats(ms, ss, threads) * sizeof(float); });
         if (wpb == 0)
             return set_error(RL_ERR_UNSUPPORTED, "rollout of the two networks needs %zu B of LDS (a CU has %zu)",
                              RolloutPolicyDual<Env>::lds_floats(ms, ss, 64) * sizeof(float), LDS_LIMIT);
-        dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
-        const size_t mean_floats = RolloutPolicyWide<Env>::lds_floats(ms, 64 * wpb);
-        const size_t lds = RolloutPolicyDual<Env>::lds_floats(ms, ss, 64 * wpb) * sizeof(float);
-        static bool attr16 = false, attr64 = false;
-        if (epw == 16) {
-            auto kern = rollout_dual_kernel<Env, 16>;
-            if (!attr16) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                attr16 = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, a, ms, ss, g->theta_std, (int)mean_floats);
-        } else {
-            auto kern = rollout_dual_kernel<Env, 64>;
-            if (!attr64) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                attr64 = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, a, ms, ss, g->theta_std, (int)mean_floats);
-        }
-        return check_launch("rollout_dual_kernel");
+        snprintf(nm, sizeof(nm), "rollout_dual_kernel<%s, %d>", env_name(Env::KIND), epw);
+        plan_fill(p, RL_ROLLOUT_DUAL, epw, waves, wpb, RolloutPolicyDual<Env>::lds_floats(ms, ss, 64 * wpb) * sizeof(float), nm);
+        return RL_OK;
     }
+    WideShape shape;
+    const bool wide_ok = wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape);
+    const int quad_waves = (n + QUAD_ENVS - 1) / QUAD_ENVS;
     if constexpr (std::is_same<Env, Swimmer>::value) {
-        // lane group per env (RLLAB_SWIMMER_LANE_KERNEL=1 selects the env-per-lane kernel for A/B timing)
-        // (RL_CFG_LIMIT_MUJOCO: the soft-constraint limits live in the scalar sub-step program only)
-        const bool lane_kernel = getenv("RLLAB_SWIMMER_LANE_KERNEL") != nullptr ||   // per launch: tests switch shapes
-                                 (a.cfg.flags & CFG_LIMIT_MUJOCO) != 0;
-        const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
-        if (!lane_kernel && small_offsets && g->hidden2 == 0 && (g->hidden0 == g->hidden1) &&
-            (g->hidden0 == 32 || g->hidden0 == 64)) {
-            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
-            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
-            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), qgrid, qblock, 0, st, a);
-            else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), qgrid, qblock, 0, st, a);
-            return check_launch("rollout_swimmer_quad_kernel");
+        // lane group per env (swimmer_lane_kernel = 1: the env-per-lane kernel; RL_CFG_LIMIT_MUJOCO: the soft-constraint
+        // limits live in the scalar sub-step program only)
+        const bool lane_kernel = o.swimmer_lane_kernel == 1 || (cfg_flags & RL_CFG_LIMIT_MUJOCO) != 0;
+        if (!lane_kernel && small_offsets && equal) {
+            snprintf(nm, sizeof(nm), "rollout_swimmer_quad_kernel<%d>", g->hidden0);
+            plan_fill(p, RL_ROLLOUT_SWIMMER_QUAD, QUAD_ENVS, quad_waves, lane_group_wpb(quad_waves, o), 0, nm);
+            return RL_OK;
         }
-        // the same lane-group physics under a wide / deep policy (RLLAB_ROLLOUT_EPW set: the generic shapes, for tests)
-        WideShape shape;
-        if (!lane_kernel && small_offsets && getenv("RLLAB_ROLLOUT_EPW") == nullptr &&
-            wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
-            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS;
-            // four wavefronts per group while every one of them still finds a SIMD of its own (RLLAB_SWIMMER_COOP = 1 / 0
-            // forces / forbids the shape: A/B timing, and the tests that compare shapes)
-            const char* cp = getenv("RLLAB_SWIMMER_COOP");
+        // the same lane-group physics under a wide / deep policy (rollout_epw set: the generic shapes, for tests)
+        if (!lane_kernel && small_offsets && !equal && epw_req == 0 && wide_ok) {
+            // four wavefronts per group while every one of them still finds a SIMD of its own
             const size_t coop_lds = RolloutPolicyCoop<Env>::lds_floats(shape) * sizeof(float);
-            if ((cp ? cp[0] == '1' : waves * COOP_WAVES <= 1024) && coop_lds <= LDS_LIMIT) {
-                auto kern = rollout_swimmer_quad_coop_kernel;
-                static bool cattr = false;
-                if (!cattr) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                    cattr = true;
-                }
-                hipLaunchKernelGGL(kern, dim3(waves), dim3(64 * COOP_WAVES), coop_lds, st, a, shape);
-                return check_launch("rollout_swimmer_quad_coop_kernel");
+            const bool coop = o.swimmer_coop == 1 || (o.swimmer_coop != 2 && quad_waves * COOP_WAVES <= 1024);
+            if (coop && coop_lds <= LDS_LIMIT) {
+                plan_fill(p, RL_ROLLOUT_SWIMMER_QUAD_COOP, QUAD_ENVS, quad_waves * COOP_WAVES, COOP_WAVES, coop_lds,
+                          "rollout_swimmer_quad_coop_kernel");
+                return RL_OK;
             }
-            const int wpb = fit_wpb(lane_group_wpb(waves), [&](int threads) {
+            const int wpb = fit_wpb(lane_group_wpb(quad_waves, o), [&](int threads) {
                 return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
-            dim3 qgrid((waves + (wpb ? wpb : 1) - 1) / (wpb ? wpb : 1)), qblock(64 * (wpb ? wpb : 1));
-            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * (wpb ? wpb : 1)) * sizeof(float);
             if (wpb > 0) {
-                auto kern = rollout_swimmer_quad_wide_kernel;
-                static bool attr = false;
-                if (!attr) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                    attr = true;
-                }
-                hipLaunchKernelGGL(kern, qgrid, qblock, lds, st, a, shape);
-                return check_launch("rollout_swimmer_quad_wide_kernel");
+                plan_fill(p, RL_ROLLOUT_SWIMMER_QUAD_WIDE, QUAD_ENVS, quad_waves, wpb,
+                          RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float), "rollout_swimmer_quad_wide_kernel");
+                return RL_OK;
             }
         }
     }
     if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
-        // one leg per lane while every lane-group wavefront still gets a SIMD of its own (RLLAB_TWO_LEG_LANE_KERNEL=0:
-        // the generic kernel, for A/B timing and for the tests that run every shape)
-        const char* tl = getenv("RLLAB_TWO_LEG_LANE_KERNEL");
-        const bool lanes_on = !(tl && tl[0] == '0') && getenv("RLLAB_ROLLOUT_EPW") == nullptr;
-        const bool small_offsets = (size_t)Env::OBS * (size_t)a.T * (size_t)a.n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
-        // one env per wavefront while the wavefronts still find (about) a SIMD each (RLLAB_TWO_LEG_WAVE_KERNEL = 1 / 0
-        // forces / forbids the shape: A/B timing, and the tests that compare shapes)
-        const char* tw = getenv("RLLAB_TWO_LEG_WAVE_KERNEL");
-        const bool wave_shape = tw ? tw[0] == '1' : a.n <= 2048;
-        if (lanes_on && wave_shape && small_offsets && g->hidden2 == 0 &&
-            (g->hidden0 == g->hidden1) && (g->hidden0 == 32 || g->hidden0 == 64)) {
-            const int waves = a.n, wpb = lane_group_wpb(waves);
-            dim3 wgrid((waves + wpb - 1) / wpb), wblock(64 * wpb);
-            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 32>), wgrid, wblock, 0, st, a);
-            else hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 64>), wgrid, wblock, 0, st, a);
-            return check_launch("rollout_two_leg_wave_kernel");
+        // one leg per lane while every lane-group wavefront still gets a SIMD of its own (two_leg_lane_kernel = 2: the
+        // generic kernel, for A/B timing and for the tests that run every shape)
+        const bool lanes_on = o.two_leg_lane_kernel != 2 && epw_req == 0;
+        // one env per wavefront while the wavefronts still find (about) a SIMD each
+        const bool wave_shape = o.two_leg_wave_kernel == 1 || (o.two_leg_wave_kernel != 2 && n <= 2048);
+        if (lanes_on && wave_shape && small_offsets && equal) {
+            snprintf(nm, sizeof(nm), "rollout_two_leg_wave_kernel<%s, %d>", env_name(Env::KIND), g->hidden0);
+            plan_fill(p, RL_ROLLOUT_TWO_LEG_WAVE, 1, n, lane_group_wpb(n, o), 0, nm);
+            return RL_OK;
         }
-        if (lanes_on && small_offsets && a.n <= 16 * 1024 && g->hidden2 == 0 && (g->hidden0 == g->hidden1) &&
-            (g->hidden0 == 32 || g->hidden0 == 64)) {
-            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS, wpb = lane_group_wpb(waves);
-            dim3 qgrid((waves + wpb - 1) / wpb), qblock(64 * wpb);
-            if (g->hidden0 == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32>), qgrid, qblock, 0, st, a);
-            else hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64>), qgrid, qblock, 0, st, a);
-            return check_launch("rollout_two_leg_quad_kernel");
+        if (lanes_on && small_offsets && n <= 16 * 1024 && equal) {
+            snprintf(nm, sizeof(nm), "rollout_two_leg_quad_kernel<%s, %d>", env_name(Env::KIND), g->hidden0);
+            plan_fill(p, RL_ROLLOUT_TWO_LEG_QUAD, QUAD_ENVS, quad_waves, lane_group_wpb(quad_waves, o), 0, nm);
+            return RL_OK;
         }
-        WideShape shape;
-        if (lanes_on && small_offsets && a.n <= 16 * 1024 &&
-            wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape)) {
-            const int waves = (a.n + QUAD_ENVS - 1) / QUAD_ENVS;
-            const int wpb = fit_wpb(lane_group_wpb(waves), [&](int threads) {
+        if (lanes_on && small_offsets && n <= 16 * 1024 && !equal && wide_ok) {
+            const int wpb = fit_wpb(lane_group_wpb(quad_waves, o), [&](int threads) {
                 return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
-            dim3 qgrid((waves + (wpb ? wpb : 1) - 1) / (wpb ? wpb : 1)), qblock(64 * (wpb ? wpb : 1));
-            const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * (wpb ? wpb : 1)) * sizeof(float);
             if (wpb > 0) {
-                auto kern = rollout_two_leg_quad_wide_kernel<Env>;
-                static bool attr = false;
-                if (!attr) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                    attr = true;
-                }
-                hipLaunchKernelGGL(kern, qgrid, qblock, lds, st, a, shape);
-                return check_launch("rollout_two_leg_quad_wide_kernel");
+                snprintf(nm, sizeof(nm), "rollout_two_leg_quad_wide_kernel<%s>", env_name(Env::KIND));
+                plan_fill(p, RL_ROLLOUT_TWO_LEG_QUAD_WIDE, QUAD_ENVS, quad_waves, wpb,
+                          RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float), nm);
+                return RL_OK;
             }
         }
     }
     // 16 envs per wavefront while that still leaves every wavefront a SIMD of its own (1024 SIMDs); beyond, the
-    // replicated physics would cost throughput.  RLLAB_ROLLOUT_EPW = 16 / 64 forces a shape (A/B timing).
-    const char* epw_str = getenv("RLLAB_ROLLOUT_EPW");      // read per launch: tests switch shapes inside one process
-    const int epw_env = epw_str ? atoi(epw_str) : 0;
-    const int epw = (epw_env == 16 || epw_env == 64) ? epw_env : (a.n <= 16 * 1024 ? 16 : 64);
-    const int waves = (a.n + epw - 1) / epw;
-    int wpb = (epw == 16) ? lane_group_wpb(waves) : 1;
-    dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
-    if (g->hidden2 == 0 && g->hidden0 == 32 && g->hidden1 == 32) {
-        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, block, 0, st, a);
-    } else if (g->hidden2 == 0 && g->hidden0 == 64 && g->hidden1 == 64) {
-        if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, block, 0, st, a);
-    } else {
-        // wide / deep policies: two or three layers of 32 / 64 / 128 units, weight fragments in (dynamic) LDS
-        WideShape shape;
-        if (!wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape))
-            return set_error(RL_ERR_UNSUPPORTED,
-                             "rl_rollout_gaussian_mlp: hidden sizes (%d,%d,%d) have no fused kernel (two or three tanh "
-                             "layers of 32 / 64 / 128 units each); use the per-step rl_vecenv_step path",
-                             g->hidden0, g->hidden1, g->hidden2);
-        wpb = fit_wpb(wpb, [&](int threads) { return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
-        if (wpb == 0)
-            return set_error(RL_ERR_UNSUPPORTED, "wide rollout policy needs %zu B of LDS (a CU has %zu)",
-                             RolloutPolicyWide<Env>::lds_floats(shape, 64) * sizeof(float), LDS_LIMIT);
-        grid = dim3((waves + wpb - 1) / wpb); block = dim3(64 * wpb);
-        const size_t lds = RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float);
-        static bool attr16 = false, attr64 = false;
-        if (epw == 16) {
-            auto kern = rollout_wide_kernel<Env, 16>;
-            if (!attr16) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                attr16 = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, a, shape);
-        } else {
-            auto kern = rollout_wide_kernel<Env, 64>;
-            if (!attr64) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-                attr64 = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, a, shape);
-        }
-        return check_launch("rollout_wide_kernel");
+    // replicated physics would cost throughput.
+    const int epw = epw_generic, waves = (n + epw - 1) / epw;
+    int wpb = (epw == 16) ? lane_group_wpb(waves, o) : 1;
+    if (equal) {
+        snprintf(nm, sizeof(nm), "rollout_kernel<%s, %d, %d, %d>", env_name(Env::KIND), g->hidden0, g->hidden1, epw);
+        plan_fill(p, RL_ROLLOUT_GENERIC, epw, waves, wpb, 0, nm);
+        return RL_OK;
     }
-    return check_launch("rollout_kernel");
+    // wide / deep policies: two or three layers of 32 / 64 / 128 units, weight fragments in (dynamic) LDS
+    if (!wide_ok)
+        return set_error(RL_ERR_UNSUPPORTED,
+                         "rl_rollout_gaussian_mlp: hidden sizes (%d,%d,%d) have no fused kernel (two or three tanh "
+                         "layers of 32 / 64 / 128 units each); use the per-step rl_vecenv_step path",
+                         g->hidden0, g->hidden1, g->hidden2);
+    wpb = fit_wpb(wpb, [&](int threads) { return RolloutPolicyWide<Env>::lds_floats(shape, threads) * sizeof(float); });
+    if (wpb == 0)
+        return set_error(RL_ERR_UNSUPPORTED, "wide rollout policy needs %zu B of LDS (a CU has %zu)",
+                         RolloutPolicyWide<Env>::lds_floats(shape, 64) * sizeof(float), LDS_LIMIT);
+    snprintf(nm, sizeof(nm), "rollout_wide_kernel<%s, %d>", env_name(Env::KIND), epw);
+    plan_fill(p, RL_ROLLOUT_WIDE, epw, waves, wpb, RolloutPolicyWide<Env>::lds_floats(shape, 64 * wpb) * sizeof(float), nm);
+    return RL_OK;
+}
+
+// hipFuncSetAttribute once per kernel (dynamic LDS beyond 64 KB)
+template <class K>
+static int allow_big_lds(K kern, bool& done) {
+    if (done) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    done = true;
+    return 0;
+}
+
+template <class Env>
+static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
+    rl_rollout_plan pl;
+    int rc = plan_rollout<Env>(g, &pl);
+    if (rc) return rc;
+    RolloutDev a;
+    a.n = g->n_envs; a.T = g->horizon; a.max_path_length = g->max_path_length;
+    a.normalize = g->normalize; a.reset_at_start = g->reset_at_start; a.env_offset = g->env_offset;
+    a.scale_reward = g->scale_reward; a.log_min_std = g->log_min_std;
+    a.seed = g->seed; a.step_counter = g->step_counter;
+    a.state = g->state; a.ts = g->ts; a.theta = g->theta; a.eps = g->eps; a.reset_draws = g->reset_draws;
+    a.obs = g->obs; a.actions = g->actions; a.means = g->means; a.rewards = g->rewards; a.dones = g->dones;
+    a.last_obs = g->last_obs;
+    rc = device_cfg<Env>(g->cfg, a.cfg);
+    if (rc) return rc;
+    a.act_noise_z = g->cfg ? g->cfg->action_noise_z : nullptr;
+    a.obs_noise_z = g->cfg ? g->cfg->obs_noise_z : nullptr;
+    a.log_stds = g->log_stds;
+    const dim3 grid(pl.workgroups), block(64 * pl.wavefronts_per_workgroup);
+    const size_t lds = (size_t)pl.lds_bytes;
+    const int H = g->hidden0, epw = pl.envs_per_wavefront;
+    WideShape shape, sshape;
+    wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape);
+    switch (pl.kernel) {
+        case RL_ROLLOUT_DUAL: {
+            wide_shape(Env::OBS, Env::ACT, g->std_hidden0, g->std_hidden1, g->std_hidden2, sshape);
+            const size_t mean_floats = RolloutPolicyWide<Env>::lds_floats(shape, 64 * pl.wavefronts_per_workgroup);
+            static bool a16 = false, a64 = false;
+            if (epw == 16) {
+                if ((rc = allow_big_lds(rollout_dual_kernel<Env, 16>, a16))) return rc;
+                hipLaunchKernelGGL((rollout_dual_kernel<Env, 16>), grid, block, lds, st, a, shape, sshape, g->theta_std, (int)mean_floats);
+            } else {
+                if ((rc = allow_big_lds(rollout_dual_kernel<Env, 64>, a64))) return rc;
+                hipLaunchKernelGGL((rollout_dual_kernel<Env, 64>), grid, block, lds, st, a, shape, sshape, g->theta_std, (int)mean_floats);
+            }
+            break;
+        }
+        case RL_ROLLOUT_GENERIC:
+            if (H == 32 && epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, block, 0, st, a);
+            else if (H == 32) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, block, 0, st, a);
+            else if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, block, 0, st, a);
+            break;
+        case RL_ROLLOUT_WIDE: {
+            static bool a16 = false, a64 = false;
+            if (epw == 16) {
+                if ((rc = allow_big_lds(rollout_wide_kernel<Env, 16>, a16))) return rc;
+                hipLaunchKernelGGL((rollout_wide_kernel<Env, 16>), grid, block, lds, st, a, shape);
+            } else {
+                if ((rc = allow_big_lds(rollout_wide_kernel<Env, 64>, a64))) return rc;
+                hipLaunchKernelGGL((rollout_wide_kernel<Env, 64>), grid, block, lds, st, a, shape);
+            }
+            break;
+        }
+        default:
+            if constexpr (std::is_same<Env, Swimmer>::value) {
+                if (pl.kernel == RL_ROLLOUT_SWIMMER_QUAD) {
+                    if (H == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), grid, block, 0, st, a);
+                    break;
+                }
+                if (pl.kernel == RL_ROLLOUT_SWIMMER_QUAD_COOP) {
+                    static bool ca = false;
+                    if ((rc = allow_big_lds(rollout_swimmer_quad_coop_kernel, ca))) return rc;
+                    hipLaunchKernelGGL(rollout_swimmer_quad_coop_kernel, grid, block, lds, st, a, shape);
+                    break;
+                }
+                if (pl.kernel == RL_ROLLOUT_SWIMMER_QUAD_WIDE) {
+                    static bool wa = false;
+                    if ((rc = allow_big_lds(rollout_swimmer_quad_wide_kernel, wa))) return rc;
+                    hipLaunchKernelGGL(rollout_swimmer_quad_wide_kernel, grid, block, lds, st, a, shape);
+                    break;
+                }
+            }
+            if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
+                if (pl.kernel == RL_ROLLOUT_TWO_LEG_WAVE) {
+                    if (H == 32) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 32>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 64>), grid, block, 0, st, a);
+                    break;
+                }
+                if (pl.kernel == RL_ROLLOUT_TWO_LEG_QUAD) {
+                    if (H == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64>), grid, block, 0, st, a);
+                    break;
+                }
+                if (pl.kernel == RL_ROLLOUT_TWO_LEG_QUAD_WIDE) {
+                    static bool ta = false;
+                    if ((rc = allow_big_lds(rollout_two_leg_quad_wide_kernel<Env>, ta))) return rc;
+                    hipLaunchKernelGGL((rollout_two_leg_quad_wide_kernel<Env>), grid, block, lds, st, a, shape);
+                    break;
+                }
+            }
+            return set_error(RL_ERR_UNSUPPORTED, "rollout plan %d has no launch for this env", pl.kernel);
+    }
+    return check_launch(pl.name);
 }
 
 }  // namespace rl
@@ -2232,6 +2264,12 @@ extern "C" int rl_rollout_gaussian_mlp(const rl_rollout_args* g, void* stream) {
         !g->means || !g->rewards || !g->dones)
         return set_error(RL_ERR_ARG, "rl_rollout_gaussian_mlp: bad argument");
     RL_DISPATCH_ENV(g->kind, launch_rollout<E>(g, (hipStream_t)stream))
+}
+
+extern "C" int rl_rollout_plan_query(const rl_rollout_args* g, rl_rollout_plan* plan) {
+    if (!g || !plan) return set_error(RL_ERR_ARG, "rl_rollout_plan_query: null argument");
+    if (g->n_envs <= 0 || g->horizon <= 0) return set_error(RL_ERR_ARG, "rl_rollout_plan_query: bad argument");
+    RL_DISPATCH_ENV(g->kind, plan_rollout<E>(g, plan))
 }
 
 extern "C" int rl_rollout_lds_bytes(int kind, int hidden0, int hidden1, int hidden2, int std_hidden0, int std_hidden1,

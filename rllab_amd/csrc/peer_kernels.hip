@@ -158,7 +158,7 @@ extern "C" int rl_peer_close(void* dev_ptr) {
 }
 
 extern "C" int rl_peer_allreduce_sum(int n, double* data, int rank, int world, void* const* mailboxes, int max_n,
-                                     uint64_t seq, int* err_dev, void* stream) {
+                                     uint64_t seq, int* err_dev, int64_t spin_limit, void* stream) {
     if (n <= 0 || !data || !mailboxes || !err_dev || world < 1 || world > PEER_MAX_WORLD || rank < 0 || rank >= world ||
         n > max_n || seq == 0)
         return set_error(RL_ERR_ARG, "rl_peer_allreduce_sum: bad argument (n = %d, max_n = %d, rank %d of %d)", n, max_n,
@@ -168,14 +168,10 @@ extern "C" int rl_peer_allreduce_sum(int n, double* data, int rank, int world, v
     for (int p = 0; p < PEER_MAX_WORLD; ++p) a.box[p] = p < world ? (char*)mailboxes[p] : nullptr;
     for (int p = 0; p < world; ++p)
         if (!a.box[p]) return set_error(RL_ERR_ARG, "rl_peer_allreduce_sum: mailbox %d is null", p);
-    // a peer that has not delivered after 10 s of wall clock is an error.  RLLAB_PEER_SPIN_LIMIT (iterations of
-    // s_sleep 8 + one load): tests of the give-up path make it milliseconds.
+    // a peer that has not delivered after 10 s of wall clock is an error.  spin_limit > 0 (iterations of s_sleep 8 + one
+    // load; the binding passes RLLAB_PEER_SPIN_LIMIT): tests of the give-up path make it milliseconds.
     a.tick_limit = 10ll * 100000000ll;
-    a.spin_limit = 1ll << 62;
-    if (const char* sl = getenv("RLLAB_PEER_SPIN_LIMIT")) {
-        const long long v = atoll(sl);
-        if (v > 0) a.spin_limit = v;
-    }
+    a.spin_limit = spin_limit > 0 ? (long long)spin_limit : (1ll << 62);
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(PEER_THREADS), 0, (hipStream_t)stream, a);
     return check_launch("peer_allreduce_kernel");
 }

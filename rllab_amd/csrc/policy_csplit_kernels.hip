@@ -778,16 +778,16 @@ static int launch_class(const CsShape& s, const rl_policy_batch* g, const float*
 // 128 units whose batch is a whole number of 32-sample tiles.  By default only nets with a 128-unit layer (four
 // wavefronts per tile): measured on MI355X (profiles/r04_notes.md) it is 13-16 % faster than wide_pass_kernel there and
 // 20 % SLOWER than policy_pass_kernel on (64, 64) nets, where LDS lets only two tiles be in flight per CU on two
-// wavefronts each.  RLLAB_FVP_SPLIT=0 switches it off (A/B runs; the f32-matrix-instruction kernels then keep cached ==
-// recomputed bit for bit), RLLAB_FVP_SPLIT=2 takes every shape it is built for (the parity tests of the two-wavefront
+// wavefronts each.  rl_launch_opts.fvp_split = 1 switches it off (A/B runs; the f32-matrix-instruction kernels then keep cached ==
+// recomputed bit for bit), = 2 takes every shape it is built for (the parity tests of the two-wavefront
 // class run that way).
 bool csplit_fvp_takes(const rl_policy_batch* g) {
     if (!g->activations || g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0) return false;
-    const char* e = getenv("RLLAB_FVP_SPLIT");
-    if (e && e[0] == '0') return false;
+    const int req = g->opts ? g->opts->fvp_split : 0;          // 1: off, 2: every shape the kernel is built for
+    if (req == 1) return false;
     cs::CsShape s;
     if (!cs::cs_shape(g, s)) return false;
-    if (e && e[0] == '2') return true;
+    if (req == 2) return true;
     return s.HT[0] == 4 || s.HT[1] == 4 || s.HT[2] == 4;
 }
 size_t csplit_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2) {

@@ -843,6 +843,23 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
         for (int p = 0; p < 3; ++p) t.p[p] = *reinterpret_cast<const bf16x8*>(ops + ((o * 3 + p) * WV + lane) * 16);
         return t;
     };
+    // acc[t] += (operand blocks base + t * NKB + kb) x Bk[kb] for both row tiles: ONE stream of 2 NKB block products that
+    // alternates the row tiles (two independent accumulator chains on the matrix pipe) with the NEXT block's three parts
+    // read from LDS before the current block's six products are issued -- a lone wavefront has nobody to hide an LDS round
+    // trip behind (first build: 28 exposed round trips per tile here)
+    auto chains = [&](int base, const auto& Bk, f32x16 (&acc_)[HT]) {
+        constexpr int NKB = sizeof(Bk) / sizeof(Parts);
+        Parts cur = op(base);
+#pragma unroll
+        for (int i = 0; i < NKB * HT; ++i) {
+            const int kb = i / HT, t = i % HT;
+            Parts nxtp = cur;
+            if (i + 1 < NKB * HT) nxtp = op(base + ((i + 1) % HT) * NKB + (i + 1) / HT);
+            __builtin_amdgcn_sched_barrier(0);
+            acc_[t] = mm6(cur, Bk[kb], acc_[t]);
+            cur = nxtp;
+        }
+    };
     bf16x8 Id[2], Idx[KB0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -900,9 +917,6 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
         const int nxt = tile + waves_total < n_tiles ? tile + waves_total : tile;
         fetch(nxt, xb_next, wgt_next);
         const float* tv = tailv + lh * TAILV;
-        auto W2_ = [&](int t, int r, int k) { return tv[(k * HT + t) * 16 + r]; };
-        auto dW2_ = [&](int t, int r, int k) { return tv[((DA + k) * HT + t) * 16 + r]; };
-        auto db1_ = [&](int t, int r) { return tv[2 * DA * HT * 16 + t * 16 + r]; };
         auto stage = [&]() { asm volatile("" ::: "memory"); };
 
         // ---- operands of this tile ---------------------------------------------------------------------------------------
@@ -919,21 +933,26 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
         // ---- tangent forward -----------------------------------------------------------------------------------------------
         f32x16 acc[HT], dh0[HT];
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
+        for (int t = 0; t < HT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        chains(O_DW0, Xs, acc);                                                            // dW0^T x + db0
 #pragma unroll
-            for (int kb = 0; kb < KB0; ++kb) acc[t] = mm6(op(O_DW0 + t * KB0 + kb), Xs[kb], acc[t]);      // dW0^T x + db0
-            times_dtanh(acc[t], h0[t], dh0[t]);
-        }
+        for (int t = 0; t < HT; ++t) times_dtanh(acc[t], h0[t], dh0[t]);
         stage();
+        {
+            // b1's tangent initialises the accumulators: the rows of this lane half in two bulk reads per row tile
+            f32x4 bq[HT][4];
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = db1_(t, r);
+                for (int q = 0; q < 4; ++q) bq[t][q] = *reinterpret_cast<const f32x4*>(tv + 2 * DA * HT * 16 + t * 16 + 4 * q);
 #pragma unroll
-            for (int kbg = 0; kbg < KBH; ++kbg) acc[t] = mm6(op(O_DW1 + t * KBH + kbg), H0s[kbg], acc[t]);  // dW1^T h0
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = bq[t][r >> 2][r & 3];
         }
+        chains(O_DW1, H0s, acc);                                                           // dW1^T h0
         stage();
         {
             Parts D0s[KBH];
@@ -943,10 +962,7 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
                 split_frag(dh0[t], tmp);
                 D0s[2 * t] = tmp[0]; D0s[2 * t + 1] = tmp[1];
             }
-#pragma unroll
-            for (int t = 0; t < HT; ++t)
-#pragma unroll
-                for (int kbg = 0; kbg < KBH; ++kbg) acc[t] = mm6(op(O_W1T + t * KBH + kbg), D0s[kbg], acc[t]);   // W1^T dh0
+            chains(O_W1T, D0s, acc);                                                       // W1^T dh0
         }
         stage();
         const float c = wgt * a.inv_count;
@@ -961,16 +977,33 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
                 set_pair(dz1[t], j, d);
                 set_pair(acc[t], j, pair_of(acc[t], j) * d);                          // dh1
             }
-#pragma unroll
-        for (int k = 0; k < DA; ++k) {
-            f32x2 pd = {0.0f, 0.0f};
+        // the output layer's rows of this lane half come in bulk: per action the 2 x 16 rows of W2 and of its tangent are
+        // sixteen 16-byte reads issued together, waited for once (a scalar read per use exposed ~190 LDS round trips per tile)
+        auto rows_of = [&](int which, int k, f32x4 (&out_)[HT][4]) {       // which: 0 = W2, 1 = dW2
 #pragma unroll
             for (int t = 0; t < HT; ++t)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    pd = __builtin_elementwise_fma(pair_of(h1[t], j), f32x2{dW2_(t, 2 * j, k), dW2_(t, 2 * j + 1, k)}, pd);
-                    pd = __builtin_elementwise_fma(pair_of(acc[t], j), f32x2{W2_(t, 2 * j, k), W2_(t, 2 * j + 1, k)}, pd);
+                for (int q = 0; q < 4; ++q)
+                    out_[t][q] = *reinterpret_cast<const f32x4*>(tv + ((which * DA + k) * HT + t) * 16 + 4 * q);
+        };
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            f32x4 wq[HT][4], dq[HT][4];
+            rows_of(0, k, wq);
+            rows_of(1, k, dq);
+            // four independent partial sums (a dependent packed multiply-add costs a lone wavefront a wait state)
+            f32x2 pa[HT], pb[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) pa[t] = pb[t] = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    const int q = j >> 1, e = 2 * (j & 1);
+                    pa[t] = __builtin_elementwise_fma(pair_of(h1[t], j), f32x2{dq[t][q][e], dq[t][q][e + 1]}, pa[t]);
+                    pb[t] = __builtin_elementwise_fma(pair_of(acc[t], j), f32x2{wq[t][q][e], wq[t][q][e + 1]}, pb[t]);
                 }
+            const f32x2 pd = (pa[0] + pb[0]) + (pa[1] + pb[1]);
             const float dmu = db2[k] + half_sum_swap(pd[0] + pd[1]);
             gmu[k] = c * dmu * fk[k];
         }
@@ -980,19 +1013,35 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
             for (int k = 0; k < DA; ++k) { gb2[k] += gmu[k]; gmub[lj * 8 + k] = gmu[k]; }
         }
         // ---- back-propagation through the output layer, sample-major --------------------------------------------------
+        {
+            f32x2 g[HT][8];
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f32x2 g = {0.0f, 0.0f};
+                for (int j = 0; j < 8; ++j) g[t][j] = f32x2{0.0f, 0.0f};
 #pragma unroll
-                for (int k = 0; k < DA; ++k)
-                    g = __builtin_elementwise_fma(f32x2{W2_(t, 2 * j, k), W2_(t, 2 * j + 1, k)}, f32x2{gmu[k], gmu[k]}, g);
-                const f32x2 gz = g * pair_of(dz1[t], j);
-                set_pair(gz1[t], j, gz);
-                const f32x2 b1n = f32x2{gb1l[t][2 * j], gb1l[t][2 * j + 1]} + gz;
-                gb1l[t][2 * j] = b1n[0]; gb1l[t][2 * j + 1] = b1n[1];
+            for (int k = 0; k < DA; ++k) {
+                f32x4 wq[HT][4];
+                rows_of(0, k, wq);
+                const f32x2 gk = {gmu[k], gmu[k]};
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = j >> 1, e = 2 * (j & 1);
+                        g[t][j] = __builtin_elementwise_fma(f32x2{wq[t][q][e], wq[t][q][e + 1]}, gk, g[t][j]);
+                    }
             }
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2 gz = g[t][j] * pair_of(dz1[t], j);
+                    set_pair(gz1[t], j, gz);
+                    const f32x2 b1n = f32x2{gb1l[t][2 * j], gb1l[t][2 * j + 1]} + gz;
+                    gb1l[t][2 * j] = b1n[0]; gb1l[t][2 * j + 1] = b1n[1];
+                }
+        }
         // ---- gW2 += h1^T gmu with the UNITS on the lanes: lane u walks the tile's samples ---------------------------------
         wave_sync();                                                   // the cotangent rows are in the buffer
         {
@@ -1017,12 +1066,10 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
             G1s[2 * t] = tmp[0]; G1s[2 * t + 1] = tmp[1];
         }
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
+        for (int t = 0; t < HT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-#pragma unroll
-            for (int kbg = 0; kbg < KBH; ++kbg) acc[t] = mm6(op(O_W1 + t * KBH + kbg), G1s[kbg], acc[t]);       // W1 gz1
-        }
+        chains(O_W1, G1s, acc);                                                            // W1 gz1
         stage();
         {
             Parts H0t[HT][2], G1t[HT][2];
@@ -1183,8 +1230,8 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
 }  // namespace split
 
 // The split product takes a cached Fisher-vector product of a two-layer 32-unit tanh net whose batch is a whole number
-// of tiles; everything else stays on policy_pass_kernel.  RLLAB_FVP_SPLIT=0 switches it off (A/B runs, tests of the
-// bit-identical cached / recomputed pair).  Returns RL_SPLIT_NOT_TAKEN when the launch is not its to make.
+// of tiles; everything else stays on policy_pass_kernel.  rl_launch_opts.fvp_split = 1 switches it off (A/B runs, tests of
+// the bit-identical cached / recomputed pair).  Returns RL_SPLIT_NOT_TAKEN when the launch is not its to make.
 // (obs_dim, act_dim) of the HIP-native envs (a (32, 32) net is rllab's default policy for every one of them) + the
 // one-output net on the Swimmer's observations.  Heads wider than two outputs run one wavefront per SIMD: their
 // per-lane sums of the thin products (16 x act_dim registers) do not fit beside 256.
@@ -1195,10 +1242,10 @@ bool split_fvp_takes(const rl_policy_batch* g) {
     if (!g->activations || g->hidden2 != 0 || g->hidden0 != g->hidden1 || (g->hidden0 != 32 && g->hidden0 != 64) ||
         g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0)
         return false;
-    const char* e = getenv("RLLAB_FVP_SPLIT");
-    if (e && e[0] == '0') return false;
+    const int req = g->opts ? g->opts->fvp_split : 0;          // 0: the library's choice, 1: f32 matrix instructions, 2: cooperative
+    if (req == 1) return false;
     if (g->hidden0 == 64) {
-        if (e && e[0] == '2') return false;        // (the tests of the cooperative class run every shape on THAT kernel)
+        if (req == 2) return false;                // (the tests of the cooperative class run every shape on THAT kernel)
 #define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return true;
         SPLIT64_SHAPES(SPLITCASE)
 #undef SPLITCASE
@@ -1211,15 +1258,14 @@ bool split_fvp_takes(const rl_policy_batch* g) {
 }
 int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     if (!split_fvp_takes(g)) return RL_SPLIT_NOT_TAKEN;
-    // two wavefronts per SIMD (operands in LDS) unless RLLAB_FVP_SPLIT_WPS=1 asks for the one-wavefront, register-resident form
+    // two wavefronts per SIMD (operands in LDS) unless rl_launch_opts.fvp_split_wps = 1 asks for the one-wavefront, register-resident form
     if (g->hidden0 == 64) {
 #define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return split::launch64<DO, DA>(g, vec, ws, ws_bytes, out, st);
         SPLIT64_SHAPES(SPLITCASE)
 #undef SPLITCASE
         return RL_SPLIT_NOT_TAKEN;
     }
-    const char* e = getenv("RLLAB_FVP_SPLIT_WPS");
-    const bool one = e && e[0] == '1';
+    const bool one = g->opts && g->opts->fvp_split_wps == 1;
 #define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) { \
         if constexpr (DA > 2) return split::launch<DO, DA, 1>(g, vec, ws, ws_bytes, out, st); \
         else return one ? split::launch<DO, DA, 1>(g, vec, ws, ws_bytes, out, st) : split::launch<DO, DA, 2>(g, vec, ws, ws_bytes, out, st); }

@@ -441,7 +441,7 @@ extern "C" int rl_adv_finish(size_t n_samples, const float* adv_in, const uint8_
 
 extern "C" int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs, const int32_t* tin,
                                 const float* returns, const uint8_t* valid, void* workspace,
-                                size_t workspace_bytes, double* out, void* stream) {
+                                size_t workspace_bytes, double* out, int variant, void* stream) {
     if (n_samples == 0 || obs_dim <= 0 || obs_dim > MAX_DO || !obs || !tin || !returns || !valid || !workspace || !out)
         return set_error(RL_ERR_ARG, "rl_lfb_normal_eq: bad argument (obs_dim <= %d)", MAX_DO);
     const int F = 2 * obs_dim + 4;
@@ -453,9 +453,9 @@ extern "C" int rl_lfb_normal_eq(size_t n_samples, int obs_dim, const float* obs,
         return set_error(RL_ERR_ARG, "rl_lfb_normal_eq: workspace too small");
     const size_t lds = (size_t)NE_WAVES * NE_TILE * (FE + 2) * sizeof(double);
     hipError_t e = hipSuccess;
-    // RLLAB_LFB_VALU=1 selects the register-blocked vector kernel (A/B timing; same sums up to association); read per
-    // launch so that the parity test can run both forms in one process
-    const bool valu = getenv("RLLAB_LFB_VALU") != nullptr;
+    // variant = 1 (rl_launch_opts.lfb_valu) selects the register-blocked vector kernel (A/B timing; same sums up to
+    // association): an argument, so that the parity test can run both forms in one process
+    const bool valu = variant == 1;
     if (FE == 32 && !valu) {
         static bool set = false;
         if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(lfb_normal_eq_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }

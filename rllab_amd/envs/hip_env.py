@@ -188,13 +188,21 @@ class HipVecEnv(object):
         layout (or its two networks) and the weight fragments of a wide / deep / dual-network shape fit the LDS of a CU
         next to the env's observation tile (rl_rollout_lds_bytes) -- e.g. a (128,128) mean net + a (128,128) log-std
         net on a 20-observation env needs 172 KB and is sampled through the per-transition loop instead."""
+        return self.rollout_plan(policy) is not None
+
+    def rollout_plan(self, policy, horizon=None):
+        """``_lib.RolloutPlan`` -- kernel, envs per wavefront, wavefronts, workgroup shape, LDS -- of ``rollout(policy, ..)``
+        on this executor under the current launch options, from the launcher itself (rl_rollout_plan_query), or None
+        when there is no fused kernel for the policy here."""
         layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
+        dual = policy.rollout_networks() if (layout is None and hasattr(policy, "rollout_networks")) else None
+        if layout is None and dual is None:
+            return None
+        T = int(horizon if horizon is not None else max(1, self.max_path_length))
+        flags = int(self.cfg.flags)
         if layout is not None:
-            return _lib.rollout_lds_fits(self.kind, layout.hidden3)
-        dual = policy.rollout_networks() if hasattr(policy, "rollout_networks") else None
-        if dual is not None:
-            return _lib.rollout_lds_fits(self.kind, dual[1], dual[3])
-        return False
+            return _lib.rollout_plan(self.kind, self.n, T, layout.hidden3, cfg_flags=flags)
+        return _lib.rollout_plan(self.kind, self.n, T, dual[1], dual[3], cfg_flags=flags)
 
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
                 obs_noise_z=None):
@@ -250,7 +258,7 @@ class HipVecEnv(object):
             cfg=ctypes.pointer(self.cfg),
             theta_std=None if theta_std is None else theta_std.data_ptr(),
             log_stds=None if log_stds is None else log_stds.data_ptr(),
-            std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2])
+            std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2], opts=_lib.launch_opts())
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1

@@ -89,7 +89,9 @@ class FusedGaussianMLPOps(object):
             hidden1=self.dims[3], hidden2=self.dims[4], inv_count=inv,
             log_min_std=math.log(pol.min_std) if pol.min_std is not None else -1e30,
             theta=theta.data_ptr(), obs=obs.data_ptr(), actions=act.data_ptr(), advantages=adv.data_ptr(),
-            old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(), weights=w.data_ptr())
+            old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(), weights=w.data_ptr(),
+            opts=_lib.launch_opts())      # (one process-wide struct, refreshed from the RLLAB_* switches before the calls
+                                          # whose kernel choice it steers: _fvp_into, fvp_variant)
         if len(self._bound) >= 2:   # full batch + (optionally) its FVP subsample
             self._bound.clear()
         self._bound[key] = (b, keep + list(inputs), inv)
@@ -262,6 +264,7 @@ class FusedGaussianMLPOps(object):
     def _fvp_into(self, b, ws, vec32, out, inputs=None):
         cached = inputs is not None and self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
         b.activations = self._acts.data_ptr() if cached else None
+        b.opts = _lib.launch_opts()
         try:
             _lib.check(_lib.lib.rl_policy_fvp(ctypes.byref(b), _lib.ptr(vec32), _lib.ptr(ws), ws.numel(),
                                               _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
@@ -276,6 +279,7 @@ class FusedGaussianMLPOps(object):
         b, _, _ = self._batch(inputs)
         cached = self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
         b.activations = self._acts.data_ptr() if cached else None
+        b.opts = _lib.launch_opts()
         try:
             return int(_lib.lib.rl_policy_fvp_variant(ctypes.byref(b)))
         finally:

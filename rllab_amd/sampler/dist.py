@@ -232,7 +232,8 @@ class PeerReducer(object):
         self.count += 1
         lib = self._lib
         lib.check(lib.lib.rl_peer_allreduce_sum(t.numel(), lib.ptr(t), self.rank, self.world, self._table, self.max_n,
-                                                self.seq, lib.ptr(self.err), lib.stream_ptr()), "rl_peer_allreduce_sum")
+                                                self.seq, lib.ptr(self.err), lib.peer_spin_limit(), lib.stream_ptr()),
+                  "rl_peer_allreduce_sum")
         return t
 
     def _raise(self, e, upto):

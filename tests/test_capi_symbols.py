@@ -56,7 +56,7 @@ def test_env_query_and_errors():
     assert _lib.lib.rl_policy_activation_bytes(1000, 100, 50, 25) == 0                        # the caller pads first
     # peer all-reduce: argument errors without touching a device
     assert _lib.lib.rl_peer_mailbox_bytes(8, 1572) == 128 + 2 * 8 * 1572 * 8 and _lib.lib.rl_peer_mailbox_bytes(9, 4) == 0
-    assert _lib.lib.rl_peer_allreduce_sum(0, None, 0, 1, None, 4, 1, None, None) == -1
+    assert _lib.lib.rl_peer_allreduce_sum(0, None, 0, 1, None, 4, 1, None, 0, None) == -1
     assert _lib.lib.rl_peer_export(None, None) == -1 and _lib.lib.rl_peer_open(None, None) == -1
 
 
@@ -120,6 +120,7 @@ def test_integration_md_bindings_match_the_library():
              "f64": ctypes.c_double, "sz": ctypes.c_size_t, "u32": ctypes.c_uint32,
              "cfgp": ctypes.POINTER(_lib.EnvCfg), "pb": ctypes.POINTER(_lib.PolicyBatch),
              "ctypes.POINTER(RolloutArgs)": ctypes.POINTER(_lib.RolloutArgs),
+             "ctypes.POINTER(RolloutPlan)": ctypes.POINTER(_lib.RolloutPlan), "ctypes.c_int64": ctypes.c_int64,
              "ip": ctypes.POINTER(ctypes.c_int), "fp": ctypes.POINTER(ctypes.c_float),
              "vpp": ctypes.POINTER(ctypes.c_void_p), "szp": ctypes.POINTER(ctypes.c_size_t)}
     found = re.findall(r"^\s*lib\.(rl_\w+)\.argtypes\s*= \[([^\]]*)\]", text, flags=re.M)
@@ -149,9 +150,11 @@ def test_integration_md_structs_are_the_library_structs():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     types_ = {"f32": ctypes.c_float, "i32f": ctypes.c_int32, "ctypes.c_int32": ctypes.c_int32, "vp": ctypes.c_void_p,
               "u64f": ctypes.c_uint64, "ctypes.c_uint64": ctypes.c_uint64, "f64": ctypes.c_double,
-              "ctypes.POINTER(EnvCfg)": ctypes.POINTER(_lib.EnvCfg), "cfgp": ctypes.POINTER(_lib.EnvCfg)}
+              "ctypes.POINTER(EnvCfg)": ctypes.POINTER(_lib.EnvCfg), "cfgp": ctypes.POINTER(_lib.EnvCfg),
+              "i32f * 7": ctypes.c_int32 * 7, "ctypes.c_char * 96": ctypes.c_char * 96}
     printed = _md_struct_fields(text)
-    want = {"EnvCfg": _lib.EnvCfg, "RolloutArgs": _lib.RolloutArgs, "PolicyBatch": _lib.PolicyBatch}
+    want = {"EnvCfg": _lib.EnvCfg, "RolloutArgs": _lib.RolloutArgs, "PolicyBatch": _lib.PolicyBatch,
+            "LaunchOpts": _lib.LaunchOpts, "RolloutPlan": _lib.RolloutPlan}
     assert set(printed) == set(want), sorted(printed)
     for name, cls in want.items():
         got = [(f, types_[t.strip()]) for f, t in printed[name]]
@@ -208,7 +211,8 @@ def test_struct_offsets_against_the_compiled_header(tmp_path):
     in the right order (test_structs_match_header_layout) do not catch a wrong width."""
     import subprocess
     from rllab_amd import _lib
-    structs = (("rl_env_cfg", _lib.EnvCfg), ("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch))
+    structs = (("rl_env_cfg", _lib.EnvCfg), ("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch),
+               ("rl_launch_opts", _lib.LaunchOpts), ("rl_rollout_plan", _lib.RolloutPlan))
     lines = ['#include "rllab_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in structs:
         lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

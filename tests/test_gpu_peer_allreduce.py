@@ -50,7 +50,8 @@ def test_ranks_as_streams_sum_in_rank_order(world, n, monkeypatch):
             for r in range(world):
                 with torch.cuda.stream(streams[r]):
                     _lib.check(_lib.lib.rl_peer_allreduce_sum(n, _lib.ptr(xs[r]), r, world, table, max_n, seq,
-                                                              _lib.ptr(err), _lib.stream_ptr()), "rl_peer_allreduce_sum")
+                                                              _lib.ptr(err), _lib.peer_spin_limit(), _lib.stream_ptr()),
+                               "rl_peer_allreduce_sum")
             torch.cuda.synchronize()
             want = np.zeros(n)
             for r in range(world):                           # the kernel's order: rank 0 first
@@ -71,7 +72,7 @@ def test_a_peer_that_never_arrives_sets_the_error_word(monkeypatch):
     x = torch.arange(n, dtype=torch.float64, device="cuda")
     try:
         _lib.check(_lib.lib.rl_peer_allreduce_sum(n, _lib.ptr(x), 0, world, table, max_n, 1, _lib.ptr(err),
-                                                  _lib.stream_ptr()), "rl_peer_allreduce_sum")
+                                                  _lib.peer_spin_limit(), _lib.stream_ptr()), "rl_peer_allreduce_sum")
         torch.cuda.synchronize()                             # the launch COMPLETES: nothing hangs
         assert int(err.item()) == 1 + 1                      # 1 + the rank whose flag never came
         # and its output is poisoned, not a sum over stale rows: CG / the line search reject a NaN step
@@ -82,9 +83,9 @@ def test_a_peer_that_never_arrives_sets_the_error_word(monkeypatch):
         s1 = torch.cuda.Stream()
         with torch.cuda.stream(s1):
             _lib.check(_lib.lib.rl_peer_allreduce_sum(n, _lib.ptr(y), 1, world, table, max_n, 2, _lib.ptr(err),
-                                                      _lib.stream_ptr()), "rl_peer_allreduce_sum")
+                                                      _lib.peer_spin_limit(), _lib.stream_ptr()), "rl_peer_allreduce_sum")
         _lib.check(_lib.lib.rl_peer_allreduce_sum(n, _lib.ptr(x), 0, world, table, max_n, 2, _lib.ptr(err),
-                                                  _lib.stream_ptr()), "rl_peer_allreduce_sum")
+                                                  _lib.peer_spin_limit(), _lib.stream_ptr()), "rl_peer_allreduce_sum")
         torch.cuda.synchronize()
         assert int(err.item()) != 0
     finally:

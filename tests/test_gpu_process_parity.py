@@ -2,6 +2,8 @@
 fixtures produced by the REAL reference ``BaseSampler.process_samples`` /
 ``LinearFeatureBaseline`` (tests/golden/, oracle/make_golden.py), and size-independent
 properties at BASELINE.json's full sizes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -302,7 +304,8 @@ def test_path_scan_and_normal_equations_vs_numpy(T, n, do, whole_paths, valu_for
     ws = _workspace(dev, do)
     out = torch.empty((F + 1) * F, dtype=torch.float64, device=dev)
     _lib.check(_lib.lib.rl_lfb_normal_eq(T * n, do, _lib.ptr(t_obs), _lib.ptr(tin), _lib.ptr(t_ret), _lib.ptr(valid),
-                                         _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()))
+                                         _lib.ptr(ws), ws.numel(), _lib.ptr(out),
+                                         1 if os.environ.get("RLLAB_LFB_VALU") else 0, _lib.stream_ptr()))
     w = want_valid.reshape(-1).astype(np.float64)
     gram = (phi * w[:, None]).T.dot(phi)
     rhs = (phi * w[:, None]).T.dot(ret.reshape(-1).astype(np.float64))

@@ -59,7 +59,7 @@ def _scan_and_stats(traj, coeffs, gamma, lam):
     F = 2 * traj.obs_dim + 4
     neq = torch.empty((F + 1) * F, dtype=torch.float64, device=dev)
     _lib.check(_lib.lib.rl_lfb_normal_eq(T * N, traj.obs_dim, _lib.ptr(traj.obs), _lib.ptr(tin), _lib.ptr(ret),
-                                         _lib.ptr(valid_u8), _lib.ptr(ws), ws.numel(), _lib.ptr(neq),
+                                         _lib.ptr(valid_u8), _lib.ptr(ws), ws.numel(), _lib.ptr(neq), 0,
                                          _lib.stream_ptr()), "rl_lfb_normal_eq")
     return dict(valid=valid, valid_u8=valid_u8, adv=adv, ret=ret, st=st.cpu().numpy(), neq=neq.cpu().numpy())
 
