@@ -205,10 +205,7 @@ def main():
     algo.init_opt()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    phase_ms = dict(sample=0.0, process=0.0, update=0.0)
-    rollout_ms = []
     last = {}
-    per_iter = []
 
     timed_events = []
     host_stamps = []   # host clock at the phase boundaries (enqueue side), for RLLAB_BENCH_HOSTTIMES=1
@@ -264,50 +261,100 @@ def main():
             timed_events.append((e, getattr(algo.optimizer, "last_backtrack_iters", None)))
             host_stamps.append(h)
 
-    for w in range(args.warmup):
-        iteration(w, False, w + 1 < args.warmup)
-    # a generation-2 pass of Python's cyclic GC walks every object torch has created (~35 ms here)
-    # and would land inside one timed iteration: collect now and freeze the survivors
-    import gc
-    gc.collect()
-    gc.freeze()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    D.reset_accounting(timing=False)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        iteration(args.warmup + k, True, k + 1 < args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    acct = D.accounting()
-    collectives_per_iter = acct["count"] / float(args.steps)
-    peer_reductions_per_iter = acct.get("peer", 0) / float(args.steps)   # in-stream rl_peer_allreduce_sum launches
-    collective_bytes_per_iter = acct["bytes"] / float(args.steps)
-    collective_ms_per_iter = None
-    if D.is_distributed():
-        # a few extra iterations with every collective bracketed by a device synchronise (host clock):
-        # what the exchange family costs per iteration, outside the timed region
-        D.reset_accounting(timing=True)
-        extra = 3
-        for k in range(extra):
-            iteration(args.warmup + args.steps + k, False, False)
+    itr_base = [0]
+
+    def timed_run(warmup, steps):
+        """``warmup`` untimed + ``steps`` timed iterations, bracketed by barrier + synchronize on both sides; returns the
+        run's record (max-over-ranks wall time, phase times of THIS rank and of every rank, collectives)."""
+        del timed_events[:], host_stamps[:]
+        pending.clear()
+        base = itr_base[0]
+        for w in range(warmup):
+            iteration(base + w, False, w + 1 < warmup)
+        # a generation-2 pass of Python's cyclic GC walks every object torch has created (~35 ms here)
+        # and would land inside one timed iteration: collect now and freeze the survivors
+        import gc
+        gc.collect()
+        gc.freeze()
         torch.cuda.synchronize()
-        collective_ms_per_iter = D.accounting()["seconds"] * 1e3 / extra
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
         D.reset_accounting(timing=False)
-    for e, backtracks in timed_events:
-        rollout_ms.append(e[0].elapsed_time(e[1]))
-        phase_ms["sample"] += e[0].elapsed_time(e[1])
-        phase_ms["process"] += e[1].elapsed_time(e[2])
-        phase_ms["update"] += e[2].elapsed_time(e[3])
-        per_iter.append((round(e[2].elapsed_time(e[3]), 3), backtracks))
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    D.all_reduce_max_(el)
-    elapsed = float(el)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            iteration(base + warmup + k, True, k + 1 < steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed_ = time.perf_counter() - t0
+        acct = D.accounting()
+        rec = dict(collectives_per_iter=acct["count"] / float(steps),
+                   peer_reductions_per_iter=acct.get("peer", 0) / float(steps),   # in-stream rl_peer_allreduce_sum launches
+                   collective_bytes_per_iter=acct["bytes"] / float(steps), collective_ms_per_iter=None,
+                   update_sum_path=D.peer_status()[0] if dist.is_initialized() else None)
+        extra = 0
+        if D.is_distributed():
+            # a few extra iterations with every collective bracketed by a device synchronise (host clock):
+            # what the exchange family costs per iteration, outside the timed region
+            D.reset_accounting(timing=True)
+            extra = 3
+            for k in range(extra):
+                iteration(base + warmup + steps + k, False, False)
+            torch.cuda.synchronize()
+            rec["collective_ms_per_iter"] = D.accounting()["seconds"] * 1e3 / extra
+            D.reset_accounting(timing=False)
+        itr_base[0] = base + warmup + steps + extra
+        ph = dict(sample=0.0, process=0.0, update=0.0)
+        rec["rollout_ms"], rec["per_iter"] = [], []
+        for e, backtracks in timed_events:
+            rec["rollout_ms"].append(e[0].elapsed_time(e[1]))
+            ph["sample"] += e[0].elapsed_time(e[1])
+            ph["process"] += e[1].elapsed_time(e[2])
+            ph["update"] += e[2].elapsed_time(e[3])
+            rec["per_iter"].append((round(e[2].elapsed_time(e[3]), 3), backtracks))
+        rec["phase_ms"] = {k: v / steps for k, v in ph.items()}
+        # every rank's wall time and phase times in ONE gather: the line carries the per-rank table and the spread
+        # (max - min) of each column -- a straggling rank or a slow link shows here, not only in the max
+        mine = torch.tensor([elapsed_ / steps * 1e3, rec["phase_ms"]["sample"], rec["phase_ms"]["process"],
+                             rec["phase_ms"]["update"]], dtype=torch.float64, device="cuda")
+        rows = D.all_gather_rows(mine).cpu().numpy()
+        rec["elapsed"] = float(rows[:, 0].max()) * steps / 1e3          # the MAX over ranks, as the contract says
+        cols = ("iteration", "sample", "process", "update")
+        rec["per_rank_ms"] = [dict(rank=r, **{c: round(float(rows[r, j]), 4) for j, c in enumerate(cols)})
+                              for r in range(rows.shape[0])]
+        rec["rank_skew_ms"] = {c: round(float(rows[:, j].max() - rows[:, j].min()), 4) for j, c in enumerate(cols)}
+        return rec
+
+    run = timed_run(args.warmup, args.steps)
+    # N > 1: the SAME invocation then times the other reduction path of the update's sums (gradient, Fisher-vector
+    # products) -- the in-stream peer all-reduce over hipIpc mailboxes (csrc/peer_kernels.hip) against the backend's
+    # all-reduce (RCCL) -- so that one lease of an 8-GPU node answers which is faster.  The headline fields are the
+    # backend's unless RLLAB_PEER_ALLREDUCE=1 asked for the peer path from the start; the other path's record rides
+    # along as `other_sum_path`.  (Skipped when the pre-flight refused the peer path, or with RLLAB_BENCH_ONE_PATH=1.)
+    other = None
+    if world > 1 and not os.environ.get("RLLAB_BENCH_ONE_PATH") and run["update_sum_path"] == "backend" \
+            and not os.environ.get("RLLAB_PEER_ALLREDUCE"):
+        os.environ["RLLAB_PEER_ALLREDUCE"] = "1"
+        try:
+            D.peer_reducer()                       # collective constructor: every rank is here
+            if D.peer_status()[0] == "peer":
+                o = timed_run(1, args.steps)
+                other = dict(update_sum_path="peer", ms_per_step=o["elapsed"] / args.steps * 1e3,
+                             value=world * n_envs * T * args.steps / o["elapsed"], phase_ms=o["phase_ms"],
+                             collectives_per_iter=o["collectives_per_iter"],
+                             peer_reductions_per_iter=o["peer_reductions_per_iter"],
+                             collective_ms_per_iter=o["collective_ms_per_iter"], per_rank_ms=o["per_rank_ms"],
+                             rank_skew_ms=o["rank_skew_ms"])
+            else:
+                other = dict(update_sum_path="peer", refused=D.peer_status()[1])
+        finally:
+            D.peer_shutdown()
+            os.environ.pop("RLLAB_PEER_ALLREDUCE", None)
+    elapsed, phase_ms, rollout_ms, per_iter = run["elapsed"], run["phase_ms"], run["rollout_ms"], run["per_iter"]
+    collectives_per_iter, peer_reductions_per_iter = run["collectives_per_iter"], run["peer_reductions_per_iter"]
+    collective_bytes_per_iter, collective_ms_per_iter = run["collective_bytes_per_iter"], run["collective_ms_per_iter"]
 
     steps_per_iter = world * n_envs * T
     value = steps_per_iter * args.steps / elapsed
@@ -424,10 +471,11 @@ def main():
         "collectives_per_iter": collectives_per_iter, "collective_bytes_per_iter": collective_bytes_per_iter,
         "peer_reductions_per_iter": peer_reductions_per_iter,
         "collective_ms_per_iter": collective_ms_per_iter,
-        "update_sum_path": D.peer_status()[0] if dist.is_initialized() else None,
+        "update_sum_path": run["update_sum_path"],
         "preflight": preflight_rec,
         "trpo_iter_ms": elapsed / args.steps * 1e3,
-        "phase_ms": {k: v / args.steps for k, v in phase_ms.items()},
+        "phase_ms": phase_ms,
+        "per_rank_ms": run["per_rank_ms"], "rank_skew_ms": run["rank_skew_ms"], "other_sum_path": other,
         "update_ms_and_backtracks_per_iteration": per_iter,
         "sampler_env_steps_per_s": world * n_envs * T / avg_rollout_s,
         "roofline": {"kernel": rollout_name, "bound": "hbm",

@@ -112,6 +112,22 @@ class LinearFeatureBaseline(Baseline):
         return (w @ self._features_dense(traj)).reshape(traj.T, traj.N)
 
     def fit_dense(self, traj, all_reduce=None):
+        """Normal equations of the batch (one launch), their sum over the ranks, the solve started asynchronously."""
+        packed = self.normal_eq_dense(traj)
+        if all_reduce is not None:
+            all_reduce(packed)
+        self.fit_from_packed(packed, 2 * traj.obs_dim + 4)
+
+    def fit_from_packed(self, packed, F):
+        """``packed`` = [Phi^T W Phi | Phi^T W y] summed over all ranks (float64 device vector): start reading it; the
+        solve happens where the coefficients are first needed."""
+        from rllab_amd.misc.device_io import read_async
+        self._coeffs_value = None
+        self._pending = (read_async(packed), F)
+
+    def normal_eq_dense(self, traj):
+        """This rank's [Phi^T W Phi | Phi^T W y] as a float64 device vector of (F + 1) F entries (linear_feature_baseline.py:
+        25-36 builds the same sums on the host)."""
         F = 2 * traj.obs_dim + 4
         if traj.obs_dim <= 21 and traj.device.type == "cuda":
             # Phi^T W Phi and Phi^T W y by rl_lfb_normal_eq: one pass, features rebuilt in LDS
@@ -137,8 +153,4 @@ class LinearFeatureBaseline(Baseline):
             y = traj.returns.reshape(-1).to(torch.float64)
             phi_w = phi * w if w is not None else phi
             packed = torch.cat([(phi_w @ phi.t()).reshape(-1), phi_w @ y])
-        if all_reduce is not None:
-            all_reduce(packed)
-        from rllab_amd.misc.device_io import read_async
-        self._coeffs_value = None
-        self._pending = (read_async(packed), F)
+        return packed

@@ -200,9 +200,16 @@ class HipVecEnv(object):
             return None
         T = int(horizon if horizon is not None else max(1, self.max_path_length))
         flags = int(self.cfg.flags)
-        if layout is not None:
-            return _lib.rollout_plan(self.kind, self.n, T, layout.hidden3, cfg_flags=flags)
-        return _lib.rollout_plan(self.kind, self.n, T, dual[1], dual[3], cfg_flags=flags)
+        hs, hs_std = (layout.hidden3, (0, 0, 0)) if layout is not None else (tuple(dual[1]), tuple(dual[3]))
+        # asked once per (sizes, launch options): the sampler asks before every rollout
+        _lib.launch_opts()
+        key = (hs, hs_std, T, flags, bytes(_lib._OPTS))
+        cache = self.__dict__.setdefault("_plan_cache", {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = _lib.rollout_plan(self.kind, self.n, T, hs, hs_std, cfg_flags=flags)
+        return cache[key]
 
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
                 obs_noise_z=None):

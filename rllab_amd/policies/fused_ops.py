@@ -104,10 +104,12 @@ class FusedGaussianMLPOps(object):
         self._acts = None
         self._acts_tag = None
 
-    def _loss_record(self, tag, out, inv):
+    def _loss_record(self, tag, out, inv, rows=None):
         """Cache entry of one loss / KL evaluation whose four per-rank sums are in ``out`` (device); starts the
-        host read.  Sharded: ONE all-gather of the four numbers, folded on the host (sum of three, max of one)."""
-        rows = D.all_gather_rows(out)            # [world, 4], kept: the device-side line search compares against them
+        host read.  Sharded: ONE all-gather of the four numbers (``rows``: already gathered, with the gradient), folded
+        on the host (sum of three, max of one)."""
+        if rows is None:
+            rows = D.all_gather_rows(out)        # [world, 4], kept: the device-side line search compares against them
         c = dict(tag=tag, out=out, rows=rows, inv=inv, dev=None, read=read_async(rows), host=None)
         self._loss_cache = c
         return c
@@ -196,10 +198,19 @@ class FusedGaussianMLPOps(object):
         have_loss = self._loss_cache is not None and self._loss_cache["tag"] == tag
         try:
             if with_loss and not have_loss:
-                out4 = torch.empty(4, dtype=torch.float64, device=keep[0].device)
+                # gradient and loss sums in one buffer: sharded (host-issued collectives), both cross the ranks in ONE
+                # all-gather, the gradient rows are then added in rank order on every rank (identical sums everywhere)
+                both = torch.empty(self.n_kernel + 4, dtype=torch.float64, device=keep[0].device)
+                out, out4 = both[:self.n_kernel], both[self.n_kernel:]
                 _lib.check(_lib.lib.rl_policy_grad_loss(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(),
                                                         _lib.ptr(out), _lib.ptr(out4), _lib.stream_ptr()),
                            "rl_policy_grad_loss")
+                if D.is_distributed() and D.peer_reducer() is None:
+                    rows = D.all_gather_rows(both)
+                    self._loss_record(tag, out4, inv, rows=rows[:, self.n_kernel:].contiguous())
+                    if b.activations:
+                        self._acts_tag = tag
+                    return self._mask_frozen(self.layout.unpack(rows[:, :self.n_kernel].sum(dim=0)))
                 self._loss_record(tag, out4, inv)
             else:
                 _lib.check(_lib.lib.rl_policy_grad(ctypes.byref(b), int(vpg), _lib.ptr(ws), ws.numel(),

@@ -183,14 +183,24 @@ def process_dense(algo, itr, traj, log=True):
                                         _lib.stream_ptr()), "rl_sample_stats")
     # the iteration's one blocking host read: batch statistics and, riding along, the recorded log_std row
     # (Entropy, AveragePolicyStd)
-    stats_read = read_async(D.all_gather_rows(st))      # [world, 20]: one collective, folded on the host
+    dense_fit = hasattr(baseline, "fit_dense")
+    if dense_fit and log:
+        logger.log("fitting baseline...")
+    if dense_fit and D.is_distributed() and hasattr(baseline, "normal_eq_dense"):
+        # sharded: the statistics row and the baseline's normal equations cross the ranks in ONE all-gather (every rank
+        # then adds the rows in rank order: identical sums everywhere) instead of a gather and an all-reduce
+        packed = baseline.normal_eq_dense(traj)
+        rows = D.all_gather_rows(torch.cat([st, packed]))
+        stats_read = read_async(rows[:, :st.numel()].contiguous())
+        baseline.fit_from_packed(rows[:, st.numel():].sum(dim=0), 2 * traj.obs_dim + 4)
+        dense_fit_done = True
+    else:
+        stats_read = read_async(D.all_gather_rows(st))      # [world, 20]: one collective, folded on the host
+        dense_fit_done = False
     ls_read = read_async(traj.log_std) if (traj.log_std is not None and traj.log_std_planes is None) else None
     # LinearFeatureBaseline's normal equations need nothing the host is about to compute (returns, path index,
     # validity are on the device already): queue them behind the statistics so the device works through the wait
-    dense_fit = hasattr(baseline, "fit_dense")
-    if dense_fit:
-        if log:
-            logger.log("fitting baseline...")
+    if dense_fit and not dense_fit_done:
         baseline.fit_dense(traj, all_reduce=D.all_reduce_sum_ if D.is_distributed() else None)
     s = fold_stats(stats_read.get())
     traj.log_std_host = ls_read.get().astype(np.float64) if ls_read is not None else None

@@ -34,17 +34,22 @@ def test_bench_iteration_over_rccl_single_rank():
     assert plain["ranks"] == 1 and plain["backend"] is None and plain["collectives_per_iter"] == 0
     forced = _bench({"RLLAB_DIST_FORCE": "1"})
     assert forced["ranks"] == 1 and forced["backend"].startswith("nccl")
-    # per TRPO iteration: statistics all-gather, normal equations, gradient (+ its loss sums), 10 FVPs,
-    # 1-2 line-search evaluations
-    assert 12 <= forced["collectives_per_iter"] <= 40, forced["collectives_per_iter"]
+    # per TRPO iteration: ONE all-gather of [statistics | normal equations], ONE of
+    # [gradient | its loss sums], 10 Fisher-vector products, the two line-search candidates decided on the device
+    assert 13 <= forced["collectives_per_iter"] <= 14.5, forced["collectives_per_iter"]
+    # one rank: every per-rank column is this rank's, the spread is zero, no second reduction path to compare
+    assert len(forced["per_rank_ms"]) == 1 and set(forced["per_rank_ms"][0]) == {"rank", "iteration", "sample", "process", "update"}
+    assert all(v == 0 for v in forced["rank_skew_ms"].values()) and forced["other_sum_path"] is None
+    assert abs(forced["per_rank_ms"][0]["iteration"] - forced["ms_per_step"]) < 1e-3
     assert forced["collective_bytes_per_iter"] < 1 << 20
     assert forced["collective_ms_per_iter"] is not None and 0 < forced["collective_ms_per_iter"] < 50
     assert forced["value"] > 0 and forced["config"]["n_envs_per_gpu"] == 512
     # the same with the in-stream peer all-reduce: the eleven sums on CG's critical path leave the host
     peer = _bench({"RLLAB_DIST_FORCE": "1", "RLLAB_PEER_ALLREDUCE": "1"})
     assert peer["peer_reductions_per_iter"] == 11 and forced["peer_reductions_per_iter"] == 0
-    assert abs(peer["collectives_per_iter"] - (forced["collectives_per_iter"] - 11)) < 1e-9
-    assert peer["collectives_per_iter"] <= 6
+    # (the gradient leaves its shared all-gather for the peer path; its loss sums keep one)
+    assert abs(peer["collectives_per_iter"] - (forced["collectives_per_iter"] - 10)) < 1e-9
+    assert peer["collectives_per_iter"] <= 5
 
 
 def test_bench_self_launches_its_ranks():
@@ -64,8 +69,16 @@ def test_bench_self_launches_its_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
     assert d["config"]["samples_per_iteration"] == 2 * 256 * 500 and d["config"]["parallelism"] == "env-sharded dp2"
-    assert 12 <= d["collectives_per_iter"] <= 40 and d["collective_ms_per_iter"] > 0
+    assert 13 <= d["collectives_per_iter"] <= 14.5 and d["collective_ms_per_iter"] > 0
     assert d["value"] > 0 and "cpu_baseline" not in d
+    # the line carries every rank's phase times and their spread, and -- measured by the same invocation -- the other
+    # reduction path of the update's sums (the in-stream peer all-reduce), ready for the first 8-GPU lease
+    assert [r["rank"] for r in d["per_rank_ms"]] == [0, 1] and all(r["iteration"] > 0 for r in d["per_rank_ms"])
+    assert set(d["rank_skew_ms"]) == {"iteration", "sample", "process", "update"} and d["rank_skew_ms"]["iteration"] >= 0
+    assert abs(max(r["iteration"] for r in d["per_rank_ms"]) - d["ms_per_step"]) < 1e-3      # `value` is the max over ranks
+    o = d["other_sum_path"]
+    assert d["update_sum_path"] == "backend" and o["update_sum_path"] == "peer"
+    assert o["peer_reductions_per_iter"] == 11 and o["collectives_per_iter"] <= 5 and o["ms_per_step"] > 0
 
 
 @pytest.mark.timeout(1500)
@@ -86,8 +99,9 @@ def test_bench_self_launches_eight_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["backend"] == "gloo" and d["scaling"] == "weak"
     assert d["config"]["samples_per_iteration"] == 8 * 64 * 500 and d["config"]["parallelism"] == "env-sharded dp8"
-    assert 12 <= d["collectives_per_iter"] <= 40 and d["collective_ms_per_iter"] > 0
+    assert 13 <= d["collectives_per_iter"] <= 14.5 and d["collective_ms_per_iter"] > 0
     assert d["value"] > 0 and "cpu_baseline" not in d
+    assert len(d["per_rank_ms"]) == 8 and d["other_sum_path"] is not None
 
 
 def test_preflight_two_ranks_on_one_device():
