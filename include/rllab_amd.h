@@ -51,7 +51,7 @@ const char* rl_last_error(void);
  * shape of the two kernel families as a function on planes), RL_CFG_LIMIT_MUJOCO, rl_policy_fvp_variant's value 2.
  * 12: rl_policy_batch.gate + rl_line_search_decide (the line search decided on the device); rl_launch_opts (rl_rollout_args.opts,
  * rl_policy_batch.opts, a trailing `variant` / `spin_limit` argument of rl_lfb_normal_eq / rl_peer_allreduce_sum) in place
- * of the library's getenv reads; rl_rollout_plan_query. */
+ * of the library's getenv reads; rl_rollout_plan_query; per-layer hidden activations (layer_activations, RL_ACT_IDENTITY). */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -227,7 +227,8 @@ typedef struct rl_rollout_args {
                                  act_dim unused floats); theta then holds the mean network the same way */
     float* log_stds;          /* with theta_std: float[act_dim][T][n] agent_info "log_std" (floored at log_min_std) */
     int32_t std_hidden0, std_hidden1, std_hidden2;   /* hidden sizes of the log-std network (as hidden0..2) */
-    int32_t reserved;
+    int32_t layer_activations;/* hidden activations of the (mean) network per layer, as rl_policy_batch.layer_activations:
+                                 0 = tanh layers; rectify / identity layers on the equal-width (32,32) / (64,64) kernels */
     const rl_launch_opts* opts;   /* host; NULL = every launch rule the library's own */
 } rl_rollout_args;
 
@@ -376,6 +377,14 @@ typedef struct rl_policy_batch {
                                 * nonlinearity, gaussian_mlp_regressor.py:31; loss and vpg gradient only, act_dim 1,
                                 * hidden 32x32) */
     const rl_launch_opts* opts;/* host; NULL = the library's own kernel choice (rl_policy_fvp_variant reports it) */
+    int32_t layer_activations; /* 0: every hidden layer uses `activation`.  Else two bits per hidden layer l (bits 2l, 2l+1)
+                                * holding rl_activation + 1 (0 in a field = `activation`): a GaussianMLPPolicy with a rectify
+                                * hidden_nonlinearity, or with ONE hidden layer -- its kernel copy is the two-layer net whose
+                                * second layer is the identity (W1 = I, b1 = 0, RL_ACT_IDENTITY) -- runs on the equal-width
+                                * two-layer kernels (rllab/policies/gaussian_mlp_policy.py:21-69, rllab/core/network.py:36-101
+                                * take any hidden_sizes / nonlinearity).  Every pass of those kernels takes the codes; the
+                                * split-operand products, the three-layer / wide kernels and rl_mlp_* take tanh layers only. */
+    int32_t reserved_pad;
     const int32_t* gate;       /* NULL, or a device word: rl_policy_loss_kl returns without evaluating anything when
                                 * *gate != 0 at the time the launch RUNS (its out4 is then unspecified).  The word is
                                 * rl_line_search_decide's "a candidate has been accepted" flag: the loss passes of
@@ -383,7 +392,7 @@ typedef struct rl_policy_batch {
                                 * batch.  Ignored by every other entry point. */
 } rl_policy_batch;
 
-enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1 };
+enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1, RL_ACT_IDENTITY = 2 };
 
 /* Scratch the three calls below need (device memory, caller-owned, reusable). */
 size_t rl_policy_workspace_bytes(int obs_dim, int act_dim, int hidden0, int hidden1, int hidden2);

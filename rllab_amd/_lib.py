@@ -62,7 +62,7 @@ class RolloutArgs(ctypes.Structure):
         ("actions", ctypes.c_void_p), ("means", ctypes.c_void_p), ("rewards", ctypes.c_void_p),
         ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p), ("cfg", ctypes.POINTER(EnvCfg)),
         ("theta_std", ctypes.c_void_p), ("log_stds", ctypes.c_void_p), ("std_hidden0", ctypes.c_int32),
-        ("std_hidden1", ctypes.c_int32), ("std_hidden2", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("std_hidden1", ctypes.c_int32), ("std_hidden2", ctypes.c_int32), ("layer_activations", ctypes.c_int32),
         ("opts", ctypes.c_void_p),
     ]
 
@@ -77,11 +77,18 @@ class PolicyBatch(ctypes.Structure):
         ("actions", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("old_means", ctypes.c_void_p),
         ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
         ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32), ("opts", ctypes.c_void_p),
-        ("gate", ctypes.c_void_p),
+        ("layer_activations", ctypes.c_int32), ("reserved_pad", ctypes.c_int32), ("gate", ctypes.c_void_p),
     ]
 
 
-ACT_TANH, ACT_RECTIFY = 0, 1
+ACT_TANH, ACT_RECTIFY, ACT_IDENTITY = 0, 1, 2
+
+
+def layer_activation_bits(codes):
+    """Per-layer activation codes -> ``layer_activations`` (two bits per layer holding code + 1); all tanh -> 0."""
+    if all(c == ACT_TANH for c in codes):
+        return 0
+    return sum((int(c) + 1) << (2 * l) for l, c in enumerate(codes))
 
 
 class LaunchOpts(ctypes.Structure):
@@ -254,11 +261,12 @@ def env_query(kind):
                 reset_is_normal=bool(nrm.value))
 
 
-def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0):
+def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0, layer_activations=0):
     """``RolloutPlan`` of a fused rollout of these sizes under the current launch options (rl_rollout_plan_query), or None
     when the library has no kernel for it (the reason is then in ``lib.rl_last_error()``)."""
     a = RolloutArgs(kind=kind, n_envs=int(n_envs), horizon=int(horizon), hidden0=hidden3[0], hidden1=hidden3[1],
-                    hidden2=hidden3[2], std_hidden0=std_hidden3[0], std_hidden1=std_hidden3[1], std_hidden2=std_hidden3[2])
+                    hidden2=hidden3[2], std_hidden0=std_hidden3[0], std_hidden1=std_hidden3[1], std_hidden2=std_hidden3[2],
+                    layer_activations=int(layer_activations))
     cfg = None
     if cfg_flags:
         cfg = EnvCfg()

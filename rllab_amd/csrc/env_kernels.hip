@@ -212,6 +212,7 @@ struct RolloutPolicy {
     float* fa1;
     float* tail;
     float* xbuf;
+    int act0 = 0, act1 = 0;     // hidden activations (rl_activation codes, wave-uniform; RolloutDev.act0 / act1)
 
     __device__ __forceinline__ void init(float* smem, const float* __restrict__ theta) {
         fa0 = smem;
@@ -254,8 +255,7 @@ struct RolloutPolicy {
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = ftanh(acc[r]);
+                act_frag(h0[t], acc, act0);
             }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -264,8 +264,7 @@ struct RolloutPolicy {
                 for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
 #pragma unroll
                 for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h1[t][r] = ftanh(acc[r]);
+                act_frag(h1[t], acc, act1);
             }
 #pragma unroll
             for (int k = 0; k < DA; ++k) {
@@ -341,6 +340,7 @@ struct RolloutPolicy16 {
     float w2[DA][NT][4];    // W2[16 t + 4 g + j][k]
     float b2[DA], lstd[DA];
     bool g0, g1, g2;
+    int act0 = 0, act1 = 0;     // hidden activations (rl_activation codes, wave-uniform)
 
     __device__ __forceinline__ void init(const float* __restrict__ th) {
         const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -391,7 +391,7 @@ struct RolloutPolicy16 {
 #pragma unroll
             for (int m = 0; m < KS0; ++m) acc = mfma16(a0[t][m], xb[m], acc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h0[t][j] = ftanh(acc[j]);
+            for (int j = 0; j < 4; ++j) h0[t][j] = act_one(acc[j], act0);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -401,7 +401,7 @@ struct RolloutPolicy16 {
 #pragma unroll
             for (int s_ = 0; s_ < KS1; ++s_) acc = mfma16(a1[t][s_], h0[s_ / 4][s_ % 4], acc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h1[t][j] = ftanh(acc[j]);
+            for (int j = 0; j < 4; ++j) h1[t][j] = act_one(acc[j], act1);
         }
         float pm[DA];
 #pragma unroll
@@ -787,6 +787,7 @@ struct RolloutDev {
     const float* act_noise_z;   // [T][Da][n] injected N(0,1) draws of the env's action noise, or null (Philox)
     const float* obs_noise_z;   // [T+1][Do][n]: slice 0 = the first observation, slice t + 1 = the one after step t
     float* log_stds;            // [Da][T][n] agent_info "log_std" of a policy with a log-std NETWORK (else unused)
+    int act0, act1;             // hidden activations of the equal-width (32,32) / (64,64) policies (rl_activation codes)
 };
 
 // A policy whose log-std is a second network on the observation (GaussianMLPPolicy(adaptive_std=True) / std_network=...,
@@ -956,9 +957,11 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
     Pol pol;
     if constexpr (EPW == 16) {
         pol.init(a.theta);
+        pol.act0 = a.act0; pol.act1 = a.act1;
     } else {
         __shared__ __attribute__((aligned(16))) float smem[RolloutPolicy<Env, H0>::LDS_FLOATS];
         pol.init(smem, a.theta);
+        pol.act0 = a.act0; pol.act1 = a.act1;
     }
     rollout_body<Env, Pol, EPW>(a, pol);
 }
@@ -1214,6 +1217,7 @@ template <int H>
 __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutDev a) {
     RolloutPolicy16<Swimmer, H> pol;
     pol.init(a.theta);
+    pol.act0 = a.act0; pol.act1 = a.act1;
     swimmer_quad_body(a, pol);
 }
 
@@ -1453,6 +1457,7 @@ template <class Env, int H>
 __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutDev a) {
     RolloutPolicy16<Env, H> pol;
     pol.init(a.theta);
+    pol.act0 = a.act0; pol.act1 = a.act1;
     two_leg_quad_body<Env>(a, pol);
 }
 
@@ -1548,6 +1553,7 @@ struct RolloutPolicyLane {
     float w2[DA], b2;          // row u of W2 (zero on the lanes that repeat a unit: H < 64), b2[a] (a = min(lane, DA - 1))
     float lstd;                // log_std[a]
     float* hbuf;               // LDS: H floats of this wavefront
+    int act0 = 0, act1 = 0;    // hidden activations (rl_activation codes, wave-uniform)
 
     __device__ __forceinline__ void init(const float* __restrict__ th, float* lds_row) {
         const int lane = threadIdx.x & 63, u = lane & (H - 1), a = lane < DA ? lane : DA - 1;
@@ -1589,10 +1595,10 @@ struct RolloutPolicyLane {
 #pragma unroll
         for (int k = 0; k < DOP; k += 2)
             acc = __builtin_elementwise_fma((rl_f32x2){w0[k], w0[k + 1]}, (rl_f32x2){o[k], k + 1 < DO ? o[k + 1] : 0.0f}, acc);
-        const float h0 = ftanh(acc[0] + acc[1]);
+        const float h0 = act_one(acc[0] + acc[1], act0);
         if (lane < H) hbuf[lane] = h0;
         wave_sync();
-        const float h1 = ftanh(b1 + dot_row(w1));
+        const float h1 = act_one(b1 + dot_row(w1), act1);
         wave_sync();                                  // (the reads of h0 are done before the next step's write)
         // output layer: unit u's contribution to every action from its own lane, summed over the lanes
         float p[DA];
@@ -1641,6 +1647,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
     __shared__ __attribute__((aligned(16))) float hrows[LANE_TPB / 64][H];
     RolloutPolicyLane<Env, H> pol;
     pol.init(a.theta, hrows[threadIdx.x >> 6]);
+    pol.act0 = a.act0; pol.act1 = a.act1;
 
     const int n = a.n, T = a.T;
     const int lane = threadIdx.x & 63;
@@ -1951,6 +1958,9 @@ static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
     plan_fill(p, RL_ROLLOUT_UNSUPPORTED, 0, 0, 0, 0, "");
     char nm[96];
     const bool equal = g->hidden2 == 0 && g->hidden0 == g->hidden1 && (g->hidden0 == 32 || g->hidden0 == 64);
+    if (g->layer_activations != 0 && (!equal || g->theta_std != nullptr))
+        return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: rectify / identity hidden layers run on the (32,32) / "
+                         "(64,64) kernels only (hidden %d,%d,%d)", g->hidden0, g->hidden1, g->hidden2);
     const bool small_offsets = (size_t)Env::OBS * (size_t)T * (size_t)n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
     const int epw_req = (o.rollout_epw == 16 || o.rollout_epw == 64) ? o.rollout_epw : 0;
     const int epw_generic = epw_req ? epw_req : (n <= 16 * 1024 ? 16 : 64);
@@ -2085,6 +2095,8 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     a.act_noise_z = g->cfg ? g->cfg->action_noise_z : nullptr;
     a.obs_noise_z = g->cfg ? g->cfg->obs_noise_z : nullptr;
     a.log_stds = g->log_stds;
+    a.act0 = layer_act(RL_ACT_TANH, g->layer_activations, 0);
+    a.act1 = layer_act(RL_ACT_TANH, g->layer_activations, 1);
     const dim3 grid(pl.workgroups), block(64 * pl.wavefronts_per_workgroup);
     const size_t lds = (size_t)pl.lds_bytes;
     const int H = g->hidden0, epw = pl.envs_per_wavefront;

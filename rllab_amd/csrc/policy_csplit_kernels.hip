@@ -782,7 +782,9 @@ static int launch_class(const CsShape& s, const rl_policy_batch* g, const float*
 // recomputed bit for bit), = 2 takes every shape it is built for (the parity tests of the two-wavefront
 // class run that way).
 bool csplit_fvp_takes(const rl_policy_batch* g) {
-    if (!g->activations || g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0) return false;
+    if (!g->activations || g->activation != RL_ACT_TANH || g->layer_activations != 0 || g->n_samples <= 0 ||
+        g->n_samples % TS != 0)
+        return false;
     const int req = g->opts ? g->opts->fvp_split : 0;          // 1: off, 2: every shape the kernel is built for
     if (req == 1) return false;
     cs::CsShape s;

@@ -96,6 +96,7 @@ struct PolicyBatch {
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
     const int* gate;           // MODE_LOSS: rl_policy_batch.gate -- non-zero word: the launch returns at once
+    int act0, act1;            // activation codes of the two hidden layers (rl_activation; RELU instantiations ignore them)
 };
 
 // hidden nonlinearity: tanh (GaussianMLPPolicy, network.py:38-39 default) or rectify (GaussianMLPRegressor /
@@ -128,6 +129,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
     }
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
     const int lj = lane & 31, lh = lane >> 5;
+    const int c0 = RELU ? 1 : a.act0, c1 = RELU ? 1 : a.act1;      // hidden activations (wave-uniform codes)
     float* const fa0 = smem + S::A0;
     float* const fa1 = smem + S::A1;
     float* const fa1t = smem + S::A1T;
@@ -288,8 +290,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = act_fn<RELU>(acc[r]);
+                act_frag(h0[t], acc, c0);
             }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -298,8 +299,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
                 for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
 #pragma unroll
                 for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h1[t][r] = act_fn<RELU>(acc[r]);
+                act_frag(h1[t], acc, c1);
             }
             if constexpr (STORE_ACTS) {
                 f32x4* dst = reinterpret_cast<f32x4*>(a.acts) + (size_t)tile * ACT_ROWS * WV + lane;
@@ -403,8 +403,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int m = 0; m < KS0; ++m) acc = mfma(fda0[(t * KS0 + m) * WV + lane], xb[m], acc);   // dW0^T x + db0
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dh0[t][r] = acc[r] * (1.0f - h0[t][r] * h0[t][r]);
+                act_bwd_frag(dh0[t], acc, h0[t], c0);
             }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -416,8 +415,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
                     acc = mfma(fda1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);                // dW1^T h0
                     acc = mfma(fa1[(t * KS1 + m) * WV + lane], dh0[m / 16][m % 16], acc);                // W1^T dh0
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dh1[t][r] = acc[r] * (1.0f - h1[t][r] * h1[t][r]);
+                act_bwd_frag(dh1[t], acc, h1[t], c1);
             }
             const float c = wgt * a.inv_count;
 #pragma unroll
@@ -456,15 +454,18 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
             // ---- back-propagation: gz1 = (W2 gmu) (1 - h1^2); gz0 = (W1 gz1) (1 - h0^2) ----------------
             f32x16 gz1[HT], gz0[HT];
 #pragma unroll
-            for (int t = 0; t < HT; ++t)
+            for (int t = 0; t < HT; ++t) {
+                f32x16 gh;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float g = 0.0f;
 #pragma unroll
                     for (int k = 0; k < DA; ++k)
                         g = __builtin_fmaf(tail[T_W2 + (32 * t + frag_unit(r, 0) + 4 * lh) * DA + k], gmu[k], g);
-                    gz1[t][r] = g * act_dz<RELU>(h1[t][r]);
+                    gh[r] = g;
                 }
+                act_bwd_frag(gz1[t], gh, h1[t], c1);
+            }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
                 f32x16 acc;
@@ -472,8 +473,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int m = 0; m < KS1; ++m) acc = mfma(fa1t[(t * KS1 + m) * WV + lane], gz1[m / 16][m % 16], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gz0[t][r] = acc[r] * act_dz<RELU>(h0[t][r]);
+                act_bwd_frag(gz0[t], acc, h0[t], c0);
             }
 
             // ---- gb2, gmu / x rows for the broadcast (VALU) products -------------------------------------
@@ -829,6 +829,8 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
     a.gate = (MODE == MODE_LOSS) ? g->gate : nullptr;
+    a.act0 = layer_act(g->activation, g->layer_activations, 0);
+    a.act1 = layer_act(g->activation, g->layer_activations, 1);
     const int n_tiles = (a.B + TS - 1) / TS;
     const size_t lds = (size_t)S::TOTAL * sizeof(float);
     if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "policy pass needs %zu B of LDS", lds);
@@ -937,8 +939,15 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
                         double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr,
                         const PlaneArgs* pl = nullptr) {
     const int d = g->obs_dim, k = g->act_dim, h0 = g->hidden0, h1 = g->hidden1;
+    // hidden activations per layer (rl_policy_batch.activation / layer_activations): the equal-width two-layer kernels
+    // take any of tanh / rectify / identity per layer at run time; every other family evaluates tanh layers only
+    const int a0 = layer_act(g->activation, g->layer_activations, 0), a1 = layer_act(g->activation, g->layer_activations, 1),
+              a2 = g->hidden2 > 0 ? layer_act(g->activation, g->layer_activations, 2) : RL_ACT_TANH;
+    if (a0 < 0 || a0 > RL_ACT_IDENTITY || a1 < 0 || a1 > RL_ACT_IDENTITY || a2 < 0 || a2 > RL_ACT_IDENTITY)
+        return set_error(RL_ERR_ARG, "unknown activation (%d, layers 0x%x)", g->activation, g->layer_activations);
+    const bool all_tanh = a0 == RL_ACT_TANH && a1 == RL_ACT_TANH && a2 == RL_ACT_TANH;
     if (mode >= MODE_OUT) {
-        if (g->activation != RL_ACT_TANH)
+        if (!all_tanh)
             return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: tanh networks");
 #define PLANECASE(DO, DA, H) \
         if (g->hidden2 == 0 && d == DO && k == DA && h0 == H && h1 == H) \
@@ -959,23 +968,25 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     if (g->hidden2 < 0) return set_error(RL_ERR_ARG, "rl_policy_batch.hidden2 = %d", g->hidden2);
     if (g->hidden2 > 0) {              // three hidden layers: the cooperative kernels (policy_wide_kernels.hip)
         if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
-        if (mode == MODE_FVP && g->activation == RL_ACT_TANH) {
+        if (!all_tanh)
+            return set_error(RL_ERR_UNSUPPORTED, "three hidden layers: tanh layers only (the cooperative kernels)");
+        if (mode == MODE_FVP) {
             const int rc = csplit_fvp_dispatch(g, vec, ws, ws_bytes, out, st);    // split-operand arithmetic (cached products)
             if (rc != RL_SPLIT_NOT_TAKEN) return rc;
         }
         return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, loss_out);
     }
-    if (g->activation == RL_ACT_RECTIFY) {
+    if (g->activation == RL_ACT_RECTIFY && g->layer_activations == 0 && k == 1 && h0 == 32 && h1 == 32 &&
+        (mode == MODE_LOSS || mode == MODE_VPG)) {
+        // the regressors' nets (GaussianMLPRegressor's default hidden nonlinearity): compile-time rectify instantiations
 #define RELUCASE(DO) \
         if (d == DO && k == 1 && h0 == 32 && h1 == 32) return dispatch_relu<Net<DO, 1, 32>>(mode, g, ws, ws_bytes, out, st, loss_out);
         RELUCASE(4) RELUCASE(6) RELUCASE(11) RELUCASE(13) RELUCASE(20) RELUCASE(21)
 #undef RELUCASE
-        return set_error(RL_ERR_UNSUPPORTED, "no rectify kernel for obs_dim=%d act_dim=%d hidden=(%d,%d)", d, k, h0, h1);
     }
-    if (g->activation != RL_ACT_TANH) return set_error(RL_ERR_ARG, "unknown activation %d", g->activation);
     if (g->kl_penalty != 0.0f && mode != MODE_VPG && mode != MODE_GRAD)
         return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the gradient passes only");
-    if (mode == MODE_FVP && cg == nullptr) {
+    if (mode == MODE_FVP && cg == nullptr && all_tanh) {
         int rc = split_fvp_dispatch(g, vec, ws, ws_bytes, out, st);          // (32, 32): one wavefront per tile
         if (rc != RL_SPLIT_NOT_TAKEN) return rc;
         rc = csplit_fvp_dispatch(g, vec, ws, ws_bytes, out, st);             // 64-unit and wide nets: cooperative
@@ -988,6 +999,9 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
 #undef NETCASE
     // anything else with tanh layers of 32 / 64 / 128 units: the cooperative kernels
     if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
+    if (!all_tanh)
+        return set_error(RL_ERR_UNSUPPORTED, "obs_dim=%d act_dim=%d hidden=(%d,%d): rectify / identity layers run on the "
+                         "equal-width two-layer kernels of the HIP-native (obs, action) pairs only", d, k, h0, h1);
     return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }
 

@@ -25,6 +25,41 @@ __device__ __forceinline__ float ftanh(float x) {
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
+// Hidden activation of a layer, chosen at RUN time by a wave-uniform code (rl_activation: 0 tanh, 1 rectify, 2 identity):
+// a policy with a rectify hidden_nonlinearity, or with ONE hidden layer (its kernel copy carries an identity second layer,
+// policies/kernel_layout.py), runs on the kernels built for the tanh nets -- rllab/policies/gaussian_mlp_policy.py:21-69 and
+// rllab/core/network.py:36-101 are free-form in both.  The branch is uniform, the tanh path is the instruction stream it
+// always was (same bits), the derivative is expressed through the activation itself.
+__device__ __forceinline__ void act_frag(f32x16& h, const f32x16& z, int code) {
+    if (code == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = ftanh(z[r]);
+    } else if (code == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = fmaxf(z[r], 0.0f);
+    } else {
+        h = z;
+    }
+}
+// out = v * d act / dz  at activation value h
+__device__ __forceinline__ void act_bwd_frag(f32x16& out, const f32x16& v, const f32x16& h, int code) {
+    if (code == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = v[r] * (1.0f - h[r] * h[r]);
+    } else if (code == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = h[r] > 0.0f ? v[r] : 0.0f;
+    } else {
+        out = v;
+    }
+}
+__device__ __forceinline__ float act_one(float z, int code) { return code == 0 ? ftanh(z) : code == 1 ? fmaxf(z, 0.0f) : z; }
+// per-layer codes of a batch / rollout: 0 = every hidden layer uses `activation`; else 2 bits per layer holding code + 1
+__host__ __device__ inline int layer_act(int activation, int layer_activations, int l) {
+    const int f = (layer_activations >> (2 * l)) & 3;
+    return (layer_activations == 0 || f == 0) ? activation : f - 1;
+}
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

@@ -1240,7 +1240,7 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
 #define SPLIT64_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(20, 3) X(20, 6) X(21, 6)
 bool split_fvp_takes(const rl_policy_batch* g) {
     if (!g->activations || g->hidden2 != 0 || g->hidden0 != g->hidden1 || (g->hidden0 != 32 && g->hidden0 != 64) ||
-        g->activation != RL_ACT_TANH || g->n_samples <= 0 || g->n_samples % TS != 0)
+        g->activation != RL_ACT_TANH || g->layer_activations != 0 || g->n_samples <= 0 || g->n_samples % TS != 0)
         return false;
     const int req = g->opts ? g->opts->fvp_split : 0;          // 0: the library's choice, 1: f32 matrix instructions, 2: cooperative
     if (req == 1) return false;

@@ -976,7 +976,7 @@ int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws
     const WidePlanes planes = {cot, out_mean, out_dmean};
     const WidePlanes* pl = &planes;
     WideShape s;
-    if (g->activation != RL_ACT_TANH || !wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, s))
+    if (g->activation != RL_ACT_TANH || g->layer_activations != 0 || !wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, s))
         return set_error(RL_ERR_UNSUPPORTED,
                          "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d,%d): two or three tanh layers "
                          "of 32 / 64 / 128 units, obs_dim <= %d, act_dim <= %d",

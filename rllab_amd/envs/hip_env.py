@@ -203,12 +203,13 @@ class HipVecEnv(object):
         hs, hs_std = (layout.hidden3, (0, 0, 0)) if layout is not None else (tuple(dual[1]), tuple(dual[3]))
         # asked once per (sizes, launch options): the sampler asks before every rollout
         _lib.launch_opts()
-        key = (hs, hs_std, T, flags, bytes(_lib._OPTS))
+        acts = layout.layer_activations if layout is not None else 0
+        key = (hs, hs_std, T, flags, acts, bytes(_lib._OPTS))
         cache = self.__dict__.setdefault("_plan_cache", {})
         if key not in cache:
             if len(cache) > 64:
                 cache.clear()
-            cache[key] = _lib.rollout_plan(self.kind, self.n, T, hs, hs_std, cfg_flags=flags)
+            cache[key] = _lib.rollout_plan(self.kind, self.n, T, hs, hs_std, cfg_flags=flags, layer_activations=acts)
         return cache[key]
 
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
@@ -265,7 +266,8 @@ class HipVecEnv(object):
             cfg=ctypes.pointer(self.cfg),
             theta_std=None if theta_std is None else theta_std.data_ptr(),
             log_stds=None if log_stds is None else log_stds.data_ptr(),
-            std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2], opts=_lib.launch_opts())
+            std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2],
+            layer_activations=layout.layer_activations if layout is not None else 0, opts=_lib.launch_opts())
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1

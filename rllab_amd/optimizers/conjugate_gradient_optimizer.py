@@ -304,8 +304,8 @@ class ConjugateGradientOptimizer(Serializable):
         first = 0
         accepted = False
         n_spec = min(int(getattr(self, "_device_line_search", 3)), self._max_backtracks)
-        if D.is_distributed() and D.peer_reducer() is None:
-            # host-issued collectives: every candidate's sums cross the ranks whether its pass was gated off or not, so
+        if D.is_distributed():
+            # every candidate's sums cross the ranks (a host-issued all-gather) whether its pass was gated off or not, so
             # the speculation is kept to the two candidates an iteration typically needs
             n_spec = min(n_spec, 2)
         if (step_vec is not None and n_spec > 0 and getattr(self._fused, "device_line_search", False)

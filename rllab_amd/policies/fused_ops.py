@@ -90,6 +90,7 @@ class FusedGaussianMLPOps(object):
             log_min_std=math.log(pol.min_std) if pol.min_std is not None else -1e30,
             theta=theta.data_ptr(), obs=obs.data_ptr(), actions=act.data_ptr(), advantages=adv.data_ptr(),
             old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(), weights=w.data_ptr(),
+            layer_activations=self.layout.layer_activations,
             opts=_lib.launch_opts())      # (one process-wide struct, refreshed from the RLLAB_* switches before the calls
                                           # whose kernel choice it steers: _fvp_into, fvp_variant)
         if len(self._bound) >= 2:   # full batch + (optionally) its FVP subsample

@@ -12,7 +12,7 @@ read.  Initialisation follows the reference: Glorot-uniform W
 import numpy as np
 import torch
 
-from rllab_amd.core.network import MLP
+from rllab_amd.core.network import MLP, rectify
 from rllab_amd.core.parameterized import Param
 from rllab_amd.core.serializable import Serializable
 from rllab_amd.distributions.diagonal_gaussian import DiagonalGaussian
@@ -21,6 +21,11 @@ from rllab_amd.policies.base import StochasticPolicy
 from rllab_amd.spaces import Box
 
 tanh = torch.tanh
+
+
+def is_rectify(f):
+    """rllab's rectify (core/network.py, lasagne.nonlinearities.rectify in the reference) under any of its torch names."""
+    return f is rectify or f is torch.relu or f is torch.nn.functional.relu
 
 
 def _default_device():
@@ -105,7 +110,7 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
     @property
     def fusable(self):
         """True when the in-kernel policy (tanh hidden layers, linear output, one free log_std row) is this policy."""
-        return (self.hidden_nonlinearity is tanh and self.output_nonlinearity is None
+        return ((self.hidden_nonlinearity is tanh or is_rectify(self.hidden_nonlinearity)) and self.output_nonlinearity is None
                 and not self.state_dependent_std)
 
     @property
@@ -128,9 +133,16 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
         else None."""
         if not hasattr(self, "_kernel_layout"):
             from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM, KernelLayout, padded_sizes
-            ok = (self.fusable and padded_sizes(self.hidden_sizes) is not None and self.flat_params.is_cuda
+            Hs = padded_sizes(self.hidden_sizes)
+            ok = (self.fusable and Hs is not None and self.flat_params.is_cuda
                   and self.flat_params.dtype == torch.float32
                   and self.obs_dim <= MAX_OBS_DIM and self.action_dim <= MAX_ACT_DIM)
+            # rectify layers and the identity layer of a one-hidden-layer policy: the equal-width two-layer kernels of the
+            # HIP-native (obs, action) pairs only (the cooperative family evaluates tanh layers)
+            if ok and (is_rectify(self.hidden_nonlinearity) or len(tuple(self.hidden_sizes)) == 1):
+                from rllab_amd.policies.fused_ops import FusedGaussianMLPOps
+                ok = (len(Hs) == 2 and Hs[0] == Hs[1] and Hs[0] in (32, 64)
+                      and (self.obs_dim, self.action_dim) in FusedGaussianMLPOps.NARROW_PAIRS)
             self._kernel_layout = KernelLayout(self) if ok else None
         return self._kernel_layout
 
@@ -143,15 +155,20 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
         hs = tuple(int(h) for h in self.hidden_sizes)
         if self.state_dependent_std:
             return "the log-std is a network (adaptive_std / std_network): the two-network kernels apply instead"
-        if self.hidden_nonlinearity is not tanh:
-            return "hidden_nonlinearity is %s (the kernels evaluate tanh layers)" % getattr(
+        if self.hidden_nonlinearity is not tanh and not is_rectify(self.hidden_nonlinearity):
+            return "hidden_nonlinearity is %s (the kernels evaluate tanh and rectify layers)" % getattr(
                 self.hidden_nonlinearity, "__name__", repr(self.hidden_nonlinearity))
         if self.output_nonlinearity is not None:
             return "output_nonlinearity is not None (the kernels' output layer is linear)"
         if padded_sizes(hs) is None:
+            if len(hs) == 1:
+                return "hidden_sizes=%r: one hidden layer runs on the kernels up to 64 units" % (hs,)
             if len(hs) not in (2, 3):
-                return "hidden_sizes=%r has %d hidden layer(s) (the kernels run two or three)" % (hs, len(hs))
+                return "hidden_sizes=%r has %d hidden layers (the kernels run one, two or three)" % (hs, len(hs))
             return "hidden_sizes=%r has a layer wider than 128 units" % (hs,)
+        if is_rectify(self.hidden_nonlinearity) or len(hs) == 1:
+            return ("rectify layers / one hidden layer run on the (32, 32) / (64, 64) kernels of the HIP-native (obs, action) "
+                    "pairs: hidden_sizes=%r, obs_dim %d, action_dim %d is not one of them" % (hs, self.obs_dim, self.action_dim))
         if not self.flat_params.is_cuda or self.flat_params.dtype != torch.float32:
             return "the parameters are not float32 on a HIP device"
         if self.obs_dim > MAX_OBS_DIM or self.action_dim > MAX_ACT_DIM:

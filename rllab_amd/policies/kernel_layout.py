@@ -43,8 +43,12 @@ def tile_for(hidden_sizes):
 
 def padded_sizes(hidden_sizes):
     """The kernels' hidden widths for ``hidden_sizes``: (H, H) of the equal-width family when it applies, else every
-    layer on its own next size of 32 / 64 / 128 (two or three layers); None when no kernel runs the net."""
+    layer on its own next size of 32 / 64 / 128 (two or three layers); None when no kernel runs the net.  ONE hidden
+    layer of at most 64 units runs as (H, H) with an identity second layer (``KernelLayout.identity_layer``)."""
     hs = tuple(int(h) for h in hidden_sizes)
+    if len(hs) == 1 and 1 <= hs[0] <= TILE_SIZES[-1]:
+        H = next(t for t in TILE_SIZES if hs[0] <= t)
+        return (H, H)
     H = tile_for(hs)
     if H is not None:
         return (H, H)
@@ -81,6 +85,9 @@ def mlp_pad_index(in_dim, hidden_sizes, padded, out_dim):
     return np.concatenate(idx), off
 
 
+ACT_TANH, ACT_RECTIFY, ACT_IDENTITY = 0, 1, 2      # rl_activation (include/rllab_amd.h)
+
+
 class KernelLayout(object):
     def __init__(self, policy):
         self.policy = policy
@@ -88,6 +95,15 @@ class KernelLayout(object):
         do, da = policy.obs_dim, policy.action_dim
         Hs = padded_sizes(hs)
         assert Hs is not None
+        # hidden activations per KERNEL layer: the policy's nonlinearity, and the identity for the second layer a
+        # one-hidden-layer policy gets in its kernel copy (W1 = I, b1 = 0: h1 = h0 exactly, products with 1 and 0)
+        from rllab_amd.policies.gaussian_mlp_policy import is_rectify
+        code = ACT_RECTIFY if is_rectify(getattr(policy, "hidden_nonlinearity", None)) else ACT_TANH
+        self.identity_layer = len(hs) == 1
+        self.layer_codes = (code, ACT_IDENTITY) if self.identity_layer else (code,) * len(Hs)
+        if self.identity_layer:
+            self._init_one_layer(policy, hs[0], Hs[0], do, da)
+            return
         self.hidden = Hs                         # what the kernels are told (rl_policy_batch.hidden0..2)
         self.H = Hs[0]                           # kept for callers of the equal-width family
         self.wide = not (len(Hs) == 2 and Hs[0] == Hs[1] and Hs[0] in TILE_SIZES)
@@ -120,6 +136,38 @@ class KernelLayout(object):
         self.index = torch.as_tensor(idx, dtype=torch.long, device=dev)
         self._theta = torch.zeros(self.P_pad, dtype=torch.float32, device=dev)
         self._tag = None
+
+    def _init_one_layer(self, policy, h, H, do, da):
+        """hidden_sizes = (h,): kernel net (do -> H -> H -> da) whose second layer is the identity.  Real parameters
+        W0 [do, h], b0 [h], Wout [h, da], bout, log_std sit at their padded positions; W1 = I and b1 = 0 are constants of
+        the kernel copy (never trained: ``unpack`` gathers the real entries only, ``pack`` leaves their tangents zero)."""
+        self.hidden, self.H = (H, H), H
+        self.wide, self.exact = False, False
+        self.P = policy.flat_params.numel()
+        oW0, ob0 = 0, do * H
+        oW1 = ob0 + H
+        ob1 = oW1 + H * H
+        oWo = ob1 + H
+        obo = oWo + H * da
+        ols = obo + da
+        self.P_pad = ols + da
+        idx = [oW0 + (np.arange(do)[:, None] * H + np.arange(h)[None, :]).reshape(-1), ob0 + np.arange(h),
+               oWo + (np.arange(h)[:, None] * da + np.arange(da)[None, :]).reshape(-1), obo + np.arange(da),
+               ols + np.arange(da)]
+        idx = np.concatenate(idx)
+        assert idx.size == self.P and len(set(idx.tolist())) == self.P
+        dev = policy.flat_params.device
+        self.index = torch.as_tensor(idx, dtype=torch.long, device=dev)
+        self._theta = torch.zeros(self.P_pad, dtype=torch.float32, device=dev)
+        self._theta[oW1 + torch.arange(H, device=dev) * (H + 1)] = 1.0        # W1 = I
+        self._tag = None
+
+    @property
+    def layer_activations(self):
+        """``rl_policy_batch.layer_activations`` / ``rl_rollout_args.layer_activations`` of this layout (0 = tanh layers)."""
+        if all(c == ACT_TANH for c in self.layer_codes):
+            return 0
+        return sum((int(c) + 1) << (2 * l) for l, c in enumerate(self.layer_codes))
 
     @property
     def hidden3(self):

@@ -36,7 +36,7 @@ def _free(lib, boxes):
 @pytest.mark.parametrize("world,n", [(2, 1572), (2, 65536), (3, 1), (3, 5900)])
 def test_ranks_as_streams_sum_in_rank_order(world, n, monkeypatch):
     from rllab_amd import _lib
-    monkeypatch.setenv("RLLAB_PEER_SPIN_LIMIT", "400000")    # a scheduling surprise fails in a fraction of a second
+    monkeypatch.setenv("RLLAB_PEER_SPIN_LIMIT", "4000000")   # a scheduling surprise fails in about a second
     max_n = 1 << 16
     boxes, table = _mailboxes(_lib, world, max_n)
     rng = np.random.RandomState(world * 1000 + n)

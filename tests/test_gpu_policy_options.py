@@ -272,3 +272,158 @@ def test_ppo_runs_on_the_kernels_and_learns(quiet_logger):
         assert float(tab["MeanKL"]) <= 0.0101 and float(tab["LossAfter"]) <= float(tab["LossBefore"]) + 1e-7
         logger.dump_tabular()
     assert np.mean(rets[-2:]) > 1.5 * np.mean(rets[:2]), rets
+
+
+# ---- one hidden layer, rectify layers (round 5): the equal-width two-layer kernels with per-layer activation codes ----------
+# gaussian_mlp_policy.py:21-69 / network.py:36-101 take any hidden_sizes and hidden_nonlinearity; a one-hidden-layer policy's
+# kernel copy is the two-layer net with an identity second layer (policies/kernel_layout.py)
+def _nl(name):
+    from rllab_amd.core.network import rectify
+    return dict(tanh=torch.tanh, rectify=rectify, torch_relu=torch.relu)[name]
+
+
+LAYERED = [((32,), "tanh"), ((20,), "tanh"), ((64,), "tanh"), ((32, 32), "rectify"), ((16,), "rectify"),
+           ((50, 25), "torch_relu")]
+
+
+def _layered_policy(do_or_kind, da, hidden, nl, seed=0, by_kind=False):
+    from rllab_amd import _lib
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    if by_kind:
+        q = _lib.env_query(do_or_kind)
+        do, da = q["obs_dim"], q["act_dim"]
+    else:
+        do = do_or_kind
+    np.random.seed(seed)
+    spec = EnvSpec(Box(-1e6 * np.ones(do), 1e6 * np.ones(do)), Box(-np.ones(da), np.ones(da)))
+    pol = GaussianMLPPolicy(spec, hidden_sizes=hidden, hidden_nonlinearity=_nl(nl))
+    th = pol.get_param_values()
+    pol.set_param_values(th + 0.1 * np.random.RandomState(seed).randn(th.size))
+    return pol
+
+
+@pytest.mark.parametrize("hidden,nl", LAYERED)
+@pytest.mark.parametrize("kind", [0, 2, 3])
+def test_fused_rollout_with_one_hidden_layer_or_rectify_layers(kind, hidden, nl, rollout_shape_all):
+    """Every launch shape of the equal-width rollouts: recorded means == float64 torch forward of the REAL net (one layer /
+    rectify), env dynamics replay bit-exactly on the host, and the launcher's plan says it is a fused kernel."""
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from oracle.replay import replay_check
+    pol = _layered_policy(kind, None, hidden, nl, by_kind=True)
+    lay = pol.kernel_layout()
+    assert lay is not None and lay.layer_activations != 0
+    assert lay.identity_layer == (len(hidden) == 1)
+    rng = np.random.RandomState(1)
+    n, T = 70, 25
+    v = HipVecEnv(kind, n, 11, normalize=True, seed=5)
+    plan = v.rollout_plan(pol, T)
+    assert plan is not None and plan.kernel in (1, 4, 7, 8), plan and plan.kernel
+    q = v.q
+    eps = rng.randn(q["act_dim"], T, n).astype(np.float32)
+    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    traj = v.rollout(pol, T, reset_at_start=True, eps=eps, reset_draws=draws)
+    assert replay_check(v, traj, max_envs=n, reset_draws=draws) == n * T
+    with torch.no_grad():
+        mean64 = pol.mean_planes(traj.obs.reshape(q["obs_dim"], -1).double(), pol.flat_params.double())
+    assert float((traj.means.reshape(q["act_dim"], -1).double() - mean64).abs().max()) <= 1e-5
+
+
+@pytest.fixture(params=["auto", "64", "generic16"])
+def rollout_shape_all(request, monkeypatch):
+    for k in ("RLLAB_ROLLOUT_EPW", "RLLAB_SWIMMER_LANE_KERNEL", "RLLAB_TWO_LEG_LANE_KERNEL"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param == "64":
+        monkeypatch.setenv("RLLAB_ROLLOUT_EPW", "64")
+        monkeypatch.setenv("RLLAB_SWIMMER_LANE_KERNEL", "1")
+    elif request.param == "generic16":
+        monkeypatch.setenv("RLLAB_ROLLOUT_EPW", "16")
+        monkeypatch.setenv("RLLAB_SWIMMER_LANE_KERNEL", "1")
+    return request.param
+
+
+@pytest.mark.parametrize("hidden,nl", LAYERED)
+@pytest.mark.parametrize("do,da", [(4, 1), (13, 2), (20, 6)])
+def test_update_kernels_with_one_hidden_layer_or_rectify_layers(do, da, hidden, nl):
+    """loss / KL / gradients / Fisher-vector product of the kernels (per-layer activation codes) against float64 autograd of
+    the real net -- the bars of the tanh tests; the product runs on the f32 matrix instructions (the split-operand kernels
+    take tanh layers), with and without the activation cache."""
+    from tests import test_gpu_update_parity as U
+    pol = _layered_policy(do, da, hidden, nl, seed=2)
+    ops = pol.fused_ops()
+    assert ops is not None and ops.layout.layer_activations != 0
+    inp = U._inputs(pol, 3008)
+    surr, kl, vpg = U._closures(pol)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    l64, k64, v64 = surr(flat64, *inp), kl(flat64, *inp), vpg(flat64, *inp)
+    s = ops.loss_stats(inp)
+    assert abs(float(-s[0]) - float(l64)) <= 2e-5 * max(1.0, abs(float(l64)))
+    assert abs(float(s[1]) - float(k64)) <= 2e-5 * max(1e-2, abs(float(k64)))
+    g64 = torch.autograd.grad(l64, flat64, retain_graph=True)[0]
+    g = ops.loss_grad(inp)
+    assert g.shape == g64.shape
+    assert float((g - g64).abs().max()) <= 2e-5 * max(1e-3, float(g64.abs().max()))
+    gv64 = torch.autograd.grad(v64, flat64)[0]
+    gv = ops.loss_grad(inp, vpg=True)
+    assert float((gv - gv64).abs().max()) <= 2e-5 * max(1e-3, float(gv64.abs().max()))
+    inp0 = U._inputs(pol, 3008, old_equals_new=True)
+    flat64 = pol.flat_params.detach().double().requires_grad_(True)
+    with torch.no_grad():
+        om64 = pol.mean_planes(inp0[0].double(), flat64.detach())
+    inp64 = (inp0[0], inp0[1], inp0[2], om64, pol.effective_log_std().detach().double().reshape(-1, 1), inp0[5], inp0[6])
+    gk = torch.autograd.grad(kl(flat64, *inp64), flat64, create_graph=True)[0]
+    v = torch.as_tensor(np.random.RandomState(3).randn(flat64.numel()), device=flat64.device)
+    hv64 = torch.autograd.grad((gk * v).sum(), flat64)[0]
+    hv = ops.fvp(inp0, v)
+    assert float((hv - hv64).abs().max()) <= 5e-5 * float(hv64.abs().max())
+    ops.loss_grad(inp0, keep_activations=True)                  # ... and from the cached activations (whole tiles: 3008 = 94 x 32)
+    assert ops.fvp_variant(inp0) == 0                           # not the split kernels: they evaluate tanh layers
+    hv_c = ops.fvp(inp0, v)
+    assert torch.equal(hv_c, hv)
+
+
+def test_policies_that_still_leave_the_kernels_say_why():
+    pol = _layered_policy(13, 2, (100,), "tanh")
+    assert pol.kernel_layout() is None and "one hidden layer" in pol.why_no_kernel_layout()
+    pol = _layered_policy(17, 2, (32,), "tanh")                     # not an (obs, action) pair of a HIP-native env
+    assert pol.kernel_layout() is None and "pairs" in pol.why_no_kernel_layout()
+    pol = _layered_policy(13, 2, (128, 128), "rectify")
+    assert pol.kernel_layout() is None and "rectify" in pol.why_no_kernel_layout()
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.spaces import Box
+    spec = EnvSpec(Box(-np.ones(13), np.ones(13)), Box(-np.ones(2), np.ones(2)))
+    pol = GaussianMLPPolicy(spec, hidden_sizes=(32, 32), hidden_nonlinearity=torch.sigmoid)
+    assert pol.kernel_layout() is None and "sigmoid" in pol.why_no_kernel_layout()
+
+
+@pytest.mark.parametrize("hidden,nl", [((32,), "tanh"), ((32, 32), "rectify")])
+def test_trpo_learns_on_the_kernels_with_one_hidden_layer_or_rectify(hidden, nl, quiet_logger):
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(1)
+    env = normalize(CartpoleEnv())
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=hidden, hidden_nonlinearity=_nl(nl))
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=256 * 100,
+                max_path_length=100, n_itr=15, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    assert algo.optimizer._fused is not None                  # the HIP update path, not autograd
+    assert algo.sampler.sampling_path(policy)[0].startswith("fused rollout kernel")
+    rets = []
+    for itr in range(15):
+        paths = algo.sampler.obtain_samples(itr)
+        assert paths.traj.log_std is not None and paths.traj.log_std_planes is None     # fused rollout
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.log_diagnostics(paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        rets.append(float(tab["AverageReturn"]))
+        assert float(tab["MeanKL"]) <= 0.0101
+        logger.dump_tabular()
+    assert np.mean(rets[-3:]) > 2.0 * np.mean(rets[:3]), rets

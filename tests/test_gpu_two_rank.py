@@ -207,7 +207,7 @@ def test_four_ranks_with_the_in_stream_peer_allreduce(tmp_path):
     moved = np.abs(th[0] - theta0).max()
     assert moved > 0 and np.abs(tp[0] - th[0]).max() <= 1e-3 * moved, (np.abs(tp[0] - th[0]).max(), moved)
     cp = np.load(str(tmp_path / "counts_peer_0.npy"))
-    assert np.all(cp[:, 1] == 11) and np.all(cp[:, 0] <= 6), cp
+    assert np.all(cp[:, 1] == 11) and np.all(cp[:, 0] <= 5), cp
 
 
 @pytest.mark.timeout(600)
@@ -228,8 +228,9 @@ def test_two_ranks_with_the_in_stream_peer_allreduce(tmp_path):
     cp = np.load(str(tmp_path / "counts_peer_0.npy"))
     ch = np.load(str(tmp_path / "counts_host_0.npy"))
     assert np.all(cp[:, 1] == 11) and np.all(ch[:, 1] == 0)          # gradient + cg_iters products, every iteration
-    assert np.all(cp[:, 0] <= 6), cp                                   # statistics, normal equations, 1-3 loss reads ...
-    assert np.all(ch[:, 0] == cp[:, 0] + 11), (ch, cp)
+    assert np.all(cp[:, 0] <= 5), cp                    # [statistics | normal equations], the gradient's loss sums, 2-3 candidates
+    # the host-backend run: ten products + the gradient, which there shares ONE all-gather with its loss sums (round 5)
+    assert np.all(ch[:, 0] == cp[:, 0] + 10), (ch, cp)
 
 
 def _wide_worker(rank, world, port, outdir):
