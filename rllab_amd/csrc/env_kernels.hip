@@ -201,7 +201,7 @@ vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length
 // matrix instructions instead of ~(DO*H + H*H + H*DA) VALU FMAs + LDS weight reads per lane --
 // with a single wavefront per SIMD the rollout is bound by instruction issue, so the policy's
 // share of the step shrinks by the ratio of those counts.
-template <class Env, int H>
+template <class Env, int H, bool ACTS = false>
 struct RolloutPolicy {
     using N = Net<Env::OBS, Env::ACT, H>;
     static constexpr int XROWS = 2 * N::KS0;                       // inputs + bias row + zero padding
@@ -255,7 +255,8 @@ struct RolloutPolicy {
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int m = 0; m < KS0; ++m) acc = mfma(fa0[(t * KS0 + m) * WV + lane], xb[m], acc);
-                act_frag(h0[t], acc, act0);
+                if constexpr (ACTS) act_frag(h0[t], acc, act0);
+                else act_frag(h0[t], acc, 0);
             }
 #pragma unroll
             for (int t = 0; t < HT; ++t) {
@@ -264,7 +265,8 @@ struct RolloutPolicy {
                 for (int r = 0; r < 16; ++r) acc[r] = tail[T_B1 + 32 * t + frag_unit(r, 0) + 4 * lh];
 #pragma unroll
                 for (int m = 0; m < KS1; ++m) acc = mfma(fa1[(t * KS1 + m) * WV + lane], h0[m / 16][m % 16], acc);
-                act_frag(h1[t], acc, act1);
+                if constexpr (ACTS) act_frag(h1[t], acc, act1);
+                else act_frag(h1[t], acc, 0);
             }
 #pragma unroll
             for (int k = 0; k < DA; ++k) {
@@ -326,7 +328,7 @@ __device__ __forceinline__ void group_sum2(float v0, float v1, float& s0, float&
     swap32(q, q, s0, s1);            // low half everywhere, high half everywhere
 }
 
-template <class Env, int H>
+template <class Env, int H, bool ACTS = false>
 struct RolloutPolicy16 {
     using N = Net<Env::OBS, Env::ACT, H>;
     static constexpr int DO = Env::OBS, DA = Env::ACT;
@@ -391,7 +393,7 @@ struct RolloutPolicy16 {
 #pragma unroll
             for (int m = 0; m < KS0; ++m) acc = mfma16(a0[t][m], xb[m], acc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h0[t][j] = act_one(acc[j], act0);
+            for (int j = 0; j < 4; ++j) h0[t][j] = ACTS ? act_one(acc[j], act0) : ftanh(acc[j]);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -401,7 +403,7 @@ struct RolloutPolicy16 {
 #pragma unroll
             for (int s_ = 0; s_ < KS1; ++s_) acc = mfma16(a1[t][s_], h0[s_ / 4][s_ % 4], acc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h1[t][j] = act_one(acc[j], act1);
+            for (int j = 0; j < 4; ++j) h1[t][j] = ACTS ? act_one(acc[j], act1) : ftanh(acc[j]);
         }
         float pm[DA];
 #pragma unroll
@@ -949,17 +951,19 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
     }
 }
 
-template <class Env, int H0, int H1, int EPW>
+// ACTS = false: tanh layers, the instruction stream of every earlier round; true: the hidden activations are taken from
+// RolloutDev.act0 / act1 at run time (rectify layers, the identity layer of a one-hidden-layer policy)
+template <class Env, int H0, int H1, int EPW, bool ACTS = false>
 __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(RolloutDev a) {
     static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
     static_assert(EPW == 64 || EPW == 16, "64 (env per lane) or 16 (four replicas)");
-    using Pol = typename std::conditional<EPW == 16, RolloutPolicy16<Env, H0>, RolloutPolicy<Env, H0>>::type;
+    using Pol = typename std::conditional<EPW == 16, RolloutPolicy16<Env, H0, ACTS>, RolloutPolicy<Env, H0, ACTS>>::type;
     Pol pol;
     if constexpr (EPW == 16) {
         pol.init(a.theta);
         pol.act0 = a.act0; pol.act1 = a.act1;
     } else {
-        __shared__ __attribute__((aligned(16))) float smem[RolloutPolicy<Env, H0>::LDS_FLOATS];
+        __shared__ __attribute__((aligned(16))) float smem[RolloutPolicy<Env, H0, ACTS>::LDS_FLOATS];
         pol.init(smem, a.theta);
         pol.act0 = a.act0; pol.act1 = a.act1;
     }
@@ -1213,9 +1217,9 @@ __device__ __forceinline__ void swimmer_quad_body(const RolloutDev& a, const Pol
     }
 }
 
-template <int H>
+template <int H, bool ACTS = false>
 __global__ void __launch_bounds__(LANE_TPB) rollout_swimmer_quad_kernel(RolloutDev a) {
-    RolloutPolicy16<Swimmer, H> pol;
+    RolloutPolicy16<Swimmer, H, ACTS> pol;
     pol.init(a.theta);
     pol.act0 = a.act0; pol.act1 = a.act1;
     swimmer_quad_body(a, pol);
@@ -1453,9 +1457,9 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
     }
 }
 
-template <class Env, int H>
+template <class Env, int H, bool ACTS = false>
 __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_kernel(RolloutDev a) {
-    RolloutPolicy16<Env, H> pol;
+    RolloutPolicy16<Env, H, ACTS> pol;
     pol.init(a.theta);
     pol.act0 = a.act0; pol.act1 = a.act1;
     two_leg_quad_body<Env>(a, pol);
@@ -1543,7 +1547,7 @@ __device__ __forceinline__ void wave_totals_uniform(float* v) {
     for (int k = 0; k < N; ++k) v[k] = lane_bcast(v[k], 63);
 }
 
-template <class Env, int H>
+template <class Env, int H, bool ACTS = false>
 struct RolloutPolicyLane {
     using N = Net<Env::OBS, Env::ACT, H>;
     static constexpr int DO = Env::OBS, DA = Env::ACT;
@@ -1595,10 +1599,10 @@ struct RolloutPolicyLane {
 #pragma unroll
         for (int k = 0; k < DOP; k += 2)
             acc = __builtin_elementwise_fma((rl_f32x2){w0[k], w0[k + 1]}, (rl_f32x2){o[k], k + 1 < DO ? o[k + 1] : 0.0f}, acc);
-        const float h0 = act_one(acc[0] + acc[1], act0);
+        const float h0 = ACTS ? act_one(acc[0] + acc[1], act0) : ftanh(acc[0] + acc[1]);
         if (lane < H) hbuf[lane] = h0;
         wave_sync();
-        const float h1 = act_one(b1 + dot_row(w1), act1);
+        const float h1 = ACTS ? act_one(b1 + dot_row(w1), act1) : ftanh(b1 + dot_row(w1));
         wave_sync();                                  // (the reads of h0 are done before the next step's write)
         // output layer: unit u's contribution to every action from its own lane, summed over the lanes
         float p[DA];
@@ -1641,11 +1645,11 @@ __device__ __forceinline__ float lane_pick(const float* v, int lane) {
     else return l3[0];
 }
 
-template <class Env, int H>
+template <class Env, int H, bool ACTS = false>
 __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutDev a) {
     using Legs = typename Env::Legs;
     __shared__ __attribute__((aligned(16))) float hrows[LANE_TPB / 64][H];
-    RolloutPolicyLane<Env, H> pol;
+    RolloutPolicyLane<Env, H, ACTS> pol;
     pol.init(a.theta, hrows[threadIdx.x >> 6]);
     pol.act0 = a.act0; pol.act1 = a.act1;
 
@@ -2097,6 +2101,7 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     a.log_stds = g->log_stds;
     a.act0 = layer_act(RL_ACT_TANH, g->layer_activations, 0);
     a.act1 = layer_act(RL_ACT_TANH, g->layer_activations, 1);
+    const bool acts = a.act0 != RL_ACT_TANH || a.act1 != RL_ACT_TANH;     // the run-time-activation instantiations
     const dim3 grid(pl.workgroups), block(64 * pl.wavefronts_per_workgroup);
     const size_t lds = (size_t)pl.lds_bytes;
     const int H = g->hidden0, epw = pl.envs_per_wavefront;
@@ -2117,10 +2122,13 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             break;
         }
         case RL_ROLLOUT_GENERIC:
-            if (H == 32 && epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 16>), grid, block, 0, st, a);
-            else if (H == 32) hipLaunchKernelGGL((rollout_kernel<Env, 32, 32, 64>), grid, block, 0, st, a);
-            else if (epw == 16) hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 16>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((rollout_kernel<Env, 64, 64, 64>), grid, block, 0, st, a);
+#define RL_GEN(HH, EE) do { if (acts) hipLaunchKernelGGL((rollout_kernel<Env, HH, HH, EE, true>), grid, block, 0, st, a); \
+                            else hipLaunchKernelGGL((rollout_kernel<Env, HH, HH, EE, false>), grid, block, 0, st, a); } while (0)
+            if (H == 32 && epw == 16) RL_GEN(32, 16);
+            else if (H == 32) RL_GEN(32, 64);
+            else if (epw == 16) RL_GEN(64, 16);
+            else RL_GEN(64, 64);
+#undef RL_GEN
             break;
         case RL_ROLLOUT_WIDE: {
             static bool a16 = false, a64 = false;
@@ -2136,8 +2144,10 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
         default:
             if constexpr (std::is_same<Env, Swimmer>::value) {
                 if (pl.kernel == RL_ROLLOUT_SWIMMER_QUAD) {
-                    if (H == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32>), grid, block, 0, st, a);
-                    else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64>), grid, block, 0, st, a);
+                    if (H == 32 && !acts) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32, false>), grid, block, 0, st, a);
+                    else if (H == 32) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<32, true>), grid, block, 0, st, a);
+                    else if (!acts) hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64, false>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((rollout_swimmer_quad_kernel<64, true>), grid, block, 0, st, a);
                     break;
                 }
                 if (pl.kernel == RL_ROLLOUT_SWIMMER_QUAD_COOP) {
@@ -2155,13 +2165,17 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             }
             if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
                 if (pl.kernel == RL_ROLLOUT_TWO_LEG_WAVE) {
-                    if (H == 32) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 32>), grid, block, 0, st, a);
-                    else hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 64>), grid, block, 0, st, a);
+                    if (H == 32 && !acts) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 32, false>), grid, block, 0, st, a);
+                    else if (H == 32) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 32, true>), grid, block, 0, st, a);
+                    else if (!acts) hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 64, false>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((rollout_two_leg_wave_kernel<Env, 64, true>), grid, block, 0, st, a);
                     break;
                 }
                 if (pl.kernel == RL_ROLLOUT_TWO_LEG_QUAD) {
-                    if (H == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32>), grid, block, 0, st, a);
-                    else hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64>), grid, block, 0, st, a);
+                    if (H == 32 && !acts) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32, false>), grid, block, 0, st, a);
+                    else if (H == 32) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 32, true>), grid, block, 0, st, a);
+                    else if (!acts) hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64, false>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((rollout_two_leg_quad_kernel<Env, 64, true>), grid, block, 0, st, a);
                     break;
                 }
                 if (pl.kernel == RL_ROLLOUT_TWO_LEG_QUAD_WIDE) {

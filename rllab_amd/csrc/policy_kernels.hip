@@ -106,7 +106,10 @@ template <bool RELU> __device__ __forceinline__ float act_dz(float h) {
     return RELU ? (h > 0.0f ? 1.0f : 0.0f) : (1.0f - h * h);
 }
 
-template <class N, int MODE, bool CACHE, bool RELU = false>
+// ACTS = false: tanh layers (RELU: the regressors' compile-time rectify) -- the instruction stream of every earlier round;
+// ACTS = true: the hidden activations are PolicyBatch.act0 / act1 at run time (rectify policies, the identity layer of a
+// one-hidden-layer policy)
+template <class N, int MODE, bool CACHE, bool RELU = false, bool ACTS = false>
 __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
     constexpr int WAVES = N::WAVES;
     static_assert(!CACHE || MODE == MODE_GRAD || MODE == MODE_FVP, "activation cache: grad writes, FVP reads");
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(Poli
     }
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
     const int lj = lane & 31, lh = lane >> 5;
-    const int c0 = RELU ? 1 : a.act0, c1 = RELU ? 1 : a.act1;      // hidden activations (wave-uniform codes)
+    const int c0 = RELU ? 1 : (ACTS ? a.act0 : 0), c1 = RELU ? 1 : (ACTS ? a.act1 : 0);   // hidden activations (wave-uniform codes)
     float* const fa0 = smem + S::A0;
     float* const fa1 = smem + S::A1;
     float* const fa1t = smem + S::A1T;
@@ -814,7 +817,7 @@ struct PlaneArgs {                 // MODE_OUT / MODE_OUT_TAN / MODE_BWD
     float* out_dmean = nullptr;
 };
 
-template <class N, int MODE, bool CACHE = false, bool RELU = false>
+template <class N, int MODE, bool CACHE = false, bool RELU = false, bool ACTS = false>
 static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspace, size_t workspace_bytes,
                        double* out, hipStream_t st, double* loss_out = nullptr, const CgArgs* cg = nullptr,
                        const PlaneArgs* planes = nullptr) {
@@ -853,7 +856,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     a.partial = (float*)workspace;
     a.partial_loss = (MODE == MODE_LOSS) ? (double*)workspace
                                          : (with_loss ? (double*)((char*)workspace + row_bytes) : nullptr);
-    auto kern = policy_pass_kernel<N, MODE, CACHE, RELU>;
+    auto kern = policy_pass_kernel<N, MODE, CACHE, RELU, ACTS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -879,20 +882,20 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     return check_launch("policy reduce kernel");
 }
 
-template <class N>
+template <class N, bool ACTS = false>
 static int dispatch_mode(int mode, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes,
                          double* out, hipStream_t st, double* loss_out, const CgArgs* cg = nullptr) {
     switch (mode) {
-        case MODE_LOSS: return launch_pass<N, MODE_LOSS>(g, vec, ws, ws_bytes, out, st);
+        case MODE_LOSS: return launch_pass<N, MODE_LOSS, false, false, ACTS>(g, vec, ws, ws_bytes, out, st);
         case MODE_GRAD:
             if constexpr (N::ACT_CACHE)
-                if (g->activations) return launch_pass<N, MODE_GRAD, true>(g, vec, ws, ws_bytes, out, st, loss_out);
-            return launch_pass<N, MODE_GRAD>(g, vec, ws, ws_bytes, out, st, loss_out);
+                if (g->activations) return launch_pass<N, MODE_GRAD, true, false, ACTS>(g, vec, ws, ws_bytes, out, st, loss_out);
+            return launch_pass<N, MODE_GRAD, false, false, ACTS>(g, vec, ws, ws_bytes, out, st, loss_out);
         case MODE_FVP:
             if constexpr (N::ACT_CACHE)
-                if (g->activations) return launch_pass<N, MODE_FVP, true>(g, vec, ws, ws_bytes, out, st, nullptr, cg);
-            return launch_pass<N, MODE_FVP>(g, vec, ws, ws_bytes, out, st, nullptr, cg);
-        case MODE_VPG: return launch_pass<N, MODE_VPG>(g, vec, ws, ws_bytes, out, st, loss_out);
+                if (g->activations) return launch_pass<N, MODE_FVP, true, false, ACTS>(g, vec, ws, ws_bytes, out, st, nullptr, cg);
+            return launch_pass<N, MODE_FVP, false, false, ACTS>(g, vec, ws, ws_bytes, out, st, nullptr, cg);
+        case MODE_VPG: return launch_pass<N, MODE_VPG, false, false, ACTS>(g, vec, ws, ws_bytes, out, st, loss_out);
     }
     return set_error(RL_ERR_ARG, "unknown policy pass mode %d", mode);
 }
@@ -994,7 +997,8 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     }
 #define NETCASE(DO, DA, H) \
     if (d == DO && k == DA && h0 == H && h1 == H) \
-        return dispatch_mode<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, loss_out, cg);
+        return all_tanh ? dispatch_mode<Net<DO, DA, H>, false>(mode, g, vec, ws, ws_bytes, out, st, loss_out, cg) \
+                        : dispatch_mode<Net<DO, DA, H>, true>(mode, g, vec, ws, ws_bytes, out, st, loss_out, cg);
     RL_NARROW_NETS(NETCASE)
 #undef NETCASE
     // anything else with tanh layers of 32 / 64 / 128 units: the cooperative kernels

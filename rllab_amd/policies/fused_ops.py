@@ -282,7 +282,12 @@ class FusedGaussianMLPOps(object):
                                               _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
         finally:
             b.activations = None
-        return D.update_sum_(out)
+        out = D.update_sum_(out)
+        if getattr(self.layout, "identity_layer", False):
+            # the identity second layer of a one-hidden-layer policy is a CONSTANT of the kernel copy: without this its
+            # (non-zero) Fisher rows would pull conjugate gradient out of the real parameters' subspace
+            out.mul_(self.layout.real_mask)
+        return out
 
     def fvp_variant(self, inputs):
         """Which arithmetic ``rl_policy_fvp`` would run the next product of this batch in (rl_policy_fvp_variant): 0 = f32
@@ -313,7 +318,8 @@ class FusedGaussianMLPOps(object):
         release / acquire, which on an 8-XCD part writes back and invalidates the per-XCD L2s -- more than the
         launch boundary it saves.  Kept as a tested alternative, off by default."""
         n = self.n_kernel
-        if D.is_distributed() or self.wide_kernels or not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
+        if D.is_distributed() or self.wide_kernels or getattr(self.layout, "identity_layer", False) or \
+                not getattr(self, "fuse_cg", bool(os.environ.get("RLLAB_FUSE_CG"))):
             for _ in range(cg_iters):
                 self._fvp_into(b, ws, p32, z, inputs)
                 _lib.check(_lib.lib.rl_cg_step(n, _lib.ptr(z), float(reg_coeff), float(residual_tol), _lib.ptr(x),

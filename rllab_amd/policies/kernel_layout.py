@@ -161,6 +161,10 @@ class KernelLayout(object):
         self._theta = torch.zeros(self.P_pad, dtype=torch.float32, device=dev)
         self._theta[oW1 + torch.arange(H, device=dev) * (H + 1)] = 1.0        # W1 = I
         self._tag = None
+        # 1 at the real parameters' positions: the constants W1 = I, b1 = 0 are not parameters, but the kernels differentiate
+        # with respect to every entry of their vector -- products and gradients are confined to the real subspace with this
+        self.real_mask = torch.zeros(self.P_pad, dtype=torch.float64, device=dev)
+        self.real_mask[self.index] = 1.0
 
     @property
     def layer_activations(self):

@@ -40,10 +40,34 @@ def test_ranks_as_streams_sum_in_rank_order(world, n, monkeypatch):
     max_n = 1 << 16
     boxes, table = _mailboxes(_lib, world, max_n)
     rng = np.random.RandomState(world * 1000 + n)
-    streams = [torch.cuda.Stream() for _ in range(world)]
     err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    # The launches of a world must be RESIDENT together.  HIP maps a process's streams onto a few hardware queues in
+    # creation order; which queue a new stream gets depends on how many streams the tests before this one created, and
+    # two ranks on ONE queue serialise (rank 0 then waits for a peer that cannot start).  Probe for a set of streams
+    # whose kernels do overlap -- a tiny two-way reduction per candidate set -- before the real runs.
+    streams, keep = None, []
+    for attempt in range(6):
+        cand = [torch.cuda.Stream() for _ in range(world)]
+        keep += cand
+        err.zero_()
+        probe = [torch.ones(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        torch.cuda.synchronize()
+        monkeypatch.setenv("RLLAB_PEER_SPIN_LIMIT", "200000")
+        for r in range(world):
+            with torch.cuda.stream(cand[r]):
+                _lib.check(_lib.lib.rl_peer_allreduce_sum(1, _lib.ptr(probe[r]), r, world, table, max_n, 100 + attempt,
+                                                          _lib.ptr(err), _lib.peer_spin_limit(), _lib.stream_ptr()),
+                           "rl_peer_allreduce_sum")
+        torch.cuda.synchronize()
+        if int(err.item()) == 0 and all(float(p_[0]) == world for p_ in probe):
+            streams = cand
+            break
+        keep.append(torch.cuda.Stream())                     # shift the round-robin by one and try again
+    assert streams is not None, "no set of %d streams of this process runs concurrently" % world
+    monkeypatch.setenv("RLLAB_PEER_SPIN_LIMIT", "4000000")
+    err.zero_()
     try:
-        for seq in range(1, 6):                              # both slots, several times over
+        for seq in range(200, 205):                          # both slots, several times over
             rows = rng.randn(world, n) * 10.0 ** rng.randint(-3, 4, size=(world, 1))
             xs = [torch.as_tensor(rows[r], device="cuda") for r in range(world)]
             torch.cuda.synchronize()

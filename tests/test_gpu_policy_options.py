@@ -381,6 +381,13 @@ def test_update_kernels_with_one_hidden_layer_or_rectify_layers(do, da, hidden, 
     assert ops.fvp_variant(inp0) == 0                           # not the split kernels: they evaluate tanh layers
     hv_c = ops.fvp(inp0, v)
     assert torch.equal(hv_c, hv)
+    # the device CG (products in the kernels' vector, where a one-hidden-layer policy's identity layer W1 = I sits as
+    # constants) == krylov.cg on the same product in the REAL parameter space: the constants' Fisher rows stay out of it
+    from rllab_amd.misc import krylov
+    g = ops.loss_grad(inp0)
+    x_dev, _ = ops.cg(inp0, g, 10, 1e-5)
+    x_ref = krylov.cg(lambda p_: ops.fvp(inp0, p_) + 1e-5 * p_, g, cg_iters=10)
+    assert float((x_dev - x_ref).abs().max()) <= 1e-6 * float(x_ref.abs().max()), float((x_dev - x_ref).abs().max())
 
 
 def test_policies_that_still_leave_the_kernels_say_why():

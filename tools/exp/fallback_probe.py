@@ -15,6 +15,9 @@ logger.set_quiet(True)
 CONFIGS = [
     ("default (32, 32)", dict()),
     ("hidden (64,)", dict(hidden_sizes=(64,))),
+    ("hidden (32,)", dict(hidden_sizes=(32,))),
+    ("hidden (20,) relu", dict(hidden_sizes=(20,), hidden_nonlinearity="relu")),
+    ("hidden (100,)", dict(hidden_sizes=(100,))),
     ("hidden (50, 50)", dict(hidden_sizes=(50, 50))),
     ("hidden (16, 16, 16)", dict(hidden_sizes=(16, 16, 16))),
     ("hidden (200, 100)", dict(hidden_sizes=(200, 100))),
@@ -36,6 +39,7 @@ for name, kw in CONFIGS:
                     max_path_length=100, n_itr=3, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=512))
         algo.start_worker(); algo.init_opt()
         fr = algo.sampler._takes_fused_rollout(policy)
+        why = algo.sampler.sampling_path(policy)[1]
         fu = type(getattr(algo.optimizer, "_fused", None)).__name__
         ts = []
         for itr in range(3):
@@ -43,6 +47,7 @@ for name, kw in CONFIGS:
             paths = algo.sampler.obtain_samples(itr); sd = algo.sampler.process_samples(itr, paths)
             algo.log_diagnostics(paths); algo.optimize_policy(itr, sd); torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3); logger.dump_tabular()
-        print("%-32s fused rollout %-5s fused update %-22s iteration %.1f ms" % (name, fr, fu, min(ts)), flush=True)
+        print("%-32s fused rollout %-5s fused update %-22s iteration %.1f ms%s" % (
+            name, fr, fu, min(ts), "" if why is None else "   [" + why[:90] + "]"), flush=True)
     except Exception as e:
         print("%-32s ERROR %s: %s" % (name, type(e).__name__, str(e)[:150]), flush=True)
