@@ -51,7 +51,8 @@ const char* rl_last_error(void);
  * shape of the two kernel families as a function on planes), RL_CFG_LIMIT_MUJOCO, rl_policy_fvp_variant's value 2.
  * 12: rl_policy_batch.gate + rl_line_search_decide (the line search decided on the device); rl_launch_opts (rl_rollout_args.opts,
  * rl_policy_batch.opts, a trailing `variant` / `spin_limit` argument of rl_lfb_normal_eq / rl_peer_allreduce_sum) in place
- * of the library's getenv reads; rl_rollout_plan_query; per-layer hidden activations (layer_activations, RL_ACT_IDENTITY). */
+ * of the library's getenv reads; rl_rollout_plan_query; per-layer hidden activations (layer_activations, RL_ACT_IDENTITY);
+ * rl_running_norm (NormalizedEnv's running observation / reward normalisation inside the fused rollout). */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -167,6 +168,24 @@ int rl_vecenv_step(int kind, int n, int normalize, float scale_reward, int max_p
                    int env_offset, const rl_env_cfg* cfg, float* obs, float* reward, uint8_t* done,
                    void* stream);
 
+/* NormalizedEnv(normalize_obs=True / normalize_reward=True) inside the fused rollout (rllab/envs/normalized_env.py:33-49,
+ * 78-92): per env copy the running estimates
+ *     mean <- (1 - alpha) mean + alpha x;   var <- (1 - alpha) var + alpha (x - mean)^2        (float64, the updated mean)
+ * and the whitened values  (x - mean) / (sqrt(var) + 1e-8)  /  reward / (sqrt(var_r) + 1e-8)  that the policy sees and the
+ * trajectory records.  Update order of the reference's executor over n NormalizedEnv copies: every step's observation --
+ * the TERMINAL one included -- feeds its copy's estimate, a finished copy is then reset and the reset observation feeds
+ * it once more and is returned whitened; the reward estimate is fed once per step, the scale_reward factor applies
+ * after the normalisation.  The arrays are state, read and written in place (they persist over rollouts and are
+ * shared with the per-transition path's NormalizingVecEnv).  Takes the generic rollout kernels. */
+typedef struct rl_running_norm {
+    double* obs_mean;          /* double[obs_dim][n]   (ignored unless normalize_obs) */
+    double* obs_var;           /* double[obs_dim][n] */
+    double* reward_mean;       /* double[n]            (ignored unless normalize_reward) */
+    double* reward_var;        /* double[n] */
+    double obs_alpha, reward_alpha;
+    int32_t normalize_obs, normalize_reward;
+} rl_running_norm;
+
 /* Launch-shape requests.  Every field: 0 = the library's own rule (what every production call passes).  The non-zero
  * values exist for A/B timing and so that the parity tests can run every launch shape against the host build; the
  * Python binding fills the struct from the RLLAB_* environment switches of INTEGRATION.md section 4 (rllab_amd/_lib.py::
@@ -230,6 +249,7 @@ typedef struct rl_rollout_args {
     int32_t layer_activations;/* hidden activations of the (mean) network per layer, as rl_policy_batch.layer_activations:
                                  0 = tanh layers; rectify / identity layers on the equal-width (32,32) / (64,64) kernels */
     const rl_launch_opts* opts;   /* host; NULL = every launch rule the library's own */
+    const rl_running_norm* norm;  /* host; NULL = no running normalisation (NormalizedEnv's defaults) */
 } rl_rollout_args;
 
 int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);

@@ -63,7 +63,7 @@ class RolloutArgs(ctypes.Structure):
         ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p), ("cfg", ctypes.POINTER(EnvCfg)),
         ("theta_std", ctypes.c_void_p), ("log_stds", ctypes.c_void_p), ("std_hidden0", ctypes.c_int32),
         ("std_hidden1", ctypes.c_int32), ("std_hidden2", ctypes.c_int32), ("layer_activations", ctypes.c_int32),
-        ("opts", ctypes.c_void_p),
+        ("opts", ctypes.c_void_p), ("norm", ctypes.c_void_p),
     ]
 
 
@@ -98,6 +98,15 @@ class LaunchOpts(ctypes.Structure):
         ("swimmer_coop", ctypes.c_int32), ("two_leg_lane_kernel", ctypes.c_int32), ("two_leg_wave_kernel", ctypes.c_int32),
         ("fvp_split", ctypes.c_int32), ("fvp_split_wps", ctypes.c_int32), ("lfb_valu", ctypes.c_int32),
         ("reserved", ctypes.c_int32 * 7),
+    ]
+
+
+class RunningNorm(ctypes.Structure):
+    """Mirror of ``rl_running_norm``: NormalizedEnv's running observation / reward normalisation inside the fused rollout."""
+    _fields_ = [
+        ("obs_mean", ctypes.c_void_p), ("obs_var", ctypes.c_void_p), ("reward_mean", ctypes.c_void_p),
+        ("reward_var", ctypes.c_void_p), ("obs_alpha", ctypes.c_double), ("reward_alpha", ctypes.c_double),
+        ("normalize_obs", ctypes.c_int32), ("normalize_reward", ctypes.c_int32),
     ]
 
 
@@ -261,18 +270,25 @@ def env_query(kind):
                 reset_is_normal=bool(nrm.value))
 
 
-def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0, layer_activations=0):
+def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0, layer_activations=0, norm=None,
+                 obs_noise=0.0):
     """``RolloutPlan`` of a fused rollout of these sizes under the current launch options (rl_rollout_plan_query), or None
     when the library has no kernel for it (the reason is then in ``lib.rl_last_error()``)."""
     a = RolloutArgs(kind=kind, n_envs=int(n_envs), horizon=int(horizon), hidden0=hidden3[0], hidden1=hidden3[1],
                     hidden2=hidden3[2], std_hidden0=std_hidden3[0], std_hidden1=std_hidden3[1], std_hidden2=std_hidden3[2],
                     layer_activations=int(layer_activations))
     cfg = None
-    if cfg_flags:
+    if cfg_flags or obs_noise:
         cfg = EnvCfg()
         check(lib.rl_env_default_cfg(kind, ctypes.byref(cfg)), "rl_env_default_cfg")
         cfg.flags = int(cfg_flags)
+        cfg.obs_noise = float(obs_noise)
         a.cfg = ctypes.pointer(cfg)
+    nrm = None
+    if norm is not None:                      # (normalize_obs, normalize_reward): only the flags are read by the query
+        nrm = RunningNorm(normalize_obs=int(bool(norm[0])), normalize_reward=int(bool(norm[1])))
+        a.norm = ctypes.addressof(nrm)
+        a.reset_at_start = 1
     if tuple(std_hidden3) != (0, 0, 0):
         a.theta_std = 1          # (only its being non-NULL is read by the query: a log-std network is present)
         a.log_stds = 1

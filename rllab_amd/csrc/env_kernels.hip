@@ -790,6 +790,10 @@ struct RolloutDev {
     const float* obs_noise_z;   // [T+1][Do][n]: slice 0 = the first observation, slice t + 1 = the one after step t
     float* log_stds;            // [Da][T][n] agent_info "log_std" of a policy with a log-std NETWORK (else unused)
     int act0, act1;             // hidden activations of the equal-width (32,32) / (64,64) policies (rl_activation codes)
+    // rl_running_norm (NORM instantiations of the generic rollout): per-env running estimates, in place
+    double* nobs_mean; double* nobs_var; double* nrew_mean; double* nrew_var;
+    double obs_alpha, rew_alpha;
+    int norm_obs, norm_rew;
 };
 
 // A policy whose log-std is a second network on the observation (GaussianMLPPolicy(adaptive_std=True) / std_network=...,
@@ -844,7 +848,10 @@ __device__ __forceinline__ void store_planes(V* row_ptr, size_t plane, uint32_t&
     }
 }
 
-template <class Env, class Pol, int EPW>
+// NORM: NormalizedEnv(normalize_obs / normalize_reward) -- the env copy's running estimates live in registers for the
+// rollout (float64: 2 Do + 2 values), are fed and applied in the reference's order (rl_running_norm in the header) and go
+// back to their arrays at the end.  The four replicas of a 16-envs-per-wavefront env carry identical copies.
+template <class Env, class Pol, int EPW, bool NORM = false>
 __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol) {
     const int n = a.n, T = a.T;
     // every lane stays alive (the matrix instructions and the cross-lane exchanges need the whole
@@ -874,6 +881,31 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
     Env::template observe<float>(s, o);
     const size_t obs_z_slice = (size_t)Env::OBS * n;
     observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
+    // running normalisation (normalized_env.py:33-49): feed the estimate with an observation, optionally whiten it
+    double nm[NORM ? Env::OBS : 1], nv[NORM ? Env::OBS : 1], rm = 0.0, rv = 1.0;
+    auto feed_obs = [&](float* ob, bool whiten) {
+        if constexpr (NORM) {
+            if (a.norm_obs) {
+                const double al = a.obs_alpha;
+#pragma unroll
+                for (int k = 0; k < Env::OBS; ++k) {
+                    const double x = (double)ob[k];
+                    nm[k] = nm[k] * (1.0 - al) + al * x;
+                    const double dlt = x - nm[k];
+                    nv[k] = nv[k] * (1.0 - al) + al * (dlt * dlt);
+                    if (whiten) ob[k] = (float)(dlt / (sqrt(nv[k]) + 1e-8));
+                }
+            }
+        }
+    };
+    if constexpr (NORM) {
+        if (a.norm_obs) {
+#pragma unroll
+            for (int k = 0; k < Env::OBS; ++k) { nm[k] = a.nobs_mean[(size_t)k * n + i]; nv[k] = a.nobs_var[(size_t)k * n + i]; }
+        }
+        if (a.norm_rew) { rm = a.nrew_mean[i]; rv = a.nrew_var[i]; }
+        feed_obs(o, true);            // reset() returns the whitened first observation
+    }
 
     uint32_t lane_f32 = (uint32_t)i * 4, lane_u8 = (uint32_t)i;      // byte offset of env i inside a row
     for (int t = 0; t < T; ++t) {
@@ -926,13 +958,25 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
                       a.step_counter + (uint64_t)t, o, r, d);
         ts += 1;
         if (a.max_path_length > 0 && ts >= a.max_path_length) d = true;
+        if constexpr (NORM) {
+            if (a.norm_rew) {             // reward / (sqrt(var) + 1e-8) after the update, then the scale (:85-92)
+                const double al = a.rew_alpha, x = (double)r;
+                rm = rm * (1.0 - al) + al * x;
+                const double dlt = x - rm;
+                rv = rv * (1.0 - al) + al * (dlt * dlt);
+                r = (float)((x / (sqrt(rv) + 1e-8)) * (double)a.scale_reward);
+            } else {
+                r = r * a.scale_reward;
+            }
+        }
         if (live) {
-            const float rs = r * a.scale_reward;
+            const float rs = NORM ? r : r * a.scale_reward;
             const uint8_t db = d ? 1 : 0;
             store_planes<1>(a.rewards + row, plane, lane_f32, &rs);
             store_planes<1>(a.dones + row, plane, lane_u8, &db);
         }
         if (d) {
+            if constexpr (NORM) feed_obs(o, false);      // the terminal observation feeds the estimate, nobody sees it
             const float* dr = a.reset_draws ? a.reset_draws + (size_t)(t + 1) * draws_slice : nullptr;
             reset_one<Env>(s, dr, n, i, a.seed, env_global, a.step_counter + (uint64_t)t + 1, a.cfg);
             Env::template observe<float>(s, o);
@@ -940,6 +984,16 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
         }
         observed<Env>(o, a.cfg, a.obs_noise_z ? a.obs_noise_z + (size_t)(t + 1) * obs_z_slice : nullptr, n, i, a.seed,
                       env_global, a.step_counter + (uint64_t)t + 1);
+        if constexpr (NORM) feed_obs(o, true);
+    }
+    if constexpr (NORM) {
+        if (live) {
+            if (a.norm_obs) {
+#pragma unroll
+                for (int k = 0; k < Env::OBS; ++k) { a.nobs_mean[(size_t)k * n + i] = nm[k]; a.nobs_var[(size_t)k * n + i] = nv[k]; }
+            }
+            if (a.norm_rew) { a.nrew_mean[i] = rm; a.nrew_var[i] = rv; }
+        }
     }
     if (live) {
         store_state<Env>(a.state, n, i, s);
@@ -953,7 +1007,7 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
 
 // ACTS = false: tanh layers, the instruction stream of every earlier round; true: the hidden activations are taken from
 // RolloutDev.act0 / act1 at run time (rectify layers, the identity layer of a one-hidden-layer policy)
-template <class Env, int H0, int H1, int EPW, bool ACTS = false>
+template <class Env, int H0, int H1, int EPW, bool ACTS = false, bool NORM = false>
 __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(RolloutDev a) {
     static_assert(H0 == H1, "the fused rollout is built for equal hidden sizes");
     static_assert(EPW == 64 || EPW == 16, "64 (env per lane) or 16 (four replicas)");
@@ -967,7 +1021,7 @@ __global__ void __launch_bounds__(EPW == 16 ? LANE_TPB : BLOCK) rollout_kernel(R
         pol.init(smem, a.theta);
         pol.act0 = a.act0; pol.act1 = a.act1;
     }
-    rollout_body<Env, Pol, EPW>(a, pol);
+    rollout_body<Env, Pol, EPW, NORM>(a, pol);
 }
 
 // the same rollout for the wide / deep policies (RolloutPolicyWide: shape at run time, weight fragments in LDS)
@@ -1968,6 +2022,23 @@ static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
     const bool small_offsets = (size_t)Env::OBS * (size_t)T * (size_t)n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
     const int epw_req = (o.rollout_epw == 16 || o.rollout_epw == 64) ? o.rollout_epw : 0;
     const int epw_generic = epw_req ? epw_req : (n <= 16 * 1024 ? 16 : 64);
+    const bool norm = g->norm != nullptr && (g->norm->normalize_obs || g->norm->normalize_reward);
+    if (norm) {
+        // running normalisation: the generic kernels of the (32,32) / (64,64) policies (the estimates ride in registers
+        // next to the env state), every env of the launch reset at its start (reset() feeds the estimate)
+        if (!equal || g->theta_std != nullptr)
+            return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: running observation / reward normalisation runs on "
+                             "the (32,32) / (64,64) kernels only (hidden %d,%d,%d)", g->hidden0, g->hidden1, g->hidden2);
+        if (!g->reset_at_start)
+            return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: running normalisation needs reset_at_start");
+        if (g->cfg && g->cfg->obs_noise != 0.0f && g->norm->normalize_obs)
+            return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: obs_noise together with normalize_obs is sampled "
+                             "through rl_vecenv_step (the terminal observation's noise draw)");
+        const int epw = epw_generic, waves = (n + epw - 1) / epw;
+        snprintf(nm, sizeof(nm), "rollout_kernel<%s, %d, %d, %d, acts, norm>", env_name(Env::KIND), g->hidden0, g->hidden1, epw);
+        plan_fill(p, RL_ROLLOUT_GENERIC, epw, waves, (epw == 16) ? lane_group_wpb(waves, o) : 1, 0, nm);
+        return RL_OK;
+    }
     if (g->theta_std != nullptr) {
         // a log-std NETWORK (adaptive_std / std_network): both networks in the kernel, log_std planes recorded
         if (!g->log_stds) return set_error(RL_ERR_ARG, "rl_rollout_gaussian_mlp: theta_std without log_stds");
@@ -2102,6 +2173,16 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     a.act0 = layer_act(RL_ACT_TANH, g->layer_activations, 0);
     a.act1 = layer_act(RL_ACT_TANH, g->layer_activations, 1);
     const bool acts = a.act0 != RL_ACT_TANH || a.act1 != RL_ACT_TANH;     // the run-time-activation instantiations
+    const bool norm = g->norm != nullptr && (g->norm->normalize_obs || g->norm->normalize_reward);
+    a.norm_obs = a.norm_rew = 0;
+    if (norm) {
+        const rl_running_norm& q = *g->norm;
+        if ((q.normalize_obs && (!q.obs_mean || !q.obs_var)) || (q.normalize_reward && (!q.reward_mean || !q.reward_var)))
+            return set_error(RL_ERR_ARG, "rl_running_norm: null estimate array");
+        a.nobs_mean = q.obs_mean; a.nobs_var = q.obs_var; a.nrew_mean = q.reward_mean; a.nrew_var = q.reward_var;
+        a.obs_alpha = q.obs_alpha; a.rew_alpha = q.reward_alpha;
+        a.norm_obs = q.normalize_obs ? 1 : 0; a.norm_rew = q.normalize_reward ? 1 : 0;
+    }
     const dim3 grid(pl.workgroups), block(64 * pl.wavefronts_per_workgroup);
     const size_t lds = (size_t)pl.lds_bytes;
     const int H = g->hidden0, epw = pl.envs_per_wavefront;
@@ -2122,7 +2203,8 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
             break;
         }
         case RL_ROLLOUT_GENERIC:
-#define RL_GEN(HH, EE) do { if (acts) hipLaunchKernelGGL((rollout_kernel<Env, HH, HH, EE, true>), grid, block, 0, st, a); \
+#define RL_GEN(HH, EE) do { if (norm) hipLaunchKernelGGL((rollout_kernel<Env, HH, HH, EE, true, true>), grid, block, 0, st, a); \
+                            else if (acts) hipLaunchKernelGGL((rollout_kernel<Env, HH, HH, EE, true>), grid, block, 0, st, a); \
                             else hipLaunchKernelGGL((rollout_kernel<Env, HH, HH, EE, false>), grid, block, 0, st, a); } while (0)
             if (H == 32 && epw == 16) RL_GEN(32, 16);
             else if (H == 32) RL_GEN(32, 64);

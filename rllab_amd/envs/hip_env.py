@@ -190,7 +190,7 @@ class HipVecEnv(object):
         net on a 20-observation env needs 172 KB and is sampled through the per-transition loop instead."""
         return self.rollout_plan(policy) is not None
 
-    def rollout_plan(self, policy, horizon=None):
+    def rollout_plan(self, policy, horizon=None, norm=None):
         """``_lib.RolloutPlan`` -- kernel, envs per wavefront, wavefronts, workgroup shape, LDS -- of ``rollout(policy, ..)``
         on this executor under the current launch options, from the launcher itself (rl_rollout_plan_query), or None
         when there is no fused kernel for the policy here."""
@@ -204,16 +204,17 @@ class HipVecEnv(object):
         # asked once per (sizes, launch options): the sampler asks before every rollout
         _lib.launch_opts()
         acts = layout.layer_activations if layout is not None else 0
-        key = (hs, hs_std, T, flags, acts, bytes(_lib._OPTS))
+        key = (hs, hs_std, T, flags, acts, norm, float(self.cfg.obs_noise), bytes(_lib._OPTS))
         cache = self.__dict__.setdefault("_plan_cache", {})
         if key not in cache:
             if len(cache) > 64:
                 cache.clear()
-            cache[key] = _lib.rollout_plan(self.kind, self.n, T, hs, hs_std, cfg_flags=flags, layer_activations=acts)
+            cache[key] = _lib.rollout_plan(self.kind, self.n, T, hs, hs_std, cfg_flags=flags, layer_activations=acts,
+                                           norm=norm, obs_noise=float(self.cfg.obs_noise))
         return cache[key]
 
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
-                obs_noise_z=None):
+                obs_noise_z=None, norm=None, scale_reward=None):
         """``horizon`` lock-step iterations of get_actions -> step -> record ->
         auto-reset in ONE launch (rl_rollout_gaussian_mlp).  Returns
         ``Trajectories``.  ``eps`` [Da, T, n] / ``reset_draws`` [T+1, R, n] / ``action_noise_z`` [T, Da, n] /
@@ -268,6 +269,18 @@ class HipVecEnv(object):
             log_stds=None if log_stds is None else log_stds.data_ptr(),
             std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2],
             layer_activations=layout.layer_activations if layout is not None else 0, opts=_lib.launch_opts())
+        if scale_reward is not None:          # NormalizingVecEnv: its outer scale (the inner executor's is 1)
+            args.scale_reward = float(scale_reward)
+        nrm = None
+        if norm is not None:
+            # NormalizedEnv(normalize_obs / normalize_reward): the wrapper's per-env running estimates (float64 device
+            # planes), fed, applied and written back by the kernel in the reference's order (rl_running_norm)
+            nrm = _lib.RunningNorm(
+                obs_mean=norm.obs_mean.data_ptr(), obs_var=norm.obs_var.data_ptr(),
+                reward_mean=norm.reward_mean.data_ptr(), reward_var=norm.reward_var.data_ptr(),
+                obs_alpha=norm.obs_alpha, reward_alpha=norm.reward_alpha,
+                normalize_obs=int(norm.normalize_obs), normalize_reward=int(norm.normalize_reward))
+            args.norm = ctypes.addressof(nrm)
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1

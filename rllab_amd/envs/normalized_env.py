@@ -175,8 +175,24 @@ class NormalizingVecEnv(object):
     def num_envs(self):
         return self.inner.n
 
-    def rollout(self, *args, **kwargs):
-        raise NotImplementedError("running obs / reward normalisation: sample through reset() / step()")
+    def takes_rollout_of(self, policy):
+        """The fused rollout under running normalisation: the generic kernels of the (32,32) / (64,64) policies carry the
+        estimates in registers (rl_running_norm); everything else is sampled through reset() / step()."""
+        if self.inner.position_ids is not None:
+            return False
+        return self.inner.rollout_plan(policy, norm=(self.normalize_obs, self.normalize_reward)) is not None
+
+    def rollout_plan(self, policy, horizon=None):
+        return self.inner.rollout_plan(policy, horizon, norm=(self.normalize_obs, self.normalize_reward))
+
+    def rollout(self, policy, horizon, reset_at_start=True, **kwargs):
+        """One launch for the whole horizon (HipVecEnv.rollout) with this wrapper's running estimates fed, applied and
+        written back by the kernel in the reference's order: observations and rewards of the returned batch are the
+        whitened ones, as ``step`` returns them."""
+        if not reset_at_start:
+            raise NotImplementedError("running normalisation: the fused rollout resets every env at its start")
+        return self.inner.rollout(policy, horizon, reset_at_start=True, norm=self, scale_reward=self.scale_reward_outer,
+                                  **kwargs)
 
     def write_back(self, env):
         """Env copy 0's estimates -> the NormalizedEnv that gets pickled (its ``_obs_mean`` / ``_obs_var`` state)."""

@@ -63,8 +63,8 @@ class VectorizedSampler(BaseSampler):
         if ve is None:
             return "none (no executor yet)", None
         if not getattr(ve, "graphable", True):
-            why = "the env wrapper keeps running observation / reward estimates (NormalizedEnv(normalize_obs / " \
-                  "normalize_reward)) that change every step"
+            why = "NormalizedEnv(normalize_obs / normalize_reward): the running estimates ride in the fused rollout of the " \
+                  "(32, 32) / (64, 64) policies only (and not together with obs_noise)"
         elif ve.position_ids is not None:
             why = "Box2DEnv(position_only=True): the fused rollout feeds the policy the full observation"
         else:
@@ -98,7 +98,7 @@ class VectorizedSampler(BaseSampler):
     def _takes_fused_rollout(self, policy):
         """True when ``obtain_samples`` is ONE asynchronous launch for this policy (the fused rollout kernels)."""
         ve = self.vec_env
-        if ve is None or ve.position_ids is not None or not getattr(ve, "graphable", True):
+        if ve is None or ve.position_ids is not None:
             return False
         if hasattr(ve, "takes_rollout_of"):
             # the kernels' own answer: a layout exists AND its weight fragments fit the LDS of a CU on this env

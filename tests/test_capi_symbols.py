@@ -154,7 +154,7 @@ def test_integration_md_structs_are_the_library_structs():
               "i32f * 7": ctypes.c_int32 * 7, "ctypes.c_char * 96": ctypes.c_char * 96}
     printed = _md_struct_fields(text)
     want = {"EnvCfg": _lib.EnvCfg, "RolloutArgs": _lib.RolloutArgs, "PolicyBatch": _lib.PolicyBatch,
-            "LaunchOpts": _lib.LaunchOpts, "RolloutPlan": _lib.RolloutPlan}
+            "LaunchOpts": _lib.LaunchOpts, "RolloutPlan": _lib.RolloutPlan, "RunningNorm": _lib.RunningNorm}
     assert set(printed) == set(want), sorted(printed)
     for name, cls in want.items():
         got = [(f, types_[t.strip()]) for f, t in printed[name]]
@@ -212,7 +212,8 @@ def test_struct_offsets_against_the_compiled_header(tmp_path):
     import subprocess
     from rllab_amd import _lib
     structs = (("rl_env_cfg", _lib.EnvCfg), ("rl_rollout_args", _lib.RolloutArgs), ("rl_policy_batch", _lib.PolicyBatch),
-               ("rl_launch_opts", _lib.LaunchOpts), ("rl_rollout_plan", _lib.RolloutPlan))
+               ("rl_launch_opts", _lib.LaunchOpts), ("rl_rollout_plan", _lib.RolloutPlan),
+               ("rl_running_norm", _lib.RunningNorm))
     lines = ['#include "rllab_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in structs:
         lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

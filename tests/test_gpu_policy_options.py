@@ -434,3 +434,118 @@ def test_trpo_learns_on_the_kernels_with_one_hidden_layer_or_rectify(hidden, nl,
         assert float(tab["MeanKL"]) <= 0.0101
         logger.dump_tabular()
     assert np.mean(rets[-3:]) > 2.0 * np.mean(rets[:3]), rets
+
+
+# ---- NormalizedEnv(normalize_obs / normalize_reward) inside the fused rollout (round 5: rl_running_norm) -----------------
+@pytest.mark.parametrize("env_name,flags", [("cartpole", (True, True)), ("swimmer", (True, False)), ("cheetah", (True, True)),
+                                            ("cartpole", (False, True))])
+@pytest.mark.parametrize("epw", ["16", "64"])
+def test_fused_rollout_with_running_normalisation_replays_on_the_host(env_name, flags, epw, monkeypatch, quiet_logger):
+    """The whole horizon in ONE launch with the wrapper's per-env running estimates in the kernel: every recorded
+    transition replays on the host build of the dynamics (oracle/host_env.py, float32) under a numpy restatement of
+    normalized_env.py:33-49,78-92 -- estimate fed by every step's observation, the terminal one included, and once more by
+    the reset observation; whitened observation = (x - mean) / (sqrt(var) + 1e-8) with the UPDATED mean; reward
+    normalised, then scaled -- observations / rewards within 2e-6, the estimates left on the device within 1e-12, means
+    within 1e-5 of a float64 forward of the recorded (whitened) observations."""
+    import importlib
+    from oracle import host_env as H
+    from rllab.envs.normalized_env import normalize
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    mod, cls = dict(cartpole=("rllab.envs.box2d.cartpole_env", "CartpoleEnv"), swimmer=("rllab.envs.mujoco.swimmer_env", "SwimmerEnv"),
+                    cheetah=("rllab.envs.mujoco.half_cheetah_env", "HalfCheetahEnv"))[env_name]
+    monkeypatch.setenv("RLLAB_ROLLOUT_EPW", epw)
+    nobs, nrew = flags
+    oa, ra, scale = 0.01, 0.02, 0.25
+    env = normalize(getattr(importlib.import_module(mod), cls)(), scale_reward=scale, normalize_obs=nobs, normalize_reward=nrew,
+                    obs_alpha=oa, reward_alpha=ra)
+    np.random.seed(3)
+    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    n, T, mpl = 37, 30, 9
+    v = env.vec_env_executor(n_envs=n, max_path_length=mpl, seed=6)
+    assert v.takes_rollout_of(pol)
+    plan = v.rollout_plan(pol, T)
+    assert plan.kernel == 1 and plan.envs_per_wavefront == int(epw) and b"norm" in plan.name
+    q = v.q
+    do, da = q["obs_dim"], q["act_dim"]
+    rng = np.random.RandomState(1)
+    eps = rng.randn(da, T, n).astype(np.float32)
+    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    # a pre-existing estimate (a resumed snapshot): the kernel must start from it, not from mean 0 / var 1
+    v.obs_mean += torch.as_tensor(0.1 * rng.randn(do, n), device=v.obs_mean.device)
+    v.reward_var *= 1.5
+    m0, v0 = v.obs_mean.cpu().numpy().copy(), v.obs_var.cpu().numpy().copy()
+    rm0, rv0 = v.reward_mean.cpu().numpy().copy(), v.reward_var.cpu().numpy().copy()
+    traj = v.rollout(pol, T, eps=eps, reset_draws=draws)
+    obs = traj.obs.cpu().numpy().astype(np.float64)
+    act, rew, done = traj.actions.cpu().numpy(), traj.rewards.cpu().numpy().astype(np.float64), traj.dones.cpu().numpy()
+    n_term = 0
+    for i in range(n):
+        mean, var, rm, rv = m0[:, i].copy(), v0[:, i].copy(), float(rm0[i]), float(rv0[i])
+
+        def feed(x, mean=mean, var=var):
+            x = x.astype(np.float64)
+            if not nobs:
+                return x
+            mean[:] = (1 - oa) * mean + oa * x
+            var[:] = (1 - oa) * var + oa * np.square(x - mean)
+            return (x - mean) / (np.sqrt(var) + 1e-8)
+        he = H.HostEnv(v.kind, np.float32, normalize=True, cfg={})
+        o = feed(he.reset(draws[0, :, i]))
+        ts = 0
+        for t in range(T):
+            np.testing.assert_allclose(obs[:, t, i], o, rtol=2e-6, atol=2e-6, err_msg="obs env %d t %d" % (i, t))
+            o_raw, r, d = he.step(act[:, t, i])
+            ts += 1
+            d = d or ts >= mpl
+            r = float(np.float32(r))
+            if nrew:
+                rm = (1 - ra) * rm + ra * r
+                rv = (1 - ra) * rv + ra * (r - rm) ** 2
+                r = r / (np.sqrt(rv) + 1e-8)
+            assert abs(rew[t, i] - r * scale) <= 2e-6 * max(1.0, abs(r * scale)), (i, t, rew[t, i], r * scale)
+            assert bool(done[t, i]) == bool(d)
+            o = feed(o_raw)
+            if d:
+                n_term += 1
+                o = feed(he.reset(draws[t + 1, :, i]))
+                ts = 0
+        if nobs:
+            assert np.allclose(v.obs_mean[:, i].cpu().numpy(), mean, rtol=1e-12, atol=1e-14)
+            assert np.allclose(v.obs_var[:, i].cpu().numpy(), var, rtol=1e-12, atol=1e-14)
+        if nrew:
+            assert abs(float(v.reward_mean[i]) - rm) <= 1e-12 * max(1.0, abs(rm)) and abs(float(v.reward_var[i]) - rv) <= 1e-12 * rv
+    assert n_term >= n                                  # terminal observations were part of the stream
+    with torch.no_grad():
+        mean64 = pol.mean_planes(traj.obs.reshape(do, -1).double(), pol.flat_params.double())
+    assert float((traj.means.reshape(da, -1).double() - mean64).abs().max()) <= 1e-5
+
+
+def test_trpo_with_running_normalisation_stays_on_the_fused_rollout(quiet_logger):
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.box2d.cartpole_env import CartpoleEnv
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext, logger
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    ext.set_seed(1)
+    env = normalize(CartpoleEnv(), normalize_obs=True, normalize_reward=True)
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=256 * 100,
+                max_path_length=100, n_itr=12, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=256))
+    algo.start_worker()
+    algo.init_opt()
+    assert algo.sampler.sampling_path(policy)[0].startswith("fused rollout kernel")
+    lens = []
+    for itr in range(12):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.log_diagnostics(paths)
+        algo.optimize_policy(itr, sd)
+        tab = logger.get_tabular()
+        lens.append(256 * 100 / float(tab["NumTrajs"]))          # rewards are whitened: episode length is the progress measure
+        assert float(tab["MeanKL"]) <= 0.0101
+        logger.dump_tabular()
+    assert np.mean(lens[-3:]) > 1.5 * np.mean(lens[:3]), lens
+    # the estimates moved, and they travel with the env (snapshot semantics of round 3)
+    v = algo.sampler.vec_env
+    assert float((v.obs_var - 1.0).abs().max()) > 1e-3
