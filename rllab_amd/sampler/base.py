@@ -230,6 +230,13 @@ def process_dense(algo, itr, traj, log=True):
     _lib.check(_lib.lib.rl_adv_finish(B, _lib.ptr(adv), _lib.ptr(valid_u8), float(mean_a), float(denom),
                                       float(shift), _lib.ptr(adv_out), _lib.stream_ptr()), "rl_adv_finish")
     traj.advantages = adv_out
+    # everything the policy update reads is on the device now: let it start (algos/npo.py::prefetch_update) BEFORE the
+    # host turns to the remaining statistics, a host-side baseline fit and the env / policy diagnostics -- the device
+    # idled ~35 us here while the host computed log lines (profiles/r05_timeline.csv)
+    paths = PathList(traj)
+    samples_data = SamplesData(_traj=traj, paths=paths)
+    if hasattr(algo, "prefetch_update") and traj.obs.is_cuda:
+        algo.prefetch_update(samples_data)
 
     if prog is not None and n_paths > 0:
         m_prog, var_prog = moments(_PROG, _PROG2, n_paths)
@@ -250,13 +257,6 @@ def process_dense(algo, itr, traj, log=True):
         ent = float(pdist.entropy_sym(dict(log_std=traj.log_std.to(torch.float64)), axis=0))
     else:
         ent = float("nan")
-
-    paths = PathList(traj)
-    samples_data = SamplesData(_traj=traj, paths=paths)
-    # everything the policy update reads is on the device now: let it start (algos/npo.py::prefetch_update) while the
-    # host fits a host-side baseline, writes the statistics below and the env / policy diagnostics
-    if hasattr(algo, "prefetch_update") and traj.obs.is_cuda:
-        algo.prefetch_update(samples_data)
 
     if not dense_fit:
         if log:
