@@ -93,9 +93,29 @@ def step_kernel_roofline(torch, kind, n=1 << 22, steps=20, warmup=3):
     gbs = step_bytes * n / (ms * 1e-3) / 1e9
     del v, act
     torch.cuda.empty_cache()
-    return {"kernel": "vecenv_step_kernel<%s> (rl_vecenv_step, one transition per launch)" % name, "n_envs": n,
-            "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-            "avg_launch_ms": ms, "bytes_per_env_step": step_bytes, "env_steps_per_s": n / (ms * 1e-3)}
+    out = {"kernel": "vecenv_step_kernel<%s> (rl_vecenv_step, one transition per launch)" % name, "n_envs": n,
+           "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+           "avg_launch_ms": ms, "bytes_per_env_step": step_bytes, "env_steps_per_s": n / (ms * 1e-3)}
+    # the vector axis: instructions per launch from the kernel's own counters (a builder-run pass of tools/
+    # step_kernel_roofline.py under --pmc, profiles/run_profile.sh; stamped with the kernel-source hash) x 64 lanes over
+    # THIS run's launch time, against the vector peak in lane-instructions (157.3 TFLOP/s counts an FMA twice)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    cls = {"cartpole": "Cartpole", "double_pendulum": "DoublePendulum", "swimmer": "Swimmer",
+           "half_cheetah": "HalfCheetah"}.get(name)
+    rec = json.load(open(tpath)).get("step_kernels") if os.path.exists(tpath) else None
+    if rec and cls in rec.get("kernels", {}):
+        k = rec["kernels"][cls]
+        if rec.get("kernel_source_hash") != kernel_source_hash():
+            out["valu_source"] = "stale: the step kernels' counters were taken from kernel sources %s, this build is %s" % (
+                rec.get("kernel_source_hash"), kernel_source_hash())
+        elif k["n_envs"] == n:
+            tfl = k["insts_valu"] * 64.0 / (ms * 1e-3) / 1e12
+            out.update({"valu_tflops": tfl, "valu_peak_tflops": 157.3 / 2.0, "valu_frac": tfl / (157.3 / 2.0),
+                        "valu_unit": "T lane-instructions/s (SQ_INSTS_VALU x 64 / launch time; an FMA counts once)",
+                        "valu_insts_per_env_step": k["insts_valu"] * 64.0 / n,
+                        "valu_issue_frac": k["active_inst_valu"] / k["wave_cycles"] if k.get("wave_cycles") else None,
+                        "valu_source": rec["source"] + "; NOT measured in this run -- only the launch time is"})
+    return out
 
 
 def self_launch_argv(n_gpus, argv, port=None):
@@ -229,7 +249,11 @@ def main():
         h.append(time.perf_counter())
         e[0], e[1], paths = (pending.pop(itr) if itr in pending else launch_rollout(itr))[:3]
         h.append(time.perf_counter())
-        samples = algo.sampler.process_samples(itr, paths)
+        algo._update_follows = True       # (as train_iteration: process_samples may start the update's first pass)
+        try:
+            samples = algo.sampler.process_samples(itr, paths)
+        finally:
+            algo._update_follows = False
         algo.log_diagnostics(paths)
         h.append(time.perf_counter())
         e[2].record()
@@ -370,7 +394,9 @@ def main():
         rec = json.load(open(tpath)).get(args.workload)
         if rec and rec.get("n_envs") == n_envs:
             if rec.get("kernel_source_hash") == kernel_source_hash():
-                traffic, traffic_src = rec["rollout_bytes_per_launch"], rec["source"]
+                traffic, traffic_src = rec["rollout_bytes_per_launch"], rec["source"] + \
+                    "; a builder-run pass committed as profiles/pmc_traffic.json, gated on the kernel-source hash -- not " \
+                    "measured in this run (valu_* and issue_slot_floor_ms come from the same file: compute_source)"
                 if rec.get("rollout_insts_valu"):
                     compute_axis = rec
             else:
@@ -506,8 +532,10 @@ def main():
             "clock_ghz": clock_hz / 1e9,
             "issue_slot_floor_ms": per_wave_step * 4.0 * T / clock_hz * 1e3,
             "valu_issue_frac": compute_axis["rollout_active_inst_valu"] / compute_axis["rollout_wave_cycles"],
-            "compute_source": compute_axis["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_WAVES / "
-                                                             "GRBM_GUI_ACTIVE")})
+            "compute_source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / SQ_WAVE_CYCLES / SQ_ACTIVE_INST_VALU / "
+                              "GRBM_GUI_ACTIVE, a builder-run pass of this command committed as profiles/pmc_traffic.json "
+                              "(%s) and gated on the kernel-source hash; NOT measured in this run -- valu_*, clock_ghz and "
+                              "issue_slot_floor_ms combine those counters with this run's launch time" % compute_axis["source"]})
     if fvp_ms is not None:
         tiles = (n_envs * T + 31) // 32
         tf = tiles * mfma_per_tile * 4096 / (fvp_ms * 1e-3) / 1e12

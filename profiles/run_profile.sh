@@ -38,5 +38,9 @@ if [ "$WORKLOAD" != "swimmer4096_trpo" ]; then ls -la gpurun_out; exit 0; fi
 python tools/step_kernel_roofline.py 2>&1 | grep "^{" > gpurun_out/${TAG}_step_kernel_roofline.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/step -- python tools/step_kernel_roofline.py > /dev/null 2>&1
 python profiles/summarize.py stats $P/step gpurun_out/${TAG}_step_kernel_stats.csv
+# ... and its vector axis: instructions per launch from the SQ counters (bench.py prices roofline_step_kernel with them)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $P/stepsq -- python tools/step_kernel_roofline.py --steps 3 --warmup 1 > /dev/null 2>&1
+python profiles/summarize.py pmc $P/stepsq gpurun_out/${TAG}_step_kernel_pmc_sq.csv
+python profiles/summarize.py stepkernels gpurun_out/${TAG}_step_kernel_pmc_sq.csv gpurun_out/pmc_traffic.json $((1 << 22)) ${ROUND}
 tail -2 gpurun_out/${TAG}_bench_under_rocprof.log
 ls -la gpurun_out

@@ -126,8 +126,35 @@ def traffic(fetch_csv, write_csv, out_json, workload="swimmer4096_trpo", n_envs=
     json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
 
 
+def step_kernels(sq_csv, out_json, n_envs, tag=""):
+    """Vector-instruction counters of the per-step boundary kernels (tools/step_kernel_roofline.py under an SQ pass) ->
+    pmc_traffic.json["step_kernels"][<env class>]: instructions and wavefronts per launch of ``n_envs`` envs, and the
+    clock of that pass -- bench.py's roofline_step_kernel prices its live launch time on the vector axis with them."""
+    import json
+    import re
+    rec = json.load(open(out_json)) if os.path.exists(out_json) else {}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = {}
+    for r in csv.DictReader(open(sq_csv)):
+        m = re.search(r"vecenv_step_kernel<rl::(\w+)>", r["kernel"])
+        if not m or not r.get("mean_SQ_INSTS_VALU"):
+            continue
+        out[m.group(1)] = dict(n_envs=int(n_envs), insts_valu=float(r["mean_SQ_INSTS_VALU"]),
+                               waves=float(r["mean_SQ_WAVES"]), gui_active=float(r["mean_GRBM_GUI_ACTIVE"]),
+                               active_inst_valu=float(r["mean_SQ_ACTIVE_INST_VALU"]),
+                               wave_cycles=float(r["mean_SQ_WAVE_CYCLES"]),
+                               ns_this_pass=float(r["mean_ns_this_pass"]) if r.get("mean_ns_this_pass") else None)
+    rec["step_kernels"] = dict(kernels=out, kernel_source_hash=bench.kernel_source_hash(),
+                               source="rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / GRBM_GUI_ACTIVE over "
+                                      "tools/step_kernel_roofline.py, a builder-run pass (%s)" % tag)
+    json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(*sys.argv[2:])
+    elif sys.argv[1] == "stepkernels":
+        step_kernels(*sys.argv[2:])
     else:
         {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -127,7 +127,13 @@ class BatchPolopt(RLAlgorithm):
         itr_start = time.time()
         with logger.prefix('itr #%d | ' % itr):
             paths = self.sampler.obtain_samples(itr)
-            samples_data = self.sampler.process_samples(itr, paths)
+            # process_samples may hand the optimizer its inputs early (prefetch_update): only here, where optimize_policy
+            # follows on the same batch -- a caller that processes samples on its own pays no extra pass or collective
+            self._update_follows = True
+            try:
+                samples_data = self.sampler.process_samples(itr, paths)
+            finally:
+                self._update_follows = False
             self.log_diagnostics(paths)
             # the next rollout depends on nothing but the updated parameters: an optimizer that decides its line search
             # on the device calls this hook once the whole update is enqueued (before it reads the outcome), so the

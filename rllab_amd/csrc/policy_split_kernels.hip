@@ -837,7 +837,14 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
         tv[2 * DA * HT * 16 + t * 16 + r] = vc[N::B1 + u];
     }
     __syncthreads();
+#if RL_ABL_OPS
+    Parts abl_op64;
+    for (int p = 0; p < 3; ++p) abl_op64.p[p] = *reinterpret_cast<const bf16x8*>(ops + (p * WV + lane) * 16);
+#endif
     auto op = [&](int o) -> Parts {
+#if RL_ABL_OPS
+        if (o >= 0) { Parts t = abl_op64; asm volatile("" : "+v"(t.p[0]), "+v"(t.p[1]), "+v"(t.p[2])); return t; }
+#endif
         Parts t;
 #pragma unroll
         for (int p = 0; p < 3; ++p) t.p[p] = *reinterpret_cast<const bf16x8*>(ops + ((o * 3 + p) * WV + lane) * 16);
@@ -977,6 +984,17 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
                 set_pair(dz1[t], j, d);
                 set_pair(acc[t], j, pair_of(acc[t], j) * d);                          // dh1
             }
+#ifndef RL_ABL_THIN
+#define RL_ABL_THIN 0          // timing ablation: the output layer's thin products and the gW2 walk left out (wrong results)
+#endif
+#if RL_ABL_THIN
+#pragma unroll
+        for (int k = 0; k < DA; ++k) gmu[k] = c * db2[k];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) gz1[t] = acc[t];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch_acts(nxt);
+#else
         // the output layer's rows of this lane half come in bulk: per action the 2 x 16 rows of W2 and of its tangent are
         // sixteen 16-byte reads issued together, waited for once (a scalar read per use exposed ~190 LDS round trips per tile)
         auto rows_of = [&](int which, int k, f32x4 (&out_)[HT][4]) {       // which: 0 = W2, 1 = dW2
@@ -1057,6 +1075,7 @@ __global__ void __launch_bounds__(4 * WV, 1) fvp_split64_kernel(Args a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the landing zone has been read: refill it
         fetch_acts(nxt);
+#endif
         stage();
         Parts G1s[KBH];
 #pragma unroll

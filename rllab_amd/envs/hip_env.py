@@ -213,15 +213,23 @@ class HipVecEnv(object):
                                            norm=norm, obs_noise=float(self.cfg.obs_noise))
         return cache[key]
 
+    def _first_layer_on_full_obs(self, theta, h0):
+        """Kernel-layout parameters of a net built on the position rows -> the same net on the full observation:
+        W0 [kept, h0] scattered into [obs_dim, h0] (flat order W0, b0, ...: policies/kernel_layout.py), the rest as is."""
+        kept, do = len(self.position_ids), self.q["obs_dim"]
+        w0 = torch.zeros((do, h0), dtype=torch.float32, device=self.device)
+        w0.index_copy_(0, self._pos_index, theta[:kept * h0].view(kept, h0))
+        return torch.cat([w0.view(-1), theta[kept * h0:]])
+
     def rollout(self, policy, horizon, reset_at_start=True, eps=None, reset_draws=None, action_noise_z=None,
                 obs_noise_z=None, norm=None, scale_reward=None):
         """``horizon`` lock-step iterations of get_actions -> step -> record ->
         auto-reset in ONE launch (rl_rollout_gaussian_mlp).  Returns
         ``Trajectories``.  ``eps`` [Da, T, n] / ``reset_draws`` [T+1, R, n] / ``action_noise_z`` [T, Da, n] /
         ``obs_noise_z`` [T+1, Do, n] inject pre-generated noise (parity runs)."""
-        if self.position_ids is not None:
-            raise NotImplementedError("position_only observations: the fused rollout feeds the policy the full "
-                                      "observation; sample through the per-transition path")
+        if self.position_ids is not None and norm is not None:
+            raise NotImplementedError("position_only observations under running normalisation: the estimates are over "
+                                      "the kept rows; sample through the per-transition path")
         T, n = int(horizon), self.n
         do, da = self.q["obs_dim"], self.q["act_dim"]
         layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
@@ -242,6 +250,13 @@ class HipVecEnv(object):
         theta_std = None if dual is None else dual[2]
         hs_std = (0, 0, 0) if dual is None else dual[3]
         log_stds = None if dual is None else torch.empty((da, T, n), **f32)
+        if self.position_ids is not None:
+            # Box2DEnv(position_only=True): the env kernel produces (and noises) the full observation and the policy was
+            # built on the kept rows (box2d_env.py:219-227).  The kernel copy of the first layer gets zero rows at the
+            # dropped observations -- products with 0, the kept rows' sums unchanged -- and the batch keeps the kept rows.
+            theta = self._first_layer_on_full_obs(theta, hs[0])
+            if theta_std is not None:
+                theta_std = self._first_layer_on_full_obs(theta_std, hs_std[0])
         assert theta.is_cuda and theta.dtype == torch.float32 and theta.is_contiguous()
         if eps is not None:
             eps = torch.as_tensor(eps, **f32).contiguous()
@@ -284,6 +299,8 @@ class HipVecEnv(object):
         _lib.check(_lib.lib.rl_rollout_gaussian_mlp(ctypes.byref(args), _lib.stream_ptr()),
                    "rl_rollout_gaussian_mlp")
         self.step_counter += T + 1
+        if self._pos_index is not None:
+            obs = obs.index_select(0, self._pos_index)
         return Trajectories(obs, act, mean, policy.recorded_log_std(), rew, done,
                             self.max_path_length, log_std_planes=log_stds)
 

@@ -227,7 +227,7 @@ class ConjugateGradientOptimizer(Serializable):
         tag = fused._eval_point(inputs)
         flat_g = self._flat_grad(inputs, keep_activations=True, with_loss=True)
         before = fused.loss_and_kl_deferred(inputs)
-        self._pre = (tag, flat_g, before)
+        self._pre = (tag, flat_g, before, inputs)      # (the tensors themselves: their ids in ``tag`` cannot be recycled)
 
     def optimize(self, inputs, extra_inputs=None, subsample_grouped_inputs=None):
         inputs = tuple(inputs) + tuple(extra_inputs or ())

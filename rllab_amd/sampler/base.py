@@ -235,7 +235,7 @@ def process_dense(algo, itr, traj, log=True):
     # idled ~35 us here while the host computed log lines (profiles/r05_timeline.csv)
     paths = PathList(traj)
     samples_data = SamplesData(_traj=traj, paths=paths)
-    if hasattr(algo, "prefetch_update") and traj.obs.is_cuda:
+    if hasattr(algo, "prefetch_update") and traj.obs.is_cuda and getattr(algo, "_update_follows", False):
         algo.prefetch_update(samples_data)
 
     if prog is not None and n_paths > 0:

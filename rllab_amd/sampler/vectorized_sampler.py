@@ -62,11 +62,12 @@ class VectorizedSampler(BaseSampler):
             return "fused rollout kernel (one launch per batch of %d envs)" % ve.n, None
         if ve is None:
             return "none (no executor yet)", None
-        if not getattr(ve, "graphable", True):
+        if not getattr(ve, "graphable", True) and ve.position_ids is not None:
+            why = "Box2DEnv(position_only=True) under NormalizedEnv(normalize_obs / normalize_reward): the running " \
+                  "estimates are over the kept rows, the fused rollout's over the full observation"
+        elif not getattr(ve, "graphable", True):
             why = "NormalizedEnv(normalize_obs / normalize_reward): the running estimates ride in the fused rollout of the " \
                   "(32, 32) / (64, 64) policies only (and not together with obs_noise)"
-        elif ve.position_ids is not None:
-            why = "Box2DEnv(position_only=True): the fused rollout feeds the policy the full observation"
         else:
             layout = policy.kernel_layout() if hasattr(policy, "kernel_layout") else None
             dual = policy.rollout_networks() if hasattr(policy, "rollout_networks") else None
@@ -98,7 +99,7 @@ class VectorizedSampler(BaseSampler):
     def _takes_fused_rollout(self, policy):
         """True when ``obtain_samples`` is ONE asynchronous launch for this policy (the fused rollout kernels)."""
         ve = self.vec_env
-        if ve is None or ve.position_ids is not None:
+        if ve is None:
             return False
         if hasattr(ve, "takes_rollout_of"):
             # the kernels' own answer: a layout exists AND its weight fragments fit the LDS of a CU on this env

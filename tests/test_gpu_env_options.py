@@ -166,7 +166,7 @@ def test_in_kernel_noise_streams_have_the_requested_scale():
 
 def test_position_only_and_the_env_classes(quiet_logger):
     """Box2DEnv(position_only=True): observations keep the position-typed <state> entries (cartpole: cart x, pole
-    angle); such an env is sampled through the per-transition path and TRPO still runs on it.  Reward-coefficient
+    angle); such an env stays on the fused rollout (test_position_only_on_the_fused_rollout) and TRPO runs on it.  Reward-coefficient
     and noise options reach the kernels through the rllab classes."""
     from rllab.algos.trpo import TRPO
     from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
@@ -187,8 +187,60 @@ def test_position_only_and_the_env_classes(quiet_logger):
                 max_path_length=50, n_itr=3, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=64))
     algo.train()
     assert np.isfinite(policy.get_param_values()).all()
+    assert algo.sampler.sampling_path(policy)[0].startswith("fused rollout kernel")
     sw = SwimmerEnv(ctrl_cost_coeff=0.0)
     sw.reset()
     _, r0, _, _ = sw.step(np.array([40.0, -40.0]))
     np.testing.assert_allclose(sw.get_body_comvel("torso")[0], r0, atol=1e-6)      # no control cost left
     assert sw.get_body_comvel("torso").shape == (3,) and sw.get_body_com("torso")[2] == 0.0
+
+
+@pytest.mark.parametrize("kind,ids", [(0, (0, 2)), (1, (0, 1, 3, 4))])
+@pytest.mark.parametrize("hidden", [(32, 32), (20,), (64, 64), (100, 50, 25)])
+def test_position_only_on_the_fused_rollout(kind, ids, hidden):
+    """Box2DEnv(position_only=True) (box2d_env.py:219-227: noise on the full observation, then the filter) in ONE launch:
+    the policy built on the kept rows runs as the same net on the full observation with zero first-layer rows at the
+    dropped entries -- actions, rewards and dones are those of a full-observation executor running that net, bit for
+    bit; the batch holds the kept rows; recorded means == float64 forward of the policy on them."""
+    from rllab_amd.envs.env_spec import EnvSpec
+    from rllab_amd.envs.hip_env import HipVecEnv
+    from rllab_amd.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd.spaces import Box
+    from oracle.replay import replay_check
+    n, T, mpl = 70, 25, 11
+    cfg = dict(obs_noise=0.05)
+    pos = HipVecEnv(kind, n, mpl, normalize=True, seed=5, cfg=cfg, position_ids=ids)
+    full = HipVecEnv(kind, n, mpl, normalize=True, seed=5, cfg=cfg)
+    q = full.q
+    do, da, kept = q["obs_dim"], q["act_dim"], len(ids)
+    assert pos.obs_rows == kept
+
+    def build(d):
+        np.random.seed(0)
+        spec = EnvSpec(Box(-1e6 * np.ones(d), 1e6 * np.ones(d)), Box(-np.ones(da), np.ones(da)))
+        return GaussianMLPPolicy(spec, hidden_sizes=hidden)
+    pol, pol_full = build(kept), build(do)
+    th = pol.get_param_values()
+    th = th + 0.1 * np.random.RandomState(3).randn(th.size)
+    pol.set_param_values(th)
+    h0 = hidden[0]
+    w0 = np.zeros((do, h0))
+    w0[list(ids)] = th[:kept * h0].reshape(kept, h0)
+    pol_full.set_param_values(np.concatenate([w0.reshape(-1), th[kept * h0:]]))
+    assert pos.takes_rollout_of(pol)
+    rng = np.random.RandomState(1)
+    eps = rng.randn(da, T, n).astype(np.float32)
+    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
+    oz = rng.randn(T + 1, do, n).astype(np.float32)
+    a = pos.rollout(pol, T, eps=eps, reset_draws=draws, obs_noise_z=oz)
+    b = full.rollout(pol_full, T, eps=eps, reset_draws=draws, obs_noise_z=oz)
+    assert a.obs.shape == (kept, T, n) and a.obs.is_contiguous()
+    assert torch.equal(a.obs, b.obs[list(ids)])
+    for x, y in ((a.actions, b.actions), (a.means, b.means), (a.rewards, b.rewards), (a.dones, b.dones)):
+        assert torch.equal(x, y)
+    assert torch.equal(pos.state, full.state)
+    assert torch.equal(pos._filtered(pos._obs), full._obs[list(ids)].t())
+    assert replay_check(full, b, max_envs=n, reset_draws=draws, obs_noise_z=oz) == n * T
+    with torch.no_grad():
+        mean64 = pol.mean_planes(a.obs.reshape(kept, -1).double(), pol.flat_params.double())
+    assert float((a.means.reshape(da, -1).double() - mean64).abs().max()) <= 1e-5

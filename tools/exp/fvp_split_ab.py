@@ -7,9 +7,10 @@ CODE = r'''
 import sys, json, os, torch
 sys.path.insert(0, %r)
 from tests import test_gpu_update_parity as U
-pol = U._policy(13, 2, 32)
+H64 = len(sys.argv) > 1 and sys.argv[1] == "64"
+pol = U._policy(20, 6, 64) if H64 else U._policy(13, 2, 32)
 ops = pol.fused_ops()
-inp = U._inputs(pol, 2048000, ragged=False, old_equals_new=True)
+inp = U._inputs(pol, 512000 if H64 else 2048000, ragged=False, old_equals_new=True)
 v = torch.randn(pol.flat_params.numel(), device="cuda", dtype=torch.float64)
 ops.loss_grad(inp, keep_activations=True)
 def t(fn, n=40):
@@ -28,6 +29,6 @@ try:
     for lib in [target + ".orig"] + sorted(glob.glob(os.path.join(ROOT, "build", "exp", "lib_*.so"))) + [target + ".orig"]:
         shutil.copy(lib, target)
         print("==", os.path.basename(lib), flush=True)
-        subprocess.call([sys.executable, "-c", CODE])
+        subprocess.call([sys.executable, "-c", CODE] + sys.argv[1:])
 finally:
     shutil.copy(target + ".orig", target)
