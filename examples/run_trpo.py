@@ -17,15 +17,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rllab.algos.trpo import TRPO  # noqa: E402
 from rllab.algos.vpg import VPG  # noqa: E402
 from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline  # noqa: E402
-from rllab.envs.normalized_env import normalize  # noqa: E402
 from rllab.misc import ext  # noqa: E402
 from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy  # noqa: E402
 
 
-def make_env(name):
+def make_env(name, position_only=False, **norm):
+    if position_only and name not in ("cartpole", "double_pendulum", "cartpole_swingup"):
+        raise SystemExit("--position-only: a Box2DEnv option")
+    box = dict(position_only=True) if position_only else {}
+
+    def normalize(env):                           # (the wrapper's running estimates: --normalize-obs / --normalize-reward)
+        from rllab.envs.normalized_env import normalize as wrap
+        return wrap(env, **norm)
     if name == "cartpole":
         from rllab.envs.box2d.cartpole_env import CartpoleEnv
-        return normalize(CartpoleEnv()), 100
+        return normalize(CartpoleEnv(**box)), 100
     if name == "swimmer":
         from rllab.envs.mujoco.swimmer_env import SwimmerEnv
         return normalize(SwimmerEnv()), 500
@@ -46,10 +52,10 @@ def make_env(name):
         return normalize(InvertedDoublePendulumEnv()), 100
     if name == "double_pendulum":
         from rllab.envs.box2d.double_pendulum_env import DoublePendulumEnv
-        return normalize(DoublePendulumEnv()), 100
+        return normalize(DoublePendulumEnv(**box)), 100
     if name == "cartpole_swingup":
         from rllab.envs.box2d.cartpole_swingup_env import CartpoleSwingupEnv
-        return normalize(CartpoleSwingupEnv()), 500
+        return normalize(CartpoleSwingupEnv(**box)), 500
     raise SystemExit("unknown env %r" % name)
 
 
@@ -61,6 +67,11 @@ def main():
     ap.add_argument("--n-itr", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--hidden", default="32", help="hidden sizes: one number H for (H, H), or a list like 100,50,25")
+    ap.add_argument("--one-hidden-layer", action="store_true", help="--hidden H means (H,) instead of (H, H)")
+    ap.add_argument("--nonlinearity", default="tanh", choices=["tanh", "relu"], help="hidden_nonlinearity")
+    ap.add_argument("--normalize-obs", action="store_true", help="NormalizedEnv(normalize_obs=True)")
+    ap.add_argument("--normalize-reward", action="store_true", help="NormalizedEnv(normalize_reward=True)")
+    ap.add_argument("--position-only", action="store_true", help="Box2DEnv(position_only=True)")
     ap.add_argument("--adaptive-std", action="store_true", help="GaussianMLPPolicy(adaptive_std=True)")
     ap.add_argument("--gae-lambda", type=float, default=1.0)
     ap.add_argument("--csv", default=None, help="write the tabular log (one row per iteration) to this file")
@@ -72,10 +83,16 @@ def main():
     if args.quiet:
         logger.set_quiet(True)
     ext.set_seed(args.seed)
-    env, horizon = make_env(args.env)
+    norm = {k: True for k in ("normalize_obs", "normalize_reward") if getattr(args, k)}
+    env, horizon = make_env(args.env, position_only=args.position_only, **norm)
     hs = tuple(int(h) for h in str(args.hidden).split(","))
-    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=hs * 2 if len(hs) == 1 else hs,
-                               adaptive_std=args.adaptive_std)
+    extra = {}
+    if args.nonlinearity == "relu":
+        from rllab.core.network import rectify
+        extra["hidden_nonlinearity"] = rectify
+    policy = GaussianMLPPolicy(env_spec=env.spec,
+                               hidden_sizes=hs * 2 if len(hs) == 1 and not args.one_hidden_layer else hs,
+                               adaptive_std=args.adaptive_std, **extra)
     baseline = LinearFeatureBaseline(env_spec=env.spec)
     kw = dict(env=env, policy=policy, baseline=baseline, batch_size=args.n_envs * horizon,
               max_path_length=horizon, n_itr=args.n_itr, discount=0.99, gae_lambda=args.gae_lambda,

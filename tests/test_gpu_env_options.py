@@ -196,7 +196,7 @@ def test_position_only_and_the_env_classes(quiet_logger):
 
 
 @pytest.mark.parametrize("kind,ids", [(0, (0, 2)), (1, (0, 1, 3, 4))])
-@pytest.mark.parametrize("hidden", [(32, 32), (20,), (64, 64), (100, 50, 25)])
+@pytest.mark.parametrize("hidden", [(32, 32), (16, 16), (64, 64), (100, 50, 25)])
 def test_position_only_on_the_fused_rollout(kind, ids, hidden):
     """Box2DEnv(position_only=True) (box2d_env.py:219-227: noise on the full observation, then the filter) in ONE launch:
     the policy built on the kept rows runs as the same net on the full observation with zero first-layer rows at the
