@@ -606,3 +606,65 @@ def test_swimmer_limit_model_option_travels_with_the_env():
     assert back.wrapped_env.limit_model == "mujoco" and back.wrapped_env._cfg["flags"] == _lib.CFG_LIMIT_MUJOCO
     with pytest.raises(ValueError):
         SwimmerEnv(limit_model="lcp")
+
+
+def test_ext_helpers_behave_like_the_reference_module():
+    """The Theano-free helpers of rllab/misc/ext.py (:23-40, :71-120, :151-182, :302-338, :373-391), each held to
+    what the reference's does on hand-worked cases -- including its quirks: a scan starts from ``base`` only when
+    ``base`` is truthy, ``lazydict.set`` replaces the thunk but not a value already computed."""
+    import random
+    import torch
+    from rllab_amd.misc import ext
+    f = lambda acc, x: acc * 2 + x
+    assert ext.scanl(f, [1, 2, 3]) == [1, 4, 11]
+    assert ext.scanl(f, [1, 2, 3], 0) == [1, 4, 11]                   # 0 is "no base"
+    assert ext.scanl(f, [1, 2, 3], 5) == [11, 24, 51]
+    assert ext.scanr(f, [1, 2, 3]) == [3, 7, 9]                       # f(x, acc) over the reversed list
+    assert ext.scanr(f, [1, 2, 3], 1) == [7, 11, 13] and ext.scanl(f, []) == []
+    assert list(ext.iscanl(lambda a, b: a + b, iter([1, 1, 1]))) == [1, 2, 3]
+    assert ext.compact(dict(a=1, b=None)) == dict(a=1) and ext.compact([None, 0, None, 2]) == [0, 2] and ext.compact(3) == 3
+    assert ext.extract_dict(dict(a=1, b=2), "b", "zz") == dict(b=2)
+    assert ext.flatten([[1, 2], [], [3]]) == [1, 2, 3]
+    n = [0]
+
+    def thunk():
+        n[0] += 1
+        return 7
+    ld = ext.lazydict(a=thunk)
+    assert n[0] == 0 and ld["a"] == 7 and ld["a"] == 7 and n[0] == 1
+    assert ld.get("a") == 7 and ld.get("zz", 4) == 4
+    ld["b"] = lambda: 9
+    assert ext.extract(ld, "b", "a") == (9, 7)
+    ld.set("b", lambda: 10)
+    assert ld["b"] == 9
+    ad = ext.AttrDict(a=1)
+    ad.b = 2
+    assert ad["b"] == 2 and ad.a == 1 and dict(ad) == dict(a=1, b=2)
+    p1 = dict(states=np.zeros((4, 2)), rewards=np.arange(4.0), only_here=np.ones(4))
+    p2 = dict(states=np.ones((3, 2)), rewards=np.arange(3.0))
+    both = ext.concat_paths(p1, p2)
+    assert sorted(both) == ["rewards", "states"] and both["states"].shape == (7, 2) and both["rewards"][4] == 0.0
+    assert ext.path_len(p1) == 4 and ext.path_len(ext.truncate_path(p1, 2)) == 2
+    random.seed(0)
+    order = list(ext.shuffled(range(10)))
+    assert sorted(order) == list(range(10)) and order != list(range(10))
+    random.seed(0)
+    assert list(ext.shuffled(range(10))) == order
+    assert ext.flatten_shape_dim((2, 3, 4)) == 24 and ext.flatten_shape_dim(()) == 1
+    x = np.array([[1.0, 10.0], [3.0, 30.0]])
+    assert np.allclose(ext.stdize(x, eps=0.0), [[-1, -1], [1, 1]])
+    y = np.arange(5)
+    xs = np.arange(10.0).reshape(5, 2)
+    got = list(ext.iterate_minibatches_generic([xs, y], 2))
+    assert [len(b[1]) for b in got] == [2, 2, 1] and np.array_equal(got[2][0], xs[4:]) and np.array_equal(got[1][1], [2, 3])
+    assert len(list(ext.iterate_minibatches_generic([xs, y]))) == 1
+    np.random.seed(1)
+    sh = list(ext.iterate_minibatches_generic([xs, y], 2, shuffle=True))
+    perm = np.concatenate([b[1] for b in sh])
+    np.random.seed(1)
+    want = np.arange(5)
+    np.random.shuffle(want)
+    assert np.array_equal(perm, want) and all(np.array_equal(b[0], xs[b[1]]) for b in sh)
+    ts = [torch.arange(6.0).reshape(2, 3), torch.arange(4.0)]
+    back = ext.unflatten_tensor_variables(ext.flatten_tensor_variables(ts), [t.shape for t in ts], ts)
+    assert all(torch.equal(a, b) for a, b in zip(ts, back))
