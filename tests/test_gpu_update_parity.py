@@ -473,7 +473,7 @@ def test_process_samples_starts_the_update(quiet_logger, monkeypatch):
     from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
     from rllab_amd.optimizers import conjugate_gradient_optimizer as cgo
 
-    def run(flag):
+    def run(flag, in_training_loop=True):
         monkeypatch.setenv("RLLAB_UPDATE_PREFETCH", flag)
         ext.set_seed(3)
         env = normalize(SwimmerEnv())
@@ -485,7 +485,10 @@ def test_process_samples_starts_the_update(quiet_logger, monkeypatch):
         used = []
         for itr in range(3):
             paths = algo.sampler.obtain_samples(itr)
+            # what BatchPolopt.train_iteration does around its process_samples call: the update follows on this batch
+            algo._update_follows = in_training_loop
             sd = algo.sampler.process_samples(itr, paths)
+            algo._update_follows = False
             used.append(getattr(algo.optimizer, "_pre", None) is not None)
             algo.log_diagnostics(paths)
             algo.optimize_policy(itr, sd)
@@ -495,6 +498,9 @@ def test_process_samples_starts_the_update(quiet_logger, monkeypatch):
     p0, used0 = run("0")
     assert used1 == [True, True, True] and used0 == [False, False, False]
     assert np.array_equal(p1, p0)
+    # a caller that processes samples on its own (no optimize_policy promised) pays no extra pass
+    p2, used2 = run("1", in_training_loop=False)
+    assert used2 == [False, False, False] and np.array_equal(p2, p0)
 
 
 @pytest.mark.parametrize("hidden", [(32, 32), (100, 50, 25)])
