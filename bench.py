@@ -475,11 +475,11 @@ def main():
         5: "fused wide / deep policy + env step + record; 16 envs per wavefront, four lanes per env in the physics sub-steps",
         6: "fused wide / deep policy + env step + record; FOUR wavefronts per group of 16 envs: the layers split by output "
            "units on 16 x 16 x 4 matrix tiles, activations through LDS; four lanes per env in the physics sub-steps",
-        7: "fused policy + env step + record; ONE env per wavefront: the policy's units on the lanes, one leg per lane in "
+        7: "fused policy + env step + record; ONE env per wavefront: the policy's units on the lanes, one body per lane in "
            "the physics sub-steps, the trajectory stored lane-distributed",
-        8: "fused policy + env step + record; 16 envs per wavefront, a lane group per env with one leg per lane in the "
+        8: "fused policy + env step + record; 16 envs per wavefront, a lane group per env with one body (of both legs) per lane in the "
            "physics sub-steps",
-        9: "fused wide / deep policy + env step + record; 16 envs per wavefront, one leg per lane in the physics sub-steps",
+        9: "fused wide / deep policy + env step + record; 16 envs per wavefront, one body (of both legs) per lane in the physics sub-steps",
     }
     rollout_name = "%s (%s)" % (plan.name.decode(), ROLLOUT_NOTES.get(plan.kernel, ""))
     out = {

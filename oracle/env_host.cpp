@@ -354,33 +354,55 @@ void swim_compare(const R* state, const R* ctrl2, int nsub, R* out_scalar, R* ou
 }
 }  // namespace
 
-// ---- lock-step emulation of the one-leg-per-lane form of the two-legged sub-step (rllab_amd/csrc/dyn_two_legs.h) ------
-// The same replay idea: the lane program's only cross-lane operation is x.other(v); pass k answers the first k
-// exchange points from the log and records point k.  Returns, for `nsub` sub-steps from the same (q, qd, tau), the
-// state of the packed form (both legs in two-component values: what HostEnv / the per-step kernels run) and of the
-// two emulated lanes (what rollout_two_leg_quad_kernel runs): they must be bit-identical, and the torso's replicated
-// coordinates must agree between the lanes.
+// ---- lock-step emulation of the one-body-per-lane instantiation of the two-legged sub-step (rllab_amd/csrc/dyn_two_legs.h) ---
+// The same replay idea: the scalar-lane program's only cross-lane operations are the context's lane moves; pass k answers
+// the first k exchange points from the log and records point k.  Returns, for `nsub` sub-steps from the same (q, qd, tau),
+// the state of the eight-component instantiation (what HostEnv / the per-step kernels / the env-per-lane rollouts run)
+// and of eight emulated scalar lanes (what rollout_two_leg_wave_kernel runs with V = float and DPP lane moves): they must
+// be bit-identical on the roles where each value is defined, and the replicated root coordinates must agree on all lanes.
 namespace {
 template <typename R>
-struct PairReplayCtx {
-    int lane, filled;
+struct LaneReplayCtx {
+    int lane, filled;                  // lane = 4 * leg + role
     mutable int counter;
-    std::vector<std::array<R, 2>>* log;
-    R other(R v) const {
+    std::vector<std::array<R, 8>>* log;
+    R move(R v, const int (&from)[8]) const {
         const int k = counter++;
-        if (k < filled) return (*log)[k][lane ^ 1];
+        if (k < filled) return (*log)[k][from[lane]];
         if ((int)log->size() <= k) log->resize(k + 1);
         if (k == filled) (*log)[k][lane] = v;
         return v;   // beyond the recorded prefix: placeholder, this pass's result is discarded
     }
+    R up(R v) const { static const int f[8] = {0, 0, 1, 2, 4, 4, 5, 6}; return move(v, f); }
+    R down(R v) const { static const int f[8] = {1, 2, 3, 3, 5, 6, 7, 7}; return move(v, f); }
+    R nxt(R v) const { static const int f[8] = {0, 2, 3, 1, 4, 6, 7, 5}; return move(v, f); }
+    R prv(R v) const { static const int f[8] = {0, 3, 1, 2, 4, 7, 5, 6}; return move(v, f); }
+    R root(R v) const { static const int f[8] = {0, 0, 0, 0, 4, 4, 4, 4}; return move(v, f); }
+    R first(R v) const { static const int f[8] = {1, 1, 1, 1, 5, 5, 5, 5}; return move(v, f); }
+    R other(R v) const { static const int f[8] = {4, 5, 6, 7, 0, 1, 2, 3}; return move(v, f); }
+    R sel_root(R a, R b) const { return (lane & 3) == 0 ? a : b; }
+    R sel_leaf(R a, R b) const { return (lane & 3) == 3 ? a : b; }
 };
+
+// run `f(ctx, lane)` on the eight lanes in lock step
+template <typename R, class F>
+void lock_step8(F&& f) {
+    std::vector<std::array<R, 8>> log;
+    int n_points = -1;
+    for (int pass = 0; n_points < 0 || pass <= n_points; ++pass)
+        for (int l = 0; l < 8; ++l) {
+            LaneReplayCtx<R> x{l, pass, 0, &log};
+            f(x, l);
+            n_points = x.counter;
+        }
+}
 
 template <class Env, typename R>
 void two_leg_compare(const R* state, const R* tau, int nsub, R* out_packed, R* out_lanes) {
     using Legs = typename Env::Legs;
-    using Tree = typename Env::Tree;
+    using LState = typename Legs::template State<R>;
     const R h = (R)0.0025;
-    // packed: exactly what Env::step runs between step_begin and step_end
+    // eight components: exactly what Env::step runs between step_begin and step_end
     {
         R q[9], qd[9];
         for (int i = 0; i < 9; ++i) { q[i] = state[i]; qd[i] = state[9 + i]; }
@@ -390,62 +412,63 @@ void two_leg_compare(const R* state, const R* tau, int nsub, R* out_packed, R* o
         Legs::template com_of<R>(q, qd, c[0], c[1], c[2], c[3]);
         for (int k = 0; k < 4; ++k) out_packed[18 + k] = c[k];
     }
-    // two lanes
+    // eight scalar lanes, as the one-env-per-wavefront kernel hands the env over and takes it back
     {
-        R sn[7], cs[7];
-        Tree::template angles<R>(state, sn, cs);
-        typename Legs::template State<R> lanes[2];
-        typename Legs::template LegK<R> kc[2];
-        R act[2][3];
-        for (int l = 0; l < 2; ++l) {
-            kc[l] = Legs::template leg_constants<R>(l);
-            for (int r = 0; r < 3; ++r) { lanes[l].qr[r] = state[r]; lanes[l].qdr[r] = state[9 + r]; }
-            lanes[l].sn[0] = sn[0]; lanes[l].cs[0] = cs[0];
-            for (int j = 0; j < 3; ++j) {
-                lanes[l].q[j] = state[3 + 3 * l + j]; lanes[l].qd[j] = state[12 + 3 * l + j];
-                lanes[l].sn[1 + j] = sn[1 + 3 * l + j]; lanes[l].cs[1 + j] = cs[1 + 3 * l + j];
-                act[l][j] = tau[1 + 3 * l + j];
-            }
+        LState lanes[8];
+        typename Legs::template LaneK<R> kc[8];
+        R act[8];
+        for (int l = 0; l < 8; ++l) {
+            const int leg = l >> 2, role = l & 3, j = role == 0 ? 2 : 2 + 3 * leg + role;
+            kc[l] = Legs::template lane_constants<R>(leg, role);
+            lanes[l].q = state[j]; lanes[l].w = state[9 + j];
+            lanes[l].p1 = state[0]; lanes[l].p2 = state[1]; lanes[l].v1 = state[9]; lanes[l].v2 = state[10];
+            act[l] = role == 0 ? (R)0 : tau[3 * leg + role];
         }
+        LState result[8];
+        auto directions = [&]() {
+            lock_step8<R>([&](const LaneReplayCtx<R>& x, int l) {
+                LState s = lanes[l];
+                Legs::template exact_directions<R, R, LaneReplayCtx<R>>(x, s);
+                result[l] = s;
+            });
+            for (int l = 0; l < 8; ++l) lanes[l] = result[l];
+        };
+        lock_step8<R>([&](const LaneReplayCtx<R>& x, int l) {
+            LState s = lanes[l];
+            Legs::template abs_rates<R, R, LaneReplayCtx<R>>(x, s);
+            result[l] = s;
+        });
+        for (int l = 0; l < 8; ++l) lanes[l] = result[l];
+        directions();
         for (int it = 0; it < nsub; ++it) {
-            std::vector<std::array<R, 2>> log;
-            int n_points = -1;
-            typename Legs::template State<R> result[2];
-            for (int pass = 0; n_points < 0 || pass <= n_points; ++pass)
-                for (int l = 0; l < 2; ++l) {
-                    PairReplayCtx<R> x{l, pass, 0, &log};
-                    typename Legs::template State<R> s = lanes[l];
-                    Legs::template substep<R, R, PairReplayCtx<R>>(x, kc[l], s, act[l], h);
-                    n_points = x.counter;
-                    result[l] = s;
-                }
-            lanes[0] = result[0]; lanes[1] = result[1];
+            lock_step8<R>([&](const LaneReplayCtx<R>& x, int l) {
+                LState s = lanes[l];
+                Legs::template substep<R, R, LaneReplayCtx<R>>(x, kc[l], s, act[l], h);
+                result[l] = s;
+            });
+            for (int l = 0; l < 8; ++l) lanes[l] = result[l];
         }
-        for (int r = 0; r < 3; ++r) { out_lanes[r] = lanes[0].qr[r]; out_lanes[9 + r] = lanes[0].qdr[r]; }
-        for (int l = 0; l < 2; ++l)
-            for (int j = 0; j < 3; ++j) { out_lanes[3 + 3 * l + j] = lanes[l].q[j]; out_lanes[12 + 3 * l + j] = lanes[l].qd[j]; }
-        // centre of mass as the kernel forms it: exact sines of the new angles, one chain per lane + one exchange
-        R c[2][4];
-        {
-            for (int l = 0; l < 2; ++l) {
-                R phi = lanes[l].qr[2];
-                rl::rl_sincos(phi, lanes[l].sn[0], lanes[l].cs[0]);
-                for (int j = 0; j < 3; ++j) { phi = phi + lanes[l].q[j]; rl::rl_sincos(phi, lanes[l].sn[1 + j], lanes[l].cs[1 + j]); }
-            }
-            std::vector<std::array<R, 2>> log;
-            int n_points = -1;
-            for (int pass = 0; n_points < 0 || pass <= n_points; ++pass)
-                for (int l = 0; l < 2; ++l) {
-                    PairReplayCtx<R> x{l, pass, 0, &log};
-                    Legs::template com<R, R, PairReplayCtx<R>>(x, kc[l], lanes[l], c[l][0], c[l][1], c[l][2], c[l][3]);
-                    n_points = x.counter;
-                }
+        out_lanes[0] = lanes[0].p1; out_lanes[1] = lanes[0].p2; out_lanes[9] = lanes[0].v1; out_lanes[10] = lanes[0].v2;
+        out_lanes[2] = lanes[0].q; out_lanes[11] = lanes[0].w;
+        for (int l = 1; l < 8; ++l) {
+            if ((l & 3) == 0) continue;
+            const int j = 2 + 3 * (l >> 2) + (l & 3);
+            out_lanes[j] = lanes[l].q; out_lanes[9 + j] = lanes[l].w;
         }
+        // centre of mass as the kernel forms it: exact sines of the new angles, then Legs::com, read on role 0
+        directions();
+        R c[8][4];
+        lock_step8<R>([&](const LaneReplayCtx<R>& x, int l) {
+            Legs::template com<R, R, LaneReplayCtx<R>>(x, kc[l], lanes[l], c[l][0], c[l][1], c[l][2], c[l][3]);
+        });
         for (int k = 0; k < 4; ++k) out_lanes[18 + k] = c[0][k];
-        // the replicated torso coordinates and the centre of mass must agree between the lanes
+        // the replicated root translation must agree on every lane, the torso and the centre of mass between the two role-0 lanes
         bool same = true;
-        for (int r = 0; r < 3; ++r) same = same && lanes[0].qr[r] == lanes[1].qr[r] && lanes[0].qdr[r] == lanes[1].qdr[r];
-        for (int k = 0; k < 4; ++k) same = same && c[0][k] == c[1][k];
+        for (int l = 1; l < 8; ++l)
+            same = same && lanes[l].p1 == lanes[0].p1 && lanes[l].p2 == lanes[0].p2 && lanes[l].v1 == lanes[0].v1 &&
+                   lanes[l].v2 == lanes[0].v2;
+        same = same && lanes[4].q == lanes[0].q && lanes[4].w == lanes[0].w && lanes[4].sn == lanes[0].sn && lanes[4].cs == lanes[0].cs;
+        for (int k = 0; k < 4; ++k) same = same && c[0][k] == c[4][k];
         if (!same) out_lanes[0] = out_lanes[0] * (R)0 + (R)1e30;   // poison: caught by the test
     }
 }

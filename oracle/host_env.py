@@ -233,8 +233,8 @@ lib.oracle_two_leg_compare_f64.argtypes = [ctypes.c_int, _f64p, _f64p, ctypes.c_
 
 
 def two_leg_compare(kind, state, tau, nsub, dtype=np.float32):
-    """(packed, emulated one-leg-per-lane) results of ``nsub`` sub-steps of a two-legged env (kind 3 / 5) from one
-    state (q[9], qd[9]) under hinge torques tau[7]: 22 values each (q, qd, centre of mass and its velocity)."""
+    """(eight-component, emulated one-body-per-scalar-lane) results of ``nsub`` sub-steps of a two-legged env (kind 3 / 5)
+    from one state (q[9], qd[9]) under hinge torques tau[7]: 22 values each (q, qd, centre of mass and its velocity)."""
     dtype = np.dtype(dtype)
     fn = lib.oracle_two_leg_compare_f32 if dtype == np.float32 else lib.oracle_two_leg_compare_f64
     a, b = np.zeros(22, dtype), np.zeros(22, dtype)

@@ -110,7 +110,7 @@ struct HalfCheetah {
         o[17] = cx; o[18] = (R)0; o[19] = cz;
     }
 
-    // Env.step in three parts (the lane-group rollout runs the sub-steps one leg per lane):
+    // Env.step in three parts (the lane-group rollouts run the sub-steps one body per lane):
     //   step_begin : NormalizedEnv action map, ctrl clamp, geared motor torques        (normalized_env.py:78-92)
     //   sub-steps  : SUBSTEPS x TwoLegs::substep
     //   step_end   : observation, reward, done                                         (half_cheetah_env.py:22-46)
@@ -147,7 +147,7 @@ struct HalfCheetah {
                            const StepOpts<R>& o = default_opts<R>()) {
         R act[ACT], tau[CheetahModel::NB];
         step_begin(a, normalize, o, act, tau);
-        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+        // all eight body lanes in one value (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
         Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
         R cz, cx, vz, vx;
         Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);

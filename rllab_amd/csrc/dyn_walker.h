@@ -81,7 +81,7 @@ struct Walker2D {
         o[18] = cx; o[19] = (R)0; o[20] = cz;
     }
 
-    // Env.step in three parts (the lane-group rollout runs the sub-steps one leg per lane); act[ACT] carries the
+    // Env.step in three parts (the lane-group rollouts run the sub-steps one body per lane); act[ACT] carries the
     // clipped action, act[ACT] the control cost accumulated in step_begin
     template <typename R>
     RL_HD static void step_begin(const R* a, int normalize, const StepOpts<R>& o, R* act, R* tau) {
@@ -115,7 +115,7 @@ struct Walker2D {
                            const StepOpts<R>& o = default_opts<R>()) {
         R act[ACT + 1], tau[WalkerModel::NB];
         step_begin(a, normalize, o, act, tau);
-        // both legs side by side in two-component values (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+        // all eight body lanes in one value (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
         Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
         R cz, cx, vz, vx;
         Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);

@@ -1297,16 +1297,54 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) rollout_swimmer_quad_coop_ker
 
 // ---------------------------------------------------------------------------
 // Lane-group rollout of the two-legged envs (HalfCheetah, Walker2D): 16 envs per wavefront, everything per
-// env-step env-per-lane on four replicas exactly as in rollout_kernel, and the physics sub-steps ONE LEG PER LANE
-// (dyn_two_legs.h, V = float): lane 4e + b of env e's quad walks the chain torso -> leg (b & 1), the other leg's
-// contributions to the torso arrive by quad-permute DPP (15 values per sub-step); lanes 2, 3 shadow lanes 0, 1.
-// The legs' state stays in the lanes across env-steps; each step hands the six motor torques in and the new state
-// and the sines of its seven absolute angles (one rl_sincos per lane and body of its chain) back out.
+// env-step env-per-lane on four replicas exactly as in rollout_kernel, and the physics sub-steps ONE BODY PER LANE of
+// the env's quad (dyn_two_legs.h, V = V2<float>: lane 4e + r of env e's quad holds role r = torso / hip link / shin /
+// foot of BOTH legs side by side in two-component values; role moves are quad-permute DPP per component, the other leg
+// is the swapped pair).  The bodies' state stays in the lanes across env-steps; each step hands the six motor torques in
+// and the new state and the centre of mass back out.
 // ---------------------------------------------------------------------------
-struct DppPair {
-    __device__ __forceinline__ float other(float v) const {      // quad_perm [1,0,3,2]
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+// lane moves of dyn_two_legs.h inside a quad: lane i of the quad reads lane P[i]
+struct TwoLegQuadMoves {
+    // quad_perm [a, b, c, d] = a | b << 2 | c << 4 | d << 6
+    enum : int {
+        UP = 0 | 0 << 2 | 1 << 4 | 2 << 6,        // parent role (role 0: itself)
+        DOWN = 1 | 2 << 2 | 3 << 4 | 3 << 6,      // child role (role 3: itself)
+        NXT = 0 | 2 << 2 | 3 << 4 | 1 << 6,       // 1 -> 2 -> 3 -> 1
+        PRV = 0 | 3 << 2 | 1 << 4 | 2 << 6,
+        ROOT = 0,                                 // [0, 0, 0, 0]
+        FIRST = 1 | 1 << 2 | 1 << 4 | 1 << 6,
+        OTHER_ROW_ROR8 = 0x128
+    };
+    template <int CTRL> __device__ __forceinline__ static float mv(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
     }
+};
+// V = float: one body per lane, the other leg eight lanes further in the row of 16 (row_ror:8)
+struct DppBodyLanes : TwoLegQuadMoves {
+    bool is_root, is_leaf;
+    __device__ __forceinline__ float up(float v) const { return mv<UP>(v); }
+    __device__ __forceinline__ float down(float v) const { return mv<DOWN>(v); }
+    __device__ __forceinline__ float nxt(float v) const { return mv<NXT>(v); }
+    __device__ __forceinline__ float prv(float v) const { return mv<PRV>(v); }
+    __device__ __forceinline__ float root(float v) const { return mv<ROOT>(v); }
+    __device__ __forceinline__ float first(float v) const { return mv<FIRST>(v); }
+    __device__ __forceinline__ float other(float v) const { return mv<OTHER_ROW_ROR8>(v); }
+    __device__ __forceinline__ float sel_root(float a, float b) const { return is_root ? a : b; }
+    __device__ __forceinline__ float sel_leaf(float a, float b) const { return is_leaf ? a : b; }
+};
+// V = V2<float>: both legs in the two components, the roles on the lanes of a quad
+struct DppBodyPairs : TwoLegQuadMoves {
+    using P = V2<float>;
+    bool is_root, is_leaf;
+    __device__ __forceinline__ P up(P v) const { return P{mv<UP>(v.x), mv<UP>(v.y)}; }
+    __device__ __forceinline__ P down(P v) const { return P{mv<DOWN>(v.x), mv<DOWN>(v.y)}; }
+    __device__ __forceinline__ P nxt(P v) const { return P{mv<NXT>(v.x), mv<NXT>(v.y)}; }
+    __device__ __forceinline__ P prv(P v) const { return P{mv<PRV>(v.x), mv<PRV>(v.y)}; }
+    __device__ __forceinline__ P root(P v) const { return P{mv<ROOT>(v.x), mv<ROOT>(v.y)}; }
+    __device__ __forceinline__ P first(P v) const { return P{mv<FIRST>(v.x), mv<FIRST>(v.y)}; }
+    __device__ __forceinline__ P other(P v) const { return v.yx; }
+    __device__ __forceinline__ P sel_root(P a, P b) const { return is_root ? a : b; }
+    __device__ __forceinline__ P sel_leaf(P a, P b) const { return is_leaf ? a : b; }
 };
 
 template <class Env, class Pol>
@@ -1323,10 +1361,11 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
     const int i = (i_raw < n) ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
     const size_t plane = (size_t)T * n;
-    // lane-group phase: quad lane / 4 works on the env held by lane q_src, this lane on leg (lane & 1)
-    const int q_src = lane >> 2, leg = lane & 1;
-    const typename Legs::template LegK<float> kc = Legs::template leg_constants<float>(leg);
-    const DppPair dpp;
+    // lane-group phase: quad lane / 4 works on the env held by lane q_src, this lane on role (lane & 3) of both legs
+    using P2 = V2<float>;
+    const int q_src = lane >> 2, role = lane & 3;
+    const typename Legs::template LaneK<P2> kc = Legs::template role_constants<float>(role);
+    const DppBodyPairs dpp{{}, role == 0, role == 3};
 
     float std_[Env::ACT];
 #pragma unroll
@@ -1365,7 +1404,7 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
         return reinterpret_cast<P>(reinterpret_cast<char*>(base + row_elems) + byte_off);
     };
 
-    typename Legs::template State<float> ls;        // resident across env-steps (valid until a reset touches the wavefront)
+    typename Legs::template State<P2> ls;           // resident across env-steps (valid until a reset touches the wavefront)
     bool chain_valid = false;
     const StepOpts<float> base_opts = opts_from_cfg<float>(a.cfg);
 
@@ -1401,7 +1440,7 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
             }
         }
 
-        // ---- Env.step: begin (env per lane) -> sub-steps (one leg per lane) -> end (env per lane) ----
+        // ---- Env.step: begin (env per lane) -> sub-steps (one body per lane) -> end (env per lane) ----
         float eact[Env::ACT_BUF], tau[7];
         StepOpts<float> opts = base_opts;
         float dact[Env::ACT];
@@ -1415,71 +1454,56 @@ __device__ __forceinline__ void two_leg_quad_body(const RolloutDev& a, const Pol
         Env::template step_begin<float>(act, a.normalize, opts, eact, tau);
         float com4[4];
         {
-            float lact[3];
+            // the own hinge's motor torque, both legs (role 0: none)
+            P2 lact = P2{0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float tb = __shfl(tau[1 + j], q_src, 64), tf = __shfl(tau[4 + j], q_src, 64);
-                lact[j] = leg ? tf : tb;
+                lact = (role == 1 + j) ? P2{tb, tf} : lact;
             }
             if (!chain_valid) {
                 // hand the env of lane q_src to its quad (first step, and after a reset anywhere in the wavefront)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    ls.qr[r] = __shfl(s[r], q_src, 64);
-                    ls.qdr[r] = __shfl(s[9 + r], q_src, 64);
-                }
+                const float p1 = __shfl(s[0], q_src, 64), p2 = __shfl(s[1], q_src, 64);
+                const float v1 = __shfl(s[9], q_src, 64), v2 = __shfl(s[10], q_src, 64);
+                ls.p1 = P2{p1, p1}; ls.p2 = P2{p2, p2}; ls.v1 = P2{v1, v1}; ls.v2 = P2{v2, v2};
+                const float q0 = __shfl(s[2], q_src, 64), w0 = __shfl(s[11], q_src, 64);
+                ls.q = P2{q0, q0};
+                ls.w = P2{w0, w0};
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const float qb = __shfl(s[3 + j], q_src, 64), qf = __shfl(s[6 + j], q_src, 64);
                     const float vb = __shfl(s[12 + j], q_src, 64), vf = __shfl(s[15 + j], q_src, 64);
-                    ls.q[j] = leg ? qf : qb;
-                    ls.qd[j] = leg ? vf : vb;
+                    ls.q = (role == 1 + j) ? P2{qb, qf} : ls.q;
+                    ls.w = (role == 1 + j) ? P2{vb, vf} : ls.w;
                 }
-            }
-            // exact sines of the chain's absolute angles (PlanarTree::angles: phi_child = phi_parent + hinge) -- unless
-            // they are the ones evaluated after the previous step's sub-steps
-            if (!chain_valid) {
-                float phi = ls.qr[2];
-                rl_sincos(phi, ls.sn[0], ls.cs[0]);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    phi = phi + ls.q[j];
-                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
-                }
+                // absolute rates and the exact sines of the absolute angles (PlanarTree::angles: phi_child = phi_parent +
+                // hinge) -- otherwise they are the ones evaluated after the previous step's sub-steps
+                Legs::template abs_rates<float, P2, DppBodyPairs>(dpp, ls);
+                Legs::template exact_directions<float, P2, DppBodyPairs>(dpp, ls);
             }
 #pragma unroll 1
             for (int it = 0; it < Env::SUBSTEPS; ++it)
-                Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
-            // the sines of the new angles: the centre of mass of step_end needs them now (each lane its chain's part,
-            // TwoLegs::com), the next step's sub-steps start from them
-            {
-                float phi = ls.qr[2];
-                rl_sincos(phi, ls.sn[0], ls.cs[0]);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    phi = phi + ls.q[j];
-                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
-                }
-            }
+                Legs::template substep<float, P2, DppBodyPairs>(dpp, kc, ls, lact, 0.0025f);
+            // the sines of the new angles: the centre of mass of step_end needs them now (TwoLegs::com), the next step's
+            // sub-steps start from them
+            Legs::template exact_directions<float, P2, DppBodyPairs>(dpp, ls);
             chain_valid = true;
-            float lc[4];
-            Legs::template com<float, float, DppPair>(dpp, kc, ls, lc[0], lc[1], lc[2], lc[3]);
-            // back to the env-per-lane copies: lane 4 el holds the back leg, 4 el + 1 the front leg
+            P2 lc[4];
+            Legs::template com<float, P2, DppBodyPairs>(dpp, kc, ls, lc[0], lc[1], lc[2], lc[3]);
+            // back to the env-per-lane copies: lane 4 el + r holds role r of both legs
             const int base = 4 * el;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                s[r] = __shfl(ls.qr[r], base, 64);
-                s[9 + r] = __shfl(ls.qdr[r], base, 64);
-            }
+            s[0] = __shfl(ls.p1.x, base, 64); s[1] = __shfl(ls.p2.x, base, 64);
+            s[9] = __shfl(ls.v1.x, base, 64); s[10] = __shfl(ls.v2.x, base, 64);
+            s[2] = __shfl(ls.q.x, base, 64); s[11] = __shfl(ls.w.x, base, 64);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                s[3 + j] = __shfl(ls.q[j], base, 64);
-                s[6 + j] = __shfl(ls.q[j], base + 1, 64);
-                s[12 + j] = __shfl(ls.qd[j], base, 64);
-                s[15 + j] = __shfl(ls.qd[j], base + 1, 64);
+                s[3 + j] = __shfl(ls.q.x, base + 1 + j, 64);
+                s[6 + j] = __shfl(ls.q.y, base + 1 + j, 64);
+                s[12 + j] = __shfl(ls.w.x, base + 1 + j, 64);
+                s[15 + j] = __shfl(ls.w.y, base + 1 + j, 64);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) com4[k] = __shfl(lc[k], base, 64);
+            for (int k = 0; k < 4; ++k) com4[k] = __shfl(lc[k].x, base, 64);
         }
         float r;
         bool d;
@@ -1542,8 +1566,11 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_wide_kernel(Rol
 //     one store instruction per array;
 //   * policy noise: lane j draws the Philox block of step t + j every 64 steps (the same (seed; env, step, POLICY)
 //     blocks as every other shape), a step reads its row with v_readlane;
-//   * physics: the one-leg-per-lane program of dyn_two_legs.h unchanged (even lanes the back leg, odd lanes the front
-//     leg; 32 identical copies), state resident across env-steps, hand-over to the per-env arithmetic by v_readlane.
+//   * physics: dyn_two_legs.h with ONE BODY PER LANE (V = float): lane (leg = bit 3, role = bits 0..1) holds the torso /
+//     hip link / shin / foot of its leg, role moves are quad-permute DPP, the other leg is row_ror:8 -- every exchange
+//     fused into the add / multiply that consumes it; 316 vector instructions per sub-step against the 570 of the
+//     former one-leg-per-lane chain walk (round 5).  State resident across env-steps, hand-over to the per-env arithmetic
+//     by v_readlane; one rl_sincos per lane and env-step.
 // Dynamics are bit-identical to every other shape (same leaf functions; replayed against the host build in the parity
 // tests); the policy's means agree with the other shapes to rounding (a different summation order), as between any two
 // of them.
@@ -1714,9 +1741,11 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
     const int i = alive ? i_raw : n - 1;
     const uint32_t env_global = (uint32_t)(a.env_offset + i);
     const size_t plane = (size_t)T * n;
-    const int leg = lane & 1;
-    const typename Legs::template LegK<float> kc = Legs::template leg_constants<float>(leg);
-    const DppPair dpp;
+    // physics: lane = body (leg = bit 3 of the lane, role = its two low bits; the second quad of each leg and the other
+    // three rows repeat the first)
+    const int role = lane & 3, leg = (lane >> 3) & 1;
+    const typename Legs::template LaneK<float> kc = Legs::template lane_constants<float>(leg, role);
+    const DppBodyLanes dpp{{}, role == 0, role == 3};
     const bool obs_lane = alive && lane < Env::OBS, act_lane = alive && lane < Env::ACT, lane0 = alive && lane == 0;
 
     const float std_l = __expf(fmaxf(pol.lstd, a.log_min_std));          // lane a: exp(log_std[a])
@@ -1777,7 +1806,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
 #pragma unroll
         for (int k = 0; k < Env::ACT; ++k) act[k] = lane_bcast(act_l, k);
 
-        // ---- Env.step: begin (per env, all lanes alike) -> sub-steps (one leg per lane) -> end (per env) ----
+        // ---- Env.step: begin (per env, all lanes alike) -> sub-steps (one body per lane) -> end (per env) ----
         float eact[Env::ACT_BUF], tau[7];
         StepOpts<float> opts = base_opts;
         float dact[Env::ACT];
@@ -1791,57 +1820,42 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_wave_kernel(RolloutD
         Env::template step_begin<float>(act, a.normalize, opts, eact, tau);
         float com4[4];
         {
-            float lact[3];
+            // the own hinge's motor torque (role 0: none)
+            float lact = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) lact[j] = leg ? tau[4 + j] : tau[1 + j];
+            for (int j = 0; j < 3; ++j) lact = (role == 1 + j) ? (leg ? tau[4 + j] : tau[1 + j]) : lact;
             if (!chain_valid) {
-                // hand the env to the leg lanes (first step, and after a reset)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    ls.qr[r] = s[r];
-                    ls.qdr[r] = s[9 + r];
-                }
+                // hand the env to the body lanes (first step, and after a reset)
+                ls.p1 = s[0]; ls.p2 = s[1]; ls.v1 = s[9]; ls.v2 = s[10];
+                ls.q = s[2];
+                ls.w = s[11];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    ls.q[j] = leg ? s[6 + j] : s[3 + j];
-                    ls.qd[j] = leg ? s[15 + j] : s[12 + j];
+                    ls.q = (role == 1 + j) ? (leg ? s[6 + j] : s[3 + j]) : ls.q;
+                    ls.w = (role == 1 + j) ? (leg ? s[15 + j] : s[12 + j]) : ls.w;
                 }
-                // exact sines of the chain's absolute angles (PlanarTree::angles: phi_child = phi_parent + hinge)
-                float phi = ls.qr[2];
-                rl_sincos(phi, ls.sn[0], ls.cs[0]);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    phi = phi + ls.q[j];
-                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
-                }
+                // absolute rates, exact sines of the absolute angles (PlanarTree::angles: phi_child = phi_parent + hinge)
+                Legs::template abs_rates<float, float, DppBodyLanes>(dpp, ls);
+                Legs::template exact_directions<float, float, DppBodyLanes>(dpp, ls);
             }
 #pragma unroll RL_TWO_LEG_SUBSTEP_UNROLL
             for (int it = 0; it < Env::SUBSTEPS; ++it)
-                Legs::template substep<float, float, DppPair>(dpp, kc, ls, lact, 0.0025f);
-            {   // the sines of the new angles: step_end's centre of mass needs them now, the next step's sub-steps start from them
-                float phi = ls.qr[2];
-                rl_sincos(phi, ls.sn[0], ls.cs[0]);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    phi = phi + ls.q[j];
-                    rl_sincos(phi, ls.sn[1 + j], ls.cs[1 + j]);
-                }
-            }
+                Legs::template substep<float, float, DppBodyLanes>(dpp, kc, ls, lact, 0.0025f);
+            // the sines of the new angles: step_end's centre of mass needs them now, the next step's sub-steps start from them
+            Legs::template exact_directions<float, float, DppBodyLanes>(dpp, ls);
             chain_valid = true;
             float lc[4];
-            Legs::template com<float, float, DppPair>(dpp, kc, ls, lc[0], lc[1], lc[2], lc[3]);
-            // back to the per-env copy: lane 0 holds the back leg, lane 1 the front leg
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                s[r] = lane_bcast(ls.qr[r], 0);
-                s[9 + r] = lane_bcast(ls.qdr[r], 0);
-            }
+            Legs::template com<float, float, DppBodyLanes>(dpp, kc, ls, lc[0], lc[1], lc[2], lc[3]);
+            // back to the per-env copy: lane r holds role r of the back leg, lane 8 + r of the front leg
+            s[0] = lane_bcast(ls.p1, 0); s[1] = lane_bcast(ls.p2, 0);
+            s[9] = lane_bcast(ls.v1, 0); s[10] = lane_bcast(ls.v2, 0);
+            s[2] = lane_bcast(ls.q, 0); s[11] = lane_bcast(ls.w, 0);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                s[3 + j] = lane_bcast(ls.q[j], 0);
-                s[6 + j] = lane_bcast(ls.q[j], 1);
-                s[12 + j] = lane_bcast(ls.qd[j], 0);
-                s[15 + j] = lane_bcast(ls.qd[j], 1);
+                s[3 + j] = lane_bcast(ls.q, 1 + j);
+                s[6 + j] = lane_bcast(ls.q, 9 + j);
+                s[12 + j] = lane_bcast(ls.w, 1 + j);
+                s[15 + j] = lane_bcast(ls.w, 9 + j);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) com4[k] = lane_bcast(lc[k], 0);
@@ -2091,7 +2105,7 @@ static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
         }
     }
     if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
-        // one leg per lane while every lane-group wavefront still gets a SIMD of its own (two_leg_lane_kernel = 2: the
+        // one body per lane while every lane-group wavefront still gets a SIMD of its own (two_leg_lane_kernel = 2: the
         // generic kernel, for A/B timing and for the tests that run every shape)
         const bool lanes_on = o.two_leg_lane_kernel != 2 && epw_req == 0;
         // one env per wavefront while the wavefronts still find (about) a SIMD each

@@ -435,10 +435,12 @@ def test_swimmer_lane_group_program_is_bitwise_the_scalar_program(dtype, nsub):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kind", [3, 5])
 def test_two_leg_lane_program_is_bitwise_the_packed_program(kind, dtype):
-    """dyn_two_legs.h instantiated one leg per lane (what rollout_two_leg_quad_kernel runs; emulated on the host with a
-    replayed exchange) must reproduce the packed instantiation (both legs in two-component values: the host build and
-    the per-step kernels) bit for bit -- state, and the centre of mass the observation carries -- with feet in the
-    floor, hinges beyond their limits and large rates."""
+    """dyn_two_legs.h instantiated one BODY per scalar lane (what rollout_two_leg_wave_kernel runs with DPP lane moves;
+    emulated on the host: eight lanes in lock step, every lane move replayed from a log) must reproduce the
+    eight-component instantiation (all lanes of an env in one value: the host build, the per-step kernels and the
+    env-per-lane rollouts) bit for bit -- state, and the centre of mass the observation carries -- with feet in the
+    floor, hinges beyond their limits and large rates; the replicated root coordinates must agree on all eight lanes and
+    the torso between its two lanes (the emulator poisons the output otherwise)."""
     rng = np.random.default_rng(5)
     z0 = 0.7 if kind == 3 else 1.25
     touched = 0
