@@ -37,6 +37,9 @@ RECIPES = [
     ("*_resource_usage.txt", "-Rpass-analysis=kernel-resource-usage lines (registers, spills, LDS) of the named kernels", "tools/resource_usage.sh"),
     ("*_preflight*.json", "multi-GPU pre-flight record", "python tools/preflight_multigpu.py"),
     ("*_notes.md", "the round's measurements, experiments and dead ends in prose", "(written by hand from the files of that round)"),
+    ("*_fallback_probe_*.txt", "which constructor options stay on the fused path, and the cost of an iteration (512 envs x 100 steps)",
+     "python tools/exp/fallback_probe.py / tools/exp/fallback_probe_envs.py"),
+    ("curves/r05_*", "tabular training logs of round 5's learning-curve runs", "tools/exp/r05_curves.sh, tools/exp/r05_call13.sh"),
     ("curves/*", "tabular training logs of the learning-curve runs", "tools/learning_curves.sh, tools/exp/r03_*curves*.sh"),
     ("run_profile.sh", "the profile recipe", "-"),
     ("summarize.py", "condenses rocprofv3 output directories into the CSVs kept here", "-"),
@@ -53,6 +56,7 @@ One evidence set per round (older intermediate sets `r01a … r01l` were pruned 
 | 2 | `r02_*` | end of round 2 |
 | 3 | `r03_*` (headline), `r03_split_*` (product kernels), `r03_wide_*` | HEAD of round 3 = `8bd729a`; `pmc_traffic.json` carries the sha256 of `rllab_amd/csrc/*` it was taken at |
 | 4 | `r04_*` | see the stamp in `pmc_traffic.json` and `r04_notes.md` |
+| 5 | `r05_*` (headline, `r05_c5_*` C5's shard, `r05_split_*` product kernels) | one run of `tools/exp/r05_final_a.sh` at the final kernel sources (stamp in `pmc_traffic.json`); `r05_notes.md` |
 """
 
 
