@@ -384,6 +384,85 @@ struct LaneReplayCtx {
     R sel_leaf(R a, R b) const { return (lane & 3) == 3 ? a : b; }
 };
 
+// the quad form: four lanes (the roles), every value a pair (leg 0, leg 1) -- what rollout_two_leg_quad_kernel runs
+template <typename R>
+struct QuadReplayCtx {
+    using P = rl::V2<R>;
+    int lane, filled;                  // lane = role
+    mutable int counter;
+    std::vector<std::array<P, 4>>* log;
+    P move(P v, const int (&from)[4]) const {
+        const int k = counter++;
+        if (k < filled) return (*log)[k][from[lane]];
+        if ((int)log->size() <= k) log->resize(k + 1);
+        if (k == filled) (*log)[k][lane] = v;
+        return v;
+    }
+    P up(P v) const { static const int f[4] = {0, 0, 1, 2}; return move(v, f); }
+    P down(P v) const { static const int f[4] = {1, 2, 3, 3}; return move(v, f); }
+    P nxt(P v) const { static const int f[4] = {0, 2, 3, 1}; return move(v, f); }
+    P prv(P v) const { static const int f[4] = {0, 3, 1, 2}; return move(v, f); }
+    P root(P v) const { static const int f[4] = {0, 0, 0, 0}; return move(v, f); }
+    P first(P v) const { static const int f[4] = {1, 1, 1, 1}; return move(v, f); }
+    P other(P v) const { return v.yx; }
+    P sel_root(P a, P b) const { return lane == 0 ? a : b; }
+    P sel_leaf(P a, P b) const { return lane == 3 ? a : b; }
+};
+template <typename R, class F>
+void lock_step4(F&& f) {
+    std::vector<std::array<rl::V2<R>, 4>> log;
+    int n_points = -1;
+    for (int pass = 0; n_points < 0 || pass <= n_points; ++pass)
+        for (int l = 0; l < 4; ++l) {
+            QuadReplayCtx<R> x{l, pass, 0, &log};
+            f(x, l);
+            n_points = x.counter;
+        }
+}
+// state, centre of mass after nsub sub-steps of the quad form, laid out like two_leg_compare's outputs
+template <class Env, typename R>
+void two_leg_quad_form(const R* state, const R* tau, int nsub, R* out) {
+    using Legs = typename Env::Legs;
+    using P = rl::V2<R>;
+    using QState = typename Legs::template State<P>;
+    const R h = (R)0.0025;
+    QState lanes[4], result[4];
+    typename Legs::template LaneK<P> kc[4];
+    P act[4];
+    for (int r = 0; r < 4; ++r) {
+        kc[r] = Legs::template role_constants<R>(r);
+        const int j0 = r == 0 ? 2 : 2 + r, j1 = r == 0 ? 2 : 5 + r;
+        lanes[r].q = P{state[j0], state[j1]}; lanes[r].w = P{state[9 + j0], state[9 + j1]};
+        lanes[r].p1 = P{state[0], state[0]}; lanes[r].p2 = P{state[1], state[1]};
+        lanes[r].v1 = P{state[9], state[9]}; lanes[r].v2 = P{state[10], state[10]};
+        act[r] = r == 0 ? P{(R)0, (R)0} : P{tau[r], tau[3 + r]};
+    }
+    auto run = [&](auto&& body) {
+        lock_step4<R>([&](const QuadReplayCtx<R>& x, int l) { QState s = lanes[l]; body(x, l, s); result[l] = s; });
+        for (int l = 0; l < 4; ++l) lanes[l] = result[l];
+    };
+    run([&](const QuadReplayCtx<R>& x, int, QState& s) { Legs::template abs_rates<R, P, QuadReplayCtx<R>>(x, s); });
+    run([&](const QuadReplayCtx<R>& x, int, QState& s) { Legs::template exact_directions<R, P, QuadReplayCtx<R>>(x, s); });
+    for (int it = 0; it < nsub; ++it)
+        run([&](const QuadReplayCtx<R>& x, int l, QState& s) { Legs::template substep<R, P, QuadReplayCtx<R>>(x, kc[l], s, act[l], h); });
+    out[0] = lanes[0].p1.x; out[1] = lanes[0].p2.x; out[9] = lanes[0].v1.x; out[10] = lanes[0].v2.x;
+    out[2] = lanes[0].q.x; out[11] = lanes[0].w.x;
+    for (int r = 1; r < 4; ++r) {
+        out[2 + r] = lanes[r].q.x; out[5 + r] = lanes[r].q.y;
+        out[11 + r] = lanes[r].w.x; out[14 + r] = lanes[r].w.y;
+    }
+    run([&](const QuadReplayCtx<R>& x, int, QState& s) { Legs::template exact_directions<R, P, QuadReplayCtx<R>>(x, s); });
+    P c[4][4];
+    lock_step4<R>([&](const QuadReplayCtx<R>& x, int l) {
+        Legs::template com<R, P, QuadReplayCtx<R>>(x, kc[l], lanes[l], c[l][0], c[l][1], c[l][2], c[l][3]);
+    });
+    for (int k = 0; k < 4; ++k) out[18 + k] = c[0][k].x;
+    bool same = lanes[0].q.x == lanes[0].q.y && lanes[0].w.x == lanes[0].w.y;       // the torso, held by both legs
+    for (int k = 0; k < 4; ++k) same = same && c[0][k].x == c[0][k].y;
+    for (int r = 0; r < 4; ++r) same = same && lanes[r].p1.x == lanes[0].p1.y && lanes[r].v2.y == lanes[0].v2.x;
+    if (!same) out[0] = out[0] * (R)0 + (R)1e30;
+}
+
 // run `f(ctx, lane)` on the eight lanes in lock step
 template <typename R, class F>
 void lock_step8(F&& f) {
@@ -485,6 +564,19 @@ int oracle_two_leg_compare_f32(int kind, const float* state, const float* tau, i
 int oracle_two_leg_compare_f64(int kind, const double* state, const double* tau, int nsub, double* out_packed, double* out_lanes) {
     if (kind == 3) two_leg_compare<rl::HalfCheetah, double>(state, tau, nsub, out_packed, out_lanes);
     else if (kind == 5) two_leg_compare<rl::Walker2D, double>(state, tau, nsub, out_packed, out_lanes);
+    else return -1;
+    return 0;
+}
+// the same sub-steps in the quad form (four role lanes, both legs side by side in every value): out[22]
+int oracle_two_leg_quad_form_f32(int kind, const float* state, const float* tau, int nsub, float* out) {
+    if (kind == 3) two_leg_quad_form<rl::HalfCheetah, float>(state, tau, nsub, out);
+    else if (kind == 5) two_leg_quad_form<rl::Walker2D, float>(state, tau, nsub, out);
+    else return -1;
+    return 0;
+}
+int oracle_two_leg_quad_form_f64(int kind, const double* state, const double* tau, int nsub, double* out) {
+    if (kind == 3) two_leg_quad_form<rl::HalfCheetah, double>(state, tau, nsub, out);
+    else if (kind == 5) two_leg_quad_form<rl::Walker2D, double>(state, tau, nsub, out);
     else return -1;
     return 0;
 }

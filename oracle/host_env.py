@@ -232,6 +232,21 @@ lib.oracle_two_leg_compare_f32.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_
 lib.oracle_two_leg_compare_f64.argtypes = [ctypes.c_int, _f64p, _f64p, ctypes.c_int, _f64p, _f64p]
 
 
+lib.oracle_two_leg_quad_form_f32.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int, _f32p]
+lib.oracle_two_leg_quad_form_f64.argtypes = [ctypes.c_int, _f64p, _f64p, ctypes.c_int, _f64p]
+
+
+def two_leg_quad_form(kind, state, tau, nsub, dtype=np.float32):
+    """The same ``nsub`` sub-steps in the quad form (four emulated role lanes, both legs side by side in two-component
+    values: the 16-envs-per-wavefront rollout): 22 values laid out like ``two_leg_compare``'s."""
+    dtype = np.dtype(dtype)
+    fn = lib.oracle_two_leg_quad_form_f32 if dtype == np.float32 else lib.oracle_two_leg_quad_form_f64
+    out = np.zeros(22, dtype)
+    rc = fn(int(kind), np.ascontiguousarray(state, dtype), np.ascontiguousarray(tau, dtype), int(nsub), out)
+    assert rc == 0
+    return out
+
+
 def two_leg_compare(kind, state, tau, nsub, dtype=np.float32):
     """(eight-component, emulated one-body-per-scalar-lane) results of ``nsub`` sub-steps of a two-legged env (kind 3 / 5)
     from one state (q[9], qd[9]) under hinge torques tau[7]: 22 values each (q, qd, centre of mass and its velocity)."""

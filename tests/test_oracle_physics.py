@@ -440,7 +440,8 @@ def test_two_leg_lane_program_is_bitwise_the_packed_program(kind, dtype):
     eight-component instantiation (all lanes of an env in one value: the host build, the per-step kernels and the
     env-per-lane rollouts) bit for bit -- state, and the centre of mass the observation carries -- with feet in the
     floor, hinges beyond their limits and large rates; the replicated root coordinates must agree on all eight lanes and
-    the torso between its two lanes (the emulator poisons the output otherwise)."""
+    the torso between its two lanes (the emulator poisons the output otherwise).  The quad form -- four role lanes, both
+    legs side by side in two-component values, what the 16-envs-per-wavefront rollout runs -- is replayed the same way."""
     rng = np.random.default_rng(5)
     z0 = 0.7 if kind == 3 else 1.25
     touched = 0
@@ -453,6 +454,9 @@ def test_two_leg_lane_program_is_bitwise_the_packed_program(kind, dtype):
             a, b = H.two_leg_compare(kind, np.concatenate([q, qd]), tau, nsub, dtype)
             assert np.all(np.isfinite(a))
             assert a.tobytes() == b.tobytes(), (trial, nsub, a, b)
+            # ... and the quad form (four role lanes, both legs in two-component values: the 16-envs-per-wavefront rollout)
+            c = H.two_leg_quad_form(kind, np.concatenate([q, qd]), tau, nsub, dtype)
+            assert a.tobytes() == c.tobytes(), (trial, nsub, a, c)
         touched += int(q[0] < z0 - 0.15)
     assert touched > 5
 
