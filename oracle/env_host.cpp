@@ -553,6 +553,19 @@ void two_leg_compare(const R* state, const R* tau, int nsub, R* out_packed, R* o
 }
 }  // namespace
 
+// the per-lane constant table of the two-leg program (dyn_two_legs.h lane_constants): out[8][20] =
+// jx, jy, cx, cy, mass, inertia, arm, stiff, damp, lo, hi, mc, cpx[2], cpy[2], crad[2], cmu[2] for lane 4 * leg + role
+template <class Env>
+static void two_leg_lane_table(double* out) {
+    using Legs = typename Env::Legs;
+    for (int l = 0; l < 8; ++l) {
+        const typename Legs::template LaneK<double> k = Legs::template lane_constants<double>(l >> 2, l & 3);
+        double* o = out + 20 * l;
+        o[0] = k.jx; o[1] = k.jy; o[2] = k.cx; o[3] = k.cy; o[4] = k.mass; o[5] = k.inertia; o[6] = k.arm; o[7] = k.stiff;
+        o[8] = k.damp; o[9] = k.lo; o[10] = k.hi; o[11] = k.mc;
+        for (int s2 = 0; s2 < 2; ++s2) { o[12 + s2] = k.cpx[s2]; o[14 + s2] = k.cpy[s2]; o[16 + s2] = k.crad[s2]; o[18 + s2] = k.cmu[s2]; }
+    }
+}
 extern "C" {
 // kind: 3 = HalfCheetah, 5 = Walker2D.  state[18] = (q, qd), tau[7] (tau[0] unused).  out_*[22] = q, qd, centre of mass (4)
 int oracle_two_leg_compare_f32(int kind, const float* state, const float* tau, int nsub, float* out_packed, float* out_lanes) {
@@ -564,6 +577,13 @@ int oracle_two_leg_compare_f32(int kind, const float* state, const float* tau, i
 int oracle_two_leg_compare_f64(int kind, const double* state, const double* tau, int nsub, double* out_packed, double* out_lanes) {
     if (kind == 3) two_leg_compare<rl::HalfCheetah, double>(state, tau, nsub, out_packed, out_lanes);
     else if (kind == 5) two_leg_compare<rl::Walker2D, double>(state, tau, nsub, out_packed, out_lanes);
+    else return -1;
+    return 0;
+}
+// dyn_two_legs.h's per-lane constant table: out[8][20] (see two_leg_lane_table above)
+int oracle_two_leg_lane_table(int kind, double* out) {
+    if (kind == 3) two_leg_lane_table<rl::HalfCheetah>(out);
+    else if (kind == 5) two_leg_lane_table<rl::Walker2D>(out);
     else return -1;
     return 0;
 }

@@ -232,6 +232,17 @@ lib.oracle_two_leg_compare_f32.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_
 lib.oracle_two_leg_compare_f64.argtypes = [ctypes.c_int, _f64p, _f64p, ctypes.c_int, _f64p, _f64p]
 
 
+lib.oracle_two_leg_lane_table.argtypes = [ctypes.c_int, _f64p]
+
+
+def two_leg_lane_table(kind):
+    """dyn_two_legs.h's per-lane constants of a two-legged env, [8 lanes = 4 * leg + role][20]: jx, jy, cx, cy, mass, inertia,
+    arm, stiff, damp, lo, hi, mc, cpx[2], cpy[2], crad[2], cmu[2]."""
+    out = np.zeros((8, 20), np.float64)
+    assert lib.oracle_two_leg_lane_table(int(kind), out) == 0
+    return out
+
+
 lib.oracle_two_leg_quad_form_f32.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int, _f32p]
 lib.oracle_two_leg_quad_form_f64.argtypes = [ctypes.c_int, _f64p, _f64p, ctypes.c_int, _f64p]
 

@@ -578,3 +578,50 @@ def test_inverted_double_pendulum_vs_independent_lagrangian():
         o32, r32, d32 = e32.step(a)
         o64, r64, d64 = e.step(a.astype(np.float64))
         assert np.abs(o32 - o64).max() < 1e-4 and abs(r32 - r64) < 1e-4 and d32 == d64
+
+
+@pytest.mark.parametrize("kind,header,ns", [(3, "cheetah_constants.h", "cheetah"), (5, "walker_constants.h", "walker")])
+def test_two_leg_lane_table_covers_the_model_exactly_once(kind, header, ns):
+    """dyn_two_legs.h hands every lane (leg, role) the constants of ONE body: the table must hold each leg body, each hinge
+    and each contact sphere of the generated model header exactly once, the torso on both legs' role-0 lanes with its
+    spheres split between them (an empty slot has radius -1e30), and the subtree masses the hinges carry."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "rllab_amd", "csrc", header)).read()
+
+    def arr(name):
+        return [float(x) for x in re.search(name + r"\[N[BC]\] = \{([^}]*)\}", hdr).group(1).split(",")]
+    JX, JY, CX, CY, MASS, INERTIA = arr("JX"), arr("JY"), arr("CX"), arr("CY"), arr("MASS"), arr("INERTIA")
+    ARM, STIFF, DAMP, LO, HI = arr("ARMATURE"), arr("STIFFNESS"), arr("DAMPING"), arr("LO"), arr("HI")
+    CBODY, CPX, CPY = [int(v) for v in arr("CBODY")], arr("CPX"), arr("CPY")
+    if ns == "cheetah":
+        rad = float(re.search(r"CRAD = ([0-9.eE+-]+)", hdr).group(1))
+        CRAD, CMU = [rad] * len(CBODY), [0.4] * len(CBODY)
+    else:
+        CRAD, CMU = arr("CRADS"), arr("CMU")
+    t = H.two_leg_lane_table(kind)
+    assert t.shape == (8, 20)
+    seen = []
+    for lane in range(8):
+        leg, role = lane >> 2, lane & 3
+        b = 0 if role == 0 else 3 * leg + role
+        jx, jy, cx, cy, mass, inertia, arm, stiff, damp, lo, hi, mc = t[lane, :12]
+        assert (cx, cy, mass, inertia) == (CX[b], CY[b], MASS[b], INERTIA[b])
+        if role == 0:
+            assert (jx, jy, arm, stiff, damp, mc) == (0, 0, 0, 0, 0, 0) and lo < -1e37 and hi > 1e37
+        else:
+            assert (jx, jy, arm, stiff, damp, lo, hi) == (JX[b], JY[b], ARM[b], STIFF[b], DAMP[b], LO[b], HI[b])
+            last = 3 if leg == 0 else 6
+            assert abs(mc - sum(MASS[b:last + 1])) < 1e-12
+        for s in range(2):
+            px, py, r, mu = t[lane, 12 + s], t[lane, 14 + s], t[lane, 16 + s], t[lane, 18 + s]
+            if r < -1e29:
+                assert role == 0 and (px, py, mu) == (0, 0, 0)     # an empty slot: only a torso lane may have one
+                continue
+            hits = [c for c in range(len(CBODY)) if CBODY[c] == b and (CPX[c], CPY[c], CRAD[c], CMU[c]) == (px, py, r, mu)
+                    and c not in seen]
+            assert hits, (lane, s)
+            seen.append(hits[0])
+    assert sorted(seen) == list(range(len(CBODY)))                  # every sphere of the model, once
+    assert np.array_equal(t[0, 2:6], t[4, 2:6])                     # the torso body on both role-0 lanes
