@@ -1568,7 +1568,7 @@ __global__ void __launch_bounds__(LANE_TPB) rollout_two_leg_quad_wide_kernel(Rol
 //     blocks as every other shape), a step reads its row with v_readlane;
 //   * physics: dyn_two_legs.h with ONE BODY PER LANE (V = float): lane (leg = bit 3, role = bits 0..1) holds the torso /
 //     hip link / shin / foot of its leg, role moves are quad-permute DPP, the other leg is row_ror:8 -- every exchange
-//     fused into the add / multiply that consumes it; 316 vector instructions per sub-step against the 570 of the
+//     fused into the add / multiply that consumes it; 312 vector instructions per sub-step against the 570 of the
 //     former one-leg-per-lane chain walk (round 5).  State resident across env-steps, hand-over to the per-env arithmetic
 //     by v_readlane; one rl_sincos per lane and env-step.
 // Dynamics are bit-identical to every other shape (same leaf functions; replayed against the host build in the parity

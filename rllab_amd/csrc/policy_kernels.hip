@@ -109,8 +109,18 @@ template <bool RELU> __device__ __forceinline__ float act_dz(float h) {
 // ACTS = false: tanh layers (RELU: the regressors' compile-time rectify) -- the instruction stream of every earlier round;
 // ACTS = true: the hidden activations are PolicyBatch.act0 / act1 at run time (rectify policies, the identity layer of a
 // one-hidden-layer policy)
+// wavefronts per SIMD of a pass: the loss pass is a forward + the distribution head -- no accumulators, a third of the
+// registers of the gradient / product passes (92 for the (32, 32) nets, 128 with a dozen spilled for (64, 64)) -- and hides
+// its matrix-result and transcendental latencies behind more wavefronts: 157 -> 138 us per pass over 2.048 M samples of the
+// headline net, 122 -> 104 us over C5's 512 k (RL_POLICY_LOSS_WPS; A/B of both libraries: tools/exp/r05_call19.sh)
+#ifndef RL_POLICY_LOSS_WPS
+#define RL_POLICY_LOSS_WPS 4
+#endif
+template <class N, int MODE>
+constexpr int pass_wps() { return (MODE == MODE_LOSS && N::WPS < RL_POLICY_LOSS_WPS) ? RL_POLICY_LOSS_WPS : N::WPS; }
+
 template <class N, int MODE, bool CACHE, bool RELU = false, bool ACTS = false>
-__global__ void __launch_bounds__(N::WAVES * WV, N::WPS) policy_pass_kernel(PolicyBatch a) {
+__global__ void __launch_bounds__(N::WAVES * WV, (pass_wps<N, MODE>())) policy_pass_kernel(PolicyBatch a) {
     constexpr int WAVES = N::WAVES;
     static_assert(!CACHE || MODE == MODE_GRAD || MODE == MODE_FVP, "activation cache: grad writes, FVP reads");
     static_assert(!RELU || MODE == MODE_LOSS || MODE == MODE_VPG, "rectify nets: loss and log-likelihood gradient");
@@ -839,7 +849,7 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     if (lds > 160 * 1024) return set_error(RL_ERR_UNSUPPORTED, "policy pass needs %zu B of LDS", lds);
     constexpr int WAVES = N::WAVES;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu > N::WPS * 4 / WAVES) blocks_per_cu = N::WPS * 4 / WAVES;
+    if (blocks_per_cu > pass_wps<N, MODE>() * 4 / WAVES) blocks_per_cu = pass_wps<N, MODE>() * 4 / WAVES;
     int grid = 256 * blocks_per_cu;
     const int need = (n_tiles + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
