@@ -52,7 +52,9 @@ const char* rl_last_error(void);
  * 12: rl_policy_batch.gate + rl_line_search_decide (the line search decided on the device); rl_launch_opts (rl_rollout_args.opts,
  * rl_policy_batch.opts, a trailing `variant` / `spin_limit` argument of rl_lfb_normal_eq / rl_peer_allreduce_sum) in place
  * of the library's getenv reads; rl_rollout_plan_query; per-layer hidden activations (layer_activations, RL_ACT_IDENTITY);
- * rl_running_norm (NormalizedEnv's running observation / reward normalisation inside the fused rollout). */
+ * rl_running_norm (NormalizedEnv's running observation / reward normalisation inside the fused rollout).
+ * 13: rl_env_terminates; rl_rollout_args.reset_at_start == 0 continues from last_obs (the sampler's further launches
+ * until batch_size whole-path samples are in, running normalisation included). */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -61,6 +63,14 @@ int rl_abi_version(void);
  * queries (rllab/envs/base.py:31-50).  All outputs are host ints. */
 int rl_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim,
                  int* reset_draws, int* reset_is_normal);
+
+/* 1 when a path of this env kind can end before max_path_length (the env's own done rule: CartpoleEnv.is_current_done,
+ * rllab/envs/box2d/cartpole_env.py:53-56; hopper / walker2d / inverted double pendulum), 0 when the reference env's done
+ * is always False (swimmer_env.py:44, half_cheetah_env.py:45, double_pendulum_env.py:60-61), negative on an unknown kind.
+ * A sampler that has to return at least batch_size samples in whole paths (rllab/algos/batch_polopt.py:23-34,
+ * sandbox/rocky/tf/samplers/vectorized_sampler.py:55) knows from this whether n_envs x max_path_length lock steps are
+ * that many samples by construction or have to be counted. */
+int rl_env_terminates(int kind);
 
 /* Action bounds of the un-normalised env (host arrays of act_dim floats).
  * Replaces Box2DEnv.action_space (box2d_env.py:99-103) and
@@ -218,7 +228,10 @@ typedef struct rl_rollout_args {
     int32_t horizon;          /* T: steps recorded per env in this call */
     int32_t max_path_length;  /* forced done when ts reaches it */
     int32_t normalize;        /* NormalizedEnv action map on/off */
-    int32_t reset_at_start;   /* reset every env before step 0 */
+    int32_t reset_at_start;   /* 1: reset every env before step 0.  0: carry on from state / ts; with last_obs != NULL the
+                                 first observation is last_obs as the previous launch, rl_vecenv_step or rl_vecenv_reset left
+                                 it (observation noise and whitening included, no estimate is fed twice) on the generic /
+                                 wide / dual kernels -- the lane-group kernels re-derive it from the state */
     int32_t hidden0, hidden1; /* tanh MLP hidden sizes: each 32, 64 or 128 (narrower layers: zero padding, exact) */
     int32_t hidden2;          /* third hidden layer, 0 = two layers (network.py:36-101 takes any hidden_sizes tuple) */
     int32_t env_offset;       /* global index of env 0 (multi-GPU sharding) */
@@ -238,7 +251,7 @@ typedef struct rl_rollout_args {
     float* means;             /* float[act_dim][T][n]  agent_info "mean" */
     float* rewards;           /* float[T][n] */
     uint8_t* dones;           /* uint8[T][n]  env done OR ts == max_path_length */
-    float* last_obs;          /* NULL or float[obs_dim][n]: observation after the last step (post-reset) */
+    float* last_obs;          /* NULL or float[obs_dim][n]: observation after the last step (post-reset), in/out */
     const rl_env_cfg* cfg;    /* host; NULL = the env's defaults */
     const float* theta_std;   /* NULL (log_std is the last row of theta), or the parameters of a log-std NETWORK on the
                                  observation -- GaussianMLPPolicy(adaptive_std=True) / std_network=...

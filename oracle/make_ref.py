@@ -19,7 +19,9 @@ Used by
   * oracle/ref_sampler.py -- the ``cpu_baseline`` of bench.py, ``kind: "reference"``:
     the reference's unmodified ``parallel_sampler`` / ``stateful_pool`` / ``rollout`` /
     ``NormalizedEnv`` timed on the GPU box's host cores (SURVEY.md 8d);
-  * tests that cross-check the port (oracle/cpu_sampler.py) against it.
+  * tests that cross-check the port (oracle/cpu_sampler.py) against it;
+  * oracle/ref_vecenv.py -- the reference's VecEnvExecutor over its NormalizedEnv copies on recorded actions
+    (tests/test_gpu_reference_vecenv.py).
 Nothing under rllab_amd/ imports it.
 """
 import hashlib
@@ -41,6 +43,12 @@ ROOTS = [
     "rllab.core.serializable", "rllab.misc.tensor_utils", "rllab.misc.special", "rllab.misc.ext",
     "rllab.misc.logger", "rllab.misc.krylov", "rllab.algos.util", "rllab.baselines.linear_feature_baseline",
     "rllab.baselines.zero_baseline", "rllab.distributions.diagonal_gaussian",
+    # the vectorised precedent's lock-step executor: run by oracle/ref_vecenv.py over the
+    # reference's NormalizedEnv copies as the checker of HipVecEnv.step / the fused rollout's running normalisation
+    "sandbox.rocky.tf.envs.vec_env_executor",
+    # ... and its sampler loop, the statement of the batch-size contract (``while n_samples < batch_size``): run by
+    # oracle/ref_vecsampler.py on a replay of a recorded batch
+    "sandbox.rocky.tf.samplers.vectorized_sampler",
 ]
 EXTRA_FILES = ["examples/trpo_cartpole.py", "examples/trpo_swimmer.py",
                # the reference's own tests of this path, run verbatim against the engine

@@ -3,7 +3,7 @@
 The reference's pure-Python hot-path modules (sampler, stateful_pool, rollout,
 process_samples, NormalizedEnv, Box, krylov, ...) import -- at module level only --
 third-party packages that are not installed here and cannot be (no network): theano,
-lasagne, Box2D, mako, pyprind, cached_property, path, pygame.  None of the functions
+lasagne, Box2D, mako, pyprind, cached_property, path, pygame, tensorflow.  None of the functions
 this repo exercises calls into them, so stub modules are enough.  Two spelling fixes
 for modern libraries: joblib's ``MemmapingPool`` (stateful_pool.py:1) and ``_ast.Num``
 (conjugate_gradient_optimizer.py:10).
@@ -23,7 +23,9 @@ STUBS = ["theano", "theano.tensor", "theano.tensor.nnet", "theano.tensor.signal"
          "lasagne", "lasagne.layers", "lasagne.nonlinearities", "lasagne.init",
          "lasagne.updates", "lasagne.utils", "lasagne.random",
          "Box2D", "pygame", "pygame.locals", "mako", "mako.template", "mako.lookup", "pyprind",
-         "path"]
+         "path",
+         # sandbox/rocky/tf/misc/tensor_utils.py imports it at module level; VecEnvExecutor uses the numpy helpers only
+         "tensorflow"]
 
 
 class _Anything(types.ModuleType):

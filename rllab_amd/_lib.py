@@ -25,7 +25,7 @@ ENV_INVERTED_DOUBLE_PENDULUM = 7
 
 # every symbol include/rllab_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
+    "rl_last_error", "rl_abi_version", "rl_env_query", "rl_env_terminates", "rl_env_action_bounds", "rl_env_default_cfg", "rl_vecenv_com",
     "rl_vecenv_reset", "rl_vecenv_step", "rl_vecenv_step_graph", "rl_counter_add", "rl_vecenv_observe", "rl_rollout_gaussian_mlp", "rl_rollout_plan_query", "rl_rollout_lds_bytes", "rl_gae",
     "rl_discount_cumsum", "rl_debug_philox", "rl_policy_workspace_bytes", "rl_policy_activation_bytes", "rl_policy_loss_kl",
     "rl_policy_grad", "rl_policy_grad_loss", "rl_policy_fvp", "rl_policy_fvp_variant", "rl_policy_fvp_cg_step", "rl_cg_init", "rl_cg_step", "rl_trpo_step", "rl_line_search_point", "rl_line_search_decide", "rl_adam_step",
@@ -178,6 +178,7 @@ def _load():
     lib.rl_last_error.argtypes = []
     lib.rl_abi_version.restype = i32
     lib.rl_env_query.argtypes = [i32, ip, ip, ip, ip, ip]
+    lib.rl_env_terminates.argtypes = [i32]
     lib.rl_env_action_bounds.argtypes = [i32, fp, fp]
     cfgp = ctypes.POINTER(EnvCfg)
     lib.rl_env_default_cfg.argtypes = [i32, cfgp]
@@ -266,8 +267,10 @@ def env_query(kind):
     o, a, s, r, nrm = (ctypes.c_int() for _ in range(5))
     check(lib.rl_env_query(kind, ctypes.byref(o), ctypes.byref(a), ctypes.byref(s), ctypes.byref(r),
                            ctypes.byref(nrm)), "rl_env_query")
+    term = lib.rl_env_terminates(kind)
+    check(min(term, 0), "rl_env_terminates")
     return dict(obs_dim=o.value, act_dim=a.value, state_dim=s.value, reset_draws=r.value,
-                reset_is_normal=bool(nrm.value))
+                reset_is_normal=bool(nrm.value), terminates=bool(term))
 
 
 def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0, layer_activations=0, norm=None,

@@ -37,6 +37,7 @@ struct Cartpole {
     static constexpr int RESET_DRAWS = 4;     // uniform [0,1) draws per reset
     static constexpr bool RESET_NORMAL = false;
     static constexpr int KIND = 0;
+    static constexpr bool TERMINATES = true;   // a path can end before max_path_length: is_current_done (cartpole_env.py:53-56)
     static constexpr bool HAS_COM = false;   // no subtree-COM export (get_body_com is a MujocoEnv method)
 
     template <typename R> struct C {

@@ -68,6 +68,7 @@ struct HalfCheetah {
     static constexpr int RESET_DRAWS = 18;  // N(0,1): 9 for qpos, 9 for qvel (MuJoCo order)
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 3;
+    static constexpr bool TERMINATES = false;   // done is always False (half_cheetah_env.py:45)
     static constexpr int SUBSTEPS = 4;      // 4 x 0.0025 s = one 0.01 s MuJoCo step, frame_skip 1
     using Tree = PlanarTree<CheetahModel>;
     using Legs = TwoLegs<CheetahModel>;

@@ -32,6 +32,7 @@ struct DoublePendulum {
     static constexpr int RESET_DRAWS = 4;  // N(0,1): angle1, angle2, w1, w2
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 1;
+    static constexpr bool TERMINATES = false;   // is_current_done returns False (double_pendulum_env.py:60-61)
     static constexpr bool HAS_COM = false;   // no subtree-COM export (get_body_com is a MujocoEnv method)
     static constexpr int VEL_ITERS = 20;
     static constexpr int POS_ITERS = 20;

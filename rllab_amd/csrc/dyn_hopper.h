@@ -33,6 +33,7 @@ struct Hopper {
     static constexpr int RESET_DRAWS = 12;  // N(0,1): 6 for qpos, 6 for qvel (MuJoCo order)
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 6;
+    static constexpr bool TERMINATES = true;   // a path can end before max_path_length (hopper_env.py:57-61)
     static constexpr int SUBSTEPS = 8;      // 8 x 0.0025 s = one 0.02 s MuJoCo step, frame_skip 1
     static constexpr int NQ = 6;
     using Tree = PlanarTree<HopperModel>;

@@ -49,6 +49,7 @@ struct InvertedDoublePendulum {
     static constexpr int RESET_DRAWS = 1;      // one uniform [0,1) draw: the first pole's start angle
     static constexpr bool RESET_NORMAL = false;
     static constexpr int KIND = 7;
+    static constexpr bool TERMINATES = true;   // a path can end before max_path_length: tip height <= 1 (inverted_double_pendulum_env.py:44)
     static constexpr bool HAS_COM = false;   // no subtree-COM export (get_body_com is a MujocoEnv method)
     static constexpr int SUBSTEPS = 8;         // 8 x 0.0025 s = frame_skip 2 x timestep 0.01
 

@@ -90,6 +90,7 @@ struct Swimmer {
     static constexpr int RESET_DRAWS = 10;  // N(0,1): 5 for qpos, 5 for qvel
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 2;
+    static constexpr bool TERMINATES = false;   // done is always False (swimmer_env.py:44)
     static constexpr int FRAME_SKIP = 50;
     using Tree = PlanarTree<SwimmerModel>;
     using Chain = SwimChain<SwimmerModel>;

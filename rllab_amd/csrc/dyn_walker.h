@@ -36,6 +36,7 @@ struct Walker2D {
     static constexpr int RESET_DRAWS = 18;  // N(0,1): 9 for qpos, 9 for qvel (MuJoCo order)
     static constexpr bool RESET_NORMAL = true;
     static constexpr int KIND = 5;
+    static constexpr bool TERMINATES = true;   // a path can end before max_path_length (walker2d_env.py:47-49)
     static constexpr int SUBSTEPS = 2;      // 2 x 0.0025 s = one 0.005 s MuJoCo step, frame_skip 1
     using Tree = PlanarTree<WalkerModel>;
     using Legs = TwoLegs<WalkerModel>;

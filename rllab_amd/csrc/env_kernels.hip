@@ -878,9 +878,17 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
     }
     float o[Env::OBS];
     float zq[Env::ACT] = {};      // policy noise of four steps, one step per replica group (lane-group shapes)
-    Env::template observe<float>(s, o);
     const size_t obs_z_slice = (size_t)Env::OBS * n;
-    observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
+    // a continuation (reset_at_start == 0) carries on from the observation the previous launch / rl_vecenv_step / reset
+    // left in last_obs -- its observation noise and whitening included, nothing is drawn or fed twice
+    const bool resume_obs = !a.reset_at_start && a.last_obs != nullptr;
+    if (resume_obs) {
+#pragma unroll
+        for (int k = 0; k < Env::OBS; ++k) o[k] = a.last_obs[(size_t)k * n + i];
+    } else {
+        Env::template observe<float>(s, o);
+        observed<Env>(o, a.cfg, a.obs_noise_z, n, i, a.seed, env_global, a.step_counter);
+    }
     // running normalisation (normalized_env.py:33-49): feed the estimate with an observation, optionally whiten it
     double nm[NORM ? Env::OBS : 1], nv[NORM ? Env::OBS : 1], rm = 0.0, rv = 1.0;
     auto feed_obs = [&](float* ob, bool whiten) {
@@ -904,7 +912,7 @@ __device__ __forceinline__ void rollout_body(const RolloutDev& a, const Pol& pol
             for (int k = 0; k < Env::OBS; ++k) { nm[k] = a.nobs_mean[(size_t)k * n + i]; nv[k] = a.nobs_var[(size_t)k * n + i]; }
         }
         if (a.norm_rew) { rm = a.nrew_mean[i]; rv = a.nrew_var[i]; }
-        feed_obs(o, true);            // reset() returns the whitened first observation
+        if (!resume_obs) feed_obs(o, true);      // reset() returns the whitened first observation
     }
 
     uint32_t lane_f32 = (uint32_t)i * 4, lane_u8 = (uint32_t)i;      // byte offset of env i inside a row
@@ -2043,8 +2051,9 @@ static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
         if (!equal || g->theta_std != nullptr)
             return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: running observation / reward normalisation runs on "
                              "the (32,32) / (64,64) kernels only (hidden %d,%d,%d)", g->hidden0, g->hidden1, g->hidden2);
-        if (!g->reset_at_start)
-            return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: running normalisation needs reset_at_start");
+        if (!g->reset_at_start && !g->last_obs && g->state)
+            return set_error(RL_ERR_ARG, "rl_rollout_gaussian_mlp: a continuation under running normalisation starts from "
+                             "last_obs (the whitened observation the previous launch ended on)");
         if (g->cfg && g->cfg->obs_noise != 0.0f && g->norm->normalize_obs)
             return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: obs_noise together with normalize_obs is sampled "
                              "through rl_vecenv_step (the terminal observation's noise draw)");
@@ -2311,6 +2320,12 @@ extern "C" int rl_env_query(int kind, int* obs_dim, int* act_dim, int* state_dim
 #define Q (obs_dim && (*obs_dim = E::OBS), act_dim && (*act_dim = E::ACT),                         \
            state_dim && (*state_dim = E::STATE), reset_draws && (*reset_draws = E::RESET_DRAWS),   \
            reset_is_normal && (*reset_is_normal = E::RESET_NORMAL ? 1 : 0), (int)RL_OK)
+    RL_DISPATCH_ENV(kind, Q)
+#undef Q
+}
+
+extern "C" int rl_env_terminates(int kind) {
+#define Q (E::TERMINATES ? 1 : 0)
     RL_DISPATCH_ENV(kind, Q)
 #undef Q
 }

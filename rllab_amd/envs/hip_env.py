@@ -57,6 +57,8 @@ class HipVecEnv(object):
         self.env_offset = int(env_offset)
         self.auto_reset = bool(auto_reset)
         self.q = _lib.env_query(kind)
+        # can a path end before max_path_length?  (rl_env_terminates: the sampler counts finished samples only then)
+        self.terminates = bool(self.q["terminates"])
         self.device = _require_device()
         self.state = torch.zeros((self.q["state_dim"], self.n), dtype=torch.float32, device=self.device)
         self.ts = torch.zeros((self.n,), dtype=torch.int32, device=self.device)
@@ -181,6 +183,7 @@ class HipVecEnv(object):
         st = torch.as_tensor(np.asarray(state, dtype=np.float32).reshape(self.n, self.q["state_dim"]))
         self.state.copy_(st.t().contiguous())
         self.ts.zero_()
+        self.observe()          # a rollout that carries on (reset_at_start=False) starts from this buffer
 
     # -- fused rollout ---------------------------------------------------------
     def takes_rollout_of(self, policy):
@@ -226,7 +229,8 @@ class HipVecEnv(object):
         """``horizon`` lock-step iterations of get_actions -> step -> record ->
         auto-reset in ONE launch (rl_rollout_gaussian_mlp).  Returns
         ``Trajectories``.  ``eps`` [Da, T, n] / ``reset_draws`` [T+1, R, n] / ``action_noise_z`` [T, Da, n] /
-        ``obs_noise_z`` [T+1, Do, n] inject pre-generated noise (parity runs)."""
+        ``obs_noise_z`` [T+1, Do, n] inject pre-generated noise (parity runs).  ``reset_at_start=False``: the envs carry
+        on from their state, step count and the observation the previous launch / ``step`` / ``reset`` ended on."""
         if self.position_ids is not None and norm is not None:
             raise NotImplementedError("position_only observations under running normalisation: the estimates are over "
                                       "the kept rows; sample through the per-transition path")

@@ -145,9 +145,11 @@ class NormalizingVecEnv(object):
     whitened.  So the inner executor steps without auto-reset, the estimates see the step's observations of all
     copies, then the finished copies are reset under a mask and only their estimates see the reset observations.
     Estimates start from the owning NormalizedEnv's (a snapshot's) and env copy 0's are written back to it when it
-    is pickled or the executor terminates.  Sampled through the per-transition loop (the fused rollout feeds the
-    policy raw observations)."""
-    graphable = False          # the sampler's hipGraph loop talks to the raw executor's buffers
+    is pickled or the executor terminates.  The (32,32) / (64,64) policies are sampled by the fused rollout, which feeds,
+    applies and writes back the same estimate planes inside the kernel (``rollout``, rl_running_norm); every other policy
+    through ``reset`` / ``step`` below, one transition at a time."""
+    graphable = False          # the sampler's hipGraph loop talks to the raw executor's buffers, not to step() below
+    stateful_rollouts = True   # a rollout advances the estimates for good: the sampler never launches one speculatively
 
     def __init__(self, inner, scale_reward, normalize_obs, normalize_reward, obs_alpha, reward_alpha, owner=None):
         self.inner = inner
@@ -188,11 +190,10 @@ class NormalizingVecEnv(object):
     def rollout(self, policy, horizon, reset_at_start=True, **kwargs):
         """One launch for the whole horizon (HipVecEnv.rollout) with this wrapper's running estimates fed, applied and
         written back by the kernel in the reference's order: observations and rewards of the returned batch are the
-        whitened ones, as ``step`` returns them."""
-        if not reset_at_start:
-            raise NotImplementedError("running normalisation: the fused rollout resets every env at its start")
-        return self.inner.rollout(policy, horizon, reset_at_start=True, norm=self, scale_reward=self.scale_reward_outer,
-                                  **kwargs)
+        whitened ones, as ``step`` returns them.  A continuation (``reset_at_start=False``) starts from the whitened
+        observation the previous launch left in the executor's buffer; no estimate is fed twice."""
+        return self.inner.rollout(policy, horizon, reset_at_start=reset_at_start, norm=self,
+                                  scale_reward=self.scale_reward_outer, **kwargs)
 
     def write_back(self, env):
         """Env copy 0's estimates -> the NormalizedEnv that gets pickled (its ``_obs_mean`` / ``_obs_var`` state)."""
@@ -218,13 +219,14 @@ class NormalizingVecEnv(object):
     def reset(self, *args, **kwargs):
         return self._whiten(self.inner.reset(*args, **kwargs))
 
-    def step(self, action_n, **kwargs):
+    def step(self, action_n, reset_draws=None, **kwargs):
+        """``reset_draws`` [R, n]: injected draws of the resets this step triggers (parity runs)."""
         is_np = not torch.is_tensor(action_n)
         a = torch.as_tensor(np.asarray(action_n), device=self.inner.device) if is_np else action_n
         obs, rew, done, info = self.inner.step(a, **kwargs)      # no auto-reset: terminal observations
         obs = self._whiten(obs)
         done = done.clone()
-        fresh = self._whiten(self.inner.reset(mask=done), only=done)   # done copies only; a launch over a mask of
+        fresh = self._whiten(self.inner.reset(mask=done, draws=reset_draws), only=done)   # done copies only; a launch over a mask of
         obs = torch.where(done.unsqueeze(1), fresh, obs)                # zeros when nobody finished (no host sync)
         r = rew.to(torch.float64)
         if self.normalize_reward:

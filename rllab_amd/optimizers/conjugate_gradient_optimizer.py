@@ -140,7 +140,10 @@ class ConjugateGradientOptimizer(Serializable):
         self._fused = None
         # fused device CG only: how many line-search candidates are decided on the device before the host looks
         # (0 = the host decides after every candidate); RLLAB_DEVICE_LINE_SEARCH overrides (A/B timing)
-        self._device_line_search = int(os.environ.get("RLLAB_DEVICE_LINE_SEARCH", "3"))
+        try:
+            self._device_line_search = max(0, int(os.environ.get("RLLAB_DEVICE_LINE_SEARCH", "3")))
+        except ValueError:
+            self._device_line_search = 3
         self._after_enqueue = None   # called once the whole update is enqueued and before its outcome is read
         self.last_backtrack_iters = None
         self.last_before = None      # (loss, constraint value) at the parameters optimize() started from

@@ -447,7 +447,7 @@ class FusedGaussianMLPOps(object):
                 self._epoch += 1                 # (the parameters MAY have moved: every cache keyed on them steps on)
         finally:
             b.gate = None
-        return dict(read=read_async(state), K=K, inv=inv)
+        return dict(read=read_async(state), K=K, inv=inv, state=state, world=brows.shape[0])
 
     def line_search_resolve(self, rec, inputs):
         """Host side of ``line_search_device``: ONE read.  Returns (accepted candidate or None, [(loss, kl)] of the
@@ -461,7 +461,13 @@ class FusedGaussianMLPOps(object):
         evals = [(-(sums[k, 0] * inv), sums[k, 1] * inv) for k in range(n_eval)]
         last = n_eval - 1                        # the parameters are at this candidate now
         host = (float(sums[last, 0] * inv), float(sums[last, 1] * inv), float(sums[last, 2] * inv), float(sums[last, 3]))
-        self._loss_cache = dict(tag=self._eval_point(inputs), out=None, rows=None, inv=inv, dev=None, read=None, host=host)
+        # the record of the current parameters: the candidate's sums (already folded over the ranks by
+        # rl_line_search_decide) as row 0 of a [world, 4] device plane of zeros -- the same shape every other record has,
+        # so loss_stats() and a further device line search from this point read it like any other
+        rows = torch.zeros((rec["world"], 4), dtype=torch.float64, device=rec["state"].device)
+        rows[0].copy_(rec["state"][2 + 4 * last:6 + 4 * last])
+        self._loss_cache = dict(tag=self._eval_point(inputs), out=rows[0], rows=rows, inv=inv, dev=None, read=None,
+                                host=host)
         return accepted, [(float(l), float(c)) for l, c in evals]
 
     def hvp_approach(self):

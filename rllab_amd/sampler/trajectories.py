@@ -43,6 +43,31 @@ class Trajectories(object):
     def device(self):
         return self.rewards.device
 
+    # -- horizons made of several launches ----------------------------------------
+    _PLANES = ("obs", "actions", "means", "log_std_planes")      # [D, T, N]
+    _ROWS = ("rewards", "dones")                                   # [T, N]
+
+    @classmethod
+    def concat(cls, chunks):
+        """Consecutive lock-step chunks of the SAME envs (the later ones launched without a reset) as one batch:
+        the planes joined along the time axis."""
+        if len(chunks) == 1:
+            return chunks[0]
+        first = chunks[0]
+        cat = lambda name, dim: (None if getattr(first, name) is None
+                                 else torch.cat([getattr(c, name) for c in chunks], dim=dim))
+        return cls(cat("obs", 1), cat("actions", 1), cat("means", 1), first.log_std, cat("rewards", 0), cat("dones", 0),
+                   first.max_path_length, log_std_planes=cat("log_std_planes", 1))
+
+    def first_steps(self, steps):
+        """The batch cut after ``steps`` lock steps (contiguous copies; ``self`` when nothing is cut)."""
+        if steps >= self.T:
+            return self
+        cut3 = lambda x: None if x is None else x[:, :steps, :].contiguous()
+        return Trajectories(cut3(self.obs), cut3(self.actions), cut3(self.means), self.log_std,
+                            self.rewards[:steps].contiguous(), self.dones[:steps].contiguous(), self.max_path_length,
+                            log_std_planes=cut3(self.log_std_planes))
+
     @property
     def B(self):
         return self.T * self.N

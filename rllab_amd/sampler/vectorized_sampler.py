@@ -4,8 +4,20 @@ rllab/sampler/parallel_sampler.py, rllab/sampler/stateful_pool.py).
 
 Contract of sandbox/rocky/tf/samplers/vectorized_sampler.py:14-108: every env is
 reset at the start of ``obtain_samples``, envs auto-reset when done, a path ends
-at ``done`` or at ``max_path_length``; trailing unfinished paths are dropped when
-``algo.whole_paths`` (reference default) and kept as truncated paths otherwise.
+at ``done`` or at ``max_path_length``, and the lock-step loop runs
+``while n_samples < batch_size`` (:55) with ``n_samples`` the samples of FINISHED
+paths -- the batch holds at least ``batch_size`` samples in whole paths
+(rllab/algos/batch_polopt.py:23-34, rllab/sampler/parallel_sampler.py:98-126) and the
+paths still running when the loop stops are dropped.  With ``algo.whole_paths=False``
+every recorded step counts, running paths are kept as truncated paths and the batch
+is cut to exactly ``batch_size`` samples in path order (``truncate_paths``,
+parallel_sampler.py:129-155).  Here: one launch of ``max_path_length`` lock steps;
+for env kinds whose ``done`` is always False (Swimmer, HalfCheetah, DoublePendulum)
+that is ``n_envs * max_path_length`` samples in whole paths by construction and
+nothing is counted.  For env kinds that terminate, the finished samples per lock
+step are counted on the device, further launches WITHOUT a reset carry the same envs
+on until the count reaches ``batch_size`` (``_meet_batch_size``), and the batch is cut
+after the lock step at which the reference's loop would have stopped.
 Differences that are the point of the rebuild: all ``n_envs`` copies advance in
 one HIP launch; with a fusable GaussianMLPPolicy the whole ``max_path_length``
 horizon (policy forward, action noise, env step, trajectory record, auto-reset)
@@ -94,6 +106,7 @@ class VectorizedSampler(BaseSampler):
         d["vec_env"] = None
         d.pop("_step_graph", None)
         d.pop("_prefetched", None)
+        d.pop("_carry_obs", None)
         return d
 
     def _takes_fused_rollout(self, policy):
@@ -113,37 +126,61 @@ class VectorizedSampler(BaseSampler):
         writes the previous iteration's log lines and snapshot.  The batch is only handed out if the parameters
         have not changed in between -- which needs ``policy.param_version()`` -- and only the fused rollout is one
         asynchronous launch: for any other policy (no version to check, or the host-bound per-transition loop,
-        where nothing overlaps) this is a no-op, never a rollout that would be thrown away.
+        where nothing overlaps) this is a no-op.  An optimizer that decides its line search on the device calls this
+        BEFORE it knows the outcome: a batch launched at parameters that were then rejected is dropped, and the
+        executor's RNG counter goes back to where it was, so a run samples the same noise with or without the
+        speculation.  An executor that carries state a dropped batch would have advanced for good -- NormalizedEnv's
+        running estimates (``stateful_rollouts``) -- is never prefetched: the reference feeds each estimate exactly
+        once per sampled transition, and a snapshot taken after the prefetch would hold estimates one batch ahead.
         ``BatchPolopt(prefetch_rollout=False)`` turns it off altogether."""
         policy = self.algo.policy
         pre = getattr(self, "_prefetched", None)
         if pre is not None and pre[0] == itr and hasattr(policy, "param_version") and pre[1] == policy.param_version():
             return                               # already queued at these very parameters
-        self._prefetched = None                  # (a batch launched at parameters that have moved on is dropped here)
+        self._drop_prefetched()
         if not hasattr(policy, "param_version") or not self._takes_fused_rollout(policy):
             return
-        t_keep = self.last_sample_time          # the enqueue of the NEXT batch is not this iteration's sample time
-        paths = self.obtain_samples(itr)
-        self.last_sample_time = t_keep
-        self._prefetched = (itr, policy.param_version(), paths)
+        if getattr(self.vec_env, "stateful_rollouts", False):
+            return
+        counter = self.vec_env.step_counter
+        first = self._rollout_chunk(policy, self.algo.max_path_length, True)
+        self._prefetched = (itr, policy.param_version(), first, counter)
+
+    def _drop_prefetched(self):
+        """A batch launched at parameters that have moved on is thrown away; the RNG counter it consumed is given back."""
+        pre = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        if pre is not None and self.vec_env is not None:
+            self.vec_env.step_counter = pre[3]
 
     def obtain_samples(self, itr):
         algo = self.algo
         policy = algo.policy
         pre = getattr(self, "_prefetched", None)
+        first = None
         if pre is not None:
-            self._prefetched = None
             if pre[0] == itr and pre[1] is not None and pre[1] == policy.param_version():
-                return pre[2]
-        T = algo.max_path_length
+                first = pre[2]
+                self._prefetched = None
+            else:
+                self._drop_prefetched()
         t_start = time.time()
+        if first is None:
+            first = self._rollout_chunk(policy, algo.max_path_length, True)
+        traj = self._meet_batch_size(policy, first)
+        self.last_num_samples = traj.B
+        self.last_sample_time = time.time() - t_start  # enqueue time only (+ the count read of a terminating env)
+        return PathList(traj)
+
+    def _rollout_chunk(self, policy, steps, first):
+        """``steps`` lock steps of every env as one ``Trajectories``; ``first``: every env is reset before (the start
+        of ``obtain_samples``), otherwise the envs carry on where the previous chunk left them."""
         graphable = getattr(self.vec_env, "graphable", True)
         if self._takes_fused_rollout(policy):
-            traj = self.vec_env.rollout(policy, T, reset_at_start=True)
-        elif self.use_graph and graphable and not os.environ.get("RLLAB_NO_GRAPH") \
-                and hasattr(policy, "recorded_log_std"):
+            return self.vec_env.rollout(policy, steps, reset_at_start=first)
+        if self.use_graph and graphable and not os.environ.get("RLLAB_NO_GRAPH") and hasattr(policy, "recorded_log_std"):
             try:
-                traj = self._stepwise_rollout_graph(policy, T)
+                return self._stepwise_rollout_graph(policy, steps, first)
             except RuntimeError as err:
                 # a policy whose get_actions cannot be captured (host round trips, data-dependent control flow):
                 # say so once and sample it with the eager loop from here on
@@ -152,12 +189,78 @@ class VectorizedSampler(BaseSampler):
                 self.use_graph = False
                 self._step_graph = None
                 torch.cuda.synchronize()
-                traj = self._stepwise_rollout(policy, T)
+        return self._stepwise_rollout(policy, steps, first)
+
+    # -- the batch-size contract ------------------------------------------------------------------------------------
+    MAX_EXTENSIONS = 64      # further launches before giving up on an env that never finishes a path
+
+    def _path_index(self, traj):
+        """(tin int32 [T, N] step index inside its path, valid bool [T, N] sample of a path that ends in the batch)."""
+        T, N = traj.T, traj.N
+        tin = torch.empty((T, N), dtype=torch.int32, device=traj.device)
+        valid = torch.empty((T, N), dtype=torch.uint8, device=traj.device)
+        _lib.check(_lib.lib.rl_path_scan(T, N, 0, _lib.ptr(traj.dones), None, None, 1, _lib.ptr(tin), _lib.ptr(valid),
+                                         None, _lib.stream_ptr()), "rl_path_scan")
+        return tin, valid.view(torch.bool)
+
+    def _finished_by_step(self, traj):
+        """[T] int64 on the device: samples in the paths that ended at or before lock step t -- ``n_samples`` of the
+        reference's loop after that step (vectorized_sampler.py:55,98-99)."""
+        tin, _ = self._path_index(traj)
+        ended = (tin.to(torch.int64) + 1) * traj.dones.to(torch.int64)
+        return torch.cumsum(ended.sum(dim=1), 0)
+
+    def _meet_batch_size(self, policy, first):
+        """Carry the envs of ``first`` (``max_path_length`` lock steps from a reset) on until the batch holds
+        ``algo.batch_size`` samples in finished paths, and cut it after the lock step at which the reference's loop
+        stops.  ``algo.whole_paths=False``: the first ``batch_size`` of those samples in path order (env by env), the
+        last kept path truncated -- what ``truncate_paths`` leaves of the list (batch_polopt.py:30-34)."""
+        algo, v = self.algo, self.vec_env
+        want, N, T = int(algo.batch_size), first.N, int(algo.max_path_length)
+        chunks = [first]
+        if not getattr(v, "terminates", True) and first.T == T and T > 0:
+            # done is always False: every path is max_path_length steps, a round of T lock steps ends them all together
+            # (nothing to count, nothing read back: the launch stays asynchronous)
+            rounds = max(1, -(-want // (N * T)))
+            for _ in range(rounds - 1):
+                chunks.append(self._rollout_chunk(policy, T, False))
+            traj = Trajectories.concat(chunks)
+            if not algo.whole_paths and traj.B > want:
+                self._keep_first(traj, want, None)
+            return traj
+        for _ in range(self.MAX_EXTENSIONS):
+            traj = Trajectories.concat(chunks)
+            chunks = [traj]
+            finished = self._finished_by_step(traj).cpu()        # the one host read of a terminating env's batch
+            hit = torch.nonzero(finished >= want)
+            if hit.numel() > 0:
+                traj = traj.first_steps(int(hit[0]) + 1)
+                if not algo.whole_paths and int(finished[int(hit[0])]) > want:
+                    self._keep_first(traj, want, self._path_index(traj)[1])
+                return traj
+            short = want - int(finished[-1])
+            # paths still running are finished by the continuation and count then; aim a little past the shortfall
+            k = max(8, -(-3 * short // (2 * N)))
+            chunks.append(self._rollout_chunk(policy, min(k, T) if T > 0 else k, False))
+        raise RuntimeError("VectorizedSampler: %d samples in finished paths after %d further launches, batch_size is %d "
+                           "(an env that never ends a path, and no max_path_length?)"
+                           % (int(finished[-1]), self.MAX_EXTENSIONS, want))
+
+    @staticmethod
+    def _keep_first(traj, want, whole):
+        """``traj.valid`` <- the first ``want`` samples of the finished paths in path order (env by env, then time);
+        the sample the cut falls on ends its path (``truncate_paths``, parallel_sampler.py:129-155).  ``whole``
+        [T, N] bool: samples of paths that end in the batch (None: all of them)."""
+        T, N = traj.T, traj.N
+        dev = traj.device
+        if whole is None:
+            rank = (torch.arange(N, device=dev).unsqueeze(0) * T + torch.arange(T, device=dev).unsqueeze(1)) + 1
+            keep = rank <= want
         else:
-            traj = self._stepwise_rollout(policy, T)
-        self.last_num_samples = traj.B
-        self.last_sample_time = time.time() - t_start  # enqueue time only; bench syncs explicitly
-        return PathList(traj)
+            rank = torch.cumsum(whole.t().reshape(-1).to(torch.int64), 0).reshape(N, T).t()   # 1-based, env-major
+            keep = whole & (rank <= want)
+        traj.valid = keep.contiguous()
+        traj.dones[keep & (rank == want)] = 1
 
     # -- arbitrary vectorised policies: one transition at a time --------------------------------------------------
     # T x (policy kernels, noise, copies, one env-step kernel) is a launch-bound loop: at 4096 envs every kernel in
@@ -222,21 +325,25 @@ class VectorizedSampler(BaseSampler):
         self._step_graph = st
         return st
 
-    def _stepwise_rollout_graph(self, policy, T):
+    def _stepwise_rollout_graph(self, policy, steps, first=True):
         v = self.vec_env
-        v.reset()
+        if first:
+            v.reset()
+        T = max(int(steps), int(self.algo.max_path_length))      # the graph's planes: one full horizon
         st = self._graph_for(policy, T)
         st["t_idx"].zero_()
         st["counter"].fill_(v.step_counter)
-        for _ in range(T):
+        for _ in range(steps):
             st["graph"].replay()
-        v.step_counter += T
+        v.step_counter += steps
+        self._carry_obs = None                                    # (the executor's own buffer holds the last observation)
         # the planes belong to the graph: hand out copies, as the eager path hands out fresh tensors
-        return Trajectories(st["obs_p"].clone(), st["act_p"].clone(), st["mean_p"].clone(),
-                            policy.recorded_log_std(), st["rew_p"].clone(), st["done_p"].clone(),
-                            v.max_path_length, log_std_planes=None if st["ls_p"] is None else st["ls_p"].clone())
+        cp3 = lambda x: x[:, :steps, :].clone()
+        return Trajectories(cp3(st["obs_p"]), cp3(st["act_p"]), cp3(st["mean_p"]),
+                            policy.recorded_log_std(), st["rew_p"][:steps].clone(), st["done_p"][:steps].clone(),
+                            v.max_path_length, log_std_planes=None if st["ls_p"] is None else cp3(st["ls_p"]))
 
-    def _stepwise_rollout(self, policy, T):
+    def _stepwise_rollout(self, policy, T, first=True):
         """Generic vectorised path: one policy.get_actions + one rl_vecenv_step launch per step."""
         v = self.vec_env
         n, do, da = v.n, v.obs_rows, v.q["act_dim"]
@@ -248,7 +355,12 @@ class VectorizedSampler(BaseSampler):
         done_p = torch.empty((T, n), dtype=torch.uint8, device=dev)
         ls_p = torch.empty((da, T, n), dtype=torch.float32, device=dev) \
             if getattr(policy, "state_dependent_std", False) else None
-        obs = v.reset()
+        if first:
+            obs = v.reset()
+        else:         # carry on from the observation the previous chunk ended on (whitened, under running normalisation)
+            obs = getattr(self, "_carry_obs", None)
+            if obs is None:
+                obs = v._filtered(v._obs)
         for t in range(T):
             obs_p[:, t, :] = obs.t()
             actions, info = policy.get_actions(obs)
@@ -259,5 +371,6 @@ class VectorizedSampler(BaseSampler):
             obs, rew, done, _ = v.step(actions)
             rew_p[t] = rew
             done_p[t] = done.to(torch.uint8)
+        self._carry_obs = obs
         return Trajectories(obs_p, act_p, mean_p, policy.recorded_log_std(), rew_p, done_p,
                             v.max_path_length, log_std_planes=ls_p)

@@ -160,72 +160,27 @@ def test_adaptive_std_policy_trains(quiet_logger):
     assert np.mean(rets[-3:]) > 1.5 * np.mean(rets[:3]), rets
 
 
-def test_running_obs_and_reward_normalisation_on_the_vectorised_path(quiet_logger):
-    """NormalizedEnv(normalize_obs=True, normalize_reward=True) keeps ``env.vectorized``: per env copy, the EMA
-    estimates of normalized_env.py:33-49 in float64, reward normalised BEFORE scale_reward (:85-92).  Checked
-    against a numpy restatement fed the raw stream of a twin executor (same seed, same actions)."""
+def test_sampler_takes_running_normalisation_through_the_transition_loop(quiet_logger):
+    """NormalizedEnv(normalize_obs=True, normalize_reward=True) keeps ``env.vectorized``; its arithmetic is pinned to the
+    reference's own classes in tests/test_gpu_reference_vecenv.py.  Here: with obs_noise-free Cartpole and a policy that
+    has a fused kernel the sampler uses the fused rollout; a policy without one goes through reset() / step()."""
     from rllab.envs.box2d.cartpole_env import CartpoleEnv
     from rllab.envs.normalized_env import normalize
     env = normalize(CartpoleEnv(), scale_reward=0.1, normalize_obs=True, normalize_reward=True, obs_alpha=0.01,
                     reward_alpha=0.02)
     assert env.vectorized
-    n, T = 33, 40
-    v = env.vec_env_executor(n_envs=n, max_path_length=15, seed=4)
-    # the twin replays the wrapper's own launch sequence on a raw executor: step without auto-reset (terminal
-    # observations), then a masked reset of the finished copies
-    raw = normalize(CartpoleEnv()).vec_env_executor(n_envs=n, max_path_length=15, seed=4, auto_reset=False)
-    rng = np.random.RandomState(0)
-    mean, var = np.zeros((n, 4)), np.ones((n, 4))
-    rmean, rvar = np.zeros(n), np.ones(n)
-
-    def whiten(o, only=None):
-        nonlocal mean, var
-        m = 0.99 * mean + 0.01 * o
-        s2 = 0.99 * var + 0.01 * np.square(o - m)
-        if only is not None:
-            m, s2 = np.where(only[:, None], m, mean), np.where(only[:, None], s2, var)
-        mean, var = m, s2
-        return (o - mean) / (np.sqrt(var) + 1e-8)
-    o = v.reset().cpu().numpy().astype(np.float64)
-    o_raw = raw.reset().cpu().numpy().astype(np.float64)
-    np.testing.assert_allclose(o, whiten(o_raw), rtol=0, atol=1e-6)
-    n_done = 0
-    for t in range(T):
-        a = torch.as_tensor(rng.randn(n, 1).astype(np.float32), device="cuda")
-        o, r, d, _ = v.step(a)
-        o_raw, r_raw, d_raw, _ = raw.step(a)
-        assert torch.equal(d, d_raw)
-        # reference order (vec_env_executor.py:16-28 over NormalizedEnv copies): every copy's estimate sees the
-        # observation its step produced, the terminal one included; a finished copy then resets, its estimate sees
-        # the reset observation as well and that one is returned
-        want = whiten(o_raw.cpu().numpy().astype(np.float64))
-        dn = d_raw.cpu().numpy()
-        o_reset = raw.reset(mask=d_raw).cpu().numpy().astype(np.float64)
-        want = np.where(dn[:, None], whiten(o_reset, only=dn), want)
-        n_done += int(dn.sum())
-        np.testing.assert_allclose(o.cpu().numpy(), want, rtol=0, atol=1e-5)
-        rr = r_raw.cpu().numpy().astype(np.float64)
-        rmean = 0.98 * rmean + 0.02 * rr
-        rvar = 0.98 * rvar + 0.02 * np.square(rr - rmean)
-        np.testing.assert_allclose(r.cpu().numpy(), rr / (np.sqrt(rvar) + 1e-8) * 0.1, rtol=1e-5, atol=1e-6)
-    assert n_done > n                                    # terminal observations were part of the stream
-    # the estimates travel with the env: pickling it (what every snapshot does) takes env copy 0's, and an executor
-    # made from the unpickled env resumes from them instead of mean 0 / var 1
-    import pickle
-    clone = pickle.loads(pickle.dumps(env))
-    np.testing.assert_allclose(clone._obs_stats.mean, mean[0], rtol=0, atol=1e-12)
-    np.testing.assert_allclose(clone._obs_stats.var, var[0], rtol=0, atol=1e-12)
-    v2 = clone.vec_env_executor(n_envs=3, max_path_length=15, seed=4)
-    np.testing.assert_allclose(v2.obs_mean.cpu().numpy(), np.tile(mean[0][:, None], (1, 3)), rtol=0, atol=1e-12)
-    # and the sampler takes such an env through the per-transition loop
     from rllab.algos.vpg import VPG
     from rllab.baselines.zero_baseline import ZeroBaseline
     from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
-    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
-    algo = VPG(env=env, policy=policy, baseline=ZeroBaseline(env_spec=env.spec), batch_size=32 * 30, max_path_length=30,
-               n_itr=2, sampler_args=dict(n_envs=32))
-    algo.train()
-    assert np.isfinite(policy.get_param_values()).all()
+    for hidden, fused in (((32, 32), True), ((48, 24), False)):
+        policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=hidden)
+        algo = VPG(env=env, policy=policy, baseline=ZeroBaseline(env_spec=env.spec), batch_size=32 * 30,
+                   max_path_length=30, n_itr=2, sampler_args=dict(n_envs=32))
+        algo.start_worker()
+        assert algo.sampler.sampling_path(policy)[0].startswith("fused rollout kernel") == fused
+        algo.shutdown_worker()
+        algo.train()
+        assert np.isfinite(policy.get_param_values()).all()
 
 
 @pytest.mark.parametrize("do,da,h", [(4, 1, 32), (13, 2, 32), (20, 6, 64)])
@@ -437,89 +392,6 @@ def test_trpo_learns_on_the_kernels_with_one_hidden_layer_or_rectify(hidden, nl,
 
 
 # ---- NormalizedEnv(normalize_obs / normalize_reward) inside the fused rollout (round 5: rl_running_norm) -----------------
-@pytest.mark.parametrize("env_name,flags", [("cartpole", (True, True)), ("swimmer", (True, False)), ("cheetah", (True, True)),
-                                            ("cartpole", (False, True))])
-@pytest.mark.parametrize("epw", ["16", "64"])
-def test_fused_rollout_with_running_normalisation_replays_on_the_host(env_name, flags, epw, monkeypatch, quiet_logger):
-    """The whole horizon in ONE launch with the wrapper's per-env running estimates in the kernel: every recorded
-    transition replays on the host build of the dynamics (oracle/host_env.py, float32) under a numpy restatement of
-    normalized_env.py:33-49,78-92 -- estimate fed by every step's observation, the terminal one included, and once more by
-    the reset observation; whitened observation = (x - mean) / (sqrt(var) + 1e-8) with the UPDATED mean; reward
-    normalised, then scaled -- observations / rewards within 2e-6, the estimates left on the device within 1e-12, means
-    within 1e-5 of a float64 forward of the recorded (whitened) observations."""
-    import importlib
-    from oracle import host_env as H
-    from rllab.envs.normalized_env import normalize
-    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
-    mod, cls = dict(cartpole=("rllab.envs.box2d.cartpole_env", "CartpoleEnv"), swimmer=("rllab.envs.mujoco.swimmer_env", "SwimmerEnv"),
-                    cheetah=("rllab.envs.mujoco.half_cheetah_env", "HalfCheetahEnv"))[env_name]
-    monkeypatch.setenv("RLLAB_ROLLOUT_EPW", epw)
-    nobs, nrew = flags
-    oa, ra, scale = 0.01, 0.02, 0.25
-    env = normalize(getattr(importlib.import_module(mod), cls)(), scale_reward=scale, normalize_obs=nobs, normalize_reward=nrew,
-                    obs_alpha=oa, reward_alpha=ra)
-    np.random.seed(3)
-    pol = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
-    n, T, mpl = 37, 30, 9
-    v = env.vec_env_executor(n_envs=n, max_path_length=mpl, seed=6)
-    assert v.takes_rollout_of(pol)
-    plan = v.rollout_plan(pol, T)
-    assert plan.kernel == 1 and plan.envs_per_wavefront == int(epw) and b"norm" in plan.name
-    q = v.q
-    do, da = q["obs_dim"], q["act_dim"]
-    rng = np.random.RandomState(1)
-    eps = rng.randn(da, T, n).astype(np.float32)
-    draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
-    # a pre-existing estimate (a resumed snapshot): the kernel must start from it, not from mean 0 / var 1
-    v.obs_mean += torch.as_tensor(0.1 * rng.randn(do, n), device=v.obs_mean.device)
-    v.reward_var *= 1.5
-    m0, v0 = v.obs_mean.cpu().numpy().copy(), v.obs_var.cpu().numpy().copy()
-    rm0, rv0 = v.reward_mean.cpu().numpy().copy(), v.reward_var.cpu().numpy().copy()
-    traj = v.rollout(pol, T, eps=eps, reset_draws=draws)
-    obs = traj.obs.cpu().numpy().astype(np.float64)
-    act, rew, done = traj.actions.cpu().numpy(), traj.rewards.cpu().numpy().astype(np.float64), traj.dones.cpu().numpy()
-    n_term = 0
-    for i in range(n):
-        mean, var, rm, rv = m0[:, i].copy(), v0[:, i].copy(), float(rm0[i]), float(rv0[i])
-
-        def feed(x, mean=mean, var=var):
-            x = x.astype(np.float64)
-            if not nobs:
-                return x
-            mean[:] = (1 - oa) * mean + oa * x
-            var[:] = (1 - oa) * var + oa * np.square(x - mean)
-            return (x - mean) / (np.sqrt(var) + 1e-8)
-        he = H.HostEnv(v.kind, np.float32, normalize=True, cfg={})
-        o = feed(he.reset(draws[0, :, i]))
-        ts = 0
-        for t in range(T):
-            np.testing.assert_allclose(obs[:, t, i], o, rtol=2e-6, atol=2e-6, err_msg="obs env %d t %d" % (i, t))
-            o_raw, r, d = he.step(act[:, t, i])
-            ts += 1
-            d = d or ts >= mpl
-            r = float(np.float32(r))
-            if nrew:
-                rm = (1 - ra) * rm + ra * r
-                rv = (1 - ra) * rv + ra * (r - rm) ** 2
-                r = r / (np.sqrt(rv) + 1e-8)
-            assert abs(rew[t, i] - r * scale) <= 2e-6 * max(1.0, abs(r * scale)), (i, t, rew[t, i], r * scale)
-            assert bool(done[t, i]) == bool(d)
-            o = feed(o_raw)
-            if d:
-                n_term += 1
-                o = feed(he.reset(draws[t + 1, :, i]))
-                ts = 0
-        if nobs:
-            assert np.allclose(v.obs_mean[:, i].cpu().numpy(), mean, rtol=1e-12, atol=1e-14)
-            assert np.allclose(v.obs_var[:, i].cpu().numpy(), var, rtol=1e-12, atol=1e-14)
-        if nrew:
-            assert abs(float(v.reward_mean[i]) - rm) <= 1e-12 * max(1.0, abs(rm)) and abs(float(v.reward_var[i]) - rv) <= 1e-12 * rv
-    assert n_term >= n                                  # terminal observations were part of the stream
-    with torch.no_grad():
-        mean64 = pol.mean_planes(traj.obs.reshape(do, -1).double(), pol.flat_params.double())
-    assert float((traj.means.reshape(da, -1).double() - mean64).abs().max()) <= 1e-5
-
-
 def test_trpo_with_running_normalisation_stays_on_the_fused_rollout(quiet_logger):
     from rllab.algos.trpo import TRPO
     from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
