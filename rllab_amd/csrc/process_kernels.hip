@@ -96,6 +96,101 @@ path_scan_kernel(int T, int n, int Do, const uint8_t* __restrict__ done, const f
     }
 }
 
+// The same scan with the chunk's done flags in registers (read once instead of four times) and the baseline
+// prediction restructured so that a thread has its chunk's L <= LMAX observation loads of one component in flight at a
+// time (d outer, steps inner: the loop above issues one dependent load per feature); EW = 16 envs per workgroup fill
+// the chip at 4096 envs, neighbouring env groups on one XCD (they share the rows' 128-B lines) -- scan_kernels.hip's
+// gae_reg_kernel has the reasoning.  Features are accumulated in the reference's order per sample: bit-identical values.
+template <int LMAX, int EW>
+__global__ void __launch_bounds__(1024)
+path_scan_reg_kernel(int T, int n, int L, int Do, const uint8_t* __restrict__ done, const float* __restrict__ obs,
+                     const double* __restrict__ coeffs, int whole_paths, int32_t* __restrict__ tin,
+                     uint8_t* __restrict__ valid, double* __restrict__ values) {
+    extern __shared__ int s_scan[];            // [KB][EW] last path start inside the chunk or -1 | [KB][EW] any done inside
+    __shared__ double s_w[2 * MAX_DO + 4];
+    const int e = threadIdx.x, k = threadIdx.y, KB = blockDim.y;
+    const int G = gridDim.x, w = blockIdx.x;
+    const int g = (G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w;
+    const int i = g * EW + e;
+    const int t0 = k * L, t1 = min(T, t0 + L);
+    const bool live = (i < n) && (t0 < T);
+    const int F = 2 * Do + 4;
+    if (coeffs)
+        for (int f = threadIdx.y * EW + threadIdx.x; f < F; f += EW * KB) s_w[f] = coeffs[f];
+    uint32_t dn = 0;                           // bit j: done[t0 + j]
+    bool prev_done = true;                     // done[t0 - 1] (a path starts at t = 0)
+    if (live) {
+        uint8_t dd[LMAX];
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) dd[j] = done[(size_t)(t0 + j < t1 ? t0 + j : t0) * n + i];
+        if (t0 > 0) prev_done = done[(size_t)(t0 - 1) * n + i] != 0;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) dn |= (t0 + j < t1 && dd[j]) ? (1u << j) : 0u;
+    }
+    int last = -1;
+    if (live) {
+        // path starts inside the chunk: t0 if prev_done, t0 + j + 1 for every done bit j with t0 + j + 1 < t1
+        const uint32_t starts = ((dn << 1) | (prev_done ? 1u : 0u)) & ((L >= 32) ? 0xffffffffu : ((1u << (t1 - t0)) - 1u));
+        if (starts) last = t0 + (31 - __clz(starts));
+    }
+    s_scan[k * EW + e] = last;
+    s_scan[(KB + k) * EW + e] = dn != 0;
+    __syncthreads();
+    if (!live) return;
+    int cur = -1;                      // last start before this chunk
+    for (int j = 0; j < k; ++j) cur = max(cur, s_scan[j * EW + e]);
+    int later = 0;                     // any done after this chunk
+    for (int j = k + 1; j < KB; ++j) later |= s_scan[(KB + j) * EW + e];
+    int ti[LMAX];
+    bool start = prev_done;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        if (start) cur = t0 + j;
+        ti[j] = t0 + j - cur;
+        start = (dn >> j) & 1u;
+    }
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        if (t0 + j < t1) {
+            const size_t off = (size_t)(t0 + j) * n + i;
+            tin[off] = ti[j];
+            valid[off] = (!whole_paths || (dn >> j) != 0u || later) ? 1 : 0;     // a done flag at or after this step
+        }
+    }
+    if (!values) return;
+    double acc[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) acc[j] = 0.0;
+    if (coeffs) {
+        const size_t plane = (size_t)T * n;
+        for (int d = 0; d < Do; ++d) {
+            float ob[LMAX];
+#pragma unroll
+            for (int j = 0; j < LMAX; ++j) ob[j] = obs[(size_t)d * plane + (size_t)(t0 + j < t1 ? t0 + j : t0) * n + i];
+            const double w0 = s_w[d], w1 = s_w[Do + d];
+#pragma unroll
+            for (int j = 0; j < LMAX; ++j) {
+                double o = (double)ob[j];
+                o = fmin(fmax(o, -10.0), 10.0);
+                acc[j] = fma(w0, o, acc[j]);
+                acc[j] = fma(w1, o * o, acc[j]);
+            }
+        }
+        const double wa = s_w[2 * Do], wb = s_w[2 * Do + 1], wc = s_w[2 * Do + 2], wd = s_w[2 * Do + 3];
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) {
+            const double al = (double)ti[j] / 100.0;
+            acc[j] = fma(wa, al, acc[j]);
+            acc[j] = fma(wb, al * al, acc[j]);
+            acc[j] = fma(wc, al * al * al, acc[j]);
+            acc[j] = fma(wd, 1.0, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j)
+        if (t0 + j < t1) values[(size_t)(t0 + j) * n + i] = acc[j];
+}
+
 // ---------------------------------------------------------------------------------------------
 // one-pass batch statistics
 // ---------------------------------------------------------------------------------------------
@@ -396,6 +491,21 @@ extern "C" int rl_path_scan(int T, int n, int obs_dim, const uint8_t* dones, con
     if (T <= 0 || n <= 0 || !dones || !tin || !valid || obs_dim < 0 || obs_dim > MAX_DO ||
         (values && coeffs && !obs))
         return set_error(RL_ERR_ARG, "rl_path_scan: bad argument (obs_dim <= %d)", MAX_DO);
+    constexpr int LMAX = 16;
+    const bool narrow = (n + 31) / 32 < 1024;
+    const int ew = narrow ? 16 : 32, kb_max = narrow ? 64 : 32;
+    if (T <= kb_max * LMAX) {
+        const int L = (T + kb_max - 1) / kb_max, KB = (T + L - 1) / L;
+        dim3 grid((n + ew - 1) / ew), block(ew, KB);
+        const size_t lds = (size_t)2 * KB * ew * sizeof(int);
+        if (narrow)
+            hipLaunchKernelGGL((path_scan_reg_kernel<LMAX, 16>), grid, block, lds, (hipStream_t)stream, T, n, L, obs_dim, dones,
+                               obs, coeffs, whole_paths, tin, valid, values);
+        else
+            hipLaunchKernelGGL((path_scan_reg_kernel<LMAX, 32>), grid, block, lds, (hipStream_t)stream, T, n, L, obs_dim, dones,
+                               obs, coeffs, whole_paths, tin, valid, values);
+        return check_launch("path_scan_reg_kernel");
+    }
     dim3 grid((n + PS_EW - 1) / PS_EW), block(PS_EW, PS_KB);
     hipLaunchKernelGGL(path_scan_kernel, grid, block, 0, (hipStream_t)stream, T, n, obs_dim, dones, obs, coeffs,
                        whole_paths, tin, valid, values);

@@ -214,9 +214,14 @@ class VectorizedSampler(BaseSampler):
         """Carry the envs of ``first`` (``max_path_length`` lock steps from a reset) on until the batch holds
         ``algo.batch_size`` samples in finished paths, and cut it after the lock step at which the reference's loop
         stops.  ``algo.whole_paths=False``: the first ``batch_size`` of those samples in path order (env by env), the
-        last kept path truncated -- what ``truncate_paths`` leaves of the list (batch_polopt.py:30-34)."""
+        last kept path truncated -- what ``truncate_paths`` leaves of the list (batch_polopt.py:30-34).
+        Sharded over ranks (each with ``n_envs`` envs and ``batch_size`` samples of the job's world x batch_size): the
+        count is the sum over the shards -- one sum all-reduce of the [T] per-step counts per look, for env kinds that
+        terminate -- so every rank carries on by the same number of lock steps and cuts at the same one, and the job
+        samples exactly what one process with all the envs would."""
         algo, v = self.algo, self.vec_env
-        want, N, T = int(algo.batch_size), first.N, int(algo.max_path_length)
+        world, rank = D.world_size(), D.rank()
+        want, N, T = int(algo.batch_size) * world, first.N * world, int(algo.max_path_length)
         chunks = [first]
         if not getattr(v, "terminates", True) and first.T == T and T > 0:
             # done is always False: every path is max_path_length steps, a round of T lock steps ends them all together
@@ -225,18 +230,21 @@ class VectorizedSampler(BaseSampler):
             for _ in range(rounds - 1):
                 chunks.append(self._rollout_chunk(policy, T, False))
             traj = Trajectories.concat(chunks)
-            if not algo.whole_paths and traj.B > want:
-                self._keep_first(traj, want, None)
+            if not algo.whole_paths and N * traj.T > want:
+                self._keep_first(traj, want - rank * traj.B, None)
             return traj
         for _ in range(self.MAX_EXTENSIONS):
             traj = Trajectories.concat(chunks)
             chunks = [traj]
-            finished = self._finished_by_step(traj).cpu()        # the one host read of a terminating env's batch
+            finished = D.all_reduce_sum_(self._finished_by_step(traj)).cpu()   # the one host read of such a batch
             hit = torch.nonzero(finished >= want)
             if hit.numel() > 0:
                 traj = traj.first_steps(int(hit[0]) + 1)
                 if not algo.whole_paths and int(finished[int(hit[0])]) > want:
-                    self._keep_first(traj, want, self._path_index(traj)[1])
+                    whole = self._path_index(traj)[1]
+                    mine = whole.sum().reshape(1)
+                    before = int(D.all_gather_rows(mine)[:rank].sum()) if world > 1 else 0   # path order: rank by rank
+                    self._keep_first(traj, want - before, whole)
                 return traj
             short = want - int(finished[-1])
             # paths still running are finished by the continuation and count then; aim a little past the shortfall
@@ -253,6 +261,7 @@ class VectorizedSampler(BaseSampler):
         [T, N] bool: samples of paths that end in the batch (None: all of them)."""
         T, N = traj.T, traj.N
         dev = traj.device
+        want = max(0, min(int(want), T * N))      # (a shard behind the cut keeps nothing, one before it everything)
         if whole is None:
             rank = (torch.arange(N, device=dev).unsqueeze(0) * T + torch.arange(T, device=dev).unsqueeze(1)) + 1
             keep = rank <= want

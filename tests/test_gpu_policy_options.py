@@ -172,7 +172,7 @@ def test_sampler_takes_running_normalisation_through_the_transition_loop(quiet_l
     from rllab.algos.vpg import VPG
     from rllab.baselines.zero_baseline import ZeroBaseline
     from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
-    for hidden, fused in (((32, 32), True), ((48, 24), False)):
+    for hidden, fused in (((32, 32), True), ((100, 50, 25), False)):
         policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=hidden)
         algo = VPG(env=env, policy=policy, baseline=ZeroBaseline(env_spec=env.spec), batch_size=32 * 30,
                    max_path_length=30, n_itr=2, sampler_args=dict(n_envs=32))

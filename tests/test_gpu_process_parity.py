@@ -228,7 +228,8 @@ def test_cartpole_whole_paths_drop_incomplete_tails(quiet_logger):
         sd = algo.sampler.process_samples(0, paths)
         tr = paths.traj
         n_valid = int(tr.valid.sum())
-        assert (n_valid == tr.B) == (not whole)
+        # at least batch_size samples in finished paths; whole_paths=False cuts the list to exactly batch_size
+        assert (512 * 100 <= n_valid < tr.B) if whole else (n_valid == 512 * 100)
         assert sd["observations"].shape[0] == n_valid
         lens = [len(p["rewards"]) for p in list(paths)[:50]]
         assert max(lens) <= 100 and min(lens) >= 1

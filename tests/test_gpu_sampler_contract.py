@@ -141,7 +141,7 @@ def test_whole_paths_false_cuts_to_exactly_batch_size(name, batch_size, T, n_env
 
 
 @pytest.mark.parametrize("hidden,norm,loop", [((300,), None, "hipGraph replay"),
-                                              ((48, 24), dict(normalize_obs=True, normalize_reward=True), "eager")])
+                                              ((100, 50, 25), dict(normalize_obs=True, normalize_reward=True), "eager")])
 def test_per_transition_loops_meet_the_contract_too(hidden, norm, loop, quiet_logger):
     algo = make_algo("cartpole", 2000, 50, None, hidden=hidden, norm=norm)
     name, _why = algo.sampler.sampling_path(algo.policy)
