@@ -20,6 +20,9 @@ Extra objects on the JSON line:
                   launch stream.  The kernel fuses 50 physics sub-steps per env-step in
                   registers and is VALU/latency bound, so the HBM fraction is tiny by
                   construction; `valu_tflops` gives the other axis.
+  roofline_scan -- the HBM-bound kernels of process_samples the north star names (discounted-return / GAE scan, path
+                  scan + baseline prediction, the baseline's normal equations): SURVEY.md 8d algorithmic bytes per sample
+                  x the batch / HIP-event time of the launch, live, against 8 TB/s.
   roofline_step_kernel -- rl_vecenv_step (the per-step boundary kernel, state through HBM every
                   launch) at 4 M envs for Cartpole and for the workload's env: the HBM-bound
                   regime of the step kernel, timed live.
@@ -115,6 +118,61 @@ def step_kernel_roofline(torch, kind, n=1 << 22, steps=20, warmup=3):
                         "valu_insts_per_env_step": k["insts_valu"] * 64.0 / n,
                         "valu_issue_frac": k["active_inst_valu"] / k["wave_cycles"] if k.get("wave_cycles") else None,
                         "valu_source": rec["source"] + "; NOT measured in this run -- only the launch time is"})
+    return out
+
+
+def scan_rooflines(torch, algo, traj, reps=20):
+    """The three scans of process_samples on the batch just sampled, each timed alone with HIP events on torch's current
+    stream (the stream the launches go to: _lib.stream_ptr()); bytes per sample = what the algorithm has to move once."""
+    from rllab_amd import _lib
+    from rllab_amd.sampler.base import path_scan
+    T, N, do = traj.T, traj.N, traj.obs_dim
+    B = T * N
+    dev = traj.device
+    base = algo.baseline
+    coeffs = base.dense_coeffs() if hasattr(base, "dense_coeffs") else None
+    if coeffs is None:
+        coeffs = torch.zeros(2 * do + 4, dtype=torch.float64, device=dev)
+    coeffs = torch.as_tensor(coeffs, dtype=torch.float64, device=dev).contiguous()
+    tin, valid, values = path_scan(traj, True, coeffs)
+    adv = torch.empty((T, N), dtype=torch.float32, device=dev)
+    ret, und = torch.empty_like(adv), torch.empty_like(adv)
+    gamma, lam = float(algo.discount), float(algo.gae_lambda)
+
+    def gae():
+        _lib.check(_lib.lib.rl_gae(T, N, _lib.ptr(traj.rewards), _lib.ptr(values), _lib.ptr(traj.dones), gamma, lam,
+                                   _lib.ptr(adv), _lib.ptr(ret), _lib.ptr(und), _lib.stream_ptr()), "rl_gae")
+
+    def scan():
+        path_scan(traj, True, coeffs)
+    out = []
+
+    def timed(name, fn, bytes_per_sample, what):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = bytes_per_sample * B / (ms * 1e-3) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                    "avg_launch_ms": ms, "bytes_per_sample": bytes_per_sample, "samples": B, "bytes": what})
+    timed("gae_reg_kernel (rl_gae: advantages, discounted and undiscounted returns, one segmented reverse scan)", gae, 25,
+          "reward f32 + baseline f64 + done u8 in, three f32 planes out")
+    timed("path_scan_reg_kernel (rl_path_scan: step-in-path index, whole-path validity, baseline prediction)", scan,
+          4 * do + 14, "done u8 + %d observation planes f32 in, index i32 + valid u8 + prediction f64 out" % do)
+    if hasattr(base, "normal_eq_dense"):
+        keep = (traj.valid, traj.tin, traj.returns)
+        traj.valid, traj.tin, traj.returns = valid, tin, ret
+        gae()
+        timed("lfb_normal_eq kernel (rl_lfb_normal_eq: Phi^T Phi and Phi^T y in float64, features rebuilt per tile)",
+              lambda: base.normal_eq_dense(traj), 4 * do + 9,
+              "%d observation planes + return f32 + index i32 + valid u8 in; the (2 Do + 4)^2 sums out" % do)
+        traj.valid, traj.tin, traj.returns = keep
     return out
 
 
@@ -525,12 +583,17 @@ def main():
         insts, waves_c = compute_axis["rollout_insts_valu"], compute_axis["rollout_waves"]
         clock_hz = compute_axis["rollout_gui_active"] / 8.0 / avg_rollout_s
         per_wave_step = insts / waves_c / T
+        floor_ms = per_wave_step * 4.0 * T / clock_hz * 1e3
         out["roofline"].update({
+            # what binds this kernel: the issue slots of a lone wavefront.  issue_frac = the launch's issue-slot floor
+            # (vector instructions per wavefront x 4 cycles, at the clock the launch ran at) / the measured launch time
+            "bound": "issue", "issue_frac": floor_ms / (avg_rollout_s * 1e3),
+            "hbm_frac": achieved / 8000.0,
             "valu_tflops": insts * 64.0 / avg_rollout_s / 1e12, "valu_peak_tflops": 157.3 / 2.0,
             "valu_unit": "T lane-instructions/s (SQ_INSTS_VALU x 64 / launch time; an FMA counts once)",
             "valu_insts_per_wavefront_and_env_step": per_wave_step,
             "clock_ghz": clock_hz / 1e9,
-            "issue_slot_floor_ms": per_wave_step * 4.0 * T / clock_hz * 1e3,
+            "issue_slot_floor_ms": floor_ms,
             "valu_issue_frac": compute_axis["rollout_active_inst_valu"] / compute_axis["rollout_wave_cycles"],
             "compute_source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / SQ_WAVE_CYCLES / SQ_ACTIVE_INST_VALU / "
                               "GRBM_GUI_ACTIVE, a builder-run pass of this command committed as profiles/pmc_traffic.json "
@@ -595,6 +658,7 @@ def main():
         # events, same recipe as tools/step_kernel_roofline.py; algorithmic bytes per env-step =
         # 4 (2 S + Da + Do + 1) + 1 + 8 (ts read + write).
         out["roofline_step_kernel"] = [step_kernel_roofline(torch, k) for k in sorted({0, env_kind})]
+        out["roofline_scan"] = scan_rooflines(torch, algo, last["samples"]["_traj"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # (1) the reference's own sampler, unmodified, in a child process (rllab must resolve to the reference there)
         from oracle import cpu_sampler, ref_sampler

@@ -4,9 +4,14 @@
 // the definition of the env's arithmetic; it is instantiated three ways and every instantiation evaluates the same
 // expressions in the same association (the front-end's per-expression a * b + c fusion sites included):
 //
-//   V = V8<R> (8-component vector: [leg 0: roles 0..3, leg 1: roles 0..3])   one env per lane / host thread -- the host
-//                 oracle build, the per-step VecEnv kernels and the env-per-lane rollouts; lane moves are component
-//                 shuffles (register renames), the arithmetic four packed-f32 instructions per operation on gfx950.
+//   V = V8<R> (8-component vector, component 2 r + L = (role r, leg L): the two legs' copies of a role side by side)
+//                 one env per lane / host thread -- the host oracle build, the per-step VecEnv kernels and the
+//                 env-per-lane rollouts.  The arithmetic is four packed-f32 instructions per operation on gfx950, one
+//                 per ROLE: every role move (up / down / nxt / prv / root / first, sel_root / sel_leaf) carries whole
+//                 aligned register pairs -- a rename, no instruction -- other() is the packed instructions' own
+//                 half-swap, and work that is meaningless on a role (the leg block on role 0) is dead as a whole
+//                 instruction.  (Leg-major components, rounds 5's order, split every role move over two pairs:
+//                 v_mov traffic and 308 live registers in the per-step kernel.)
 //   V = V2<float> (both legs side by side, the roles on the four lanes of a quad)   rollout_two_leg_quad_kernel, 16 envs
 //                 per wavefront; role moves are quad-permute DPP, the other leg is the swapped pair.
 //   V = float     (one body per lane: roles on the lanes of a quad, the other leg eight lanes further in the row)
@@ -108,19 +113,21 @@ RL_HD void rl_rotate_small_v(V& sn, V& cs, V d) {
     cs = c;
 }
 
-// all eight lanes of an env in one value: component 4 L + r = (leg L, role r)
+// all eight lanes of an env in one value: component 2 r + L = (role r, leg L)
 struct EightLanes {
+    static constexpr int leg_of(int c) { return c & 1; }
+    static constexpr int role_of(int c) { return c >> 1; }
 #define RL_SHUF(...) __builtin_shufflevector(v, v, __VA_ARGS__)
-    template <typename V> RL_HD V up(V v) const { return RL_SHUF(0, 0, 1, 2, 4, 4, 5, 6); }
-    template <typename V> RL_HD V down(V v) const { return RL_SHUF(1, 2, 3, 3, 5, 6, 7, 7); }
-    template <typename V> RL_HD V nxt(V v) const { return RL_SHUF(0, 2, 3, 1, 4, 6, 7, 5); }
-    template <typename V> RL_HD V prv(V v) const { return RL_SHUF(0, 3, 1, 2, 4, 7, 5, 6); }
-    template <typename V> RL_HD V root(V v) const { return RL_SHUF(0, 0, 0, 0, 4, 4, 4, 4); }
-    template <typename V> RL_HD V first(V v) const { return RL_SHUF(1, 1, 1, 1, 5, 5, 5, 5); }
-    template <typename V> RL_HD V other(V v) const { return RL_SHUF(4, 5, 6, 7, 0, 1, 2, 3); }
+    template <typename V> RL_HD V up(V v) const { return RL_SHUF(0, 1, 0, 1, 2, 3, 4, 5); }
+    template <typename V> RL_HD V down(V v) const { return RL_SHUF(2, 3, 4, 5, 6, 7, 6, 7); }
+    template <typename V> RL_HD V nxt(V v) const { return RL_SHUF(0, 1, 4, 5, 6, 7, 2, 3); }
+    template <typename V> RL_HD V prv(V v) const { return RL_SHUF(0, 1, 6, 7, 2, 3, 4, 5); }
+    template <typename V> RL_HD V root(V v) const { return RL_SHUF(0, 1, 0, 1, 0, 1, 0, 1); }
+    template <typename V> RL_HD V first(V v) const { return RL_SHUF(2, 3, 2, 3, 2, 3, 2, 3); }
+    template <typename V> RL_HD V other(V v) const { return RL_SHUF(1, 0, 3, 2, 5, 4, 7, 6); }
 #undef RL_SHUF
-    template <typename V> RL_HD V sel_root(V a, V b) const { return __builtin_shufflevector(a, b, 0, 9, 10, 11, 4, 13, 14, 15); }
-    template <typename V> RL_HD V sel_leaf(V a, V b) const { return __builtin_shufflevector(a, b, 8, 9, 10, 3, 12, 13, 14, 7); }
+    template <typename V> RL_HD V sel_root(V a, V b) const { return __builtin_shufflevector(a, b, 0, 1, 10, 11, 12, 13, 14, 15); }
+    template <typename V> RL_HD V sel_leaf(V a, V b) const { return __builtin_shufflevector(a, b, 8, 9, 10, 11, 12, 13, 6, 7); }
 };
 
 template <class Mdl>
@@ -208,7 +215,7 @@ struct TwoLegs {
         LaneK<V8<R>> k;
         RL_UNROLL
         for (int i = 0; i < 8; ++i) {
-            const LaneK<R> a = lane_constants<R>(i >> 2, i & 3);
+            const LaneK<R> a = lane_constants<R>(EightLanes::leg_of(i), EightLanes::role_of(i));
 #define RL_PUT(f) k.f[i] = a.f
             RL_PUT(jx); RL_PUT(jy); RL_PUT(cx); RL_PUT(cy); RL_PUT(mass); RL_PUT(inertia); RL_PUT(arm); RL_PUT(stiff);
             RL_PUT(damp); RL_PUT(lo); RL_PUT(hi); RL_PUT(mc);
@@ -452,7 +459,8 @@ struct TwoLegs {
         const EightLanes x;
         RL_UNROLL
         for (int i = 0; i < 8; ++i) {
-            const int j = (i & 3) == 0 ? 2 : 2 + 3 * (i >> 2) + (i & 3);
+            const int role = EightLanes::role_of(i), leg = EightLanes::leg_of(i);
+            const int j = role == 0 ? 2 : 2 + 3 * leg + role;
             s.q[i] = q[j];
             s.w[i] = qd[j];
         }
@@ -478,10 +486,10 @@ struct TwoLegs {
     }
     template <typename R>
     RL_HD static void sincos_lanes(V8<R> phi, V8<R>& sn, V8<R>& cs) {
-        // (the torso's angle sits in components 0 and 4: evaluated once)
+        // (the torso's angle sits in components 0 and 1: evaluated once)
         RL_UNROLL
         for (int i = 0; i < 8; ++i) {
-            if (i == 4) { sn[4] = sn[0]; cs[4] = cs[0]; continue; }
+            if (i == 1) { sn[1] = sn[0]; cs[1] = cs[0]; continue; }
             R a, b;
             rl_sincos((R)phi[i], a, b);
             sn[i] = a;
@@ -493,9 +501,8 @@ struct TwoLegs {
         q[0] = s.p1[0]; q[1] = s.p2[0]; qd[0] = s.v1[0]; qd[1] = s.v2[0];
         q[2] = s.q[0]; qd[2] = s.w[0];
         RL_UNROLL
-        for (int i = 1; i < 8; ++i) {
-            if ((i & 3) == 0) continue;
-            const int j = 2 + 3 * (i >> 2) + (i & 3);
+        for (int i = 2; i < 8; ++i) {
+            const int j = 2 + 3 * EightLanes::leg_of(i) + EightLanes::role_of(i);
             q[j] = s.q[i];
             qd[j] = s.w[i];
         }
@@ -518,7 +525,8 @@ struct TwoLegs {
         const LaneK<V8<R>> k = all_lane_constants<R>();
         V8<R> act;
         RL_UNROLL
-        for (int i = 0; i < 8; ++i) act[i] = (i & 3) == 0 ? (R)0 : tau[3 * (i >> 2) + (i & 3)];
+        for (int i = 0; i < 8; ++i)
+            act[i] = EightLanes::role_of(i) == 0 ? (R)0 : tau[3 * EightLanes::leg_of(i) + EightLanes::role_of(i)];
         const EightLanes x;
         for (int it = 0; it < n; ++it) substep<R, V8<R>, EightLanes>(x, k, s, act, h);
         store(s, q, qd);

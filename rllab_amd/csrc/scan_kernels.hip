@@ -246,8 +246,14 @@ extern "C" int rl_gae(int T, int n, const float* rewards, const double* values, 
     constexpr int LMAX = 16;
     if (T <= 64 * LMAX) {
         // register-resident chunks: up to 64 chunks of up to 16 steps; 16 envs per workgroup while 32 would leave CUs idle
-        const bool narrow = (n + 31) / 32 < 1024;
-        const int ew = narrow ? 16 : 32, kb_max = narrow ? 64 : 32;
+#ifndef RL_GAE_NARROW_BELOW
+#define RL_GAE_NARROW_BELOW 1024     // workgroups of 32 envs below which 16-env workgroups are launched instead
+#endif
+#ifndef RL_GAE_KB_NARROW
+#define RL_GAE_KB_NARROW 32          // chunks per 16-env workgroup: 32 x 16 steps (512 threads) beat 63 x 8 (14.0 against 22.4 us
+#endif                               // at 4096 envs x 500 steps, tools/exp/scan_time.py): the fold over the chunks is serial
+        const bool narrow = (n + 31) / 32 < RL_GAE_NARROW_BELOW;
+        const int ew = narrow ? 16 : 32, kb_max = narrow ? RL_GAE_KB_NARROW : 32;
         if (T <= kb_max * LMAX) {
             const int L = (T + kb_max - 1) / kb_max, KB = (T + L - 1) / L;
             dim3 grid((n + ew - 1) / ew), block(ew, KB);
