@@ -21,10 +21,13 @@ from rllab.misc import ext  # noqa: E402
 from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy  # noqa: E402
 
 
-def make_env(name, position_only=False, **norm):
+def make_env(name, position_only=False, constraint=None, **norm):
     if position_only and name not in ("cartpole", "double_pendulum", "cartpole_swingup"):
         raise SystemExit("--position-only: a Box2DEnv option")
     box = dict(position_only=True) if position_only else {}
+    mj = dict(constraint or {})        # HalfCheetahEnv / Walker2DEnv / HopperEnv(limit_model=.., contact_model=..): engine options
+    if mj and name not in ("half_cheetah", "walker2d", "hopper"):
+        raise SystemExit("--limit-model / --contact-model: options of half_cheetah, walker2d, hopper")
 
     def normalize(env):                           # (the wrapper's running estimates: --normalize-obs / --normalize-reward)
         from rllab.envs.normalized_env import normalize as wrap
@@ -40,13 +43,13 @@ def make_env(name, position_only=False, **norm):
         return normalize(SwimmerEnv(limit_model="mujoco")), 500
     if name == "half_cheetah":
         from rllab.envs.mujoco.half_cheetah_env import HalfCheetahEnv
-        return normalize(HalfCheetahEnv()), 500
+        return normalize(HalfCheetahEnv(**mj)), 500
     if name == "walker2d":
         from rllab.envs.mujoco.walker2d_env import Walker2DEnv
-        return normalize(Walker2DEnv()), 500
+        return normalize(Walker2DEnv(**mj)), 500
     if name == "hopper":
         from rllab.envs.mujoco.hopper_env import HopperEnv
-        return normalize(HopperEnv()), 500
+        return normalize(HopperEnv(**mj)), 500
     if name == "inverted_double_pendulum":
         from rllab.envs.mujoco.inverted_double_pendulum_env import InvertedDoublePendulumEnv
         return normalize(InvertedDoublePendulumEnv()), 100
@@ -74,6 +77,8 @@ def main():
     ap.add_argument("--position-only", action="store_true", help="Box2DEnv(position_only=True)")
     ap.add_argument("--adaptive-std", action="store_true", help="GaussianMLPPolicy(adaptive_std=True)")
     ap.add_argument("--gae-lambda", type=float, default=1.0)
+    ap.add_argument("--limit-model", default=None, choices=["penalty", "mujoco"], help="legged envs: joint limits")
+    ap.add_argument("--contact-model", default=None, choices=["penalty", "mujoco"], help="legged envs: floor contacts")
     ap.add_argument("--csv", default=None, help="write the tabular log (one row per iteration) to this file")
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args()
@@ -84,7 +89,8 @@ def main():
         logger.set_quiet(True)
     ext.set_seed(args.seed)
     norm = {k: True for k in ("normalize_obs", "normalize_reward") if getattr(args, k)}
-    env, horizon = make_env(args.env, position_only=args.position_only, **norm)
+    constraint = {k: getattr(args, k) for k in ("limit_model", "contact_model") if getattr(args, k)}
+    env, horizon = make_env(args.env, position_only=args.position_only, constraint=constraint, **norm)
     hs = tuple(int(h) for h in str(args.hidden).split(","))
     extra = {}
     if args.nonlinearity == "relu":

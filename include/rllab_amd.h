@@ -54,7 +54,8 @@ const char* rl_last_error(void);
  * of the library's getenv reads; rl_rollout_plan_query; per-layer hidden activations (layer_activations, RL_ACT_IDENTITY);
  * rl_running_norm (NormalizedEnv's running observation / reward normalisation inside the fused rollout).
  * 13: rl_env_terminates; rl_rollout_args.reset_at_start == 0 continues from last_obs (the sampler's further launches
- * until batch_size whole-path samples are in, running normalisation included). */
+ * until batch_size whole-path samples are in, running normalisation included); RL_CFG_CONTACT_MUJOCO, and RL_CFG_LIMIT_MUJOCO
+ * for the legged envs. */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -114,13 +115,22 @@ enum rl_env_cfg_flags {
                                    * origin at the XML pose, cartpole_env.py:28-43 -- DESIGN.md section 5) */
     RL_CFG_FIXED_START = 2,       /* InvertedDoublePendulumEnv(random_start=False)
                                    * (inverted_double_pendulum_env.py:20,47-58) */
-    RL_CFG_LIMIT_MUJOCO = 4       /* SwimmerEnv(limit_model="mujoco") (engine option): the two hinge limits act through
+    RL_CFG_LIMIT_MUJOCO = 4,      /* SwimmerEnv(limit_model="mujoco") (engine option): the two hinge limits act through
                                    * MuJoCo's documented soft-constraint model with the MJCF's own solreflimit = "0.02 1"
                                    * and solimplimit = "0 .8 .03" (vendor/mujoco_models/swimmer.xml:31,34): reference
                                    * acceleration + impedance, constraint forces f >= 0 minimising
                                    * 1/2 f'(A + R)f + f'(a0 - a_ref), solved exactly for the (at most two) active rows --
-                                   * instead of the default penalty spring-damper.  Swimmer only; such launches run the
-                                   * scalar sub-step program (the four-lanes-per-env rollout is built for the default). */
+                                   * instead of the default penalty spring-damper; such launches run the scalar sub-step
+                                   * program (the four-lanes-per-env rollout is built for the default).
+                                   * HalfCheetahEnv / Walker2DEnv / HopperEnv(limit_model="mujoco"): the hinges' limits as rows
+                                   * of the projected Gauss-Seidel constraint solve of csrc/dyn_mjc.h, parameters from
+                                   * vendor/mujoco_models/half_cheetah.xml:38 (hopper / walker2d: MuJoCo's defaults). */
+    RL_CFG_CONTACT_MUJOCO = 8     /* HalfCheetahEnv / Walker2DEnv / HopperEnv(contact_model="mujoco") (engine option): the
+                                   * capsule end spheres' floor contacts through the same soft-constraint model -- condim 3,
+                                   * pyramidal cone (two edge rows J_n +- mu J_t per contact in the plane), the MJCFs' own
+                                   * solref / solimp / margin (half_cheetah.xml:39, hopper.xml:5, walker2d.xml:6), up to 8
+                                   * contacts at once, 100 Gauss-Seidel sweeps -- instead of the default spring-damper
+                                   * penalty.  Either flag takes these envs to the env-per-lane rollout kernels. */
 };
 
 /* The options env `kind` runs with by default (host struct out). */

@@ -41,6 +41,7 @@ def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None, ac
         env = H.HostEnv(kind, np.float32, normalize=vec_env.normalize, cfg=cfg)
         fresh = True
         ts = 0
+        o_step = None        # the observation the host's previous step() returned
         for t in range(T):
             if fresh:
                 if reset_draws is not None:
@@ -50,12 +51,14 @@ def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None, ac
                     set_state_from_obs(env, obs[:, t, n])
                 fresh = False
                 ts = 0
-            # the observation recorded at step t carries noise slice t (slice 0 = the first, t = after step t - 1)
-            o_host = env.observe(obs_noise_z[t, :, n] if noisy_obs else None)
+            # the observation recorded at step t carries noise slice t (slice 0 = the first, t = after step t - 1): inside a
+            # path it is what the previous step() returned (for the Hopper under the soft-constraint models that carries the
+            # step's own constraint forces, which observe() cannot re-derive from the state), at a path start observe()'s
+            o_host = o_step if o_step is not None else env.observe(obs_noise_z[t, :, n] if noisy_obs else None)
             assert np.array_equal(o_host.view(np.uint32), obs[:, t, n].view(np.uint32)), \
                 "obs mismatch env %d t %d: host %r gpu %r" % (n, t, o_host, obs[:, t, n])
-            _, r, d = env.step(act[:, t, n], zact=None if action_noise_z is None else action_noise_z[t, :, n],
-                               zobs=obs_noise_z[t + 1, :, n] if noisy_obs else None)
+            o_step, r, d = env.step(act[:, t, n], zact=None if action_noise_z is None else action_noise_z[t, :, n],
+                                    zobs=obs_noise_z[t + 1, :, n] if noisy_obs else None)
             ts += 1
             if vec_env.max_path_length > 0 and ts >= vec_env.max_path_length:
                 d = True
@@ -66,6 +69,7 @@ def replay_check(vec_env, traj, max_envs=64, verbose=False, reset_draws=None, ac
             compared += 1
             if d:
                 fresh = True
+                o_step = None
     if verbose:
         print("replay_check: %d env-steps bit-identical" % compared)
     return compared

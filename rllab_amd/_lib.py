@@ -46,7 +46,7 @@ class EnvCfg(ctypes.Structure):
     ]
 
 
-CFG_POLE_FOLLOWS_CART, CFG_FIXED_START, CFG_LIMIT_MUJOCO = 1, 2, 4
+CFG_POLE_FOLLOWS_CART, CFG_FIXED_START, CFG_LIMIT_MUJOCO, CFG_CONTACT_MUJOCO = 1, 2, 4, 8
 
 
 class RolloutArgs(ctypes.Structure):

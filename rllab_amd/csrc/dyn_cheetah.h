@@ -23,6 +23,7 @@
 #pragma once
 #include "cheetah_constants.h"
 #include "dyn_two_legs.h"
+#include "dyn_mjc.h"
 
 namespace rl {
 
@@ -60,6 +61,12 @@ struct CheetahModel {
     static constexpr double MU = 0.4;
 };
 
+// half_cheetah.xml:38-39: joints solreflimit = ".02 1", solimplimit = "0 .8 .03"; geoms solref = "0.02 1", solimp = "0.0 0.8 0.01"
+struct CheetahMjcPar {
+    RL_HD static constexpr MjcSol limit() { return MjcSol{0.02, 1.0, 0.0, 0.8, 0.03, 0.0}; }
+    RL_HD static constexpr MjcSol contact() { return MjcSol{0.02, 1.0, 0.0, 0.8, 0.01, 0.0}; }
+};
+
 struct HalfCheetah {
     static constexpr int OBS = 20;
     static constexpr int ACT = 6;
@@ -72,6 +79,7 @@ struct HalfCheetah {
     static constexpr int SUBSTEPS = 4;      // 4 x 0.0025 s = one 0.01 s MuJoCo step, frame_skip 1
     using Tree = PlanarTree<CheetahModel>;
     using Legs = TwoLegs<CheetahModel>;
+    using Mjc = MjcTree<CheetahModel, CheetahMjcPar>;     // limit_model / contact_model = "mujoco" (dyn_mjc.h)
 
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
         RL_UNROLL
@@ -146,10 +154,24 @@ struct HalfCheetah {
     template <typename R>
     RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
                            const StepOpts<R>& o = default_opts<R>()) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // host build: the constraint model is a run-time option of the one step (device: MjcEnv<> instantiations)
+        if (o.flags & (CFG_LIMIT_MUJOCO | CFG_CONTACT_MUJOCO)) {
+            step_model<R, true>(s, a, normalize, obs, reward, done, o);
+            return;
+        }
+#endif
+        step_model<R, false>(s, a, normalize, obs, reward, done, o);
+    }
+    static constexpr bool HAS_MJC = true;
+    template <typename R, bool MJC>
+    RL_HD static void step_model(R* s, const R* a, int normalize, R* obs, R& reward, bool& done, const StepOpts<R>& o) {
         R act[ACT], tau[CheetahModel::NB];
         step_begin(a, normalize, o, act, tau);
-        // all eight body lanes in one value (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
-        Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
+        if constexpr (MJC)
+            Mjc::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS, o.flags);       // MuJoCo's soft constraints
+        else   // all eight body lanes in one value (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+            Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
         R cz, cx, vz, vx;
         Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
         step_end_com(s, act, cz, cx, vz, vx, obs, reward, done, o);

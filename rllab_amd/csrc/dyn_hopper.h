@@ -19,12 +19,19 @@
 // thigh, leg, foot], qd[6].
 #pragma once
 #include "dyn_legged.h"
+#include "dyn_mjc.h"
 #include "hopper_constants.h"
 
 namespace rl {
 
 RL_LEGGED_CONSTANTS(HopperK, hopper);
 using HopperModel = LeggedModel<HopperK>;
+
+// hopper.xml:4-5: geoms margin 0.001, solref ".02 1", solimp ".8 .8 .01"; the joints set none (MuJoCo's defaults)
+struct HopperMjcPar {
+    RL_HD static constexpr MjcSol limit() { return MjcSol{0.02, 1.0, 0.9, 0.95, 0.001, 0.0}; }
+    RL_HD static constexpr MjcSol contact() { return MjcSol{0.02, 1.0, 0.8, 0.8, 0.01, 0.001}; }
+};
 
 struct Hopper {
     static constexpr int OBS = 20;
@@ -37,6 +44,7 @@ struct Hopper {
     static constexpr int SUBSTEPS = 8;      // 8 x 0.0025 s = one 0.02 s MuJoCo step, frame_skip 1
     static constexpr int NQ = 6;
     using Tree = PlanarTree<HopperModel>;
+    using Mjc = MjcTree<HopperModel, HopperMjcPar>;       // limit_model / contact_model = "mujoco" (dyn_mjc.h)
 
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
         RL_UNROLL
@@ -69,9 +77,16 @@ struct Hopper {
         write_obs(s, cx, cz, o);
     }
 
-    template <typename R> RL_HD static void write_obs(const R* s, R cx, R cz, R* o) {
+    // qfrc: data.qfrc_constraint as the constraint solve of the step's last sub-step left it (limit_model / contact_model =
+    // "mujoco"); null: the penalty models' generalised force at the state (also what reset() / get_current_obs report)
+    template <typename R> RL_HD static void write_obs(const R* s, R cx, R cz, R* o, const R* qfrc = nullptr) {
         R qf[NQ];
-        Tree::template constraint_forces<R>(s, s + NQ, qf);
+        if (qfrc) {
+            RL_UNROLL
+            for (int i = 0; i < NQ; ++i) qf[i] = qfrc[i];
+        } else {
+            Tree::template constraint_forces<R>(s, s + NQ, qf);
+        }
         o[0] = s[0];
         o[1] = s[2];
         RL_UNROLL
@@ -88,6 +103,18 @@ struct Hopper {
     template <typename R>
     RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
                            const StepOpts<R>& o = default_opts<R>()) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // host build: the constraint model is a run-time option of the one step (device: MjcEnv<> instantiations)
+        if (o.flags & (CFG_LIMIT_MUJOCO | CFG_CONTACT_MUJOCO)) {
+            step_model<R, true>(s, a, normalize, obs, reward, done, o);
+            return;
+        }
+#endif
+        step_model<R, false>(s, a, normalize, obs, reward, done, o);
+    }
+    static constexpr bool HAS_MJC = true;
+    template <typename R, bool MJC>
+    RL_HD static void step_model(R* s, const R* a, int normalize, R* obs, R& reward, bool& done, const StepOpts<R>& o) {
         R act[ACT], tau[HopperModel::NB];
         tau[0] = (R)0;
         R ctrl_cost = (R)0;
@@ -106,14 +133,20 @@ struct Hopper {
         R q[NQ], qd[NQ];
         RL_UNROLL
         for (int i = 0; i < NQ; ++i) { q[i] = s[i]; qd[i] = s[NQ + i]; }
-        R sn[HopperModel::NB], cs[HopperModel::NB];
-        Tree::template angles<R>(q, sn, cs);
-        for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025, sn, cs);
+        constexpr bool mjc = MJC;
+        R qfrc[NQ];
+        if constexpr (MJC) {
+            Mjc::template advance<R>(q, qd, tau, (R)0.0025, SUBSTEPS, o.flags, qfrc);    // MuJoCo's soft constraints
+        } else {
+            R sn[HopperModel::NB], cs[HopperModel::NB];
+            Tree::template angles<R>(q, sn, cs);
+            for (int it = 0; it < SUBSTEPS; ++it) Tree::template substep<R>(q, qd, tau, (R)0.0025, sn, cs);
+        }
         RL_UNROLL
         for (int i = 0; i < NQ; ++i) { s[i] = q[i]; s[NQ + i] = qd[i]; }
         R cz, cx, vz, vx;
         Tree::template com<R>(q, qd, cz, cx, vz, vx);
-        write_obs(s, cx, cz, obs);
+        write_obs(s, cx, cz, obs, mjc ? qfrc : nullptr);
         // reward = comvel_x + alive_coeff - 0.5 * ctrl_cost_coeff * sum((action / scaling)^2), alive_coeff 1,
         // ctrl_cost_coeff 0.01                                                    (hopper_env.py:27-28,53-55)
         reward = vx + o.alive_coeff - (R)0.5 * o.ctrl_cost_coeff * ctrl_cost;

@@ -523,6 +523,9 @@ struct TwoLegs {
         State<V8<R>> s;
         load(q, qd, s);
         const LaneK<V8<R>> k = all_lane_constants<R>();
+        // (tried in round 6: the most-used constants pinned in scalar register tuples for the env step, so that the packed
+        //  instructions read (role, both legs) as one scalar pair instead of the compiler's two literal multiplies -- the
+        //  per-step kernel got SLOWER, 0.77 -> 0.84 ms at 4 M envs: profiles/r06_notes.md)
         V8<R> act;
         RL_UNROLL
         for (int i = 0; i < 8; ++i)

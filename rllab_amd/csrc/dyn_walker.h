@@ -21,12 +21,19 @@
 #pragma once
 #include "dyn_legged.h"
 #include "dyn_two_legs.h"
+#include "dyn_mjc.h"
 #include "walker_constants.h"
 
 namespace rl {
 
 RL_LEGGED_CONSTANTS(WalkerK, walker);
 using WalkerModel = LeggedModel<WalkerK>;   // joint limits + capsule-floor contacts: dyn_legged.h
+
+// walker2d.xml:3-7 sets no solver parameter: MuJoCo's defaults, solref = "0.02 1", solimp = "0.9 0.95 0.001", margin 0
+struct WalkerMjcPar {
+    RL_HD static constexpr MjcSol limit() { return MjcSol{0.02, 1.0, 0.9, 0.95, 0.001, 0.0}; }
+    RL_HD static constexpr MjcSol contact() { return MjcSol{0.02, 1.0, 0.9, 0.95, 0.001, 0.0}; }
+};
 
 struct Walker2D {
     static constexpr int OBS = 21;
@@ -40,6 +47,7 @@ struct Walker2D {
     static constexpr int SUBSTEPS = 2;      // 2 x 0.0025 s = one 0.005 s MuJoCo step, frame_skip 1
     using Tree = PlanarTree<WalkerModel>;
     using Legs = TwoLegs<WalkerModel>;
+    using Mjc = MjcTree<WalkerModel, WalkerMjcPar>;       // limit_model / contact_model = "mujoco" (dyn_mjc.h)
 
     template <typename R> RL_HD static void action_bounds(R* lb, R* ub) {
         RL_UNROLL
@@ -114,10 +122,24 @@ struct Walker2D {
     template <typename R>
     RL_HD static void step(R* s, const R* a, int normalize, R* obs, R& reward, bool& done,
                            const StepOpts<R>& o = default_opts<R>()) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // host build: the constraint model is a run-time option of the one step (device: MjcEnv<> instantiations)
+        if (o.flags & (CFG_LIMIT_MUJOCO | CFG_CONTACT_MUJOCO)) {
+            step_model<R, true>(s, a, normalize, obs, reward, done, o);
+            return;
+        }
+#endif
+        step_model<R, false>(s, a, normalize, obs, reward, done, o);
+    }
+    static constexpr bool HAS_MJC = true;
+    template <typename R, bool MJC>
+    RL_HD static void step_model(R* s, const R* a, int normalize, R* obs, R& reward, bool& done, const StepOpts<R>& o) {
         R act[ACT + 1], tau[WalkerModel::NB];
         step_begin(a, normalize, o, act, tau);
-        // all eight body lanes in one value (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
-        Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
+        if constexpr (MJC)
+            Mjc::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS, o.flags);       // MuJoCo's soft constraints
+        else   // all eight body lanes in one value (dyn_two_legs.h): exact sines at the start, SUBSTEPS sub-steps
+            Legs::template advance<R>(s, s + 9, tau, (R)0.0025, SUBSTEPS);
         R cz, cx, vz, vx;
         Legs::template com_of<R>(s, s + 9, cz, cx, vz, vx);
         step_end_com(s, act, cz, cx, vz, vx, obs, reward, done, o);

@@ -1923,9 +1923,13 @@ static int device_cfg(const rl_env_cfg* cfg, EnvCfg& c) {
     c.action_noise = cfg->action_noise; c.obs_noise = cfg->obs_noise;
     if (cfg->frame_skip > 0) c.frame_skip = cfg->frame_skip;
     c.flags = cfg->flags;
-    if ((cfg->flags & RL_CFG_LIMIT_MUJOCO) && !std::is_same<Env, Swimmer>::value)
+    constexpr bool legged = has_mjc<Env>::value;          // HalfCheetah, Walker2D, Hopper (csrc/dyn_mjc.h)
+    if ((cfg->flags & RL_CFG_LIMIT_MUJOCO) && !(std::is_same<Env, Swimmer>::value || legged))
         return set_error(RL_ERR_UNSUPPORTED, "rl_env_cfg.flags: RL_CFG_LIMIT_MUJOCO (soft-constraint joint limits) is built "
-                                             "for the Swimmer only");
+                                             "for the Swimmer, HalfCheetah, Walker2D and Hopper");
+    if ((cfg->flags & RL_CFG_CONTACT_MUJOCO) && !legged)
+        return set_error(RL_ERR_UNSUPPORTED, "rl_env_cfg.flags: RL_CFG_CONTACT_MUJOCO (soft-constraint floor contacts) is "
+                                             "built for HalfCheetah, Walker2D and Hopper");
     if (cfg->link_len < 0.0f || cfg->link_len > 8.0f)
         return set_error(RL_ERR_ARG, "rl_env_cfg.link_len = %g (0 = the model's, else (0, 8])", (double)cfg->link_len);
     if (cfg->link_len > 0.0f) c.link_len = cfg->link_len;
@@ -1971,6 +1975,12 @@ static int launch_step(int n, int normalize, float scale_reward, int mpl, int au
     EnvCfg c;
     int rc = device_cfg<Env>(cfg, c);
     if (rc) return rc;
+    if constexpr (has_mjc<Env>::value && !is_mjc_env<Env>::value) {
+        // limit_model / contact_model = "mujoco": the kernel instantiated for the soft-constraint step
+        if (c.flags & (RL_CFG_LIMIT_MUJOCO | RL_CFG_CONTACT_MUJOCO))
+            return launch_step<MjcEnv<Env>>(n, normalize, scale_reward, mpl, auto_reset, state, ts, actions, reset_draws, seed,
+                                            step, step_dev, env_offset, cfg, obs, reward, done, st);
+    }
     hipLaunchKernelGGL(vecenv_step_kernel<Env>, grid, dim3(BLOCK), 0, st, n, normalize, scale_reward, mpl,
                        auto_reset, state, ts, actions, reset_draws, seed, step, step_dev, env_offset, c,
                        cfg ? cfg->action_noise_z : nullptr, cfg ? cfg->obs_noise_z : nullptr, obs, reward, done);
@@ -2116,7 +2126,9 @@ static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
     if constexpr (std::is_same<Env, HalfCheetah>::value || std::is_same<Env, Walker2D>::value) {
         // one body per lane while every lane-group wavefront still gets a SIMD of its own (two_leg_lane_kernel = 2: the
         // generic kernel, for A/B timing and for the tests that run every shape)
-        const bool lanes_on = o.two_leg_lane_kernel != 2 && epw_req == 0;
+        // (RL_CFG_LIMIT_MUJOCO / RL_CFG_CONTACT_MUJOCO: the constraint solve of dyn_mjc.h lives in the env-per-lane program only)
+        const bool lanes_on = o.two_leg_lane_kernel != 2 && epw_req == 0 &&
+                              (cfg_flags & (RL_CFG_LIMIT_MUJOCO | RL_CFG_CONTACT_MUJOCO)) == 0;
         // one env per wavefront while the wavefronts still find (about) a SIMD each
         const bool wave_shape = o.two_leg_wave_kernel == 1 || (o.two_leg_wave_kernel != 2 && n <= 2048);
         if (lanes_on && wave_shape && small_offsets && equal) {
@@ -2177,6 +2189,10 @@ static int allow_big_lds(K kern, bool& done) {
 
 template <class Env>
 static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
+    if constexpr (has_mjc<Env>::value && !is_mjc_env<Env>::value) {
+        // limit_model / contact_model = "mujoco": the env-per-lane kernels instantiated for the soft-constraint step
+        if (g->cfg && (g->cfg->flags & (RL_CFG_LIMIT_MUJOCO | RL_CFG_CONTACT_MUJOCO))) return launch_rollout<MjcEnv<Env>>(g, st);
+    }
     rl_rollout_plan pl;
     int rc = plan_rollout<Env>(g, &pl);
     if (rc) return rc;

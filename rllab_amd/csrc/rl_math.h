@@ -218,7 +218,10 @@ enum EnvCfgFlags : int {
     CFG_FIXED_START = 2,         // InvertedDoublePendulumEnv(random_start=False)
     CFG_LIMIT_MUJOCO = 4,        // SwimmerEnv(limit_model="mujoco"): joint limits by MuJoCo's documented soft-constraint
                                  // model from the MJCF's own solreflimit / solimplimit (dyn_swimmer_chain.h) instead
-                                 // of the penalty spring-damper
+                                 // of the penalty spring-damper; HalfCheetahEnv / Walker2DEnv / HopperEnv(limit_model=
+                                 // "mujoco"): the hinges' limits as rows of dyn_mjc.h's constraint solve
+    CFG_CONTACT_MUJOCO = 8,      // HalfCheetahEnv / Walker2DEnv / HopperEnv(contact_model="mujoco"): the capsule end spheres'
+                                 // floor contacts as pyramidal-cone rows of dyn_mjc.h's constraint solve (penalty otherwise)
 };
 template <typename R>
 struct StepOpts {

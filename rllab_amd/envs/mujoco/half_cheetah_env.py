@@ -11,9 +11,12 @@ class HalfCheetahEnv(MujocoEnv, Serializable):
     KIND = _lib.ENV_HALF_CHEETAH
     OBS_ENDS_WITH_TORSO_COM = True     # obs = [..., com_subtree(torso)] (get_body_com)
 
-    def __init__(self, *args, **kwargs):
-        super(HalfCheetahEnv, self).__init__(*args, **kwargs)
-        Serializable.__init__(self, *args, **kwargs)
+    def __init__(self, limit_model="penalty", contact_model="penalty", *args, **kwargs):
+        """``limit_model`` / ``contact_model``: "penalty" (default) or "mujoco" (MujocoEnv._constraint_flags; the MJCF's
+        own solver parameters, vendor/mujoco_models/half_cheetah.xml:38-39,53)."""
+        self.limit_model, self.contact_model = limit_model, contact_model
+        Serializable.quick_init(self, locals())
+        super(HalfCheetahEnv, self).__init__(*args, **self._constraint_flags(limit_model, contact_model, kwargs))
 
     def log_diagnostics(self, paths):
         self._log_forward_progress(paths)

@@ -10,12 +10,17 @@ class HopperEnv(MujocoEnv, Serializable):
     FILE = 'hopper.xml'
     KIND = _lib.ENV_HOPPER
 
-    def __init__(self, alive_coeff=1, ctrl_cost_coeff=0.01, *args, **kwargs):
+    def __init__(self, alive_coeff=1, ctrl_cost_coeff=0.01, limit_model="penalty", contact_model="penalty", *args,
+                 **kwargs):
+        """``limit_model`` / ``contact_model``: "penalty" (default) or "mujoco" (MujocoEnv._constraint_flags;
+        vendor/mujoco_models/hopper.xml:5); with "mujoco" the observed qfrc_constraint of a step is J^T f of its last
+        constraint solve."""
         self.alive_coeff = alive_coeff
         self.ctrl_cost_coeff = ctrl_cost_coeff
+        self.limit_model, self.contact_model = limit_model, contact_model
         Serializable.quick_init(self, locals())
         super(HopperEnv, self).__init__(*args, alive_coeff=float(alive_coeff), ctrl_cost_coeff=float(ctrl_cost_coeff),
-                                        **kwargs)
+                                        **self._constraint_flags(limit_model, contact_model, kwargs))
 
     def log_diagnostics(self, paths):
         self._log_forward_progress(paths)

@@ -8,6 +8,8 @@ that name a different model are rejected loudly.
 """
 import numpy as np
 
+from rllab_amd import _lib
+
 from rllab_amd.envs.hip_env import HipEnv
 
 
@@ -29,6 +31,22 @@ class MujocoEnv(HipEnv):
             raise ValueError("action_noise must be >= 0")
         self.action_noise = float(action_noise)
         HipEnv.__init__(self, cfg=dict(engine_cfg, action_noise=self.action_noise))
+
+    @staticmethod
+    def _constraint_flags(limit_model, contact_model, kwargs):
+        """Engine options of the legged envs (the reference delegates both to MuJoCo 1.31): "penalty" = the spring-damper
+        models of csrc/dyn_two_legs.h / dyn_legged.h (default; the one-body-per-lane rollout kernels), "mujoco" = MuJoCo's
+        documented soft-constraint model with the MJCF's own solref / solimp / friction (csrc/dyn_mjc.h: projected
+        Gauss-Seidel over the active limit and pyramidal contact rows), on the env-per-lane kernels."""
+        for name, val in (("limit_model", limit_model), ("contact_model", contact_model)):
+            if val not in ("penalty", "mujoco"):
+                raise ValueError("%s=%r: 'penalty' or 'mujoco'" % (name, val))
+        flags = int(kwargs.get("flags", 0))
+        if limit_model == "mujoco":
+            flags |= _lib.CFG_LIMIT_MUJOCO
+        if contact_model == "mujoco":
+            flags |= _lib.CFG_CONTACT_MUJOCO
+        return dict(kwargs, flags=flags) if flags else kwargs
 
     # -- state-level API of the reference base class (mujoco_env.py:109-238) --------------------------------------
     @property

@@ -26,22 +26,23 @@ def test_header_symbols_exported():
 def test_env_query_and_errors():
     from rllab_amd import _lib
     assert _lib.env_query(_lib.ENV_CARTPOLE) == dict(obs_dim=4, act_dim=1, state_dim=16, reset_draws=4,
-                                                     reset_is_normal=False)
+                                                     reset_is_normal=False, terminates=True)
     assert _lib.env_query(_lib.ENV_DOUBLE_PENDULUM) == dict(obs_dim=6, act_dim=1, state_dim=17, reset_draws=4,
-                                                            reset_is_normal=True)
+                                                            reset_is_normal=True, terminates=False)
     assert _lib.env_query(_lib.ENV_SWIMMER) == dict(obs_dim=13, act_dim=2, state_dim=10, reset_draws=10,
-                                                    reset_is_normal=True)
+                                                    reset_is_normal=True, terminates=False)
     assert _lib.env_query(_lib.ENV_HALF_CHEETAH) == dict(obs_dim=20, act_dim=6, state_dim=18, reset_draws=18,
-                                                         reset_is_normal=True)
+                                                         reset_is_normal=True, terminates=False)
     assert _lib.env_query(_lib.ENV_CARTPOLE_SWINGUP) == _lib.env_query(_lib.ENV_CARTPOLE)
     assert _lib.env_query(_lib.ENV_WALKER2D) == dict(obs_dim=21, act_dim=6, state_dim=18, reset_draws=18,
-                                                     reset_is_normal=True)
+                                                     reset_is_normal=True, terminates=True)
     lb, ub = _lib.env_action_bounds(_lib.ENV_WALKER2D)
     assert list(ub) == [150, 100, 100, 150, 100, 100] and list(lb) == [-150, -100, -100, -150, -100, -100]
     lb, ub = _lib.env_action_bounds(_lib.ENV_HALF_CHEETAH)
     assert list(lb) == [-1] * 6 and list(ub) == [1] * 6
     lb, ub = _lib.env_action_bounds(_lib.ENV_SWIMMER)
     assert list(lb) == [-50, -50] and list(ub) == [50, 50]
+    assert [_lib.lib.rl_env_terminates(k) for k in range(8)] == [1, 0, 0, 0, 1, 1, 1, 1] and _lib.lib.rl_env_terminates(99) == -1
     assert _lib.lib.rl_env_query(99, None, None, None, None, None) == -1
     assert b"env kind 99" in _lib.lib.rl_last_error()
     assert _lib.lib.rl_vecenv_reset(0, 0, None, None, None, None, 0, 0, 0, None, None, None) == -1

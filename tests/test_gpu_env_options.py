@@ -22,6 +22,9 @@ CASES = [
     (3, dict(action_noise=0.4)),
     (5, dict(ctrl_cost_coeff=0.3, action_noise=0.05)),
     (6, dict(ctrl_cost_coeff=0.2, alive_coeff=2.5, action_noise=0.05)),
+    # limit_model / contact_model = "mujoco" (RL_CFG_LIMIT_MUJOCO = 4, RL_CFG_CONTACT_MUJOCO = 8): csrc/dyn_mjc.h
+    (3, dict(flags=4)), (3, dict(flags=8)), (3, dict(flags=12)), (3, dict(flags=12, action_noise=0.3)),
+    (5, dict(flags=12)), (5, dict(flags=8, ctrl_cost_coeff=0.3)), (6, dict(flags=12)), (6, dict(flags=4, alive_coeff=0.5)),
     (7, dict(flags=2)), (7, dict(action_noise=0.2)),
 ]
 
@@ -73,6 +76,9 @@ def test_vecenv_step_with_options_bit_exact(kind, cfg):
     (2, dict(flags=4), (32, 32)),                                     # soft-constraint joint limits: the scalar program
     (3, dict(action_noise=0.3), (64, 64)),
     (6, dict(ctrl_cost_coeff=0.2, alive_coeff=0.5, action_noise=0.05), (32, 32)),
+    # MuJoCo's soft-constraint limits and contacts (csrc/dyn_mjc.h): the env-per-lane kernels
+    (3, dict(flags=12), (64, 64)), (3, dict(flags=8, action_noise=0.2), (32, 32)), (5, dict(flags=12), (32, 32)),
+    (6, dict(flags=12), (32, 32)),
 ])
 def test_fused_rollout_with_options_replays_on_the_host(kind, cfg, hidden):
     from rllab_amd.envs.hip_env import HipVecEnv
@@ -85,7 +91,7 @@ def test_fused_rollout_with_options_replays_on_the_host(kind, cfg, hidden):
     q = v.q
     eps = rng.randn(q["act_dim"], T, n).astype(np.float32)
     draws = (rng.randn if q["reset_is_normal"] else rng.rand)(T + 1, q["reset_draws"], n).astype(np.float32)
-    if cfg.get("flags", 0) & 4:
+    if kind == 2 and cfg.get("flags", 0) & 4:
         draws *= 150.0           # limit model: start far outside the reset distribution (hinge angles ~ 1.5 N(0,1) rad
                                  # against limits of 1.745), so that the limit rows are active from the first sub-step
     za = rng.randn(T, q["act_dim"], n).astype(np.float32)
@@ -244,3 +250,40 @@ def test_position_only_on_the_fused_rollout(kind, ids, hidden):
     with torch.no_grad():
         mean64 = pol.mean_planes(a.obs.reshape(kept, -1).double(), pol.flat_params.double())
     assert float((a.means.reshape(da, -1).double() - mean64).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["half_cheetah", "walker2d", "hopper"])
+def test_soft_constraint_models_through_the_env_classes(name, quiet_logger):
+    """HalfCheetahEnv / Walker2DEnv / HopperEnv(limit_model="mujoco", contact_model="mujoco"): the options reach the kernels
+    as rl_env_cfg flags, such an env is sampled by the fused env-per-lane rollout (the one-body-per-lane kernels are built
+    for the penalty models), its first batch replays on the host build bit for bit, and TRPO steps on it."""
+    import importlib
+    from rllab.algos.trpo import TRPO
+    from rllab.baselines.linear_feature_baseline import LinearFeatureBaseline
+    from rllab.envs.normalized_env import normalize
+    from rllab.misc import ext
+    from rllab.policies.gaussian_mlp_policy import GaussianMLPPolicy
+    from rllab_amd import _lib
+    cls = dict(half_cheetah="HalfCheetahEnv", walker2d="Walker2DEnv", hopper="HopperEnv")[name]
+    Env = getattr(importlib.import_module("rllab.envs.mujoco.%s_env" % name), cls)
+    with pytest.raises(ValueError):
+        Env(contact_model="box2d")
+    ext.set_seed(2)
+    env = normalize(Env(limit_model="mujoco", contact_model="mujoco"))
+    policy = GaussianMLPPolicy(env_spec=env.spec, hidden_sizes=(32, 32))
+    algo = TRPO(env=env, policy=policy, baseline=LinearFeatureBaseline(env_spec=env.spec), batch_size=96 * 40,
+                max_path_length=40, n_itr=2, discount=0.99, step_size=0.01, sampler_args=dict(n_envs=96, seed=5))
+    algo.start_worker()
+    algo.init_opt()
+    v = algo.sampler.vec_env
+    assert int(v.cfg.flags) == _lib.CFG_LIMIT_MUJOCO | _lib.CFG_CONTACT_MUJOCO
+    assert algo.sampler.sampling_path(policy)[0].startswith("fused rollout kernel")
+    assert v.rollout_plan(policy, 40).name.decode().startswith("rollout_kernel<")
+    pickled = __import__("pickle").loads(__import__("pickle").dumps(env))
+    assert pickled.wrapped_env.contact_model == "mujoco" and pickled.wrapped_env.limit_model == "mujoco"
+    theta0 = policy.get_param_values()
+    for itr in range(2):
+        paths = algo.sampler.obtain_samples(itr)
+        sd = algo.sampler.process_samples(itr, paths)
+        algo.optimize_policy(itr, sd)
+    assert np.isfinite(policy.get_param_values()).all() and np.abs(policy.get_param_values() - theta0).max() > 0

@@ -608,6 +608,27 @@ def test_swimmer_limit_model_option_travels_with_the_env():
         SwimmerEnv(limit_model="lcp")
 
 
+@pytest.mark.parametrize("mod,cls", [("half_cheetah_env", "HalfCheetahEnv"), ("walker2d_env", "Walker2DEnv"), ("hopper_env", "HopperEnv")])
+def test_legged_constraint_model_options_travel_with_the_env(mod, cls):
+    """HalfCheetahEnv / Walker2DEnv / HopperEnv(limit_model=.., contact_model=..) set RL_CFG_LIMIT_MUJOCO / RL_CFG_CONTACT_MUJOCO,
+    default to the penalty models, survive pickling; unknown models are rejected."""
+    import importlib
+    from rllab_amd import _lib
+    from rllab_amd.envs.normalized_env import normalize
+    Env = getattr(importlib.import_module("rllab_amd.envs.mujoco." + mod), cls)
+    assert Env()._cfg.get("flags", 0) == 0 and (Env().limit_model, Env().contact_model) == ("penalty", "penalty")
+    assert Env(limit_model="mujoco")._cfg["flags"] == _lib.CFG_LIMIT_MUJOCO
+    assert Env(contact_model="mujoco")._cfg["flags"] == _lib.CFG_CONTACT_MUJOCO
+    env = Env(limit_model="mujoco", contact_model="mujoco")
+    assert env._cfg["flags"] == _lib.CFG_LIMIT_MUJOCO | _lib.CFG_CONTACT_MUJOCO == 12
+    back = pickle.loads(pickle.dumps(normalize(env)))
+    assert back.wrapped_env._cfg["flags"] == 12 and back.wrapped_env.contact_model == "mujoco"
+    with pytest.raises(ValueError):
+        Env(contact_model="lcp")
+    with pytest.raises(ValueError):
+        Env(limit_model="hard")
+
+
 def test_ext_helpers_behave_like_the_reference_module():
     """The Theano-free helpers of rllab/misc/ext.py (:23-40, :71-120, :151-182, :302-338, :373-391), each held to
     what the reference's does on hand-worked cases -- including its quirks: a scan starts from ``base`` only when

@@ -625,3 +625,116 @@ def test_two_leg_lane_table_covers_the_model_exactly_once(kind, header, ns):
             seen.append(hits[0])
     assert sorted(seen) == list(range(len(CBODY)))                  # every sphere of the model, once
     assert np.array_equal(t[0, 2:6], t[4, 2:6])                     # the torso body on both role-0 lanes
+
+
+# ---- limit_model / contact_model = "mujoco": csrc/dyn_mjc.h against oracle/np_mjc.py -----------------------------------
+def _mjc_cases():
+    from oracle import np_cheetah as C
+    from oracle import np_mjc as MJ
+    from oracle import np_planar as P
+    gen_c = lambda rng: (np.concatenate([rng.randn(1), [rng.uniform(-0.25, -0.05)], rng.uniform(-.3, .3, 1),
+                                         rng.uniform(-1.3, 1.2, 6)]), rng.randn(9) * 2)
+    gen_w = lambda rng: (np.concatenate([[rng.uniform(1.12, 1.19)], rng.randn(1), rng.uniform(-.1, .1, 1),
+                                         rng.uniform(-0.3, 0.2, 2), rng.uniform(-1, 1, 1), rng.uniform(-2.8, 0.1, 2),
+                                         rng.uniform(-.3, .3, 1)]), rng.randn(9) * 2)
+    gen_h = lambda rng: (np.concatenate([[rng.uniform(1.10, 1.22)], rng.randn(1), rng.uniform(-.1, .1, 1),
+                                         rng.uniform(-0.3, 0.2, 2), rng.uniform(-1, 1, 1)]), rng.randn(6) * 2)
+    return {3: (MJ.cheetah, C.to_engine_state, gen_c, 2.0, 2e-9), 5: (MJ.walker, P.walker_to_engine_state, gen_w, 2.0, 1e-8),
+            6: (MJ.hopper, P.hopper_to_engine_state, gen_h, 1.0, 2e-9)}
+
+
+@pytest.mark.parametrize("flags", [12, 4, 8])
+@pytest.mark.parametrize("kind", [3, 5, 6])
+def test_mujoco_soft_constraints_vs_independent_restatement(kind, flags):
+    """HalfCheetahEnv / Walker2DEnv / HopperEnv(limit_model="mujoco", contact_model="mujoco") (rl_env_cfg flags 4 / 8):
+    one env step of csrc/dyn_mjc.h, float64 host build, against oracle/np_mjc.py -- the rigid body by the
+    automatic-differentiation Lagrangian in MuJoCo's coordinates, constraint Jacobians by autograd, reference
+    acceleration / impedance / regulariser retyped from MuJoCo's documented model with the MJCFs' own solref / solimp /
+    margin / friction, the quadratic programme over f >= 0 by the same 100 Gauss-Seidel sweeps (agreement to the two
+    rigid-body formulations' rounding) and, beside it, EXACTLY by scipy's NNLS (whose optimality conditions are checked, and
+    from which the sweeps' forces differ by a bounded acceleration) -- from states with feet in the floor and hinges beyond
+    their range; the class whose flag is off keeps its penalty form."""
+    from oracle import np_mjc as MJ
+    make, to_engine, gen, ascale, tol = _mjc_cases()[kind]
+    model = make()
+    rng = np.random.RandomState(100 * kind + flags)
+    e = H.HostEnv(kind, np.float64, normalize=True, cfg=dict(flags=flags))
+    lb, ub = H.action_bounds(kind)
+    info = {}
+    for trial in range(3):
+        qp, qv = gen(rng)
+        e.state[:] = to_engine(qp, qv)
+        a = rng.randn(len(lb)) * ascale
+        e.step(a)
+        ctrl = np.clip(lb + (a + 1.0) * 0.5 * (ub - lb), lb, ub)
+        q2, v2 = MJ.advance(model, qp, qv, ctrl, limit_mj=bool(flags & 4), contact_mj=bool(flags & 8), solver="pgs", info=info)
+        assert np.abs(e.state - to_engine(q2, v2)).max() < tol, (trial, np.abs(e.state - to_engine(q2, v2)).max())
+    assert info["K"] >= 3                          # constraint rows were active (summed over trials and sub-steps)
+    assert info["kkt"] < 1e-9                      # the NNLS forces satisfy f >= 0, H f + g >= 0, f . (H f + g) = 0
+    assert info["sweeps_gap"] < 0.05               # 100 sweeps against the exact minimiser, m / s^2 (x 0.0025 s per sub-step)
+
+
+@pytest.mark.parametrize("kind,name", [(3, "cheetah"), (5, "walker"), (6, "hopper")])
+def test_mujoco_soft_constraints_behave(kind, name):
+    """What the model must DO: without constraint rows the step is the penalty model's (same rigid body, two
+    formulations: 1e-9); a body dropped on the floor comes to rest ON it (penetration below a centimetre, nothing
+    explodes); a hinge driven against its limit stops within hundredths of a radian of it; float32 tracks float64."""
+    q = H.query(kind)
+    nq = q["state_dim"] // 2
+    rng = np.random.RandomState(kind)
+    # (i) in the air, inside every range: no row, the two rigid-body programs agree
+    a, b = H.HostEnv(kind, np.float64, normalize=True, cfg=dict(flags=12)), H.HostEnv(kind, np.float64, normalize=True)
+    z = 0.3 * rng.randn(q["reset_draws"])
+    a.reset(z); b.reset(z)
+    lo, hi = limits_of(kind)
+    for env in (a, b):
+        env.state[0] += 1.0
+        env.state[3:nq] = 0.5 * (lo + hi) + 0.05 * z[3:nq]      # (the reset pose has hinges ON their limits: mid-range instead)
+    act = 0.1 * rng.randn(q["act_dim"])
+    for _ in range(3):
+        a.step(act); b.step(act)
+    assert np.abs(a.state - b.state).max() < 1e-9
+    # (ii) dropped from the reset pose with zero action
+    e64, e32 = (H.HostEnv(kind, dt, normalize=True, cfg=dict(flags=12)) for dt in (np.float64, np.float32))
+    e64.reset(np.zeros(q["reset_draws"])); e32.reset(np.zeros(q["reset_draws"]))
+    worst_gap = 0.0
+    from oracle import np_mjc as MJ
+    import torch
+    model = _mjc_cases()[kind][0]()
+    to_mj = {3: lambda s: np.concatenate([[s[1], s[0] - 0.7], s[2:9]]),
+             5: lambda s: s[:9] * np.concatenate([[1, 1, 1], model_sign(kind)]),
+             6: lambda s: s[:6] * np.concatenate([[1, 1, 1], model_sign(kind)])}[kind]
+    for t in range(40):
+        e64.step(np.zeros(q["act_dim"])); e32.step(np.zeros(q["act_dim"]))
+        pts, _, rads, _ = model.spheres(torch.as_tensor(to_mj(e64.state)))
+        worst_gap = min(worst_gap, float((pts[1::2].numpy() - np.array(rads)).min()))
+    assert -0.02 < worst_gap < 0.0                          # touched the floor, never sank two centimetres into it (impact from the drop)
+    assert np.abs(e64.state[nq:]).max() < 20.0 and np.isfinite(e64.state).all()
+    assert np.abs(e64.state - e32.state.astype(np.float64)).max() < 5e-3
+    # (iii) the first hinge released 0.03 rad beyond its upper limit, in the air: the limit row brings it back
+    e = H.HostEnv(kind, np.float64, normalize=True, cfg=dict(flags=4))
+    e.reset(np.zeros(q["reset_draws"]))
+    lo, hi = limits_of(kind)
+    e.state[3:nq] = 0.5 * (lo + hi)
+    e.state[3] = hi[0] + 0.03
+    over = []
+    for _ in range(12):
+        e.state[0] += 0.05                                   # (stay clear of the floor while it falls)
+        e.step(np.zeros(q["act_dim"]))
+        over.append(float(e.state[3] - hi[0]))
+    assert max(over) < 0.03 and over[-1] < 0.01 and np.isfinite(e.state).all()
+
+
+def model_sign(kind):
+    from oracle import np_planar as P
+    return {5: P.WALKER.sign, 6: P.HOPPER.sign}[kind]
+
+
+def limits_of(kind):
+    """Hinge ranges in the engine's (tree) sign convention, read from the generated constants headers."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rllab_amd", "csrc")
+    hdr = open(os.path.join(root, {3: "cheetah_constants.h", 5: "walker_constants.h", 6: "hopper_constants.h"}[kind])).read()
+    grab = lambda nm: np.array([float(x) for x in re.search(r"\b%s\[NB\] = \{([^}]*)\}" % nm, hdr).group(1).split(",")])[1:]
+    return grab("LO"), grab("HI")

@@ -8,6 +8,7 @@ import pytest
 class _FakeVecEnv(object):
     position_ids = None
     graphable = True
+    step_counter = 0
 
 
 def _sampler(policy):
@@ -47,37 +48,33 @@ def test_prefetch_is_a_noop_without_a_parameter_version_or_a_fused_rollout():
 
     for pol in (NoVersion(), Stepwise()):
         s = _sampler(pol)
-        s.obtain_samples = lambda itr: calls.append(itr)
+        s._rollout_chunk = lambda policy, steps, first: calls.append(steps)
         s.prefetch(3)
         assert calls == [] and getattr(s, "_prefetched", None) is None
 
     pol = Fused()
     s = _sampler(pol)
-    real = s.obtain_samples
     s.last_sample_time = 0.125
 
-    def fake(itr):
-        calls.append(itr)
-        s.last_sample_time = 99.0
-        return "batch%d" % itr
-    s.obtain_samples = fake
+    def fake_chunk(policy, steps, first):
+        calls.append((steps, first))
+        s.vec_env.step_counter += steps + 1            # a launch consumes RNG counters
+        return types.SimpleNamespace(B=10, tag="batch%d" % len(calls))
+    s._rollout_chunk = fake_chunk
+    s._meet_batch_size = lambda policy, first: first   # (a never-terminating env: the first launch is the batch)
     s.prefetch(4)
-    assert calls == [4] and s._prefetched == (4, 7, "batch4")
+    assert calls == [(5, True)] and s._prefetched[:2] == (4, 7) and s._prefetched[2].tag == "batch1"
     assert s.last_sample_time == 0.125             # the enqueue of the next batch is not this iteration's time
     s.prefetch(4)                                  # idempotent
-    assert calls == [4]
-    s.obtain_samples = real
-    assert s.obtain_samples(4) == "batch4"         # same version: handed out
-    assert s._prefetched is None
-    s.obtain_samples = fake
+    assert calls == [(5, True)]
+    assert s.obtain_samples(4).traj.tag == "batch1"    # same version: handed out
+    assert s._prefetched is None and s.vec_env.step_counter == 6
     s.prefetch(5)
-    pol.v = 8                                      # parameters moved: the prefetched batch must not be used
-    s.obtain_samples = real
-    s._takes_fused_rollout = lambda p: False
-    s._stepwise_rollout = lambda p, T: types.SimpleNamespace(B=10)
-    s.use_graph = False
+    assert s.vec_env.step_counter == 12
+    pol.v = 8                                      # parameters moved: the prefetched batch must not be used ...
     out = s.obtain_samples(5)
-    assert out != "batch5"
+    assert out.traj.tag == "batch3"                # ... a new one is launched, from the RNG counter the dropped one started at
+    assert s.vec_env.step_counter == 12
 
 
 def test_logger_decides_who_writes_at_write_time(tmp_path, monkeypatch):
