@@ -55,7 +55,7 @@ const char* rl_last_error(void);
  * rl_running_norm (NormalizedEnv's running observation / reward normalisation inside the fused rollout).
  * 13: rl_env_terminates; rl_rollout_args.reset_at_start == 0 continues from last_obs (the sampler's further launches
  * until batch_size whole-path samples are in, running normalisation included); RL_CFG_CONTACT_MUJOCO, and RL_CFG_LIMIT_MUJOCO
- * for the legged envs. */
+ * for the legged envs; rl_rollout_args.std_layer_activations, identity layers on the cooperative (wide) kernels. */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -273,6 +273,10 @@ typedef struct rl_rollout_args {
                                  0 = tanh layers; rectify / identity layers on the equal-width (32,32) / (64,64) kernels */
     const rl_launch_opts* opts;   /* host; NULL = every launch rule the library's own */
     const rl_running_norm* norm;  /* host; NULL = no running normalisation (NormalizedEnv's defaults) */
+    int32_t std_layer_activations;/* with theta_std: hidden activations of the log-std network (as layer_activations).  Next to a
+                                     log-std network both words may hold tanh / identity layers only: a ONE-hidden-layer
+                                     network (gaussian_mlp_policy.py:60-90 takes any hidden sizes) runs as (H, H) with W1 = I */
+    int32_t reserved_tail;
 } rl_rollout_args;
 
 int rl_rollout_gaussian_mlp(const rl_rollout_args* args, void* stream);

@@ -63,7 +63,8 @@ class RolloutArgs(ctypes.Structure):
         ("dones", ctypes.c_void_p), ("last_obs", ctypes.c_void_p), ("cfg", ctypes.POINTER(EnvCfg)),
         ("theta_std", ctypes.c_void_p), ("log_stds", ctypes.c_void_p), ("std_hidden0", ctypes.c_int32),
         ("std_hidden1", ctypes.c_int32), ("std_hidden2", ctypes.c_int32), ("layer_activations", ctypes.c_int32),
-        ("opts", ctypes.c_void_p), ("norm", ctypes.c_void_p),
+        ("opts", ctypes.c_void_p), ("norm", ctypes.c_void_p), ("std_layer_activations", ctypes.c_int32),
+        ("reserved_tail", ctypes.c_int32),
     ]
 
 
@@ -274,12 +275,12 @@ def env_query(kind):
 
 
 def rollout_plan(kind, n_envs, horizon, hidden3, std_hidden3=(0, 0, 0), cfg_flags=0, layer_activations=0, norm=None,
-                 obs_noise=0.0):
+                 obs_noise=0.0, std_layer_activations=0):
     """``RolloutPlan`` of a fused rollout of these sizes under the current launch options (rl_rollout_plan_query), or None
     when the library has no kernel for it (the reason is then in ``lib.rl_last_error()``)."""
     a = RolloutArgs(kind=kind, n_envs=int(n_envs), horizon=int(horizon), hidden0=hidden3[0], hidden1=hidden3[1],
                     hidden2=hidden3[2], std_hidden0=std_hidden3[0], std_hidden1=std_hidden3[1], std_hidden2=std_hidden3[2],
-                    layer_activations=int(layer_activations))
+                    layer_activations=int(layer_activations), std_layer_activations=int(std_layer_activations))
     cfg = None
     if cfg_flags or obs_noise:
         cfg = EnvCfg()

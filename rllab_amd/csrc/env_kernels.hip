@@ -516,7 +516,7 @@ struct RolloutPolicyWide {
 #pragma unroll
                     for (int m = 0; m < KS0; ++m) acc = mfma(f[0][(t * KS0 + m) * WV + lane], xb[m], acc);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) h[0][t][r] = ftanh(acc[r]);
+                    for (int r = 0; r < 16; ++r) h[0][t][r] = (s.ident & 1) ? acc[r] : ftanh(acc[r]);
                 }
 #pragma unroll
             for (int l = 1; l < WIDE_MAX_L; ++l)
@@ -536,7 +536,7 @@ struct RolloutPolicyWide {
                                         acc = mfma(f[l][(t * ks + 16 * tt + mm) * WV + lane], h[(l + 1) & 1][tt][mm], acc);
                                 }
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) h[l & 1][t][r] = ftanh(acc[r]);
+                            for (int r = 0; r < 16; ++r) h[l & 1][t][r] = ((s.ident >> l) & 1) ? acc[r] : ftanh(acc[r]);
                         }
                 }
             // the last hidden layer sits in h[(L - 1) & 1]: both cases spelled out, a run-time index would send the
@@ -654,7 +654,7 @@ struct RolloutPolicyCoop {
     // k-steps of group g (registers: layer 0) or read from `src`
     template <int NBW, bool FROM_REGS>
     __device__ __forceinline__ void blocks(const float* wfl, const float* bl, int G, const f32x4* xg, const float* src,
-                                           float* dst) const {
+                                           float* dst, bool ident) const {
         const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
         const int lp = n * 4 + q;                               // the lane's slot inside an activation group
         f32x4 acc[NBW][2];
@@ -696,14 +696,18 @@ struct RolloutPolicyCoop {
         for (int j = 0; j < NBW; ++j) {
             const int b = wave + COOP_WAVES * j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[b * 256 + (n * 4 + r) * 4 + q] = ftanh(acc[j][0][r] + acc[j][1][r]);
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[j][0][r] + acc[j][1][r];
+                dst[b * 256 + (n * 4 + r) * 4 + q] = ident ? z : ftanh(z);
+            }
         }
     }
     template <bool FROM_REGS>
     __device__ __forceinline__ void layer(int l, int K, const f32x4* xg, const float* src, float* dst) const {
         const int nb = s.H[l] / 16;                            // 2, 4 or 8 blocks
-        if (wave + COOP_WAVES < nb) blocks<2, FROM_REGS>(wf[l], bias[l], K / 16, xg, src, dst);
-        else if (wave < nb) blocks<1, FROM_REGS>(wf[l], bias[l], K / 16, xg, src, dst);
+        const bool ident = (s.ident >> l) & 1;                  // (WideShape.ident: an identity layer)
+        if (wave + COOP_WAVES < nb) blocks<2, FROM_REGS>(wf[l], bias[l], K / 16, xg, src, dst, ident);
+        else if (wave < nb) blocks<1, FROM_REGS>(wf[l], bias[l], K / 16, xg, src, dst, ident);
         __syncthreads();
     }
 
@@ -2048,9 +2052,18 @@ static int plan_rollout(const rl_rollout_args* g, rl_rollout_plan* p) {
     plan_fill(p, RL_ROLLOUT_UNSUPPORTED, 0, 0, 0, 0, "");
     char nm[96];
     const bool equal = g->hidden2 == 0 && g->hidden0 == g->hidden1 && (g->hidden0 == 32 || g->hidden0 == 64);
-    if (g->layer_activations != 0 && (!equal || g->theta_std != nullptr))
-        return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: rectify / identity hidden layers run on the (32,32) / "
-                         "(64,64) kernels only (hidden %d,%d,%d)", g->hidden0, g->hidden1, g->hidden2);
+    WideShape act_probe;
+    act_probe.L = g->hidden2 > 0 ? 3 : 2;
+    const bool wide_acts_ok = wide_activations(g->layer_activations, act_probe);   // tanh / identity layers only
+    WideShape std_probe;
+    std_probe.L = g->std_hidden2 > 0 ? 3 : 2;
+    const bool std_acts_ok = wide_activations(g->std_layer_activations, std_probe);
+    if ((g->layer_activations != 0 && !wide_acts_ok && (!equal || g->theta_std != nullptr)) ||
+        (g->theta_std != nullptr && !std_acts_ok))
+        return set_error(RL_ERR_UNSUPPORTED, "rl_rollout_gaussian_mlp: rectify hidden layers run on the (32,32) / (64,64) "
+                         "kernels only (and not next to a log-std network), identity layers on those and on the wide / two-"
+                         "network kernels (hidden %d,%d,%d, layers 0x%x / 0x%x)", g->hidden0, g->hidden1, g->hidden2,
+                         g->layer_activations, g->std_layer_activations);
     const bool small_offsets = (size_t)Env::OBS * (size_t)T * (size_t)n * 4 < ((size_t)1 << 32);   // 32-bit plane offsets
     const int epw_req = (o.rollout_epw == 16 || o.rollout_epw == 64) ? o.rollout_epw : 0;
     const int epw_generic = epw_req ? epw_req : (n <= 16 * 1024 ? 16 : 64);
@@ -2226,10 +2239,12 @@ static int launch_rollout(const rl_rollout_args* g, hipStream_t st) {
     const size_t lds = (size_t)pl.lds_bytes;
     const int H = g->hidden0, epw = pl.envs_per_wavefront;
     WideShape shape, sshape;
-    wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape);
+    if (wide_shape(Env::OBS, Env::ACT, g->hidden0, g->hidden1, g->hidden2, shape))
+        wide_activations(g->layer_activations, shape);      // identity layers (plan_rollout refused anything else)
     switch (pl.kernel) {
         case RL_ROLLOUT_DUAL: {
             wide_shape(Env::OBS, Env::ACT, g->std_hidden0, g->std_hidden1, g->std_hidden2, sshape);
+            wide_activations(g->std_layer_activations, sshape);
             const size_t mean_floats = RolloutPolicyWide<Env>::lds_floats(shape, 64 * pl.wavefronts_per_workgroup);
             static bool a16 = false, a64 = false;
             if (epw == 16) {

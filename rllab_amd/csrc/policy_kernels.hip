@@ -960,10 +960,11 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
         return set_error(RL_ERR_ARG, "unknown activation (%d, layers 0x%x)", g->activation, g->layer_activations);
     const bool all_tanh = a0 == RL_ACT_TANH && a1 == RL_ACT_TANH && a2 == RL_ACT_TANH;
     if (mode >= MODE_OUT) {
-        if (!all_tanh)
-            return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: tanh networks");
+        if (a0 == RL_ACT_RECTIFY || a1 == RL_ACT_RECTIFY || a2 == RL_ACT_RECTIFY)
+            return set_error(RL_ERR_UNSUPPORTED, "rl_mlp_forward / rl_mlp_backward: tanh (and identity) layers");
+        // (an identity layer -- the second layer of a one-hidden-layer network -- runs on the cooperative kernels)
 #define PLANECASE(DO, DA, H) \
-        if (g->hidden2 == 0 && d == DO && k == DA && h0 == H && h1 == H) \
+        if (all_tanh && g->hidden2 == 0 && d == DO && k == DA && h0 == H && h1 == H) \
             return dispatch_planes<Net<DO, DA, H>>(mode, g, vec, ws, ws_bytes, out, st, pl);
         PLANECASE(4, 1, 32) PLANECASE(6, 1, 32) PLANECASE(11, 1, 32) PLANECASE(13, 2, 32) PLANECASE(20, 3, 32)
         PLANECASE(20, 6, 32) PLANECASE(21, 6, 32)
@@ -1013,9 +1014,10 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
 #undef NETCASE
     // anything else with tanh layers of 32 / 64 / 128 units: the cooperative kernels
     if (cg) return set_error(RL_ERR_UNSUPPORTED, "rl_policy_fvp_cg_step: two-layer 32 / 64-unit nets only");
-    if (!all_tanh)
-        return set_error(RL_ERR_UNSUPPORTED, "obs_dim=%d act_dim=%d hidden=(%d,%d): rectify / identity layers run on the "
+    if (a0 == RL_ACT_RECTIFY || a1 == RL_ACT_RECTIFY)
+        return set_error(RL_ERR_UNSUPPORTED, "obs_dim=%d act_dim=%d hidden=(%d,%d): rectify layers run on the "
                          "equal-width two-layer kernels of the HIP-native (obs, action) pairs only", d, k, h0, h1);
+    // (identity layers: wide_pass_kernel takes them -- the second layer of a one-hidden-layer net of 65 .. 128 units)
     return wide_dispatch(mode, g, vec, ws, ws_bytes, out, st, loss_out);
 }
 

@@ -25,6 +25,8 @@ constexpr int WIDE_BS = 33;            // LDS tile row stride (floats)
 
 struct WideShape {
     int L;                 // hidden layers: 2 or 3
+    int ident;             // bit l: hidden layer l is the IDENTITY (a one-hidden-layer net of 65 .. 128 units runs as (128, 128)
+                           // with W1 = I, b1 = 0, policies/kernel_layout.py); every other layer is tanh
     int DO, DA;
     int H[WIDE_MAX_L];     // padded widths, 32 / 64 / 128 (H[2] = 0 when L == 2)
     int HT[WIDE_MAX_L];    // H / 32
@@ -46,6 +48,7 @@ struct WideShape {
 inline bool wide_shape(int DO, int DA, int h0, int h1, int h2, WideShape& s) {
     const int hs[3] = {h0, h1, h2};
     s.L = (h2 > 0) ? 3 : 2;
+    s.ident = 0;
     if (DO < 1 || DO > WIDE_MAX_DO || DA < 1 || DA > WIDE_MAX_DA) return false;
     for (int l = 0; l < WIDE_MAX_L; ++l) {
         s.H[l] = (l < s.L) ? hs[l] : 0;
@@ -82,4 +85,18 @@ inline bool wide_shape(int DO, int DA, int h0, int h1, int h2, WideShape& s) {
     return true;
 }
 
+}  // namespace rl
+
+namespace rl {
+// layer_activations (rl_policy_batch / rl_rollout_args: 2 bits per layer, 0 = the default, else code + 1) -> WideShape.ident;
+// false when a layer asks for anything but tanh (code 0) or the identity (code 2)
+inline bool wide_activations(int layer_activations, WideShape& s) {
+    s.ident = 0;
+    for (int l = 0; l < s.L; ++l) {
+        const int f = (layer_activations >> (2 * l)) & 3;
+        if (f == 3) s.ident |= 1 << l;            // RL_ACT_IDENTITY + 1
+        else if (f != 0 && f != 1) return false;  // RL_ACT_RECTIFY + 1
+    }
+    return true;
+}
 }  // namespace rl

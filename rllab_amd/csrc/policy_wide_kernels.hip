@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                 }
                 if (J.busy && J.q == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = ftanh(acc[r]);
+                    for (int r = 0; r < 16; ++r) acc[r] = ((s.ident >> l) & 1) ? acc[r] : ftanh(acc[r]);
                     wide_put(smem + p.Hb[l], J.t, lane, acc);
                     if (cache_wr) {
                         float* dst = a.cache + (size_t)tile * ctile + coff[l] + (32 * J.t + 4 * lh) * 32 + lj;
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                 if (J.busy && J.q == 0) {
                     const f32x16 hl = wide_get(smem + p.Hb[l], J.t, lane);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dacc[r] *= (1.0f - hl[r] * hl[r]);
+                    for (int r = 0; r < 16; ++r) dacc[r] *= ((s.ident >> l) & 1) ? 1.0f : (1.0f - hl[r] * hl[r]);
                     wide_put(smem + p.Db[l], J.t, lane, dacc);
                 }
             }
@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
 #pragma unroll
                 for (int k = 0; k < MAXDA; ++k)
                     if (k < DA) g = __builtin_fmaf(tail[s.tWo + u * DA + k], gmu[k], g);
-                gz[r] = g * (1.0f - hlast[r] * hlast[r]);
+                gz[r] = g * (((s.ident >> (L - 1)) & 1) ? 1.0f : (1.0f - hlast[r] * hlast[r]));
             }
             wide_put(smem + p.Db[L - 1], wave, lane, gz);      // the tangent of this layer is consumed: reuse its tile
         }
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             if (bbusy && q == 0) {
                 const f32x16 hb = wide_get(smem + p.Hb[l - 1], t, lane);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gz[r] = acc[r] * (1.0f - hb[r] * hb[r]);
+                for (int r = 0; r < 16; ++r) gz[r] = acc[r] * (((s.ident >> (l - 1)) & 1) ? 1.0f : (1.0f - hb[r] * hb[r]));
                 wide_put(smem + p.Db[l - 1], t, lane, gz);
             }
             __syncthreads();
@@ -976,11 +976,13 @@ int wide_dispatch(int mode, const rl_policy_batch* g, const float* vec, void* ws
     const WidePlanes planes = {cot, out_mean, out_dmean};
     const WidePlanes* pl = &planes;
     WideShape s;
-    if (g->activation != RL_ACT_TANH || g->layer_activations != 0 || !wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, s))
+    if (g->activation != RL_ACT_TANH || !wide_shape(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, s) ||
+        !wide_activations(g->layer_activations, s))
         return set_error(RL_ERR_UNSUPPORTED,
-                         "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d,%d): two or three tanh layers "
-                         "of 32 / 64 / 128 units, obs_dim <= %d, act_dim <= %d",
-                         g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, WIDE_MAX_DO, WIDE_MAX_DA);
+                         "no fused policy kernel for obs_dim=%d act_dim=%d hidden=(%d,%d,%d), layers 0x%x: two or three tanh "
+                         "(or identity) layers of 32 / 64 / 128 units, obs_dim <= %d, act_dim <= %d",
+                         g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2, g->layer_activations, WIDE_MAX_DO,
+                         WIDE_MAX_DA);
     return s.L == 2 ? wide_shape_class<2>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl)
                     : wide_shape_class<3>(s, mode, g, vec, ws, ws_bytes, out, st, loss_out, pl);
 }

@@ -206,14 +206,15 @@ class HipVecEnv(object):
         hs, hs_std = (layout.hidden3, (0, 0, 0)) if layout is not None else (tuple(dual[1]), tuple(dual[3]))
         # asked once per (sizes, launch options): the sampler asks before every rollout
         _lib.launch_opts()
-        acts = layout.layer_activations if layout is not None else 0
-        key = (hs, hs_std, T, flags, acts, norm, float(self.cfg.obs_noise), bytes(_lib._OPTS))
+        acts = layout.layer_activations if layout is not None else int(dual[4])
+        acts_std = 0 if layout is not None else int(dual[5])
+        key = (hs, hs_std, T, flags, acts, acts_std, norm, float(self.cfg.obs_noise), bytes(_lib._OPTS))
         cache = self.__dict__.setdefault("_plan_cache", {})
         if key not in cache:
             if len(cache) > 64:
                 cache.clear()
             cache[key] = _lib.rollout_plan(self.kind, self.n, T, hs, hs_std, cfg_flags=flags, layer_activations=acts,
-                                           norm=norm, obs_noise=float(self.cfg.obs_noise))
+                                           norm=norm, obs_noise=float(self.cfg.obs_noise), std_layer_activations=acts_std)
         return cache[key]
 
     def _first_layer_on_full_obs(self, theta, h0):
@@ -287,7 +288,8 @@ class HipVecEnv(object):
             theta_std=None if theta_std is None else theta_std.data_ptr(),
             log_stds=None if log_stds is None else log_stds.data_ptr(),
             std_hidden0=hs_std[0], std_hidden1=hs_std[1], std_hidden2=hs_std[2],
-            layer_activations=layout.layer_activations if layout is not None else 0, opts=_lib.launch_opts())
+            layer_activations=layout.layer_activations if layout is not None else int(dual[4]),
+            std_layer_activations=0 if dual is None else int(dual[5]), opts=_lib.launch_opts())
         if scale_reward is not None:          # NormalizingVecEnv: its outer scale (the inner executor's is 1)
             args.scale_reward = float(scale_reward)
         nrm = None

@@ -74,7 +74,8 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         self.policy = policy
         self.layout = _IdentityLayout(policy)
         do, da = policy.obs_dim, policy.action_dim
-        from rllab_amd.policies.kernel_layout import layer_padded_sizes, mlp_pad_index
+        from rllab_amd.policies.kernel_layout import layer_padded_sizes, mlp_identity_ones, mlp_layer_activations, mlp_pad_index
+        self.acts, self.ones = [], []    # per network: layer_activations word of its kernel copy, positions of its constant ones
         self.nets = []                   # (offset, size, padded hidden triple) of [mean net, std net] in the flat vector
         self.pad = []                    # per network: (index of its real parameters in its padded copy or None, padded size)
         for net in (policy._mean_network, policy._std_network):
@@ -84,6 +85,8 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
             self.nets.append((off, net.end_offset - off, Hs + (0,) * (3 - len(Hs))))
             idx, p_pad = mlp_pad_index(do, hs, Hs, da)
             assert idx.size == net.end_offset - off
+            self.acts.append(mlp_layer_activations(hs))          # (a one-hidden-layer network: tanh, then the identity W1 = I)
+            self.ones.append(torch.as_tensor(mlp_identity_ones(do, hs, Hs), dtype=torch.long, device=policy.flat_params.device))
             self.pad.append((None if hs == Hs else torch.as_tensor(idx, dtype=torch.long, device=policy.flat_params.device),
                              int(p_pad)))
         assert self.nets[0][0] == 0 and self.nets[1][0] == self.nets[0][1]
@@ -111,6 +114,8 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
                 idx, p_pad = self.pad[i]
                 if self._net_theta[i] is None:       # (padded positions and the Da trailing floats stay zero for good)
                     self._net_theta[i] = torch.zeros(p_pad + pol.action_dim, dtype=torch.float32, device=flat.device)
+                    if self.ones[i].numel():
+                        self._net_theta[i][self.ones[i]] = 1.0
                 self._scatter(i, self._net_theta[i], flat[off:off + size])
             self._theta_tag = tag
         return self._net_theta
@@ -160,9 +165,10 @@ class FusedAdaptiveStdOps(FusedGaussianMLPOps):
         pol = self.policy
         log_min = math.log(pol.min_std) if pol.min_std is not None else -1e30
         structs = []
-        for (_, _, h) in self.nets:
+        for (_, _, h), acts in zip(self.nets, self.acts):
             structs.append(_lib.PolicyBatch(
                 n_samples=B, obs_dim=self.dims[0], act_dim=da, hidden0=h[0], hidden1=h[1], hidden2=h[2], inv_count=inv,
+                layer_activations=acts,
                 log_min_std=log_min, theta=None, obs=obs.data_ptr(), actions=act.data_ptr(),
                 advantages=adv.data_ptr(), old_means=old_mean.data_ptr(), old_log_std=old_ls.data_ptr(),
                 weights=w.data_ptr()))

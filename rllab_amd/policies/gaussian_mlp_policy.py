@@ -137,12 +137,16 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
             ok = (self.fusable and Hs is not None and self.flat_params.is_cuda
                   and self.flat_params.dtype == torch.float32
                   and self.obs_dim <= MAX_OBS_DIM and self.action_dim <= MAX_ACT_DIM)
-            # rectify layers and the identity layer of a one-hidden-layer policy: the equal-width two-layer kernels of the
-            # HIP-native (obs, action) pairs only (the cooperative family evaluates tanh layers)
+            # rectify layers: the equal-width two-layer kernels of the HIP-native (obs, action) pairs only (the cooperative
+            # family evaluates tanh and identity layers); the identity layer of a one-hidden-layer policy: those, or the
+            # cooperative family's (128, 128) shape when the layer is 65 .. 128 tanh units wide
             if ok and (is_rectify(self.hidden_nonlinearity) or len(tuple(self.hidden_sizes)) == 1):
                 from rllab_amd.policies.fused_ops import FusedGaussianMLPOps
-                ok = (len(Hs) == 2 and Hs[0] == Hs[1] and Hs[0] in (32, 64)
-                      and (self.obs_dim, self.action_dim) in FusedGaussianMLPOps.NARROW_PAIRS)
+                narrow = (len(Hs) == 2 and Hs[0] == Hs[1] and Hs[0] in (32, 64)
+                          and (self.obs_dim, self.action_dim) in FusedGaussianMLPOps.NARROW_PAIRS)
+                one_wide = (len(tuple(self.hidden_sizes)) == 1 and Hs == (128, 128)
+                            and not is_rectify(self.hidden_nonlinearity))
+                ok = narrow or one_wide
             self._kernel_layout = KernelLayout(self) if ok else None
         return self._kernel_layout
 
@@ -162,7 +166,7 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
             return "output_nonlinearity is not None (the kernels' output layer is linear)"
         if padded_sizes(hs) is None:
             if len(hs) == 1:
-                return "hidden_sizes=%r: one hidden layer runs on the kernels up to 64 units" % (hs,)
+                return "hidden_sizes=%r: one hidden layer runs on the kernels up to 128 units" % (hs,)
             if len(hs) not in (2, 3):
                 return "hidden_sizes=%r has %d hidden layers (the kernels run one, two or three)" % (hs, len(hs))
             return "hidden_sizes=%r has a layer wider than 128 units" % (hs,)
@@ -179,13 +183,14 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
     def rollout_networks(self):
         """For a policy with a log-std NETWORK (adaptive_std / std_network) whose two networks the rollout kernels take
         -- two or three tanh hidden layers of at most 128 units each (zero-padded to 32 / 64 / 128 per layer), linear
-        outputs, float32 parameters on the device: ``(theta_mean, hidden3_mean, theta_std, hidden3_std)`` with each theta in the kernels'
-        policy layout [network parameters | action_dim unused floats] (persistent buffers, refreshed when the
+        outputs, float32 parameters on the device: ``(theta_mean, hidden3_mean, theta_std, hidden3_std, layer_activations_mean,
+        layer_activations_std)`` with each theta in the kernels' policy layout [network parameters | action_dim unused floats] (persistent buffers, refreshed when the
         parameters have moved).  None otherwise (such policies are sampled through the per-transition loop)."""
         if not self.state_dependent_std:
             return None
         if not hasattr(self, "_rollout_nets"):
-            from rllab_amd.policies.kernel_layout import MAX_ACT_DIM, MAX_OBS_DIM, layer_padded_sizes, mlp_pad_index
+            from rllab_amd.policies.kernel_layout import (MAX_ACT_DIM, MAX_OBS_DIM, layer_padded_sizes, mlp_identity_ones,
+                                                         mlp_layer_activations, mlp_pad_index)
             nets = (self._mean_network, self._std_network)
             ok = (self.flat_params.is_cuda and self.flat_params.dtype == torch.float32
                   and self.obs_dim <= MAX_OBS_DIM and self.action_dim <= MAX_ACT_DIM
@@ -195,15 +200,20 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
             if ok:
                 dev = self.flat_params.device
                 spans = [(n.params[0].offset, n.end_offset - n.params[0].offset) for n in nets]
-                pads, hid, bufs = [], [], []
-                for n in nets:          # every layer zero-padded to 32 / 64 / 128 (exact: tanh(0) = 0)
-                    hs = tuple(int(h) for h in n.hidden_sizes)
+                pads, hid, bufs, acts = [], [], [], []
+                for n in nets:          # every layer zero-padded to 32 / 64 / 128 (exact: tanh(0) = 0); a one-hidden-layer
+                    hs = tuple(int(h) for h in n.hidden_sizes)      # network runs with the identity as its second layer
                     Hs = layer_padded_sizes(hs)
                     idx, p_pad = mlp_pad_index(self.obs_dim, hs, Hs, self.action_dim)
                     pads.append(None if hs == Hs else torch.as_tensor(idx, dtype=torch.long, device=dev))
                     hid.append(Hs + (0,) * (3 - len(Hs)))
-                    bufs.append(torch.zeros(p_pad + self.action_dim, dtype=torch.float32, device=dev))
-                self._rollout_nets = dict(spans=spans, bufs=bufs, hidden=hid, pads=pads, tag=None)
+                    buf = torch.zeros(p_pad + self.action_dim, dtype=torch.float32, device=dev)
+                    ones = mlp_identity_ones(self.obs_dim, hs, Hs)
+                    if ones.size:
+                        buf[torch.as_tensor(ones, dtype=torch.long, device=dev)] = 1.0          # W1 = I: constants for good
+                    bufs.append(buf)
+                    acts.append(mlp_layer_activations(hs))
+                self._rollout_nets = dict(spans=spans, bufs=bufs, hidden=hid, pads=pads, acts=acts, tag=None)
         r = self._rollout_nets
         if r is None:
             return None
@@ -216,7 +226,7 @@ class GaussianMLPPolicy(StochasticPolicy, Serializable):
                 else:
                     buf.index_copy_(0, idx, flat[off:off + size])
             r["tag"] = tag
-        return r["bufs"][0], r["hidden"][0], r["bufs"][1], r["hidden"][1]
+        return r["bufs"][0], r["hidden"][0], r["bufs"][1], r["hidden"][1], r["acts"][0], r["acts"][1]
 
     def effective_log_std(self, flat=None):
         if self._log_std_param is None:

@@ -28,6 +28,7 @@ TILE_SIZES = (32, 64)            # the equal-width two-layer kernels
 WIDE_TILE_SIZES = (32, 64, 128)  # per-layer widths of the cooperative kernels
 MAX_OBS_DIM = 30                 # obs_dim + 1 (bias slot) must fit one 32-row input tile
 MAX_ACT_DIM = 8
+ACT_TANH, ACT_RECTIFY, ACT_IDENTITY = 0, 1, 2      # rl_activation (include/rllab_amd.h)
 
 
 def tile_for(hidden_sizes):
@@ -44,10 +45,11 @@ def tile_for(hidden_sizes):
 def padded_sizes(hidden_sizes):
     """The kernels' hidden widths for ``hidden_sizes``: (H, H) of the equal-width family when it applies, else every
     layer on its own next size of 32 / 64 / 128 (two or three layers); None when no kernel runs the net.  ONE hidden
-    layer of at most 64 units runs as (H, H) with an identity second layer (``KernelLayout.identity_layer``)."""
+    layer of at most 128 units runs as (H, H) with an identity second layer (``KernelLayout.identity_layer``)."""
     hs = tuple(int(h) for h in hidden_sizes)
-    if len(hs) == 1 and 1 <= hs[0] <= TILE_SIZES[-1]:
-        H = next(t for t in TILE_SIZES if hs[0] <= t)
+    if len(hs) == 1 and 1 <= hs[0] <= WIDE_TILE_SIZES[-1]:
+        # (65 .. 128 units: the cooperative family's (128, 128) shape, its second layer the identity as well)
+        H = next(t for t in WIDE_TILE_SIZES if hs[0] <= t)
         return (H, H)
     H = tile_for(hs)
     if H is not None:
@@ -59,17 +61,46 @@ def padded_sizes(hidden_sizes):
 
 def layer_padded_sizes(hidden_sizes):
     """Every layer on its own next size of 32 / 64 / 128 (two or three layers); None when no kernel runs the net.
-    (The networks-on-planes entry points -- adaptive_std -- take any such triple.)"""
+    (The networks-on-planes entry points -- adaptive_std -- take any such triple.)  ONE hidden layer of at most 128 units
+    runs as (H, H) with the identity as its second layer (``mlp_identity_ones`` / ``mlp_layer_activations``)."""
     hs = tuple(int(h) for h in hidden_sizes)
+    if len(hs) == 1 and 1 <= hs[0] <= WIDE_TILE_SIZES[-1]:
+        H = next(t for t in WIDE_TILE_SIZES if hs[0] <= t)
+        return (H, H)
     if len(hs) not in (2, 3) or min(hs) < 1 or max(hs) > WIDE_TILE_SIZES[-1]:
         return None
     return tuple(next(t for t in WIDE_TILE_SIZES if h <= t) for h in hs)
+
+
+def mlp_layer_activations(hidden_sizes):
+    """``layer_activations`` word (2 bits per layer: code + 1) of the KERNEL copy of a tanh MLP: 0 (tanh layers) unless the net
+    has one hidden layer -- then tanh, identity."""
+    return ((ACT_TANH + 1) | ((ACT_IDENTITY + 1) << 2)) if len(tuple(hidden_sizes)) == 1 else 0
+
+
+def mlp_identity_ones(in_dim, hidden_sizes, padded):
+    """Positions, in the padded kernel-layout vector, of the ones of the identity second layer W1 = I that the kernel copy of a
+    ONE-hidden-layer MLP carries as constants (empty otherwise)."""
+    hs, Hs = tuple(int(h) for h in hidden_sizes), tuple(int(h) for h in padded)
+    if len(hs) != 1:
+        return np.zeros(0, dtype=np.int64)
+    H = Hs[0]
+    oW1 = in_dim * H + H
+    return oW1 + np.arange(H) * (H + 1)
 
 
 def mlp_pad_index(in_dim, hidden_sizes, padded, out_dim):
     """Position of every parameter of an MLP (flat order W_0, b_0, ..., W_out, b_out; W_l is [in, out] row-major) inside
     the same net with its hidden widths zero-padded to ``padded``; returns (index array [P_real], P_pad)."""
     hs, Hs = tuple(int(h) for h in hidden_sizes), tuple(int(h) for h in padded)
+    if len(hs) == 1:
+        # (in -> h -> out) inside (in -> H -> H [identity] -> out): W0, b0, then the constants W1 = I, b1 = 0, then Wout, bout
+        h, H = hs[0], Hs[0]
+        oWo = in_dim * H + H + H * H + H
+        idx = [(np.arange(in_dim)[:, None] * H + np.arange(h)[None, :]).reshape(-1), in_dim * H + np.arange(h),
+               oWo + (np.arange(h)[:, None] * out_dim + np.arange(out_dim)[None, :]).reshape(-1),
+               oWo + H * out_dim + np.arange(out_dim)]
+        return np.concatenate(idx), oWo + H * out_dim + out_dim
     ins_real, ins_pad = (in_dim,) + hs, (in_dim,) + Hs
     idx, off = [], 0
     for l in range(len(Hs)):
@@ -85,7 +116,6 @@ def mlp_pad_index(in_dim, hidden_sizes, padded, out_dim):
     return np.concatenate(idx), off
 
 
-ACT_TANH, ACT_RECTIFY, ACT_IDENTITY = 0, 1, 2      # rl_activation (include/rllab_amd.h)
 
 
 class KernelLayout(object):
@@ -142,7 +172,7 @@ class KernelLayout(object):
         W0 [do, h], b0 [h], Wout [h, da], bout, log_std sit at their padded positions; W1 = I and b1 = 0 are constants of
         the kernel copy (never trained: ``unpack`` gathers the real entries only, ``pack`` leaves their tangents zero)."""
         self.hidden, self.H = (H, H), H
-        self.wide, self.exact = False, False
+        self.wide, self.exact = H not in TILE_SIZES, False      # 128: the cooperative kernels (identity layers since round 6)
         self.P = policy.flat_params.numel()
         oW0, ob0 = 0, do * H
         oW1 = ob0 + H

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(4, 1, 32, 32), (13, 2, 32, 32), (13, 2, 64, 32), (20, 6, 32, 64),
           (13, 2, (128, 64, 32), 32), (20, 6, (128, 128), (128, 64)), (17, 3, 64, 32), (11, 1, (64, 32), (32, 64, 32)),
           # widths that are not tile sizes: each network zero-padded per layer (rllab's own (100, 50, 25), a narrow std net)
-          (13, 2, (100, 50, 25), (20, 20)), (20, 6, (48, 48), (100, 50, 25)), (4, 1, (8, 8), (5, 7, 9))]
+          (13, 2, (100, 50, 25), (20, 20)), (20, 6, (48, 48), (100, 50, 25)), (4, 1, (8, 8), (5, 7, 9)),
+          # one hidden layer (round 6): the network's kernel copy is (H, H) with W1 = I, an identity layer
+          (13, 2, (32, 32), (16,)), (20, 6, (100,), (16,)), (4, 1, (20,), (32, 32))]
 
 
 def _policy(do, da, hm, hs, min_std=1e-6, seed=0):
@@ -200,7 +202,9 @@ def test_trpo_with_adaptive_std_and_free_form_widths_stays_on_the_kernels(quiet_
 
 
 @pytest.mark.parametrize("kind,hm,hs", [(0, (32, 32), (32, 32)), (2, (64, 64), (32, 32)), (3, (128, 64, 32), (32, 32)),
-                                        (6, (32, 32), (64, 64)), (2, (100, 50, 25), (20, 20)), (0, (8, 8), (5, 7, 9))])
+                                        (6, (32, 32), (64, 64)), (2, (100, 50, 25), (20, 20)), (0, (8, 8), (5, 7, 9)),
+                                        # one hidden layer (round 6): (H, H) with the identity as second layer
+                                        (2, (32, 32), (16,)), (3, (100,), (16,)), (0, (20,), (32, 32))])
 @pytest.mark.parametrize("epw", ["16", "64"])
 def test_fused_rollout_with_a_log_std_network(kind, hm, hs, epw, monkeypatch):
     """rl_rollout_gaussian_mlp with rl_rollout_args.theta_std: mean AND log-std network evaluated in the kernel every
