@@ -219,8 +219,10 @@ typedef struct rl_launch_opts {
     int32_t two_leg_lane_kernel;  /* 2: forbid the one-leg-per-lane kernels (HalfCheetah / Walker2D) */
     int32_t two_leg_wave_kernel;  /* 1 force, 2 forbid one env per wavefront */
     int32_t fvp_split;            /* rl_policy_fvp: 1 = f32 matrix instructions only, 2 = the cooperative split kernel for
-                                   * every shape it is built for */
-    int32_t fvp_split_wps;        /* 1: fvp_split_kernel with one wavefront per SIMD (register-resident operands) */
+                                   * every shape it is built for, 3 = the 16-sample-tile split kernel (four wavefronts per
+                                   * SIMD) for the (32, 32) shapes it is built for */
+    int32_t fvp_split_wps;        /* 1: fvp_split_kernel with one wavefront per SIMD (register-resident operands); 4: the
+                                   * 16-sample-tile kernel (fvp_split = 3) with four wavefronts per SIMD instead of three */
     int32_t lfb_valu;             /* rl_lfb_normal_eq: 1 = the register-blocked vector kernel */
     int32_t reserved[7];
 } rl_launch_opts;

@@ -150,10 +150,11 @@ def launch_opts():
     v = e("RLLAB_TWO_LEG_WAVE_KERNEL")
     o.two_leg_wave_kernel = 0 if not v else (1 if v[0] == "1" else 2)
     v = e("RLLAB_FVP_SPLIT")
-    o.fvp_split = 0 if not v else (1 if v[0] == "0" else 2 if v[0] == "2" else 0)
+    o.fvp_split = 0 if not v else (1 if v[0] == "0" else 2 if v[0] == "2" else 3 if v[0] == "3" else 0)
     v = e("RLLAB_FVP_SPLIT_WPS")
-    o.fvp_split_wps = 1 if v and v[0] == "1" else 0
+    o.fvp_split_wps = int(v[0]) if v and v[0] in "134" else 0
     o.lfb_valu = 1 if e("RLLAB_LFB_VALU") is not None else 0
+    o.reserved[0] = _env_int("RLLAB_SPLIT16_ABLATE", range(1, 8))     # timing ablations of fvp_split16_kernel (wrong results)
     return ctypes.addressof(o)
 
 

@@ -1275,8 +1275,12 @@ bool split_fvp_takes(const rl_policy_batch* g) {
 #undef SPLITCASE
     return false;
 }
+bool split16_fvp_takes(const rl_policy_batch* g);                       // policy_split16_kernels.hip
+int split16_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
 int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     if (!split_fvp_takes(g)) return RL_SPLIT_NOT_TAKEN;
+    // rl_launch_opts.fvp_split = 3: the 16-sample-tile kernel, four wavefronts per SIMD, for the shapes it is built for (A/B)
+    if (g->opts && g->opts->fvp_split == 3 && split16_fvp_takes(g)) return split16_fvp_dispatch(g, vec, ws, ws_bytes, out, st);
     // two wavefronts per SIMD (operands in LDS) unless rl_launch_opts.fvp_split_wps = 1 asks for the one-wavefront, register-resident form
     if (g->hidden0 == 64) {
 #define SPLITCASE(DO, DA) if (g->obs_dim == DO && g->act_dim == DA) return split::launch64<DO, DA>(g, vec, ws, ws_bytes, out, st);
@@ -1296,9 +1300,11 @@ int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, siz
 }  // namespace rl
 
 namespace rl { bool csplit_fvp_takes(const rl_policy_batch* g); }     // policy_csplit_kernels.hip
+namespace rl { bool split16_fvp_takes(const rl_policy_batch* g); }    // policy_split16_kernels.hip
 
 extern "C" int rl_policy_fvp_variant(const rl_policy_batch* g) {
     if (!g) return rl::set_error(RL_ERR_ARG, "rl_policy_fvp_variant: null batch");
+    if (g->opts && g->opts->fvp_split == 3 && rl::split_fvp_takes(g) && rl::split16_fvp_takes(g)) return 3;
     if (rl::split_fvp_takes(g)) return 1;
     return rl::csplit_fvp_takes(g) ? 2 : 0;
 }

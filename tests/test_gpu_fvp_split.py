@@ -181,3 +181,63 @@ def test_full_size_product_against_float64_double_backward(do, da, h, n_envs, mo
         if plain is not None:
             err_p = float((plain[i] - hv64).abs().max()) / scale
             assert err <= 2.0 * err_p + 2e-6, (err, err_p)
+
+
+SPLIT16_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (13, 1)]     # csrc/policy_split16_kernels.hip (at most two actions)
+
+
+@pytest.mark.parametrize("do,da", SPLIT16_SHAPES)
+@pytest.mark.parametrize("B", [32, 4096, 64000, 70016])
+@pytest.mark.parametrize("wps", ["4", "3"])
+def test_sixteen_sample_tile_product_is_the_same_f32_accurate_product(do, da, B, wps, monkeypatch):
+    """rl_launch_opts.fvp_split = 3: the split product on 16-sample tiles / v_mfma_f32_16x16x32_bf16, four wavefronts per
+    SIMD (round 6).  Same arithmetic as fvp_split_kernel in another order: within the reference tolerance of the float64
+    product, no worse than the f32 matrix instructions, and a different kernel did run."""
+    pol = U._policy(do, da, 32)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, B, old_equals_new=True)
+    rng = np.random.RandomState(17)
+    vs = [torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2)]
+    want = _f64_products(pol, inp, vs)
+    ops.loss_grad(inp, keep_activations=True)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
+    plain = [ops.fvp(inp, v) for v in vs]
+    monkeypatch.delenv("RLLAB_FVP_SPLIT")
+    split = [ops.fvp(inp, v) for v in vs]
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "3")
+    monkeypatch.setenv("RLLAB_FVP_SPLIT_WPS", wps)       # wavefronts per SIMD: four (128 registers) or three
+    assert _variant(ops, inp) == 3                       # the launch below IS fvp_split16_kernel
+    tile16 = [ops.fvp(inp, v) for v in vs]
+    for hv_t, hv_s, hv_p, hv64 in zip(tile16, split, plain, want):
+        scale = float(hv64.abs().max())
+        err_t, err_p = float((hv_t - hv64).abs().max()) / scale, float((hv_p - hv64).abs().max()) / scale
+        worst = [(n, float((hv_t - hv64)[a:b].abs().max()) / scale) for n, a, b in _blocks(pol, 32)]
+        assert err_t <= 5e-5, worst
+        assert err_t <= 2.0 * err_p + 2e-6, (err_t, err_p, worst)
+        assert float((hv_t - hv_s).abs().max()) <= 2e-5 * scale          # the two split kernels agree to rounding
+        assert not torch.equal(hv_t, hv_s)
+
+
+def test_sixteen_sample_tile_product_leaves_other_shapes_to_the_shipped_kernels(monkeypatch):
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "3")
+    for do, da, h, want in ((20, 6, 32, 1), (20, 6, 64, 1), (13, 2, 64, 1)):
+        pol = U._policy(do, da, h)
+        ops = pol.fused_ops()
+        inp = U._inputs(pol, 4096, old_equals_new=True)
+        ops.loss_grad(inp, keep_activations=True)
+        assert _variant(ops, inp) == want
+
+
+def test_full_size_sixteen_sample_tile_product_matches_the_shipped_kernel(monkeypatch):
+    """BASELINE config C3's batch (2 048 000 samples, ragged weights): both split kernels against each other."""
+    pol = U._policy(13, 2, 32)
+    ops = pol.fused_ops()
+    inp = U._inputs(pol, 4096 * 500, old_equals_new=True)
+    ops.loss_grad(inp, keep_activations=True)
+    v = torch.as_tensor(np.random.RandomState(3).randn(pol.flat_params.numel()), device="cuda")
+    ref = ops.fvp(inp, v)
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "3")
+    assert _variant(ops, inp) == 3
+    got = ops.fvp(inp, v)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float(v.dot(got)) > 0
