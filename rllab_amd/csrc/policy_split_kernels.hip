@@ -263,8 +263,11 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     constexpr bool TAIL_LDS = INV_LDS || DA > 2;   // the output layer's rows in LDS (wide heads: 32 DA registers otherwise)
     constexpr int TAILV = 16 * DA * 2 + 16;        // floats per lane half: W2 rows | dW2 rows | db1
     constexpr int SPILL_BYTES = INV_LDS ? 2 * 3 * WV * 16 : 0;   // a wavefront's h0 parts wait here for the back-propagation
-    constexpr int XROWS = 8 * KB0 + 1;                           // observation slots of a lane + the weight
-    constexpr int XLAND_BYTES = RL_SPLIT_ASM_DMA ? XROWS * WV * 4 : 0;   // the next tile's observations land here too
+    // the next tile's observations + weight land as XPIECES pieces of 8 rows x 32 samples (rows < DO: inputs, row DO: the
+    // weight -- its slot in x_ext is the constant 1): an LDS-direct piece costs the CU ~120 - 150 cycles whatever it carries
+    // (profiles/r06_notes.md section 6; rounds 3 - 5 sent 8 KB0 + 1 pieces of 256 bytes here)
+    constexpr int XPIECES = (DO + 1 + 7) / 8;
+    constexpr int XLAND_BYTES = RL_SPLIT_ASM_DMA ? XPIECES * WV * 16 : 0;
     constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES + XLAND_BYTES;
     constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + (INV_LDS ? OPS_BYTES : 0) + (TAIL_LDS ? 2 * TAILV * 4 : 0);
     static_assert(DO + 1 <= 32, "two k-blocks of inputs + the bias slot");
@@ -286,36 +289,30 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
     // one tile ahead: the observation slots and the weight in registers, the cached activations by LDS-direct loads
     // (branch-free: a lane half beyond the inputs reads a clamped row and selects the constant)
 #if RL_SPLIT_ASM_DMA
-    // The observation slots and the weight travel the same way as the activations: one global_load_lds_dword per slot
-    // (row i of the wavefront's x landing zone = 64 lanes x 4 B), hidden from the compiler's wait-count bookkeeping --
-    // a tracked load next to hidden ones would make every vmcnt(N) it computes wait for the younger hidden loads too.
-    // take_x() reads the rows back once the tile's s_waitcnt vmcnt(0) has passed.
+    // The observations and the weight travel the same way as the activations, hidden from the compiler's wait-count
+    // bookkeeping (a tracked load next to hidden ones would make every vmcnt(N) it computes wait for the younger hidden
+    // loads too): lane L of piece p carries samples 4 (L & 7) .. + 3 of row 8 p + (L >> 3), so the piece lands row-major
+    // [8 rows][32 samples] and take_x() reads x[d][sample] at (32 d + sample) floats, conflict-free.
     const unsigned xland_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)xland);
-    auto dma_row = [&](const float* g, unsigned row) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(xland_lds + row * (WV * 4)) : "memory");
-    };
     auto fetch = [&](int tile, float (&)[KB0][8], float&) {
-        const int b = tile * TS + lj;
 #pragma unroll
-        for (int kb = 0; kb < KB0; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 16 * kb + 8 * lh + j;
-                dma_row(a.obs + (size_t)(d < DO ? d : DO - 1) * B + b, 8 * kb + j);
-            }
-        dma_row(a.weight + b, 8 * KB0);
+        for (int p = 0; p < XPIECES; ++p) {
+            const int d = 8 * p + (lane >> 3);
+            const float* g = (d < DO ? a.obs + (size_t)d * B : a.weight) + tile * TS + 4 * (lane & 7);
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(xland_lds + p * (WV * 16)) : "memory");
+        }
     };
     auto take_x = [&](float (&xq)[KB0][8], float& wq) {
-        const float* xl = reinterpret_cast<const float*>(xland);
+        const float* xl = reinterpret_cast<const float*>(xland) + lj;
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = 16 * kb + 8 * lh + j;
-                const float v = xl[(8 * kb + j) * WV + lane];
+                const float v = xl[32 * (d < DO ? d : DO)];
                 xq[kb][j] = d < DO ? v : (d == DO ? 1.0f : 0.0f);
             }
-        wq = xl[8 * KB0 * WV + lane];
+        wq = xl[32 * DO];
     };
 #else
     auto fetch = [&](int tile, float (&xq)[KB0][8], float& wq) {
@@ -1220,7 +1217,7 @@ static int launch(const rl_policy_batch* g, const float* vec, void* ws, size_t w
     using N = Net<DO, DA, H>;
     constexpr int WAVES = 4 * WPS;
     constexpr int KB0 = (DO + 1 + 15) / 16;
-    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0) + (RL_SPLIT_ASM_DMA ? (8 * KB0 + 1) * WV * 4 : 0)) +
+    constexpr int LDS_BYTES = WAVES * (LAND_BYTES + (WPS == 2 ? 2 * 3 * WV * 16 : 0) + (RL_SPLIT_ASM_DMA ? ((DO + 1 + 7) / 8) * WV * 16 : 0)) +
                               (WPS == 2 ? ops_bytes(KB0) : 0) +
                               ((WPS == 2 || DA > 2) ? 2 * (16 * DA * 2 + 16) * 4 : 0);
     Args a;
