@@ -38,7 +38,8 @@ def test_the_reference_experiment_sizes_stay_fused():
     assert padded_sizes((100, 50, 25)) == (128, 64, 32) and padded_sizes((128, 128)) == (128, 128)
     assert padded_sizes((48, 20)) == (64, 64) and padded_sizes((32, 32)) == (32, 32)        # the equal-width family
     assert padded_sizes((129, 32)) is None and padded_sizes((8, 8, 8, 8)) is None
-    assert padded_sizes((32,)) == (32, 32) and padded_sizes((40,)) == (64, 64) and padded_sizes((65,)) is None   # one layer: + identity
+    assert padded_sizes((32,)) == (32, 32) and padded_sizes((40,)) == (64, 64)      # one layer: + identity
+    assert padded_sizes((65,)) == (128, 128) and padded_sizes((129,)) is None       # (65 .. 128 units: the cooperative family, round 6)
     for hidden in ((100, 50, 25), (128, 128)):
         pol = _policy(13, 2, hidden)
         assert pol.kernel_layout() is not None and pol.kernel_layout().wide
