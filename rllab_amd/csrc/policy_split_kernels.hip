@@ -135,6 +135,31 @@ __device__ __forceinline__ float half_sum_swap(float v) {
 #ifndef RL_SPLIT_SCALAR_SUB
 #define RL_SPLIT_SCALAR_SUB 0
 #endif
+//   RL_SPLIT_BULK_ROWS  (with RL_SPLIT_PK; round 6) the output layer's rows of a lane half come in bulk -- per action the
+//                  16 rows of W2 and of its tangent are eight 16-byte LDS reads issued together and waited for once -- and
+//                  its per-lane dot products run as FOUR independent packed partial sums.  By the ISA of the round-5 build
+//                  this stage was one chain of 16 dependent v_pk_fma_f32 per action (a wait state behind every one) with a
+//                  ds_read_b128 + s_waitcnt lgkmcnt(0) in front of every other one: ~20 exposed LDS round trips per tile
+//                  (fvp_split64_kernel got this form in round 5; the 32-unit kernel had not).
+#ifndef RL_SPLIT_BULK_ROWS
+#define RL_SPLIT_BULK_ROWS 1
+#endif
+//   RL_SPLIT_OPS_AHEAD  (two wavefronts per SIMD: operand blocks in LDS; round 6) the three parts of the NEXT operand block
+//                  are read before the six products of the current one are issued (and the first block of a chain before
+//                  the vector work in front of it): by the ISA every block was read right in front of its use and
+//                  waited for -- seven exposed LDS round trips per tile
+#ifndef RL_SPLIT_OPS_AHEAD
+#define RL_SPLIT_OPS_AHEAD 1
+#endif
+//   RL_SPLIT_FILL  (with RL_SPLIT_OPS_AHEAD; round 6) vector work that does not depend on a chain of products is issued INSIDE
+//                  it: a v_mfma_f32_32x32x16_bf16 occupies the matrix pipe for 8 passes and leaves ~5 issue slots of its
+//                  own wavefront free (MI355X_MICROARCH.md), which a chain of six dependent products otherwise wastes.  The
+//                  split of dh0 (needed by the chain after next) rides inside dW1^T h0.  MEASURED: nothing (0.2117 - 0.2149 ms
+//                  with the filler on dot / packed or on plain instructions against 0.2095 - 0.2147 without, same box,
+//                  profiles/r06_notes.md section 7) and 17 spilled registers -- off.
+#ifndef RL_SPLIT_FILL
+#define RL_SPLIT_FILL 0
+#endif
 #ifndef RL_SPLIT_ASM_DMA
 #define RL_SPLIT_ASM_DMA 1
 #endif
@@ -184,6 +209,20 @@ __device__ __forceinline__ void split_pair(float a0, float a1, Parts& out, int j
     out.p[0][j] = h[0]; out.p[0][j + 1] = h[1];
     out.p[1][j] = m[0]; out.p[1][j + 1] = m[1];
     out.p[2][j] = q[0]; out.p[2][j + 1] = q[1];
+}
+// the same split on PLAIN vector instructions (v_cvt_pk_bf16_f32, v_lshlrev_b32, v_and_b32, v_sub_f32): the form that runs in
+// the issue slots a matrix instruction of the same wavefront leaves free -- packed-f32 and dot instructions cost extra
+// cycles beside the matrix pipe (MI355X_MICROARCH.md: "price of one filler beside MFMAs")
+__device__ __forceinline__ void split_pair_plain(float a0, float a1, Parts& out, int j) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float l0 = r0 - __uint_as_float(m << 16), l1 = r1 - __uint_as_float(m & 0xffff0000u);
+    const unsigned q = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{l0, l1}, bf16x2));
+    const bf16x2 hh = __builtin_bit_cast(bf16x2, h), mm = __builtin_bit_cast(bf16x2, m), qq = __builtin_bit_cast(bf16x2, q);
+    out.p[0][j] = hh[0]; out.p[0][j + 1] = hh[1];
+    out.p[1][j] = mm[0]; out.p[1][j + 1] = mm[1];
+    out.p[2][j] = qq[0]; out.p[2][j + 1] = qq[1];
 }
 __device__ __forceinline__ void split8(const float* v, Parts& out) {
 #pragma unroll
@@ -432,6 +471,22 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             return R_ops[o];
         }
     };
+    // acc += sum_kb op(base + kb) x Bk[kb] with the operand blocks read one AHEAD: `cur` holds block `base` (read by the
+    // caller or by the previous chain), the block after the last one of this chain is `nxt_o` (< 0: none)
+    auto chain_ahead = [&](int base, int nb, const Parts* Bk, f32x16 acc_, Parts& cur, int nxt_o) -> f32x16 {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb < nb) {
+                Parts nxtp = cur;
+                const int o = kb + 1 < nb ? base + kb + 1 : nxt_o;
+                if (o >= 0) nxtp = op(o);
+                __builtin_amdgcn_sched_barrier(0);
+                acc_ = mm6(cur, Bk[kb], acc_);
+                cur = nxtp;
+            }
+        }
+        return acc_;
+    };
     // identity operands of the transpositions: B[k][n] = (k == n) in the k order of the fragment they meet
     bf16x8 Id[2], Idx[KB0];
 #pragma unroll
@@ -513,6 +568,13 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         auto stage = [&]() { if constexpr (TAIL_LDS) asm volatile("" ::: "memory"); };
 
         // ---- operands of this tile ---------------------------------------------------------------------------------------
+#if RL_SPLIT_OPS_AHEAD
+        Parts opcur;
+        if constexpr (INV_LDS) {              // the first operand block travels while the tile's inputs are split
+            opcur = op(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         Parts Xs[KB0], H0s[2];
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) split8(xb[kb], Xs[kb]);
@@ -522,12 +584,41 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#if RL_SPLIT_OPS_AHEAD
+        if constexpr (INV_LDS) acc = chain_ahead(0, KB0, Xs, acc, opcur, KB0);    // dW0^T x + db0 (leaves block KB0 in opcur)
+        else
+#endif
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) acc = mm6(op(kb), Xs[kb], acc);          // dW0^T x + db0
         f32x16 dh0;
         times_dtanh(acc, h0, dh0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = db1_(r);
+#if RL_SPLIT_OPS_AHEAD && RL_SPLIT_FILL
+        Parts D0s_f[2];
+        if constexpr (INV_LDS) {
+            // dW1^T h0 with the split of dh0 inside: per operand block one region of [three part reads of the next block,
+            // the split of eight values of dh0 twice, six products], the vector instructions spread between the products
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Parts nxtp = op(kb == 0 ? KB0 + 1 : KB0 + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) split_pair_plain(dh0[8 * kb + j], dh0[8 * kb + j + 1], D0s_f[kb], j);
+                acc = mm6(opcur, H0s[kb], acc);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight vector instructions
+                }
+                opcur = nxtp;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+#elif RL_SPLIT_OPS_AHEAD
+        if constexpr (INV_LDS) acc = chain_ahead(KB0, 2, H0s, acc, opcur, KB0 + 2);     // dW1^T h0 (leaves W1^T's first block)
+        else
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) acc = mm6(op(KB0 + kb), H0s[kb], acc);       // dW1^T h0
         if constexpr (INV_LDS) {
@@ -539,7 +630,15 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         stage();
         {
             Parts D0s[2];
+#if RL_SPLIT_OPS_AHEAD && RL_SPLIT_FILL
+            if constexpr (INV_LDS) { D0s[0] = D0s_f[0]; D0s[1] = D0s_f[1]; }
+            else
+#endif
             split_frag(dh0, D0s);
+#if RL_SPLIT_OPS_AHEAD
+            if constexpr (INV_LDS) acc = chain_ahead(KB0 + 2, 2, D0s, acc, opcur, -1);  // W1^T dh0
+            else
+#endif
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) acc = mm6(op(KB0 + 2 + kb), D0s[kb], acc);   // W1^T dh0
         }
@@ -558,6 +657,67 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             set_pair(dz1, j, d);
             set_pair(acc, j, pair_of(acc, j) * d);                                // dh1
         }
+#if RL_SPLIT_BULK_ROWS
+        // rows r = 0 .. 15 of column k (which: 0 = W2, 1 = its tangent) of this lane half: four 16-byte reads (LDS) or moves
+        auto rows_of = [&](int which, int k, f32x4 (&out_)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (TAIL_LDS) out_[q] = *reinterpret_cast<const f32x4*>(tv + (which * DA + k) * 16 + 4 * q);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out_[q][e] = which ? R_dW2[4 * q + e][k] : R_W2[4 * q + e][k];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < DA; ++k) {
+            f32x4 wq[4], dq[4];
+            rows_of(0, k, wq);
+            rows_of(1, k, dq);
+            f32x2 pa[2], pb[2];
+            pa[0] = pa[1] = pb[0] = pb[1] = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = j >> 1, e = 2 * (j & 1);
+                pa[j & 1] = __builtin_elementwise_fma(pair_of(h1, j), f32x2{dq[q][e], dq[q][e + 1]}, pa[j & 1]);
+                pb[j & 1] = __builtin_elementwise_fma(pair_of(acc, j), f32x2{wq[q][e], wq[q][e + 1]}, pb[j & 1]);
+            }
+            const f32x2 pd = (pa[0] + pb[0]) + (pa[1] + pb[1]);
+            const float dmu = db2[k] + half_sum_swap(pd[0] + pd[1]);
+            gmu[k] = c * dmu * fk[k];
+        }
+        if (lh == 0) {
+            wsum += c;
+#pragma unroll
+            for (int k = 0; k < DA; ++k) gb2[k] += gmu[k];
+        }
+        stage();
+        // ---- back-propagation, sample-major ---------------------------------------------------------------------------------
+        {
+            f32x2 g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < DA; ++k) {
+                f32x4 wq[4];
+                rows_of(0, k, wq);
+                const f32x2 gk = {gmu[k], gmu[k]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = j >> 1, e = 2 * (j & 1);
+                    g[j] = __builtin_elementwise_fma(f32x2{wq[q][e], wq[q][e + 1]}, gk, g[j]);
+                    const f32x2 w2 = __builtin_elementwise_fma(pair_of(h1, j), gk, f32x2{gW2l[2 * j][k], gW2l[2 * j + 1][k]});
+                    gW2l[2 * j][k] = w2[0]; gW2l[2 * j + 1][k] = w2[1];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x2 gz = g[j] * pair_of(dz1, j);
+                set_pair(gz1, j, gz);
+                const f32x2 b1n = f32x2{gb1l[2 * j], gb1l[2 * j + 1]} + gz;
+                gb1l[2 * j] = b1n[0]; gb1l[2 * j + 1] = b1n[1];
+            }
+        }
+#else
 #pragma unroll
         for (int k = 0; k < DA; ++k) {
             f32x2 pd = {0.0f, 0.0f};
@@ -590,6 +750,7 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
             const f32x2 b1n = f32x2{gb1l[2 * j], gb1l[2 * j + 1]} + gz;
             gb1l[2 * j] = b1n[0]; gb1l[2 * j + 1] = b1n[1];
         }
+#endif
 #else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -627,10 +788,20 @@ __global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_split_kernel(Args a) {
         }
 #endif
         stage();
+#if RL_SPLIT_OPS_AHEAD
+        if constexpr (INV_LDS) {
+            opcur = op(KB0 + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         Parts G1s[2];
         split_frag(gz1, G1s);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#if RL_SPLIT_OPS_AHEAD
+        if constexpr (INV_LDS) acc = chain_ahead(KB0 + 4, 2, G1s, acc, opcur, -1);      // W1 gz1
+        else
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) acc = mm6(op(KB0 + 4 + kb), G1s[kb], acc);       // W1 gz1
         stage();
