@@ -224,7 +224,7 @@ typedef struct rl_launch_opts {
     int32_t fvp_split_wps;        /* 1: fvp_split_kernel with one wavefront per SIMD (register-resident operands); 4: the
                                    * 16-sample-tile kernel (fvp_split = 3) with four wavefronts per SIMD instead of three */
     int32_t lfb_valu;             /* rl_lfb_normal_eq: 1 = the register-blocked vector kernel */
-    int32_t reserved[7];
+    int32_t reserved[7];          /* reserved[0]: timing ablations of fvp_split16_kernel (WRONG results; tools/exp/fvp_split16_time.py) */
 } rl_launch_opts;
 
 /* Arguments of the fused rollout: T lock-step iterations of
