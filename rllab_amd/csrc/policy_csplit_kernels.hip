@@ -79,6 +79,21 @@ constexpr int CS_MAX_GRID = 512;
 #ifndef CS_ABLATE_MFMA      // 1: no matrix instructions in the chains: wrong results
 #define CS_ABLATE_MFMA 0
 #endif
+// CS_KSPLIT (round 6): a layer with FEWER row tiles than the workgroup has wavefronts (the narrow layers of a tapering net:
+// (100, 50, 25) pads to 4 / 2 / 1 row tiles) is split over K as well -- the WW / HT wavefronts that share a row tile each
+// contract over their slice of the k-blocks and the partial sums meet in LDS at the tile's owner, which adds the bias
+// tangent, applies the tanh derivative and publishes as before.  Same for the output layer's two chains (per chain and
+// k-block) and for the products over the sample axis whose output tiles are fewer than the wavefronts (per sample block:
+// two wavefronts hold partial accumulators of the same tile for the whole launch and meet once, at the end).  A tile's
+// time is the k-block steps of its BUSIEST wavefront (~620 cycles each at one wavefront per SIMD, whatever the shape:
+// profiles/r04_notes.md): (100, 50, 25) 46 -> 27 steps.  0: ownership by row tile only (rounds 4 - 5), for A/B runs.
+#ifndef CS_KSPLIT
+#define CS_KSPLIT 1
+#endif
+// CS_SHAPES: 1 = the common shapes are instantiated with their row-tile counts as compile-time constants
+#ifndef CS_SHAPES
+#define CS_SHAPES 1
+#endif
 
 // kind 0: dW_l^T (vec)    1: W_l^T (theta)    2: W_l (theta; back-propagation through layer l)
 //      3: dWo^T (vec)     4: Wo^T (theta)     rows = action slots (one row tile, rows >= DA zero), k = units of layer L-1
@@ -96,6 +111,9 @@ struct CsShape {
     CsImage im[MAX_IMG];
     int n_im, stage_items;
     int lX, lH[3], lG[3], lM, ldb[3], lpart, lds_total;    // LDS byte offsets (lM: the image of the cotangent on the mean)
+    int RF[3];                      // wavefronts sharing a row tile of layer l in the tangent forward pass (k-slices; 1: none)
+    int RO;                         // ... sharing a unit tile of the last hidden layer in the output layer's chains (1, 2, 4)
+    int SW[3], SO;                  // sample-axis products of layer l / of the output layer split per sample block (0 / 1)
     int fmt;                        // activation cache: 0 = fragment rows (policy_kernels.hip), 1 = unit rows (wide)
     int frow[3];                    // fmt 0: first 16-byte row of layer l inside a tile; fmt 1: float offset of layer l
     int rows, ctile;                // fmt 0: 16-byte rows per tile; fmt 1: floats per tile
@@ -272,9 +290,23 @@ __device__ __forceinline__ f32x16 cs_gemm(const bf16x8* __restrict__ A, int nkb,
 
 // L hidden layers; WW wavefronts per workgroup; MT = most output tiles of a hidden-to-hidden weight gradient one
 // wavefront accumulates
-template <int L, int WW, int MT>
+template <int L, int WW, int MT, int SHP>
 __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
     const CsShape& s = a.s;
+    // row tiles per layer and everything derived from them: compile-time constants in the instantiations of the common
+    // shapes (SHP = HT0 | HT1 << 4 | HT2 << 8), read from the shape record otherwise (SHP = 0)
+    auto HTc = [&](int l) -> int { return SHP ? (SHP >> (4 * l)) & 15 : s.HT[l]; };
+    auto Hc = [&](int l) -> int { return SHP ? 32 * ((SHP >> (4 * l)) & 15) : s.H[l]; };
+    auto KBc = [&](int l) -> int { return (SHP && l >= 1) ? 2 * ((SHP >> (4 * (l - 1))) & 15) : s.KB[l]; };
+    auto RFc = [&](int l) -> int {
+        if (!SHP) return s.RF[l];
+        if (!CS_KSPLIT || l < 1) return 1;
+        const int r = WW / HTc(l), kb = KBc(l);
+        return r > kb ? kb : (r < 1 ? 1 : r);
+    };
+    auto ROc = [&]() -> int { return SHP ? (CS_KSPLIT ? WW / HTc(L - 1) : 1) : s.RO; };
+    auto SWc = [&](int l) -> int { return SHP ? (CS_KSPLIT && l >= 1 && 2 * HTc(l - 1) * HTc(l) <= WW) : s.SW[l]; };
+    auto SOc = [&]() -> int { return SHP ? (CS_KSPLIT && 2 * HTc(L - 1) <= WW) : s.SO; };
     constexpr int NT = WW * WV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / WV), lane = tid % WV;
@@ -299,7 +331,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
 #pragma unroll
     for (int l = 1; l < L; ++l) {
         float* db = reinterpret_cast<float*>(smem + s.ldb[l]);
-        for (int e = tid; e < s.HT[l] * 32; e += NT) {                // [(t * 2 + half) * 16 + r]
+        for (int e = tid; e < HTc(l) * 32; e += NT) {                // [(t * 2 + half) * 16 + r]
             const int r = e & 15, hf_ = (e >> 4) & 1, t = e >> 5;
             db[e] = vc[s.ob[l] + 32 * t + frag_unit(r, hf_)];
         }
@@ -311,27 +343,46 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
     constexpr int NSEQ = 3 * L + 1;
     int seq[NSEQ], skb[NSEQ], nxt[NSEQ], nkbn[NSEQ], nxt2[NSEQ];   // image offset and k-blocks of a chain; of the chain this
                                                                    // wavefront runs next; offset of the one after that
+    // k-slices (CS_KSPLIT): in layer l's tangent forward pass this wavefront works on row tile ft[l], k-blocks fk0[l] ..
+    // + fnk[l] - 1 of both chains (fnk = 0: idle there); the tile's owner is the wavefront of slice 0 (= wave ft[l])
+    int ft[L], fk0[L], fnk[L];
+    ft[0] = wave; fk0[0] = 0; fnk[0] = wave < HTc(0) ? KBc(0) : 0;
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        const int ks = wave / HTc(l);
+        ft[l] = wave % HTc(l);
+        fnk[l] = ks < RFc(l) ? KBc(l) / RFc(l) : 0;
+        fk0[l] = ks * fnk[l];
+    }
+    // output layer: unit tile ot of the last hidden layer; RO = 1: both chains, both k-blocks; 2: chain oq, both
+    // k-blocks; 4: chain oq >> 1, k-block oq & 1
+    const int ot = wave % HTc(L - 1), oq = wave / HTc(L - 1);
+    const bool o_busy = oq < ROc();
+    const bool o_c0 = o_busy && (ROc() == 1 || (ROc() == 2 ? oq == 0 : (oq >> 1) == 0));
+    const bool o_c1 = o_busy && (ROc() == 1 || (ROc() == 2 ? oq == 1 : (oq >> 1) == 1));
+    const int o_k0 = ROc() == 4 ? (oq & 1) : 0, o_nk = ROc() == 4 ? 1 : 2;
     {
         auto rowimg = [&](int base16, int kb, bool busy) -> int { return busy ? base16 + wave * kb * 3 * 64 : -1; };
-        const bool last = wave < s.HT[L - 1];
-        seq[0] = rowimg(s.iFD[0], s.KB[0], wave < s.HT[0]);
-        skb[0] = s.KB[0];
+        const bool last = wave < HTc(L - 1);
+        seq[0] = rowimg(s.iFD[0], KBc(0), wave < HTc(0));
+        skb[0] = KBc(0);
 #pragma unroll
         for (int l = 1; l < L; ++l) {
-            seq[2 * l - 1] = rowimg(s.iFD[l], s.KB[l], wave < s.HT[l]);
-            seq[2 * l] = rowimg(s.iFT[l], s.KB[l], wave < s.HT[l]);
-            skb[2 * l - 1] = skb[2 * l] = s.KB[l];
+            const int o16 = (ft[l] * KBc(l) + fk0[l]) * 3 * 64;
+            seq[2 * l - 1] = fnk[l] ? s.iFD[l] + o16 : -1;
+            seq[2 * l] = fnk[l] ? s.iFT[l] + o16 : -1;
+            skb[2 * l - 1] = skb[2 * l] = fnk[l] ? fnk[l] : 1;
         }
-        // output layer: ONE row tile (the action slots), k-blocks 2 w and 2 w + 1 = this wavefront's units
-        seq[2 * L - 1] = last ? s.iDO + 2 * wave * 3 * 64 : -1;
-        seq[2 * L] = last ? s.iTO + 2 * wave * 3 * 64 : -1;
+        // output layer: ONE row tile (the action slots), k-blocks 2 t and 2 t + 1 = the units of tile t
+        seq[2 * L - 1] = o_c0 ? s.iDO + (2 * ot + o_k0) * 3 * 64 : -1;
+        seq[2 * L] = o_c1 ? s.iTO + (2 * ot + o_k0) * 3 * 64 : -1;
         seq[2 * L + 1] = rowimg(s.iWO, 1, last);
-        skb[2 * L - 1] = skb[2 * L] = 2;
+        skb[2 * L - 1] = skb[2 * L] = o_nk;
         skb[2 * L + 1] = 1;
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
-            seq[2 * L + 2 + (L - 1 - l)] = rowimg(s.iBT[l], s.H[l] / 16, wave < s.HT[l - 1]);
-            skb[2 * L + 2 + (L - 1 - l)] = s.H[l] / 16;
+            seq[2 * L + 2 + (L - 1 - l)] = rowimg(s.iBT[l], Hc(l) / 16, wave < HTc(l - 1));
+            skb[2 * L + 2 + (L - 1 - l)] = Hc(l) / 16;
         }
     }
 #pragma unroll
@@ -387,17 +438,19 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
     const int B = a.B, n_tiles = B / TS;
     char* const Xp = smem + s.lX;
     float* const part = reinterpret_cast<float*>(smem + s.lpart);
+    f32x4* const xch = reinterpret_cast<f32x4*>(smem + s.lpart);    // k-slice exchange slots (4 KB each) alias the partial sums
+                                                                    // of the output layer: different phases of a tile
 
     // one tile ahead: the cached fragments of the layers this wavefront owns, the observation slots of this thread's
     // item of the input image, the sample weight
     f32x16 hq[L];
     float xq[8], wq = 0.0f;
-    const bool x_item = tid < s.KB[0] * WV;
+    const bool x_item = tid < KBc(0) * WV;
     const int x_kb = tid >> 6;
     auto fetch = [&](int tile) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if (wave < s.HT[l]) {
+            if (wave < HTc(l)) {
                 if (s.fmt == 0) {
                     const f32x4* src = reinterpret_cast<const f32x4*>(a.acts) +
                                        ((size_t)tile * s.rows + s.frow[l] + 4 * wave) * WV + lane;
@@ -442,7 +495,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         }
 #pragma unroll
         for (int l = 0; l < L; ++l)
-            if (wave < s.HT[l]) cs_publish(own + s.lH[l], hf[l]);
+            if (wave < HTc(l)) cs_publish(own + s.lH[l], hf[l]);
         if (!CS_FETCH_LATE && !CS_ABLATE_FETCH) {
             // the next tile starts travelling (the workgroup's last tile fetches itself again: no branch around the loads)
             const int nx = tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile;
@@ -454,38 +507,63 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         // every layer's tangent is published (its image passes to the cotangent later) ----------------------------------
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if (wave < s.HT[l]) {
-                f32x16 acc;
-                if (l == 0) {
+            const bool owner = wave < HTc(l);
+            f32x16 acc;
+            if (l == 0) {
+                if (owner) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    acc = cs_gemm(imgl + seq[0], s.KB[0], Xp + lane_off, acc, pre, imgl + nxt[0], nkbn[0], imgl + nxt2[0]);
-                } else {
-                    const f32x4* db = reinterpret_cast<const f32x4*>(smem + s.ldb[l]) + (wave * 2 + lh) * 4;
+                    acc = cs_gemm(imgl + seq[0], KBc(0), Xp + lane_off, acc, pre, imgl + nxt[0], nkbn[0], imgl + nxt2[0]);
+                }
+            } else {
+                if (fnk[l]) {
+                    // the owner starts from the bias tangent, a k-slice from zero
+                    const f32x4* db = reinterpret_cast<const f32x4*>(smem + s.ldb[l]) + (ft[l] * 2 + lh) * 4;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = db[q];
+                        const f32x4 v = owner ? db[q] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[4 * q + e] = v[e];
                     }
-                    acc = cs_gemm(imgl + seq[2 * l - 1], s.KB[l], smem + s.lH[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l - 1], nkbn[2 * l - 1], imgl + nxt2[2 * l - 1]);
-                    acc = cs_gemm(imgl + seq[2 * l], s.KB[l], smem + s.lG[l - 1] + lane_off, acc, pre, imgl + nxt[2 * l], nkbn[2 * l], imgl + nxt2[2 * l]);
+                    const int bo = fk0[l] * 3 * CH + lane_off;
+                    acc = cs_gemm(imgl + seq[2 * l - 1], fnk[l], smem + s.lH[l - 1] + bo, acc, pre, imgl + nxt[2 * l - 1], nkbn[2 * l - 1], imgl + nxt2[2 * l - 1]);
+                    acc = cs_gemm(imgl + seq[2 * l], fnk[l], smem + s.lG[l - 1] + bo, acc, pre, imgl + nxt[2 * l], nkbn[2 * l], imgl + nxt2[2 * l]);
+                    if (!owner) {                            // slice ks >= 1 of tile ft: exchange slot wave - HT[l]
+                        f32x4* dst = xch + ((wave - HTc(l)) * 4) * WV + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[q * WV] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    }
                 }
+                if (RFc(l) > 1) __syncthreads();
+                if (owner && RFc(l) > 1) {
+                    for (int ks = 1; ks < RFc(l); ++ks) {
+                        const f32x4* src = xch + ((wave + HTc(l) * (ks - 1)) * 4) * WV + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = src[q * WV];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[4 * q + e] += v[e];
+                        }
+                    }
+                }
+            }
+            if (owner) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] *= (1.0f - hf[l][r] * hf[l][r]);
                 cs_publish(own + s.lG[l], acc);
             }
-            if (l + 1 < L) __syncthreads();
+            if (l + 1 < L || ROc() > 1) __syncthreads();      // (RO > 1: the output chains read other wavefronts' images)
         }
 
         // ---- output layer: dmu = dWo^T h + Wo^T dh + dbo.  Each wavefront contracts over its own 32 units (the two
         // k-blocks it has just published: its LDS operations complete in order, no barrier), partial sums meet in LDS ----
-        if (wave < s.HT[L - 1]) {
+        if (o_busy) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = cs_gemm(imgl + seq[2 * L - 1], 2, own + s.lH[L - 1], acc, pre, imgl + nxt[2 * L - 1], nkbn[2 * L - 1], imgl + nxt2[2 * L - 1]);
-            acc = cs_gemm(imgl + seq[2 * L], 2, own + s.lG[L - 1], acc, pre, imgl + nxt[2 * L], nkbn[2 * L], imgl + nxt2[2 * L]);
+            const int bo = ot * TILE_IMG + o_k0 * 3 * CH + lane_off;
+            if (o_c0) acc = cs_gemm(imgl + seq[2 * L - 1], o_nk, smem + s.lH[L - 1] + bo, acc, pre, imgl + nxt[2 * L - 1], nkbn[2 * L - 1], imgl + nxt2[2 * L - 1]);
+            if (o_c1) acc = cs_gemm(imgl + seq[2 * L], o_nk, smem + s.lG[L - 1] + bo, acc, pre, imgl + nxt[2 * L], nkbn[2 * L], imgl + nxt2[2 * L]);
             f32x4 v4;                                        // rows frag_unit(r, half), r < 4 = action slots r + 4 half
 #pragma unroll
             for (int r = 0; r < 4; ++r) v4[r] = acc[r];
@@ -495,7 +573,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         {
             const float c = wgt * a.inv_count;
             f32x4 g4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int w = 0; w < s.HT[L - 1]; ++w) {
+            for (int w = 0; w < HTc(L - 1) * ROc(); ++w) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(part + (w * WV + lane) * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g4[r] += v[r];
@@ -526,7 +604,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         __syncthreads();
 
         // ---- back-propagation: gz_{L-1} = (Wo gmu) (1 - h^2), gz_{l-1} = (W_l gz_l) (1 - h_{l-1}^2) ----------------------
-        if (wave < s.HT[L - 1]) {
+        if (wave < HTc(L - 1)) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -541,12 +619,12 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         __syncthreads();
 #pragma unroll
         for (int l = L - 1; l >= 1; --l) {
-            if (wave < s.HT[l - 1]) {
+            if (wave < HTc(l - 1)) {
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 const int si = 2 * L + 2 + (L - 1 - l);
-                acc = cs_gemm(imgl + seq[si], s.H[l] / 16, smem + s.lG[l] + lane_off, acc, pre, imgl + nxt[si], nkbn[si], imgl + nxt2[si]);
+                acc = cs_gemm(imgl + seq[si], Hc(l) / 16, smem + s.lG[l] + lane_off, acc, pre, imgl + nxt[si], nkbn[si], imgl + nxt2[si]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[r] *= (1.0f - hf[l - 1][r] * hf[l - 1][r]);
@@ -569,7 +647,17 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         if (!CS_ABLATE_OUTER) {
 #pragma unroll
         for (int l = 1; l < L; ++l) {
-            const int HTa = s.HT[l - 1], nt = HTa * s.HT[l];
+            const int HTa = HTc(l - 1), nt = HTa * HTc(l);
+            if (SWc(l)) {
+                // fewer output tiles than wavefronts: wavefront w takes sample block w / nt of tile w % nt (its partial
+                // accumulator meets the other block's after the last tile)
+                if (wave < 2 * nt) {
+                    const int tau = wave % nt, kbs = wave / nt, ti = tau % HTa, tj = tau / HTa;
+                    const Parts A = cs_tr(smem + s.lH[l - 1] + ti * TILE_IMG + tr_off, kbs);
+                    const Parts Bq = cs_tr(smem + s.lG[l] + tj * TILE_IMG + tr_off, kbs);
+                    gW[l - 1][0] = mm6(A, Bq, gW[l - 1][0]);
+                }
+            } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int tau = wave + WW * m;
@@ -583,8 +671,18 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
                     }
                 }
             }
+            }
         }
-        if (wave < s.HT[L - 1]) {
+        if (SOc()) {
+            // (from the top: wavefronts WW - 1, WW - 2, .. -- the hidden layers' split products fill the low ones first)
+            const int wo = WW - 1 - wave;
+            if (wo < 2 * HTc(L - 1)) {
+                const int t = wo % HTc(L - 1), kbs = wo / HTc(L - 1);
+                const Parts A = cs_tr(smem + s.lH[L - 1] + t * TILE_IMG + tr_off, kbs);
+                const Parts Bq = cs_tr(smem + s.lM + tr_off, kbs);
+                gWo = mm6(A, Bq, gWo);
+            }
+        } else if (wave < HTc(L - 1)) {
 #pragma unroll
             for (int kbs = 0; kbs < 2; ++kbs) {
                 const Parts A = cs_tr(smem + s.lH[L - 1] + wave * TILE_IMG + tr_off, kbs);
@@ -592,7 +690,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
                 gWo = mm6(A, Bq, gWo);
             }
         }
-        if (wave < s.HT[0]) {
+        if (wave < HTc(0)) {
 #pragma unroll
             for (int kbs = 0; kbs < 2; ++kbs) {
                 const Parts A = cs_tr(Xp + tr_off, kbs);                          // rows: lane l32 = input slot l32
@@ -603,12 +701,52 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
         }
     }
 
+    // ---- accumulators that were split per sample block meet at the owner of their tile (the parts images are dead: the
+    // fold area aliases them, one 4 KB slot per wavefront and accumulator) --------------------------------------------
+    {
+        bool any = SOc() != 0;
+#pragma unroll
+        for (int l = 1; l < L; ++l) any = any || SWc(l) != 0;
+        if (any) {
+            __syncthreads();
+            f32x4* const fold = reinterpret_cast<f32x4*>(smem);
+            auto put = [&](int slot, const f32x16& v) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fold[(slot * 4 + q) * WV + lane] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            };
+            auto add = [&](int slot, f32x16& v) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = fold[(slot * 4 + q) * WV + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] += t[e];
+                }
+            };
+#pragma unroll
+            for (int l = 1; l < L; ++l) {
+                const int nt = HTc(l - 1) * HTc(l);
+                if (SWc(l) && wave >= nt && wave < 2 * nt) put(wave * L + l - 1, gW[l - 1][0]);
+            }
+            const int wo = WW - 1 - wave, hto = HTc(L - 1);
+            if (SOc() && wo >= hto && wo < 2 * hto) put(wave * L + L - 1, gWo);
+            __syncthreads();
+#pragma unroll
+            for (int l = 1; l < L; ++l) {
+                const int nt = HTc(l - 1) * HTc(l);
+                if (SWc(l) && wave < nt) add((wave + nt) * L + l - 1, gW[l - 1][0]);
+            }
+            if (SOc() && wo < hto) add((WW - 1 - (wo + hto)) * L + L - 1, gWo);
+        }
+    }
+    // (with SO the owner of unit tile t of the output layer's gradient is wavefront WW - 1 - t)
+    const int o_owner_tile = SOc() ? WW - 1 - wave : wave;
+
     // ---- one partial row per workgroup: every parameter has exactly one owner -------------------------------------------
     float* row = a.partial + (size_t)blockIdx.x * s.P;
     const int cu = tr_unit(lj);
 #pragma unroll
     for (int l = 1; l < L; ++l) {
-        const int HTa = s.HT[l - 1], nt = HTa * s.HT[l];
+        const int HTa = HTc(l - 1), nt = HTa * HTc(l);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int tau = wave + WW * m;
@@ -616,26 +754,26 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
                 const int ti = tau % HTa, tj = tau / HTa;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    row[s.oW[l] + (32 * ti + tr_unit(frag_unit(r, lh))) * s.H[l] + 32 * tj + cu] = gW[l - 1][m][r];
+                    row[s.oW[l] + (32 * ti + tr_unit(frag_unit(r, lh))) * Hc(l) + 32 * tj + cu] = gW[l - 1][m][r];
             }
         }
     }
-    if (wave < s.HT[0]) {
+    if (wave < HTc(0)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = frag_unit(r, lh);                  // input slot (the input image's units are its slots)
-            if (d < DO) row[s.oW[0] + d * s.H[0] + 32 * wave + cu] = gW0[r];
+            if (d < DO) row[s.oW[0] + d * Hc(0) + 32 * wave + cu] = gW0[r];
             else if (d == DO) row[s.ob[0] + 32 * wave + cu] = gW0[r];
         }
     }
-    if (wave < s.HT[L - 1] && lj < DA) {                      // column lj of the product = action slot lj
+    if (o_owner_tile >= 0 && o_owner_tile < HTc(L - 1) && lj < DA) {      // column lj of the product = action slot lj
 #pragma unroll
-        for (int r = 0; r < 16; ++r) row[s.oWo + (32 * wave + tr_unit(frag_unit(r, lh))) * DA + lj] = gWo[r];
+        for (int r = 0; r < 16; ++r) row[s.oWo + (32 * o_owner_tile + tr_unit(frag_unit(r, lh))) * DA + lj] = gWo[r];
     }
     // per-lane sums of the bias gradients: fold the 32 samples of a lane half
 #pragma unroll
     for (int l = 1; l < L; ++l) {
-        if (wave < s.HT[l]) {
+        if (wave < HTc(l)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = gb[l - 1][r];
@@ -703,7 +841,25 @@ static bool cs_shape(const rl_policy_batch* g, CsShape& s) {
     for (int l = 0; l < 3; ++l) { s.lG[l] = o; o += (l < s.L) ? s.HT[l] * TILE_IMG : 0; }
     s.lM = o; o += TILE_IMG;
     for (int l = 0; l < 3; ++l) { s.ldb[l] = o; o += (l >= 1 && l < s.L) ? s.HT[l] * 128 : 0; }
-    s.lpart = o; o += 4 * WV * 4 * (int)sizeof(float);
+    // k-slices (see CS_KSPLIT)
+    const int WWh = maxht;          // wavefronts per workgroup = row tiles of the widest layer (2 or 4)
+    int xslots = 1;
+    s.RF[0] = 1;
+    for (int l = 1; l < 3; ++l) {
+        s.RF[l] = 1; s.SW[l] = 0;
+        if (CS_KSPLIT && l < s.L) {
+            int r = WWh / s.HT[l];
+            if (r > s.KB[l]) r = s.KB[l];
+            s.RF[l] = r < 1 ? 1 : r;
+            if (s.HT[l] * (s.RF[l] - 1) > xslots) xslots = s.HT[l] * (s.RF[l] - 1);
+            s.SW[l] = 2 * s.HT[l - 1] * s.HT[l] <= WWh;
+        }
+    }
+    s.SW[0] = 0;
+    s.RO = CS_KSPLIT ? WWh / s.HT[lastl] : 1;
+    s.SO = CS_KSPLIT && 2 * s.HT[lastl] <= WWh;
+    s.lpart = o; o += xslots * 4 * WV * 4 * (int)sizeof(float);
+    if (o < WWh * s.L * 4 * WV * 4 * (int)sizeof(float)) o = WWh * s.L * 4 * WV * 4 * (int)sizeof(float);   // the fold area
     s.lds_total = o;
     // activation cache, as the gradient pass of the same net wrote it
     s.fmt = net_has_narrow_kernel(g->obs_dim, g->act_dim, g->hidden0, g->hidden1, g->hidden2) ? 0 : 1;
@@ -722,7 +878,7 @@ static size_t cs_workspace(const CsShape& s) {
     return rows + (size_t)s.img16 * 16 + 64;
 }
 
-template <int L, int WW, int MT>
+template <int L, int WW, int MT, int SHP = 0>
 static int launch(const CsShape& s, const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out,
                   hipStream_t st) {
     if (ws_bytes < cs_workspace(s))
@@ -746,7 +902,7 @@ static int launch(const CsShape& s, const rl_policy_batch* g, const float* vec, 
     int grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     if (grid > CS_MAX_GRID) grid = CS_MAX_GRID;
-    auto kern = csplit_fvp_kernel<L, WW, MT>;
+    auto kern = csplit_fvp_kernel<L, WW, MT, SHP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -767,6 +923,19 @@ static int launch_class(const CsShape& s, const rl_policy_batch* g, const float*
     for (int l = 0; l < s.L; ++l) {
         if (s.HT[l] > maxht) maxht = s.HT[l];
         if (l >= 1 && s.HT[l - 1] * s.HT[l] > 8) mt4 = 1;
+    }
+    // the tapering / equal-width shapes with a 128-unit first layer as compile-time constants (CS_SHAPES; HT0 | HT1 << 4 |
+    // HT2 << 8): (128, 128), (128, 64) = the padded (100, 50), (128, 32); (128, 64, 32) = the padded (100, 50, 25) of the
+    // reference's benchmark policies, ...; everything else runs the generic instantiations
+    if (CS_SHAPES) {
+        const int shp = s.HT[0] | s.HT[1] << 4 | (s.L == 3 ? s.HT[2] << 8 : 0);
+#define CS_CASE(LL, SH, MTT) if (shp == SH) return launch<LL, 4, MTT, SH>(s, g, vec, ws, ws_bytes, out, st);
+        if constexpr (L == 2) {
+            CS_CASE(2, 0x44, 4) CS_CASE(2, 0x24, 2) CS_CASE(2, 0x14, 2) CS_CASE(2, 0x42, 2) CS_CASE(2, 0x41, 2)
+        } else {
+            CS_CASE(3, 0x244, 4) CS_CASE(3, 0x144, 4) CS_CASE(3, 0x224, 2) CS_CASE(3, 0x124, 2) CS_CASE(3, 0x114, 2)
+        }
+#undef CS_CASE
     }
     if (maxht == 2) return launch<L, 2, 2>(s, g, vec, ws, ws_bytes, out, st);
     return mt4 ? launch<L, 4, 4>(s, g, vec, ws, ws_bytes, out, st) : launch<L, 4, 2>(s, g, vec, ws, ws_bytes, out, st);
