@@ -290,8 +290,11 @@ __device__ __forceinline__ f32x16 cs_gemm(const bf16x8* __restrict__ A, int nkb,
 
 // L hidden layers; WW wavefronts per workgroup; MT = most output tiles of a hidden-to-hidden weight gradient one
 // wavefront accumulates
-template <int L, int WW, int MT, int SHP>
-__global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
+// WSP >= 0: the instruction stream of wavefront WSP alone (CS_PER_WAVE: which chains it runs, which tiles it owns and every
+// image offset that depends on them are then compile-time constants; the kernel branches ONCE, on the wavefront's index).
+// All copies execute the same sequence of workgroup barriers.
+template <int L, int WW, int MT, int SHP, int WSP>
+__device__ __forceinline__ void cs_body(const CsArgs& a) {
     const CsShape& s = a.s;
     // row tiles per layer and everything derived from them: compile-time constants in the instantiations of the common
     // shapes (SHP = HT0 | HT1 << 4 | HT2 << 8), read from the shape record otherwise (SHP = 0)
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
     auto SOc = [&]() -> int { return SHP ? (CS_KSPLIT && 2 * HTc(L - 1) <= WW) : s.SO; };
     constexpr int NT = WW * WV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / WV), lane = tid % WV;
+    const int tid = threadIdx.x, wave = WSP >= 0 ? WSP : __builtin_amdgcn_readfirstlane(tid / WV), lane = tid % WV;
     const int lj = lane & 31, lh = lane >> 5;
     const int DO = s.DO, DA = s.DA;
     const float* __restrict__ th = a.theta;
@@ -800,6 +803,27 @@ __global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
                 row[s.ols + k] = cc * vc[s.ols + k] * ws;
             }
         }
+    }
+}
+
+// CS_PER_WAVE 1: one copy of the instruction stream per wavefront index for the three commonest shapes.  MEASURED (round 6,
+// tools/exp/r06_call7.sh, same box): (100, 50, 25) 2.333 against 2.346 ms, (128, 64) 1.82 against 1.87, (128, 128) 3.01
+// against 2.71 (four copies of the loop no longer sit in the instruction cache together) -- off.
+#ifndef CS_PER_WAVE
+#define CS_PER_WAVE 0
+#endif
+template <int L, int WW, int MT, int SHP>
+__global__ void __launch_bounds__(WW * WV, 1) csplit_fvp_kernel(CsArgs a) {
+    if constexpr (CS_PER_WAVE && (SHP == 0x124 || SHP == 0x24 || SHP == 0x44)) {
+        static_assert(WW == 4, "four copies");
+        switch (__builtin_amdgcn_readfirstlane(threadIdx.x / WV)) {
+            case 0: cs_body<L, WW, MT, SHP, 0>(a); break;
+            case 1: cs_body<L, WW, MT, SHP, 1>(a); break;
+            case 2: cs_body<L, WW, MT, SHP, 2>(a); break;
+            default: cs_body<L, WW, MT, SHP, 3>(a); break;
+        }
+    } else {
+        cs_body<L, WW, MT, SHP, -1>(a);
     }
 }
 
