@@ -63,9 +63,14 @@ constexpr int TILE_IMG = 6 * CH;   // one row tile of a parts image: two k-block
 constexpr int MAX_IMG = 10;     // operand images of one launch
 constexpr int CS_MAX_GRID = 512;
 // experiment knobs (timing ablations; tools/exp/csplit_variants.sh).  CS_FETCH_LATE: the next tile's cached fragments
-// start travelling after the tile's last operand-image load instead of before its first.
+// start travelling after the tile's last operand-image load (in front of the products over the sample axis, which read
+// LDS only) instead of at the top of the tile.  The memory queue answers in order: an operand-image load issued behind
+// the HBM loads of the fragments is not "there" before they are, so with the early fetch the first chain of every tile
+// sat out an HBM round trip (SQ_WAIT_ANY 50 % of the wave cycles, profiles/r06_csplit_pmc_sq.csv).  Round 4 measured the
+// late fetch slower on the unbalanced shapes; with the k-slices it is 8 - 19 % faster on every shape (round 6,
+// tools/exp/r06_call9.sh: (128, 128) 2.68 -> 2.47 ms, (100, 50, 25) 2.36 -> 2.18, (128, 128, 64) 4.23 -> 3.42) -- on.
 #ifndef CS_FETCH_LATE
-#define CS_FETCH_LATE 0
+#define CS_FETCH_LATE 1
 #endif
 #ifndef CS_ABLATE_FETCH     // 1: no per-tile HBM loads at all (the first tile's registers are reused): wrong results
 #define CS_ABLATE_FETCH 0
