@@ -38,6 +38,9 @@ namespace rl {
 int launch_reduce_rows(const float* partial, int rows, int cols, double* out, hipStream_t st);   // policy_kernels.hip
 int launch_reduce_loss(const double* partial, int rows, double* out, hipStream_t st);
 
+#ifndef WIDE_PREFETCH
+#define WIDE_PREFETCH 1
+#endif
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int WW = 4;                  // wavefronts per workgroup = row tiles of the widest layer
 constexpr int WNT = WW * WV;
@@ -382,11 +385,56 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
     for (int l = 1; l < L; ++l) coff[l] = coff[l - 1] + 32 * s.H[l - 1];
     const size_t ctile = (size_t)coff[L - 1] + 32 * s.H[L - 1];
 
+    // One tile ahead (WIDE_PREFETCH): the observation slots of this thread, the sample weight and the distribution head's
+    // inputs of the NEXT tile travel while this one is worked on.  A workgroup is alone on its CU (one wavefront per SIMD):
+    // loaded where they are used, each of these HBM round trips was sat out in full, twice per tile.  The loads are issued
+    // BEHIND the tile's last operand-image load -- the memory queue answers in order, a younger image load would wait for
+    // them (policy_csplit_kernels.hip: CS_FETCH_LATE) -- and in front of work that reads LDS only.
+    constexpr int XPT = (WIDE_MAX_DO * 32 + WNT - 1) / WNT;      // observation values per thread
+    constexpr bool HEAD_IN = !FVP && !BWD && !OUTMODE;           // the head reads actions, advantages, the old distribution
+    float nx_x[XPT], nx_wgt = 0.0f, nx_adv = 0.0f, nx_act[MAXDA], nx_om[MAXDA];
+#pragma unroll
+    for (int k = 0; k < MAXDA; ++k) { nx_act[k] = 0.0f; nx_om[k] = 0.0f; }
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) {
+            const int e = tid + j * WNT, d = e >> 5, bb = t * 32 + (e & 31);
+            nx_x[j] = (e < DO * 32) ? __builtin_nontemporal_load(a.obs + (size_t)d * B + (bb < B ? bb : B - 1)) : 0.0f;
+        }
+        const int b_ = t * 32 + lj, bi_ = b_ < B ? b_ : B - 1;
+        nx_wgt = b_ < B ? a.weight[bi_] : 0.0f;
+        if constexpr (HEAD_IN) {
+            nx_adv = a.adv[bi_];
+#pragma unroll
+            for (int k = 0; k < MAXDA; ++k)
+                if (k < DA) { nx_act[k] = a.act[(size_t)k * B + bi_]; nx_om[k] = a.old_mean[(size_t)k * B + bi_]; }
+        }
+    };
+    if (WIDE_PREFETCH && (int)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    bool fetched = false;
+    auto prefetch_next = [&](int tile) {                 // (the workgroup's last tile fetches itself again: no branch)
+        if (WIDE_PREFETCH && !fetched) {
+            prefetch(tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile);
+            fetched = true;
+        }
+    };
+
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile * 32 + lj;
         const int bi = b < B ? b : B - 1;
-        const float wgt = b < B ? a.weight[bi] : 0.0f;
+        const float wgt = WIDE_PREFETCH ? nx_wgt : (b < B ? a.weight[bi] : 0.0f);
+        float hd_adv = nx_adv, hd_act[MAXDA], hd_om[MAXDA];
+#pragma unroll
+        for (int k = 0; k < MAXDA; ++k) { hd_act[k] = nx_act[k]; hd_om[k] = nx_om[k]; }
+        fetched = false;
         __syncthreads();                                   // everybody is done with the previous tile's buffers
+        if (WIDE_PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < XPT; ++j) {
+                const int e = tid + j * WNT;
+                if (e < DO * 32) X[(e >> 5) * BS + (e & 31)] = nx_x[j];
+            }
+        } else
         for (int e = tid; e < DO * 32; e += WNT) {
             const int d = e >> 5, sm = e & 31;
             const int bb = tile * 32 + sm;
@@ -499,6 +547,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             __syncthreads();
         }
 
+        if (!GRADLIKE) prefetch_next(tile);                 // forward-only passes: no operand image is loaded behind this point
         // ---- output layer: partial dot products over this wavefront's quarter of the last hidden layer -----------
         // lane (sample lj, half lh) covers units [q0, q0 + HL / 8) of the quarter, halves are folded by half_sum
         // (FVP: the tangent of the output only; OUT_TAN: output and tangent; BWD: nothing -- the cotangent is given)
@@ -580,15 +629,15 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
                 mean[k] = k < DA ? tail[s.tbo + k] + ((part[(0 * DA + k) * 32 + lj] + part[(1 * DA + k) * 32 + lj]) +
                                                       (part[(2 * DA + k) * 32 + lj] + part[(3 * DA + k) * 32 + lj]))
                                  : 0.0f;
-            const float advb = a.adv[bi];
+            const float advb = WIDE_PREFETCH ? hd_adv : a.adv[bi];
             float zz_new = 0.0f, zz_old = 0.0f, sls_new = 0.0f, sls_old = 0.0f, kl = 0.0f;
             float znew[MAXDA], dmv[MAXDA], numv[MAXDA];
 #pragma unroll
             for (int k = 0; k < MAXDA; ++k) {
                 znew[k] = 0.0f; dmv[k] = 0.0f; numv[k] = 0.0f;
                 if (k < DA) {
-                    const float ak = a.act[(size_t)k * B + bi];
-                    const float mo = a.old_mean[(size_t)k * B + bi];
+                    const float ak = WIDE_PREFETCH ? hd_act[k] : a.act[(size_t)k * B + bi];
+                    const float mo = WIDE_PREFETCH ? hd_om[k] : a.old_mean[(size_t)k * B + bi];
                     const float lo = a.old_log_std[k];
                     const float so = __expf(lo);
                     znew[k] = (ak - mean[k]) * inv_std[k];
@@ -736,6 +785,7 @@ __global__ void __launch_bounds__(WNT, (wide_wps<L, MODE, KSPLIT, MT>())) wide_p
             }
         }
 
+        prefetch_next(tile);
         // ---- outer products over the sample axis (K = 32 samples = 16 k-steps) ------------------------------------
         // operand m of lane (c, half): value of unit c (of the row / column tile) at sample 2 m + half
 #pragma unroll
