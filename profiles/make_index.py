@@ -19,6 +19,12 @@ RECIPES = [
     ("*_c5_kernel_stats.csv", "kernel stats of C5's per-GPU shard", "profiles/run_profile.sh <tag> cheetah1024_trpo_gae"),
     ("*_c5_pmc_*.csv", "PMC passes of C5's per-GPU shard (one counter group per pass)", "profiles/run_profile.sh <tag> cheetah1024_trpo_gae"),
     ("*_c2_*.csv", "kernel stats / PMC passes of C2 (Cartpole 4096 envs, VPG)", "profiles/run_profile.sh <tag> cartpole4096_vpg"),
+    ("r06_csplit_*.csv", "SQ counter passes / kernel stats of csplit_fvp_kernel on (100, 50, 25) and (128, 128) at 2.048 M samples", "tools/exp/r06_call8.sh"),
+    ("r06_c7_csplit_ab.txt", "cooperative product per library: round start / one instruction stream per wavefront (off) / compile-time shapes + k-slices", "tools/exp/r06_call7.sh"),
+    ("r06_c9_csplit_ab.txt", "cooperative product per library: k-slices + compile-time shapes / round start / + late fetch", "tools/exp/r06_call9.sh"),
+    ("r06_c10_csplit_ab.txt", "cooperative product: the library of the round's start, timed in the call that ran the parity tests and the wide bench lines on the final one", "tools/exp/r06_call10.sh"),
+    ("r06_c11_policy_time.txt", "wide loss / gradient / product passes with (.orig) and without (lib_before_wpf) the one-tile-ahead prefetch", "tools/exp/r06_call11.sh"),
+    ("r06_wide_kernel_bench.txt", "loss / gradient / product passes of the wide nets at the final sources", "python tools/kernel_bench.py --configs ..."),
     ("*_split_kernel_stats.csv", "kernel stats of the three Fisher-vector-product kernels back to back", "tools/prof_split.sh"),
     ("*_split_pmc_*.csv", "PMC passes of the product kernels", "tools/prof_split.sh"),
     ("*_split64_*.csv", "kernel stats / PMC passes of the 64-unit split product", "tools/prof_split.sh 64"),
@@ -57,6 +63,7 @@ One evidence set per round (older intermediate sets `r01a … r01l` were pruned 
 | 3 | `r03_*` (headline), `r03_split_*` (product kernels), `r03_wide_*` | HEAD of round 3 = `8bd729a`; `pmc_traffic.json` carries the sha256 of `rllab_amd/csrc/*` it was taken at |
 | 4 | `r04_*` | see the stamp in `pmc_traffic.json` and `r04_notes.md` |
 | 5 | `r05_*` (headline, `r05_c5_*` C5's shard, `r05_split_*` product kernels) | one run of `tools/exp/r05_final_a.sh` at the final kernel sources (stamp in `pmc_traffic.json`); `r05_notes.md` |
+| 6 | `r06_*` (headline, `r06_c5_*`, `r06_c2_*`, `r06_split16_*`, `r06_csplit_*`) | one run of `tools/exp/r06_final_all.sh` at the final kernel sources (stamp in `pmc_traffic.json`); `r06_notes.md` |
 """
 
 

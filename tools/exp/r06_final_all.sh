@@ -19,6 +19,8 @@ for w in cartpole4096_vpg cheetah1024_trpo_gae double_pendulum4096_trpo; do
 done
 bash tools/exp/r06_call5.sh > $O/r06_split_profile.log 2>&1
 python tools/exp/fvp_split16_time.py 1 2>&1 | grep "^{" > $O/r06_split16_time.txt
+bash tools/exp/r06_call8.sh > $O/r06_csplit_profile.log 2>&1
+timeout 600 python tools/kernel_bench.py --configs "13,2,100-50-25,2048000;13,2,128-128,2048000;20,6,128-64,512000" 2>&1 | grep "^{" > $O/r06_wide_kernel_bench.txt
 for n in 16384 65536; do
   python bench.py --n-envs $n --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r06_bench_n$n.json
 done
