@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 # input k-blocks, narrow layers inside wide nets, heads of 1 .. 8 actions
 SHAPES = [(13, 2, (64, 64)), (20, 6, (64, 64)), (4, 1, (64, 64)), (17, 8, (64, 64)), (13, 2, (128, 128)),
           (20, 6, (128, 128)), (13, 2, (100, 50, 25)), (21, 6, (128, 64)), (11, 1, (64, 32)), (13, 2, (32, 64)),
-          (20, 3, (64, 64, 64)), (13, 2, (128, 128, 64))]
+          (20, 3, (64, 64, 64)), (13, 2, (128, 128, 64)),
+          # round 6, k-slices: a row tile shared by FOUR wavefronts (128 -> 32), slices of ONE k-block, a sample-axis product
+          # of a single output tile split per sample block (32 -> 32 inside a four-wavefront workgroup), run-time shapes
+          (13, 2, (128, 32)), (17, 6, (128, 32, 32)), (11, 3, (32, 32, 128)), (13, 2, (64, 128, 32))]
 
 
 def _policy(do, da, hidden):
