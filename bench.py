@@ -497,7 +497,8 @@ def main():
         v = torch.randn(policy.flat_params.numel(), device="cuda", dtype=torch.float64)
         ops.loss_grad(inp, keep_activations=True)     # as ConjugateGradientOptimizer.optimize does before CG
         # which arithmetic the library runs these products in (0: f32 matrix instructions, 1: bf16 matrix
-        # instructions on three-way split f32 operands -- csrc/policy_split_kernels.hip)
+        # instructions on three-way split f32 operands -- csrc/policy_split_kernels.hip, 4: f16 matrix instructions on
+        # two-way split operands -- csrc/policy_splith_kernels.hip)
         fvp_variant = ops.fvp_variant(inp)
         def timed20(fn):
             for _ in range(3):
@@ -615,6 +616,19 @@ def main():
                                    "accumulation: dropped terms <= 2^-23 |a b| worst case, 2^-28 mean (tests/test_split_arithmetic.py, test_gpu_fvp_split.py)",
                      "bf16_mfma_per_32_samples": bf16_mfma,
                      "bf16_pipe_frac": tiles * bf16_mfma * 32768 / (fvp_ms * 1e-3) / 2.5e15}
+        elif fvp_variant == 4:
+            # the two-way f16 split (csrc/policy_splith_kernels.hip): the same algorithmic f32 work against the same peak;
+            # what the f16 pipe executes is three cross terms per product + 14 transposition products per tile
+            kern = "%s (Fisher-vector product, v_mfma_f32_32x32x16_f16 on two-way split f32 operands)" % (
+                "fvp_splith_kernel" if h == 32 else "fvp_splith64_kernel")
+            kb0 = (do + 1 + 15) // 16
+            f16_mfma = 3 * (ht * kb0 + 3 * ht * 2 * ht + 2 * ht * ht + 2 * ht) + 2 * (3 * 2 * ht + kb0)
+            extra = {"arithmetic": "f32 operands split hi + 2^-11 lo' (f16 parts, lo scaled to stay normal), three cross terms per "
+                                   "product, f32 accumulation, per-launch power-of-two operand scales with worst-case bounds; "
+                                   "closer to float64 than an f32 fma chain (tools/ubench/f16_split.hip, "
+                                   "tests/test_gpu_fvp_split.py)",
+                     "f16_mfma_per_32_samples": f16_mfma,
+                     "f16_pipe_frac": tiles * f16_mfma * 32768 / (fvp_ms * 1e-3) / 2.5e15}
         elif fvp_variant == 2:
             kern = ("csplit_fvp_kernel (Fisher-vector product of a wide / deep net, cooperative tiling, "
                     "v_mfma_f32_32x32x16_bf16 on three-way split f32 operands; parts images in LDS, transposing reads)")

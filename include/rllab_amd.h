@@ -55,7 +55,9 @@ const char* rl_last_error(void);
  * rl_running_norm (NormalizedEnv's running observation / reward normalisation inside the fused rollout).
  * 13: rl_env_terminates; rl_rollout_args.reset_at_start == 0 continues from last_obs (the sampler's further launches
  * until batch_size whole-path samples are in, running normalisation included); RL_CFG_CONTACT_MUJOCO, and RL_CFG_LIMIT_MUJOCO
- * for the legged envs; rl_rollout_args.std_layer_activations, identity layers on the cooperative (wide) kernels. */
+ * for the legged envs; rl_rollout_args.std_layer_activations, identity layers on the cooperative (wide) kernels.
+ * 14: rl_policy_batch.obs_absmax (the two-way f16 split Fisher-vector product), rl_launch_opts.fvp_split = 4 / 5,
+ * rl_policy_fvp_variant's value 4. */
 int rl_abi_version(void);
 
 /* Static facts about an env kind: observation / action / persisted-state sizes,
@@ -220,7 +222,9 @@ typedef struct rl_launch_opts {
     int32_t two_leg_wave_kernel;  /* 1 force, 2 forbid one env per wavefront */
     int32_t fvp_split;            /* rl_policy_fvp: 1 = f32 matrix instructions only, 2 = the cooperative split kernel for
                                    * every shape it is built for, 3 = the 16-sample-tile split kernel (four wavefronts per
-                                   * SIMD) for the (32, 32) shapes it is built for */
+                                   * SIMD) for the (32, 32) shapes it is built for, 4 = the two-way f16 split kernels (also
+                                   * the library's choice, 0, whenever rl_policy_batch.obs_absmax is set and the shape is
+                                   * theirs), 5 = the three-way bf16 split kernels although obs_absmax is set */
     int32_t fvp_split_wps;        /* 1: fvp_split_kernel with one wavefront per SIMD (register-resident operands); 4: the
                                    * 16-sample-tile kernel (fvp_split = 3) with four wavefronts per SIMD instead of three */
     int32_t lfb_valu;             /* rl_lfb_normal_eq: 1 = the register-blocked vector kernel */
@@ -439,6 +443,12 @@ typedef struct rl_policy_batch {
                                 * rl_line_search_decide's "a candidate has been accepted" flag: the loss passes of
                                 * the candidates enqueued behind an accepted one cost a launch, not a pass over the
                                 * batch.  Ignored by every other entry point. */
+    float* obs_absmax;         /* NULL, or one device float.  With `activations` set, rl_policy_grad / rl_policy_grad_loss
+                                * (vpg == 0) leave max_{d,b} |obs[d][b]| of the batch there (no extra pass: the gradient pass holds the
+                                * observations), and rl_policy_fvp -- under the same guarantee as for `activations` -- takes
+                                * it as the bound from which the two-way f16 split product (policy_splith_kernels.hip)
+                                * scales its operands; a larger value than the true maximum is valid (coarser scales), a
+                                * smaller one is not.  NULL: the three-way bf16 split product, which needs no bound. */
 } rl_policy_batch;
 
 enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1, RL_ACT_IDENTITY = 2 };
@@ -485,7 +495,12 @@ int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspac
  *      tiles.  Same result to f32 rounding, not bit for bit.  RLLAB_FVP_SPLIT=0 in the environment selects 0.
  *   2  the same arithmetic in the cooperative tiling (csrc/policy_csplit_kernels.hip: parts images in LDS, transposing
  *      reads for the sample-axis products): cached products of two or three tanh layers of 32 / 64 / 128 units with a
- *      128-unit layer (RLLAB_FVP_SPLIT=2: every such net that is not all-32) on whole 32-sample tiles. */
+ *      128-unit layer (RLLAB_FVP_SPLIT=2: every such net that is not all-32) on whole 32-sample tiles.
+ *   4  f16 matrix instructions on TWO-way split operands, lo part scaled by 2^11, three cross terms per product with f32
+ *      accumulation (csrc/policy_splith_kernels.hip; closer to float64 than an f32 fma chain, tools/ubench/f16_split.hip),
+ *      every operand class under a per-launch power-of-two scale with worst-case bounds: the cached products of 1 for the
+ *      two-wavefront (32, 32) shapes and the (64, 64) shapes, when rl_policy_batch.obs_absmax is set (RLLAB_FVP_SPLIT=5:
+ *      variant 1 all the same). */
 int rl_policy_fvp_variant(const rl_policy_batch* batch);
 
 /* ---- policies whose log-std is a NETWORK (GaussianMLPPolicy(adaptive_std=True) / std_network=...,

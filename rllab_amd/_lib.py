@@ -79,6 +79,7 @@ class PolicyBatch(ctypes.Structure):
         ("old_log_std", ctypes.c_void_p), ("weights", ctypes.c_void_p), ("activations", ctypes.c_void_p),
         ("kl_penalty", ctypes.c_float), ("activation", ctypes.c_int32), ("opts", ctypes.c_void_p),
         ("layer_activations", ctypes.c_int32), ("reserved_pad", ctypes.c_int32), ("gate", ctypes.c_void_p),
+        ("obs_absmax", ctypes.c_void_p),
     ]
 
 
@@ -150,7 +151,7 @@ def launch_opts():
     v = e("RLLAB_TWO_LEG_WAVE_KERNEL")
     o.two_leg_wave_kernel = 0 if not v else (1 if v[0] == "1" else 2)
     v = e("RLLAB_FVP_SPLIT")
-    o.fvp_split = 0 if not v else (1 if v[0] == "0" else 2 if v[0] == "2" else 3 if v[0] == "3" else 0)
+    o.fvp_split = 0 if not v else (1 if v[0] == "0" else int(v[0]) if v[0] in "2345" else 0)
     v = e("RLLAB_FVP_SPLIT_WPS")
     o.fvp_split_wps = int(v[0]) if v and v[0] in "134" else 0
     o.lfb_valu = 1 if e("RLLAB_LFB_VALU") is not None else 0

@@ -10,4 +10,4 @@ char* error_buffer() {
 }  // namespace rl
 
 extern "C" const char* rl_last_error(void) { return rl::error_buffer(); }
-extern "C" int rl_abi_version(void) { return 13; }
+extern "C" int rl_abi_version(void) { return 14; }

@@ -96,6 +96,8 @@ struct PolicyBatch {
     float* partial;            // [grid][P]          (grad-like modes)
     double* partial_loss;      // [grid][LOSS_COLS]  (MODE_LOSS; MODE_GRAD: optional, null = gradient only)
     const int* gate;           // MODE_LOSS: rl_policy_batch.gate -- non-zero word: the launch returns at once
+    unsigned* obs_absmax;      // MODE_GRAD with the cache: max |obs| of the batch as the bits of a float (atomic max; zeroed by
+                               // the launcher), for the f16 split product's scales (policy_splith_kernels.hip); null = not asked
     int act0, act1;            // activation codes of the two hidden layers (rl_activation; RELU instantiations ignore them)
 };
 
@@ -232,6 +234,7 @@ __global__ void __launch_bounds__(N::WAVES * WV, (pass_wps<N, MODE>())) policy_p
     };
     float xb[KS0], xb_next[KS0];
     float wgt = 0.0f, wgt_next = 0.0f;
+    float xabs = 0.0f;                          // (cache-writing gradient pass only) running max |x| of this lane
     if (wave_global < n_tiles) fetch(wave_global, xb_next, wgt_next);
     // cached activations travel one tile ahead as well (FVP only), by LDS-direct loads into a wave-private landing
     // zone: 8 KB per tile would not fit the register budget of two wavefronts per SIMD next to the accumulators
@@ -315,6 +318,8 @@ __global__ void __launch_bounds__(N::WAVES * WV, (pass_wps<N, MODE>())) policy_p
                 act_frag(h1[t], acc, c1);
             }
             if constexpr (STORE_ACTS) {
+#pragma unroll
+                for (int m = 0; m < KS0; ++m) xabs = fmaxf(xabs, 2 * m + lh < DO ? fabsf(xb[m]) : 0.0f);   // (not the bias slot)
                 f32x4* dst = reinterpret_cast<f32x4*>(a.acts) + (size_t)tile * ACT_ROWS * WV + lane;
 #pragma unroll
                 for (int t = 0; t < HT; ++t)
@@ -594,6 +599,13 @@ __global__ void __launch_bounds__(N::WAVES * WV, (pass_wps<N, MODE>())) policy_p
         }
     }
 
+    if constexpr (STORE_ACTS) {
+        // a maximum is order-independent, and non-negative floats order like their bit patterns
+        if (a.obs_absmax != nullptr) {
+            xabs = wave_max(xabs);
+            if (lane == 0) atomicMax(a.obs_absmax, __float_as_uint(xabs));
+        }
+    }
     // ---- fold the wavefronts of this workgroup in a fixed order, write ONE partial row --------
     __syncthreads();   // every wave is done with the weight fragments: the fold buffer aliases them
     auto fold_loss = [&]() {
@@ -817,6 +829,7 @@ struct WideShape;
 // policy_split_kernels.hip: the cached Fisher-vector product of the 32-unit nets on the bf16 matrix pipe (three-way
 // split operands, f32 accuracy); RL_SPLIT_NOT_TAKEN when the launch is not its to make
 int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
+int splith_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
 int csplit_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st);
 size_t csplit_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not its shape
 size_t wide_workspace_bytes_for(int obs_dim, int act_dim, int h0, int h1, int h2);   // 0 = not a wide shape
@@ -842,6 +855,12 @@ static int launch_pass(const rl_policy_batch* g, const float* vec, void* workspa
     a.old_mean = g->old_means; a.old_log_std = g->old_log_std; a.weight = g->weights;
     a.inv_count = g->inv_count; a.log_min_std = g->log_min_std;
     a.gate = (MODE == MODE_LOSS) ? g->gate : nullptr;
+    a.obs_absmax = nullptr;
+    if (MODE == MODE_GRAD && CACHE && g->activations && g->obs_absmax) {
+        a.obs_absmax = reinterpret_cast<unsigned*>(g->obs_absmax);
+        hipError_t e = hipMemsetAsync(g->obs_absmax, 0, sizeof(float), st);
+        if (e != hipSuccess) return set_error(RL_ERR_HIP, "hipMemsetAsync(obs_absmax): %s", hipGetErrorString(e));
+    }
     a.act0 = layer_act(g->activation, g->layer_activations, 0);
     a.act1 = layer_act(g->activation, g->layer_activations, 1);
     const int n_tiles = (a.B + TS - 1) / TS;
@@ -1001,7 +1020,9 @@ static int dispatch_net(int mode, const rl_policy_batch* g, const float* vec, vo
     if (g->kl_penalty != 0.0f && mode != MODE_VPG && mode != MODE_GRAD)
         return set_error(RL_ERR_ARG, "rl_policy_batch.kl_penalty applies to the gradient passes only");
     if (mode == MODE_FVP && cg == nullptr && all_tanh) {
-        int rc = split_fvp_dispatch(g, vec, ws, ws_bytes, out, st);          // (32, 32): one wavefront per tile
+        int rc = splith_fvp_dispatch(g, vec, ws, ws_bytes, out, st);         // two-way f16 split (obs_absmax set)
+        if (rc != RL_SPLIT_NOT_TAKEN) return rc;
+        rc = split_fvp_dispatch(g, vec, ws, ws_bytes, out, st);              // (32, 32): one wavefront per tile
         if (rc != RL_SPLIT_NOT_TAKEN) return rc;
         rc = csplit_fvp_dispatch(g, vec, ws, ws_bytes, out, st);             // 64-unit and wide nets: cooperative
         if (rc != RL_SPLIT_NOT_TAKEN) return rc;

@@ -85,6 +85,11 @@ struct Parts { bf16x8 p[3]; };                 // hi, mid, lo of eight values
 #ifndef RL_ABL_OPS
 #define RL_ABL_OPS 0
 #endif
+//   RL_ABL_HALF   two parts per operand and three cross terms per product (the instruction stream a two-way f16 split
+//                 would have: timing only)
+#ifndef RL_ABL_HALF
+#define RL_ABL_HALF 0
+#endif
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 #if RL_ABL_MFMA
     asm volatile("" : "+v"(c) : "v"(a), "v"(b));
@@ -95,9 +100,11 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 // c += A B to f32 accuracy: the six cross terms, smallest first
 __device__ __forceinline__ f32x16 mm6(const Parts& A, const Parts& B, f32x16 c) {
+#if !RL_ABL_HALF
     c = mfma16(A.p[1], B.p[1], c);
     c = mfma16(A.p[0], B.p[2], c);
     c = mfma16(A.p[2], B.p[0], c);
+#endif
     c = mfma16(A.p[0], B.p[1], c);
     c = mfma16(A.p[1], B.p[0], c);
     c = mfma16(A.p[0], B.p[0], c);
@@ -203,6 +210,15 @@ __device__ __forceinline__ void split_pair(float a0, float a1, Parts& out, int j
     const f32x2 a = {a0, a1};
     const bf16x2 h = __builtin_convertvector(a, bf16x2);
     const f32x2 r = residual(a, h);
+#if RL_ABL_HALF
+    {
+        const bf16x2 m = __builtin_convertvector(r * f32x2{2048.0f, 2048.0f}, bf16x2);
+        out.p[0][j] = h[0]; out.p[0][j + 1] = h[1];
+        out.p[1][j] = m[0]; out.p[1][j + 1] = m[1];
+        out.p[2][j] = m[0]; out.p[2][j + 1] = m[1];
+        return;
+    }
+#endif
     const bf16x2 m = __builtin_convertvector(r, bf16x2);
     const f32x2 l = residual(r, m);
     const bf16x2 q = __builtin_convertvector(l, bf16x2);
@@ -250,7 +266,7 @@ __device__ __forceinline__ void pack_exact(const f32x16& d, Parts (&out)[2], int
 // frag_unit(8 kb + j, half) as k-block kb.  part (A: rows = samples, k = units) x identity, on the matrix pipe, exact.
 __device__ __forceinline__ void transpose_units(const Parts (&f)[2], const bf16x8 (&Id)[2], Parts (&out)[2]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < (RL_ABL_HALF ? 2 : 3); ++p) {
         f32x16 d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[r] = 0.0f;
@@ -263,7 +279,7 @@ __device__ __forceinline__ void transpose_units(const Parts (&f)[2], const bf16x
 template <int KB0>
 __device__ __forceinline__ void transpose_inputs(const Parts (&f)[KB0], const bf16x8 (&Idx)[KB0], Parts (&out)[2]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < (RL_ABL_HALF ? 2 : 3); ++p) {
         f32x16 d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[r] = 0.0f;
@@ -1469,10 +1485,12 @@ int split_fvp_dispatch(const rl_policy_batch* g, const float* vec, void* ws, siz
 
 namespace rl { bool csplit_fvp_takes(const rl_policy_batch* g); }     // policy_csplit_kernels.hip
 namespace rl { bool split16_fvp_takes(const rl_policy_batch* g); }    // policy_split16_kernels.hip
+namespace rl { bool splith_fvp_takes(const rl_policy_batch* g); }     // policy_splith_kernels.hip
 
 extern "C" int rl_policy_fvp_variant(const rl_policy_batch* g) {
     if (!g) return rl::set_error(RL_ERR_ARG, "rl_policy_fvp_variant: null batch");
     if (g->opts && g->opts->fvp_split == 3 && rl::split_fvp_takes(g) && rl::split16_fvp_takes(g)) return 3;
+    if (rl::splith_fvp_takes(g)) return 4;
     if (rl::split_fvp_takes(g)) return 1;
     return rl::csplit_fvp_takes(g) ? 2 : 0;
 }

@@ -34,6 +34,7 @@ class FusedGaussianMLPOps(object):
         self._loss_cache = None
         self._bound = {}     # key -> (PolicyBatch, tensors kept alive, inv_count float); <= 2 entries
         self._acts = None    # hidden-activation cache the gradient pass fills for the FVP passes
+        self._absmax = None  # ... and max |obs| of the batch (rl_policy_batch.obs_absmax)
         self._acts_tag = None
 
     # parameter updates written by our own kernels straight into the parameter vector (see _eval_point): kept on the
@@ -195,6 +196,10 @@ class FusedGaussianMLPOps(object):
             if self._acts is None or self._acts.numel() < need or self._acts.device != keep[0].device:
                 self._acts = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
             b.activations = self._acts.data_ptr()
+            # max |obs| of the batch, left by the same pass: the bound the two-way f16 split products scale by
+            if self._absmax is None or self._absmax.device != keep[0].device:
+                self._absmax = torch.zeros(1, dtype=torch.float32, device=keep[0].device)
+            b.obs_absmax = self._absmax.data_ptr()
         tag = self._eval_point(inputs)
         have_loss = self._loss_cache is not None and self._loss_cache["tag"] == tag
         try:
@@ -220,6 +225,7 @@ class FusedGaussianMLPOps(object):
                 self._acts_tag = tag
         finally:
             b.activations = None
+            b.obs_absmax = None
         return self._mask_frozen(self.layout.unpack(D.update_sum_(out)))
 
     # ``GaussianMLPPolicy(learn_std=False)``: the log_std row is a parameter that is not trainable.  The passes compute
@@ -276,12 +282,14 @@ class FusedGaussianMLPOps(object):
     def _fvp_into(self, b, ws, vec32, out, inputs=None):
         cached = inputs is not None and self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
         b.activations = self._acts.data_ptr() if cached else None
+        b.obs_absmax = self._absmax.data_ptr() if cached and self._absmax is not None else None
         b.opts = _lib.launch_opts()
         try:
             _lib.check(_lib.lib.rl_policy_fvp(ctypes.byref(b), _lib.ptr(vec32), _lib.ptr(ws), ws.numel(),
                                               _lib.ptr(out), _lib.stream_ptr()), "rl_policy_fvp")
         finally:
             b.activations = None
+            b.obs_absmax = None
         out = D.update_sum_(out)
         if getattr(self.layout, "identity_layer", False):
             # the identity second layer of a one-hidden-layer policy is a CONSTANT of the kernel copy: without this its
@@ -296,11 +304,13 @@ class FusedGaussianMLPOps(object):
         b, _, _ = self._batch(inputs)
         cached = self._acts_tag is not None and self._acts_tag == self._eval_point(inputs)
         b.activations = self._acts.data_ptr() if cached else None
+        b.obs_absmax = self._absmax.data_ptr() if cached and self._absmax is not None else None
         b.opts = _lib.launch_opts()
         try:
             return int(_lib.lib.rl_policy_fvp_variant(ctypes.byref(b)))
         finally:
             b.activations = None
+            b.obs_absmax = None
 
     def fvp(self, inputs, vec):
         b, keep, _ = self._batch(inputs)

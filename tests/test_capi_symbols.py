@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(_lib.lib, n), "librllab_amd.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.rl_abi_version() == 13
+    assert _lib.lib.rl_abi_version() == 14
 
 
 def test_env_query_and_errors():

@@ -47,10 +47,11 @@ def test_cooperative_split_product_is_an_f32_accurate_product(do, da, hidden, B,
     plain = [ops.fvp(inp, v) for v in vs]
     monkeypatch.delenv("RLLAB_FVP_SPLIT")
     # by default the kernel takes the nets with a 128-unit layer (where it is the faster one); RLLAB_FVP_SPLIT=2: every shape
-    # (the HIP-native (obs, action) pairs at (64, 64) have the one-wavefront-per-tile split kernel since round 5: variant 1)
+    # (the HIP-native (obs, action) pairs at (64, 64) have the one-wavefront-per-tile split kernels since round 5: variant 4,
+    # the two-way f16 split, since round 6)
     from tests.test_gpu_fvp_split import SPLIT64_SHAPES
     narrow64 = tuple(pol.kernel_layout().hidden3) == (64, 64, 0) and (do, da) in SPLIT64_SHAPES    # (padded widths count)
-    assert _variant(ops, inp) == (2 if max(pol.kernel_layout().hidden3) == 128 else 1 if narrow64 else 0)
+    assert _variant(ops, inp) == (2 if max(pol.kernel_layout().hidden3) == 128 else 4 if narrow64 else 0)
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "2")
     assert _variant(ops, inp) == 2                       # the launch below IS the cooperative split kernel
     split = [ops.fvp(inp, v) for v in vs]

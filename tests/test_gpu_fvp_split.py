@@ -1,7 +1,9 @@
-"""The split-operand Fisher-vector product (csrc/policy_split_kernels.hip: bf16 matrix instructions on three-way split
-f32 operands, six cross terms, f32 accumulation) against float64 autograd of the reference's mean KL (PerlmutterHvp,
+"""The split-operand Fisher-vector products -- csrc/policy_split_kernels.hip (bf16 matrix instructions on three-way split
+f32 operands, six cross terms; variant 1) and csrc/policy_splith_kernels.hip (f16 matrix instructions on two-way split
+operands under per-launch power-of-two scales, three cross terms; variant 4, the library's choice where it is built) --
+against float64 autograd of the reference's mean KL (PerlmutterHvp,
 rllab/optimizers/conjugate_gradient_optimizer.py:27-55) and against the f32-matrix-instruction product of the same
-batch: it must be an f32-accurate product, not a reduced-precision one."""
+batch: each must be an f32-accurate product, not a reduced-precision one."""
 import numpy as np
 import pytest
 import torch
@@ -15,8 +17,23 @@ SPLIT64_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6)]  
 ALL_SPLIT = [(d, a, 32) for d, a in SPLIT_SHAPES] + [(d, a, 64) for d, a in SPLIT64_SHAPES]
 
 
+SPLITH_SHAPES = [(4, 1, 32), (6, 1, 32), (11, 1, 32), (13, 2, 32), (13, 1, 32)] + [(d, a, 64) for d, a in SPLIT64_SHAPES]
+ARITH = ["f16x2", "bf16x3"]
+
+
 def _variant(ops, inp):
     return ops.fvp_variant(inp)
+
+
+def _arith(monkeypatch, arith, shape):
+    """Select the split arithmetic for the launches that follow; returns the variant rl_policy_fvp_variant must report:
+    4 = two-way f16 (the library's choice for the shapes it is built for), 1 = three-way bf16 (RLLAB_FVP_SPLIT=5, or
+    the library's choice elsewhere)."""
+    if arith == "bf16x3":
+        monkeypatch.setenv("RLLAB_FVP_SPLIT", "5")
+        return 1
+    monkeypatch.delenv("RLLAB_FVP_SPLIT", raising=False)
+    return 4 if tuple(shape) in SPLITH_SHAPES else 1
 
 
 def _f64_products(pol, inp, vs):
@@ -39,9 +56,12 @@ def _blocks(pol, h=32):
     return out
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("do,da,h", ALL_SPLIT)
 @pytest.mark.parametrize("B", [32, 4096, 64000])
-def test_split_product_is_an_f32_accurate_product(do, da, h, B, monkeypatch):
+def test_split_product_is_an_f32_accurate_product(do, da, h, B, arith, monkeypatch):
+    if arith == "f16x2" and (do, da, h) not in SPLITH_SHAPES:
+        pytest.skip("the wide-head (32, 32) shapes run the bf16 kernel (one wavefront per SIMD)")
     pol = U._policy(do, da, h)
     ops = pol.fused_ops()
     inp = U._inputs(pol, B, old_equals_new=True)
@@ -53,8 +73,8 @@ def test_split_product_is_an_f32_accurate_product(do, da, h, B, monkeypatch):
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
     assert _variant(ops, inp) == 0
     plain = [ops.fvp(inp, v) for v in vs]
-    monkeypatch.delenv("RLLAB_FVP_SPLIT")
-    assert _variant(ops, inp) == 1                       # the launch below IS the split kernel
+    want_variant = _arith(monkeypatch, arith, (do, da, h))
+    assert _variant(ops, inp) == want_variant            # the launch below IS that split kernel
     split = [ops.fvp(inp, v) for v in vs]
     assert ops._acts_tag is not None
     for hv_s, hv_p, hv64 in zip(split, plain, want):
@@ -71,17 +91,21 @@ def test_split_product_takes_only_its_batches(monkeypatch):
     instructions and keeps the cached product bit-identical to the recomputed one."""
     pol = U._policy(13, 2, 32)
     ops = pol.fused_ops()
-    for B, want in ((4096, 1), (4100, 0), (63, 0)):
+    for B, want in ((4096, 4), (4100, 0), (63, 0)):
         inp = U._inputs(pol, B, old_equals_new=True)
         ops.release()
         assert _variant(ops, inp) == 0                   # nothing cached yet
         ops.loss_grad(inp, keep_activations=True)
         assert _variant(ops, inp) == want
+        if want:
+            monkeypatch.setenv("RLLAB_FVP_SPLIT", "5")   # the three-way bf16 split on request
+            assert _variant(ops, inp) == 1
+            monkeypatch.delenv("RLLAB_FVP_SPLIT")
     pol64 = U._policy(13, 2, 64)
     ops64 = pol64.fused_ops()
     inp = U._inputs(pol64, 4096, old_equals_new=True)
     ops64.loss_grad(inp, keep_activations=True)
-    assert _variant(ops64, inp) == 1                     # (64, 64): the one-wavefront-per-tile split kernel since round 5
+    assert _variant(ops64, inp) == 4                     # (64, 64): the one-wavefront-per-tile split kernels since round 5
     inp_r = U._inputs(pol64, 4100, old_equals_new=True)
     ops64.loss_grad(inp_r, keep_activations=True)
     assert _variant(ops64, inp_r) == 0                   # ... whole tiles only, like the 32-unit kernel
@@ -92,14 +116,16 @@ def test_split_product_takes_only_its_batches(monkeypatch):
     assert _variant(ops64, inp) == 0
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("do,da,h", [(13, 2, 32), (20, 6, 64)])
-def test_cg_on_the_split_product_solves_the_same_system(do, da, h, monkeypatch):
+def test_cg_on_the_split_product_solves_the_same_system(do, da, h, arith, monkeypatch):
     """Ten CG iterations (krylov.cg, rllab/misc/krylov.py:7-39) on either product: the same solution to f32 accuracy."""
     pol = U._policy(do, da, h)
     ops = pol.fused_ops()
     inp = U._inputs(pol, 64000, old_equals_new=True)
     g = ops.loss_grad(inp, keep_activations=True)
-    assert _variant(ops, inp) == 1
+    want_variant = _arith(monkeypatch, arith, (do, da, h))
+    assert _variant(ops, inp) == want_variant
     x_s, xhx_s = ops.cg(inp, g, 10, 1e-5)
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
     x_p, xhx_p = ops.cg(inp, g, 10, 1e-5)
@@ -107,8 +133,9 @@ def test_cg_on_the_split_product_solves_the_same_system(do, da, h, monkeypatch):
     assert abs(float(xhx_s) - float(xhx_p)) <= 1e-5 * abs(float(xhx_p))
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("do,da,h,B", [(13, 2, 32, 4096 * 500), (20, 6, 64, 1024 * 500)])
-def test_full_size_products_are_linear_symmetric_and_positive(do, da, h, B):
+def test_full_size_products_are_linear_symmetric_and_positive(do, da, h, B, arith, monkeypatch):
     """At BASELINE config C3's batch (4096 envs x 500 steps = 2 048 000 samples, ragged weights): the split product is
     linear in the vector, symmetric (v . F w == w . F v) and positive (v . F v > 0) -- properties of the Fisher matrix of
     rllab/optimizers/conjugate_gradient_optimizer.py:27-55 that do not need a float64 pass over two million samples."""
@@ -116,7 +143,8 @@ def test_full_size_products_are_linear_symmetric_and_positive(do, da, h, B):
     ops = pol.fused_ops()
     inp = U._inputs(pol, B, old_equals_new=True)
     ops.loss_grad(inp, keep_activations=True)
-    assert _variant(ops, inp) == 1
+    want_variant = _arith(monkeypatch, arith, (do, da, h))
+    assert _variant(ops, inp) == want_variant
     rng = np.random.RandomState(11)
     v, w = (torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2))
     Fv, Fw = ops.fvp(inp, v), ops.fvp(inp, w)
@@ -150,8 +178,9 @@ def _f64_products_chunked(pol, inp, vs, chunk=256 * 1024):
     return out
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("do,da,h,n_envs", [(13, 2, 32, 4096), (20, 6, 64, 1024)])
-def test_full_size_product_against_float64_double_backward(do, da, h, n_envs, monkeypatch):
+def test_full_size_product_against_float64_double_backward(do, da, h, n_envs, arith, monkeypatch):
     """The product at the FULL batch of BASELINE configs C3 (4096 Swimmer envs x 500 steps = 2 048 000 samples, (32, 32))
     and C5's per-GPU shard (1024 HalfCheetah envs x 500 = 512 000 samples, (64, 64)) against a float64 double-backward of
     the reference's mean KL over every sample (PerlmutterHvp, conjugate_gradient_optimizer.py:27-55): the reference
@@ -164,14 +193,17 @@ def test_full_size_product_against_float64_double_backward(do, da, h, n_envs, mo
     vs = [torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") for _ in range(2)]
     want = _f64_products_chunked(pol, inp, vs)
     ops.loss_grad(inp, keep_activations=True)
+    want_variant = _arith(monkeypatch, arith, (do, da, h))
     variant = _variant(ops, inp)
+    assert variant == want_variant
     got = [ops.fvp(inp, v) for v in vs]
     plain = None
-    if variant in (1, 2):
+    if variant in (1, 2, 4):
         monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
         assert _variant(ops, inp) == 0
         plain = [ops.fvp(inp, v) for v in vs]
         monkeypatch.delenv("RLLAB_FVP_SPLIT")
+        _arith(monkeypatch, arith, (do, da, h))
     for i, (hv, hv64) in enumerate(zip(got, want)):
         scale = float(hv64.abs().max())
         err = float((hv - hv64).abs().max()) / scale
@@ -202,7 +234,8 @@ def test_sixteen_sample_tile_product_is_the_same_f32_accurate_product(do, da, B,
     ops.loss_grad(inp, keep_activations=True)
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
     plain = [ops.fvp(inp, v) for v in vs]
-    monkeypatch.delenv("RLLAB_FVP_SPLIT")
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "5")           # the 32-sample-tile kernel of the same (bf16) arithmetic
+    assert _variant(ops, inp) == 1
     split = [ops.fvp(inp, v) for v in vs]
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "3")
     monkeypatch.setenv("RLLAB_FVP_SPLIT_WPS", wps)       # wavefronts per SIMD: four (128 registers) or three
@@ -235,9 +268,65 @@ def test_full_size_sixteen_sample_tile_product_matches_the_shipped_kernel(monkey
     inp = U._inputs(pol, 4096 * 500, old_equals_new=True)
     ops.loss_grad(inp, keep_activations=True)
     v = torch.as_tensor(np.random.RandomState(3).randn(pol.flat_params.numel()), device="cuda")
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "5")
     ref = ops.fvp(inp, v)
     monkeypatch.setenv("RLLAB_FVP_SPLIT", "3")
     assert _variant(ops, inp) == 3
     got = ops.fvp(inp, v)
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     assert float(v.dot(got)) > 0
+
+
+# ---- the two-way f16 split (variant 4): range.  f16 has five exponent bits, so everything rests on the per-launch scales ----
+
+def _scaled_inputs(pol, B, obs_scale):
+    inp = list(U._inputs(pol, B, old_equals_new=True))
+    inp[0] = inp[0] * obs_scale
+    with torch.no_grad():
+        inp[3] = pol.mean_planes(inp[0].double(), pol.flat_params.double()).float()         # old mean == new mean
+    return tuple(inp)
+
+
+@pytest.mark.parametrize("do,da,h", [(13, 2, 32), (20, 6, 64)])
+@pytest.mark.parametrize("obs_scale,vec_scale,log_std", [(1.0, 1e-8, 0.0), (1.0, 1e8, 0.0), (1e4, 1.0, 0.0), (1e-4, 1.0, 0.0),
+                                                         (30.0, 1e3, -4.0), (1.0, 1.0, 3.0), (1e3, 1e-6, -5.0)])
+def test_f16_split_product_keeps_f32_accuracy_over_magnitudes(do, da, h, obs_scale, vec_scale, log_std, monkeypatch):
+    """Observations from 1e-4 to 1e4, directions from 1e-8 to 1e8, sigma from e^-5 to e^3 (the Fisher's 1 / sigma^2 from
+    2e4 to 2e-3): no operand of the f16 matrix instructions overflows (the result is finite) and the product stays as
+    close to float64 as the f32 matrix instructions' -- the scales are worst-case bounds computed per launch
+    (policy_splith_kernels.hip::make_scales), max |obs| coming from the gradient pass (rl_policy_batch.obs_absmax)."""
+    pol = U._policy(do, da, h)
+    with torch.no_grad():
+        pol.flat_params[-da:].fill_(log_std)          # the log_std row closes the flat vector
+    ops = pol.fused_ops()
+    inp = _scaled_inputs(pol, 4096, obs_scale)
+    rng = np.random.RandomState(23)
+    vs = [torch.as_tensor(rng.randn(pol.flat_params.numel()) * vec_scale, device="cuda") for _ in range(2)]
+    # a direction whose blocks differ by ten orders of magnitude
+    mixed = torch.as_tensor(rng.randn(pol.flat_params.numel()), device="cuda") * vec_scale
+    for (n, a, b), f in zip(_blocks(pol, h), (1e5, 1.0, 1e-5, 1.0, 1e3, 1e-3, 1.0)):
+        mixed[a:b] *= f
+    vs.append(mixed)
+    want = _f64_products(pol, inp, vs)
+    ops.loss_grad(inp, keep_activations=True)
+    assert float(ops._absmax) == float(inp[0].abs().max())
+    assert _variant(ops, inp) == 4
+    got = [ops.fvp(inp, v) for v in vs]
+    monkeypatch.setenv("RLLAB_FVP_SPLIT", "0")
+    plain = [ops.fvp(inp, v) for v in vs]
+    for hv, hv_p, hv64 in zip(got, plain, want):
+        assert bool(torch.isfinite(hv).all())
+        scale = float(hv64.abs().max())
+        err, err_p = float((hv - hv64).abs().max()) / scale, float((hv_p - hv64).abs().max()) / scale
+        assert err <= 2.0 * err_p + 2e-6, (err, err_p)
+
+
+def test_obs_absmax_is_what_the_gradient_pass_saw():
+    """rl_policy_grad with the activation cache leaves max |obs| in rl_policy_batch.obs_absmax; a second batch overwrites
+    it (the launcher zeroes the word first), smaller or larger."""
+    pol = U._policy(13, 2, 32)
+    ops = pol.fused_ops()
+    for scale in (50.0, 0.01, 7.0):
+        inp = _scaled_inputs(pol, 64000, scale)
+        ops.loss_grad(inp, keep_activations=True)
+        assert float(ops._absmax) == float(inp[0].abs().max())

@@ -8,6 +8,7 @@ extra=""
 [ "$tu" = "env_kernels" ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
 [ "$tu" = "policy_split_kernels" ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
 [ "$tu" = "policy_csplit_kernels" ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+[ "$tu" = "policy_splith_kernels" ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vectorize $extra "$@" -c -o build/exp/${tu}_$tag.o rllab_amd/csrc/$tu.hip
 objs=$(ls build/obj/*.o | grep -v "/$tu.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/lib_$tag.so build/exp/${tu}_$tag.o $objs

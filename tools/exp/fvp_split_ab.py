@@ -26,9 +26,16 @@ print(json.dumps(dict(split_ms=[round(t(lambda: ops.fvp(inp, v)), 4) for _ in ra
 target = os.path.join(ROOT, "rllab_amd", "librllab_amd.so")
 shutil.copy(target, target + ".orig")
 try:
-    for lib in [target + ".orig"] + sorted(glob.glob(os.path.join(ROOT, "build", "exp", "lib_*.so"))) + [target + ".orig"]:
+    # (the shipped library twice: on the three-way bf16 split, RLLAB_FVP_SPLIT=5, and on its own choice)
+    for lib, env in [(target + ".orig", "5"), (target + ".orig", None)] + \
+            [(l, None) for l in sorted(glob.glob(os.path.join(ROOT, "build", "exp", "lib_*.so")))] + \
+            [(target + ".orig", None), (target + ".orig", "5")]:
         shutil.copy(lib, target)
-        print("==", os.path.basename(lib), flush=True)
-        subprocess.call([sys.executable, "-c", CODE] + sys.argv[1:])
+        e = dict(os.environ)
+        e.pop("RLLAB_FVP_SPLIT", None)
+        if env:
+            e["RLLAB_FVP_SPLIT"] = env
+        print("==", os.path.basename(lib), "RLLAB_FVP_SPLIT=%s" % env if env else "", flush=True)
+        subprocess.call([sys.executable, "-c", CODE] + sys.argv[1:], env=e)
 finally:
     shutil.copy(target + ".orig", target)
