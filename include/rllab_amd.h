@@ -448,7 +448,8 @@ typedef struct rl_policy_batch {
                                 * observations), and rl_policy_fvp -- under the same guarantee as for `activations` -- takes
                                 * it as the bound from which the two-way f16 split product (policy_splith_kernels.hip)
                                 * scales its operands; a larger value than the true maximum is valid (coarser scales), a
-                                * smaller one is not.  NULL: the three-way bf16 split product, which needs no bound. */
+                                * smaller one is not; the scales also assume weights in [0, 1] (they are 0 / 1 validity).  NULL: the three-way
+                                * bf16 split product, which needs no bound. */
 } rl_policy_batch;
 
 enum rl_activation { RL_ACT_TANH = 0, RL_ACT_RECTIFY = 1, RL_ACT_IDENTITY = 2 };
@@ -499,7 +500,7 @@ int rl_policy_fvp(const rl_policy_batch* batch, const float* vec, void* workspac
  *   4  f16 matrix instructions on TWO-way split operands, lo part scaled by 2^11, three cross terms per product with f32
  *      accumulation (csrc/policy_splith_kernels.hip; closer to float64 than an f32 fma chain, tools/ubench/f16_split.hip),
  *      every operand class under a per-launch power-of-two scale with worst-case bounds: the cached products of 1 for the
- *      two-wavefront (32, 32) shapes and the (64, 64) shapes, when rl_policy_batch.obs_absmax is set (RLLAB_FVP_SPLIT=5:
+ *      (32, 32) and (64, 64) shapes, when rl_policy_batch.obs_absmax is set (RLLAB_FVP_SPLIT=5:
  *      variant 1 all the same). */
 int rl_policy_fvp_variant(const rl_policy_batch* batch);
 

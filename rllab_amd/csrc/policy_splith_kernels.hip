@@ -352,11 +352,11 @@ constexpr int ops_bytes(int kb0) { return ops_count(kb0) * 3 * WV * 16; }
 // (XT_SCALE; x~ < 2^6, so 2^8 x~ < 2^14): an observation down to 2^-17 of the batch maximum keeps every bit.
 constexpr float XT_SCALE = 256.0f;
 
-template <int DO, int DA>
-__global__ void __launch_bounds__(8 * WV, 1) fvp_splith_kernel(Args a) {
+template <int DO, int DA, int WPS>
+__global__ void __launch_bounds__(4 * WPS * WV, 1) fvp_splith_kernel(Args a) {
     using N = Net<DO, DA, H>;
     constexpr int P = N::P;
-    constexpr int WAVES = 8;
+    constexpr int WAVES = 4 * WPS;                 // two wavefronts per SIMD; wide heads (16 DA registers of thin sums): one
     constexpr int KB0 = (DO + 1 + 15) / 16;
     constexpr int N_OPS = ops_count(KB0), OPS_BYTES = ops_bytes(KB0);
     constexpr int TAILV = 16 * DA * 2 + 16;        // floats per lane half: W2 rows | dW2~ rows | db1~
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(8 * WV, 1) fvp_splith_kernel(Args a) {
     constexpr int XLAND_BYTES = XPIECES * WV * 16;
     constexpr int WAVE_BYTES = LAND_BYTES + SPILL_BYTES + XLAND_BYTES;
     constexpr int LDS_TOTAL = WAVES * WAVE_BYTES + OPS_BYTES + 2 * TAILV * 4 + WAVES * 5 * 4;
-    static_assert(DO + 1 <= 32 && DA <= 2, "two k-blocks of inputs + the bias slot; thin heads");
+    static_assert(DO + 1 <= 32 && (DA <= 2 || WPS == 1), "two k-blocks of inputs + the bias slot; thin heads at two per SIMD");
     static_assert(LDS_TOTAL >= WAVES * P * 4 && LDS_TOTAL <= 160 * 1024, "LDS budget; the fold rows alias the landing zones");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x / WV, lane = threadIdx.x % WV;
@@ -1181,7 +1181,8 @@ static Args make_args(const rl_policy_batch* g, const float* vec) {
 template <int DO, int DA>
 static int launch32(const rl_policy_batch* g, const float* vec, void* ws, size_t ws_bytes, double* out, hipStream_t st) {
     using N = Net<DO, DA, H>;
-    constexpr int WAVES = 8;
+    constexpr int WPS = DA <= 2 ? 2 : 1;
+    constexpr int WAVES = 4 * WPS;
     constexpr int KB0 = (DO + 1 + 15) / 16;
     constexpr int LDS_BYTES = WAVES * (LAND_BYTES + 2 * 2 * WV * 16 + ((DO + 1 + 7) / 8) * WV * 16) + ops_bytes(KB0) +
                               2 * (16 * DA * 2 + 16) * 4 + WAVES * 5 * 4;
@@ -1192,7 +1193,7 @@ static int launch32(const rl_policy_batch* g, const float* vec, void* ws, size_t
     const size_t need = (size_t)grid * N::P * sizeof(float);
     if (ws_bytes < need) return set_error(RL_ERR_ARG, "policy pass workspace too small: %zu < %zu bytes", ws_bytes, need);
     a.partial = (float*)ws;
-    auto kern = fvp_splith_kernel<DO, DA>;
+    auto kern = fvp_splith_kernel<DO, DA, WPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1237,8 +1238,8 @@ static int launch64(const rl_policy_batch* g, const float* vec, void* ws, size_t
 
 }  // namespace splith
 
-// the (obs_dim, act_dim) pairs of fvp_split_kernel's two-wavefront shapes and of fvp_split64_kernel
-#define SPLITH_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1)
+// the (obs_dim, act_dim) pairs of fvp_split_kernel and of fvp_split64_kernel
+#define SPLITH_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(13, 1) X(20, 3) X(20, 6) X(21, 6)
 #define SPLITH64_SHAPES(X) X(4, 1) X(6, 1) X(11, 1) X(13, 2) X(20, 3) X(20, 6) X(21, 6)
 bool split_fvp_takes(const rl_policy_batch* g);                          // policy_split_kernels.hip
 // The f16 form takes what the bf16 split kernels take, for the shapes above, when the caller provides max |obs|

@@ -17,7 +17,7 @@ SPLIT64_SHAPES = [(4, 1), (6, 1), (11, 1), (13, 2), (20, 3), (20, 6), (21, 6)]  
 ALL_SPLIT = [(d, a, 32) for d, a in SPLIT_SHAPES] + [(d, a, 64) for d, a in SPLIT64_SHAPES]
 
 
-SPLITH_SHAPES = [(4, 1, 32), (6, 1, 32), (11, 1, 32), (13, 2, 32), (13, 1, 32)] + [(d, a, 64) for d, a in SPLIT64_SHAPES]
+SPLITH_SHAPES = ALL_SPLIT          # (round 6, later: the wide-head (32, 32) shapes too, one wavefront per SIMD)
 ARITH = ["f16x2", "bf16x3"]
 
 
@@ -61,7 +61,7 @@ def _blocks(pol, h=32):
 @pytest.mark.parametrize("B", [32, 4096, 64000])
 def test_split_product_is_an_f32_accurate_product(do, da, h, B, arith, monkeypatch):
     if arith == "f16x2" and (do, da, h) not in SPLITH_SHAPES:
-        pytest.skip("the wide-head (32, 32) shapes run the bf16 kernel (one wavefront per SIMD)")
+        pytest.skip("a shape of the bf16 kernels only")
     pol = U._policy(do, da, h)
     ops = pol.fused_ops()
     inp = U._inputs(pol, B, old_equals_new=True)

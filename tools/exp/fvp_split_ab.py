@@ -8,9 +8,10 @@ import sys, json, os, torch
 sys.path.insert(0, %r)
 from tests import test_gpu_update_parity as U
 H64 = len(sys.argv) > 1 and sys.argv[1] == "64"
-pol = U._policy(20, 6, 64) if H64 else U._policy(13, 2, 32)
+WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"        # (20, 6) on (32, 32): one wavefront per SIMD
+pol = U._policy(20, 6, 64) if H64 else U._policy(20, 6, 32) if WIDE else U._policy(13, 2, 32)
 ops = pol.fused_ops()
-inp = U._inputs(pol, 512000 if H64 else 2048000, ragged=False, old_equals_new=True)
+inp = U._inputs(pol, 512000 if (H64 or WIDE) else 2048000, ragged=False, old_equals_new=True)
 v = torch.randn(pol.flat_params.numel(), device="cuda", dtype=torch.float64)
 ops.loss_grad(inp, keep_activations=True)
 def t(fn, n=40):
