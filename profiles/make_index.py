@@ -23,6 +23,14 @@ RECIPES = [
     ("r06_c7_csplit_ab.txt", "cooperative product per library: round start / one instruction stream per wavefront (off) / compile-time shapes + k-slices", "tools/exp/r06_call7.sh"),
     ("r06_c9_csplit_ab.txt", "cooperative product per library: k-slices + compile-time shapes / round start / + late fetch", "tools/exp/r06_call9.sh"),
     ("r06_c10_csplit_ab.txt", "cooperative product: the library of the round's start, timed in the call that ran the parity tests and the wide bench lines on the final one", "tools/exp/r06_call10.sh"),
+    ("r06_f16_split.txt", "device facts of the two-way f16 split: subnormal inputs honoured, accuracy of five product forms against float64 over ten magnitude regimes, the five-instruction split bit for bit, instruction rates", "tools/ubench/f16_split.hip (tools/exp/r06_call15.sh)"),
+    ("r06_c14_half*.txt", "what a two-part / three-term product would buy: RL_ABL_HALF timing ablation of the bf16 split kernels (wrong results)", "tools/exp/r06_call14.sh"),
+    ("r06_c16_splith_ab*.txt", "fvp() per library: bf16 three-way / f16 two-way / ablations and variants of policy_splith_kernels.hip", "tools/exp/r06_call16.sh"),
+    ("r06_c18_splith_check.txt", "two-way f16 / three-way bf16 / f32 products against float64 over shapes, direction and observation scales, with timings", "tools/exp/fvp_splith_check.py (tools/exp/r06_call18.sh)"),
+    ("r06_c17_bench_*.json", "headline and C5 bench lines, f16 two-way (default) and bf16 three-way (RLLAB_FVP_SPLIT=5) interleaved in one call", "tools/exp/r06_call17.sh"),
+    ("r06_c20_splith_ab_wide.txt", "fvp() of (20, 6) on (32, 32), 512 k samples: bf16 three-way against f16 two-way at one wavefront per SIMD", "tools/exp/r06_call20.sh"),
+    ("r06_splith_*.csv", "SQ counter passes / FETCH_SIZE / kernel stats of the bf16 and the f16 split products, (32, 32) at 2.048 M and (64, 64) at 512 k samples", "tools/exp/r06_call19.sh"),
+    ("curves/r06_splith_*", "learning under the f16 two-way and the bf16 three-way split products, same seeds; 1500-iteration soak", "tools/exp/r06_splith_curves.sh"),
     ("r06_c11_policy_time.txt", "wide loss / gradient / product passes with (.orig) and without (lib_before_wpf) the one-tile-ahead prefetch", "tools/exp/r06_call11.sh"),
     ("r06_wide_kernel_bench.txt", "loss / gradient / product passes of the wide nets at the final sources", "python tools/kernel_bench.py --configs ..."),
     ("*_split_kernel_stats.csv", "kernel stats of the three Fisher-vector-product kernels back to back", "tools/prof_split.sh"),
@@ -63,7 +71,7 @@ One evidence set per round (older intermediate sets `r01a … r01l` were pruned 
 | 3 | `r03_*` (headline), `r03_split_*` (product kernels), `r03_wide_*` | HEAD of round 3 = `8bd729a`; `pmc_traffic.json` carries the sha256 of `rllab_amd/csrc/*` it was taken at |
 | 4 | `r04_*` | see the stamp in `pmc_traffic.json` and `r04_notes.md` |
 | 5 | `r05_*` (headline, `r05_c5_*` C5's shard, `r05_split_*` product kernels) | one run of `tools/exp/r05_final_a.sh` at the final kernel sources (stamp in `pmc_traffic.json`); `r05_notes.md` |
-| 6 | `r06_*` (headline, `r06_c5_*`, `r06_c2_*`, `r06_split16_*`, `r06_csplit_*`) | one run of `tools/exp/r06_final_all.sh` at the final kernel sources (stamp in `pmc_traffic.json`); `r06_notes.md` |
+| 6 | `r06_*` (headline, `r06_c5_*`, `r06_c2_*`, `r06_split16_*`, `r06_csplit_*`) | one run of `tools/exp/r06_final2_all.sh` at the final kernel sources (stamp in `pmc_traffic.json`); `r06_notes.md` |
 """
 
 
