@@ -66,6 +66,9 @@ struct PA { f16x8 hi, lo, hs; };    // image: hi, lo = A - hi, hs = 2^-11 hi
 #ifndef RL_ABL_SPLIT
 #define RL_ABL_SPLIT 0
 #endif
+#ifndef RL_ABL_TRANSPOSE
+#define RL_ABL_TRANSPOSE 0       // the transpositions left out (the parts are handed on as they are): what transposing LDS reads could buy at most
+#endif
 
 __device__ __forceinline__ f32x16 mf(f16x8 a, f16x8 b, f32x16 c) {
 #if RL_ABL_MFMA
@@ -202,6 +205,10 @@ __device__ __forceinline__ void pack_exact(const f32x16& d, f16x8& o0, f16x8& o1
 }
 // sample-major parts of a 32-unit fragment -> unit-major parts (part x identity on the matrix pipe, exact)
 __device__ __forceinline__ void transpose_units(const PB (&f)[2], const f16x8 (&Id)[2], PB (&out)[2]) {
+#if RL_ABL_TRANSPOSE
+    out[0] = f[0]; out[1] = f[1];
+    return;
+#endif
     f32x16 d;
 #pragma unroll
     for (int r = 0; r < 16; ++r) d[r] = 0.0f;
@@ -216,6 +223,10 @@ __device__ __forceinline__ void transpose_units(const PB (&f)[2], const f16x8 (&
 }
 template <int KB0>
 __device__ __forceinline__ void transpose_inputs(const PB (&f)[KB0], const f16x8 (&Idx)[KB0], PB (&out)[2]) {
+#if RL_ABL_TRANSPOSE
+    out[0] = f[0]; out[1] = f[KB0 - 1];
+    return;
+#endif
     f32x16 d;
 #pragma unroll
     for (int r = 0; r < 16; ++r) d[r] = 0.0f;
