@@ -412,17 +412,48 @@ lfb_normal_eq_mfma_kernel(size_t B, int Do, const float* __restrict__ obs, const
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     const size_t n_tiles = (B + NE_TILE - 1) / NE_TILE;
-    for (size_t tl = (size_t)blockIdx.x * NE_WAVES + wave; tl < n_tiles; tl += (size_t)gridDim.x * NE_WAVES) {
-        const size_t b = tl * NE_TILE + lane;
-        const bool use = (b < B) && valid[b];
+    // A sample's inputs travel ONE TILE AHEAD in registers, every load of a tile issued together (round 6: the feature
+    // loop used to load an observation component, use it, load the next -- Do dependent round trips per tile in front of
+    // the matrix instructions).  Same features, same sums in the same order: bit-identical output.
+    float xo[MAX_DO], rt = 0.0f;
+    int tn = 0;
+    bool use_n = false;
+    auto fetch = [&](size_t t_) {
+        const size_t b = t_ * NE_TILE + lane;
+        const bool in = (t_ < n_tiles) && (b < B);
+        const size_t bc = in ? b : 0;
+        use_n = in && valid[bc];
+        tn = tin[bc];
+        rt = ret[bc];
+#pragma unroll
+        for (int d = 0; d < MAX_DO; ++d) xo[d] = obs[(size_t)(d < Do ? d : 0) * B + bc];
+    };
+    const size_t stride = (size_t)gridDim.x * NE_WAVES;
+    size_t tl = (size_t)blockIdx.x * NE_WAVES + wave;
+    fetch(tl);
+    for (; tl < n_tiles; tl += stride) {
+        const bool use = use_n;
         double* row = tile + (size_t)lane * STR;
         if (use) {
-            lfb_features(Do, obs, B, b, tin[b], [&](int f, double v) { row[f] = v; });
-            row[F] = (double)ret[b];
+#pragma unroll
+            for (int d = 0; d < MAX_DO; ++d)
+                if (d < Do) {
+                    double o = (double)xo[d];
+                    o = fmin(fmax(o, -10.0), 10.0);
+                    row[d] = o;
+                    row[Do + d] = o * o;
+                }
+            const double al = (double)tn / 100.0;
+            row[2 * Do] = al;
+            row[2 * Do + 1] = al * al;
+            row[2 * Do + 2] = al * al * al;
+            row[2 * Do + 3] = 1.0;
+            row[F] = (double)rt;
             for (int f = F + 1; f < FE; ++f) row[f] = 0.0;
         } else {
             for (int f = 0; f < FE; ++f) row[f] = 0.0;
         }
+        fetch(tl + stride);          // (clamped to sample 0 beyond the batch: no branch around the loads)
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
