@@ -147,8 +147,13 @@ vecenv_com_kernel(int n, const float* __restrict__ state, float* __restrict__ co
 // ---------------------------------------------------------------------------
 // VecEnvExecutor.step
 // ---------------------------------------------------------------------------
+// (two wavefronts per SIMD asked for: the one-thread two-leg programs sit at 255 + 2 registers, one above the budget that
+// lets a second wavefront hide the first one's waits -- STEP_WPS, round 6)
+#ifndef RL_STEP_WPS
+#define RL_STEP_WPS 2
+#endif
 template <class Env>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, RL_STEP_WPS)
 vecenv_step_kernel(int n, int normalize, float scale_reward, int max_path_length, int auto_reset,
                    float* __restrict__ state, int32_t* __restrict__ ts,
                    const float* __restrict__ actions, const float* __restrict__ reset_draws,
